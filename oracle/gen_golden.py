@@ -1,0 +1,294 @@
+"""Generate tests/golden/*.npz by EXECUTING THE REFERENCE ITSELF (TEST INFRASTRUCTURE).
+
+Runs only in the build container, where /root/reference exists:
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+The reference has no tests / golden vectors of its own, so these fixtures are
+the pins: every tensor below is an output of the reference's unmodified PyTorch modules
+(modules/FastDiff/module/{FastDiff_model,modules,util}.py), fed with the seed-reproducible synthetic
+weights and inputs of oracle/synth.py.  The only shim is `torch.Tensor.cuda = identity`, because the
+reference hard-codes .cuda() (util.py:68,217,427) and this container has no GPU.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF = os.environ.get("FASTDIFF_REFERENCE", "/root/reference")
+sys.path.insert(0, HERE)
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+
+torch.Tensor.cuda = lambda self, *a, **k: self   # CPU shim, see docstring
+
+import synth  # noqa: E402
+from modules.FastDiff.module.FastDiff_model import FastDiff  # noqa: E402
+from modules.FastDiff.module import modules as ref_modules  # noqa: E402
+from modules.FastDiff.module import util as ref_util  # noqa: E402
+
+torch.set_num_threads(8)
+SEED = 1234
+
+# Inference schedules: modules/FastDiff/task/FastDiff.py:76-91
+SCHEDULES = {
+    1000: ("linspace", 0.000001, 0.01, 1000),
+    200: ("linspace", 0.0001, 0.02, 200),
+    8: [6.689325005027058e-07, 1.0033881153503899e-05, 0.00015496854030061513, 0.002387222135439515,
+        0.035597629845142365, 0.3681158423423767, 0.4735414385795593, 0.5],
+    6: [1.7838445955931093e-06, 2.7984189728158526e-05, 0.00043231004383414984, 0.006634317338466644,
+        0.09357017278671265, 0.6000000238418579],
+    4: [3.2176e-04, 2.5743e-03, 2.5376e-02, 7.0414e-01],
+    3: [9.0000e-05, 9.0000e-03, 6.0000e-01],
+}
+
+
+def schedule_tensor(N):
+    s = SCHEDULES[N]
+    if isinstance(s, tuple):
+        return torch.linspace(s[1], s[2], s[3])
+    return torch.FloatTensor(s)
+
+
+def make_model(dtype=torch.float32):
+    m = FastDiff().eval()
+    sd = {k: torch.from_numpy(v.copy()) for k, v in synth.synth_state_dict(SEED).items()}
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return m.to(dtype)
+
+
+def gen_schedule():
+    out = {}
+    dh = ref_util.compute_hyperparams_given_schedule(torch.linspace(1e-6, 0.01, 1000))
+    out["train_alpha"] = dh["alpha"].numpy()
+    out["train_sigma"] = dh["sigma"].numpy()
+    out["train_beta"] = dh["beta"].numpy()
+    for N in SCHEDULES:
+        beta = schedule_tensor(N)
+        out[f"N{N}_beta"] = beta.numpy().copy()
+        # exactly the statements of sampling_given_noise_schedule (util.py:187-204)
+        beta_infer = beta
+        alpha_infer = 1 - beta_infer
+        sigma_infer = beta_infer + 0
+        for n in range(1, N):
+            alpha_infer[n] *= alpha_infer[n - 1]
+            sigma_infer[n] *= (1 - alpha_infer[n - 1]) / (1 - alpha_infer[n])
+        alpha_infer = torch.sqrt(alpha_infer)
+        sigma_infer = torch.sqrt(sigma_infer)
+        steps = [ref_util.map_noise_scale_to_time_step(alpha_infer[n], dh["alpha"]) for n in range(N)]
+        out[f"N{N}_steps"] = np.array(steps, np.float64)
+        out[f"N{N}_alpha_hat"] = alpha_infer.numpy()
+        out[f"N{N}_sigma_hat"] = sigma_infer.numpy()
+        # per-step coefficients, the expressions of util.py:220-227
+        ce, cd, c1s, c2s, c3s = [], [], [], [], []
+        for n in range(N):
+            ce.append((beta_infer[n] / torch.sqrt(1 - alpha_infer[n] ** 2.)).item())
+            cd.append(torch.sqrt(1 - beta_infer[n]).item())
+            alpha_next = alpha_infer[n] / (1 - beta_infer[n]).sqrt()
+            c1 = alpha_next / alpha_infer[n]
+            c2 = -(1 - alpha_infer[n] ** 2.).sqrt() * c1
+            c3 = (1 - alpha_next ** 2.).sqrt()
+            c1s.append(c1.item()); c2s.append(c2.item()); c3s.append(c3.item())
+        for k, v in (("c_eps", ce), ("c_div", cd), ("c1", c1s), ("c2", c2s), ("c3", c3s)):
+            out[f"N{N}_{k}"] = np.array(v, np.float32)
+    np.savez_compressed(os.path.join(GOLD, "schedule.npz"), **out)
+    return dh
+
+
+def gen_embed():
+    half = 64
+    table = torch.exp(torch.arange(half) * -(np.log(10000) / (half - 1)))   # util.py:425-427
+    steps = torch.tensor([[0.0], [1.0], [7.413235306739807], [74.99228298664093], [498.05368650332093], [999.0]])
+    emb = ref_util.calc_diffusion_step_embedding(steps, 128)
+    emb64 = ref_util.calc_diffusion_step_embedding(steps.double(), 128)
+    np.savez_compressed(os.path.join(GOLD, "embed.npz"), table=table.numpy(), steps=steps.numpy(),
+                        emb_f32=emb.numpy(), emb_f64=emb64.numpy())
+
+
+def gen_ops():
+    """Function-level pins: standalone reference modules / methods on small random tensors."""
+    out = {}
+    u = lambda stream, shape, scale=1.0: (synth.hash_uniform(77, stream, int(np.prod(shape))) * np.float32(scale)).reshape(shape)  # noqa: E731
+    with torch.no_grad():
+        # location_variable_convolution (modules.py:220-253) at the three hops of the model
+        blk = ref_modules.TimeAware_LVCBlock(32, 80, 8)
+        for i, (hop, T) in enumerate(((8, 5), (64, 3), (256, 2))):
+            x = u(10 + i, (2, 32, T * hop)); k = u(20 + i, (2, 32, 64, 3, T), 0.2); b = u(30 + i, (2, 64, T), 0.5)
+            y = blk.location_variable_convolution(torch.from_numpy(x), torch.from_numpy(k), torch.from_numpy(b), 1, hop)
+            y64 = blk.location_variable_convolution(torch.from_numpy(x).double(), torch.from_numpy(k).double(),
+                                                    torch.from_numpy(b).double(), 1, hop)
+            out[f"lvc{hop}_x"], out[f"lvc{hop}_k"], out[f"lvc{hop}_b"] = x, k, b
+            out[f"lvc{hop}_y"], out[f"lvc{hop}_y64"] = y.numpy(), y64.numpy()
+        # DiffusionDBlock (modules.py:116-138), factors 4 and 8
+        for f in (4, 8):
+            db = ref_modules.DiffusionDBlock(32, 32, f).eval()
+            ws = []
+            with torch.no_grad():
+                for j, p in enumerate(db.parameters()):
+                    w = u(100 + 10 * f + j, tuple(p.shape), 0.12)
+                    p.copy_(torch.from_numpy(w))
+            named = dict(db.named_parameters())
+            ws = [named["residual_dense.weight"], named["residual_dense.bias"]]
+            for i in range(3):
+                ws += [named[f"conv.{i}.weight"], named[f"conv.{i}.bias"]]
+            x = u(200 + f, (2, 32, 40 * f))
+            out[f"dblock{f}_x"] = x
+            out[f"dblock{f}_y"] = db(torch.from_numpy(x)).numpy()
+            out[f"dblock{f}_y64"] = db.double()(torch.from_numpy(x).double()).numpy()
+            for j, w in enumerate(ws):
+                out[f"dblock{f}_w{j}"] = w.detach().float().numpy()
+        # ConvTranspose1d as TimeAware_LVCBlock builds it (modules.py:163-166)
+        for r in (8, 4):
+            ct = torch.nn.ConvTranspose1d(32, 32, 2 * r, stride=r, padding=r // 2 + r % 2, output_padding=r % 2)
+            w = u(300 + r, (32, 32, 2 * r), 0.1); b = u(310 + r, (32,), 0.1)
+            ct.weight.copy_(torch.from_numpy(w)); ct.bias.copy_(torch.from_numpy(b))
+            x = u(320 + r, (2, 32, 11))
+            out[f"convt{r}_x"], out[f"convt{r}_w"], out[f"convt{r}_b"] = x, w, b
+            out[f"convt{r}_y"] = ct(torch.from_numpy(x)).numpy()
+        # weight-norm fold (FastDiff_model.py:115-122): torch's own _weight_norm
+        v = u(400, (64, 80, 5), 0.3); g = np.abs(u(401, (64, 1, 1))) + np.float32(0.5)
+        out["wn_v"], out["wn_g"] = v, g
+        out["wn_w"] = torch._weight_norm(torch.from_numpy(v), torch.from_numpy(g), 0).numpy()
+    np.savez_compressed(os.path.join(GOLD, "ops.npz"), **out)
+
+
+def gen_forward():
+    m32 = make_model(torch.float32)
+    m64 = make_model(torch.float64)
+    cases = {
+        # name: (B, T, steps, mel range, want taps)
+        "f1": (1, 4, [7.413235306739807], (-6.0, 1.5), True),
+        "f2": (2, 7, [23.467590302228928, 498.05368650332093], (-6.0, 1.5), False),
+        "f3": (1, 33, [74.99228298664093], (-6.0, 1.5), False),
+        "f4": (1, 5, [3.0], (-11.5, 2.0), False),     # Tacotron-style natural-log mel range (FastDiff_tacotron.yaml)
+    }
+    for ci, (name, (B, T, steps, (lo, hi), want_taps)) in enumerate(cases.items()):
+        mel = synth.synth_mel(SEED + ci, B, T, lo, hi)
+        audio = synth.synth_audio(SEED + ci, B, T)
+        st = torch.tensor(steps, dtype=torch.float32).view(B, 1)
+        out = {"mel": mel, "audio": audio, "steps": st.numpy()}
+        taps = {}
+        hooks = []
+        if want_taps:
+            def keep(key):
+                def fn(mod, inp, res):
+                    if isinstance(res, tuple):
+                        taps[key + "_kernels"] = res[0].detach().numpy().copy()
+                        taps[key + "_bias"] = res[1].detach().numpy().copy()
+                    else:
+                        taps[key] = res.detach().numpy().copy()
+                return fn
+            hooks.append(m32.first_audio_conv.register_forward_hook(keep("a0")))
+            for d in range(3):
+                hooks.append(m32.downsample[d].register_forward_hook(keep(f"a{d + 1}")))
+            for n in range(3):
+                hooks.append(m32.lvc_blocks[n].register_forward_hook(keep(f"x{n}")))
+                hooks.append(m32.lvc_blocks[n].kernel_predictor.register_forward_hook(keep(f"kp{n}")))
+            hooks.append(m32.fc_t2.register_forward_hook(keep("fc_t2_pre")))
+        with torch.no_grad():
+            y32 = m32((torch.from_numpy(audio), torch.from_numpy(mel), st))
+            y64 = m64((torch.from_numpy(audio).double(), torch.from_numpy(mel).double(), st.double()))
+        for h in hooks:
+            h.remove()
+        out["y_f32"] = y32.numpy()
+        out["y_f64"] = y64.numpy()
+        for k, v in taps.items():
+            if k.endswith("_kernels"):
+                # [B,4,32,64,3,T] view -> store as the raw conv output [B,24576,T]
+                v = v.reshape(v.shape[0], -1, v.shape[-1])
+            if k.endswith("_bias"):
+                v = v.reshape(v.shape[0], -1, v.shape[-1])
+            out["tap_" + k] = v
+        np.savez_compressed(os.path.join(GOLD, f"forward_{name}.npz"), **out)
+        print(name, "max|y|", float(np.abs(out["y_f32"]).max()), "f32-vs-f64", float(np.abs(out["y_f32"] - out["y_f64"]).max()))
+
+
+def run_sampler(model, dtype, B, T, N, dh, noises, ddim, return_sequence):
+    """Call the reference sampler with std_normal replaced by a replay of `noises` (x_T first, then z_{N-1}..z_1)."""
+    it = iter(noises)
+    orig = ref_util.std_normal
+    # .clone(): the sampler updates x in place (util.py:226-227); never let it alias the recorded noise
+    ref_util.std_normal = lambda size: torch.from_numpy(next(it).copy()).to(dtype).view(*size).clone()
+    net = model if dtype == torch.float32 else (lambda data: model((data[0], data[1], data[2].double())))
+    try:
+        devnull = open(os.devnull, "w")
+        stdout, sys.stdout = sys.stdout, devnull
+        res = ref_util.sampling_given_noise_schedule(net, (B, 1, T * 256), dh, schedule_tensor(N),
+                                                     condition=model._mel, ddim=ddim,
+                                                     return_sequence=return_sequence)
+    finally:
+        sys.stdout = stdout
+        ref_util.std_normal = orig
+    return res
+
+
+def gen_sample(dh):
+    m32 = make_model(torch.float32)
+    m64 = make_model(torch.float64)
+    cases = {
+        # name: (B, T, N, ddim, return_sequence, run_f64)
+        "s1": (2, 6, 4, False, True, True),
+        "s2": (1, 5, 4, True, True, True),
+        "s3": (1, 5, 6, False, False, True),
+        "s4": (1, 4, 1000, False, False, True),
+        "s5": (1, 4, 8, False, False, True),
+    }
+    for ci, (name, (B, T, N, ddim, seq, run64)) in enumerate(cases.items()):
+        mel = synth.synth_mel(SEED + 100 + ci, B, T)
+        n_el = B * T * 256
+        x_T = synth.hash_normal(SEED + 100 + ci, 1, n_el).reshape(B, 1, T * 256)
+        # z[n] is the noise added after step n (n>0); stored [N,B,1,L], z[0] unused (zeros)
+        z = np.zeros((N, B, 1, T * 256), np.float32)
+        for n in range(1, N):
+            z[n] = synth.hash_normal(SEED + 100 + ci, 2 + n, n_el).reshape(B, 1, T * 256)
+        noises = [x_T] + [z[n] for n in range(N - 1, 0, -1)]
+        out = {"mel": mel, "x_T": x_T, "N": np.int64(N), "ddim": np.int64(ddim), "seed": np.int64(SEED + 100 + ci)}
+        for tag, model, dt in (("f32", m32, torch.float32), ("f64", m64, torch.float64)):
+            if tag == "f64" and not run64:
+                continue
+            model._mel = torch.from_numpy(mel).to(dt)
+            dh_t = {"T": dh["T"], "alpha": dh["alpha"], "beta": dh["beta"], "sigma": dh["sigma"]}
+            res = run_sampler(model, dt, B, T, N, dh_t, noises, ddim, seq)
+            if seq:
+                out[f"seq_{tag}"] = np.stack([r.numpy() for r in res])
+            else:
+                out[f"y_{tag}"] = res.numpy()
+        np.savez_compressed(os.path.join(GOLD, f"sample_{name}.npz"), **out)
+        key = "seq_f32" if seq else "y_f32"
+        k64 = "seq_f64" if seq else "y_f64"
+        print(name, "max|y|", float(np.abs(out[key]).max()), "f32-vs-f64", float(np.abs(out[key] - out[k64]).max()) if k64 in out else None)
+
+
+def gen_statedict_manifest():
+    """Key set + shapes of the reference module's state_dict, and a default-init digest, for the drop-in shim test."""
+    torch.manual_seed(SEED)
+    m = FastDiff()
+    sd = m.state_dict()
+    names = np.array(list(sd.keys()))
+    shapes = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+    # a cheap digest of the default init: per-tensor sum and abs-sum
+    sums = np.array([float(v.double().sum()) for v in sd.values()])
+    asums = np.array([float(v.double().abs().sum()) for v in sd.values()])
+    np.savez_compressed(os.path.join(GOLD, "state_dict_manifest.npz"), names=names, shapes=shapes, sums=sums, asums=asums)
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    which = sys.argv[1:] or ["schedule", "embed", "ops", "forward", "sample", "manifest"]
+    dh = gen_schedule()
+    if "embed" in which:
+        gen_embed()
+    if "ops" in which:
+        gen_ops()
+    if "forward" in which:
+        gen_forward()
+    if "sample" in which:
+        gen_sample(dh)
+    if "manifest" in which:
+        gen_statedict_manifest()
+    print("golden fixtures written to", GOLD)

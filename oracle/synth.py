@@ -1,0 +1,105 @@
+"""Deterministic synthetic weights / inputs for parity tests (TEST INFRASTRUCTURE).
+
+The reference ships no checkpoint that is reachable offline, and a 61 MB random state_dict is too
+large to commit.  So the golden fixtures are generated from weights that BOTH sides can rebuild
+bit-exactly from a seed with integer arithmetic only (a counter-based splitmix64 hash -> 24-bit
+uniform), scaled like torch's default Conv1d/Linear init (uniform +-1/sqrt(fan_in)) so the
+network is as well conditioned as `torch.manual_seed(1234); FastDiff()`.
+
+Parameter names / shapes are those of the reference state_dict
+(modules/FastDiff/module/FastDiff_model.py:13-72, modules.py:116-125,141-187,257-318).
+"""
+import numpy as np
+
+RATIOS = (8, 8, 4)
+C, COND, HID, LAYERS, KS = 32, 80, 64, 4, 3
+E_IN, E_MID, E_OUT = 128, 512, 512
+L_W = C * 2 * C * KS * LAYERS   # 24576
+L_B = 2 * C * LAYERS            # 256
+KP_RES_IDX = (1, 3, 6, 8, 11, 13)   # Conv1d positions inside KernelPredictor.residual_conv (modules.py:298-313)
+
+
+def param_spec():
+    """[(name, shape, kind)] in reference state_dict naming; kind: 'wn' (weight-normed Conv1d -> _g/_v), 'plain'."""
+    spec = [("first_audio_conv", (C, 1, 7), "wn"),
+            ("fc_t1", (E_MID, E_IN), "plain"), ("fc_t2", (E_OUT, E_MID), "plain")]
+    for n, r in enumerate(RATIOS):
+        p = f"lvc_blocks.{n}"
+        spec.append((f"{p}.upsample", (C, C, 2 * r), "plain"))
+        spec.append((f"{p}.kernel_predictor.input_conv.0", (HID, COND, 5), "wn"))
+        for j in KP_RES_IDX:
+            spec.append((f"{p}.kernel_predictor.residual_conv.{j}", (HID, HID, 3), "wn"))
+        spec.append((f"{p}.kernel_predictor.kernel_conv", (L_W, HID, 3), "wn"))
+        spec.append((f"{p}.kernel_predictor.bias_conv", (L_B, HID, 3), "wn"))
+        spec.append((f"{p}.fc_t", (COND, E_OUT), "plain"))
+        for i in range(LAYERS):
+            spec.append((f"{p}.convs.{i}", (C, C, 3), "wn"))
+        d = f"downsample.{n}"
+        spec.append((f"{d}.residual_dense", (C, C, 1), "wn"))
+        for i in range(3):
+            spec.append((f"{d}.conv.{i}", (C, C, 3), "wn"))
+    spec.append(("final_conv.0", (1, C, 7), "wn"))
+    return spec
+
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+    z = x
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+    return z ^ (z >> np.uint64(31))
+
+
+def hash_uniform(seed: int, stream: int, n: int) -> np.ndarray:
+    """n float32 values uniform in [-1, 1), reproducible bit-for-bit everywhere (integer ops only)."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64)
+        base = _splitmix64(np.uint64(seed) * np.uint64(0x100000001B3) + np.uint64(stream))
+        h = _splitmix64(idx ^ base)
+    u24 = (h >> np.uint64(40)).astype(np.int64)            # 24 bits
+    return ((u24 - (1 << 23)).astype(np.float32) / np.float32(1 << 23)).astype(np.float32)
+
+
+def hash_normal(seed: int, stream: int, n: int) -> np.ndarray:
+    """Approximately N(0,1) float32 (sum of 12 uniforms), reproducible; used for x_T and injected noise."""
+    acc = np.zeros(n, dtype=np.float64)
+    for k in range(12):
+        acc += hash_uniform(seed, stream * 16 + k, n).astype(np.float64) * 0.5 + 0.5
+    return (acc - 6.0).astype(np.float32)
+
+
+def synth_state_dict(seed: int = 1234) -> dict:
+    """Reference-named float32 state_dict: weight_v/weight_g/bias for weight-normed convs, weight/bias otherwise."""
+    sd = {}
+    for stream, (name, shape, kind) in enumerate(param_spec()):
+        n = int(np.prod(shape))
+        if name.endswith(".upsample"):
+            fan_in = shape[1] * shape[2]     # ConvTranspose1d: torch computes fan_in from dim 1
+        else:
+            fan_in = int(np.prod(shape[1:]))
+        bound = np.float32(1.0 / np.sqrt(fan_in))
+        w = (hash_uniform(seed, 3 * stream, n) * bound).reshape(shape)
+        nb = shape[1] if name.endswith(".upsample") else shape[0]
+        b = hash_uniform(seed, 3 * stream + 1, nb) * bound
+        if kind == "wn":
+            norm = np.sqrt((w.astype(np.float64) ** 2).sum(axis=(1, 2), keepdims=True)).astype(np.float32)
+            g = norm * (np.float32(1.0) + np.float32(0.1) * hash_uniform(seed, 3 * stream + 2, shape[0]).reshape(-1, 1, 1))
+            sd[name + ".weight_v"] = w
+            sd[name + ".weight_g"] = g.astype(np.float32)
+        else:
+            sd[name + ".weight"] = w
+        sd[name + ".bias"] = b.astype(np.float32)
+    return sd
+
+
+def synth_mel(seed: int, B: int, T: int, lo: float = -6.0, hi: float = 1.5) -> np.ndarray:
+    """Uniform on [mel_vmin, mel_vmax] (base.yaml:15-16), shape [B,80,T]."""
+    u = hash_uniform(seed, 900001, B * COND * T) * np.float32(0.5) + np.float32(0.5)
+    return (u * np.float32(hi - lo) + np.float32(lo)).reshape(B, COND, T).astype(np.float32)
+
+
+def synth_audio(seed: int, B: int, T: int, stream: int = 900002) -> np.ndarray:
+    return hash_normal(seed, stream, B * T * 256).reshape(B, 1, T * 256)
