@@ -1,0 +1,58 @@
+"""Build libfastdiff_hip.so (gfx950) in-tree:  python -m fastdiff_amd.build [--force]
+
+hipcc cross-compiles for gfx950 without a GPU; the resulting .so is git-ignored but travels to the GPU box.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(HERE, "build")
+SOURCES = ["fd_api.cpp", "fd_kernels_naive.hip", "fd_kernels_fast.hip"]
+HEADERS = ["fd_internal.h", "fd_kernels.h", "fd_device.h", os.path.join("..", "..", "include", "fastdiff_hip.h")]
+LIB = os.path.join(LIBDIR, "libfastdiff_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-x", "hip", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [sp] + hdrs):
+            jobs.append([HIPCC] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + ["-c", sp, "-o", obj])
+    if jobs and not os.path.exists(HIPCC):
+        raise RuntimeError(f"{HIPCC} not found and {LIB} is stale: cannot build the HIP extension")
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0 or verbose:
+            sys.stderr.write(r.stdout + r.stderr)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if jobs or _stale(LIB, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

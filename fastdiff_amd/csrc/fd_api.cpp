@@ -1,0 +1,748 @@
+// fd_api.cpp -- host side of libfastdiff_hip.so: context, state_dict ingestion (weight-norm fold + repack),
+// workspace, the denoiser step sequence, the hipGraph-replayed reverse loop, taps and profiling.
+#include <math.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "fd_kernels.h"
+
+static std::string g_create_error;
+
+#define FD_FAIL(h, code, ...)                                   \
+    do {                                                        \
+        char buf__[512];                                        \
+        snprintf(buf__, sizeof(buf__), __VA_ARGS__);            \
+        if (h) (h)->err = buf__; else g_create_error = buf__;   \
+        return (code);                                          \
+    } while (0)
+
+#define FD_HIP(h, expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e__ = (expr);                                                                          \
+        if (e__ != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__));    \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// profiling helpers (declared in fd_internal.h)
+// ------------------------------------------------------------------------------------------------
+void fd_prof_begin(const fdk::Launch &L, const char *name)
+{
+    fd_context *c = L.ctx;
+    if (!c->profile || L.capturing) return;
+    ProfEntry pe;
+    pe.name = name;
+    hipEvent_t ev[2];
+    for (int i = 0; i < 2; ++i) {
+        if (!c->event_pool.empty()) { ev[i] = c->event_pool.back(); c->event_pool.pop_back(); }
+        else if (hipEventCreate(&ev[i]) != hipSuccess) return;
+    }
+    pe.e0 = ev[0]; pe.e1 = ev[1];
+    hipEventRecord(pe.e0, L.stream);
+    c->prof_pending.push_back(pe);
+}
+
+void fd_prof_end(const fdk::Launch &L)
+{
+    fd_context *c = L.ctx;
+    if (!c->profile || L.capturing || c->prof_pending.empty()) return;
+    hipEventRecord(c->prof_pending.back().e1, L.stream);
+}
+
+static void prof_drain(fd_context *c)
+{
+    for (auto &pe : c->prof_pending) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(pe.e1) == hipSuccess && hipEventElapsedTime(&ms, pe.e0, pe.e1) == hipSuccess) {
+            auto &acc = c->prof_acc[pe.name];
+            acc.first += 1;
+            acc.second += ms;
+        }
+        c->event_pool.push_back(pe.e0);
+        c->event_pool.push_back(pe.e1);
+    }
+    c->prof_pending.clear();
+}
+
+// ------------------------------------------------------------------------------------------------
+// expected state_dict (FastDiff_model.py:13-72; modules.py:116-125,141-187,257-318)
+// ------------------------------------------------------------------------------------------------
+struct ParamSpec { std::string name; std::vector<int64_t> dims; bool weight_norm; bool transposed_conv; bool linear; };
+
+static const int KP_RES_IDX[6] = {1, 3, 6, 8, 11, 13};
+
+static std::vector<ParamSpec> param_specs()
+{
+    using namespace fd;
+    std::vector<ParamSpec> s;
+    s.push_back({"first_audio_conv", {C, 1, 7}, true, false, false});
+    s.push_back({"fc_t1", {E_MID, E_IN}, false, false, true});
+    s.push_back({"fc_t2", {E_OUT, E_MID}, false, false, true});
+    for (int n = 0; n < NBLK; ++n) {
+        const std::string p = "lvc_blocks." + std::to_string(n);
+        s.push_back({p + ".upsample", {C, C, 2 * ratio(n)}, false, true, false});
+        s.push_back({p + ".kernel_predictor.input_conv.0", {HID, COND, 5}, true, false, false});
+        for (int j = 0; j < 6; ++j)
+            s.push_back({p + ".kernel_predictor.residual_conv." + std::to_string(KP_RES_IDX[j]), {HID, HID, 3}, true, false, false});
+        s.push_back({p + ".kernel_predictor.kernel_conv", {KW, HID, 3}, true, false, false});
+        s.push_back({p + ".kernel_predictor.bias_conv", {KB, HID, 3}, true, false, false});
+        s.push_back({p + ".fc_t", {COND, E_OUT}, false, false, true});
+        for (int i = 0; i < LAYERS; ++i) s.push_back({p + ".convs." + std::to_string(i), {C, C, 3}, true, false, false});
+        const std::string d = "downsample." + std::to_string(n);
+        s.push_back({d + ".residual_dense", {C, C, 1}, true, false, false});
+        for (int i = 0; i < 3; ++i) s.push_back({d + ".conv." + std::to_string(i), {C, C, 3}, true, false, false});
+    }
+    s.push_back({"final_conv.0", {1, C, 7}, true, false, false});
+    return s;
+}
+
+static int64_t numel(const std::vector<int64_t> &d)
+{
+    int64_t n = 1;
+    for (auto v : d) n *= v;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI: lifecycle
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *fd_version(void) { return "fastdiff_hip 0.1 (gfx950)"; }
+
+int fd_default_config(fd_config *cfg)
+{
+    if (!cfg) return FD_ERR_INVALID;
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->audio_channels = 1; cfg->inner_channels = 32; cfg->cond_channels = 80; cfg->n_upsample = 3;
+    cfg->upsample_ratios[0] = 8; cfg->upsample_ratios[1] = 8; cfg->upsample_ratios[2] = 4;
+    cfg->lvc_layers_each_block = 4; cfg->lvc_kernel_size = 3; cfg->kpnet_hidden_channels = 64; cfg->kpnet_conv_size = 3;
+    cfg->diffusion_step_embed_dim_in = 128; cfg->diffusion_step_embed_dim_mid = 512; cfg->diffusion_step_embed_dim_out = 512;
+    cfg->use_weight_norm = 1;
+    return FD_OK;
+}
+
+const char *fd_last_error(fd_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int fd_create(const fd_config *cfg, int device, fd_handle *out)
+{
+    fd_context *nullh = nullptr;
+    if (!cfg || !out) FD_FAIL(nullh, FD_ERR_INVALID, "fd_create: null argument");
+    fd_config ref;
+    fd_default_config(&ref);
+    if (cfg->audio_channels != ref.audio_channels || cfg->inner_channels != ref.inner_channels ||
+        cfg->cond_channels != ref.cond_channels || cfg->n_upsample != ref.n_upsample ||
+        cfg->upsample_ratios[0] != 8 || cfg->upsample_ratios[1] != 8 || cfg->upsample_ratios[2] != 4 ||
+        cfg->lvc_layers_each_block != ref.lvc_layers_each_block || cfg->lvc_kernel_size != ref.lvc_kernel_size ||
+        cfg->kpnet_hidden_channels != ref.kpnet_hidden_channels || cfg->kpnet_conv_size != ref.kpnet_conv_size ||
+        cfg->diffusion_step_embed_dim_in != ref.diffusion_step_embed_dim_in ||
+        cfg->diffusion_step_embed_dim_mid != ref.diffusion_step_embed_dim_mid ||
+        cfg->diffusion_step_embed_dim_out != ref.diffusion_step_embed_dim_out)
+        FD_FAIL(nullh, FD_ERR_UNSUPPORTED,
+                "fd_create: only the base.yaml architecture (inner 32, cond 80, ratios [8,8,4], 4 LVC layers k3, kpnet 64/k3, "
+                "embed 128/512/512) has gfx950 kernels");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        FD_FAIL(nullh, FD_ERR_HIP, "fd_create: no HIP device available (%s); there is no CPU fallback", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) FD_FAIL(nullh, FD_ERR_INVALID, "fd_create: device %d out of range (0..%d)", device, ndev - 1);
+    FD_HIP(nullh, hipSetDevice(device));
+    fd_context *c = new fd_context();
+    c->cfg = *cfg;
+    c->device = device;
+    for (int i = 0; i < ST_COUNT; ++i) c->fast[i] = true;
+    if ((e = hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipMalloc(&c->scratch, 65536)) != hipSuccess) {
+        g_create_error = std::string("fd_create: ") + hipGetErrorString(e);
+        delete c;
+        return FD_ERR_HIP;
+    }
+    *out = c;
+    return FD_OK;
+}
+
+static void free_workspace(fd_context *c)
+{
+    Workspace &w = c->ws;
+    void *ptrs[] = {w.noise, w.a[0], w.a[1], w.a[2], w.a[3], w.kp_h0, w.kp_hA, w.kp_hB, w.kpack, w.xA, w.xB,
+                    w.xtap[0], w.xtap[1], w.xtap[2], w.mel, w.x, w.steps, w.params};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    w = Workspace();
+}
+
+static void drop_graph(fd_context *c)
+{
+    if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
+    c->graph_B = c->graph_T = 0;
+}
+
+int fd_destroy(fd_handle h)
+{
+    if (!h) return FD_ERR_INVALID;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    prof_drain(h);
+    for (auto ev : h->event_pool) hipEventDestroy(ev);
+    drop_graph(h);
+    free_workspace(h);
+    for (void *p : h->dev_allocs) hipFree(p);
+    if (h->scratch) hipFree(h->scratch);
+    if (h->cap_stream) hipStreamDestroy(h->cap_stream);
+    delete h;
+    return FD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weights
+// ------------------------------------------------------------------------------------------------
+int fd_set_weight(fd_handle h, const char *name, const float *host_data, const int64_t *dims, int ndim)
+{
+    if (!h || !name || !host_data || !dims || ndim <= 0 || ndim > 4) return FD_ERR_INVALID;
+    const std::string key(name);
+    // find the owning parameter and the expected shape of this tensor
+    static const std::vector<ParamSpec> specs = param_specs();
+    std::vector<int64_t> expect;
+    for (const auto &s : specs) {
+        if (key.compare(0, s.name.size(), s.name) != 0 || key.size() <= s.name.size() || key[s.name.size()] != '.') continue;
+        const std::string suffix = key.substr(s.name.size() + 1);
+        if (suffix == "weight" || suffix == "weight_v") expect = s.dims;
+        else if (suffix == "weight_g") { expect = {s.dims[0], 1, 1}; }
+        else if (suffix == "bias") expect = {s.transposed_conv ? s.dims[1] : s.dims[0]};
+        else continue;
+        break;
+    }
+    if (expect.empty()) FD_FAIL(h, FD_ERR_INVALID, "fd_set_weight: unexpected key '%s' (not in the FastDiff state_dict)", name);
+    std::vector<int64_t> got(dims, dims + ndim);
+    if (got != expect) {
+        std::string a, b;
+        for (auto v : got) a += std::to_string(v) + ",";
+        for (auto v : expect) b += std::to_string(v) + ",";
+        FD_FAIL(h, FD_ERR_INVALID, "fd_set_weight: size mismatch for %s: got [%s] expected [%s]", name, a.c_str(), b.c_str());
+    }
+    auto &slot = h->raw[key];
+    slot.first = got;
+    slot.second.assign(host_data, host_data + numel(got));
+    h->committed = false;
+    return FD_OK;
+}
+
+namespace {
+
+struct Folded { std::vector<float> w, b; };
+
+// w = v * (g / ||v||), norm over everything but dim 0 (torch._weight_norm(v, g, 0)); plain weights pass through
+int fold_param(fd_context *h, const ParamSpec &s, Folded &out)
+{
+    const auto itb = h->raw.find(s.name + ".bias");
+    if (itb == h->raw.end()) FD_FAIL(h, FD_ERR_MISSING, "fd_commit_weights: missing tensor %s.bias", s.name.c_str());
+    out.b = itb->second.second;
+    const auto itw = h->raw.find(s.name + ".weight");
+    const auto itv = h->raw.find(s.name + ".weight_v");
+    const auto itg = h->raw.find(s.name + ".weight_g");
+    if (itv != h->raw.end() && itg != h->raw.end()) {
+        const std::vector<float> &v = itv->second.second, &g = itg->second.second;
+        const int64_t cout = s.dims[0], per = numel(s.dims) / cout;
+        out.w.resize(v.size());
+        for (int64_t o = 0; o < cout; ++o) {
+            double ss = 0.0;
+            for (int64_t j = 0; j < per; ++j) ss += (double)v[o * per + j] * (double)v[o * per + j];
+            const float scale = g[o] / (float)sqrt(ss);
+            for (int64_t j = 0; j < per; ++j) out.w[o * per + j] = v[o * per + j] * scale;
+        }
+    } else if (itw != h->raw.end()) {
+        out.w = itw->second.second;
+    } else {
+        FD_FAIL(h, FD_ERR_MISSING, "fd_commit_weights: missing tensor %s.weight (or weight_g/weight_v)", s.name.c_str());
+    }
+    return FD_OK;
+}
+
+int upload(fd_context *h, const void *src, size_t bytes, const void **dst)
+{
+    void *d = nullptr;
+    FD_HIP(h, hipMalloc(&d, bytes));
+    h->dev_allocs.push_back(d);
+    FD_HIP(h, hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+    *dst = d;
+    return FD_OK;
+}
+
+int upload_f(fd_context *h, const std::vector<float> &v, const float **dst)
+{
+    return upload(h, v.data(), v.size() * sizeof(float), reinterpret_cast<const void **>(dst));
+}
+
+// Conv weight [cout][cin][ks] -> MFMA A-operand pack [mt][s4][lane][4], kk = tap*cin + ci = 2*(4*s4+r) + (lane>>5)
+std::vector<float> pack_A(const std::vector<float> &w, int cout, int cin, int ks)
+{
+    const int ns4 = cin * ks / 8, nmt = cout / 32;
+    std::vector<float> p((size_t)nmt * ns4 * 256);
+    for (int mt = 0; mt < nmt; ++mt)
+        for (int s4 = 0; s4 < ns4; ++s4)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r) {
+                    const int o = mt * 32 + (lane & 31), kk = 2 * (4 * s4 + r) + (lane >> 5);
+                    const int tap = kk / cin, ci = kk % cin;
+                    p[(((size_t)mt * ns4 + s4) * 64 + lane) * 4 + r] = w[((size_t)o * cin + ci) * ks + tap];
+                }
+    return p;
+}
+
+void unpack_kernel_index(int p, int &layer, int &in, int &out, int &tap)
+{
+    layer = p / fd::KLAYER;
+    const int q = p % fd::KLAYER, r = q & 3, lane = (q >> 2) & 63, ms = q >> 8;
+    const int mt = ms / 12, s4 = ms % 12, step = 4 * s4 + r, kk = 2 * step + (lane >> 5);
+    tap = kk / fd::C; in = kk % fd::C; out = mt * 32 + (lane & 31);
+}
+
+}  // namespace
+
+int fd_commit_weights(fd_handle h)
+{
+    if (!h) return FD_ERR_INVALID;
+    FD_HIP(h, hipSetDevice(h->device));
+    FD_HIP(h, hipDeviceSynchronize());
+    for (void *p : h->dev_allocs) hipFree(p);
+    h->dev_allocs.clear();
+    h->w = DevWeights();
+    drop_graph(h);
+
+    std::map<std::string, Folded> f;
+    for (const auto &s : param_specs()) {
+        int rc = fold_param(h, s, f[s.name]);
+        if (rc != FD_OK) return rc;
+    }
+    DevWeights &w = h->w;
+    int rc;
+#define UP(vec, dst) if ((rc = upload_f(h, vec, &(dst))) != FD_OK) return rc
+    auto up_conv = [&](const std::string &name, ConvW &cw) -> int {
+        int r1 = upload_f(h, f[name].w, &cw.w);
+        if (r1 != FD_OK) return r1;
+        return upload_f(h, f[name].b, &cw.b);
+    };
+    if ((rc = up_conv("first_audio_conv", w.first)) != FD_OK) return rc;
+    if ((rc = up_conv("final_conv.0", w.final_)) != FD_OK) return rc;
+    // embed MLP, transposed
+    auto transpose = [](const std::vector<float> &m, int rows, int cols) {
+        std::vector<float> t((size_t)rows * cols);
+        for (int r = 0; r < rows; ++r)
+            for (int c = 0; c < cols; ++c) t[(size_t)c * rows + r] = m[(size_t)r * cols + c];
+        return t;
+    };
+    UP(transpose(f["fc_t1"].w, fd::E_MID, fd::E_IN), w.fc_t1_T);
+    UP(f["fc_t1"].b, w.fc_t1_b);
+    UP(transpose(f["fc_t2"].w, fd::E_OUT, fd::E_MID), w.fc_t2_T);
+    UP(f["fc_t2"].b, w.fc_t2_b);
+    {   // frequency table of calc_diffusion_step_embedding (util.py:425-427): fp32 product, fp32 exp
+        std::vector<float> table(64);
+        const float cst = (float)(-(log(10000.0) / 63.0));
+        for (int j = 0; j < 64; ++j) {
+            volatile float arg = (float)j * cst;
+            table[j] = expf(arg);
+        }
+        UP(table, w.embed_table);
+    }
+    for (int n = 0; n < fd::NBLK; ++n) {
+        const std::string p = "lvc_blocks." + std::to_string(n), d = "downsample." + std::to_string(n);
+        if ((rc = up_conv(d + ".residual_dense", w.down[n].res)) != FD_OK) return rc;
+        for (int i = 0; i < 3; ++i) {
+            if ((rc = up_conv(d + ".conv." + std::to_string(i), w.down[n].conv[i])) != FD_OK) return rc;
+            UP(pack_A(f[d + ".conv." + std::to_string(i)].w, fd::C, fd::C, 3), w.down_pack[n][i]);
+        }
+        UP(pack_A(f[d + ".residual_dense"].w, fd::C, fd::C, 1), w.down_pack[n][3]);
+        if ((rc = up_conv(p + ".fc_t", w.blk[n].fc_t)) != FD_OK) return rc;
+        UP(transpose(f[p + ".fc_t"].w, fd::COND, fd::E_OUT), w.fc_t_T[n]);
+        w.fc_t_b[n] = w.blk[n].fc_t.b;
+        if ((rc = up_conv(p + ".upsample", w.blk[n].up)) != FD_OK) return rc;
+        if ((rc = up_conv(p + ".kernel_predictor.input_conv.0", w.blk[n].kp_in)) != FD_OK) return rc;
+        UP(pack_A(f[p + ".kernel_predictor.input_conv.0"].w, fd::HID, fd::COND, 5), w.kp_in_pack[n]);
+        for (int j = 0; j < 6; ++j) {
+            const std::string nm = p + ".kernel_predictor.residual_conv." + std::to_string(KP_RES_IDX[j]);
+            if ((rc = up_conv(nm, w.blk[n].kp_res[j])) != FD_OK) return rc;
+            UP(pack_A(f[nm].w, fd::HID, fd::HID, 3), w.kp_res_pack[n][j]);
+        }
+        if ((rc = up_conv(p + ".kernel_predictor.kernel_conv", w.blk[n].kc)) != FD_OK) return rc;
+        if ((rc = up_conv(p + ".kernel_predictor.bias_conv", w.blk[n].bc)) != FD_OK) return rc;
+        for (int i = 0; i < fd::LAYERS; ++i) {
+            if ((rc = up_conv(p + ".convs." + std::to_string(i), w.blk[n].convs[i])) != FD_OK) return rc;
+            UP(pack_A(f[p + ".convs." + std::to_string(i)].w, fd::C, fd::C, 3), w.lvc_conv_pack[n][i]);
+        }
+        {   // GEMM B-operand pack: rows in packed-record order, kk = tap*64 + c
+            const std::vector<float> &kc = f[p + ".kernel_predictor.kernel_conv"].w, &kcb = f[p + ".kernel_predictor.kernel_conv"].b;
+            const std::vector<float> &bc = f[p + ".kernel_predictor.bias_conv"].w, &bcb = f[p + ".kernel_predictor.bias_conv"].b;
+            std::vector<float> gp((size_t)(fd::KREC / 32) * 24 * 256), gb(fd::KREC);
+            for (int pt = 0; pt < fd::KREC / 32; ++pt)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int pp = pt * 32 + (lane & 31);
+                    const float *wrow;
+                    if (pp < fd::KW) {
+                        int layer, in, out, tap;
+                        unpack_kernel_index(pp, layer, in, out, tap);
+                        const int row = ((layer * fd::C + in) * 2 * fd::C + out) * 3 + tap;   // [layers,in,out,k] view (modules.py:333-338)
+                        wrow = kc.data() + (size_t)row * fd::HID * 3;
+                        gb[pp] = kcb[row];
+                    } else {
+                        wrow = bc.data() + (size_t)(pp - fd::KW) * fd::HID * 3;
+                        gb[pp] = bcb[pp - fd::KW];
+                    }
+                    for (int s4 = 0; s4 < 24; ++s4)
+                        for (int r = 0; r < 4; ++r) {
+                            const int kk = 2 * (4 * s4 + r) + (lane >> 5), tap = kk / fd::HID, c = kk % fd::HID;
+                            gp[(((size_t)pt * 24 + s4) * 64 + lane) * 4 + r] = wrow[c * 3 + tap];
+                        }
+                }
+            UP(gp, w.gemm_pack[n]);
+            UP(gb, w.gemm_bias[n]);
+        }
+    }
+    {
+        std::vector<int> perm(fd::KW);
+        for (int layer = 0; layer < fd::LAYERS; ++layer)
+            for (int in = 0; in < fd::C; ++in)
+                for (int out = 0; out < 2 * fd::C; ++out)
+                    for (int tap = 0; tap < 3; ++tap)
+                        perm[((layer * fd::C + in) * 2 * fd::C + out) * 3 + tap] = fd::kernel_index(layer, in, out, tap);
+        if ((rc = upload(h, perm.data(), perm.size() * sizeof(int), reinterpret_cast<const void **>(&w.kc_perm))) != FD_OK) return rc;
+    }
+#undef UP
+    h->raw.clear();     // host copies are no longer needed
+    h->committed = true;
+    return FD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------------
+static int ensure_workspace(fd_context *h, int B, int T)
+{
+    Workspace &w = h->ws;
+    if (w.B >= B && w.T >= T && w.params) return FD_OK;
+    FD_HIP(h, hipDeviceSynchronize());
+    drop_graph(h);
+    const int nB = std::max(B, w.B), nT = std::max(T, w.T);
+    free_workspace(h);
+    const size_t L = (size_t)nT * fd::HOPT, f = sizeof(float);
+    size_t total = 0;
+    auto alloc = [&](float **p, size_t n) -> hipError_t {
+        total += n * f;
+        return hipMalloc(reinterpret_cast<void **>(p), n * f);
+    };
+    hipError_t e = hipSuccess;
+#define WS(p, n) if (e == hipSuccess) e = alloc(&(p), (n))
+    WS(w.noise, (size_t)1024 * nB * fd::NBLK * fd::COND);
+    WS(w.a[0], nB * fd::C * L); WS(w.a[1], nB * fd::C * L / 4); WS(w.a[2], nB * fd::C * L / 32); WS(w.a[3], (size_t)nB * fd::C * nT);
+    WS(w.kp_h0, (size_t)fd::NBLK * nB * fd::HID * nT); WS(w.kp_hA, (size_t)fd::NBLK * nB * fd::HID * nT);
+    WS(w.kp_hB, (size_t)fd::NBLK * nB * fd::HID * nT);
+    WS(w.kpack, (size_t)fd::NBLK * nB * nT * fd::KREC);
+    WS(w.xA, nB * fd::C * L); WS(w.xB, nB * fd::C * L);
+    WS(w.xtap[0], nB * fd::C * L / 32); WS(w.xtap[1], nB * fd::C * L / 4); WS(w.xtap[2], nB * fd::C * L);
+    WS(w.mel, (size_t)nB * fd::COND * nT); WS(w.x, nB * L); WS(w.steps, (size_t)std::max(nB, 64));
+#undef WS
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w.params), sizeof(StepParams));
+    if (e == hipSuccess) e = hipMemset(w.params, 0, sizeof(StepParams));
+    if (e != hipSuccess) {
+        free_workspace(h);
+        FD_FAIL(h, FD_ERR_HIP, "workspace allocation for B=%d T=%d (%.1f MB) failed: %s", nB, nT, total / 1e6, hipGetErrorString(e));
+    }
+    w.B = nB; w.T = nT; w.bytes = total;
+    return FD_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// stage dispatch + the denoiser step
+// ------------------------------------------------------------------------------------------------
+namespace fdk {
+
+hipError_t first_conv(const Launch &L, const StepIO &io, int B, int T)
+{
+    return L.ctx->fast[ST_FIRST] ? fast_first_conv(L, io, B, T) : naive_first_conv(L, io, B, T);
+}
+hipError_t dblock(const Launch &L, int d, int B, int T) { return L.ctx->fast[ST_DBLOCK] ? fast_dblock(L, d, B, T) : naive_dblock(L, d, B, T); }
+hipError_t kp_front(const Launch &L, const StepIO &io, int B, int T)
+{
+    return L.ctx->fast[ST_KP_FRONT] ? fast_kp_front(L, io, B, T) : naive_kp_front(L, io, B, T);
+}
+hipError_t kp_gemm(const Launch &L, int B, int T) { return L.ctx->fast[ST_KP_GEMM] ? fast_kp_gemm(L, B, T) : naive_kp_gemm(L, B, T); }
+
+// One TimeAware_LVCBlock (modules.py:190-218) given the packed kernels of kp_gemm.  x_in: [B,32,Lin].
+static hipError_t lvc_block_run(const Launch &L, int n, const float *x_in, int B, int T, float **x_out)
+{
+    fd_context *c = L.ctx;
+    Workspace &ws = c->ws;
+    const int Lin = T * (fd::hop(n) / fd::ratio(n));
+    float *cur = (x_in == ws.xA) ? ws.xB : ws.xA;
+    float *other = (cur == ws.xA) ? ws.xB : ws.xA;
+    hipError_t e = c->fast[ST_CONVT] ? fast_convt(L, n, x_in, cur, B, Lin) : naive_convt(L, n, x_in, cur, B, Lin);
+    if (e != hipSuccess) return e;
+    const float *skip = ws.a[2 - n];
+    for (int i = 0; i < fd::LAYERS; ++i) {
+        if (c->fast[ST_LVC]) {
+            e = fast_lvc_layer(L, n, i, cur, skip, other, B, T);
+            std::swap(cur, other);
+        } else {
+            e = naive_lvc_layer(L, n, i, cur, skip, other, B, T);
+        }
+        if (e != hipSuccess) return e;
+    }
+    if (c->keep_taps) {
+        e = hipMemcpyAsync(ws.xtap[n], cur, sizeof(float) * (size_t)B * fd::C * T * fd::hop(n), hipMemcpyDeviceToDevice, L.stream);
+        if (e != hipSuccess) return e;
+    }
+    *x_out = cur;
+    return hipSuccess;
+}
+
+static hipError_t run_step(const Launch &L, const StepIO &io, int B, int T)
+{
+    fd_context *c = L.ctx;
+    Workspace &ws = c->ws;
+    hipError_t e;
+    if ((e = first_conv(L, io, B, T)) != hipSuccess) return e;
+    for (int d = 0; d < fd::NBLK; ++d)
+        if ((e = dblock(L, d, B, T)) != hipSuccess) return e;
+    if ((e = kp_front(L, io, B, T)) != hipSuccess) return e;
+    if ((e = kp_gemm(L, B, T)) != hipSuccess) return e;
+    float *x = ws.a[3];
+    for (int n = 0; n < fd::NBLK; ++n) {
+        float *xo = nullptr;
+        if ((e = lvc_block_run(L, n, x, B, T, &xo)) != hipSuccess) return e;
+        x = xo;
+    }
+    if (c->fast[ST_FINAL]) return fast_final(L, io, x, B, T);
+    // naive tail: eps into the free ping-pong buffer (or the caller's), then the separate update kernel
+    float *eps = io.sampler ? ((x == ws.xA) ? ws.xB : ws.xA) : io.eps_out;
+    if ((e = naive_final_eps(L, x, eps, B, T)) != hipSuccess) return e;
+    if (io.sampler) return naive_update(L, ws.x, eps, (int64_t)B * T * fd::HOPT);
+    return hipSuccess;
+}
+
+}  // namespace fdk
+
+// ------------------------------------------------------------------------------------------------
+// C ABI: compute
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+static int check_common(fd_handle h, int B, int T, const char *who)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!h->committed) FD_FAIL(h, FD_ERR_STATE, "%s: weights not committed (call fd_commit_weights after fd_set_weight)", who);
+    if (B <= 0 || T <= 0) FD_FAIL(h, FD_ERR_INVALID, "%s: B=%d T=%d must be positive", who, B, T);
+    if ((int64_t)B * T * fd::HOPT * fd::C >= (int64_t)1 << 31)
+        FD_FAIL(h, FD_ERR_INVALID, "%s: B*T too large for one call (B=%d, T=%d); split the batch", who, B, T);
+    FD_HIP(h, hipSetDevice(h->device));
+    return FD_OK;
+}
+
+int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps, int B, int T, const int *lens,
+               float *eps_out, void *stream)
+{
+    int rc = check_common(h, B, T, "fd_forward");
+    if (rc != FD_OK) return rc;
+    (void)lens;   // results are those of the padded tensor (see header)
+    if (!x || !mel || !steps || !eps_out) FD_FAIL(h, FD_ERR_INVALID, "fd_forward: null pointer");
+    if (x == eps_out) FD_FAIL(h, FD_ERR_INVALID, "fd_forward: eps_out must not alias x");
+    if ((rc = ensure_workspace(h, B, T)) != FD_OK) return rc;
+    fdk::Launch L = {h, (hipStream_t)stream, false};
+    StepIO io = {x, mel, steps, eps_out, 0};
+    hipError_t e = fdk::embed(L, io, B, 1);
+    if (e == hipSuccess) e = fdk::run_step(L, io, B, T);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_forward: kernel launch failed: %s", hipGetErrorString(e));
+    h->last_B = B; h->last_T = T;
+    return FD_OK;
+}
+
+static unsigned mode_signature(const fd_context *h)
+{
+    unsigned s = h->keep_taps ? 1u : 0u;
+    for (int i = 0; i < ST_COUNT; ++i) s = (s << 1) | (h->fast[i] ? 1u : 0u);
+    return s;
+}
+
+int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, const fd_step *table, int N, int ddim,
+              const float *x_T, const float *z, uint64_t seed, float *out, float *seq_out, void *stream_)
+{
+    int rc = check_common(h, B, T, "fd_sample");
+    if (rc != FD_OK) return rc;
+    (void)lens;
+    if (!mel || !table || !out) FD_FAIL(h, FD_ERR_INVALID, "fd_sample: null pointer");
+    if (N <= 0 || N > 1024) FD_FAIL(h, FD_ERR_INVALID, "fd_sample: N=%d outside 1..1024", N);
+    if ((rc = ensure_workspace(h, B, T)) != FD_OK) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    Workspace &ws = h->ws;
+    const size_t n_el = (size_t)B * T * fd::HOPT;
+
+    // per-call parameters -> device block the captured kernels read
+    {
+        std::vector<char> blob(sizeof(StepParams));
+        StepParams *p = reinterpret_cast<StepParams *>(blob.data());
+        memset(p, 0, sizeof(StepParams));
+        memcpy(p->table, table, sizeof(fd_step) * N);
+        p->z = z; p->seq = seq_out; p->seed = seed; p->n_steps = N; p->ddim = ddim ? 1 : 0; p->step_idx = 0;
+        // only the used prefix of the table plus the trailer needs to travel
+        const size_t head = sizeof(fd_step) * N;
+        FD_HIP(h, hipMemcpyAsync(ws.params, p, head, hipMemcpyHostToDevice, stream));
+        const size_t off = offsetof(StepParams, z);
+        FD_HIP(h, hipMemcpyAsync(reinterpret_cast<char *>(ws.params) + off, blob.data() + off, sizeof(StepParams) - off,
+                                 hipMemcpyHostToDevice, stream));
+        FD_HIP(h, hipStreamSynchronize(stream));   // blob is a stack-lifetime staging buffer
+    }
+    FD_HIP(h, hipMemcpyAsync(ws.mel, mel, sizeof(float) * (size_t)B * fd::COND * T, hipMemcpyDeviceToDevice, stream));
+    fdk::Launch L = {h, stream, false};
+    hipError_t e = hipSuccess;
+    if (x_T) FD_HIP(h, hipMemcpyAsync(ws.x, x_T, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
+    else if ((e = fdk::init_noise(L, ws.x, (int64_t)n_el, seed)) != hipSuccess)
+        FD_FAIL(h, FD_ERR_HIP, "fd_sample: init_noise failed: %s", hipGetErrorString(e));
+    if (seq_out) FD_HIP(h, hipMemcpyAsync(seq_out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
+
+    StepIO io = {ws.x, ws.mel, nullptr, nullptr, 1};
+    if ((e = fdk::embed(L, io, B, N)) != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample: embed failed: %s", hipGetErrorString(e));
+
+    const bool graph = h->use_graph && !h->profile;
+    if (graph) {
+        const unsigned sig = mode_signature(h);
+        if (!h->graph_exec || h->graph_B != B || h->graph_T != T || h->graph_sig != sig) {
+            drop_graph(h);
+            FD_HIP(h, hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+            fdk::Launch Lc = {h, h->cap_stream, true};
+            e = fdk::run_step(Lc, io, B, T);
+            if (e == hipSuccess) e = fdk::advance_step(Lc);
+            hipGraph_t g = nullptr;
+            hipError_t e2 = hipStreamEndCapture(h->cap_stream, &g);
+            if (e != hipSuccess || e2 != hipSuccess) {
+                if (g) hipGraphDestroy(g);
+                FD_FAIL(h, FD_ERR_HIP, "fd_sample: graph capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+            }
+            h->graph = g;
+            FD_HIP(h, hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+            h->graph_B = B; h->graph_T = T; h->graph_sig = sig;
+        }
+        for (int k = 0; k < N; ++k) FD_HIP(h, hipGraphLaunch(h->graph_exec, stream));
+    } else {
+        for (int k = 0; k < N; ++k) {
+            e = fdk::run_step(L, io, B, T);
+            if (e == hipSuccess) e = fdk::advance_step(L);
+            if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample: step %d failed: %s", k, hipGetErrorString(e));
+        }
+    }
+    FD_HIP(h, hipMemcpyAsync(out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
+    h->last_B = B; h->last_T = T;
+    return FD_OK;
+}
+
+int fd_peak_normalize_int16(fd_handle h, const float *wav, int B, int64_t len, int16_t *pcm, void *stream)
+{
+    if (!h || !wav || !pcm || B <= 0 || len <= 0 || B > 16384) return FD_ERR_INVALID;
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch L = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::peak_normalize_int16(L, wav, B, len, pcm);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_peak_normalize_int16: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// options, taps, profile
+// ------------------------------------------------------------------------------------------------
+int fd_set_option(fd_handle h, const char *key, const char *value)
+{
+    if (!h || !key || !value) return FD_ERR_INVALID;
+    const std::string k(key), v(value);
+    static const char *stage_names[ST_COUNT] = {"embed", "first", "dblock", "kp_front", "kp_gemm", "convt", "lvc", "final"};
+    auto parse_mode = [&](bool &dst) -> int {
+        if (v == "fast") dst = true;
+        else if (v == "naive") dst = false;
+        else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: %s expects fast|naive, got '%s'", key, value);
+        return FD_OK;
+    };
+    if (k == "kernels") {
+        bool m = true;
+        int rc = parse_mode(m);
+        if (rc != FD_OK) return rc;
+        for (int i = 0; i < ST_COUNT; ++i) h->fast[i] = m;
+        return FD_OK;
+    }
+    if (k.compare(0, 8, "kernels.") == 0) {
+        for (int i = 0; i < ST_COUNT; ++i)
+            if (k.substr(8) == stage_names[i]) return parse_mode(h->fast[i]);
+        FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: unknown stage '%s'", key);
+    }
+    const bool on = (v == "1" || v == "true" || v == "on");
+    if (k == "graph") { h->use_graph = on; return FD_OK; }
+    if (k == "profile") { h->profile = on; return FD_OK; }
+    if (k == "taps") { h->keep_taps = on; return FD_OK; }
+    FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: unknown option '%s'", key);
+}
+
+int64_t fd_read_tap(fd_handle h, const char *name, float *host_dst, int64_t capacity)
+{
+    if (!h || !name) return FD_ERR_INVALID;
+    const int B = h->last_B, T = h->last_T;
+    if (B == 0) FD_FAIL(h, FD_ERR_STATE, "fd_read_tap: no forward has run yet");
+    const Workspace &w = h->ws;
+    const int64_t L = (int64_t)T * fd::HOPT;
+    const std::string k(name);
+    const float *src = nullptr;
+    int64_t n = 0;
+    if (k == "noise") { src = w.noise; n = (int64_t)B * fd::NBLK * fd::COND; }
+    else if (k == "a0") { src = w.a[0]; n = B * fd::C * L; }
+    else if (k == "a1") { src = w.a[1]; n = B * fd::C * L / 4; }
+    else if (k == "a2") { src = w.a[2]; n = B * fd::C * L / 32; }
+    else if (k == "a3") { src = w.a[3]; n = (int64_t)B * fd::C * T; }
+    else if (k.size() == 6 && k.compare(0, 5, "kpack") == 0 && k[5] >= '0' && k[5] <= '2') {
+        n = (int64_t)B * T * fd::KREC; src = w.kpack + (k[5] - '0') * n;
+    } else if (k.size() == 5 && k.compare(0, 4, "kp_h") == 0 && k[4] >= '0' && k[4] <= '2') {
+        n = (int64_t)B * fd::HID * T; src = w.kp_hB + (k[4] - '0') * n;
+    } else if (k.size() == 2 && k[0] == 'x' && k[1] >= '0' && k[1] <= '2') {
+        if (!h->keep_taps) FD_FAIL(h, FD_ERR_STATE, "fd_read_tap: set option taps=1 before the forward to keep block outputs");
+        const int blk = k[1] - '0';
+        src = w.xtap[blk]; n = (int64_t)B * fd::C * T * fd::hop(blk);
+    } else FD_FAIL(h, FD_ERR_INVALID, "fd_read_tap: unknown tap '%s'", name);
+    if (!host_dst) return n;
+    if (capacity < n) FD_FAIL(h, FD_ERR_INVALID, "fd_read_tap: capacity %lld < %lld", (long long)capacity, (long long)n);
+    FD_HIP(h, hipSetDevice(h->device));
+    FD_HIP(h, hipDeviceSynchronize());
+    FD_HIP(h, hipMemcpy(host_dst, src, sizeof(float) * n, hipMemcpyDeviceToHost));
+    return n;
+}
+
+int fd_kernel_index(int layer, int in_ch, int out_ch, int tap)
+{
+    if (layer < 0 || layer >= fd::LAYERS || in_ch < 0 || in_ch >= fd::C || out_ch < 0 || out_ch >= 2 * fd::C || tap < 0 || tap >= 3)
+        return FD_ERR_INVALID;
+    return fd::kernel_index(layer, in_ch, out_ch, tap);
+}
+
+int fd_get_profile(fd_handle h, fd_kernel_stat *stats, int capacity)
+{
+    if (!h) return FD_ERR_INVALID;
+    hipSetDevice(h->device);
+    prof_drain(h);
+    int i = 0;
+    for (const auto &kv : h->prof_acc) {
+        if (stats && i < capacity) {
+            memset(&stats[i], 0, sizeof(fd_kernel_stat));
+            strncpy(stats[i].name, kv.first.c_str(), sizeof(stats[i].name) - 1);
+            stats[i].launches = kv.second.first;
+            stats[i].total_ms = kv.second.second;
+        }
+        ++i;
+    }
+    return i;
+}
+
+int fd_reset_profile(fd_handle h)
+{
+    if (!h) return FD_ERR_INVALID;
+    prof_drain(h);
+    h->prof_acc.clear();
+    return FD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,167 @@
+// fd_internal.h -- shared between the host side (fd_api.cpp, fd_weights.cpp) and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/fastdiff_hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// Fixed architecture of this build (modules/FastDiff/config/base.yaml:21-33).  fd_create rejects
+// anything else: the four dataset YAMLs of the reference never change the network shape.
+// ---------------------------------------------------------------------------------------------
+namespace fd {
+constexpr int C = 32;          // inner_channels
+constexpr int COND = 80;       // cond_channels
+constexpr int HID = 64;        // kpnet_hidden_channels
+constexpr int NBLK = 3;
+constexpr int LAYERS = 4;      // lvc_layers_each_block
+constexpr int HOPT = 256;      // prod(upsample_ratios)
+constexpr int E_IN = 128, E_MID = 512, E_OUT = 512;
+constexpr int KLAYER = 2 * C * C * 3;        // 6144 predicted-kernel floats per (frame, layer)
+constexpr int KW = KLAYER * LAYERS;          // 24576
+constexpr int KB = 2 * C * LAYERS;           // 256 predicted biases per frame
+constexpr int KREC = KW + KB;                // 24832 floats: one frame's packed record
+__host__ __device__ constexpr int ratio(int n) { return n == 2 ? 4 : 8; }        // upsample_ratios [8,8,4]
+__host__ __device__ constexpr int hop(int n) { return n == 0 ? 8 : (n == 1 ? 64 : 256); }
+__host__ __device__ constexpr int down_factor(int d) { return d == 0 ? 4 : 8; }   // reversed ratios (FastDiff_model.py:63)
+
+// Packed position of predicted-kernel element K[layer][in][out][tap] inside a frame record.
+// The record of one (frame, layer) is laid out as the A operand of v_mfma_f32_32x32x2_f32:
+//   [mt = out/32][s4 = step/4][lane][r = step%4],  step = kk/2, lane = (out%32) + 32*(kk%2), kk = tap*32 + in
+// so a lane fetches four consecutive k-steps of its row with one 16-byte load.
+__host__ __device__ inline int kernel_index(int layer, int in, int out, int tap)
+{
+    const int kk = tap * C + in, step = kk >> 1, hi = kk & 1;
+    const int s4 = step >> 2, r = step & 3, mt = out >> 5, lane = (out & 31) + 32 * hi;
+    return layer * KLAYER + ((mt * 12 + s4) * 64 + lane) * 4 + r;
+}
+}  // namespace fd
+
+// ---------------------------------------------------------------------------------------------
+// Device-side weights
+// ---------------------------------------------------------------------------------------------
+struct ConvW {
+    const float *w = nullptr;   // folded, reference layout [out][in][k]  (ConvTranspose: [in][out][k]; Linear: [out][in])
+    const float *b = nullptr;
+};
+
+struct DevWeights {
+    // reference-layout (naive kernels, VALU kernels)
+    ConvW first, final_;
+    struct { ConvW res, conv[3]; } down[fd::NBLK];
+    struct { ConvW fc_t, up, kp_in, kp_res[6], kc, bc, convs[fd::LAYERS]; } blk[fd::NBLK];
+    // embed MLP, transposed [in][out] so thread-per-output reads are coalesced
+    const float *fc_t1_T = nullptr, *fc_t1_b = nullptr, *fc_t2_T = nullptr, *fc_t2_b = nullptr;
+    const float *fc_t_T[fd::NBLK] = {}, *fc_t_b[fd::NBLK] = {};
+    const float *embed_table = nullptr;           // [64] fp32 frequencies
+    // MFMA A-operand packs ([mt][s4][lane][4], kk = tap*Cin + in)
+    const float *down_pack[fd::NBLK][4] = {};     // conv0..2 (K=96), res 1x1 (K=32)
+    const float *lvc_conv_pack[fd::NBLK][fd::LAYERS] = {};
+    const float *kp_in_pack[fd::NBLK] = {};       // 80->64 k5: 2 mt x 50 s4
+    const float *kp_res_pack[fd::NBLK][6] = {};   // 64->64 k3: 2 mt x 24 s4
+    const float *gemm_pack[fd::NBLK] = {};        // kernel_conv+bias_conv as MFMA B operand: [776 ptile][24 s4][64][4]
+    const float *gemm_bias[fd::NBLK] = {};        // [24832] conv biases in packed order
+    const float *up_pack[fd::NBLK] = {};          // ConvTranspose as per-phase A operands: [r phases][8 s4][64][4]
+    const int *kc_perm = nullptr;                 // [24576] reference kernel_conv row -> packed position
+};
+
+// ---------------------------------------------------------------------------------------------
+// Per-call step description read by kernels from device memory (so a captured graph is pointer-free)
+// ---------------------------------------------------------------------------------------------
+struct StepParams {
+    fd_step table[1024];
+    const float *z;        // injected noise [N,B,L] or null
+    float *seq;            // trajectory [N+1,B,L] or null
+    unsigned long long seed;
+    int n_steps;
+    int ddim;
+    int step_idx;          // advanced on device at the end of every captured step
+    int pad;
+};
+
+enum Stage { ST_EMBED = 0, ST_FIRST, ST_DBLOCK, ST_KP_FRONT, ST_KP_GEMM, ST_CONVT, ST_LVC, ST_FINAL, ST_COUNT };
+
+struct Workspace {
+    int B = 0, T = 0;           // capacity
+    float *noise = nullptr;     // [1024][B][3][80]
+    float *a[4] = {};           // a0..a3
+    float *kp_h0 = nullptr, *kp_hA = nullptr, *kp_hB = nullptr;   // [3][B][64][T]
+    float *kpack = nullptr;     // [3][B][T][KREC]
+    float *xA = nullptr, *xB = nullptr;                           // [B][32][L] ping-pong
+    float *xtap[fd::NBLK] = {}; // block outputs kept for fd_read_tap
+    float *mel = nullptr;       // [B][80][T] library-owned copy used by the sampler graph
+    float *x = nullptr;         // [B][L] running x_t of the sampler
+    float *steps = nullptr;     // [B] step values for fd_forward
+    StepParams *params = nullptr;
+    size_t bytes = 0;
+};
+
+struct ProfEntry { std::string name; hipEvent_t e0, e1; };
+
+struct fd_context {
+    fd_config cfg;
+    int device = 0;
+    std::string err;
+    bool committed = false;
+    bool fast[ST_COUNT];
+    bool use_graph = true;
+    bool profile = false;
+    bool keep_taps = false;
+    std::map<std::string, std::pair<std::vector<int64_t>, std::vector<float>>> raw;   // host copies from fd_set_weight
+    std::vector<void *> dev_allocs;          // weight arena pieces
+    DevWeights w;
+    Workspace ws;
+    int last_B = 0, last_T = 0;
+    hipStream_t cap_stream = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_B = 0, graph_T = 0;
+    unsigned graph_sig = 0;
+    StepParams *host_params = nullptr;       // pinned staging
+    void *scratch = nullptr;                 // 64 KB device scratch (abs-max words, ...)
+    std::vector<ProfEntry> prof_pending;
+    std::vector<hipEvent_t> event_pool;
+    std::map<std::string, std::pair<int64_t, double>> prof_acc;
+};
+
+// Arguments of one denoiser step (all device pointers)
+struct StepIO {
+    const float *x_in;     // [B][L] current x_t
+    const float *mel;      // [B][80][T]
+    const float *steps;    // [B] (forward mode) -- ignored in sampler mode (table[step_idx].t)
+    float *eps_out;        // forward mode: eps destination; sampler mode: null (x updated in place)
+    int sampler;           // 0 = fd_forward, 1 = fd_sample step
+};
+
+// kernels (fd_kernels_*.hip) -- each returns hipError from launch
+namespace fdk {
+struct Launch {
+    fd_context *ctx;
+    hipStream_t stream;
+    bool capturing;
+};
+hipError_t embed(const Launch &L, const StepIO &io, int B, int n_steps);
+hipError_t first_conv(const Launch &L, const StepIO &io, int B, int T);
+hipError_t dblock(const Launch &L, int d, int B, int T);
+hipError_t kp_front(const Launch &L, const StepIO &io, int B, int T);
+hipError_t kp_gemm(const Launch &L, int B, int T);
+hipError_t advance_step(const Launch &L);
+hipError_t init_noise(const Launch &L, float *x, int64_t n, unsigned long long seed);
+hipError_t peak_normalize_int16(const Launch &L, const float *wav, int B, int64_t len, int16_t *pcm);
+}  // namespace fdk
+
+// profiling-aware launch helper
+void fd_prof_begin(const fdk::Launch &L, const char *name);
+void fd_prof_end(const fdk::Launch &L);
+
+#define FD_LAUNCH(L, name, kernel, grid, block, shmem, ...)                                  \
+    do {                                                                                     \
+        fd_prof_begin(L, name);                                                              \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, (L).stream, __VA_ARGS__);             \
+        fd_prof_end(L);                                                                      \
+        hipError_t e__ = hipGetLastError();                                                  \
+        if (e__ != hipSuccess) return e__;                                                   \
+    } while (0)

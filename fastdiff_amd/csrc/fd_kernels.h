@@ -1,0 +1,23 @@
+// fd_kernels.h -- internal: per-stage entry points of the naive and the fast (MFMA) kernel sets.
+#pragma once
+#include "fd_internal.h"
+
+namespace fdk {
+// naive set (fd_kernels_naive.hip)
+hipError_t naive_first_conv(const Launch &L, const StepIO &io, int B, int T);
+hipError_t naive_dblock(const Launch &L, int d, int B, int T);
+hipError_t naive_kp_front(const Launch &L, const StepIO &io, int B, int T);
+hipError_t naive_kp_gemm(const Launch &L, int B, int T);
+hipError_t naive_convt(const Launch &L, int n, const float *x_in, float *x_out, int B, int Lin);
+hipError_t naive_lvc_layer(const Launch &L, int n, int layer, float *x, const float *skip, float *y, int B, int T);
+hipError_t naive_final_eps(const Launch &L, const float *x32, float *eps, int B, int T);
+hipError_t naive_update(const Launch &L, float *x, const float *eps, int64_t n);
+// fast set (fd_kernels_fast.hip)
+hipError_t fast_first_conv(const Launch &L, const StepIO &io, int B, int T);
+hipError_t fast_dblock(const Launch &L, int d, int B, int T);
+hipError_t fast_kp_front(const Launch &L, const StepIO &io, int B, int T);
+hipError_t fast_kp_gemm(const Launch &L, int B, int T);
+hipError_t fast_convt(const Launch &L, int n, const float *x_in, float *x_out, int B, int Lin);
+hipError_t fast_lvc_layer(const Launch &L, int n, int layer, const float *x_in, const float *skip, float *x_out, int B, int T);
+hipError_t fast_final(const Launch &L, const StepIO &io, const float *x32, int B, int T);
+}  // namespace fdk

@@ -1,0 +1,635 @@
+// fd_kernels_fast.hip -- the gfx950 kernel set of the FastDiff denoiser step.
+//
+// Everything with a channel contraction runs on the exact-fp32 matrix pipe, v_mfma_f32_32x32x2_f32
+// (bit-for-bit an fp32 fmaf chain, so the fp32 parity bar of the reference holds):
+//   D[row][col] += A[row][k] * B[k][col],   wave64 operand layout (MI355X_MICROARCH / cdna_hip guide 3):
+//     A: lane l holds A[row = l&31][k = l>>5]          (1 VGPR)
+//     B: lane l holds B[k = l>>5][col = l&31]          (1 VGPR)
+//     D: lane l, reg r holds D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]   (16 VGPRs)
+// Convolutions map as: row = output channel, col = time, k = (tap, input channel); the B operand is read
+// straight out of an LDS-staged sliding window (32 consecutive time samples per half-wave: conflict free),
+// the A operand (weights, or the predicted per-frame kernel of the location-variable convolution) sits in
+// registers, pre-packed in HBM as [s4 = step/4][lane][4] so each lane fetches 4 k-steps with one 16 B load.
+#include "fd_kernels.h"
+#include "fd_device.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace fdk_fast {
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int drow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+__device__ __forceinline__ float lrelu(float v, float s) { return fmaxf(v, v * s); }   // 0 < s < 1
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+__device__ __forceinline__ float f4c(const float4 &v, int r) { return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w)); }
+
+// =================================================================================================
+// a3: first_audio_conv  Conv1d(1,32,k7,pad3)  (FastDiff_model.py:34-36,89)   -- VALU, HBM-write bound
+// =================================================================================================
+__global__ void __launch_bounds__(256) k_first_conv(const float *__restrict__ x, const float *__restrict__ w,
+                                                    const float *__restrict__ bias, float *__restrict__ a0, int L)
+{
+    const int b = blockIdx.y;
+    const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (t0 >= L) return;
+    const float *xr = x + (int64_t)b * L;
+    float xv[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const int p = t0 - 3 + i;
+        xv[i] = (p >= 0 && p < L) ? xr[p] : 0.0f;
+    }
+#pragma unroll 4
+    for (int o = 0; o < fd::C; ++o) {
+        float wv[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) wv[k] = w[o * 7 + k];
+        const float bv = bias[o];
+        float4 r = make_float4(bv, bv, bv, bv);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            r.x += wv[k] * xv[k]; r.y += wv[k] * xv[k + 1]; r.z += wv[k] * xv[k + 2]; r.w += wv[k] * xv[k + 3];
+        }
+        *reinterpret_cast<float4 *>(a0 + ((int64_t)b * fd::C + o) * L + t0) = r;
+    }
+}
+
+// =================================================================================================
+// a4: DiffusionDBlock (modules.py:127-138), fused: strided pick, 3 dilated convs, 1x1 residual, add
+// One workgroup = one 128-column tile at the DOWN-sampled rate; every layer is computed on all 128 columns
+// and the valid region shrinks by the dilation (1+2+4 = 7 per side), so tiles advance by 114 columns.
+// =================================================================================================
+constexpr int DB_LD = 136;   // 128 + 4 guard columns each side (max dilation 4)
+constexpr int DB_STRIDE = 114;
+
+template <int DIL, bool LRELU>
+__device__ __forceinline__ void conv96_tile(f32x16 &acc, const float4 (&wa)[12], const float *in, int ld, int col, int hi)
+{
+    // 48 k-steps: kk = 2s+hi = tap*32 + ci
+#pragma unroll
+    for (int s = 0; s < 48; ++s) {
+        const int tap = s >> 4, ci = ((2 * s) & 31) + hi;
+        float v = in[ci * ld + col + (tap - 1) * DIL];
+        if (LRELU) v = lrelu(v, 0.2f);
+        acc = mfma32(f4c(wa[s >> 2], s & 3), v, acc);
+    }
+}
+
+template <int F>
+__global__ void __launch_bounds__(256, 2) k_dblock(const float *__restrict__ xin, float *__restrict__ out,
+                                                   const float *__restrict__ p0, const float *__restrict__ p1,
+                                                   const float *__restrict__ p2, const float *__restrict__ pr,
+                                                   const float *__restrict__ b0, const float *__restrict__ b1,
+                                                   const float *__restrict__ b2, const float *__restrict__ br, int Lin, int Lo)
+{
+    __shared__ __attribute__((aligned(16))) float xs[fd::C * DB_LD];
+    __shared__ __attribute__((aligned(16))) float hA[fd::C * DB_LD];
+    __shared__ __attribute__((aligned(16))) float hB[fd::C * DB_LD];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int pbase = blockIdx.x * DB_STRIDE - 7;   // down-sampled position of tile column 0
+    // stage the strided pick x[..., ::F]; zero outside [0, Lo) and in the guard columns
+    for (int idx = tid; idx < fd::C * DB_LD; idx += 256) {
+        const int ci = idx / DB_LD, cc = idx % DB_LD, p = pbase + cc - 4;
+        float v = 0.0f;
+        if (cc >= 4 && cc < 132 && p >= 0 && p < Lo) v = xin[((int64_t)b * fd::C + ci) * Lin + (int64_t)p * F];
+        xs[idx] = v;
+        hA[idx] = 0.0f;
+        hB[idx] = 0.0f;
+    }
+    __syncthreads();
+    const int c = wave * 32 + l31;        // this lane's tile column
+    const int p = pbase + c;              // its down-sampled position
+    const bool inside = (p >= 0 && p < Lo);
+    float4 wa[12];
+    f32x16 acc;
+    // layer 1: dil 1 on leaky_relu(xs)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) wa[i] = reinterpret_cast<const float4 *>(p0)[i * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = b0[drow(r, hi)];
+    conv96_tile<1, true>(acc, wa, xs, DB_LD, 4 + c, hi);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hA[drow(r, hi) * DB_LD + 4 + c] = inside ? acc[r] : 0.0f;
+    __syncthreads();
+    // layer 2: dil 2
+#pragma unroll
+    for (int i = 0; i < 12; ++i) wa[i] = reinterpret_cast<const float4 *>(p1)[i * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = b1[drow(r, hi)];
+    conv96_tile<2, true>(acc, wa, hA, DB_LD, 4 + c, hi);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hB[drow(r, hi) * DB_LD + 4 + c] = inside ? acc[r] : 0.0f;
+    __syncthreads();
+    // layer 3: dil 4, plus the 1x1 residual on the raw pick (residual_dense commutes with the nearest pick)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) wa[i] = reinterpret_cast<const float4 *>(p2)[i * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = b2[drow(r, hi)] + br[drow(r, hi)];
+    conv96_tile<4, true>(acc, wa, hB, DB_LD, 4 + c, hi);
+    {
+        float4 wr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wr[i] = reinterpret_cast<const float4 *>(pr)[i * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = mfma32(f4c(wr[s >> 2], s & 3), xs[(2 * s + hi) * DB_LD + 4 + c], acc);
+    }
+    if (inside && c >= 7 && c < 7 + DB_STRIDE) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[((int64_t)b * fd::C + drow(r, hi)) * Lo + p] = acc[r];
+    }
+}
+
+// =================================================================================================
+// a5 (front): KernelPredictor input conv + six 64->64 convs (modules.py:293-313,328-329) -- one launch per layer,
+// all three LVC blocks' predictors in grid.z.  M = 64 out channels (2 row tiles), N = 64 frames per workgroup.
+// =================================================================================================
+template <int CIN, int KS, bool FIRST, bool LAST>
+__global__ void __launch_bounds__(256) k_kp_conv(const float *__restrict__ in, float *__restrict__ out,
+                                                 const float *__restrict__ h0, const float *pk0, const float *pk1,
+                                                 const float *pk2, const float *bs0, const float *bs1, const float *bs2,
+                                                 const float *__restrict__ noise, const StepParams *params, int sampler,
+                                                 int B, int T)
+{
+    constexpr int PAD = (KS - 1) / 2, LD = 64 + 2 * PAD + 2, NS4 = CIN * KS / 8;
+    __shared__ float xs[CIN * LD];
+    const int blk = blockIdx.z, b = blockIdx.y, t0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const float *pk = blk == 0 ? pk0 : (blk == 1 ? pk1 : pk2);
+    const float *bs = blk == 0 ? bs0 : (blk == 1 ? bs1 : bs2);
+    const float *src = FIRST ? in + (int64_t)b * CIN * T : in + ((int64_t)blk * B + b) * CIN * T;
+    const float *nz = nullptr;
+    if (FIRST) {
+        const int step = sampler ? params->step_idx : 0;
+        nz = noise + (((int64_t)step * B + b) * fd::NBLK + blk) * fd::COND;
+    }
+    for (int idx = tid; idx < CIN * LD; idx += 256) {
+        const int ci = idx / LD, cc = idx % LD, t = t0 - PAD + cc;
+        float v = 0.0f;
+        if (t >= 0 && t < T) {
+            v = src[(int64_t)ci * T + t];
+            if (FIRST) v += nz[ci];            // condition = c + noise; the zero padding stays zero (modules.py:203)
+        }
+        xs[idx] = v;
+    }
+    __syncthreads();
+    const int mt = wave & 1, nt = wave >> 1;
+    const float4 *pa = reinterpret_cast<const float4 *>(pk) + (int64_t)mt * NS4 * 64 + lane;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bs[mt * 32 + drow(r, hi)];
+    const int col = nt * 32 + l31;
+#pragma unroll 2
+    for (int s4 = 0; s4 < NS4; ++s4) {
+        const float4 a4 = pa[s4 * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kk = 8 * s4 + 2 * r;          // even member of the pair; kk = tap*CIN + ci
+            const int tap = kk / CIN, ci = kk % CIN + hi;
+            acc = mfma32(f4c(a4, r), xs[ci * LD + col + tap], acc);
+        }
+    }
+    const int t = t0 + col;
+    if (t < T) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = mt * 32 + drow(r, hi);
+            const int64_t oi = (((int64_t)blk * B + b) * fd::HID + o) * T + t;
+            float v = lrelu(acc[r], 0.1f);
+            if (LAST) v += h0[oi];
+            out[oi] = v;
+        }
+    }
+}
+
+// =================================================================================================
+// a5 (GEMM): kernel_conv + bias_conv (modules.py:315-318,330-331) as ONE fp32-MFMA GEMM per LVC block:
+//   kpack[b][t][p] = gbias[p] + sum_{tap,c} Wp[p][tap*64+c] * h[b][c][t+tap-1],   p in [0,24832)
+// rows of the MFMA = frames (A from an LDS window of h), cols = 32 consecutive packed positions p
+// (B = weights, register-stationary: 96 VGPRs per wave, loaded once and reused for every frame tile of the
+// workgroup's chunk).  Output goes out frame-major so the LVC kernel reads a frame's record contiguously.
+// =================================================================================================
+constexpr int GEMM_LDH = 36;
+
+__global__ void __launch_bounds__(256, 2) k_kp_gemm(const float *__restrict__ h /*[3][B][64][T]*/, float *__restrict__ kpack,
+                                                    const float *g0, const float *g1, const float *g2, const float *gb0,
+                                                    const float *gb1, const float *gb2, int B, int T, int tiles_per_utt,
+                                                    int tiles_per_wg)
+{
+    __shared__ float hs[2][fd::HID * GEMM_LDH];
+    const int blk = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const float *gp = blk == 0 ? g0 : (blk == 1 ? g1 : g2);
+    const float *gb = blk == 0 ? gb0 : (blk == 1 ? gb1 : gb2);
+    const int ptile = blockIdx.x * 4 + wave, pcol = ptile * 32 + l31;
+    const int total_tiles = B * tiles_per_utt;
+    const int ft0 = blockIdx.y * tiles_per_wg;
+    const int ft1 = min(total_tiles, ft0 + tiles_per_wg);
+    if (ft0 >= ft1) return;
+    float4 wb[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) wb[i] = reinterpret_cast<const float4 *>(gp)[((int64_t)ptile * 24 + i) * 64 + lane];
+    const float bias = gb[pcol];
+    const float *hblk = h + (int64_t)blk * B * fd::HID * T;
+    float *kblk = kpack + (int64_t)blk * B * T * fd::KREC;
+
+    auto stage = [&](int ft, int buf) {
+        const int b = ft / tiles_per_utt, t0 = (ft % tiles_per_utt) * 32;
+        for (int idx = tid; idx < fd::HID * 34; idx += 256) {
+            const int c = idx / 34, cc = idx % 34, t = t0 - 1 + cc;
+            hs[buf][c * GEMM_LDH + cc] = (t >= 0 && t < T) ? hblk[((int64_t)b * fd::HID + c) * T + t] : 0.0f;
+        }
+    };
+    stage(ft0, 0);
+    __syncthreads();
+    for (int ft = ft0; ft < ft1; ++ft) {
+        const int buf = (ft - ft0) & 1;
+        if (ft + 1 < ft1) stage(ft + 1, buf ^ 1);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bias;
+        const float *hw = hs[buf] + hi * GEMM_LDH + l31;
+#pragma unroll
+        for (int s = 0; s < 96; ++s) {     // kk = 2s+hi = tap*64 + c
+            const int tap = s >> 5, c2 = (2 * s) & 63;
+            acc = mfma32(hw[c2 * GEMM_LDH + tap], f4c(wb[s >> 2], s & 3), acc);
+        }
+        const int b = ft / tiles_per_utt, t0 = (ft % tiles_per_utt) * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = t0 + drow(r, hi);
+            if (t < T) kblk[((int64_t)b * T + t) * fd::KREC + pcol] = acc[r];
+        }
+        __syncthreads();
+    }
+}
+
+// =================================================================================================
+// a6: ConvTranspose1d(32,32,2r,stride r) of leaky_relu(x,0.2) (modules.py:163-166,205-206) -- VALU v1
+// out[o, q*r+ph] = b[o] + sum_i x[i,jA]*W[i,o,kA] + x[i,jB]*W[i,o,kB]
+// =================================================================================================
+template <int R>
+__global__ void __launch_bounds__(256) k_convt(const float *__restrict__ xin, const float *__restrict__ w,
+                                               const float *__restrict__ bias, float *__restrict__ out, int Lin)
+{
+    constexpr int Q = 256 / R;                 // input positions per workgroup
+    __shared__ float ws[fd::C * fd::C * 2 * R];
+    __shared__ float xs[fd::C * (Q + 2)];
+    const int b = blockIdx.y, tid = threadIdx.x, q0 = blockIdx.x * Q, Lout = Lin * R;
+    for (int idx = tid; idx < fd::C * fd::C * 2 * R; idx += 256) ws[idx] = w[idx];
+    for (int idx = tid; idx < fd::C * (Q + 2); idx += 256) {
+        const int ci = idx / (Q + 2), jj = idx % (Q + 2), j = q0 - 1 + jj;
+        float v = 0.0f;
+        if (j >= 0 && j < Lin) v = lrelu(xin[((int64_t)b * fd::C + ci) * Lin + j], 0.2f);
+        xs[idx] = v;
+    }
+    __syncthreads();
+    const int t = q0 * R + tid;
+    if (t >= Lout) return;
+    const int p = R / 2;
+    const int jA = (t + p) / R, kA = t + p - jA * R, jB = jA - 1, kB = kA + R;   // kA in [0,R), kB in [R,2R)
+    const int ja = jA - (q0 - 1), jb = jB - (q0 - 1);
+    float acc[fd::C];
+#pragma unroll
+    for (int o = 0; o < fd::C; ++o) acc[o] = bias[o];
+    for (int i = 0; i < fd::C; ++i) {
+        const float xa = xs[i * (Q + 2) + ja], xb = xs[i * (Q + 2) + jb];
+        const float *wi = ws + i * fd::C * 2 * R;
+#pragma unroll
+        for (int o = 0; o < fd::C; ++o) acc[o] += xa * wi[o * 2 * R + kA] + xb * wi[o * 2 * R + kB];
+    }
+#pragma unroll
+    for (int o = 0; o < fd::C; ++o) out[((int64_t)b * fd::C + o) * Lout + t] = acc[o];
+}
+
+// =================================================================================================
+// a7+a8+a9: one whole LVC layer (modules.py:208-217), fused:
+//   x' = x + skip ; y = lrelu(conv_{k3,dil}(lrelu(x'))) ; z = LVC(y; K_f, bias_f) ; out = x' + sigmoid(z[:32])*tanh(z[32:])
+// HBM traffic is the algorithmic minimum of the layer: read x, skip, the frame's predicted kernel; write out.
+// Workgroup = 4 waves x WC columns.  Each wave: dilated conv on its WC columns + the 2 halo columns the
+// LVC taps need (one extra MFMA tile), y kept wave-private in LDS, then
+//   HOP >= 64: LVC on the matrix pipe, A = the frame's 64x96 predicted kernel (96 VGPRs), 2 row tiles share B
+//   HOP == 8 : LVC on VALU, lane = output channel (a 32-column MFMA tile would straddle 4 different kernels)
+// =================================================================================================
+template <int HOP, int DIL>
+struct LvcCfg {
+    static constexpr int WC = (HOP == 8) ? 32 : 64;            // columns per wave
+    static constexpr int W = 4 * WC;                            // columns per workgroup
+    static constexpr int H = (DIL + 1 + 3) & ~3;                // staged halo (multiple of 4 for 16 B loads)
+    static constexpr int XLD = W + 2 * H;
+    static constexpr int YLD = WC + 4;                          // y columns -1 .. WC, padded
+};
+
+template <int HOP, int DIL>
+__global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ xin, const float *__restrict__ skip,
+                                                      float *__restrict__ xout, const float *__restrict__ kpack, int layer,
+                                                      const float *__restrict__ wpack, const float *__restrict__ cbias,
+                                                      int T)
+{
+    using Cfg = LvcCfg<HOP, DIL>;
+    constexpr int WC = Cfg::WC, W = Cfg::W, H = Cfg::H, XLD = Cfg::XLD, YLD = Cfg::YLD;
+    __shared__ __attribute__((aligned(16))) float xs[fd::C * XLD];
+    __shared__ __attribute__((aligned(16))) float ys[4][fd::C * YLD];
+    const int Ln = T * HOP;
+    const int b = blockIdx.y, w0 = blockIdx.x * W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int cw = wave * WC;                       // first column of this wave inside the tile
+    const bool wave_valid = (w0 + cw) < Ln;         // hop>=64: a wave owns whole frames; hop 8: checked per frame below
+
+    // ---- stage x' = x + skip with halo, zero outside the signal --------------------------------------
+    {
+        const float *xr = xin + (int64_t)b * fd::C * Ln, *sr = skip + (int64_t)b * fd::C * Ln;
+        for (int idx = tid; idx < fd::C * (XLD / 4); idx += 256) {
+            const int ci = idx / (XLD / 4), c4 = idx % (XLD / 4), g = w0 - H + 4 * c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g >= 0 && g < Ln) {
+                const float4 a = *reinterpret_cast<const float4 *>(xr + (int64_t)ci * Ln + g);
+                const float4 s = *reinterpret_cast<const float4 *>(sr + (int64_t)ci * Ln + g);
+                v = make_float4(a.x + s.x, a.y + s.y, a.z + s.z, a.w + s.w);
+            }
+            *reinterpret_cast<float4 *>(xs + ci * XLD + 4 * c4) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- dilated conv on the matrix pipe: y columns cw-1 .. cw+WC ---------------------------------------
+    float *yw = ys[wave];
+    if (wave_valid) {
+        float4 wa[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) wa[i] = reinterpret_cast<const float4 *>(wpack)[i * 64 + lane];
+        float cb[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cb[r] = cbias[drow(r, hi)];
+        constexpr int NT = WC / 32;
+#pragma unroll
+        for (int ct = 0; ct <= NT; ++ct) {
+            // tile ct < NT: columns ct*32 + l31 ; halo tile: lane 0 -> column -1, lane 1 -> column WC, others idle on column 0
+            int c;
+            bool store;
+            if (ct < NT) { c = ct * 32 + l31; store = true; }
+            else { c = (l31 == 0) ? -1 : ((l31 == 1) ? WC : 0); store = (l31 < 2); }
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = cb[r];
+            conv96_tile<DIL, true>(acc, wa, xs, XLD, H + cw + c, hi);
+            const int g = w0 + cw + c;
+            const bool inside = (g >= 0 && g < Ln);             // y is zero-padded for the LVC taps (modules.py:240)
+            if (store) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yw[drow(r, hi) * YLD + c + 1] = inside ? lrelu(acc[r], 0.2f) : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+    if (!wave_valid) return;
+
+    const int64_t orow = (int64_t)b * fd::C * Ln;
+    if constexpr (HOP >= 64) {
+        // ---- LVC on the matrix pipe ----------------------------------------------------------------------
+        const int f = (w0 + cw) / HOP;
+        const float *rec = kpack + ((int64_t)b * T + f) * fd::KREC;
+        const float4 *kp4 = reinterpret_cast<const float4 *>(rec + layer * fd::KLAYER) + lane;
+        float4 ka0[12], ka1[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { ka0[i] = kp4[i * 64]; ka1[i] = kp4[(12 + i) * 64]; }
+        const float *kb = rec + fd::KW + layer * 64;
+        float bz0[16], bz1[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { bz0[r] = kb[drow(r, hi)]; bz1[r] = kb[32 + drow(r, hi)]; }
+#pragma unroll
+        for (int nt = 0; nt < WC / 32; ++nt) {
+            f32x16 a0, a1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { a0[r] = bz0[r]; a1[r] = bz1[r]; }
+            const float *yb = yw + hi * YLD + nt * 32 + l31;     // y index = column + 1 + (tap - 1)
+#pragma unroll
+            for (int s = 0; s < 48; ++s) {
+                const int tap = s >> 4, c2 = (2 * s) & 31;
+                const float v = yb[c2 * YLD + tap];
+                a0 = mfma32(f4c(ka0[s >> 2], s & 3), v, a0);
+                a1 = mfma32(f4c(ka1[s >> 2], s & 3), v, a1);
+            }
+            const int c = cw + nt * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = drow(r, hi);
+                const float xr = xs[ch * XLD + H + c];
+                xout[orow + (int64_t)ch * Ln + w0 + c] = xr + fast_sigmoid(a0[r]) * fast_tanh(a1[r]);
+            }
+        }
+    } else {
+        // ---- LVC on VALU (hop 8): lane = output channel, 4 frames of 8 columns per wave -----------------------
+        const int mt = lane >> 5;
+#pragma unroll 1
+        for (int fi = 0; fi < WC / HOP; ++fi) {
+            const int f = (w0 + cw) / HOP + fi;
+            if (f >= T) break;                 // T need not be a multiple of 4: the last wave may own fewer frames
+            const float *rec = kpack + ((int64_t)b * T + f) * fd::KREC;
+            const float4 *kp4 = reinterpret_cast<const float4 *>(rec + layer * fd::KLAYER) + (int64_t)mt * 12 * 64 + l31;
+            float4 ke[12], ko[12];   // even / odd kk of this lane's output row
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { ke[i] = kp4[i * 64]; ko[i] = kp4[i * 64 + 32]; }
+            float z[8];
+            const float bz = rec[fd::KW + layer * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) z[c] = bz;
+#pragma unroll
+            for (int in = 0; in < fd::C; ++in) {
+                // y window of input channel `in`: wave-relative columns fi*8-1 .. fi*8+8  -> y index fi*8 .. fi*8+9
+                const float *yr = yw + in * YLD + fi * 8;
+                const float4 y0 = *reinterpret_cast<const float4 *>(yr);
+                const float4 y1 = *reinterpret_cast<const float4 *>(yr + 4);
+                const float2 y2 = *reinterpret_cast<const float2 *>(yr + 8);
+                const float yv[10] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w, y2.x, y2.y};
+#pragma unroll
+                for (int tap = 0; tap < 3; ++tap) {
+                    const int kk = tap * 32 + in, step = kk >> 1;
+                    const float kv = (kk & 1) ? f4c(ko[step >> 2], step & 3) : f4c(ke[step >> 2], step & 3);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) z[c] += kv * yv[c + tap];
+                }
+            }
+            // gate: sigmoid half lives in lanes 0..31, tanh half in lanes 32..63
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float zt = __shfl_down(z[c], 32, 64);
+                z[c] = fast_sigmoid(z[c]) * fast_tanh(zt);
+            }
+            if (lane < 32) {
+                const int c0 = cw + fi * 8;
+                float *dst = xout + orow + (int64_t)lane * Ln + w0 + c0;
+                const float *xr = xs + lane * XLD + H + c0;
+                const float4 o0 = make_float4(xr[0] + z[0], xr[1] + z[1], xr[2] + z[2], xr[3] + z[3]);
+                const float4 o1 = make_float4(xr[4] + z[4], xr[5] + z[5], xr[6] + z[6], xr[7] + z[7]);
+                *reinterpret_cast<float4 *>(dst) = o0;
+                *reinterpret_cast<float4 *>(dst + 4) = o1;
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// a10 + sampler: final_conv Conv1d(32,1,k7) (FastDiff_model.py:67-68,100) with the reverse-step update
+// (util.py:219-229) fused into its epilogue.  VALU; each thread produces 4 consecutive samples.
+// =================================================================================================
+__global__ void __launch_bounds__(256) k_final(const float *__restrict__ x32, const float *__restrict__ w,
+                                               const float *__restrict__ bias, float *__restrict__ eps_out,
+                                               float *__restrict__ xstate, const StepParams *params, int sampler, int L,
+                                               int64_t n4_total)
+{
+    const int b = blockIdx.y;
+    const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (t0 >= L) return;
+    const float bv = bias[0];
+    float4 acc = make_float4(bv, bv, bv, bv);
+    for (int ci = 0; ci < fd::C; ++ci) {
+        const float *xr = x32 + ((int64_t)b * fd::C + ci) * L;
+        float v[12];
+        const float4 m = *reinterpret_cast<const float4 *>(xr + t0);
+        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi4 = lo;
+        if (t0 >= 4) lo = *reinterpret_cast<const float4 *>(xr + t0 - 4);
+        if (t0 + 4 < L) hi4 = *reinterpret_cast<const float4 *>(xr + t0 + 4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = m.x; v[5] = m.y; v[6] = m.z; v[7] = m.w;
+        v[8] = hi4.x; v[9] = hi4.y; v[10] = hi4.z; v[11] = hi4.w;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const float wv = w[ci * 7 + k];       // tap k reads x[t + k - 3] = v[(t - t0) + k + 1]
+            acc.x += wv * v[k + 1]; acc.y += wv * v[k + 2]; acc.z += wv * v[k + 3]; acc.w += wv * v[k + 4];
+        }
+    }
+    const int64_t i4 = ((int64_t)b * L + t0) >> 2;
+    if (!sampler) {
+        reinterpret_cast<float4 *>(eps_out)[i4] = acc;
+    } else {
+        const float4 xv = reinterpret_cast<const float4 *>(xstate)[i4];
+        reinterpret_cast<float4 *>(xstate)[i4] = fdk::sampler_update4(xv, acc, params, i4, n4_total);
+    }
+}
+
+}  // namespace fdk_fast
+
+// ------------------------------------------------------------------------------------------------
+// stage drivers (fast mode)
+// ------------------------------------------------------------------------------------------------
+namespace fdk {
+using namespace fdk_fast;
+
+hipError_t fast_first_conv(const Launch &L, const StepIO &io, int B, int T)
+{
+    const DevWeights &w = L.ctx->w;
+    const int Lf = T * fd::HOPT;
+    FD_LAUNCH(L, "first_conv", k_first_conv, dim3((Lf + 1023) / 1024, B), dim3(256), 0, io.x_in, w.first.w, w.first.b,
+              L.ctx->ws.a[0], Lf);
+    return hipSuccess;
+}
+
+hipError_t fast_dblock(const Launch &L, int d, int B, int T)
+{
+    fd_context *c = L.ctx;
+    const DevWeights &w = c->w;
+    int Lin = T * fd::HOPT;
+    for (int i = 0; i < d; ++i) Lin /= fd::down_factor(i);
+    const int f = fd::down_factor(d), Lo = Lin / f;
+    const dim3 grid((Lo + DB_STRIDE - 1) / DB_STRIDE, B);
+    if (f == 4)
+        FD_LAUNCH(L, "dblock_f4", k_dblock<4>, grid, dim3(256), 0, c->ws.a[d], c->ws.a[d + 1], w.down_pack[d][0], w.down_pack[d][1],
+                  w.down_pack[d][2], w.down_pack[d][3], w.down[d].conv[0].b, w.down[d].conv[1].b, w.down[d].conv[2].b,
+                  w.down[d].res.b, Lin, Lo);
+    else
+        FD_LAUNCH(L, "dblock_f8", k_dblock<8>, grid, dim3(256), 0, c->ws.a[d], c->ws.a[d + 1], w.down_pack[d][0], w.down_pack[d][1],
+                  w.down_pack[d][2], w.down_pack[d][3], w.down[d].conv[0].b, w.down[d].conv[1].b, w.down[d].conv[2].b,
+                  w.down[d].res.b, Lin, Lo);
+    return hipSuccess;
+}
+
+hipError_t fast_kp_front(const Launch &L, const StepIO &io, int B, int T)
+{
+    fd_context *c = L.ctx;
+    const DevWeights &w = c->w;
+    const dim3 grid((T + 63) / 64, B, fd::NBLK);
+    Workspace &ws = c->ws;
+    FD_LAUNCH(L, "kp_in_conv", (k_kp_conv<fd::COND, 5, true, false>), grid, dim3(256), 0, io.mel, ws.kp_h0, (const float *)nullptr,
+              w.kp_in_pack[0], w.kp_in_pack[1], w.kp_in_pack[2], w.blk[0].kp_in.b, w.blk[1].kp_in.b, w.blk[2].kp_in.b,
+              (const float *)ws.noise, (const StepParams *)ws.params, io.sampler, B, T);
+    const float *in = ws.kp_h0;
+    for (int l = 0; l < 6; ++l) {   // h0 -> A -> B -> A -> B -> A -> B(+h0)
+        float *out = (l & 1) ? ws.kp_hB : ws.kp_hA;
+        if (l < 5)
+            FD_LAUNCH(L, "kp_res_conv", (k_kp_conv<fd::HID, 3, false, false>), grid, dim3(256), 0, in, out, (const float *)nullptr,
+                      w.kp_res_pack[0][l], w.kp_res_pack[1][l], w.kp_res_pack[2][l], w.blk[0].kp_res[l].b, w.blk[1].kp_res[l].b,
+                      w.blk[2].kp_res[l].b, (const float *)nullptr, (const StepParams *)nullptr, 0, B, T);
+        else
+            FD_LAUNCH(L, "kp_res_conv", (k_kp_conv<fd::HID, 3, false, true>), grid, dim3(256), 0, in, out, (const float *)ws.kp_h0,
+                      w.kp_res_pack[0][l], w.kp_res_pack[1][l], w.kp_res_pack[2][l], w.blk[0].kp_res[l].b, w.blk[1].kp_res[l].b,
+                      w.blk[2].kp_res[l].b, (const float *)nullptr, (const StepParams *)nullptr, 0, B, T);
+        in = out;
+    }
+    return hipSuccess;
+}
+
+hipError_t fast_kp_gemm(const Launch &L, int B, int T)
+{
+    fd_context *c = L.ctx;
+    const DevWeights &w = c->w;
+    const int tiles_per_utt = (T + 31) / 32, total = B * tiles_per_utt;
+    const int tiles_per_wg = total < 16 ? total : 16;
+    const dim3 grid(fd::KREC / 128, (total + tiles_per_wg - 1) / tiles_per_wg, fd::NBLK);
+    FD_LAUNCH(L, "kp_gemm", k_kp_gemm, grid, dim3(256), 0, (const float *)c->ws.kp_hB, c->ws.kpack, w.gemm_pack[0], w.gemm_pack[1],
+              w.gemm_pack[2], w.gemm_bias[0], w.gemm_bias[1], w.gemm_bias[2], B, T, tiles_per_utt, tiles_per_wg);
+    return hipSuccess;
+}
+
+hipError_t fast_convt(const Launch &L, int n, const float *x_in, float *x_out, int B, int Lin)
+{
+    const DevWeights &w = L.ctx->w;
+    if (fd::ratio(n) == 8)
+        FD_LAUNCH(L, "convt_r8", k_convt<8>, dim3((Lin + 31) / 32, B), dim3(256), 0, x_in, w.blk[n].up.w, w.blk[n].up.b, x_out, Lin);
+    else
+        FD_LAUNCH(L, "convt_r4", k_convt<4>, dim3((Lin + 63) / 64, B), dim3(256), 0, x_in, w.blk[n].up.w, w.blk[n].up.b, x_out, Lin);
+    return hipSuccess;
+}
+
+template <int HOP, int DIL>
+static hipError_t launch_lvc(const Launch &L, const char *name, int n, int layer, const float *x_in, const float *skip, float *x_out,
+                             int B, int T)
+{
+    fd_context *c = L.ctx;
+    const DevWeights &w = c->w;
+    constexpr int W = LvcCfg<HOP, DIL>::W;
+    const int Ln = T * HOP;
+    const float *kp = c->ws.kpack + (int64_t)n * B * T * fd::KREC;
+    FD_LAUNCH(L, name, (k_lvc_layer<HOP, DIL>), dim3((Ln + W - 1) / W, B), dim3(256), 0, x_in, skip, x_out, kp, layer,
+              w.lvc_conv_pack[n][layer], w.blk[n].convs[layer].b, T);
+    return hipSuccess;
+}
+
+hipError_t fast_lvc_layer(const Launch &L, int n, int layer, const float *x_in, const float *skip, float *x_out, int B, int T)
+{
+#define FD_LVC_CASE(HOP_, NAME_)                                                                                    \
+    switch (layer) {                                                                                                \
+    case 0: return launch_lvc<HOP_, 1>(L, NAME_ "_d1", n, layer, x_in, skip, x_out, B, T);                           \
+    case 1: return launch_lvc<HOP_, 3>(L, NAME_ "_d3", n, layer, x_in, skip, x_out, B, T);                           \
+    case 2: return launch_lvc<HOP_, 9>(L, NAME_ "_d9", n, layer, x_in, skip, x_out, B, T);                           \
+    default: return launch_lvc<HOP_, 27>(L, NAME_ "_d27", n, layer, x_in, skip, x_out, B, T);                        \
+    }
+    if (n == 0) { FD_LVC_CASE(8, "lvc_layer_h8") }
+    if (n == 1) { FD_LVC_CASE(64, "lvc_layer_h64") }
+    FD_LVC_CASE(256, "lvc_layer_h256")
+#undef FD_LVC_CASE
+}
+
+hipError_t fast_final(const Launch &L, const StepIO &io, const float *x32, int B, int T)
+{
+    fd_context *c = L.ctx;
+    const DevWeights &w = c->w;
+    const int Lf = T * fd::HOPT;
+    FD_LAUNCH(L, "final_conv_update", k_final, dim3((Lf + 1023) / 1024, B), dim3(256), 0, x32, w.final_.w, w.final_.b, io.eps_out,
+              c->ws.x, (const StepParams *)c->ws.params, io.sampler, Lf, (int64_t)B * Lf / 4);
+    return hipSuccess;
+}
+
+}  // namespace fdk

@@ -1,0 +1,309 @@
+"""Host-side mirror of the reference denoiser module, backed by libfastdiff_hip.so.
+
+`FastDiff` keeps the reference's constructor signature, parameter names / shapes / registration order
+(so `state_dict()`, `load_state_dict(ckpt['state_dict']['model'])`, `.cuda()`, `.eval()` behave as for
+modules/FastDiff/module/FastDiff_model.py:10-122) and the `forward(data)` contract
+(FastDiff_model.py:74-102).  The torch.nn sub-modules below are parameter holders only: no
+PyTorch op runs on the compute path -- forward() hands raw device pointers to the C ABI
+(include/fastdiff_hip.h).  There is no CPU fallback: without the HIP library or a HIP device it raises.
+"""
+import ctypes as ct
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _capi
+
+
+class _DBlockParams(nn.Module):
+    """Parameters of DiffusionDBlock (modules.py:116-125)."""
+
+    def __init__(self, input_size, hidden_size, factor):
+        super().__init__()
+        self.factor = factor
+        self.residual_dense = nn.Conv1d(input_size, hidden_size, 1)
+        self.conv = nn.ModuleList([
+            nn.Conv1d(input_size, hidden_size, 3, dilation=1, padding=1),
+            nn.Conv1d(hidden_size, hidden_size, 3, dilation=2, padding=2),
+            nn.Conv1d(hidden_size, hidden_size, 3, dilation=4, padding=4),
+        ])
+
+
+class _KernelPredictorParams(nn.Module):
+    """Parameters of KernelPredictor (modules.py:257-318)."""
+
+    def __init__(self, cond_channels, conv_in_channels, conv_out_channels, conv_layers, conv_kernel_size,
+                 hidden, kp_conv_size, dropout):
+        super().__init__()
+        l_w = conv_in_channels * conv_out_channels * conv_kernel_size * conv_layers
+        l_b = conv_out_channels * conv_layers
+        pad = (kp_conv_size - 1) // 2
+        act = lambda: nn.LeakyReLU(negative_slope=0.1)  # noqa: E731
+        self.input_conv = nn.Sequential(nn.Conv1d(cond_channels, hidden, 5, padding=2, bias=True), act())
+        layers = []
+        for _ in range(3):
+            layers += [nn.Dropout(dropout),
+                       nn.Conv1d(hidden, hidden, kp_conv_size, padding=pad, bias=True), act(),
+                       nn.Conv1d(hidden, hidden, kp_conv_size, padding=pad, bias=True), act()]
+        self.residual_conv = nn.Sequential(*layers)
+        self.kernel_conv = nn.Conv1d(hidden, l_w, kp_conv_size, padding=pad, bias=True)
+        self.bias_conv = nn.Conv1d(hidden, l_b, kp_conv_size, padding=pad, bias=True)
+
+
+class _LVCBlockParams(nn.Module):
+    """Parameters of TimeAware_LVCBlock (modules.py:141-187), registered and constructed in the reference's order."""
+
+    def __init__(self, in_channels, cond_channels, upsample_ratio, conv_layers, conv_kernel_size, cond_hop_length,
+                 kpnet_hidden_channels, kpnet_conv_size, kpnet_dropout, noise_scale_embed_dim_out):
+        super().__init__()
+        self.cond_hop_length = cond_hop_length
+        self.convs = nn.ModuleList()
+        r = upsample_ratio
+        self.upsample = nn.ConvTranspose1d(in_channels, in_channels, kernel_size=2 * r, stride=r,
+                                           padding=r // 2 + r % 2, output_padding=r % 2)
+        self.kernel_predictor = _KernelPredictorParams(cond_channels, in_channels, 2 * in_channels, conv_layers,
+                                                       conv_kernel_size, kpnet_hidden_channels, kpnet_conv_size,
+                                                       kpnet_dropout)
+        self.fc_t = nn.Linear(noise_scale_embed_dim_out, cond_channels)
+        for i in range(conv_layers):
+            pad = (3 ** i) * int((conv_kernel_size - 1) / 2)
+            self.convs.append(nn.Conv1d(in_channels, in_channels, kernel_size=conv_kernel_size, padding=pad,
+                                        dilation=3 ** i))
+
+
+class FastDiff(nn.Module):
+    """Drop-in for `modules.FastDiff.module.FastDiff_model.FastDiff` on an MI355X."""
+
+    def __init__(self, audio_channels=1, inner_channels=32, cond_channels=80, upsample_ratios=[8, 8, 4],
+                 lvc_layers_each_block=4, lvc_kernel_size=3, kpnet_hidden_channels=64, kpnet_conv_size=3,
+                 dropout=0.0, diffusion_step_embed_dim_in=128, diffusion_step_embed_dim_mid=512,
+                 diffusion_step_embed_dim_out=512, use_weight_norm=True):
+        super().__init__()
+        if dropout != 0.0:
+            raise NotImplementedError("fastdiff_amd is the inference path: dropout must be 0.0 (base.yaml:29)")
+        self.diffusion_step_embed_dim_in = diffusion_step_embed_dim_in
+        self.audio_channels = audio_channels
+        self.cond_channels = cond_channels
+        self.lvc_block_nums = len(upsample_ratios)
+        self._cfg = dict(audio_channels=audio_channels, inner_channels=inner_channels, cond_channels=cond_channels,
+                         upsample_ratios=list(upsample_ratios), lvc_layers_each_block=lvc_layers_each_block,
+                         lvc_kernel_size=lvc_kernel_size, kpnet_hidden_channels=kpnet_hidden_channels,
+                         kpnet_conv_size=kpnet_conv_size, diffusion_step_embed_dim_in=diffusion_step_embed_dim_in,
+                         diffusion_step_embed_dim_mid=diffusion_step_embed_dim_mid,
+                         diffusion_step_embed_dim_out=diffusion_step_embed_dim_out, use_weight_norm=use_weight_norm)
+        self.hop_length = int(np.prod(upsample_ratios))
+
+        self.first_audio_conv = nn.Conv1d(1, inner_channels, kernel_size=7, padding=3, dilation=1, bias=True)
+        self.lvc_blocks = nn.ModuleList()
+        self.downsample = nn.ModuleList()
+        self.fc_t = nn.ModuleList()
+        self.fc_t1 = nn.Linear(diffusion_step_embed_dim_in, diffusion_step_embed_dim_mid)
+        self.fc_t2 = nn.Linear(diffusion_step_embed_dim_mid, diffusion_step_embed_dim_out)
+        hop = 1
+        for n in range(self.lvc_block_nums):
+            hop *= upsample_ratios[n]
+            self.lvc_blocks.append(_LVCBlockParams(inner_channels, cond_channels, upsample_ratios[n],
+                                                   lvc_layers_each_block, lvc_kernel_size, hop, kpnet_hidden_channels,
+                                                   kpnet_conv_size, dropout, diffusion_step_embed_dim_out))
+            self.downsample.append(_DBlockParams(inner_channels, inner_channels,
+                                                 upsample_ratios[self.lvc_block_nums - n - 1]))
+        self.final_conv = nn.Sequential(nn.Conv1d(inner_channels, audio_channels, kernel_size=7, padding=3,
+                                                  dilation=1, bias=True))
+        if use_weight_norm:
+            self.apply_weight_norm()
+        # HIP side
+        self._handle = None
+        self._handle_device = None
+        self._synced_state = None
+        self._options = {}
+
+    # ---- reference API --------------------------------------------------------------------------------
+    def apply_weight_norm(self):
+        def _apply(m):
+            if isinstance(m, (nn.Conv1d, nn.Conv2d)):
+                torch.nn.utils.weight_norm(m)
+        self.apply(_apply)
+
+    def remove_weight_norm(self):
+        def _remove(m):
+            try:
+                torch.nn.utils.remove_weight_norm(m)
+            except ValueError:
+                return
+        self.apply(_remove)
+
+    def forward(self, data):
+        """eps = net((audio [B,1,L], c [B,80,T] or [80,T], diffusion_steps [B,1])) -- FastDiff_model.py:74-102."""
+        audio, c, diffusion_steps = data
+        self._require_inference(audio, c)
+        audio = audio.contiguous().float()
+        B, ch, L = audio.shape
+        c = self._prep_condition(c, B, audio.device)
+        T = c.shape[-1]
+        # the reference's check is `in_length == kernel_length * hop_size` (modules.py:236)
+        assert ch == 1 and L == T * self.hop_length, "length of (x, kernel) is not matched"
+        steps = diffusion_steps.to(device=audio.device, dtype=torch.float32).reshape(-1).contiguous()
+        assert steps.numel() == B
+        out = torch.empty_like(audio)
+        lib, h = self._ready(audio.device)
+        rc = lib.fd_forward(h, audio.data_ptr(), c.data_ptr(), steps.data_ptr(), B, T, None, out.data_ptr(),
+                            self._stream(audio.device))
+        _capi.check(lib, h, rc, "fd_forward")
+        return out
+
+    # ---- HIP-side entry used by fastdiff_amd.util.sampling_given_noise_schedule ---------------------------
+    def sample(self, condition, table, ddim=False, x_T=None, noise=None, seed=0, return_sequence=False):
+        """Run the N-step reverse loop on the device.
+
+        table: list of dicts with keys t, c_eps, c_div, sigma, c1, c2, c3, add_noise (executed first -> last).
+        x_T [B,1,L] / noise [N,B,1,L] optional device tensors (None -> on-device Philox keyed by `seed`)."""
+        B = condition.shape[0]
+        self._require_inference(condition, condition)
+        condition = condition.contiguous().float()
+        T = condition.shape[-1]
+        L = T * self.hop_length
+        N = len(table)
+        steps = (_capi.FdStep * N)()
+        for k, row in enumerate(table):
+            steps[k] = _capi.FdStep(float(row["t"]), float(row["c_eps"]), float(row["c_div"]), float(row["sigma"]),
+                                    float(row["c1"]), float(row["c2"]), float(row["c3"]), int(row["add_noise"]))
+        dev = condition.device
+        out = torch.empty((B, 1, L), device=dev, dtype=torch.float32)
+        seq = torch.empty((N + 1, B, 1, L), device=dev, dtype=torch.float32) if return_sequence else None
+        if x_T is not None:
+            x_T = x_T.to(device=dev, dtype=torch.float32).contiguous()
+            assert tuple(x_T.shape) == (B, 1, L)
+        if noise is not None:
+            noise = noise.to(device=dev, dtype=torch.float32).contiguous()
+            assert tuple(noise.shape) == (N, B, 1, L)
+        lib, h = self._ready(dev)
+        rc = lib.fd_sample(h, condition.data_ptr(), B, T, None, steps, N, int(bool(ddim)),
+                           None if x_T is None else x_T.data_ptr(), None if noise is None else noise.data_ptr(),
+                           ct.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), out.data_ptr(),
+                           None if seq is None else seq.data_ptr(), self._stream(dev))
+        _capi.check(lib, h, rc, "fd_sample")
+        if return_sequence:
+            return [seq[k] for k in range(N + 1)]
+        return out
+
+    def peak_normalize_int16(self, wav):
+        """wav [B,1,L] float32 -> int16 PCM [B,L]: wav/abs(wav).max() * 32767 (FastDiff.py:110; utils/audio.py:11-16)."""
+        self._require_inference(wav, wav)
+        wav = wav.contiguous().float()
+        B = wav.shape[0]
+        L = wav.numel() // B
+        pcm = torch.empty((B, L), device=wav.device, dtype=torch.int16)
+        lib, h = self._ready(wav.device)
+        rc = lib.fd_peak_normalize_int16(h, wav.data_ptr(), B, L, pcm.data_ptr(), self._stream(wav.device))
+        _capi.check(lib, h, rc, "fd_peak_normalize_int16")
+        return pcm
+
+    # ---- options / introspection (tests, bench) ---------------------------------------------------------
+    def set_option(self, key, value):
+        self._options[key] = str(value)
+        if self._handle is not None:
+            lib = _capi.load()
+            _capi.check(lib, self._handle, lib.fd_set_option(self._handle, key.encode(), str(value).encode()), "fd_set_option")
+
+    def read_tap(self, name):
+        lib = _capi.load()
+        n = lib.fd_read_tap(self._handle, name.encode(), None, 0)
+        _capi.check(lib, self._handle, n, "fd_read_tap")
+        buf = np.empty(n, np.float32)
+        _capi.check(lib, self._handle, lib.fd_read_tap(self._handle, name.encode(), buf.ctypes.data, n), "fd_read_tap")
+        return buf
+
+    def profile(self, reset=False):
+        lib = _capi.load()
+        stats = (_capi.FdKernelStat * 128)()
+        n = lib.fd_get_profile(self._handle, stats, 128)
+        res = {stats[i].name.decode(): (int(stats[i].launches), float(stats[i].total_ms)) for i in range(min(n, 128))}
+        if reset:
+            lib.fd_reset_profile(self._handle)
+        return res
+
+    @staticmethod
+    def kernel_index(layer, in_ch, out_ch, tap):
+        return _capi.load().fd_kernel_index(layer, in_ch, out_ch, tap)
+
+    # ---- internals ----------------------------------------------------------------------------------------
+    def _require_inference(self, *tensors):
+        for t in tensors:
+            if not t.is_cuda:
+                raise RuntimeError("fastdiff_amd.FastDiff runs only on a HIP device (no CPU fallback): move the module "
+                                   "and its inputs to cuda")
+        if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+            raise NotImplementedError("fastdiff_amd implements the inference path only; training "
+                                      "(theta_timestep_loss, util.py:291-325) stays on the PyTorch module")
+
+    def _prep_condition(self, c, B, device):
+        c = c.to(device=device, dtype=torch.float32)
+        if c.dim() == 2:                      # egs/demo.ipynb feeds [80,T]; the reference broadcasts it (modules.py:203)
+            c = c.unsqueeze(0)
+        if c.shape[0] != B:
+            c = c.expand(B, -1, -1)
+        assert c.shape[1] == self.cond_channels
+        return c.contiguous()
+
+    @staticmethod
+    def _stream(device):
+        return ct.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+    def _state_signature(self):
+        return tuple((k, v.data_ptr(), v._version) for k, v in self.state_dict(keep_vars=True).items())
+
+    def _ready(self, device):
+        """Create the context on `device` if needed and (re)upload weights when any parameter changed."""
+        lib = _capi.load()
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if self._handle is None or self._handle_device != idx:
+            self._release()
+            cfg = _capi.FdConfig()
+            lib.fd_default_config(ct.byref(cfg))
+            c = self._cfg
+            if len(c["upsample_ratios"]) > 8:
+                raise NotImplementedError("at most 8 upsample stages")
+            cfg.audio_channels, cfg.inner_channels, cfg.cond_channels = c["audio_channels"], c["inner_channels"], c["cond_channels"]
+            cfg.n_upsample = len(c["upsample_ratios"])
+            for i in range(8):
+                cfg.upsample_ratios[i] = c["upsample_ratios"][i] if i < cfg.n_upsample else 0
+            cfg.lvc_layers_each_block, cfg.lvc_kernel_size = c["lvc_layers_each_block"], c["lvc_kernel_size"]
+            cfg.kpnet_hidden_channels, cfg.kpnet_conv_size = c["kpnet_hidden_channels"], c["kpnet_conv_size"]
+            cfg.diffusion_step_embed_dim_in = c["diffusion_step_embed_dim_in"]
+            cfg.diffusion_step_embed_dim_mid = c["diffusion_step_embed_dim_mid"]
+            cfg.diffusion_step_embed_dim_out = c["diffusion_step_embed_dim_out"]
+            cfg.use_weight_norm = int(bool(c["use_weight_norm"]))
+            h = ct.c_void_p()
+            rc = lib.fd_create(ct.byref(cfg), idx, ct.byref(h))
+            _capi.check(lib, None, rc, "fd_create")
+            self._handle, self._handle_device, self._synced_state = h, idx, None
+            for k, v in self._options.items():
+                _capi.check(lib, h, lib.fd_set_option(h, k.encode(), v.encode()), "fd_set_option")
+        sig = self._state_signature()
+        if sig != self._synced_state:
+            self._upload_weights(lib)
+            self._synced_state = sig
+        return lib, self._handle
+
+    def _upload_weights(self, lib):
+        h = self._handle
+        for name, t in self.state_dict().items():
+            a = np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
+            dims = (ct.c_int64 * a.ndim)(*a.shape)
+            rc = lib.fd_set_weight(h, name.encode(), a.ctypes.data, dims, a.ndim)
+            _capi.check(lib, h, rc, f"fd_set_weight({name})")
+        _capi.check(lib, h, lib.fd_commit_weights(h), "fd_commit_weights")
+
+    def _release(self):
+        if self._handle is not None:
+            try:
+                _capi.load().fd_destroy(self._handle)
+            finally:
+                self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass

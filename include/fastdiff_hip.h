@@ -1,0 +1,149 @@
+/*
+ * fastdiff_hip.h -- C ABI of libfastdiff_hip.so: the MI355X (gfx950) FastDiff vocoder inference path.
+ *
+ * This is the drop-in boundary under the reference's Python API.  Every entry point names the
+ * reference interface it replaces (path:line in Rongjiehuang/FastDiff).  Plain pointers and sizes
+ * only; no torch types.  All tensors are float32, contiguous, [batch][channel][time] with time
+ * innermost -- the reference's own layout.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative fd_status on failure; fd_last_error() gives text.
+ *   - a handle is bound to one device and is NOT thread safe (one handle per GPU/stream, like one
+ *     reference process per GPU under mp.spawn, utils/trainer.py:94-107).
+ *   - device pointers are caller-owned; all work is enqueued asynchronously on `stream`
+ *     (a hipStream_t passed as void*; NULL = the default stream).  No hidden synchronisation except
+ *     in fd_create / fd_destroy / fd_commit_weights / fd_read_tap / workspace growth.
+ *   - there is no CPU fallback: without a usable HIP device every compute call fails with FD_ERR_HIP.
+ */
+#ifndef FASTDIFF_HIP_H
+#define FASTDIFF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FD_API __attribute__((visibility("default")))
+
+typedef struct fd_context *fd_handle;
+
+enum fd_status {
+    FD_OK = 0,
+    FD_ERR_INVALID = -1,      /* bad argument (the reference would raise AssertionError / ValueError)     */
+    FD_ERR_UNSUPPORTED = -2,  /* architecture hyper-parameters this build has no kernels for                */
+    FD_ERR_HIP = -3,          /* HIP runtime error (no device, launch failure, out of memory ...)            */
+    FD_ERR_STATE = -4,        /* call order (e.g. forward before fd_commit_weights)                          */
+    FD_ERR_MISSING = -5       /* a state_dict tensor was never provided                                      */
+};
+
+/* Constructor arguments of FastDiff(...) -- modules/FastDiff/module/FastDiff_model.py:13-26;
+ * filled from hparams at modules/FastDiff/task/FastDiff.py:17-29 (modules/FastDiff/config/base.yaml:21-33). */
+typedef struct fd_config {
+    int audio_channels;                 /* 1   */
+    int inner_channels;                 /* 32  */
+    int cond_channels;                  /* 80  */
+    int n_upsample;                     /* 3   */
+    int upsample_ratios[8];             /* 8,8,4 */
+    int lvc_layers_each_block;          /* 4   */
+    int lvc_kernel_size;                /* 3   */
+    int kpnet_hidden_channels;          /* 64  */
+    int kpnet_conv_size;                /* 3   */
+    int diffusion_step_embed_dim_in;    /* 128 */
+    int diffusion_step_embed_dim_mid;   /* 512 */
+    int diffusion_step_embed_dim_out;   /* 512 */
+    int use_weight_norm;                /* 1   */
+} fd_config;
+
+/* One reverse step of sampling_given_noise_schedule (modules/FastDiff/module/util.py:216-229).
+ * The host (Python shim) derives these with the reference's own fp32 arithmetic (util.py:187-204):
+ *   t      = steps_infer[n]                       mapped (fractional) diffusion step fed to the net (:217)
+ *   c_eps  = beta_n / sqrt(1 - alpha_hat_n^2)     x -= c_eps * eps                                   (:226)
+ *   c_div  = sqrt(1 - beta_n)                     x /= c_div                                         (:227)
+ *   sigma  = sigma_hat_n                          x  = x + sigma * z   when add_noise (n > 0)        (:228-229)
+ *   c1,c2,c3                                      the "ddim" branch x = c1*x + c2*eps + c3*eps       (:219-224)
+ * table[0] is the step executed FIRST (n = N-1), table[N-1] the last (n = 0). */
+typedef struct fd_step {
+    float t, c_eps, c_div, sigma, c1, c2, c3;
+    int32_t add_noise;
+} fd_step;
+
+/* Fills *cfg with the reference defaults above. */
+FD_API int fd_default_config(fd_config *cfg);
+
+/* FastDiff(**cfg).cuda(device): creates kernels' context on HIP device `device`.
+ * Replaces: FastDiff.__init__ + .cuda() (FastDiff_model.py:13-72; FastDiff.py:17-29,  egs/demo.ipynb cell 0). */
+FD_API int fd_create(const fd_config *cfg, int device, fd_handle *out);
+FD_API int fd_destroy(fd_handle h);
+
+/* Text of the last error on this handle (h may be NULL: last error of a failed fd_create). */
+FD_API const char *fd_last_error(fd_handle h);
+
+/* load_state_dict(ckpt['state_dict']['model']) -- utils/trainer.py:355-356; egs/demo.ipynb cell 0.
+ * `name` is the reference state_dict key ("lvc_blocks.0.kernel_predictor.kernel_conv.weight_v", "fc_t1.bias" ...;
+ * after remove_weight_norm() the "*.weight" form is accepted instead of weight_g/weight_v, FastDiff_model.py:104-113).
+ * `host_data` is a HOST pointer, copied before return.  dims must equal the reference shape. */
+FD_API int fd_set_weight(fd_handle h, const char *name, const float *host_data, const int64_t *dims, int ndim);
+
+/* Folds weight-norm (w = g*v/||v||, FastDiff_model.py:115-122), repacks for the kernels and uploads.
+ * Fails with FD_ERR_MISSING naming the first absent tensor. */
+FD_API int fd_commit_weights(fd_handle h);
+
+/* eps = FastDiff.forward((x, mel, steps))  -- FastDiff_model.py:74-102.
+ *   x     [B,1,T*256] device     mel [B,80,T] device     steps [B] device (float; fractional allowed, util.py:217)
+ *   lens  [B] host, nullable: valid frames per utterance of a zero-padded batch.  Results are those of running the
+ *         whole padded tensor (what the reference does with a collate_2d batch, utils/__init__.py:136-150).
+ *   eps_out [B,1,T*256] device, must not alias x.
+ * Errors: T*256 length mismatch is the reference's assert at modules.py:236. */
+FD_API int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps, int B, int T,
+                      const int *lens, float *eps_out, void *stream);
+
+/* x_0 = sampling_given_noise_schedule(net, (B,1,T*256), dh, schedule, condition=mel, ddim, return_sequence)
+ * -- util.py:158-235, called from FastDiff.py:101-103 and the notebooks.
+ *   table   [N] host (see fd_step)
+ *   x_T     [B,1,L] device, nullable: start noise.  NULL -> drawn on device (Philox4x32-10, `seed`).
+ *   z       [N,B,1,L] device, nullable: z[k] is added after executed step k when table[k].add_noise
+ *           (the reference draws std_normal on the CPU each step, util.py:63-68,229).  NULL -> Philox.
+ *   out     [B,1,L] device result x_0.
+ *   seq_out nullable, [N+1,B,1,L] device: x after each step, seq_out[0] = x_T (return_sequence=True, util.py:212-214,230-234).
+ * The N-step loop is replayed from a hipGraph (one captured denoiser step, step scalars read from a device table). */
+FD_API int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, const fd_step *table, int N,
+                     int ddim, const float *x_T, const float *z, uint64_t seed, float *out, float *seq_out,
+                     void *stream);
+
+/* Waveform epilogue: wav/abs(wav).max() per utterance (FastDiff.py:110), *32767 -> int16
+ * (utils/audio.py:11-16).  wav [B,1,L] device -> pcm [B,L] device int16. */
+FD_API int fd_peak_normalize_int16(fd_handle h, const float *wav, int B, int64_t L, int16_t *pcm, void *stream);
+
+/* Options: "kernels" = "fast" | "naive" (all stages), "kernels.<stage>" for one stage
+ * (embed, first, dblock, kp_front, kp_gemm, convt, lvc, final); "graph" = "1" | "0"; "profile" = "1" | "0". */
+FD_API int fd_set_option(fd_handle h, const char *key, const char *value);
+
+/* Test / introspection hooks (not on the reference's API surface) -------------------------------------- */
+
+/* Copies an intermediate of the LAST fd_forward to host (synchronises).  Names: "noise" [B,3,80], "a0".."a3",
+ * "kp_h<n>" [B,64,T], "kpack<n>" [B,T,24832] (packed predicted kernels+bias of block n), "x<n>" [B,32,L_n].
+ * Returns the number of floats (also when host_dst is NULL), or a negative status. */
+FD_API int64_t fd_read_tap(fd_handle h, const char *name, float *host_dst, int64_t capacity);
+
+/* Position of predicted-kernel element (layer, in, out, tap) inside one frame's 24832-float packed record;
+ * bias (layer, out) is at 24576 + layer*64 + out.  Lets tests unpack "kpack<n>" into the reference's
+ * [B,4,32,64,3,T] view (modules.py:333-338). */
+FD_API int fd_kernel_index(int layer, int in_ch, int out_ch, int tap);
+
+/* Per-kernel timing gathered with hipEvents on the launch stream while option "profile"="1" (graph off).
+ * Fills up to `capacity` entries; returns the number of distinct kernels. */
+typedef struct fd_kernel_stat {
+    char name[48];
+    int64_t launches;
+    double total_ms;
+} fd_kernel_stat;
+FD_API int fd_get_profile(fd_handle h, fd_kernel_stat *stats, int capacity);
+FD_API int fd_reset_profile(fd_handle h);
+
+FD_API const char *fd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTDIFF_HIP_H */

@@ -1,0 +1,162 @@
+"""CPU tests of the host side: schedule arithmetic against the reference-generated golden tables, the drop-in
+module surface (state_dict keys / shapes / seeded init), the C ABI's symbol table, and loud failure without a GPU."""
+import ctypes as ct
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, ROOT
+
+import fastdiff_amd
+from fastdiff_amd import _capi, sampler, schedules
+
+
+def _ulp_close(a, b, ulps=1):
+    a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+    return np.all(np.abs(a - b) <= ulps * np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32)))
+
+
+def test_training_schedule_matches_reference():
+    g = load_golden("schedule")
+    dh = schedules.training_hyperparams()
+    assert dh["T"] == 1000
+    # identical torch ops -> normally bit-identical; torch.sqrt's vector path may differ by an ulp across hosts
+    assert _ulp_close(dh["alpha"].numpy(), g["train_alpha"])
+    assert _ulp_close(dh["sigma"].numpy(), g["train_sigma"])
+
+
+@pytest.mark.parametrize("N", [3, 4, 6, 8, 200, 1000])
+def test_inference_tables_match_reference(N):
+    g = load_golden("schedule")
+    dh = {"T": 1000, "alpha": torch.from_numpy(g["train_alpha"]), "beta": torch.from_numpy(g["train_beta"]),
+          "sigma": torch.from_numpy(g["train_sigma"])}
+    beta = schedules.noise_schedule_for(N)
+    assert np.array_equal(beta.numpy(), g[f"N{N}_beta"])
+    s = sampler.InferenceSchedule(dh, beta, verbose=False)
+    assert s.N == N
+    assert _ulp_close(s.alpha_hat.numpy(), g[f"N{N}_alpha_hat"])
+    assert _ulp_close(s.sigma_hat.numpy(), g[f"N{N}_sigma_hat"])
+    rows = s.rows()
+    assert [r["add_noise"] for r in rows] == [1] * (N - 1) + [0]
+    t = np.array([r["t"] for r in rows][::-1])
+    np.testing.assert_allclose(t, g[f"N{N}_steps"].astype(np.float32), rtol=0, atol=2e-3)
+    for k in ("c_eps", "c_div", "c1", "c2", "c3"):
+        got = np.array([r[k] for r in rows][::-1], np.float32)
+        np.testing.assert_allclose(got, g[f"N{N}_{k}"], rtol=2e-5, atol=1e-7, err_msg=k)
+    np.testing.assert_allclose(np.array([r["sigma"] for r in rows][::-1], np.float32), g[f"N{N}_sigma_hat"], rtol=2e-7)
+
+
+def test_n1000_maps_to_integer_steps():
+    dh = schedules.training_hyperparams()
+    s = sampler.InferenceSchedule(dh, schedules.noise_schedule_for(1000), verbose=False)
+    assert np.array_equal(s.steps.numpy(), np.arange(1000, dtype=np.float32))
+
+
+def test_schedule_selection_errors():
+    with pytest.raises(NotImplementedError):            # FastDiff.py:92-93
+        schedules.noise_schedule_for(5)
+    assert len(schedules.noise_schedule_for('4')) == 4    # hparams deliver N as a string (utils/hparams.py:88-101)
+    assert torch.equal(schedules.noise_schedule_for(7, [0.1, 0.2]), torch.FloatTensor([0.1, 0.2]))
+
+
+def test_map_noise_scale_edges():
+    alpha = torch.tensor([0.9, 0.8, 0.5, 0.1])
+    assert sampler.map_noise_scale_to_time_step(torch.tensor(0.95), alpha) == 0
+    assert sampler.map_noise_scale_to_time_step(torch.tensor(0.05), alpha) == 3
+    assert abs(sampler.map_noise_scale_to_time_step(torch.tensor(0.65), alpha) - 1.5) < 1e-6
+
+
+def test_step_embedding_matches_reference():
+    g = load_golden("embed")
+    e = sampler.calc_diffusion_step_embedding(torch.from_numpy(g["steps"]), 128)
+    np.testing.assert_allclose(e.numpy(), g["emb_f32"], rtol=0, atol=2e-6)
+    with pytest.raises(AssertionError):
+        sampler.calc_diffusion_step_embedding(torch.zeros(1, 1), 127)
+
+
+def test_state_dict_surface_is_the_references():
+    g = load_golden("state_dict_manifest")
+    torch.manual_seed(1234)
+    m = fastdiff_amd.FastDiff()
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["names"]]
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == [str(s) for s in g["shapes"]]
+    assert sum(v.numel() for v in sd.values()) == 15315410
+    # same construction order -> same random init as `torch.manual_seed(1234); FastDiff()` of the reference
+    sums = np.array([float(v.double().sum()) for v in sd.values()])
+    np.testing.assert_allclose(sums, g["sums"], rtol=0, atol=1e-9)
+    m.remove_weight_norm()
+    assert "first_audio_conv.weight" in m.state_dict() and "first_audio_conv.weight_g" not in m.state_dict()
+
+
+def test_constructor_rejects_training_only_options():
+    with pytest.raises(NotImplementedError):
+        fastdiff_amd.FastDiff(dropout=0.1)
+
+
+def test_capi_exports_every_declared_symbol():
+    lib = _capi.load()
+    header = open(os.path.join(ROOT, "include", "fastdiff_hip.h")).read()
+    declared = sorted(set(re.findall(r"FD_API\s+[\w\s\*]+?\b(fd_\w+)\s*\(", header)))
+    assert declared, "no FD_API declarations parsed"
+    assert sorted(_capi.EXPORTS) == declared
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.fd_version().startswith(b"fastdiff_hip")
+    # layout introspection is pure host code
+    idx = {lib.fd_kernel_index(l, i, o, k) for l in range(4) for i in range(32) for o in range(64) for k in range(3)}
+    assert idx == set(range(24576)), "kernel_index must be a bijection onto the packed record"
+    assert lib.fd_kernel_index(4, 0, 0, 0) < 0
+
+
+def test_struct_sizes_match_header():
+    assert ct.sizeof(_capi.FdStep) == 32
+    assert ct.sizeof(_capi.FdConfig) == 4 * 20
+    assert ct.sizeof(_capi.FdKernelStat) == 64
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_fails_loudly_without_a_gpu():
+    lib = _capi.load()
+    cfg = _capi.FdConfig()
+    lib.fd_default_config(ct.byref(cfg))
+    h = ct.c_void_p()
+    rc = lib.fd_create(ct.byref(cfg), 0, ct.byref(h))
+    assert rc == _capi.FD_ERR_HIP
+    assert b"no CPU fallback" in lib.fd_last_error(None)
+    m = fastdiff_amd.FastDiff()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m((torch.zeros(1, 1, 256), torch.zeros(1, 80, 1), torch.zeros(1, 1)))
+
+
+def test_unsupported_architecture_is_refused():
+    lib = _capi.load()
+    cfg = _capi.FdConfig()
+    lib.fd_default_config(ct.byref(cfg))
+    cfg.inner_channels = 64
+    h = ct.c_void_p()
+    assert lib.fd_create(ct.byref(cfg), 0, ct.byref(h)) == _capi.FD_ERR_UNSUPPORTED
+
+
+def test_foreign_net_host_loop_matches_oracle_update(oracle64):
+    """sampling_given_noise_schedule with a denoiser we do not own: the host loop applies the same step table."""
+    g = load_golden("schedule")
+    dh = {"T": 1000, "alpha": torch.from_numpy(g["train_alpha"])}
+    B, L = 1, 256
+    x_T = torch.randn(B, 1, L)
+    noise = torch.randn(4, B, 1, L)
+    net = lambda data: 0.25 * data[0] + 0.01 * data[2].view(-1, 1, 1)   # noqa: E731
+    seq = sampler.sampling_given_noise_schedule(net, (B, 1, L), dh, schedules.noise_schedule_for(4), condition=None,
+                                                return_sequence=True, x_T=x_T, noise=noise, verbose=False)
+    assert len(seq) == 5
+    rows = sampler.InferenceSchedule(dh, schedules.noise_schedule_for(4), verbose=False).rows()
+    x = x_T.clone()
+    for k, r in enumerate(rows):
+        eps = 0.25 * x + 0.01 * r["t"]
+        x = (x - r["c_eps"] * eps) / r["c_div"]
+        if r["add_noise"]:
+            x = x + r["sigma"] * noise[k]
+        torch.testing.assert_close(seq[k + 1], x)
