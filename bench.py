@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""bench.py -- FastDiff vocoder inference on MI355X: real-time factor of the N=4 reverse sampler.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch: fd_sample() of B=8 utterances of 80x864 mel (10.03 s each)
+through N=4 reverse steps (BASELINE.json configs[1]), mel resident in HBM, waveform left in HBM.  With N GPUs every
+rank runs its own batch (independent utterances, no data-path collective): weak scaling, value = whole-job audio
+seconds per wall second.  Prints ONE JSON line on rank 0.
+
+Extra objects in the line:
+  roofline     -- the dominant kernel of the step, timed live with HIP events on the launch stream (library option
+                  "profile"), algorithmic bytes/flops per launch from DESIGN.md;
+  cpu_baseline -- the CPU oracle (a C port of the reference algorithm, oracle/) timed on this host on a bounded
+                  sample: one utterance (B=1, T=864), N=4.  The reference's own PyTorch CPU path cannot be timed on the
+                  GPU box (/root/reference is absent there); its timing in the build container is in DESIGN.md.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SR, HOP = 22050, 256
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix = fp32 vector peak
+
+
+def kernel_model(name, B, T):
+    """Algorithmic work of ONE launch of a kernel family: (bound, bytes, flops)."""
+    L = T * HOP
+    if name.startswith("lvc_layer_h"):
+        hop = int(name.split("_h")[1].split("_")[0])
+        # read x, skip (32 ch each), write x (32 ch) at rate hop*T; read the frame's 64x96 kernel + 64 biases
+        return "hbm", 4.0 * B * T * (96 * hop + 6208), 2.0 * B * T * hop * (32 * 96 + 64 * 96)
+    if name == "kp_gemm":
+        # all 3 LVC blocks in one launch: [24832 x 192] x [192 x B*T] each, output written once
+        return "mfma", 3 * 4.0 * (B * T * 24832 + 24832 * 192 + B * T * 64), 3 * 2.0 * 24832 * 192 * B * T
+    if name.startswith("kp_"):
+        cin, ks = (80, 5) if name == "kp_in_conv" else (64, 3)
+        return "mfma", 3 * 4.0 * B * T * (cin + 64), 3 * 2.0 * 64 * cin * ks * B * T
+    if name.startswith("dblock"):
+        return "hbm", None, None
+    if name.startswith("convt"):
+        return "hbm", None, None
+    if name == "first_conv":
+        return "hbm", 4.0 * B * L * 33, 2.0 * 7 * 32 * B * L
+    if name == "final_conv_update":
+        return "hbm", 4.0 * B * L * 34, 2.0 * 7 * 32 * B * L
+    return "hbm", None, None
+
+
+def family(name):
+    for p in ("lvc_layer_h8", "lvc_layer_h64", "lvc_layer_h256"):
+        if name.startswith(p + "_"):
+            return p
+    return name
+
+
+def measure_roofline(model, mel, rows, B, T, nsteps):
+    """Eager (graph off) profiled pass: per-kernel HIP-event timing on the launch stream."""
+    model.set_option("profile", "1")
+    try:
+        with torch.no_grad():
+            model.sample(mel, rows, seed=1)
+            torch.cuda.synchronize()
+            model.profile(reset=True)
+            for _ in range(2):
+                model.sample(mel, rows, seed=1)
+            torch.cuda.synchronize()
+        stats = model.profile(reset=True)
+    finally:
+        model.set_option("profile", "0")
+    fam = {}
+    for name, (launches, ms) in stats.items():
+        f = fam.setdefault(family(name), [0, 0.0])
+        f[0] += launches
+        f[1] += ms
+    total_ms = sum(v[1] for v in fam.values())
+    table = {}
+    for name, (launches, ms) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+        bound, nbytes, flops = kernel_model(name, B, T)
+        avg_ms = ms / launches
+        e = {"launches": launches, "avg_us": round(avg_ms * 1e3, 2), "share": round(ms / total_ms, 4)}
+        if nbytes:
+            e["GBps"] = round(nbytes / (avg_ms * 1e-3) / 1e9, 1)
+        if flops:
+            e["TFLOPs"] = round(flops / (avg_ms * 1e-3) / 1e12, 2)
+        table[name] = e
+    dom = next(iter(table))
+    bound, nbytes, flops = kernel_model(dom, B, T)
+    avg_s = fam[dom][1] / fam[dom][0] * 1e-3
+    if bound == "mfma" and flops:
+        roof = {"kernel": dom, "bound": "mfma", "achieved": round(flops / avg_s / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s"}
+    else:
+        roof = {"kernel": dom, "bound": "hbm", "achieved": round((nbytes or 0.0) / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s"}
+    roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+    roof["avg_launch_us"] = round(avg_s * 1e6, 2)
+    roof["traffic"] = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # filled from rocprofv3 --pmc passes, see profiles/README.md
+    if os.path.exists(pmc):
+        try:
+            roof["traffic"] = json.load(open(pmc)).get(dom)
+        except Exception:
+            pass
+    return roof, table
+
+
+def cpu_baseline(T, rows):
+    """The CPU oracle (C port of the reference algorithm, OpenMP) on one utterance, N=len(rows) steps."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import synth
+    from oracle import Oracle
+    o = Oracle("f32")
+    o.set_weights(synth.synth_state_dict(1234))
+    mel = synth.synth_mel(1, 1, T)
+    x_T = synth.hash_normal(1, 1, T * HOP).reshape(1, 1, T * HOP)
+    N = len(rows)
+    z = np.zeros((N, 1, 1, T * HOP), np.float32)
+    ex = rows[::-1]   # oracle tables are indexed by reverse index n
+    table = {"steps": [r["t"] for r in ex], "c_eps": [r["c_eps"] for r in ex], "c_div": [r["c_div"] for r in ex],
+             "sigma_hat": [r["sigma"] for r in ex], "c1": [r["c1"] for r in ex], "c2": [r["c2"] for r in ex],
+             "c3": [r["c3"] for r in ex]}
+    o.forward(synth.synth_audio(1, 1, 16), synth.synth_mel(1, 1, 16), np.zeros(1, np.float32))   # warm the thread pool
+    t0 = time.perf_counter()
+    o.sample(mel, table, x_T, z)
+    dt = time.perf_counter() - t0
+    return {"value": round((T * HOP / SR) / dt, 3), "unit": "x real-time", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"oracle/fastdiff_oracle.c (fp32, OpenMP) B=1 T={T} N={N}: {dt:.2f} s wall",
+            "samples_per_s": round(T * HOP / dt, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--frames", type=int, default=864)
+    ap.add_argument("--nsteps", type=int, default=4, help="reverse steps N (3,4,6,8,200,1000)")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: fastdiff_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import fastdiff_amd
+    from fastdiff_amd import sampler, schedules
+
+    B, T, N = args.batch, args.frames, args.nsteps
+    torch.manual_seed(1234)                       # weights = FastDiff() default init, seed 1234
+    model = fastdiff_amd.FastDiff().to(dev).eval()
+    if args.no_graph:
+        model.set_option("graph", "0")
+    torch.manual_seed(1234 + rank)
+    mel = (torch.rand(B, 80, T) * 7.5 - 6.0).to(dev)    # uniform on [mel_vmin, mel_vmax]
+    dh = schedules.training_hyperparams()
+    rows = sampler.InferenceSchedule(dh, schedules.noise_schedule_for(N), verbose=False).rows()
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            out = model.sample(mel, rows, seed=i)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = model.sample(mel, rows, seed=100 + i)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    audio_s = world * B * T * HOP / SR
+    line = {
+        "metric": "real-time factor (audio-sec/wall-sec), N=%d reverse steps, 80x%d mel" % (N, T),
+        "value": round(audio_s / (ms_per_step / 1e3), 2),
+        "unit": "x real-time",
+        "samples_per_s": round(world * B * T * HOP / (ms_per_step / 1e3), 1),
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: LJSpeech FastDiff.yaml shape, batch=%d utterances of 80x%d mel, "
+                               "N=%d, HIP LVC/dilated-conv kernels + hipGraph sampler" % (B, T, N),
+                   "batch_per_gpu": B, "frames": T, "reverse_steps": N, "sharding": "utterances/rank, no collective",
+                   "graph": not args.no_graph, "weights": "random init seed 1234 (no checkpoint offline)"},
+    }
+    if rank == 0 and world == 1:
+        if not args.no_roofline:
+            roof, table = measure_roofline(model, mel, rows, B, T, N)
+            line["roofline"] = roof
+            line["kernels"] = table
+        if not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(T, rows)
+            except Exception as e:   # the checker is optional for the measurement
+                line["cpu_baseline"] = {"error": repr(e)}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,296 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against the CPU oracle
+and the reference-generated golden fixtures.
+
+Tolerances: the reference's own fp32-vs-fp64 noise floor for one forward is ~3e-6 on
+|y| <= 8, so  single forward  max|d| <= 2e-5;   N<=8 loop with injected noise  max|d| <= 1e-4;
+N=1000 loop: within 10x of the fp32 reference's own drift against its fp64 run.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 2e-5
+LOOP_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def gc():
+    import gpu_common
+    return gpu_common
+
+
+@pytest.fixture(scope="module")
+def model(gc):
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return gc.make_model()
+
+
+@pytest.fixture(scope="module")
+def sched():
+    return load_golden("schedule")
+
+
+def test_native_library_is_the_one_running(model):
+    """The ops must come from the in-tree HIP library, not a fallback."""
+    from fastdiff_amd import _capi
+    lib = _capi.load()
+    assert lib.fd_version().startswith(b"fastdiff_hip")
+    maps = open("/proc/self/maps").read()
+    assert "fastdiff_amd/lib/libfastdiff_hip.so" in maps
+
+
+# ------------------------------------------------------------------------------------------------ forward vs golden
+@pytest.mark.parametrize("case", ["f1", "f2", "f3", "f4"])
+def test_forward_matches_reference_golden(model, gc, case):
+    g = load_golden("forward_" + case)
+    model.set_option("kernels", "fast")
+    y = gc.run_forward(model, g["audio"], g["mel"], g["steps"])
+    assert gc.maxdiff(y, g["y_f64"]) < FWD_TOL
+    assert gc.maxdiff(y, g["y_f32"]) < FWD_TOL
+
+
+def test_forward_naive_kernels_match_golden(model, gc):
+    g = load_golden("forward_f2")
+    model.set_option("kernels", "naive")
+    try:
+        y = gc.run_forward(model, g["audio"], g["mel"], g["steps"])
+    finally:
+        model.set_option("kernels", "fast")
+    assert gc.maxdiff(y, g["y_f64"]) < FWD_TOL
+
+
+def test_every_intermediate_matches_reference(model, gc):
+    """Per-function pins: first conv, the three DBlocks, each KernelPredictor's kernels/bias,
+    each LVC block output -- against the reference's own forward hooks."""
+    g = load_golden("forward_f1")
+    model.set_option("kernels", "fast")
+    model.set_option("taps", "1")
+    try:
+        y = gc.run_forward(model, g["audio"], g["mel"], g["steps"])
+        taps = gc.read_taps(model, 1, 4)
+    finally:
+        model.set_option("taps", "0")
+    for k in ("a0", "a1", "a2", "a3", "x0", "x1", "x2"):
+        assert gc.maxdiff(taps[k], g["tap_" + k]) < FWD_TOL, k
+    for n in range(3):
+        assert gc.maxdiff(taps[f"kernels{n}"], g[f"tap_kp{n}_kernels"]) < FWD_TOL, n
+        assert gc.maxdiff(taps[f"bias{n}"], g[f"tap_kp{n}_bias"]) < FWD_TOL, n
+    assert gc.maxdiff(y, g["y_f64"]) < FWD_TOL
+
+
+@pytest.mark.parametrize("stage", ["first", "dblock", "kp_front", "kp_gemm", "convt", "lvc", "final"])
+def test_each_fast_stage_against_oracle(model, gc, oracle64, stage):
+    """One fast stage at a time on top of the naive set: localises a wrong kernel."""
+    import synth
+    B, T = 2, 37                      # odd T: partial tiles in every kernel
+    mel, audio = synth.synth_mel(7, B, T), synth.synth_audio(7, B, T)
+    steps = np.array([3.25, 480.5], np.float32)
+    y_ref = oracle64.forward(audio, mel, steps)
+    model.set_option("kernels", "naive")
+    model.set_option("kernels." + stage, "fast")
+    try:
+        y = gc.run_forward(model, audio, mel, steps)
+    finally:
+        model.set_option("kernels", "fast")
+    assert gc.maxdiff(y, y_ref) < FWD_TOL
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 3), (1, 63), (2, 130)])
+def test_forward_ragged_sizes_against_oracle(model, gc, oracle64, B, T):
+    import synth
+    mel, audio = synth.synth_mel(11 + T, B, T), synth.synth_audio(11 + T, B, T)
+    steps = np.linspace(0.0, 999.0, B).astype(np.float32)
+    y_ref = oracle64.forward(audio, mel, steps)
+    y = gc.run_forward(model, audio, mel, steps)
+    assert gc.maxdiff(y, y_ref) < FWD_TOL
+
+
+def test_forward_accepts_unbatched_mel_and_long_steps(model, gc):
+    """egs/demo.ipynb passes a [80,T] mel; training passes integer steps (util.py:311-319)."""
+    g = load_golden("forward_f1")
+    with torch.no_grad():
+        y = model((torch.from_numpy(g["audio"]).cuda(), torch.from_numpy(g["mel"][0]).cuda(),
+                   torch.tensor([[7]], dtype=torch.long).cuda()))
+        y2 = model((torch.from_numpy(g["audio"]).cuda(), torch.from_numpy(g["mel"]).cuda(), torch.tensor([[7.0]]).cuda()))
+    assert torch.equal(y, y2)
+
+
+def test_length_mismatch_is_the_references_assert(model):
+    with pytest.raises(AssertionError, match="not matched"):        # modules.py:236
+        model((torch.zeros(1, 1, 255).cuda(), torch.zeros(1, 80, 1).cuda(), torch.zeros(1, 1).cuda()))
+
+
+def test_remove_weight_norm_changes_nothing(gc):
+    """a11: folding weight-norm on load == evaluating it every forward (FastDiff_model.py:104-122)."""
+    g = load_golden("forward_f1")
+    m = gc.make_model()
+    y0 = gc.run_forward(m, g["audio"], g["mel"], g["steps"])
+    m.remove_weight_norm()
+    y1 = gc.run_forward(m, g["audio"], g["mel"], g["steps"])
+    assert gc.maxdiff(y0, y1) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ sampler vs golden
+@pytest.mark.parametrize("case", ["s1", "s2", "s3", "s5"])
+def test_sampler_matches_reference_golden(model, gc, sched, case):
+    g = load_golden("sample_" + case)
+    N, ddim = int(g["N"]), bool(g["ddim"])
+    B, _, T = g["mel"].shape
+    rows, _ = gc.table_rows(sched, N)
+    noise = gc.exec_order_noise(gc.noise_from_seed(int(g["seed"]), B, T, N))
+    seq = "seq_f64" in g
+    with torch.no_grad():
+        res = model.sample(torch.from_numpy(g["mel"]).cuda(), rows, ddim=ddim, x_T=torch.from_numpy(g["x_T"]).cuda(),
+                           noise=torch.from_numpy(noise).cuda(), return_sequence=seq)
+    torch.cuda.synchronize()
+    got = np.stack([r.cpu().numpy() for r in res]) if seq else res.cpu().numpy()
+    key = "seq" if seq else "y"
+    assert gc.maxdiff(got, g[key + "_f64"]) < LOOP_TOL
+    assert gc.maxdiff(got, g[key + "_f32"]) < LOOP_TOL
+
+
+def test_sampler_graph_replay_equals_eager(model, gc, sched):
+    g = load_golden("sample_s1")
+    rows, _ = gc.table_rows(sched, 4)
+    noise = torch.from_numpy(gc.exec_order_noise(gc.noise_from_seed(int(g["seed"]), 2, 6, 4))).cuda()
+    args = dict(x_T=torch.from_numpy(g["x_T"]).cuda(), noise=noise)
+    with torch.no_grad():
+        a = model.sample(torch.from_numpy(g["mel"]).cuda(), rows, **args)
+        a2 = model.sample(torch.from_numpy(g["mel"]).cuda(), rows, **args)     # cached graph, second replay
+        model.set_option("graph", "0")
+        try:
+            b = model.sample(torch.from_numpy(g["mel"]).cuda(), rows, **args)
+        finally:
+            model.set_option("graph", "1")
+    assert torch.equal(a, b) and torch.equal(a, a2)
+
+
+def test_n1000_full_schedule_drift(model, gc, sched):
+    """BASELINE config 3 (long-loop hipGraph stress): N=1000, drift bounded by 10x the fp32 reference's own."""
+    g = load_golden("sample_s4")
+    rows, _ = gc.table_rows(sched, 1000)
+    noise = gc.exec_order_noise(gc.noise_from_seed(int(g["seed"]), 1, 4, 1000))
+    with torch.no_grad():
+        y = model.sample(torch.from_numpy(g["mel"]).cuda(), rows, x_T=torch.from_numpy(g["x_T"]).cuda(),
+                         noise=torch.from_numpy(noise).cuda())
+    y = y.cpu().numpy()
+    ref_drift = gc.maxdiff(g["y_f32"], g["y_f64"])
+    assert np.isfinite(y).all()
+    assert gc.maxdiff(y, g["y_f64"]) < 10 * ref_drift, (gc.maxdiff(y, g["y_f64"]), ref_drift)
+
+
+def test_drop_in_sampling_function(model, gc, sched, oracle64):
+    """The reference call shape: sampling_given_noise_schedule(net, size, dh, schedule, condition=mel)."""
+    import fastdiff_amd
+    import synth
+    B, T = 2, 5
+    mel = synth.synth_mel(21, B, T)
+    dh = fastdiff_amd.schedules.training_hyperparams()
+    sch_t = fastdiff_amd.schedules.noise_schedule_for(4).cuda()
+    x_T = synth.hash_normal(5, 1, B * T * 256).reshape(B, 1, T * 256)
+    z = gc.noise_from_seed(5, B, T, 4)
+    y = fastdiff_amd.sampling_given_noise_schedule(model, (B, 1, T * 256), dh, sch_t, condition=torch.from_numpy(mel).cuda(),
+                                                   x_T=torch.from_numpy(x_T).cuda(),
+                                                   noise=torch.from_numpy(gc.exec_order_noise(z)).cuda(), verbose=False)
+    _, table = gc.table_rows(sched, 4)
+    ref = oracle64.sample(mel, table, x_T, z)
+    assert gc.maxdiff(y.cpu().numpy(), ref) < LOOP_TOL
+    # on-device Philox: reproducible per seed, different across seeds, finite
+    kw = dict(condition=torch.from_numpy(mel).cuda(), verbose=False)
+    a = fastdiff_amd.sampling_given_noise_schedule(model, (B, 1, T * 256), dh, sch_t, seed=3, **kw)
+    b = fastdiff_amd.sampling_given_noise_schedule(model, (B, 1, T * 256), dh, sch_t, seed=3, **kw)
+    c = fastdiff_amd.sampling_given_noise_schedule(model, (B, 1, T * 256), dh, sch_t, seed=4, **kw)
+    assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()
+    # the reference's own random stream (CPU generator, reference order)
+    torch.manual_seed(99)
+    r1 = fastdiff_amd.sampling_given_noise_schedule(model, (B, 1, T * 256), dh, sch_t, noise_source="reference", **kw)
+    torch.manual_seed(99)
+    xT = torch.normal(0, 1, size=(B, 1, T * 256))
+    zs = [torch.normal(0, 1, size=(B, 1, T * 256)) for _ in range(3)] + [torch.zeros(B, 1, T * 256)]
+    r2 = fastdiff_amd.sampling_given_noise_schedule(model, (B, 1, T * 256), dh, sch_t, x_T=xT.cuda(),
+                                                    noise=torch.stack(zs).cuda(), **kw)
+    assert torch.equal(r1, r2)
+
+
+def test_philox_noise_statistics(model):
+    import fastdiff_amd
+    B, T = 4, 16
+    dh = fastdiff_amd.schedules.training_hyperparams()
+    rows = [{"t": 0.0, "c_eps": 0.0, "c_div": 1.0, "sigma": 1.0, "c1": 1.0, "c2": 0.0, "c3": 0.0, "add_noise": 1},
+            {"t": 0.0, "c_eps": 0.0, "c_div": 1.0, "sigma": 0.0, "c1": 1.0, "c2": 0.0, "c3": 0.0, "add_noise": 0}]
+    with torch.no_grad():
+        seq = model.sample(torch.zeros(B, 80, T).cuda(), rows, seed=1234, return_sequence=True)
+    x_T, x1 = seq[0].double(), seq[1].double()
+    z = x1 - x_T                                  # c_eps = 0: the step only adds sigma*z
+    for v in (x_T, z):
+        assert abs(v.mean().item()) < 0.02 and abs(v.var().item() - 1.0) < 0.03
+        assert abs((v ** 4).mean().item() - 3.0) < 0.2
+    assert abs((x_T * z).mean().item()) < 0.02    # independent streams
+
+
+# ------------------------------------------------------------------------------------------------ full BASELINE size
+def test_full_size_forward_against_oracle(model, gc, oracle64):
+    """BASELINE shape: one 80x864 mel (10.03 s).  Direct comparison with the fp64 oracle."""
+    import synth
+    B, T = 1, 864
+    mel, audio = synth.synth_mel(1234, B, T), synth.synth_audio(1234, B, T)
+    steps = np.array([498.05368], np.float32)
+    y_ref = oracle64.forward(audio, mel, steps)
+    y = gc.run_forward(model, audio, mel, steps)
+    assert gc.maxdiff(y, y_ref) < FWD_TOL
+
+
+def test_full_size_batch_properties(model, gc):
+    """B=8 x T=864 (BASELINE config 2): size-independent properties -- batch items are independent and bit-reproducible,
+    the fast set agrees with the naive set, and a one-frame mel perturbation stays inside the finite receptive field
+    (+-16 frames)."""
+    import synth
+    B, T = 8, 864
+    mel, audio = synth.synth_mel(99, B, T), synth.synth_audio(99, B, T)
+    steps = np.full(B, 74.992283, np.float32)
+    y = gc.run_forward(model, audio, mel, steps)
+    assert np.isfinite(y).all()
+    y_again = gc.run_forward(model, audio, mel, steps)
+    assert np.array_equal(y, y_again)
+    y3 = gc.run_forward(model, audio[3:4], mel[3:4], steps[3:4])
+    assert np.array_equal(y[3:4], y3)
+    model.set_option("kernels", "naive")
+    try:
+        y_naive = gc.run_forward(model, audio[:1], mel[:1], steps[:1])
+    finally:
+        model.set_option("kernels", "fast")
+    assert gc.maxdiff(y[:1], y_naive) < FWD_TOL
+    mel2 = mel.copy()
+    mel2[0, :, 400] += 1.0
+    y2 = gc.run_forward(model, audio, mel2, steps)
+    d = np.abs(y2 - y)[0, 0]
+    changed = np.nonzero(d > 0)[0]
+    assert changed.size > 0
+    assert changed.min() >= (400 - 16) * 256 and changed.max() < (400 + 17) * 256
+    assert np.array_equal(y2[1:], y[1:])
+
+
+def test_full_size_sampler_n4(model, gc, sched):
+    """N=4, B=8, T=864 through the hipGraph path: finite, reproducible with injected seed, per-item independent."""
+    import synth
+    B, T = 8, 864
+    mel = torch.from_numpy(synth.synth_mel(5, B, T)).cuda()
+    rows, _ = gc.table_rows(sched, 4)
+    with torch.no_grad():
+        a = model.sample(mel, rows, seed=77)
+        b = model.sample(mel, rows, seed=77)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert a.shape == (B, 1, T * 256)
+
+
+# ------------------------------------------------------------------------------------------------ epilogue (8f row 1)
+def test_peak_normalize_int16_bit_exact(model, oracle64):
+    rng = np.random.default_rng(3)
+    wav = (rng.standard_normal((3, 1, 4096)) * rng.uniform(0.1, 5.0, (3, 1, 1))).astype(np.float32)
+    pcm = model.peak_normalize_int16(torch.from_numpy(wav).cuda()).cpu().numpy()
+    ref = oracle64.peak_normalize_int16(wav).reshape(3, 4096)
+    assert np.array_equal(pcm, ref)
