@@ -91,14 +91,22 @@ __global__ void __launch_bounds__(256, 2) k_dblock(const float *__restrict__ xin
     __shared__ __attribute__((aligned(16))) float hB[fd::C * DB_LD];
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int pbase = blockIdx.x * DB_STRIDE - 7;   // down-sampled position of tile column 0
-    // stage the strided pick x[..., ::F]; zero outside [0, Lo) and in the guard columns
-    for (int idx = tid; idx < fd::C * DB_LD; idx += 256) {
-        const int ci = idx / DB_LD, cc = idx % DB_LD, p = pbase + cc - 4;
-        float v = 0.0f;
-        if (cc >= 4 && cc < 132 && p >= 0 && p < Lo) v = xin[((int64_t)b * fd::C + ci) * Lin + (int64_t)p * F];
-        xs[idx] = v;
-        hA[idx] = 0.0f;
-        hB[idx] = 0.0f;
+    // stage the strided pick x[..., ::F]; zero outside [0, Lo) and in the guard columns (loads batched ahead of the writes)
+    {
+        constexpr int NK = fd::C * DB_LD / 256;     // 17
+        float v[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int idx = k * 256 + tid, ci = idx / DB_LD, cc = idx - ci * DB_LD, p = pbase + cc - 4;
+            v[k] = (cc >= 4 && cc < 132 && p >= 0 && p < Lo) ? xin[((int64_t)b * fd::C + ci) * Lin + (int64_t)p * F] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int idx = k * 256 + tid;
+            xs[idx] = v[k];
+            hA[idx] = 0.0f;
+            hB[idx] = 0.0f;
+        }
     }
     __syncthreads();
     const int c = wave * 32 + l31;        // this lane's tile column
@@ -166,14 +174,27 @@ __global__ void __launch_bounds__(256) k_kp_conv(const float *__restrict__ in, f
         const int step = sampler ? params->step_idx : 0;
         nz = noise + (((int64_t)step * B + b) * fd::NBLK + blk) * fd::COND;
     }
-    for (int idx = tid; idx < CIN * LD; idx += 256) {
-        const int ci = idx / LD, cc = idx % LD, t = t0 - PAD + cc;
-        float v = 0.0f;
-        if (t >= 0 && t < T) {
-            v = src[(int64_t)ci * T + t];
-            if (FIRST) v += nz[ci];            // condition = c + noise; the zero padding stays zero (modules.py:203)
+    {   // stage the input window; loads batched ahead of the LDS writes
+        constexpr int TOTAL = CIN * LD, NK = (TOTAL + 255) / 256, KB = (NK + 1) / 2;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float v[KB];
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                const int idx = (half * KB + k) * 256 + tid, ci = idx / LD, cc = idx - ci * LD, t = t0 - PAD + cc;
+                float x = 0.0f;
+                if (idx < TOTAL && t >= 0 && t < T) {
+                    x = src[(int64_t)ci * T + t];
+                    if (FIRST) x += nz[ci];        // condition = c + noise; the zero padding stays zero (modules.py:203)
+                }
+                v[k] = x;
+            }
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                const int idx = (half * KB + k) * 256 + tid;
+                if (idx < TOTAL) xs[idx] = v[k];
+            }
         }
-        xs[idx] = v;
     }
     __syncthreads();
     const int mt = wave & 1, nt = wave >> 1;
@@ -212,58 +233,75 @@ __global__ void __launch_bounds__(256) k_kp_conv(const float *__restrict__ in, f
 // (B = weights, register-stationary: 96 VGPRs per wave, loaded once and reused for every frame tile of the
 // workgroup's chunk).  Output goes out frame-major so the LVC kernel reads a frame's record contiguously.
 // =================================================================================================
-constexpr int GEMM_LDH = 36;
+constexpr int GEMM_CT = 8;                       // frame tiles (of 32) per workgroup chunk
+constexpr int GEMM_LDH = GEMM_CT * 32 + 4;       // 256 frames + 1 halo each side, padded
 
+// The workgroup stages its whole chunk of h (64 x 258 floats, 66 KB) once, so the tile loop has no barrier and
+// no staging: per 32-frame tile a wave issues 96 MFMAs, 96 LDS reads with immediate offsets and 16 stores.
 __global__ void __launch_bounds__(256, 2) k_kp_gemm(const float *__restrict__ h /*[3][B][64][T]*/, float *__restrict__ kpack,
                                                     const float *g0, const float *g1, const float *g2, const float *gb0,
-                                                    const float *gb1, const float *gb2, int B, int T, int tiles_per_utt,
-                                                    int tiles_per_wg)
+                                                    const float *gb1, const float *gb2, int B, int T, int chunks_per_utt,
+                                                    int chunk_tiles)
 {
-    __shared__ float hs[2][fd::HID * GEMM_LDH];
+    __shared__ float hs[fd::HID * GEMM_LDH];
     const int blk = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const float *gp = blk == 0 ? g0 : (blk == 1 ? g1 : g2);
     const float *gb = blk == 0 ? gb0 : (blk == 1 ? gb1 : gb2);
     const int ptile = blockIdx.x * 4 + wave, pcol = ptile * 32 + l31;
-    const int total_tiles = B * tiles_per_utt;
-    const int ft0 = blockIdx.y * tiles_per_wg;
-    const int ft1 = min(total_tiles, ft0 + tiles_per_wg);
-    if (ft0 >= ft1) return;
+    const int b = blockIdx.y / chunks_per_utt, chunk = blockIdx.y % chunks_per_utt;
+    const int t_begin = chunk * chunk_tiles * 32;                 // first frame of the chunk
+    const int n_frames = min(T - t_begin, chunk_tiles * 32);
+    const int n_tiles = (n_frames + 31) >> 5;
+    // weights: register-stationary B operand, one 32-column tile per wave
     float4 wb[24];
 #pragma unroll
     for (int i = 0; i < 24; ++i) wb[i] = reinterpret_cast<const float4 *>(gp)[((int64_t)ptile * 24 + i) * 64 + lane];
     const float bias = gb[pcol];
-    const float *hblk = h + (int64_t)blk * B * fd::HID * T;
-    float *kblk = kpack + (int64_t)blk * B * T * fd::KREC;
-
-    auto stage = [&](int ft, int buf) {
-        const int b = ft / tiles_per_utt, t0 = (ft % tiles_per_utt) * 32;
-        for (int idx = tid; idx < fd::HID * 34; idx += 256) {
-            const int c = idx / 34, cc = idx % 34, t = t0 - 1 + cc;
-            hs[buf][c * GEMM_LDH + cc] = (t >= 0 && t < T) ? hblk[((int64_t)b * fd::HID + c) * T + t] : 0.0f;
+    // stage h[b][:, t_begin-1 .. t_begin+chunk_tiles*32] (zero outside the utterance).  Loads are issued in batches of
+    // 13 before any LDS write: a load->wait->write loop would serialise ~65 L2 round trips per thread.
+    {
+        const float *hb = h + ((int64_t)blk * B + b) * fd::HID * T;
+        const int ncols = chunk_tiles * 32 + 2, total = fd::HID * ncols;
+#pragma unroll 1
+        for (int k0 = 0; k0 < total; k0 += 13 * 256) {
+            float v[13];
+#pragma unroll
+            for (int j = 0; j < 13; ++j) {
+                const int idx = k0 + j * 256 + tid, c = idx / ncols, cc = idx - c * ncols, t = t_begin - 1 + cc;
+                v[j] = (idx < total && t >= 0 && t < T) ? hb[(int64_t)c * T + t] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 13; ++j) {
+                const int idx = k0 + j * 256 + tid, c = idx / ncols, cc = idx - c * ncols;
+                if (idx < total) hs[c * GEMM_LDH + cc] = v[j];
+            }
         }
-    };
-    stage(ft0, 0);
+    }
     __syncthreads();
-    for (int ft = ft0; ft < ft1; ++ft) {
-        const int buf = (ft - ft0) & 1;
-        if (ft + 1 < ft1) stage(ft + 1, buf ^ 1);
+    float *kout = kpack + ((int64_t)blk * B + b) * T * fd::KREC + pcol;   // + t*KREC
+    const float *hw = hs + hi * GEMM_LDH + l31;
+#pragma unroll 1
+    for (int tile = 0; tile < n_tiles; ++tile) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = bias;
-        const float *hw = hs[buf] + hi * GEMM_LDH + l31;
+        const float *ht = hw + tile * 32;
 #pragma unroll
-        for (int s = 0; s < 96; ++s) {     // kk = 2s+hi = tap*64 + c
+        for (int s = 0; s < 96; ++s) {     // kk = 2s+hi = tap*64 + c ; frame column = local frame + tap (column 0 is t_begin-1)
             const int tap = s >> 5, c2 = (2 * s) & 63;
-            acc = mfma32(hw[c2 * GEMM_LDH + tap], f4c(wb[s >> 2], s & 3), acc);
+            acc = mfma32(ht[c2 * GEMM_LDH + tap], f4c(wb[s >> 2], s & 3), acc);
         }
-        const int b = ft / tiles_per_utt, t0 = (ft % tiles_per_utt) * 32;
+        const int t0 = t_begin + tile * 32;
+        const unsigned base = (unsigned)(t0 + 4 * hi) * (unsigned)fd::KREC;     // < 2^32: checked on the host
+        if (t0 + 32 <= T) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int t = t0 + drow(r, hi);
-            if (t < T) kblk[((int64_t)b * T + t) * fd::KREC + pcol] = acc[r];
+            for (int r = 0; r < 16; ++r) kout[base + (unsigned)(((r & 3) + 8 * (r >> 2)) * fd::KREC)] = acc[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (t0 + drow(r, hi) < T) kout[base + (unsigned)(((r & 3) + 8 * (r >> 2)) * fd::KREC)] = acc[r];
         }
-        __syncthreads();
     }
 }
 
@@ -276,15 +314,31 @@ __global__ void __launch_bounds__(256) k_convt(const float *__restrict__ xin, co
                                                const float *__restrict__ bias, float *__restrict__ out, int Lin)
 {
     constexpr int Q = 256 / R;                 // input positions per workgroup
-    __shared__ float ws[fd::C * fd::C * 2 * R];
+    __shared__ __attribute__((aligned(16))) float ws[fd::C * fd::C * 2 * R];
     __shared__ float xs[fd::C * (Q + 2)];
     const int b = blockIdx.y, tid = threadIdx.x, q0 = blockIdx.x * Q, Lout = Lin * R;
-    for (int idx = tid; idx < fd::C * fd::C * 2 * R; idx += 256) ws[idx] = w[idx];
-    for (int idx = tid; idx < fd::C * (Q + 2); idx += 256) {
-        const int ci = idx / (Q + 2), jj = idx % (Q + 2), j = q0 - 1 + jj;
-        float v = 0.0f;
-        if (j >= 0 && j < Lin) v = lrelu(xin[((int64_t)b * fd::C + ci) * Lin + j], 0.2f);
-        xs[idx] = v;
+    {   // weights -> LDS with 16 B loads, all in flight before the writes
+        constexpr int NW4 = fd::C * fd::C * 2 * R / 4 / 256;     // float4 per thread: 8 (R=4) or 16 (R=8)
+#pragma unroll
+        for (int k0 = 0; k0 < NW4; k0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = reinterpret_cast<const float4 *>(w)[(k0 + k) * 256 + tid];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) reinterpret_cast<float4 *>(ws)[(k0 + k) * 256 + tid] = v[k];
+        }
+        constexpr int NX = (fd::C * (Q + 2) + 255) / 256;
+        float xv[NX];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int idx = k * 256 + tid, ci = idx / (Q + 2), jj = idx - ci * (Q + 2), j = q0 - 1 + jj;
+            xv[k] = (idx < fd::C * (Q + 2) && j >= 0 && j < Lin) ? lrelu(xin[((int64_t)b * fd::C + ci) * Lin + j], 0.2f) : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int idx = k * 256 + tid;
+            if (idx < fd::C * (Q + 2)) xs[idx] = xv[k];
+        }
     }
     __syncthreads();
     const int t = q0 * R + tid;
@@ -320,92 +374,123 @@ struct LvcCfg {
     static constexpr int W = 4 * WC;                            // columns per workgroup
     static constexpr int H = (DIL + 1 + 3) & ~3;                // staged halo (multiple of 4 for 16 B loads)
     static constexpr int XLD = W + 2 * H;
-    static constexpr int YLD = WC + 4;                          // y columns -1 .. WC, padded
+    static constexpr int YLD = W + 4;                           // y columns -1 .. W, padded to a multiple of 4
 };
 
 template <int HOP, int DIL>
 __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ xin, const float *__restrict__ skip,
                                                       float *__restrict__ xout, const float *__restrict__ kpack, int layer,
-                                                      const float *__restrict__ wpack, const float *__restrict__ cbias,
-                                                      int T)
+                                                      const float *__restrict__ wpack, const float *__restrict__ wref,
+                                                      const float *__restrict__ cbias, int T)
 {
     using Cfg = LvcCfg<HOP, DIL>;
     constexpr int WC = Cfg::WC, W = Cfg::W, H = Cfg::H, XLD = Cfg::XLD, YLD = Cfg::YLD;
     __shared__ __attribute__((aligned(16))) float xs[fd::C * XLD];
-    __shared__ __attribute__((aligned(16))) float ys[4][fd::C * YLD];
+    __shared__ __attribute__((aligned(16))) float ys[fd::C * YLD];
     const int Ln = T * HOP;
     const int b = blockIdx.y, w0 = blockIdx.x * W;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int cw = wave * WC;                       // first column of this wave inside the tile
     const bool wave_valid = (w0 + cw) < Ln;         // hop>=64: a wave owns whole frames; hop 8: checked per frame below
 
-    // ---- stage x' = x + skip with halo, zero outside the signal --------------------------------------
+    // ---- the frame's predicted kernel (A operand of the LVC) is requested first: its HBM latency hides under the conv
+    float4 ka0[12], ka1[12];
+    float4 bz0[4], bz1[4];
+    if constexpr (HOP >= 64) {
+        if (wave_valid) {
+            const int f = (w0 + cw) / HOP;
+            const float *rec = kpack + ((int64_t)b * T + f) * fd::KREC;
+            const float4 *kp4 = reinterpret_cast<const float4 *>(rec + layer * fd::KLAYER) + lane;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { ka0[i] = kp4[i * 64]; ka1[i] = kp4[(12 + i) * 64]; }
+            // D rows of a lane are {0..3, 8..11, 16..19, 24..27} + 4*hi: four 16 B loads per 32-row tile
+            const float4 *kb4 = reinterpret_cast<const float4 *>(rec + fd::KW + layer * 64);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bz0[j] = kb4[2 * j + hi]; bz1[j] = kb4[8 + 2 * j + hi]; }
+        }
+    }
+
+    // ---- stage x' = x + skip with halo, zero outside the signal.  All loads of a batch are in flight before the first
+    // LDS write (a load->wait->write loop would serialise the HBM round trips).
     {
         const float *xr = xin + (int64_t)b * fd::C * Ln, *sr = skip + (int64_t)b * fd::C * Ln;
-        for (int idx = tid; idx < fd::C * (XLD / 4); idx += 256) {
-            const int ci = idx / (XLD / 4), c4 = idx % (XLD / 4), g = w0 - H + 4 * c4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g >= 0 && g < Ln) {
-                const float4 a = *reinterpret_cast<const float4 *>(xr + (int64_t)ci * Ln + g);
-                const float4 s = *reinterpret_cast<const float4 *>(sr + (int64_t)ci * Ln + g);
-                v = make_float4(a.x + s.x, a.y + s.y, a.z + s.z, a.w + s.w);
+        constexpr int NF4 = XLD / 4, TOTAL = fd::C * NF4, NK = (TOTAL + 255) / 256, KB = (NK + 1) / 2;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float4 xa[KB], sa[KB];
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                const int idx = (half * KB + k) * 256 + tid, ci = idx / NF4, c4 = idx - ci * NF4, g = w0 - H + 4 * c4;
+                const bool ok = idx < TOTAL && g >= 0 && g < Ln;
+                xa[k] = ok ? *reinterpret_cast<const float4 *>(xr + (int64_t)ci * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                sa[k] = ok ? *reinterpret_cast<const float4 *>(sr + (int64_t)ci * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            *reinterpret_cast<float4 *>(xs + ci * XLD + 4 * c4) = v;
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                const int idx = (half * KB + k) * 256 + tid, ci = idx / NF4, c4 = idx - ci * NF4;
+                if (idx < TOTAL)
+                    *reinterpret_cast<float4 *>(xs + ci * XLD + 4 * c4) =
+                        make_float4(xa[k].x + sa[k].x, xa[k].y + sa[k].y, xa[k].z + sa[k].z, xa[k].w + sa[k].w);
+            }
         }
     }
     __syncthreads();
 
-    // ---- dilated conv on the matrix pipe: y columns cw-1 .. cw+WC ---------------------------------------
-    float *yw = ys[wave];
+    // ---- dilated conv: interior columns on the matrix pipe, y index = column + 1 ------------------------------------------
     if (wave_valid) {
         float4 wa[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) wa[i] = reinterpret_cast<const float4 *>(wpack)[i * 64 + lane];
-        float cb[16];
+        const float4 *cb4 = reinterpret_cast<const float4 *>(cbias);
+        float4 cb[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) cb[r] = cbias[drow(r, hi)];
-        constexpr int NT = WC / 32;
+        for (int j = 0; j < 4; ++j) cb[j] = cb4[2 * j + hi];
 #pragma unroll
-        for (int ct = 0; ct <= NT; ++ct) {
-            // tile ct < NT: columns ct*32 + l31 ; halo tile: lane 0 -> column -1, lane 1 -> column WC, others idle on column 0
-            int c;
-            bool store;
-            if (ct < NT) { c = ct * 32 + l31; store = true; }
-            else { c = (l31 == 0) ? -1 : ((l31 == 1) ? WC : 0); store = (l31 < 2); }
+        for (int ct = 0; ct < WC / 32; ++ct) {
+            const int c = cw + ct * 32 + l31;
             f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = cb[r];
-            conv96_tile<DIL, true>(acc, wa, xs, XLD, H + cw + c, hi);
-            const int g = w0 + cw + c;
-            const bool inside = (g >= 0 && g < Ln);             // y is zero-padded for the LVC taps (modules.py:240)
-            if (store) {
+            for (int r = 0; r < 16; ++r) acc[r] = f4c(cb[r >> 2], r & 3);
+            conv96_tile<DIL, true>(acc, wa, xs, XLD, H + c, hi);
+            const bool inside = (w0 + c) < Ln;              // y is zero-padded for the LVC taps (modules.py:240)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) yw[drow(r, hi) * YLD + c + 1] = inside ? lrelu(acc[r], 0.2f) : 0.0f;
+            for (int r = 0; r < 16; ++r) ys[drow(r, hi) * YLD + c + 1] = inside ? lrelu(acc[r], 0.2f) : 0.0f;
+        }
+    } else {
+        // a wave past the end of the signal still owns y columns its left neighbour's taps read: they are zero padding
+#pragma unroll
+        for (int ct = 0; ct < WC / 32; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ys[drow(r, hi) * YLD + cw + ct * 32 + l31 + 1] = 0.0f;
+    }
+    // ---- the two halo columns (-1 and W) the LVC taps reach: 2 x 32 outputs x 96 MACs on VALU, 4 threads per output ----
+    {
+        const int side = tid >> 7, o = (tid & 127) >> 2, part = tid & 3;
+        const int c = side ? W : -1, g = w0 + c;
+        float accv = 0.0f;
+        if (g >= 0 && g < Ln) {
+#pragma unroll
+            for (int j = 0; j < 24; ++j) {
+                const int kk = part * 24 + j, tap = kk >> 5, ci = kk & 31;       // kk = tap*32 + ci
+                accv += wref[(o * fd::C + ci) * 3 + tap] * lrelu(xs[ci * XLD + H + c + (tap - 1) * DIL], 0.2f);
             }
         }
+        accv += __shfl_xor(accv, 1, 64);
+        accv += __shfl_xor(accv, 2, 64);
+        if (part == 0) ys[o * YLD + c + 1] = (g >= 0 && g < Ln) ? lrelu(accv + cbias[o], 0.2f) : 0.0f;
     }
     __syncthreads();
     if (!wave_valid) return;
 
     const int64_t orow = (int64_t)b * fd::C * Ln;
     if constexpr (HOP >= 64) {
-        // ---- LVC on the matrix pipe ----------------------------------------------------------------------
-        const int f = (w0 + cw) / HOP;
-        const float *rec = kpack + ((int64_t)b * T + f) * fd::KREC;
-        const float4 *kp4 = reinterpret_cast<const float4 *>(rec + layer * fd::KLAYER) + lane;
-        float4 ka0[12], ka1[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) { ka0[i] = kp4[i * 64]; ka1[i] = kp4[(12 + i) * 64]; }
-        const float *kb = rec + fd::KW + layer * 64;
-        float bz0[16], bz1[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { bz0[r] = kb[drow(r, hi)]; bz1[r] = kb[32 + drow(r, hi)]; }
+        // ---- LVC on the matrix pipe: A = the frame's 64x96 predicted kernel, the two 32-row tiles share every B read ----
 #pragma unroll
         for (int nt = 0; nt < WC / 32; ++nt) {
             f32x16 a0, a1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { a0[r] = bz0[r]; a1[r] = bz1[r]; }
-            const float *yb = yw + hi * YLD + nt * 32 + l31;     // y index = column + 1 + (tap - 1)
+            for (int r = 0; r < 16; ++r) { a0[r] = f4c(bz0[r >> 2], r & 3); a1[r] = f4c(bz1[r >> 2], r & 3); }
+            const float *yb = ys + hi * YLD + cw + nt * 32 + l31;     // y index = column + 1 + (tap - 1)
 #pragma unroll
             for (int s = 0; s < 48; ++s) {
                 const int tap = s >> 4, c2 = (2 * s) & 31;
@@ -439,8 +524,8 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
             for (int c = 0; c < 8; ++c) z[c] = bz;
 #pragma unroll
             for (int in = 0; in < fd::C; ++in) {
-                // y window of input channel `in`: wave-relative columns fi*8-1 .. fi*8+8  -> y index fi*8 .. fi*8+9
-                const float *yr = yw + in * YLD + fi * 8;
+                // y window of input channel `in`: tile columns cw+fi*8-1 .. +8  -> y index cw+fi*8 .. +9
+                const float *yr = ys + in * YLD + cw + fi * 8;
                 const float4 y0 = *reinterpret_cast<const float4 *>(yr);
                 const float4 y1 = *reinterpret_cast<const float4 *>(yr + 4);
                 const float2 y2 = *reinterpret_cast<const float2 *>(yr + 8);
@@ -575,11 +660,12 @@ hipError_t fast_kp_gemm(const Launch &L, int B, int T)
 {
     fd_context *c = L.ctx;
     const DevWeights &w = c->w;
-    const int tiles_per_utt = (T + 31) / 32, total = B * tiles_per_utt;
-    const int tiles_per_wg = total < 16 ? total : 16;
-    const dim3 grid(fd::KREC / 128, (total + tiles_per_wg - 1) / tiles_per_wg, fd::NBLK);
+    const int tiles_per_utt = (T + 31) / 32;
+    const int chunks_per_utt = (tiles_per_utt + GEMM_CT - 1) / GEMM_CT;
+    const int chunk_tiles = (tiles_per_utt + chunks_per_utt - 1) / chunks_per_utt;     // balanced, <= GEMM_CT
+    const dim3 grid(fd::KREC / 128, B * chunks_per_utt, fd::NBLK);
     FD_LAUNCH(L, "kp_gemm", k_kp_gemm, grid, dim3(256), 0, (const float *)c->ws.kp_hB, c->ws.kpack, w.gemm_pack[0], w.gemm_pack[1],
-              w.gemm_pack[2], w.gemm_bias[0], w.gemm_bias[1], w.gemm_bias[2], B, T, tiles_per_utt, tiles_per_wg);
+              w.gemm_pack[2], w.gemm_bias[0], w.gemm_bias[1], w.gemm_bias[2], B, T, chunks_per_utt, chunk_tiles);
     return hipSuccess;
 }
 
@@ -603,7 +689,7 @@ static hipError_t launch_lvc(const Launch &L, const char *name, int n, int layer
     const int Ln = T * HOP;
     const float *kp = c->ws.kpack + (int64_t)n * B * T * fd::KREC;
     FD_LAUNCH(L, name, (k_lvc_layer<HOP, DIL>), dim3((Ln + W - 1) / W, B), dim3(256), 0, x_in, skip, x_out, kp, layer,
-              w.lvc_conv_pack[n][layer], w.blk[n].convs[layer].b, T);
+              w.lvc_conv_pack[n][layer], w.blk[n].convs[layer].w, w.blk[n].convs[layer].b, T);
     return hipSuccess;
 }
 

@@ -13,7 +13,7 @@ def fam(name):
     m = re.search(r"k_lvc_layer<(\d+)", name)
     if m:
         return "lvc_layer_h" + m.group(1)
-    m = re.search(r"(k_\w+)", name)
+    m = re.search(r"::(k_\w+)", name)
     return m.group(1) if m else name[:40]
 
 
