@@ -26,7 +26,7 @@ class FdKernelStat(ct.Structure):
 
 
 EXPORTS = ["fd_default_config", "fd_create", "fd_destroy", "fd_last_error", "fd_set_weight", "fd_commit_weights",
-           "fd_forward", "fd_sample", "fd_peak_normalize_int16", "fd_set_option", "fd_read_tap", "fd_kernel_index",
+           "fd_forward", "fd_sample", "fd_peak_normalize_int16", "fd_set_option", "fd_read_tap", "fd_kernel_index", "fd_bias_index",
            "fd_get_profile", "fd_reset_profile", "fd_version"]
 
 _lib = None
@@ -62,6 +62,7 @@ def load():
     lib.fd_read_tap.argtypes = [vp, ct.c_char_p, vp, ct.c_int64]
     lib.fd_read_tap.restype = ct.c_int64
     lib.fd_kernel_index.argtypes = [ci, ci, ci, ci]
+    lib.fd_bias_index.argtypes = [ci, ci]
     lib.fd_get_profile.argtypes = [vp, ct.POINTER(FdKernelStat), ci]
     lib.fd_reset_profile.argtypes = [vp]
     _lib = lib

@@ -296,8 +296,9 @@ void unpack_kernel_index(int p, int &layer, int &in, int &out, int &tap)
 {
     layer = p / fd::KLAYER;
     const int q = p % fd::KLAYER, r = q & 3, lane = (q >> 2) & 63, ms = q >> 8;
-    const int mt = ms / 12, s4 = ms % 12, step = 4 * s4 + r, kk = 2 * step + (lane >> 5);
-    tap = kk / fd::C; in = kk % fd::C; out = mt * 32 + (lane & 31);
+    const int mt = ms / 12, s4 = ms % 12, step = 4 * s4 + r, kk = 2 * step + (lane >> 5), row = lane & 31;
+    tap = kk / fd::C; in = kk % fd::C;
+    out = 16 * mt + (row & 15) + 32 * (row >> 4);      // inverse of kernel_tile / kernel_row
 }
 
 }  // namespace
@@ -387,8 +388,11 @@ int fd_commit_weights(fd_handle h)
                         wrow = kc.data() + (size_t)row * fd::HID * 3;
                         gb[pp] = kcb[row];
                     } else {
-                        wrow = bc.data() + (size_t)(pp - fd::KW) * fd::HID * 3;
-                        gb[pp] = bcb[pp - fd::KW];
+                        // bias record [layer][mt][row]  ->  bias_conv row layer*64 + out (view [layers,out], modules.py:339-342)
+                        const int q = pp - fd::KW, layer = q >> 6, mt = (q >> 5) & 1, row = q & 31;
+                        const int brow = layer * 64 + 16 * mt + (row & 15) + 32 * (row >> 4);
+                        wrow = bc.data() + (size_t)brow * fd::HID * 3;
+                        gb[pp] = bcb[brow];
                     }
                     for (int s4 = 0; s4 < 24; ++s4)
                         for (int r = 0; r < 4; ++r) {
@@ -408,6 +412,10 @@ int fd_commit_weights(fd_handle h)
                     for (int tap = 0; tap < 3; ++tap)
                         perm[((layer * fd::C + in) * 2 * fd::C + out) * 3 + tap] = fd::kernel_index(layer, in, out, tap);
         if ((rc = upload(h, perm.data(), perm.size() * sizeof(int), reinterpret_cast<const void **>(&w.kc_perm))) != FD_OK) return rc;
+        std::vector<int> bperm(fd::KB);
+        for (int layer = 0; layer < fd::LAYERS; ++layer)
+            for (int out = 0; out < 2 * fd::C; ++out) bperm[layer * 64 + out] = fd::bias_index(layer, out) - fd::KW;
+        if ((rc = upload(h, bperm.data(), bperm.size() * sizeof(int), reinterpret_cast<const void **>(&w.bc_perm))) != FD_OK) return rc;
     }
 #undef UP
     h->raw.clear();     // host copies are no longer needed
@@ -717,6 +725,12 @@ int fd_kernel_index(int layer, int in_ch, int out_ch, int tap)
     if (layer < 0 || layer >= fd::LAYERS || in_ch < 0 || in_ch >= fd::C || out_ch < 0 || out_ch >= 2 * fd::C || tap < 0 || tap >= 3)
         return FD_ERR_INVALID;
     return fd::kernel_index(layer, in_ch, out_ch, tap);
+}
+
+int fd_bias_index(int layer, int out_ch)
+{
+    if (layer < 0 || layer >= fd::LAYERS || out_ch < 0 || out_ch >= 2 * fd::C) return FD_ERR_INVALID;
+    return fd::bias_index(layer, out_ch);
 }
 
 int fd_get_profile(fd_handle h, fd_kernel_stat *stats, int capacity)

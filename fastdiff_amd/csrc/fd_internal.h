@@ -30,14 +30,23 @@ __host__ __device__ constexpr int down_factor(int d) { return d == 0 ? 4 : 8; } 
 
 // Packed position of predicted-kernel element K[layer][in][out][tap] inside a frame record.
 // The record of one (frame, layer) is laid out as the A operand of v_mfma_f32_32x32x2_f32:
-//   [mt = out/32][s4 = step/4][lane][r = step%4],  step = kk/2, lane = (out%32) + 32*(kk%2), kk = tap*32 + in
-// so a lane fetches four consecutive k-steps of its row with one 16-byte load.
+//   [mt][s4 = step/4][lane][r = step%4],  step = kk/2, lane = row + 32*(kk%2), kk = tap*32 + in
+// so a lane fetches four consecutive k-steps of its row with one 16-byte load.  The 64 output channels are
+// split over the two 32-row tiles so that each tile is closed under the gate (modules.py:217): gate channel
+// ch = out%32 has its sigmoid input (out < 32) and its tanh input (out >= 32) in the SAME tile, 16 rows apart:
+//   mt = ch/16,  row = ch%16 + 16*(out/32).
+// In the MFMA result a lane then holds both halves of a channel (registers r and r+8), so sigmoid*tanh needs no
+// cross-lane traffic, and for hop 256 a wave needs only ONE of the two tiles (48 instead of 96 operand registers).
+__host__ __device__ inline int kernel_row(int out) { return (out & 15) + 16 * (out >> 5); }
+__host__ __device__ inline int kernel_tile(int out) { return (out & 31) >> 4; }
 __host__ __device__ inline int kernel_index(int layer, int in, int out, int tap)
 {
     const int kk = tap * C + in, step = kk >> 1, hi = kk & 1;
-    const int s4 = step >> 2, r = step & 3, mt = out >> 5, lane = (out & 31) + 32 * hi;
+    const int s4 = step >> 2, r = step & 3, mt = kernel_tile(out), lane = kernel_row(out) + 32 * hi;
     return layer * KLAYER + ((mt * 12 + s4) * 64 + lane) * 4 + r;
 }
+// Position of predicted bias (layer, out): same [mt][row] order as the kernel rows.
+__host__ __device__ inline int bias_index(int layer, int out) { return KW + layer * 64 + kernel_tile(out) * 32 + kernel_row(out); }
 }  // namespace fd
 
 // ---------------------------------------------------------------------------------------------
@@ -66,6 +75,7 @@ struct DevWeights {
     const float *gemm_bias[fd::NBLK] = {};        // [24832] conv biases in packed order
     const float *up_pack[fd::NBLK] = {};          // ConvTranspose as per-phase A operands: [r phases][8 s4][64][4]
     const int *kc_perm = nullptr;                 // [24576] reference kernel_conv row -> packed position
+    const int *bc_perm = nullptr;                 // [256] reference bias_conv row -> position inside the bias part
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -22,7 +22,12 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c)
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ int drow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
-__device__ __forceinline__ float lrelu(float v, float s) { return fmaxf(v, v * s); }   // 0 < s < 1
+__device__ __forceinline__ float lrelu(float v, float s)   // 0 < s < 1:  max(v, s*v)
+{
+    // median(v, s*v, +inf) == max(v, s*v).  One v_med3_f32 instead of fmaxf()'s canonicalise + v_max pair, and -- unlike
+    // an inline-asm v_max -- visible to the compiler's VALU->MFMA hazard padding.
+    return __builtin_amdgcn_fmed3f(v, v * s, __builtin_inff());
+}
 __device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
 __device__ __forceinline__ float f4c(const float4 &v, int r) { return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w)); }
@@ -377,6 +382,25 @@ struct LvcCfg {
     static constexpr int YLD = W + 4;                           // y columns -1 .. W, padded to a multiple of 4
 };
 
+#ifdef FD_LVC_TIMING
+__device__ long long fd_dbg[64 * 4 * 8];
+#define FD_STAMP(i) do { if (lane == 0 && blockIdx.y == FD_LVC_TIMING && blockIdx.x >= 100 && blockIdx.x < 164) \
+        fd_dbg[((blockIdx.x - 100) * 4 + wave) * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FD_STAMP(i)
+#endif
+
+// sigmoid(a) * tanh(b) with two exponentials and one reciprocal:  (1 - v) / ((1 + u)(1 + v)),  u = e^-a, v = e^-2b.
+// The clamps keep u, v finite; beyond them sigmoid/tanh are saturated to fp32 precision anyway.
+__device__ __forceinline__ float gate(float a, float b)
+{
+    a = __builtin_amdgcn_fmed3f(a, -30.0f, 30.0f);
+    b = __builtin_amdgcn_fmed3f(b, -15.0f, 15.0f);
+    const float u = __builtin_amdgcn_exp2f(a * -1.4426950408889634f);
+    const float v = __builtin_amdgcn_exp2f(b * -2.8853900817779268f);
+    return (1.0f - v) * __builtin_amdgcn_rcpf((1.0f + u) * (1.0f + v));
+}
+
 template <int HOP, int DIL>
 __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ xin, const float *__restrict__ skip,
                                                       float *__restrict__ xout, const float *__restrict__ kpack, int layer,
@@ -384,130 +408,182 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
                                                       const float *__restrict__ cbias, int T)
 {
     using Cfg = LvcCfg<HOP, DIL>;
-    constexpr int WC = Cfg::WC, W = Cfg::W, H = Cfg::H, XLD = Cfg::XLD, YLD = Cfg::YLD;
+    constexpr int WC = Cfg::WC, W = Cfg::W, H = Cfg::H, XLD = Cfg::XLD, YLD = Cfg::YLD, NT = WC / 32;
+    // LVC work split (hop >= 64).  hop 256: the whole tile is ONE frame, so the waves split the 64 output rows instead of
+    // re-loading the same kernel four times: wave = (row tile mt, column half), 4 column tiles each, 48 operand registers.
+    // hop 64: a wave owns one frame (64 columns) and both row tiles.
+    constexpr int LT = (HOP == 256) ? 1 : 2;           // row tiles per wave
+    constexpr int LN = (HOP == 256) ? 4 : 2;           // column tiles per wave
     __shared__ __attribute__((aligned(16))) float xs[fd::C * XLD];
     __shared__ __attribute__((aligned(16))) float ys[fd::C * YLD];
     const int Ln = T * HOP;
     const int b = blockIdx.y, w0 = blockIdx.x * W;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-    const int cw = wave * WC;                       // first column of this wave inside the tile
+    const int cw = wave * WC;                       // first conv column of this wave inside the tile
     const bool wave_valid = (w0 + cw) < Ln;         // hop>=64: a wave owns whole frames; hop 8: checked per frame below
+    const int mt0 = (HOP == 256) ? (wave & 1) : 0;
+    const int lcw = (HOP == 256) ? 128 * (wave >> 1) : cw;     // first LVC column of this wave
+    FD_STAMP(0);
 
-    // ---- the frame's predicted kernel (A operand of the LVC) is requested first: its HBM latency hides under the conv
-    float4 ka0[12], ka1[12];
-    float4 bz0[4], bz1[4];
+    // ---- every global read is issued up front in the order of its latency; the first wait is at the first use --------------
+    // (a) the frame's predicted kernel + bias: A operand of the LVC (HBM)
+    float4 ka[LT][12];
+    float4 bz[LT][4];
     if constexpr (HOP >= 64) {
         if (wave_valid) {
-            const int f = (w0 + cw) / HOP;
+            const int f = (w0 + lcw) / HOP;
             const float *rec = kpack + ((int64_t)b * T + f) * fd::KREC;
             const float4 *kp4 = reinterpret_cast<const float4 *>(rec + layer * fd::KLAYER) + lane;
-#pragma unroll
-            for (int i = 0; i < 12; ++i) { ka0[i] = kp4[i * 64]; ka1[i] = kp4[(12 + i) * 64]; }
             // D rows of a lane are {0..3, 8..11, 16..19, 24..27} + 4*hi: four 16 B loads per 32-row tile
             const float4 *kb4 = reinterpret_cast<const float4 *>(rec + fd::KW + layer * 64);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { bz0[j] = kb4[2 * j + hi]; bz1[j] = kb4[8 + 2 * j + hi]; }
+            for (int m = 0; m < LT; ++m) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) ka[m][i] = kp4[((mt0 + m) * 12 + i) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bz[m][j] = kb4[(mt0 + m) * 8 + 2 * j + hi];
+            }
         }
     }
-
-    // ---- stage x' = x + skip with halo, zero outside the signal.  All loads of a batch are in flight before the first
-    // LDS write (a load->wait->write loop would serialise the HBM round trips).
+    // (b) dilated-conv weights (L2): A operand of the conv, needed right after the staging barrier
+    float4 wa[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) wa[i] = reinterpret_cast<const float4 *>(wpack)[i * 64 + lane];
+    float4 cb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cb[j] = reinterpret_cast<const float4 *>(cbias)[2 * j + hi];
+    // (c) x and skip tiles with halo (HBM), all in flight before the first LDS write
     {
         const float *xr = xin + (int64_t)b * fd::C * Ln, *sr = skip + (int64_t)b * fd::C * Ln;
-        constexpr int NF4 = XLD / 4, TOTAL = fd::C * NF4, NK = (TOTAL + 255) / 256, KB = (NK + 1) / 2;
+        constexpr int NF4 = XLD / 4, TOTAL = fd::C * NF4, NK = (TOTAL + 255) / 256;
+        constexpr int NB = (HOP == 64) ? 2 : 1, KB = (NK + NB - 1) / NB;   // hop 64 holds 104 kernel registers: two batches
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int bt = 0; bt < NB; ++bt) {
             float4 xa[KB], sa[KB];
 #pragma unroll
             for (int k = 0; k < KB; ++k) {
-                const int idx = (half * KB + k) * 256 + tid, ci = idx / NF4, c4 = idx - ci * NF4, g = w0 - H + 4 * c4;
+                const int idx = (bt * KB + k) * 256 + tid, ci = idx / NF4, c4 = idx - ci * NF4, g = w0 - H + 4 * c4;
                 const bool ok = idx < TOTAL && g >= 0 && g < Ln;
                 xa[k] = ok ? *reinterpret_cast<const float4 *>(xr + (int64_t)ci * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
                 sa[k] = ok ? *reinterpret_cast<const float4 *>(sr + (int64_t)ci * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            __builtin_amdgcn_sched_barrier(0);      // keep the loads above ahead of everything below
 #pragma unroll
             for (int k = 0; k < KB; ++k) {
-                const int idx = (half * KB + k) * 256 + tid, ci = idx / NF4, c4 = idx - ci * NF4;
+                const int idx = (bt * KB + k) * 256 + tid, ci = idx / NF4, c4 = idx - ci * NF4;
                 if (idx < TOTAL)
                     *reinterpret_cast<float4 *>(xs + ci * XLD + 4 * c4) =
                         make_float4(xa[k].x + sa[k].x, xa[k].y + sa[k].y, xa[k].z + sa[k].z, xa[k].w + sa[k].w);
             }
         }
     }
+    // (d) halo columns: thread = (side, out channel o, quarter q of the input channels); its 24 conv weights
+    //     w[o][8q..8q+7][0..2] are consecutive floats (L2), consumed after the conv
+    const int hside = tid >> 7, ho = (tid & 127) >> 2, hq = tid & 3;
     __syncthreads();
+    FD_STAMP(1);
 
-    // ---- dilated conv: interior columns on the matrix pipe, y index = column + 1 ------------------------------------------
+    // ---- dilated conv: interior columns on the matrix pipe (y index = column + 1); the LDS write-back of tile i is
+    //      issued under the MFMAs of tile i+1 ---------------------------------------------------------------------------------
     if (wave_valid) {
-        float4 wa[12];
+        f32x16 acc[NT];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) wa[i] = reinterpret_cast<const float4 *>(wpack)[i * 64 + lane];
-        const float4 *cb4 = reinterpret_cast<const float4 *>(cbias);
-        float4 cb[4];
+        for (int ct = 0; ct < NT; ++ct) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) cb[j] = cb4[2 * j + hi];
+            for (int r = 0; r < 16; ++r) acc[ct][r] = f4c(cb[r >> 2], r & 3);
+            const int col = H + cw + ct * 32 + l31;
 #pragma unroll
-        for (int ct = 0; ct < WC / 32; ++ct) {
-            const int c = cw + ct * 32 + l31;
-            f32x16 acc;
+            for (int s = 0; s < 48; ++s) {
+                const int tap = s >> 4, ci = ((2 * s) & 31) + hi;
+                const float v = lrelu(xs[ci * XLD + col + (tap - 1) * DIL], 0.2f);
+                acc[ct] = mfma32(f4c(wa[s >> 2], s & 3), v, acc[ct]);
+                if (ct > 0 && s % 3 == 1) {             // write-back of the previous tile, one row per 3 k-steps
+                    const int r = s / 3, cp = cw + (ct - 1) * 32 + l31;
+                    ys[drow(r, hi) * YLD + cp + 1] = (w0 + cp) < Ln ? lrelu(acc[ct - 1][r], 0.2f) : 0.0f;
+                }
+            }
+        }
+        {
+            const int cp = cw + (NT - 1) * 32 + l31;
+            const bool inside = (w0 + cp) < Ln;          // y is zero-padded for the LVC taps (modules.py:240)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = f4c(cb[r >> 2], r & 3);
-            conv96_tile<DIL, true>(acc, wa, xs, XLD, H + c, hi);
-            const bool inside = (w0 + c) < Ln;              // y is zero-padded for the LVC taps (modules.py:240)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ys[drow(r, hi) * YLD + c + 1] = inside ? lrelu(acc[r], 0.2f) : 0.0f;
+            for (int r = 0; r < 16; ++r) ys[drow(r, hi) * YLD + cp + 1] = inside ? lrelu(acc[NT - 1][r], 0.2f) : 0.0f;
         }
     } else {
         // a wave past the end of the signal still owns y columns its left neighbour's taps read: they are zero padding
 #pragma unroll
-        for (int ct = 0; ct < WC / 32; ++ct)
+        for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; ++r) ys[drow(r, hi) * YLD + cw + ct * 32 + l31 + 1] = 0.0f;
     }
+    FD_STAMP(2);
     // ---- the two halo columns (-1 and W) the LVC taps reach: 2 x 32 outputs x 96 MACs on VALU, 4 threads per output ----
     {
-        const int side = tid >> 7, o = (tid & 127) >> 2, part = tid & 3;
-        const int c = side ? W : -1, g = w0 + c;
+        float4 hwt[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) hwt[j] = reinterpret_cast<const float4 *>(wref + (ho * fd::C + 8 * hq) * 3)[j];
+        const float hbias = cbias[ho];
+        const int c = hside ? W : -1, g = w0 + c;
         float accv = 0.0f;
         if (g >= 0 && g < Ln) {
+            const float wv[24] = {hwt[0].x, hwt[0].y, hwt[0].z, hwt[0].w, hwt[1].x, hwt[1].y, hwt[1].z, hwt[1].w,
+                                  hwt[2].x, hwt[2].y, hwt[2].z, hwt[2].w, hwt[3].x, hwt[3].y, hwt[3].z, hwt[3].w,
+                                  hwt[4].x, hwt[4].y, hwt[4].z, hwt[4].w, hwt[5].x, hwt[5].y, hwt[5].z, hwt[5].w};
 #pragma unroll
-            for (int j = 0; j < 24; ++j) {
-                const int kk = part * 24 + j, tap = kk >> 5, ci = kk & 31;       // kk = tap*32 + ci
-                accv += wref[(o * fd::C + ci) * 3 + tap] * lrelu(xs[ci * XLD + H + c + (tap - 1) * DIL], 0.2f);
-            }
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int tap = 0; tap < 3; ++tap)
+                    accv += wv[j * 3 + tap] * lrelu(xs[(8 * hq + j) * XLD + H + c + (tap - 1) * DIL], 0.2f);
         }
         accv += __shfl_xor(accv, 1, 64);
         accv += __shfl_xor(accv, 2, 64);
-        if (part == 0) ys[o * YLD + c + 1] = (g >= 0 && g < Ln) ? lrelu(accv + cbias[o], 0.2f) : 0.0f;
+        if (hq == 0) ys[ho * YLD + c + 1] = (g >= 0 && g < Ln) ? lrelu(accv + hbias, 0.2f) : 0.0f;
     }
+    FD_STAMP(3);
     __syncthreads();
+    FD_STAMP(4);
     if (!wave_valid) return;
 
     const int64_t orow = (int64_t)b * fd::C * Ln;
     if constexpr (HOP >= 64) {
-        // ---- LVC on the matrix pipe: A = the frame's 64x96 predicted kernel, the two 32-row tiles share every B read ----
+        // ---- LVC on the matrix pipe: A = rows of the frame's 64x96 predicted kernel.  With the gate-paired row order a
+        //      lane holds sigmoid input (register r) and tanh input (r+8) of channel 16*mt + drow(r), r < 8.
+        //      The gate/residual/store epilogue of column tile i runs under the MFMAs of tile i+1. -----------------------
+        float *xo = xout + orow + (int64_t)(4 * hi) * Ln + w0 + lcw + l31;    // + channel*Ln + nt*32
+        const unsigned Lnu = (unsigned)Ln;
+        f32x16 a[LN][LT];
+        auto epilogue_row = [&](int nt, int m, int r) {          // r < 8
+            const int chl = 16 * (mt0 + m) + (r & 3) + 8 * (r >> 2);     // channel minus 4*hi
+            const float xr = xs[(chl + 4 * hi) * XLD + H + lcw + nt * 32 + l31];
+            xo[(unsigned)chl * Lnu + (unsigned)(nt * 32)] = xr + gate(a[nt][m][r], a[nt][m][r + 8]);
+        };
+        constexpr int EPI = 8 * LT, GAP = 48 / EPI;       // epilogue items per column tile, k-steps between two of them
 #pragma unroll
-        for (int nt = 0; nt < WC / 32; ++nt) {
-            f32x16 a0, a1;
+        for (int nt = 0; nt < LN; ++nt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { a0[r] = f4c(bz0[r >> 2], r & 3); a1[r] = f4c(bz1[r >> 2], r & 3); }
-            const float *yb = ys + hi * YLD + cw + nt * 32 + l31;     // y index = column + 1 + (tap - 1)
+            for (int m = 0; m < LT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a[nt][m][r] = f4c(bz[m][r >> 2], r & 3);
+            const float *yb = ys + hi * YLD + lcw + nt * 32 + l31;     // y index = column + 1 + (tap - 1)
 #pragma unroll
             for (int s = 0; s < 48; ++s) {
                 const int tap = s >> 4, c2 = (2 * s) & 31;
                 const float v = yb[c2 * YLD + tap];
-                a0 = mfma32(f4c(ka0[s >> 2], s & 3), v, a0);
-                a1 = mfma32(f4c(ka1[s >> 2], s & 3), v, a1);
-            }
-            const int c = cw + nt * 32 + l31;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ch = drow(r, hi);
-                const float xr = xs[ch * XLD + H + c];
-                xout[orow + (int64_t)ch * Ln + w0 + c] = xr + fast_sigmoid(a0[r]) * fast_tanh(a1[r]);
+                for (int m = 0; m < LT; ++m) a[nt][m] = mfma32(f4c(ka[m][s >> 2], s & 3), v, a[nt][m]);
+                if (nt > 0 && s % GAP == GAP / 2) {
+                    const int e = s / GAP;
+                    epilogue_row(nt - 1, e / 8, e % 8);
+                }
             }
+            if (nt == 0) FD_STAMP(5);
         }
+        FD_STAMP(6);
+#pragma unroll
+        for (int e = 0; e < EPI; ++e) epilogue_row(LN - 1, e / 8, e % 8);
+        FD_STAMP(7);
     } else {
-        // ---- LVC on VALU (hop 8): lane = output channel, 4 frames of 8 columns per wave -----------------------
+        // ---- LVC on VALU (hop 8): lane = output row (mt = lane/32, row = lane%32), 4 frames of 8 columns per wave ------------
         const int mt = lane >> 5;
 #pragma unroll 1
         for (int fi = 0; fi < WC / HOP; ++fi) {
@@ -519,9 +595,9 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
 #pragma unroll
             for (int i = 0; i < 12; ++i) { ke[i] = kp4[i * 64]; ko[i] = kp4[i * 64 + 32]; }
             float z[8];
-            const float bz = rec[fd::KW + layer * 64 + lane];
+            const float bzv = rec[fd::KW + layer * 64 + lane];     // bias record is [mt][row] too
 #pragma unroll
-            for (int c = 0; c < 8; ++c) z[c] = bz;
+            for (int c = 0; c < 8; ++c) z[c] = bzv;
 #pragma unroll
             for (int in = 0; in < fd::C; ++in) {
                 // y window of input channel `in`: tile columns cw+fi*8-1 .. +8  -> y index cw+fi*8 .. +9
@@ -538,16 +614,16 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
                     for (int c = 0; c < 8; ++c) z[c] += kv * yv[c + tap];
                 }
             }
-            // gate: sigmoid half lives in lanes 0..31, tanh half in lanes 32..63
+            // gate: rows 0..15 of a tile hold the sigmoid inputs, rows 16..31 the tanh inputs of the same channels
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const float zt = __shfl_down(z[c], 32, 64);
-                z[c] = fast_sigmoid(z[c]) * fast_tanh(zt);
+                const float zt = __shfl_down(z[c], 16, 64);
+                z[c] = gate(z[c], zt);
             }
-            if (lane < 32) {
-                const int c0 = cw + fi * 8;
-                float *dst = xout + orow + (int64_t)lane * Ln + w0 + c0;
-                const float *xr = xs + lane * XLD + H + c0;
+            if ((lane & 16) == 0) {
+                const int ch = 16 * mt + (lane & 15), c0 = cw + fi * 8;
+                float *dst = xout + orow + (int64_t)ch * Ln + w0 + c0;
+                const float *xr = xs + ch * XLD + H + c0;
                 const float4 o0 = make_float4(xr[0] + z[0], xr[1] + z[1], xr[2] + z[2], xr[3] + z[3]);
                 const float4 o1 = make_float4(xr[4] + z[4], xr[5] + z[5], xr[6] + z[6], xr[7] + z[7]);
                 *reinterpret_cast<float4 *>(dst) = o0;

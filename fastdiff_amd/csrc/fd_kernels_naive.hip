@@ -101,8 +101,8 @@ __global__ void k_lvc_gate(const float *y, const float *kpack, float *x, int B, 
     const int b = (int)(idx / ((int64_t)Ln * fd::C));
     const int f = t / hop;
     const float *rec = kpack + ((int64_t)b * T + f) * fd::KREC;
-    float zs = rec[fd::KW + layer * 64 + ch];
-    float zt = rec[fd::KW + layer * 64 + ch + fd::C];
+    float zs = rec[fd::bias_index(layer, ch)];
+    float zt = rec[fd::bias_index(layer, ch + fd::C)];
     for (int i = 0; i < fd::C; ++i)
         for (int k = 0; k < 3; ++k) {
             const int p = t + k - 1;
@@ -204,7 +204,7 @@ hipError_t naive_kp_gemm(const Launch &L, int B, int T)
         a.out = c->ws.kpack + (int64_t)n * B * T * fd::KREC; a.out_mode = 1; a.out_rec = fd::KREC;
         a.Cout = fd::KW; a.w = w.blk[n].kc.w; a.b = w.blk[n].kc.b; a.perm = w.kc_perm; a.out_off = 0;
         if ((e = conv1d(L, "naive_kernel_conv", a)) != hipSuccess) return e;
-        a.Cout = fd::KB; a.w = w.blk[n].bc.w; a.b = w.blk[n].bc.b; a.perm = nullptr; a.out_off = fd::KW;
+        a.Cout = fd::KB; a.w = w.blk[n].bc.w; a.b = w.blk[n].bc.b; a.perm = w.bc_perm; a.out_off = fd::KW;
         if ((e = conv1d(L, "naive_bias_conv", a)) != hipSuccess) return e;
     }
     return hipSuccess;

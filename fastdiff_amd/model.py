@@ -227,6 +227,10 @@ class FastDiff(nn.Module):
     def kernel_index(layer, in_ch, out_ch, tap):
         return _capi.load().fd_kernel_index(layer, in_ch, out_ch, tap)
 
+    @staticmethod
+    def bias_index(layer, out_ch):
+        return _capi.load().fd_bias_index(layer, out_ch)
+
     # ---- internals ----------------------------------------------------------------------------------------
     def _require_inference(self, *tensors):
         for t in tensors:

@@ -126,10 +126,11 @@ FD_API int fd_set_option(fd_handle h, const char *key, const char *value);
  * Returns the number of floats (also when host_dst is NULL), or a negative status. */
 FD_API int64_t fd_read_tap(fd_handle h, const char *name, float *host_dst, int64_t capacity);
 
-/* Position of predicted-kernel element (layer, in, out, tap) inside one frame's 24832-float packed record;
- * bias (layer, out) is at 24576 + layer*64 + out.  Lets tests unpack "kpack<n>" into the reference's
- * [B,4,32,64,3,T] view (modules.py:333-338). */
+/* Position of predicted-kernel element (layer, in, out, tap), and of predicted bias (layer, out), inside one frame's
+ * 24832-float packed record.  Lets tests unpack "kpack<n>" into the reference's [B,4,32,64,3,T] / [B,4,64,T] views
+ * (modules.py:333-342). */
 FD_API int fd_kernel_index(int layer, int in_ch, int out_ch, int tap);
+FD_API int fd_bias_index(int layer, int out_ch);
 
 /* Per-kernel timing gathered with hipEvents on the launch stream while option "profile"="1" (graph off).
  * Fills up to `capacity` entries; returns the number of distinct kernels. */

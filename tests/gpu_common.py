@@ -8,6 +8,7 @@ import synth
 STAGES = ["first", "dblock", "kp_front", "kp_gemm", "convt", "lvc", "final"]
 
 _perm = None
+_bperm = None
 
 
 def kernel_perm():
@@ -24,11 +25,18 @@ def kernel_perm():
     return _perm
 
 
+def bias_perm():
+    global _bperm
+    if _bperm is None:
+        _bperm = np.array([fastdiff_amd.FastDiff.bias_index(l, o) for l in range(4) for o in range(64)], np.int64)
+    return _bperm
+
+
 def unpack_kpack(kpack, B, T):
     """packed [B,T,24832] -> (kernels [B,24576,T], bias [B,256,T]) in the reference's conv-output layout."""
     rec = kpack.reshape(B, T, 24832)
     kern = rec[:, :, kernel_perm()].transpose(0, 2, 1)
-    bias = rec[:, :, 24576:].transpose(0, 2, 1)
+    bias = rec[:, :, bias_perm()].transpose(0, 2, 1)
     return kern, bias
 
 

@@ -110,6 +110,12 @@ def test_capi_exports_every_declared_symbol():
     idx = {lib.fd_kernel_index(l, i, o, k) for l in range(4) for i in range(32) for o in range(64) for k in range(3)}
     assert idx == set(range(24576)), "kernel_index must be a bijection onto the packed record"
     assert lib.fd_kernel_index(4, 0, 0, 0) < 0
+    bidx = {lib.fd_bias_index(l, o) for l in range(4) for o in range(64)}
+    assert bidx == set(range(24576, 24832))
+    # the gate pair (out, out+32) of a channel sits 16 rows apart in the same 32-row MFMA tile
+    for o in range(32):
+        a, b = lib.fd_kernel_index(0, 0, o, 0), lib.fd_kernel_index(0, 0, o + 32, 0)
+        assert b - a == 16 * 4 and lib.fd_bias_index(0, o + 32) - lib.fd_bias_index(0, o) == 16
 
 
 def test_struct_sizes_match_header():
