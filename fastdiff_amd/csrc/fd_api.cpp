@@ -360,6 +360,21 @@ int fd_commit_weights(fd_handle h)
         UP(transpose(f[p + ".fc_t"].w, fd::COND, fd::E_OUT), w.fc_t_T[n]);
         w.fc_t_b[n] = w.blk[n].fc_t.b;
         if ((rc = up_conv(p + ".upsample", w.blk[n].up)) != FD_OK) return rc;
+        {   // ConvTranspose1d weight [in][out][2r] -> per-phase MFMA A operands [ph][s4][lane][4], kk = sel*32 + i
+            const int r = fd::ratio(n), ks = 2 * r, pd = r / 2;
+            const std::vector<float> &uw = f[p + ".upsample"].w;
+            std::vector<float> up((size_t)r * 8 * 256);
+            for (int ph = 0; ph < r; ++ph)
+                for (int s4 = 0; s4 < 8; ++s4)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int q = 0; q < 4; ++q) {
+                            const int kk = 2 * (4 * s4 + q) + (lane >> 5), sel = kk >> 5, i = kk & 31, o = lane & 31;
+                            // sel 0: the nearer input position (jA), sel 1: the one before it (jB = jA - 1, tap + r)
+                            const int kA = (ph < pd) ? ph + pd : ph - pd, k = sel ? kA + r : kA;
+                            up[(((size_t)ph * 8 + s4) * 64 + lane) * 4 + q] = uw[((size_t)i * fd::C + o) * ks + k];
+                        }
+            UP(up, w.up_pack[n]);
+        }
         if ((rc = up_conv(p + ".kernel_predictor.input_conv.0", w.blk[n].kp_in)) != FD_OK) return rc;
         UP(pack_A(f[p + ".kernel_predictor.input_conv.0"].w, fd::HID, fd::COND, 5), w.kp_in_pack[n]);
         for (int j = 0; j < 6; ++j) {

@@ -238,10 +238,10 @@ __global__ void __launch_bounds__(256) k_kp_conv(const float *__restrict__ in, f
 // (B = weights, register-stationary: 96 VGPRs per wave, loaded once and reused for every frame tile of the
 // workgroup's chunk).  Output goes out frame-major so the LVC kernel reads a frame's record contiguously.
 // =================================================================================================
-constexpr int GEMM_CT = 8;                       // frame tiles (of 32) per workgroup chunk
+constexpr int GEMM_CT = 9;                       // frame tiles (of 32) per workgroup chunk (T=864 -> 3 chunks of 9)
 constexpr int GEMM_LDH = GEMM_CT * 32 + 4;       // 256 frames + 1 halo each side, padded
 
-// The workgroup stages its whole chunk of h (64 x 258 floats, 66 KB) once, so the tile loop has no barrier and
+// The workgroup stages its whole chunk of h (64 x 290 floats, 75 KB) once, so the tile loop has no barrier and
 // no staging: per 32-frame tile a wave issues 96 MFMAs, 96 LDS reads with immediate offsets and 16 stores.
 __global__ void __launch_bounds__(256, 2) k_kp_gemm(const float *__restrict__ h /*[3][B][64][T]*/, float *__restrict__ kpack,
                                                     const float *g0, const float *g1, const float *g2, const float *gb0,
@@ -311,57 +311,71 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm(const float *__restrict__ h 
 }
 
 // =================================================================================================
-// a6: ConvTranspose1d(32,32,2r,stride r) of leaky_relu(x,0.2) (modules.py:163-166,205-206) -- VALU v1
-// out[o, q*r+ph] = b[o] + sum_i x[i,jA]*W[i,o,kA] + x[i,jB]*W[i,o,kB]
+// a6: ConvTranspose1d(32,32,2r,stride r,pad r/2) of leaky_relu(x,0.2) (modules.py:163-166,205-206)
 // =================================================================================================
+// out[o, q*R + ph] = b[o] + sum_i x[i, q + offA]*W[i, o, kA] + x[i, q + offB]*W[i, o, kB]: for each of the R output phases a
+// 32x64 by 64x(columns) product on the matrix pipe, rows = output channel, cols = input position q, k = (tap select, i).
+// A operands (per-phase weight slices) are pre-packed [phase][s4][lane][4]; B comes from an LDS window of leaky_relu(x).
+constexpr int CT_LD = 132;     // 128 input positions + 1 halo each side, padded
+
 template <int R>
-__global__ void __launch_bounds__(256) k_convt(const float *__restrict__ xin, const float *__restrict__ w,
+__global__ void __launch_bounds__(256, 2) k_convt(const float *__restrict__ xin, const float *__restrict__ pack,
                                                const float *__restrict__ bias, float *__restrict__ out, int Lin)
 {
-    constexpr int Q = 256 / R;                 // input positions per workgroup
-    __shared__ __attribute__((aligned(16))) float ws[fd::C * fd::C * 2 * R];
-    __shared__ float xs[fd::C * (Q + 2)];
-    const int b = blockIdx.y, tid = threadIdx.x, q0 = blockIdx.x * Q, Lout = Lin * R;
-    {   // weights -> LDS with 16 B loads, all in flight before the writes
-        constexpr int NW4 = fd::C * fd::C * 2 * R / 4 / 256;     // float4 per thread: 8 (R=4) or 16 (R=8)
+    __shared__ float xs[fd::C * CT_LD];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int q0 = blockIdx.x * 128, Lout = Lin * R;
+    {
+        constexpr int TOTAL = fd::C * 130, NK = (TOTAL + 255) / 256;
+        float v[NK];
 #pragma unroll
-        for (int k0 = 0; k0 < NW4; k0 += 8) {
-            float4 v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = reinterpret_cast<const float4 *>(w)[(k0 + k) * 256 + tid];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) reinterpret_cast<float4 *>(ws)[(k0 + k) * 256 + tid] = v[k];
-        }
-        constexpr int NX = (fd::C * (Q + 2) + 255) / 256;
-        float xv[NX];
-#pragma unroll
-        for (int k = 0; k < NX; ++k) {
-            const int idx = k * 256 + tid, ci = idx / (Q + 2), jj = idx - ci * (Q + 2), j = q0 - 1 + jj;
-            xv[k] = (idx < fd::C * (Q + 2) && j >= 0 && j < Lin) ? lrelu(xin[((int64_t)b * fd::C + ci) * Lin + j], 0.2f) : 0.0f;
+        for (int k = 0; k < NK; ++k) {
+            const int idx = k * 256 + tid, ci = idx / 130, jj = idx - ci * 130, j = q0 - 1 + jj;
+            v[k] = (idx < TOTAL && j >= 0 && j < Lin) ? lrelu(xin[((int64_t)b * fd::C + ci) * Lin + j], 0.2f) : 0.0f;
         }
 #pragma unroll
-        for (int k = 0; k < NX; ++k) {
-            const int idx = k * 256 + tid;
-            if (idx < fd::C * (Q + 2)) xs[idx] = xv[k];
+        for (int k = 0; k < NK; ++k) {
+            const int idx = k * 256 + tid, ci = idx / 130, jj = idx - ci * 130;
+            if (idx < TOTAL) xs[ci * CT_LD + jj] = v[k];
         }
     }
     __syncthreads();
-    const int t = q0 * R + tid;
-    if (t >= Lout) return;
-    const int p = R / 2;
-    const int jA = (t + p) / R, kA = t + p - jA * R, jB = jA - 1, kB = kA + R;   // kA in [0,R), kB in [R,2R)
-    const int ja = jA - (q0 - 1), jb = jB - (q0 - 1);
-    float acc[fd::C];
+    const int ql = wave * 32 + l31, q = q0 + ql;
+    if (q0 + wave * 32 >= Lin) return;
+    float4 cb[4];
 #pragma unroll
-    for (int o = 0; o < fd::C; ++o) acc[o] = bias[o];
-    for (int i = 0; i < fd::C; ++i) {
-        const float xa = xs[i * (Q + 2) + ja], xb = xs[i * (Q + 2) + jb];
-        const float *wi = ws + i * fd::C * 2 * R;
+    for (int j = 0; j < 4; ++j) cb[j] = reinterpret_cast<const float4 *>(bias)[2 * j + hi];
+    float *ob = out + ((int64_t)b * fd::C + 4 * hi) * Lout + (int64_t)q * R;
+    const unsigned Lu = (unsigned)Lout;
+    float4 wa[2][8];
 #pragma unroll
-        for (int o = 0; o < fd::C; ++o) acc[o] += xa * wi[o * 2 * R + kA] + xb * wi[o * 2 * R + kB];
+    for (int i = 0; i < 8; ++i) wa[0][i] = reinterpret_cast<const float4 *>(pack)[i * 64 + lane];
+    f32x16 acc[R];
+#pragma unroll
+    for (int ph = 0; ph < R; ++ph) {
+        if (ph + 1 < R) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wa[(ph + 1) & 1][i] = reinterpret_cast<const float4 *>(pack)[((ph + 1) * 8 + i) * 64 + lane];
+        }
+        const int offA = (ph < R / 2) ? 0 : 1, offB = offA - 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ph][r] = f4c(cb[r >> 2], r & 3);
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {          // kk = 2s+hi = sel*32 + i
+            const int sel = s >> 4, i = ((2 * s) & 31) + hi;
+            acc[ph] = mfma32(f4c(wa[ph & 1][s >> 2], s & 3), xs[i * CT_LD + 1 + ql + (sel ? offB : offA)], acc[ph]);
+        }
     }
+    // a lane holds the R consecutive outputs q*R .. q*R+R-1 of 16 channels: 16 B stores, 32 lanes cover 32*R contiguous floats
+    if (q < Lin) {
 #pragma unroll
-    for (int o = 0; o < fd::C; ++o) out[((int64_t)b * fd::C + o) * Lout + t] = acc[o];
+        for (int r = 0; r < 16; ++r) {
+            float *dst = ob + (unsigned)((r & 3) + 8 * (r >> 2)) * Lu;
+#pragma unroll
+            for (int p4 = 0; p4 < R; p4 += 4)
+                *reinterpret_cast<float4 *>(dst + p4) = make_float4(acc[p4][r], acc[p4 + 1][r], acc[p4 + 2][r], acc[p4 + 3][r]);
+        }
+    }
 }
 
 // =================================================================================================
@@ -748,10 +762,11 @@ hipError_t fast_kp_gemm(const Launch &L, int B, int T)
 hipError_t fast_convt(const Launch &L, int n, const float *x_in, float *x_out, int B, int Lin)
 {
     const DevWeights &w = L.ctx->w;
+    const dim3 grid((Lin + 127) / 128, B);
     if (fd::ratio(n) == 8)
-        FD_LAUNCH(L, "convt_r8", k_convt<8>, dim3((Lin + 31) / 32, B), dim3(256), 0, x_in, w.blk[n].up.w, w.blk[n].up.b, x_out, Lin);
+        FD_LAUNCH(L, "convt_r8", k_convt<8>, grid, dim3(256), 0, x_in, w.up_pack[n], w.blk[n].up.b, x_out, Lin);
     else
-        FD_LAUNCH(L, "convt_r4", k_convt<4>, dim3((Lin + 63) / 64, B), dim3(256), 0, x_in, w.blk[n].up.w, w.blk[n].up.b, x_out, Lin);
+        FD_LAUNCH(L, "convt_r4", k_convt<4>, grid, dim3(256), 0, x_in, w.up_pack[n], w.blk[n].up.b, x_out, Lin);
     return hipSuccess;
 }
 
