@@ -46,6 +46,13 @@ typedef struct {
 
 int fdo_real_bytes(void) { return (int)sizeof(real); }
 
+#ifdef _OPENMP
+#include <omp.h>
+int fdo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
+#else
+int fdo_set_threads(int n) { (void)n; return 1; }
+#endif
+
 /* ------------------------------------------------------------------ */
 /* elementary ops                                                      */
 /* ------------------------------------------------------------------ */

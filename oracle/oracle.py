@@ -79,6 +79,10 @@ class Oracle:
         self._wptr = None
         self.table = self.embed_table()
 
+    def set_threads(self, n):
+        """OpenMP threads used by the oracle; returns the count in effect."""
+        return int(self.lib.fdo_set_threads(int(n)))
+
     # -- helpers -----------------------------------------------------------------------------
     def _a(self, x):
         return np.ascontiguousarray(x, dtype=self.dtype)

@@ -1,16 +1,25 @@
 #!/bin/bash
-# One GPU-box session: diagnostics -> tests -> smoke -> bench -> rocprof.  Everything lands in gpurun_out/.
+# One full GPU-box session: tests -> smoke -> bench -> rocprofv3 kernel stats -> PMC passes.  Results land in gpurun_out/.
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1
-echo "== diag" ; timeout 900 python tools/gpu_diag.py > gpurun_out/diag.log 2>&1 ; echo "diag rc=$?" ; tail -25 gpurun_out/diag.log
-echo "== pytest gpu" ; timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1 ; echo "pytest rc=$?" ; tail -40 gpurun_out/pytest_gpu.log
-echo "== smoke" ; timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1 ; echo "smoke rc=$?" ; tail -3 gpurun_out/smoke.log
-echo "== bench" ; timeout 900 python bench.py --steps 10 --warmup 2 > gpurun_out/bench.log 2>&1 ; echo "bench rc=$?" ; tail -5 gpurun_out/bench.log
+echo "== pytest gpu" ; timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1 ; echo "pytest rc=$?" ; tail -4 gpurun_out/pytest_gpu.log
+echo "== smoke" ; timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1 ; echo "smoke rc=$?" ; tail -1 gpurun_out/smoke.log
+echo "== bench" ; timeout 900 python bench.py > gpurun_out/bench.log 2>&1 ; echo "bench rc=$?" ; grep '^{' gpurun_out/bench.log | cut -c1-900
+echo "== bench N=1000 B=1 (config 3)" ; timeout 900 python bench.py --batch 1 --nsteps 1000 --steps 2 --warmup 1 --no-roofline --no-cpu-baseline > gpurun_out/bench_n1000.log 2>&1 ; grep '^{' gpurun_out/bench_n1000.log | cut -c1-400
+echo "== bench B=1 N=4" ; timeout 900 python bench.py --batch 1 --steps 20 --no-cpu-baseline > gpurun_out/bench_b1.log 2>&1 ; grep '^{' gpurun_out/bench_b1.log | cut -c1-400
 echo "== rocprof kernel-trace"
-cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-roofline --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1 ; echo "rocprof rc=$?"
-cd $GRAFT_REPO_ROOT; ls -R gpurun_out/prof 2>/dev/null | head -20
-f=$(find gpurun_out/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -40 "$f"
-# keep only the small summaries (the merge-back limit is 64 MiB)
-find gpurun_out/prof -name '*kernel_trace.csv' -size +20M -delete 2>/dev/null
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o kt -- python $R/bench.py --steps 5 --warmup 1 --no-roofline --no-cpu-baseline > $R/gpurun_out/rocprof.log 2>&1 ; echo "rocprof rc=$?"
+cd $R; find gpurun_out/prof -name '*kernel_trace.csv' -size +20M -delete 2>/dev/null
+echo "== PMC"
+OUT=$R/gpurun_out/pmc; mkdir -p $OUT; cd /tmp
+CMD="python $R/bench.py --steps 2 --warmup 1 --no-roofline --no-cpu-baseline --no-graph"
+pass() { name=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT -o $name -- $CMD > $OUT/$name.log 2>&1; echo "$name rc=$?"; }
+pass p1 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
+pass p2 FETCH_SIZE
+pass p3 WRITE_SIZE
+pass p4 SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_MFMA
+cd $R; python tools/pmc_summary.py $OUT --json $OUT/pmc_traffic.json > $OUT/summary.txt 2>&1; cat $OUT/summary.txt | grep -v "at::native\|rocclr"
+find $OUT -name '*.csv' -size +8M -delete

@@ -1,12 +1,24 @@
-"""Aggregate rocprofv3 counter_collection CSVs per kernel family: mean counter value per dispatch."""
+"""Aggregate rocprofv3 counter_collection CSVs per kernel family (mean per dispatch) and derive HBM traffic.
+
+    python tools/pmc_summary.py <dir with pN_counter_collection.csv> [--json out.json]
+
+HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE reports half of the bytes of a wide
+coalesced read stream (MI355X_MICROARCH.md, HBM section).  Calibration in our own access pattern: final_conv_update reads
+32 channels + x (233.6 MB at B=8,T=864) and FETCH_SIZE*2*1024 = 243 MB; first_conv writes exactly 226.5 MB and
+WRITE_SIZE*1024 = 226.5 MB.
+"""
 import csv
 import glob
+import json
 import os
 import re
 import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+BENCH_NAME = {"k_kp_gemm": "kp_gemm", "k_final": "final_conv_update", "k_first_conv": "first_conv", "k_embed": "embed",
+              "k_dblock": "dblock", "k_convt": "convt", "k_kp_conv": "kp_conv", "k_advance": "advance_step",
+              "k_init_noise": "init_noise"}
 
 
 def fam(name):
@@ -14,7 +26,7 @@ def fam(name):
     if m:
         return "lvc_layer_h" + m.group(1)
     m = re.search(r"::(k_\w+)", name)
-    return m.group(1) if m else name[:40]
+    return BENCH_NAME.get(m.group(1), m.group(1)) if m else name[:40]
 
 
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
@@ -30,6 +42,21 @@ for f in sorted(glob.glob(os.path.join(out, "p1_kernel_trace.csv"))):
         for row in csv.DictReader(fh):
             k = fam(row["Kernel_Name"])
             dur[k][0] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"]); dur[k][1] += 1
+traffic = {}
 for k in sorted(acc, key=lambda k: -dur[k][0]):
     d = dur[k][0] / max(dur[k][1], 1)
-    print(f"{k:22s} n={dur[k][1]:4d} avg_us={d/1e3:9.1f} " + " ".join(f"{c}={v[0]/v[1]:.4g}" for c, v in sorted(acc[k].items())))
+    c = {n: v[0] / v[1] for n, v in acc[k].items()}
+    line = f"{k:20s} n={dur[k][1]:4d} avg_us={d/1e3:9.1f}"
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        hbm = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+        traffic[k] = round(hbm)
+        line += f" hbm_MB={hbm/1e6:8.1f} (fetch*2={2*c['FETCH_SIZE']*1024/1e6:.1f} write={c['WRITE_SIZE']*1024/1e6:.1f})"
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("GRBM_GUI_ACTIVE"):
+        line += f" mfma_busy={c['SQ_VALU_MFMA_BUSY_CYCLES']/(c['GRBM_GUI_ACTIVE']/8*1024):.3f}"
+    for n in ("SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_LDS_BANK_CONFLICT"):
+        if n in c:
+            line += f" {n[3:]}={c[n]:.3g}"
+    print(line)
+if "--json" in sys.argv:
+    with open(sys.argv[sys.argv.index("--json") + 1], "w") as fh:
+        json.dump(traffic, fh, indent=1, sort_keys=True)
