@@ -152,6 +152,10 @@ int fd_create(const fd_config *cfg, int device, fd_handle *out)
     fd_context *c = new fd_context();
     c->cfg = *cfg;
     c->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
+    }
     for (int i = 0; i < ST_COUNT; ++i) c->fast[i] = true;
     if ((e = hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc(&c->scratch, 65536)) != hipSuccess) {

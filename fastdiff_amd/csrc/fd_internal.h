@@ -114,6 +114,7 @@ struct ProfEntry { std::string name; hipEvent_t e0, e1; };
 struct fd_context {
     fd_config cfg;
     int device = 0;
+    int num_cus = 256;
     std::string err;
     bool committed = false;
     bool fast[ST_COUNT];

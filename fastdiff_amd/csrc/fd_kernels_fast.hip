@@ -238,75 +238,114 @@ __global__ void __launch_bounds__(256) k_kp_conv(const float *__restrict__ in, f
 // (B = weights, register-stationary: 96 VGPRs per wave, loaded once and reused for every frame tile of the
 // workgroup's chunk).  Output goes out frame-major so the LVC kernel reads a frame's record contiguously.
 // =================================================================================================
-constexpr int GEMM_CT = 9;                       // frame tiles (of 32) per workgroup chunk (T=864 -> 3 chunks of 9)
-constexpr int GEMM_LDH = GEMM_CT * 32 + 4;       // 256 frames + 1 halo each side, padded
+constexpr int GEMM_CT = 4;                       // frame tiles (of 32) per work item
+constexpr int GEMM_LDH = GEMM_CT * 32 + 4;       // 128 frames + 1 halo each side, padded
+constexpr int GEMM_NCOLS = GEMM_CT * 32 + 2;
+constexpr int GEMM_NK = (fd::HID * GEMM_NCOLS + 255) / 256;   // staged floats per thread
 
-// The workgroup stages its whole chunk of h (64 x 290 floats, 75 KB) once, so the tile loop has no barrier and
-// no staging: per 32-frame tile a wave issues 96 MFMAs, 96 LDS reads with immediate offsets and 16 stores.
+#ifdef FD_GEMM_TIMING
+__device__ long long fd_gdbg[64 * 4 * 4];
+#endif
+
+// Persistent, software-pipelined form.  A work item = (LVC block, 128-column group, utterance, chunk of <= 4 frame tiles).
+// Each of the 2 x #CU workgroups owns a CONTIGUOUS range of items, ordered so that consecutive items share the column
+// group: the 96 weight registers of a wave are re-loaded only when the group changes (about once per workgroup), the h
+// window of item i+1 is fetched into registers before the MFMAs of item i and written to the other LDS buffer after
+// them, and the only barrier is one per item.  The matrix pipe never waits on a prologue.
 __global__ void __launch_bounds__(256, 2) k_kp_gemm(const float *__restrict__ h /*[3][B][64][T]*/, float *__restrict__ kpack,
                                                     const float *g0, const float *g1, const float *g2, const float *gb0,
                                                     const float *gb1, const float *gb2, int B, int T, int chunks_per_utt,
-                                                    int chunk_tiles)
+                                                    int chunk_tiles, int n_items)
 {
-    __shared__ float hs[fd::HID * GEMM_LDH];
-    const int blk = blockIdx.z;
+    __shared__ float hs[2][fd::HID * GEMM_LDH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-    const float *gp = blk == 0 ? g0 : (blk == 1 ? g1 : g2);
-    const float *gb = blk == 0 ? gb0 : (blk == 1 ? gb1 : gb2);
-    const int ptile = blockIdx.x * 4 + wave, pcol = ptile * 32 + l31;
-    const int b = blockIdx.y / chunks_per_utt, chunk = blockIdx.y % chunks_per_utt;
-    const int t_begin = chunk * chunk_tiles * 32;                 // first frame of the chunk
-    const int n_frames = min(T - t_begin, chunk_tiles * 32);
-    const int n_tiles = (n_frames + 31) >> 5;
-    // weights: register-stationary B operand, one 32-column tile per wave
-    float4 wb[24];
-#pragma unroll
-    for (int i = 0; i < 24; ++i) wb[i] = reinterpret_cast<const float4 *>(gp)[((int64_t)ptile * 24 + i) * 64 + lane];
-    const float bias = gb[pcol];
-    // stage h[b][:, t_begin-1 .. t_begin+chunk_tiles*32] (zero outside the utterance).  Loads are issued in batches of
-    // 13 before any LDS write: a load->wait->write loop would serialise ~65 L2 round trips per thread.
-    {
-        const float *hb = h + ((int64_t)blk * B + b) * fd::HID * T;
-        const int ncols = chunk_tiles * 32 + 2, total = fd::HID * ncols;
-#pragma unroll 1
-        for (int k0 = 0; k0 < total; k0 += 13 * 256) {
-            float v[13];
-#pragma unroll
-            for (int j = 0; j < 13; ++j) {
-                const int idx = k0 + j * 256 + tid, c = idx / ncols, cc = idx - c * ncols, t = t_begin - 1 + cc;
-                v[j] = (idx < total && t >= 0 && t < T) ? hb[(int64_t)c * T + t] : 0.0f;
-            }
-#pragma unroll
-            for (int j = 0; j < 13; ++j) {
-                const int idx = k0 + j * 256 + tid, c = idx / ncols, cc = idx - c * ncols;
-                if (idx < total) hs[c * GEMM_LDH + cc] = v[j];
-            }
-        }
-    }
+    constexpr int XG = fd::KREC / 128;
+    const int ny = B * chunks_per_utt;
+    const int i0 = (int)((int64_t)blockIdx.x * n_items / gridDim.x), i1 = (int)((int64_t)(blockIdx.x + 1) * n_items / gridDim.x);
+    if (i0 >= i1) return;
+
+    struct Item { int blk, xg, b, t_begin; };
+    auto decode = [&](int id) {
+        Item it;
+        it.blk = id / (XG * ny);
+        const int rem = id - it.blk * (XG * ny);
+        it.xg = rem / ny;
+        const int yy = rem - it.xg * ny;
+        it.b = yy / chunks_per_utt;
+        it.t_begin = (yy - it.b * chunks_per_utt) * chunk_tiles * 32;
+        return it;
+    };
+    // h[blk][b][:, t_begin-1 .. t_begin+128] -> registers (zero outside the utterance) -> LDS buffer.  Thread = (column
+    // tid%128, row parity tid/128): every per-load address is base + j*const, so nothing per-element stays live (a flat
+    // idx/130 mapping makes the compiler keep ~100 hoisted offsets in registers and spill them).
+    float v[33];
+    const int scol = tid & 127, srow = tid >> 7;
+#define FD_GEMM_FETCH(it)                                                                                              \
+    do {                                                                                                               \
+        const float *hb__ = h + (((int64_t)(it).blk * B + (it).b) * fd::HID + srow) * T + ((it).t_begin - 1);          \
+        const bool ok__ = ((it).t_begin - 1 + scol) >= 0 && ((it).t_begin - 1 + scol) < T;                             \
+        _Pragma("unroll") for (int j = 0; j < 32; ++j) v[j] = ok__ ? hb__[(int64_t)(2 * j) * T + scol] : 0.0f;         \
+        const int t2__ = (it).t_begin + 127 + (tid & 1);     /* columns 128,129 of rows 0..63: threads 0..127 */          \
+        v[32] = (tid < 128 && t2__ < T) ? hb__[(int64_t)((tid >> 1) - srow) * T + 128 + (tid & 1)] : 0.0f;                \
+    } while (0)
+#define FD_GEMM_COMMIT(bufi)                                                                                           \
+    do {                                                                                                               \
+        float *hd__ = hs[bufi] + srow * GEMM_LDH + scol;                                                               \
+        _Pragma("unroll") for (int j = 0; j < 32; ++j) hd__[2 * j * GEMM_LDH] = v[j];                                   \
+        if (tid < 128) hs[bufi][(tid >> 1) * GEMM_LDH + 128 + (tid & 1)] = v[32];                                       \
+    } while (0)
+
+    Item cur = decode(i0);
+    FD_GEMM_FETCH(cur);
+    FD_GEMM_COMMIT(0);
     __syncthreads();
-    float *kout = kpack + ((int64_t)blk * B + b) * T * fd::KREC + pcol;   // + t*KREC
-    const float *hw = hs + hi * GEMM_LDH + l31;
+    float4 wb[24];
+    float bias = 0.0f;
+    int have_blk = -1, have_xg = -1, buf = 0;
 #pragma unroll 1
-    for (int tile = 0; tile < n_tiles; ++tile) {
-        f32x16 acc;
+    for (int i = i0; i < i1; ++i) {
+        if (cur.blk != have_blk || cur.xg != have_xg) {      // new column group: (re)load the register-stationary weights
+            const float *gp = cur.blk == 0 ? g0 : (cur.blk == 1 ? g1 : g2);
+            const float *gb = cur.blk == 0 ? gb0 : (cur.blk == 1 ? gb1 : gb2);
+            const int ptile = cur.xg * 4 + wave;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = bias;
-        const float *ht = hw + tile * 32;
-#pragma unroll
-        for (int s = 0; s < 96; ++s) {     // kk = 2s+hi = tap*64 + c ; frame column = local frame + tap (column 0 is t_begin-1)
-            const int tap = s >> 5, c2 = (2 * s) & 63;
-            acc = mfma32(ht[c2 * GEMM_LDH + tap], f4c(wb[s >> 2], s & 3), acc);
+            for (int k = 0; k < 24; ++k) wb[k] = reinterpret_cast<const float4 *>(gp)[((int64_t)ptile * 24 + k) * 64 + lane];
+            bias = gb[ptile * 32 + l31];
+            have_blk = cur.blk; have_xg = cur.xg;
         }
-        const int t0 = t_begin + tile * 32;
-        const unsigned base = (unsigned)(t0 + 4 * hi) * (unsigned)fd::KREC;     // < 2^32: checked on the host
-        if (t0 + 32 <= T) {
+        Item nxt = cur;
+        const bool more = (i + 1 < i1);
+        if (more) { nxt = decode(i + 1); FD_GEMM_FETCH(nxt); }
+        const int n_frames = min(T - cur.t_begin, chunk_tiles * 32);
+        const int n_tiles = (n_frames + 31) >> 5;
+        float *kout = kpack + ((int64_t)cur.blk * B + cur.b) * T * fd::KREC + (cur.xg * 4 + wave) * 32 + l31;   // + t*KREC
+        const float *hw = hs[buf] + hi * GEMM_LDH + l31;
+#pragma unroll 1
+        for (int tile = 0; tile < n_tiles; ++tile) {
+            f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) kout[base + (unsigned)(((r & 3) + 8 * (r >> 2)) * fd::KREC)] = acc[r];
-        } else {
+            for (int r = 0; r < 16; ++r) acc[r] = bias;
+            const float *ht = hw + tile * 32;
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (t0 + drow(r, hi) < T) kout[base + (unsigned)(((r & 3) + 8 * (r >> 2)) * fd::KREC)] = acc[r];
+            for (int s = 0; s < 96; ++s) {     // kk = 2s+hi = tap*64 + c ; frame column = local frame + tap (column 0 is t_begin-1)
+                const int tap = s >> 5, c2 = (2 * s) & 63;
+                acc = mfma32(ht[c2 * GEMM_LDH + tap], f4c(wb[s >> 2], s & 3), acc);
+            }
+            const int t0 = cur.t_begin + tile * 32;
+            const unsigned base = (unsigned)(t0 + 4 * hi) * (unsigned)fd::KREC;     // < 2^32: checked on the host
+            if (t0 + 32 <= T) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) kout[base + (unsigned)(((r & 3) + 8 * (r >> 2)) * fd::KREC)] = acc[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t0 + drow(r, hi) < T) kout[base + (unsigned)(((r & 3) + 8 * (r >> 2)) * fd::KREC)] = acc[r];
+            }
         }
+        if (more) FD_GEMM_COMMIT(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+        cur = nxt;
     }
 }
 
@@ -437,6 +476,13 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
     const bool wave_valid = (w0 + cw) < Ln;         // hop>=64: a wave owns whole frames; hop 8: checked per frame below
     const int mt0 = (HOP == 256) ? (wave & 1) : 0;
     const int lcw = (HOP == 256) ? 128 * (wave >> 1) : cw;     // first LVC column of this wave
+#ifdef FD_STAGGER
+    {   // experiment: de-synchronise the two workgroups that share a CU (ids 256..511 of the first dispatch wave start late)
+        const unsigned lid = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lid >= 256u && lid < 512u)
+            for (unsigned i = 0; i < FD_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     FD_STAMP(0);
 
     // ---- every global read is issued up front in the order of its latency; the first wait is at the first use --------------
@@ -661,6 +707,7 @@ __global__ void __launch_bounds__(256) k_final(const float *__restrict__ x32, co
     if (t0 >= L) return;
     const float bv = bias[0];
     float4 acc = make_float4(bv, bv, bv, bv);
+#pragma unroll 8
     for (int ci = 0; ci < fd::C; ++ci) {
         const float *xr = x32 + ((int64_t)b * fd::C + ci) * L;
         float v[12];
@@ -753,9 +800,11 @@ hipError_t fast_kp_gemm(const Launch &L, int B, int T)
     const int tiles_per_utt = (T + 31) / 32;
     const int chunks_per_utt = (tiles_per_utt + GEMM_CT - 1) / GEMM_CT;
     const int chunk_tiles = (tiles_per_utt + chunks_per_utt - 1) / chunks_per_utt;     // balanced, <= GEMM_CT
-    const dim3 grid(fd::KREC / 128, B * chunks_per_utt, fd::NBLK);
-    FD_LAUNCH(L, "kp_gemm", k_kp_gemm, grid, dim3(256), 0, (const float *)c->ws.kp_hB, c->ws.kpack, w.gemm_pack[0], w.gemm_pack[1],
-              w.gemm_pack[2], w.gemm_bias[0], w.gemm_bias[1], w.gemm_bias[2], B, T, chunks_per_utt, chunk_tiles);
+    const int n_items = fd::NBLK * (fd::KREC / 128) * B * chunks_per_utt;
+    const int grid = n_items < 2 * c->num_cus ? n_items : 2 * c->num_cus;              // persistent: 2 workgroups per CU
+    FD_LAUNCH(L, "kp_gemm", k_kp_gemm, dim3(grid), dim3(256), 0, (const float *)c->ws.kp_hB, c->ws.kpack, w.gemm_pack[0],
+              w.gemm_pack[1], w.gemm_pack[2], w.gemm_bias[0], w.gemm_bias[1], w.gemm_bias[2], B, T, chunks_per_utt, chunk_tiles,
+              n_items);
     return hipSuccess;
 }
 
