@@ -231,6 +231,108 @@ __global__ void __launch_bounds__(256) k_kp_conv(const float *__restrict__ in, f
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// a5 (front), fused: input conv + the six residual convs + skip add in ONE launch for all three predictors.
+// Workgroup = one (block, utterance, 48-frame tile).  All seven layers are evaluated on the same 64 columns
+// (frames t0-8 .. t0+55) with the activations ping-ponging through LDS; each k3 layer invalidates one column per side
+// (the k5 input conv is covered by the staged +-2 halo), so columns 8..55 are exact after layer 7.  Wave = (32-row
+// tile, 32-column tile).  Activations outside the utterance are forced to zero after every layer: that is the zero
+// padding each reference conv applies to its own input.
+// -------------------------------------------------------------------------------------------------
+constexpr int KPF_VALID = 48, KPF_LDI = 68, KPF_LDH = 66;
+
+struct KpFrontW {
+    const float *in_pack[fd::NBLK], *in_b[fd::NBLK];
+    const float *res_pack[fd::NBLK][6], *res_b[fd::NBLK][6];
+};
+
+__global__ void __launch_bounds__(256, 2) k_kp_front(const float *__restrict__ mel, float *__restrict__ hout, KpFrontW w,
+                                                     const float *__restrict__ noise, const StepParams *params, int sampler,
+                                                     int B, int T)
+{
+    __shared__ float xin[fd::COND * KPF_LDI];     // mel + noise, columns <-> frames t0-10 .. t0+57
+    __shared__ float h0[fd::HID * KPF_LDH];       // input-conv output (kept for the skip add), column c at index c+1
+    __shared__ float hA[fd::HID * KPF_LDH];
+    __shared__ float hB[fd::HID * KPF_LDH];
+    const int blk = blockIdx.z, b = blockIdx.y, t0 = blockIdx.x * KPF_VALID;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int mt = wave & 1, nt = wave >> 1;
+    const int step = sampler ? params->step_idx : 0;
+    const float *nz = noise + (((int64_t)step * B + b) * fd::NBLK + blk) * fd::COND;
+    {   // stage mel + noise (loads batched), zero the guard columns of the activation buffers
+        constexpr int TOTAL = fd::COND * KPF_LDI, NK = (TOTAL + 255) / 256;
+        float v[NK];
+        const float *src = mel + (int64_t)b * fd::COND * T;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int idx = k * 256 + tid, ci = idx / KPF_LDI, cc = idx - ci * KPF_LDI, t = t0 - 10 + cc;
+            v[k] = (idx < TOTAL && t >= 0 && t < T) ? src[(int64_t)ci * T + t] + nz[ci] : 0.0f;   // padding stays zero (modules.py:203)
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int idx = k * 256 + tid;
+            if (idx < TOTAL) xin[idx] = v[k];
+        }
+        if (tid < 128) {
+            const int row = tid >> 1, col = (tid & 1) ? KPF_LDH - 1 : 0;
+            h0[row * KPF_LDH + col] = 0.0f; hA[row * KPF_LDH + col] = 0.0f; hB[row * KPF_LDH + col] = 0.0f;
+        }
+    }
+    __syncthreads();
+    const int c = nt * 32 + l31;                 // this lane's column; frame t0 - 8 + c
+    const int t = t0 - 8 + c;
+    const bool inside = (t >= 0 && t < T);
+    // ---- layer 0: Conv1d(80,64,k5,pad2) + lrelu 0.1 -------------------------------------------------------------------
+    {
+        const float4 *pa = reinterpret_cast<const float4 *>(w.in_pack[blk]) + (int64_t)mt * 50 * 64 + lane;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = w.in_b[blk][mt * 32 + drow(r, hi)];
+#pragma unroll 5
+        for (int s4 = 0; s4 < 50; ++s4) {
+            const float4 a4 = pa[s4 * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kk = 8 * s4 + 2 * r, tap = kk / fd::COND, ci = kk % fd::COND + hi;     // kk = tap*80 + ci
+                acc = mfma32(f4c(a4, r), xin[ci * KPF_LDI + c + tap], acc);                        // frame t + tap - 2 -> column c + tap
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h0[(mt * 32 + drow(r, hi)) * KPF_LDH + c + 1] = inside ? lrelu(acc[r], 0.1f) : 0.0f;
+    }
+    __syncthreads();
+    // ---- six Conv1d(64,64,k3,pad1) + lrelu 0.1; the last one adds h0 and goes to HBM ----------------------------------
+    const float *src = h0;
+#pragma unroll 1
+    for (int l = 0; l < 6; ++l) {
+        float *dst = (l & 1) ? hB : hA;
+        const float4 *pa = reinterpret_cast<const float4 *>(w.res_pack[blk][l]) + (int64_t)mt * 24 * 64 + lane;
+        float4 wa[24];
+#pragma unroll
+        for (int i = 0; i < 24; ++i) wa[i] = pa[i * 64];
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = w.res_b[blk][l][mt * 32 + drow(r, hi)];
+#pragma unroll
+        for (int s = 0; s < 96; ++s) {           // kk = 2s+hi = tap*64 + ci
+            const int tap = s >> 5, ci = ((2 * s) & 63) + hi;
+            acc = mfma32(f4c(wa[s >> 2], s & 3), src[ci * KPF_LDH + c + tap], acc);               // column c + tap - 1 at index c + tap
+        }
+        if (l < 5) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(mt * 32 + drow(r, hi)) * KPF_LDH + c + 1] = inside ? lrelu(acc[r], 0.1f) : 0.0f;
+            __syncthreads();
+            src = dst;
+        } else if (inside && c >= 8 && c < 8 + KPF_VALID) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = mt * 32 + drow(r, hi);
+                hout[(((int64_t)blk * B + b) * fd::HID + o) * T + t] = lrelu(acc[r], 0.1f) + h0[o * KPF_LDH + c + 1];
+            }
+        }
+    }
+}
+
 // =================================================================================================
 // a5 (GEMM): kernel_conv + bias_conv (modules.py:315-318,330-331) as ONE fp32-MFMA GEMM per LVC block:
 //   kpack[b][t][p] = gbias[p] + sum_{tap,c} Wp[p][tap*64+c] * h[b][c][t+tap-1],   p in [0,24832)
@@ -772,24 +874,14 @@ hipError_t fast_kp_front(const Launch &L, const StepIO &io, int B, int T)
 {
     fd_context *c = L.ctx;
     const DevWeights &w = c->w;
-    const dim3 grid((T + 63) / 64, B, fd::NBLK);
-    Workspace &ws = c->ws;
-    FD_LAUNCH(L, "kp_in_conv", (k_kp_conv<fd::COND, 5, true, false>), grid, dim3(256), 0, io.mel, ws.kp_h0, (const float *)nullptr,
-              w.kp_in_pack[0], w.kp_in_pack[1], w.kp_in_pack[2], w.blk[0].kp_in.b, w.blk[1].kp_in.b, w.blk[2].kp_in.b,
-              (const float *)ws.noise, (const StepParams *)ws.params, io.sampler, B, T);
-    const float *in = ws.kp_h0;
-    for (int l = 0; l < 6; ++l) {   // h0 -> A -> B -> A -> B -> A -> B(+h0)
-        float *out = (l & 1) ? ws.kp_hB : ws.kp_hA;
-        if (l < 5)
-            FD_LAUNCH(L, "kp_res_conv", (k_kp_conv<fd::HID, 3, false, false>), grid, dim3(256), 0, in, out, (const float *)nullptr,
-                      w.kp_res_pack[0][l], w.kp_res_pack[1][l], w.kp_res_pack[2][l], w.blk[0].kp_res[l].b, w.blk[1].kp_res[l].b,
-                      w.blk[2].kp_res[l].b, (const float *)nullptr, (const StepParams *)nullptr, 0, B, T);
-        else
-            FD_LAUNCH(L, "kp_res_conv", (k_kp_conv<fd::HID, 3, false, true>), grid, dim3(256), 0, in, out, (const float *)ws.kp_h0,
-                      w.kp_res_pack[0][l], w.kp_res_pack[1][l], w.kp_res_pack[2][l], w.blk[0].kp_res[l].b, w.blk[1].kp_res[l].b,
-                      w.blk[2].kp_res[l].b, (const float *)nullptr, (const StepParams *)nullptr, 0, B, T);
-        in = out;
+    KpFrontW kw;
+    for (int n = 0; n < fd::NBLK; ++n) {
+        kw.in_pack[n] = w.kp_in_pack[n]; kw.in_b[n] = w.blk[n].kp_in.b;
+        for (int l = 0; l < 6; ++l) { kw.res_pack[n][l] = w.kp_res_pack[n][l]; kw.res_b[n][l] = w.blk[n].kp_res[l].b; }
     }
+    const dim3 grid((T + KPF_VALID - 1) / KPF_VALID, B, fd::NBLK);
+    FD_LAUNCH(L, "kp_front", k_kp_front, grid, dim3(256), 0, io.mel, c->ws.kp_hB, kw, (const float *)c->ws.noise,
+              (const StepParams *)c->ws.params, io.sampler, B, T);
     return hipSuccess;
 }
 
