@@ -58,6 +58,8 @@ def kernel_model(name, B, T):
 
 
 def family(name):
+    if os.environ.get("FD_BENCH_SPLIT"):
+        return name
     for p in ("lvc_layer_h8", "lvc_layer_h64", "lvc_layer_h256"):
         if name.startswith(p + "_"):
             return p
