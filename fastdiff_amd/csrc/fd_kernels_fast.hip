@@ -22,14 +22,22 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c)
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ int drow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+// On gfx950 fp32 VALU instructions do NOT execute under a running fp32 MFMA (tools/ubench/coexec_probe.hip: every extra
+// VALU op costs ~4 cycles of matrix-pipe time, also when it comes from the other wave of the SIMD), so the inner loops
+// must not spend VALU on addressing.  The compiler likes to pair LDS reads of neighbouring taps into ds_read2_b32, whose
+// 8-bit offsets then force a fresh v_add per row.  Hiding the relation between the per-tap offsets keeps every read a
+// plain ds_read_b32 with a 16-bit immediate from three fixed base registers.
+__device__ __forceinline__ int opaque(int x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
 __device__ __forceinline__ float lrelu(float v, float s)   // 0 < s < 1:  max(v, s*v)
 {
     // median(v, s*v, +inf) == max(v, s*v).  One v_med3_f32 instead of fmaxf()'s canonicalise + v_max pair, and -- unlike
     // an inline-asm v_max -- visible to the compiler's VALU->MFMA hazard padding.
     return __builtin_amdgcn_fmed3f(v, v * s, __builtin_inff());
 }
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
 __device__ __forceinline__ float f4c(const float4 &v, int r) { return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w)); }
 
 // =================================================================================================
@@ -75,10 +83,11 @@ template <int DIL, bool LRELU>
 __device__ __forceinline__ void conv96_tile(f32x16 &acc, const float4 (&wa)[12], const float *in, int ld, int col, int hi)
 {
     // 48 k-steps: kk = 2s+hi = tap*32 + ci
+    const int o[3] = {opaque(hi * ld + col - DIL), opaque(hi * ld + col), opaque(hi * ld + col + DIL)};
 #pragma unroll
     for (int s = 0; s < 48; ++s) {
-        const int tap = s >> 4, ci = ((2 * s) & 31) + hi;
-        float v = in[ci * ld + col + (tap - 1) * DIL];
+        const int tap = s >> 4, c2 = (2 * s) & 31;
+        float v = in[o[tap] + c2 * ld];
         if (LRELU) v = lrelu(v, 0.2f);
         acc = mfma32(f4c(wa[s >> 2], s & 3), v, acc);
     }
@@ -157,81 +166,6 @@ __global__ void __launch_bounds__(256, 2) k_dblock(const float *__restrict__ xin
 }
 
 // =================================================================================================
-// a5 (front): KernelPredictor input conv + six 64->64 convs (modules.py:293-313,328-329) -- one launch per layer,
-// all three LVC blocks' predictors in grid.z.  M = 64 out channels (2 row tiles), N = 64 frames per workgroup.
-// =================================================================================================
-template <int CIN, int KS, bool FIRST, bool LAST>
-__global__ void __launch_bounds__(256) k_kp_conv(const float *__restrict__ in, float *__restrict__ out,
-                                                 const float *__restrict__ h0, const float *pk0, const float *pk1,
-                                                 const float *pk2, const float *bs0, const float *bs1, const float *bs2,
-                                                 const float *__restrict__ noise, const StepParams *params, int sampler,
-                                                 int B, int T)
-{
-    constexpr int PAD = (KS - 1) / 2, LD = 64 + 2 * PAD + 2, NS4 = CIN * KS / 8;
-    __shared__ float xs[CIN * LD];
-    const int blk = blockIdx.z, b = blockIdx.y, t0 = blockIdx.x * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-    const float *pk = blk == 0 ? pk0 : (blk == 1 ? pk1 : pk2);
-    const float *bs = blk == 0 ? bs0 : (blk == 1 ? bs1 : bs2);
-    const float *src = FIRST ? in + (int64_t)b * CIN * T : in + ((int64_t)blk * B + b) * CIN * T;
-    const float *nz = nullptr;
-    if (FIRST) {
-        const int step = sampler ? params->step_idx : 0;
-        nz = noise + (((int64_t)step * B + b) * fd::NBLK + blk) * fd::COND;
-    }
-    {   // stage the input window; loads batched ahead of the LDS writes
-        constexpr int TOTAL = CIN * LD, NK = (TOTAL + 255) / 256, KB = (NK + 1) / 2;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float v[KB];
-#pragma unroll
-            for (int k = 0; k < KB; ++k) {
-                const int idx = (half * KB + k) * 256 + tid, ci = idx / LD, cc = idx - ci * LD, t = t0 - PAD + cc;
-                float x = 0.0f;
-                if (idx < TOTAL && t >= 0 && t < T) {
-                    x = src[(int64_t)ci * T + t];
-                    if (FIRST) x += nz[ci];        // condition = c + noise; the zero padding stays zero (modules.py:203)
-                }
-                v[k] = x;
-            }
-#pragma unroll
-            for (int k = 0; k < KB; ++k) {
-                const int idx = (half * KB + k) * 256 + tid;
-                if (idx < TOTAL) xs[idx] = v[k];
-            }
-        }
-    }
-    __syncthreads();
-    const int mt = wave & 1, nt = wave >> 1;
-    const float4 *pa = reinterpret_cast<const float4 *>(pk) + (int64_t)mt * NS4 * 64 + lane;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = bs[mt * 32 + drow(r, hi)];
-    const int col = nt * 32 + l31;
-#pragma unroll 2
-    for (int s4 = 0; s4 < NS4; ++s4) {
-        const float4 a4 = pa[s4 * 64];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int kk = 8 * s4 + 2 * r;          // even member of the pair; kk = tap*CIN + ci
-            const int tap = kk / CIN, ci = kk % CIN + hi;
-            acc = mfma32(f4c(a4, r), xs[ci * LD + col + tap], acc);
-        }
-    }
-    const int t = t0 + col;
-    if (t < T) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int o = mt * 32 + drow(r, hi);
-            const int64_t oi = (((int64_t)blk * B + b) * fd::HID + o) * T + t;
-            float v = lrelu(acc[r], 0.1f);
-            if (LAST) v += h0[oi];
-            out[oi] = v;
-        }
-    }
-}
-
-// -------------------------------------------------------------------------------------------------
 // a5 (front), fused: input conv + the six residual convs + skip add in ONE launch for all three predictors.
 // Workgroup = one (block, utterance, 48-frame tile).  All seven layers are evaluated on the same 64 columns
 // (frames t0-8 .. t0+55) with the activations ping-ponging through LDS; each k3 layer invalidates one column per side
@@ -421,17 +355,17 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm(const float *__restrict__ h 
         const int n_frames = min(T - cur.t_begin, chunk_tiles * 32);
         const int n_tiles = (n_frames + 31) >> 5;
         float *kout = kpack + ((int64_t)cur.blk * B + cur.b) * T * fd::KREC + (cur.xg * 4 + wave) * 32 + l31;   // + t*KREC
-        const float *hw = hs[buf] + hi * GEMM_LDH + l31;
 #pragma unroll 1
         for (int tile = 0; tile < n_tiles; ++tile) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = bias;
-            const float *ht = hw + tile * 32;
+            const int hc = hi * GEMM_LDH + l31 + tile * 32;
+            const int ho3[3] = {opaque(hc), opaque(hc + 1), opaque(hc + 2)};
 #pragma unroll
             for (int s = 0; s < 96; ++s) {     // kk = 2s+hi = tap*64 + c ; frame column = local frame + tap (column 0 is t_begin-1)
                 const int tap = s >> 5, c2 = (2 * s) & 63;
-                acc = mfma32(ht[c2 * GEMM_LDH + tap], f4c(wb[s >> 2], s & 3), acc);
+                acc = mfma32(hs[buf][ho3[tap] + c2 * GEMM_LDH], f4c(wb[s >> 2], s & 3), acc);
             }
             const int t0 = cur.t_begin + tile * 32;
             const unsigned base = (unsigned)(t0 + 4 * hi) * (unsigned)fd::KREC;     // < 2^32: checked on the host
@@ -578,13 +512,6 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
     const bool wave_valid = (w0 + cw) < Ln;         // hop>=64: a wave owns whole frames; hop 8: checked per frame below
     const int mt0 = (HOP == 256) ? (wave & 1) : 0;
     const int lcw = (HOP == 256) ? 128 * (wave >> 1) : cw;     // first LVC column of this wave
-#ifdef FD_STAGGER
-    {   // experiment: de-synchronise the two workgroups that share a CU (ids 256..511 of the first dispatch wave start late)
-        const unsigned lid = blockIdx.y * gridDim.x + blockIdx.x;
-        if (lid >= 256u && lid < 512u)
-            for (unsigned i = 0; i < FD_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     FD_STAMP(0);
 
     // ---- every global read is issued up front in the order of its latency; the first wait is at the first use --------------
@@ -653,11 +580,12 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
         for (int ct = 0; ct < NT; ++ct) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ct][r] = f4c(cb[r >> 2], r & 3);
-            const int col = H + cw + ct * 32 + l31;
+            const int col = hi * XLD + H + cw + ct * 32 + l31;
+            const int o[3] = {opaque(col - DIL), opaque(col), opaque(col + DIL)};
 #pragma unroll
             for (int s = 0; s < 48; ++s) {
-                const int tap = s >> 4, ci = ((2 * s) & 31) + hi;
-                const float v = lrelu(xs[ci * XLD + col + (tap - 1) * DIL], 0.2f);
+                const int tap = s >> 4, c2 = (2 * s) & 31;
+                const float v = lrelu(xs[o[tap] + c2 * XLD], 0.2f);
                 acc[ct] = mfma32(f4c(wa[s >> 2], s & 3), v, acc[ct]);
                 if (ct > 0 && s % 3 == 1) {             // write-back of the previous tile, one row per 3 k-steps
                     const int r = s / 3, cp = cw + (ct - 1) * 32 + l31;
@@ -726,11 +654,12 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
             for (int m = 0; m < LT; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a[nt][m][r] = f4c(bz[m][r >> 2], r & 3);
-            const float *yb = ys + hi * YLD + lcw + nt * 32 + l31;     // y index = column + 1 + (tap - 1)
+            const int yc = hi * YLD + lcw + nt * 32 + l31;             // y index = column + 1 + (tap - 1)
+            const int yo[3] = {opaque(yc), opaque(yc + 1), opaque(yc + 2)};
 #pragma unroll
             for (int s = 0; s < 48; ++s) {
                 const int tap = s >> 4, c2 = (2 * s) & 31;
-                const float v = yb[c2 * YLD + tap];
+                const float v = ys[yo[tap] + c2 * YLD];
 #pragma unroll
                 for (int m = 0; m < LT; ++m) a[nt][m] = mfma32(f4c(ka[m][s >> 2], s & 3), v, a[nt][m]);
                 if (nt > 0 && s % GAP == GAP / 2) {

@@ -53,6 +53,28 @@ __global__ void __launch_bounds__(256, 2) probe(const float *__restrict__ w, flo
                 acc[3] = mfma32(wb[(s + 4) % 96], wb[s], acc[3]);
             }
         }
+        if (MODE == 6) {        // conv-like: 48 steps, weights in regs as A, B = lrelu(LDS)
+#pragma unroll
+            for (int s = 0; s < 48; ++s) {
+                float v = hs[(((2 * s) & 31) + hi) * LD + 4 + l31 + (it & 7) * 16 + ((s >> 4) - 1) * 9];
+                v = __builtin_amdgcn_fmed3f(v, v * 0.2f, __builtin_inff());
+                acc[0] = mfma32(wb[s], v, acc[0]);
+            }
+#pragma unroll
+            for (int s = 0; s < 48; ++s) {
+                float v = hs[(((2 * s) & 31) + hi) * LD + 36 + l31 + (it & 7) * 16 + ((s >> 4) - 1) * 9];
+                v = __builtin_amdgcn_fmed3f(v, v * 0.2f, __builtin_inff());
+                acc[1] = mfma32(wb[s], v, acc[1]);
+            }
+        }
+        if (MODE == 7) {        // lvc-like: 48 steps x 2 row tiles sharing B from LDS, A in regs
+#pragma unroll
+            for (int s = 0; s < 48; ++s) {
+                const float v = hs[(((2 * s) & 31) + hi) * LD + 4 + l31 + (it & 7) * 16 + (s >> 4)];
+                acc[0] = mfma32(wb[s], v, acc[0]);
+                acc[1] = mfma32(wb[48 + s], v, acc[1]);
+            }
+        }
         if (MODE == 3 || MODE == 5) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[(size_t)((it & 7) * 16 + r) * 256] = acc[0][r] + acc[1][r];
@@ -99,6 +121,8 @@ int main()
         run<2>("2: 2 chains, A from LDS", w, out, grid);
         run<3>("3: 1 chain, LDS + 16 stores/96", w, out, grid);
         run<5>("5: 2 chains, LDS + 16 stores/96", w, out, grid);
+        run<6>("6: conv-like (lrelu(LDS) as B), 2x48", w, out, grid);
+        run<7>("7: lvc-like (2 row tiles share B)", w, out, grid);
     }
     return 0;
 }
