@@ -503,6 +503,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
     // hop 64: a wave owns one frame (64 columns) and both row tiles.
     constexpr int LT = (HOP == 256) ? 1 : 2;           // row tiles per wave
     constexpr int LN = (HOP == 256) ? 4 : 2;           // column tiles per wave
+    constexpr bool PREACT = (HOP == 256);              // xs holds leaky_relu(x'), the raw residual lives in registers (hop 64: no register room)
     __shared__ __attribute__((aligned(16))) float xs[fd::C * XLD];
     __shared__ __attribute__((aligned(16))) float ys[fd::C * YLD];
     const int Ln = T * HOP;
@@ -560,9 +561,18 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
 #pragma unroll
             for (int k = 0; k < KB; ++k) {
                 const int idx = (bt * KB + k) * 256 + tid, ci = idx / NF4, c4 = idx - ci * NF4;
-                if (idx < TOTAL)
-                    *reinterpret_cast<float4 *>(xs + ci * XLD + 4 * c4) =
-                        make_float4(xa[k].x + sa[k].x, xa[k].y + sa[k].y, xa[k].z + sa[k].z, xa[k].w + sa[k].w);
+                if (idx < TOTAL) {
+                    const float4 r = make_float4(xa[k].x + sa[k].x, xa[k].y + sa[k].y, xa[k].z + sa[k].z, xa[k].w + sa[k].w);
+                    if constexpr (PREACT) {
+                        // the conv reads every element three times (once per tap): activate once here instead of per read.
+                        // The raw values of the centre columns (the residual) are parked in ys until the conv overwrites it.
+                        *reinterpret_cast<float4 *>(xs + ci * XLD + 4 * c4) =
+                            make_float4(lrelu(r.x, 0.2f), lrelu(r.y, 0.2f), lrelu(r.z, 0.2f), lrelu(r.w, 0.2f));
+                        if (c4 >= H / 4 && c4 < H / 4 + W / 4) *reinterpret_cast<float4 *>(ys + ci * YLD + 4 * c4 - H) = r;
+                    } else {
+                        *reinterpret_cast<float4 *>(xs + ci * XLD + 4 * c4) = r;
+                    }
+                }
             }
         }
     }
@@ -571,6 +581,18 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
     const int hside = tid >> 7, ho = (tid & 127) >> 2, hq = tid & 3;
     __syncthreads();
     FD_STAMP(1);
+    // residual values of this lane's outputs (hop >= 64): registers, so that ys can take the conv output
+    float resid[PREACT ? LN : 1][PREACT ? 8 * LT : 1];
+    if constexpr (PREACT) {
+#pragma unroll
+        for (int nt = 0; nt < LN; ++nt)
+#pragma unroll
+            for (int m = 0; m < LT; ++m)
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    resid[nt][m * 8 + r] = ys[(16 * (mt0 + m) + (r & 3) + 8 * (r >> 2) + 4 * hi) * YLD + lcw + nt * 32 + l31];
+        __syncthreads();
+    }
 
     // ---- dilated conv: interior columns on the matrix pipe (y index = column + 1); the LDS write-back of tile i is
     //      issued under the MFMAs of tile i+1 ---------------------------------------------------------------------------------
@@ -585,7 +607,8 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
 #pragma unroll
             for (int s = 0; s < 48; ++s) {
                 const int tap = s >> 4, c2 = (2 * s) & 31;
-                const float v = lrelu(xs[o[tap] + c2 * XLD], 0.2f);
+                const float xv = xs[o[tap] + c2 * XLD];
+                const float v = PREACT ? xv : lrelu(xv, 0.2f);
                 acc[ct] = mfma32(f4c(wa[s >> 2], s & 3), v, acc[ct]);
                 if (ct > 0 && s % 3 == 1) {             // write-back of the previous tile, one row per 3 k-steps
                     const int r = s / 3, cp = cw + (ct - 1) * 32 + l31;
@@ -623,7 +646,10 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
             for (int j = 0; j < 8; ++j)
 #pragma unroll
                 for (int tap = 0; tap < 3; ++tap)
-                    accv += wv[j * 3 + tap] * lrelu(xs[(8 * hq + j) * XLD + H + c + (tap - 1) * DIL], 0.2f);
+                {
+                    const float xv = xs[(8 * hq + j) * XLD + H + c + (tap - 1) * DIL];
+                    accv += wv[j * 3 + tap] * (PREACT ? xv : lrelu(xv, 0.2f));
+                }
         }
         accv += __shfl_xor(accv, 1, 64);
         accv += __shfl_xor(accv, 2, 64);
@@ -644,7 +670,9 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
         f32x16 a[LN][LT];
         auto epilogue_row = [&](int nt, int m, int r) {          // r < 8
             const int chl = 16 * (mt0 + m) + (r & 3) + 8 * (r >> 2);     // channel minus 4*hi
-            const float xr = xs[(chl + 4 * hi) * XLD + H + lcw + nt * 32 + l31];
+            float xr;
+            if constexpr (PREACT) xr = resid[nt][m * 8 + r];
+            else xr = xs[(chl + 4 * hi) * XLD + H + lcw + nt * 32 + l31];
             xo[(unsigned)chl * Lnu + (unsigned)(nt * 32)] = xr + gate(a[nt][m][r], a[nt][m][r + 8]);
         };
         constexpr int EPI = 8 * LT, GAP = 48 / EPI;       // epilogue items per column tile, k-steps between two of them
