@@ -43,9 +43,9 @@ def kernel_model(name, B, T):
     if name == "kp_gemm":
         # all 3 LVC blocks in one launch: [24832 x 192] x [192 x B*T] each, output written once
         return "mfma", 3 * 4.0 * (B * T * 24832 + 24832 * 192 + B * T * 64), 3 * 2.0 * 24832 * 192 * B * T
-    if name.startswith("kp_"):
-        cin, ks = (80, 5) if name == "kp_in_conv" else (64, 3)
-        return "mfma", 3 * 4.0 * B * T * (cin + 64), 3 * 2.0 * 64 * cin * ks * B * T
+    if name == "kp_front":
+        # input conv (K=400) + six 64->64 k3 convs (K=192) for the three predictors, fused through LDS
+        return "mfma", 3 * 4.0 * B * T * (80 + 64), 3 * 2.0 * 64 * (400 + 6 * 192) * B * T
     if name.startswith("dblock"):
         return "hbm", None, None
     if name.startswith("convt"):
