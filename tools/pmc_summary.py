@@ -17,7 +17,7 @@ from collections import defaultdict
 
 out = sys.argv[1]
 BENCH_NAME = {"k_kp_gemm": "kp_gemm", "k_final": "final_conv_update", "k_first_conv": "first_conv", "k_embed": "embed",
-              "k_dblock": "dblock", "k_convt": "convt", "k_kp_conv": "kp_conv", "k_advance": "advance_step",
+              "k_dblock": "dblock", "k_convt": "convt", "k_kp_front": "kp_front", "k_advance": "advance_step",
               "k_init_noise": "init_noise"}
 
 
