@@ -421,6 +421,46 @@ int fd_commit_weights(fd_handle h)
                 }
             UP(gp, w.gemm_pack[n]);
             UP(gb, w.gemm_bias[n]);
+            // bf16x3 form: W = W1 + W2 + W3 (round-to-nearest-even pieces); B operand of v_mfma_f32_32x32x16_bf16:
+            // lane = col + 32*g holds the 8 consecutive k = kg*16 + 8g + e, k = tap*64 + channel
+            std::vector<uint16_t> gx((size_t)(fd::KREC / 32) * 3 * 12 * 64 * 8);
+            auto bf16_rne = [](float x) -> uint16_t {
+                uint32_t u;
+                memcpy(&u, &x, 4);
+                u += 0x7FFFu + ((u >> 16) & 1u);
+                return (uint16_t)(u >> 16);
+            };
+            auto bf16_val = [](uint16_t b) -> float {
+                uint32_t u = (uint32_t)b << 16;
+                float f;
+                memcpy(&f, &u, 4);
+                return f;
+            };
+            for (int pt = 0; pt < fd::KREC / 32; ++pt)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int pp = pt * 32 + (lane & 31), g = lane >> 5;
+                    const float *wrow;
+                    if (pp < fd::KW) {
+                        int layer, in, out, tap;
+                        unpack_kernel_index(pp, layer, in, out, tap);
+                        wrow = kc.data() + (size_t)(((layer * fd::C + in) * 2 * fd::C + out) * 3 + tap) * fd::HID * 3;
+                    } else {
+                        const int q = pp - fd::KW, layer = q >> 6, mt = (q >> 5) & 1, row = q & 31;
+                        wrow = bc.data() + (size_t)(layer * 64 + 16 * mt + (row & 15) + 32 * (row >> 4)) * fd::HID * 3;
+                    }
+                    for (int kg = 0; kg < 12; ++kg)
+                        for (int e = 0; e < 8; ++e) {
+                            const int kk = kg * 16 + g * 8 + e, tap = kk / fd::HID, ch = kk % fd::HID;
+                            float r = wrow[ch * 3 + tap];
+                            for (int q = 0; q < 3; ++q) {
+                                const uint16_t piece = bf16_rne(r);
+                                gx[((((size_t)pt * 3 + q) * 12 + kg) * 64 + lane) * 8 + e] = piece;
+                                r -= bf16_val(piece);
+                            }
+                        }
+                }
+            if ((rc = upload(h, gx.data(), gx.size() * sizeof(uint16_t), reinterpret_cast<const void **>(&w.gemm_x3_pack[n]))) != FD_OK)
+                return rc;
         }
     }
     {
@@ -588,7 +628,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
 
 static unsigned mode_signature(const fd_context *h)
 {
-    unsigned s = h->keep_taps ? 1u : 0u;
+    unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_x3 ? 2u : 0u);
     for (int i = 0; i < ST_COUNT; ++i) s = (s << 1) | (h->fast[i] ? 1u : 0u);
     return s;
 }
@@ -701,6 +741,12 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
         FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: unknown stage '%s'", key);
     }
     const bool on = (v == "1" || v == "true" || v == "on");
+    if (k == "gemm") {
+        if (v == "bf16x3") h->gemm_x3 = true;
+        else if (v == "fp32") h->gemm_x3 = false;
+        else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: gemm expects bf16x3|fp32, got '%s'", value);
+        return FD_OK;
+    }
     if (k == "graph") { h->use_graph = on; return FD_OK; }
     if (k == "profile") { h->profile = on; return FD_OK; }
     if (k == "taps") { h->keep_taps = on; return FD_OK; }

@@ -73,6 +73,7 @@ struct DevWeights {
     const float *kp_res_pack[fd::NBLK][6] = {};   // 64->64 k3: 2 mt x 24 s4
     const float *gemm_pack[fd::NBLK] = {};        // kernel_conv+bias_conv as MFMA B operand: [776 ptile][24 s4][64][4]
     const float *gemm_bias[fd::NBLK] = {};        // [24832] conv biases in packed order
+    const uint16_t *gemm_x3_pack[fd::NBLK] = {};  // same weights as three bf16 pieces: [776 ptile][3][12 kg][64 lane][8]
     const float *up_pack[fd::NBLK] = {};          // ConvTranspose as per-phase A operands: [r phases][8 s4][64][4]
     const int *kc_perm = nullptr;                 // [24576] reference kernel_conv row -> packed position
     const int *bc_perm = nullptr;                 // [256] reference bias_conv row -> position inside the bias part
@@ -121,6 +122,7 @@ struct fd_context {
     bool use_graph = true;
     bool profile = false;
     bool keep_taps = false;
+    bool gemm_x3 = true;                      // kp_gemm on the bf16 pipe with the exact 3-way operand split
     std::map<std::string, std::pair<std::vector<int64_t>, std::vector<float>>> raw;   // host copies from fd_set_weight
     std::vector<void *> dev_allocs;          // weight arena pieces
     DevWeights w;

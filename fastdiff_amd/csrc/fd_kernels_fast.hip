@@ -385,6 +385,171 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm(const float *__restrict__ h 
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// kp_gemm, split-precision form ("bf16x3"): the same contraction on the bf16 matrix pipe at fp32-level accuracy.
+// Every fp32 operand is written as the exact sum of three bf16 pieces (x = x1 + x2 + x3, 8 significant bits each) and
+// the six partial products of weight <= 4 are accumulated in fp32:
+//     W*h = W1h1 + (W1h2 + W2h1) + (W1h3 + W2h2 + W3h1) + O(2^-24 |W||h|)
+// (numpy study: max error 7.9e-7 against fp64 on |K| <= 3 where a plain fp32 GEMM has 1.6e-6).  bf16 products are exact
+// in fp32, so all rounding happens in the fp32 accumulators; the leading term gets its own accumulator so that the
+// small corrections are not swamped.  v_mfma_f32_32x32x16_bf16 runs at 16x the fp32 MFMA rate: 72 of them (2304 cycles)
+// replace 96 fp32 MFMAs (6144 cycles) per 32x32 output tile, and -- unlike fp32 MFMA -- co-execute with VALU work.
+// The weight pieces are split once at load time (round-to-nearest-even), the h pieces on the fly while staging
+// (truncation: and / sub / and / sub / and).  Same persistent item walk and register-stationary weights as the fp32 form.
+// LDS image per piece: [row = frame+halo][64 channels] bf16 (128 B rows); the 16 B slot index is XOR-ed with row&7 so a
+// ds_read_b128 wave access spreads over all banks.
+// -------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int GX_CT = 2;                        // frame tiles per item
+constexpr int GX_ROWS = GX_CT * 32 + 2;         // 66 rows: frames t_begin-1 .. t_begin+64
+constexpr int GX_PIECE = GX_ROWS * 128;         // bytes per piece
+constexpr int GX_NV = 9;                        // channel PAIRS staged per thread: 8 (rows 0..63) + 1 (rows 64,65; wave 0)
+
+__device__ __forceinline__ bf16x8 as_bf16x8(const float4 &v)
+{
+    union { float4 f; bf16x8 b; } u;
+    u.f = v;
+    return u.b;
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const float4 &a, const float4 &b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b), c, 0, 0, 0);
+}
+
+__global__ void __launch_bounds__(256, 2) k_kp_gemm_x3(const float *__restrict__ h /*[3][B][64][T]*/, float *__restrict__ kpack,
+                                                       const float4 *g0, const float4 *g1, const float4 *g2, const float *gb0,
+                                                       const float *gb1, const float *gb2, int B, int T, int chunks_per_utt,
+                                                       int chunk_tiles, int n_items)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char hs[2][3 * GX_PIECE];     // 2 x 25 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    constexpr int XG = fd::KREC / 128;
+    const int ny = B * chunks_per_utt;
+    const int i0 = (int)((int64_t)blockIdx.x * n_items / gridDim.x), i1 = (int)((int64_t)(blockIdx.x + 1) * n_items / gridDim.x);
+    if (i0 >= i1) return;
+
+    struct Item { int blk, xg, b, t_begin; };
+    auto decode = [&](int id) {
+        Item it;
+        it.blk = id / (XG * ny);
+        const int rem = id - it.blk * (XG * ny);
+        it.xg = rem / ny;
+        const int yy = rem - it.xg * ny;
+        it.b = yy / chunks_per_utt;
+        it.t_begin = (yy - it.b * chunks_per_utt) * chunk_tiles * 32;
+        return it;
+    };
+    // staging map: lanes run along time (coalesced 256 B global reads), a wave takes channel pairs cp = wave, wave+4, ...;
+    // the two extra rows 64, 65 are fetched by wave 0 (lane = cp + 32*(row-64)).  One dword per pair and piece goes to LDS.
+    float va[GX_NV], vb[GX_NV];
+#define FD_GX_FETCH(it)                                                                                               \
+    do {                                                                                                              \
+        const float *hb__ = h + ((int64_t)(it).blk * B + (it).b) * fd::HID * T;                                       \
+        const int t__ = (it).t_begin - 1 + lane;                                                                      \
+        const bool ok__ = t__ >= 0 && t__ < T;                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                               \
+            const int cp = 4 * j + wave;                                                                              \
+            va[j] = ok__ ? hb__[(int64_t)(2 * cp) * T + t__] : 0.0f;                                                  \
+            vb[j] = ok__ ? hb__[(int64_t)(2 * cp + 1) * T + t__] : 0.0f;                                              \
+        }                                                                                                             \
+        const int t2__ = (it).t_begin + 63 + hi;                                                                      \
+        const bool ok2__ = wave == 0 && t2__ < T;                                                                     \
+        va[8] = ok2__ ? hb__[(int64_t)(2 * l31) * T + t2__] : 0.0f;                                                   \
+        vb[8] = ok2__ ? hb__[(int64_t)(2 * l31 + 1) * T + t2__] : 0.0f;                                               \
+    } while (0)
+    // exact three-way bf16 split by truncation; piece q of the channel pair goes to one dword of piece image q
+#define FD_GX_SPLIT_STORE(bufi, a_, b_, row_, cp_)                                                                    \
+    do {                                                                                                              \
+        unsigned a = __float_as_uint(a_), b2 = __float_as_uint(b_);                                                   \
+        const unsigned off = (unsigned)(row_) * 128u + ((((unsigned)(cp_) >> 2) ^ ((unsigned)(row_) & 7u)) << 4) + (((unsigned)(cp_) & 3u) << 2); \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                               \
+            const unsigned ah = a & 0xFFFF0000u, bh = b2 & 0xFFFF0000u;                                               \
+            *reinterpret_cast<unsigned *>(&hs[bufi][q * GX_PIECE + off]) = (ah >> 16) | bh;                            \
+            a = __float_as_uint(__uint_as_float(a) - __uint_as_float(ah));                                            \
+            b2 = __float_as_uint(__uint_as_float(b2) - __uint_as_float(bh));                                          \
+        }                                                                                                             \
+    } while (0)
+#define FD_GX_COMMIT(bufi)                                                                                            \
+    do {                                                                                                              \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) FD_GX_SPLIT_STORE(bufi, va[j], vb[j], lane, 4 * j + wave);      \
+        if (wave == 0) FD_GX_SPLIT_STORE(bufi, va[8], vb[8], 64 + hi, l31);                                           \
+    } while (0)
+
+    // per-lane byte offsets of the 12 A-operand reads of a tile (tap, 16-channel group): row = frame + tap, swizzled slot
+    unsigned aoff[12];
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const unsigned row = (unsigned)(l31 + tap);
+            aoff[tap * 4 + k4] = row * 128u + ((((unsigned)(k4 * 2 + hi)) ^ (row & 7u)) << 4);
+        }
+
+    Item cur = decode(i0);
+    FD_GX_FETCH(cur);
+    FD_GX_COMMIT(0);
+    __syncthreads();
+    float4 wq[3][12];
+    float bias = 0.0f;
+    int have_blk = -1, have_xg = -1, buf = 0;
+#pragma unroll 1
+    for (int i = i0; i < i1; ++i) {
+        if (cur.blk != have_blk || cur.xg != have_xg) {      // new column group: (re)load the register-stationary weight pieces
+            const float4 *gp = cur.blk == 0 ? g0 : (cur.blk == 1 ? g1 : g2);
+            const float *gb = cur.blk == 0 ? gb0 : (cur.blk == 1 ? gb1 : gb2);
+            const int ptile = cur.xg * 4 + wave;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int kg = 0; kg < 12; ++kg) wq[q][kg] = gp[(((int64_t)ptile * 3 + q) * 12 + kg) * 64 + lane];
+            bias = gb[ptile * 32 + l31];
+            have_blk = cur.blk; have_xg = cur.xg;
+        }
+        Item nxt = cur;
+        const bool more = (i + 1 < i1);
+        if (more) { nxt = decode(i + 1); FD_GX_FETCH(nxt); }
+        const int n_frames = min(T - cur.t_begin, chunk_tiles * 32);
+        const int n_tiles = (n_frames + 31) >> 5;
+        float *kout = kpack + ((int64_t)cur.blk * B + cur.b) * T * fd::KREC + (cur.xg * 4 + wave) * 32 + l31;   // + t*KREC
+#pragma unroll 1
+        for (int tile = 0; tile < n_tiles; ++tile) {
+            f32x16 hiacc, loacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { hiacc[r] = bias; loacc[r] = 0.0f; }
+            const unsigned char *hb = &hs[buf][tile * 32 * 128];        // row of frame 0 of this tile (tap 0 = previous frame)
+#pragma unroll
+            for (int kg = 0; kg < 12; ++kg) {      // kg = tap*4 + k4: logical k = kg*16 + 8*hi + e = tap*64 + channel
+                const float4 a1 = *reinterpret_cast<const float4 *>(hb + aoff[kg]);
+                const float4 a2 = *reinterpret_cast<const float4 *>(hb + GX_PIECE + aoff[kg]);
+                const float4 a3 = *reinterpret_cast<const float4 *>(hb + 2 * GX_PIECE + aoff[kg]);
+                hiacc = mfma_bf16(a1, wq[0][kg], hiacc);
+                loacc = mfma_bf16(a1, wq[1][kg], loacc);
+                loacc = mfma_bf16(a2, wq[0][kg], loacc);
+                loacc = mfma_bf16(a1, wq[2][kg], loacc);
+                loacc = mfma_bf16(a2, wq[1][kg], loacc);
+                loacc = mfma_bf16(a3, wq[0][kg], loacc);
+            }
+            const int t0 = cur.t_begin + tile * 32;
+            const unsigned base = (unsigned)(t0 + 4 * hi) * (unsigned)fd::KREC;
+            if (t0 + 32 <= T) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) kout[base + (unsigned)(((r & 3) + 8 * (r >> 2)) * fd::KREC)] = hiacc[r] + loacc[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t0 + drow(r, hi) < T) kout[base + (unsigned)(((r & 3) + 8 * (r >> 2)) * fd::KREC)] = hiacc[r] + loacc[r];
+            }
+        }
+        if (more) FD_GX_COMMIT(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+        cur = nxt;
+    }
+#undef FD_GX_FETCH
+#undef FD_GX_COMMIT
+#undef FD_GX_SPLIT_STORE
+}
+
 // =================================================================================================
 // a6: ConvTranspose1d(32,32,2r,stride r,pad r/2) of leaky_relu(x,0.2) (modules.py:163-166,205-206)
 // =================================================================================================
@@ -847,13 +1012,20 @@ hipError_t fast_kp_gemm(const Launch &L, int B, int T)
     fd_context *c = L.ctx;
     const DevWeights &w = c->w;
     const int tiles_per_utt = (T + 31) / 32;
-    const int chunks_per_utt = (tiles_per_utt + GEMM_CT - 1) / GEMM_CT;
-    const int chunk_tiles = (tiles_per_utt + chunks_per_utt - 1) / chunks_per_utt;     // balanced, <= GEMM_CT
+    const int ct = c->gemm_x3 ? GX_CT : GEMM_CT;
+    const int chunks_per_utt = (tiles_per_utt + ct - 1) / ct;
+    const int chunk_tiles = (tiles_per_utt + chunks_per_utt - 1) / chunks_per_utt;     // balanced, <= ct
     const int n_items = fd::NBLK * (fd::KREC / 128) * B * chunks_per_utt;
     const int grid = n_items < 2 * c->num_cus ? n_items : 2 * c->num_cus;              // persistent: 2 workgroups per CU
-    FD_LAUNCH(L, "kp_gemm", k_kp_gemm, dim3(grid), dim3(256), 0, (const float *)c->ws.kp_hB, c->ws.kpack, w.gemm_pack[0],
-              w.gemm_pack[1], w.gemm_pack[2], w.gemm_bias[0], w.gemm_bias[1], w.gemm_bias[2], B, T, chunks_per_utt, chunk_tiles,
-              n_items);
+    if (c->gemm_x3)
+        FD_LAUNCH(L, "kp_gemm_bf16x3", k_kp_gemm_x3, dim3(grid), dim3(256), 0, (const float *)c->ws.kp_hB, c->ws.kpack,
+                  reinterpret_cast<const float4 *>(w.gemm_x3_pack[0]), reinterpret_cast<const float4 *>(w.gemm_x3_pack[1]),
+                  reinterpret_cast<const float4 *>(w.gemm_x3_pack[2]), w.gemm_bias[0], w.gemm_bias[1], w.gemm_bias[2], B, T,
+                  chunks_per_utt, chunk_tiles, n_items);
+    else
+        FD_LAUNCH(L, "kp_gemm", k_kp_gemm, dim3(grid), dim3(256), 0, (const float *)c->ws.kp_hB, c->ws.kpack, w.gemm_pack[0],
+                  w.gemm_pack[1], w.gemm_pack[2], w.gemm_bias[0], w.gemm_bias[1], w.gemm_bias[2], B, T, chunks_per_utt,
+                  chunk_tiles, n_items);
     return hipSuccess;
 }
 

@@ -116,7 +116,9 @@ FD_API int fd_sample(fd_handle h, const float *mel, int B, int T, const int *len
 FD_API int fd_peak_normalize_int16(fd_handle h, const float *wav, int B, int64_t L, int16_t *pcm, void *stream);
 
 /* Options: "kernels" = "fast" | "naive" (all stages), "kernels.<stage>" for one stage
- * (embed, first, dblock, kp_front, kp_gemm, convt, lvc, final); "graph" = "1" | "0"; "profile" = "1" | "0". */
+ * (embed, first, dblock, kp_front, kp_gemm, convt, lvc, final); "graph" = "1" | "0"; "profile" = "1" | "0";
+ * "gemm" = "bf16x3" (default: exact 3-way bf16 operand split on the bf16 matrix pipe, fp32-level error) | "fp32";
+ * "taps" = "1" | "0" (keep block outputs for fd_read_tap). */
 FD_API int fd_set_option(fd_handle h, const char *key, const char *value);
 
 /* Test / introspection hooks (not on the reference's API surface) -------------------------------------- */
