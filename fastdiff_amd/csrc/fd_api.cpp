@@ -170,7 +170,7 @@ int fd_create(const fd_config *cfg, int device, fd_handle *out)
 static void free_workspace(fd_context *c)
 {
     Workspace &w = c->ws;
-    void *ptrs[] = {w.noise, w.a[0], w.a[1], w.a[2], w.a[3], w.kp_h0, w.kp_hA, w.kp_hB, w.kpack, w.xA, w.xB,
+    void *ptrs[] = {w.noise, w.a[0], w.a[1], w.a[2], w.a[3], w.kp_h0, w.kp_hA, w.kp_hB, w.kpack, w.h_x3, w.xA, w.xB,
                     w.xtap[0], w.xtap[1], w.xtap[2], w.mel, w.x, w.steps, w.params};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -506,6 +506,7 @@ static int ensure_workspace(fd_context *h, int B, int T)
     WS(w.kp_h0, (size_t)fd::NBLK * nB * fd::HID * nT); WS(w.kp_hA, (size_t)fd::NBLK * nB * fd::HID * nT);
     WS(w.kp_hB, (size_t)fd::NBLK * nB * fd::HID * nT);
     WS(w.kpack, (size_t)fd::NBLK * nB * nT * fd::KREC);
+    WS(w.h_x3, (size_t)fd::NBLK * nB * (((nT + 63) / 64) * 64 + 2) * 96 + 256);      // + slack for the rounded-up last DMA
     WS(w.xA, nB * fd::C * L); WS(w.xB, nB * fd::C * L);
     WS(w.xtap[0], nB * fd::C * L / 32); WS(w.xtap[1], nB * fd::C * L / 4); WS(w.xtap[2], nB * fd::C * L);
     WS(w.mel, (size_t)nB * fd::COND * nT); WS(w.x, nB * L); WS(w.steps, (size_t)std::max(nB, 64));

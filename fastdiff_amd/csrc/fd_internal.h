@@ -101,6 +101,7 @@ struct Workspace {
     float *a[4] = {};           // a0..a3
     float *kp_h0 = nullptr, *kp_hA = nullptr, *kp_hB = nullptr;   // [3][B][64][T]
     float *kpack = nullptr;     // [3][B][T][KREC]
+    float *h_x3 = nullptr;      // bf16 piece images of the predictor hidden state: [3][B][3][64*ceil(T/64)+2][64] x 2 B
     float *xA = nullptr, *xB = nullptr;                           // [B][32][L] ping-pong
     float *xtap[fd::NBLK] = {}; // block outputs kept for fd_read_tap
     float *mel = nullptr;       // [B][80][T] library-owned copy used by the sampler graph

@@ -369,6 +369,9 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm(const float *__restrict__ h 
             }
             const int t0 = cur.t_begin + tile * 32;
             const unsigned base = (unsigned)(t0 + 4 * hi) * (unsigned)fd::KREC;     // < 2^32: checked on the host
+#ifdef FD_GX_NO_STORE
+            if (acc[0] != 12345.678f) continue;
+#endif
             if (t0 + 32 <= T) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) kout[base + (unsigned)(((r & 3) + 8 * (r >> 2)) * fd::KREC)] = acc[r];
@@ -402,8 +405,12 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm(const float *__restrict__ h 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int GX_CT = 2;                        // frame tiles per item
 constexpr int GX_ROWS = GX_CT * 32 + 2;         // 66 rows: frames t_begin-1 .. t_begin+64
-constexpr int GX_PIECE = GX_ROWS * 128;         // bytes per piece
-constexpr int GX_NV = 9;                        // channel PAIRS staged per thread: 8 (rows 0..63) + 1 (rows 64,65; wave 0)
+constexpr int GX_ROWB = 3 * 128;                // bytes per row of the piece image: [piece][64 ch] bf16
+constexpr int GX_WINB = GX_ROWS * GX_ROWB;      // 25344 B per item window
+constexpr int GX_NDMA = (GX_WINB + 4095) / 4096;   // 4 KB (256 lanes x 16 B) DMA rounds per window: 6 full + 1 partial
+constexpr int GX_BUFB = GX_NDMA * 4096;         // LDS bytes per buffer (the partial round is padded to a whole wave)
+
+__host__ __device__ inline int gx_rows(int T) { return ((T + 63) / 64) * 64 + 2; }   // image rows per (block, utterance)
 
 __device__ __forceinline__ bf16x8 as_bf16x8(const float4 &v)
 {
@@ -416,138 +423,202 @@ __device__ __forceinline__ f32x16 mfma_bf16(const float4 &a, const float4 &b, f3
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b), c, 0, 0, 0);
 }
 
-__global__ void __launch_bounds__(256, 2) k_kp_gemm_x3(const float *__restrict__ h /*[3][B][64][T]*/, float *__restrict__ kpack,
-                                                       const float4 *g0, const float4 *g1, const float4 *g2, const float *gb0,
-                                                       const float *gb1, const float *gb2, int B, int T, int chunks_per_utt,
-                                                       int chunk_tiles, int n_items)
+// h (fp32 [3][B][64][T]) -> bf16 piece image [3][B][row = t+1][piece][64 channels]; rows 0 and > T are zero.
+// Exact 3-way split by truncation (and / sub).  The 16-byte slot of a row is XOR-ed with (row>>1)&7: with 384-byte rows the
+// 16-lane service groups of ds_read_b128 then touch every bank once, and because the swizzle depends only on the ABSOLUTE
+// row (item windows start at multiples of 64 frames) the GEMM can pull a window into LDS as one linear DMA copy.
+__global__ void __launch_bounds__(256) k_h_split(const float *__restrict__ h, unsigned *__restrict__ hx, int B, int T, int R)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char hs[2][3 * GX_PIECE];     // 2 x 25 KB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int bb = blockIdx.y;                           // blk*B + b
+    const int e = blockIdx.x * 256 + threadIdx.x, cp = e / R, row = e - cp * R;     // lanes along rows: coalesced h reads
+    if (cp >= 32) return;
+    const int t = row - 1;
+    const bool ok = t >= 0 && t < T;
+    const float *hb = h + (int64_t)bb * fd::HID * T;
+    unsigned a = ok ? __float_as_uint(hb[(int64_t)(2 * cp) * T + t]) : 0u;
+    unsigned b2 = ok ? __float_as_uint(hb[(int64_t)(2 * cp + 1) * T + t]) : 0u;
+    const unsigned slot = ((unsigned)cp >> 2) ^ (((unsigned)row >> 1) & 7u);
+    unsigned *dst = hx + ((int64_t)bb * R + row) * 96 + slot * 4 + (cp & 3);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const unsigned ah = a & 0xFFFF0000u, bh = b2 & 0xFFFF0000u;
+        dst[q * 32] = (ah >> 16) | bh;
+        a = __float_as_uint(__uint_as_float(a) - __uint_as_float(ah));
+        b2 = __float_as_uint(__uint_as_float(b2) - __uint_as_float(bh));
+    }
+}
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+#ifdef FD_GX_TIMING
+__device__ long long fd_gxdbg[8];
+#define GX_STAMP(k) do { const long long t__ = __builtin_amdgcn_s_memtime(); ph[k] += t__ - tl; tl = t__; } while (0)
+#else
+#define GX_STAMP(k) do { } while (0)
+#endif
+
+struct GxItem { int blk, xg, b, chunk; };
+
+// Async copy of one item window (25344 B, contiguous in the piece image) into an LDS buffer: 16 B per lane, LDS side linear
+// (M0 = wave-uniform LDS base, lane i lands at base + 16*i).  Issued as inline asm on purpose: for the builtin the compiler
+// puts a full vmcnt(0) in front of the next ds_read of ANY LDS address, which would serialise the copy with the MFMAs of the
+// current item; the waits are counted by hand in gx_item instead.
+__device__ __forceinline__ void gx_dma(const char *hx, char *lds_buf, const GxItem &it, int B, int R, int wave_u, int lane)
+{
+#ifndef FD_GX_NO_FETCH
+    const char *src = hx + (((int64_t)it.blk * B + it.b) * R + it.chunk * 64) * GX_ROWB + wave_u * 1024;    // uniform
+    const unsigned dst = (unsigned)(uintptr_t)(lds_ptr_t)(lds_buf + wave_u * 1024);
+    const unsigned voff = lane * 16;
+    unsigned keep;
+#pragma unroll
+    for (int j = 0; j < GX_NDMA; ++j) {
+        if (j == GX_NDMA - 1 && wave_u != 0) break;      // the last 768 B (rounded to one wave; the image has slack behind it)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(src + j * 4096), "s"(dst + j * 4096)
+                     : "memory");
+    }
+#endif
+}
+
+// One work item = (LVC block, 128-column group, utterance, 64 frames): 2 frame tiles x 72 MFMAs per wave.
+//   BUF   which LDS buffer holds this item's window (the other one receives the next item's window by DMA meanwhile)
+//   FULL  both tiles are whole (always, except the ragged last chunk of an utterance)
+// Vector-memory order per item: [DMA of next window] [16 stores of tile 0] [16 stores of tile 1].  vmcnt retires in order,
+// so "vmcnt(16)" after the MFMAs of tile 1 waits for the DMA but not for the stores in flight; store acknowledgements are
+// never waited for on this path.
+template <int BUF, bool FULL>
+__device__ __forceinline__ void gx_item(char *lds, const GxItem &cur, bool more, const GxItem &nxt, const char *hx, float *kpack,
+                                        const float4 (&wq)[3][12], float bias, const int (&aoff)[12], int B, int T, int R,
+                                        int wave_u, int lane)
+{
+    const int l31 = lane & 31, hi = lane >> 5;
+    if (more) gx_dma(hx, lds + (BUF ^ 1) * GX_BUFB, nxt, B, R, wave_u, lane);
+    const int t_begin = cur.chunk * 64;
+    float *krow = kpack + (((int64_t)cur.blk * B + cur.b) * T + t_begin) * fd::KREC + (cur.xg * 4 + wave_u) * 32;     // uniform
+    const unsigned loff = (unsigned)(4 * hi) * (unsigned)fd::KREC + (unsigned)l31;
+    const int n_tiles = FULL ? 2 : ((T - t_begin + 31) >> 5);
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile) {
+        if (!FULL && tile >= n_tiles) break;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bias;
+        const char *hb = lds + BUF * GX_BUFB + tile * 32 * GX_ROWB;
+#pragma unroll
+        for (int kg = 0; kg < 12; ++kg) {      // kg = tap*4 + k4: logical k = kg*16 + 8*hi + e = tap*64 + channel
+            const float4 a1 = *reinterpret_cast<const float4 *>(hb + aoff[kg]);
+            const float4 a2 = *reinterpret_cast<const float4 *>(hb + aoff[kg] + 128);
+            const float4 a3 = *reinterpret_cast<const float4 *>(hb + aoff[kg] + 256);
+            // leading term first, then the corrections: W1h1 | W2h1, W1h2 | W3h1, W2h2, W1h3
+            acc = mfma_bf16(a1, wq[0][kg], acc);
+            acc = mfma_bf16(a1, wq[1][kg], acc);
+            acc = mfma_bf16(a2, wq[0][kg], acc);
+            acc = mfma_bf16(a1, wq[2][kg], acc);
+            acc = mfma_bf16(a2, wq[1][kg], acc);
+            acc = mfma_bf16(a3, wq[0][kg], acc);
+        }
+        if (FULL && tile == 1 && more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // DMA landed; tile-0 stores may fly
+#ifdef FD_GX_NO_STORE
+        if (acc[0] != 12345.678f) continue;
+#endif
+        float *kt = krow + (int64_t)tile * 32 * fd::KREC;
+        if (FULL) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) (kt + ((r & 3) + 8 * (r >> 2)) * fd::KREC)[loff] = acc[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (t_begin + tile * 32 + drow(r, hi) < T) (kt + ((r & 3) + 8 * (r >> 2)) * fd::KREC)[loff] = acc[r];
+        }
+    }
+    if (!FULL && more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // every wave's DMA share is in LDS; everybody is done reading this item's buffer
+}
+
+__global__ void __launch_bounds__(256, 2) k_kp_gemm_x3(const char *__restrict__ hx /*[3][B][R][3][64] bf16*/, float *__restrict__ kpack,
+                                                       const float4 *g0, const float4 *g1, const float4 *g2, const float *gb0,
+                                                       const float *gb1, const float *gb2, int B, int T, int R, int chunks_per_utt,
+                                                       int n_items)
+{
+    __shared__ __attribute__((aligned(16))) char lds[2 * GX_BUFB];     // 2 x 28 KB
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int XG = fd::KREC / 128;
-    const int ny = B * chunks_per_utt;
     const int i0 = (int)((int64_t)blockIdx.x * n_items / gridDim.x), i1 = (int)((int64_t)(blockIdx.x + 1) * n_items / gridDim.x);
     if (i0 >= i1) return;
 
-    struct Item { int blk, xg, b, t_begin; };
-    auto decode = [&](int id) {
-        Item it;
-        it.blk = id / (XG * ny);
-        const int rem = id - it.blk * (XG * ny);
-        it.xg = rem / ny;
-        const int yy = rem - it.xg * ny;
-        it.b = yy / chunks_per_utt;
-        it.t_begin = (yy - it.b * chunks_per_utt) * chunk_tiles * 32;
+    // items are ordered (block, column group, utterance, chunk), chunk fastest: consecutive items share the weights
+    GxItem cur;
+    {
+        const int ny = B * chunks_per_utt;
+        cur.blk = i0 / (XG * ny);
+        const int rem = i0 - cur.blk * (XG * ny);
+        cur.xg = rem / ny;
+        const int yy = rem - cur.xg * ny;
+        cur.b = yy / chunks_per_utt;
+        cur.chunk = yy - cur.b * chunks_per_utt;
+    }
+    auto advance = [&](GxItem it) {
+        if (++it.chunk == chunks_per_utt) {
+            it.chunk = 0;
+            if (++it.b == B) {
+                it.b = 0;
+                if (++it.xg == XG) { it.xg = 0; ++it.blk; }
+            }
+        }
         return it;
     };
-    // staging map: lanes run along time (coalesced 256 B global reads), a wave takes channel pairs cp = wave, wave+4, ...;
-    // the two extra rows 64, 65 are fetched by wave 0 (lane = cp + 32*(row-64)).  One dword per pair and piece goes to LDS.
-    float va[GX_NV], vb[GX_NV];
-#define FD_GX_FETCH(it)                                                                                               \
-    do {                                                                                                              \
-        const float *hb__ = h + ((int64_t)(it).blk * B + (it).b) * fd::HID * T;                                       \
-        const int t__ = (it).t_begin - 1 + lane;                                                                      \
-        const bool ok__ = t__ >= 0 && t__ < T;                                                                        \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                               \
-            const int cp = 4 * j + wave;                                                                              \
-            va[j] = ok__ ? hb__[(int64_t)(2 * cp) * T + t__] : 0.0f;                                                  \
-            vb[j] = ok__ ? hb__[(int64_t)(2 * cp + 1) * T + t__] : 0.0f;                                              \
-        }                                                                                                             \
-        const int t2__ = (it).t_begin + 63 + hi;                                                                      \
-        const bool ok2__ = wave == 0 && t2__ < T;                                                                     \
-        va[8] = ok2__ ? hb__[(int64_t)(2 * l31) * T + t2__] : 0.0f;                                                   \
-        vb[8] = ok2__ ? hb__[(int64_t)(2 * l31 + 1) * T + t2__] : 0.0f;                                               \
-    } while (0)
-    // exact three-way bf16 split by truncation; piece q of the channel pair goes to one dword of piece image q
-#define FD_GX_SPLIT_STORE(bufi, a_, b_, row_, cp_)                                                                    \
-    do {                                                                                                              \
-        unsigned a = __float_as_uint(a_), b2 = __float_as_uint(b_);                                                   \
-        const unsigned off = (unsigned)(row_) * 128u + ((((unsigned)(cp_) >> 2) ^ ((unsigned)(row_) & 7u)) << 4) + (((unsigned)(cp_) & 3u) << 2); \
-        _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                               \
-            const unsigned ah = a & 0xFFFF0000u, bh = b2 & 0xFFFF0000u;                                               \
-            *reinterpret_cast<unsigned *>(&hs[bufi][q * GX_PIECE + off]) = (ah >> 16) | bh;                            \
-            a = __float_as_uint(__uint_as_float(a) - __uint_as_float(ah));                                            \
-            b2 = __float_as_uint(__uint_as_float(b2) - __uint_as_float(bh));                                          \
-        }                                                                                                             \
-    } while (0)
-#define FD_GX_COMMIT(bufi)                                                                                            \
-    do {                                                                                                              \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) FD_GX_SPLIT_STORE(bufi, va[j], vb[j], lane, 4 * j + wave);      \
-        if (wave == 0) FD_GX_SPLIT_STORE(bufi, va[8], vb[8], 64 + hi, l31);                                           \
-    } while (0)
 
-    // per-lane byte offsets of the 12 A-operand reads of a tile (tap, 16-channel group): row = frame + tap, swizzled slot
-    unsigned aoff[12];
+    // byte offset of the 12 A-operand reads of a tile: row = frame + tap, 16-byte slot (2*k4 + hi) ^ ((row >> 1) & 7)
+    int aoff[12];
 #pragma unroll
     for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4) {
-            const unsigned row = (unsigned)(l31 + tap);
-            aoff[tap * 4 + k4] = row * 128u + ((((unsigned)(k4 * 2 + hi)) ^ (row & 7u)) << 4);
+            const int row = l31 + tap;
+            aoff[tap * 4 + k4] = row * GX_ROWB + (((k4 * 2 + hi) ^ ((row >> 1) & 7)) << 4);
         }
 
-    Item cur = decode(i0);
-    FD_GX_FETCH(cur);
-    FD_GX_COMMIT(0);
-    __syncthreads();
+    gx_dma(hx, lds, cur, B, R, wave_u, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
     float4 wq[3][12];
     float bias = 0.0f;
-    int have_blk = -1, have_xg = -1, buf = 0;
+    int have_blk = -1, have_xg = -1;
 #pragma unroll 1
-    for (int i = i0; i < i1; ++i) {
-        if (cur.blk != have_blk || cur.xg != have_xg) {      // new column group: (re)load the register-stationary weight pieces
-            const float4 *gp = cur.blk == 0 ? g0 : (cur.blk == 1 ? g1 : g2);
-            const float *gb = cur.blk == 0 ? gb0 : (cur.blk == 1 ? gb1 : gb2);
-            const int ptile = cur.xg * 4 + wave;
+    for (int i = i0; i < i1; i += 2) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
+        for (int half = 0; half < 2; ++half) {
+            if (half == 1 && i + 1 >= i1) break;
+            if (cur.blk != have_blk || cur.xg != have_xg) {      // new column group: (re)load the register-stationary weight pieces
+                const float4 *gp = cur.blk == 0 ? g0 : (cur.blk == 1 ? g1 : g2);
+                const float *gb = cur.blk == 0 ? gb0 : (cur.blk == 1 ? gb1 : gb2);
+                const int ptile = cur.xg * 4 + wave_u;
 #pragma unroll
-                for (int kg = 0; kg < 12; ++kg) wq[q][kg] = gp[(((int64_t)ptile * 3 + q) * 12 + kg) * 64 + lane];
-            bias = gb[ptile * 32 + l31];
-            have_blk = cur.blk; have_xg = cur.xg;
-        }
-        Item nxt = cur;
-        const bool more = (i + 1 < i1);
-        if (more) { nxt = decode(i + 1); FD_GX_FETCH(nxt); }
-        const int n_frames = min(T - cur.t_begin, chunk_tiles * 32);
-        const int n_tiles = (n_frames + 31) >> 5;
-        float *kout = kpack + ((int64_t)cur.blk * B + cur.b) * T * fd::KREC + (cur.xg * 4 + wave) * 32 + l31;   // + t*KREC
-#pragma unroll 1
-        for (int tile = 0; tile < n_tiles; ++tile) {
-            f32x16 hiacc, loacc;
+                for (int q = 0; q < 3; ++q)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { hiacc[r] = bias; loacc[r] = 0.0f; }
-            const unsigned char *hb = &hs[buf][tile * 32 * 128];        // row of frame 0 of this tile (tap 0 = previous frame)
-#pragma unroll
-            for (int kg = 0; kg < 12; ++kg) {      // kg = tap*4 + k4: logical k = kg*16 + 8*hi + e = tap*64 + channel
-                const float4 a1 = *reinterpret_cast<const float4 *>(hb + aoff[kg]);
-                const float4 a2 = *reinterpret_cast<const float4 *>(hb + GX_PIECE + aoff[kg]);
-                const float4 a3 = *reinterpret_cast<const float4 *>(hb + 2 * GX_PIECE + aoff[kg]);
-                hiacc = mfma_bf16(a1, wq[0][kg], hiacc);
-                loacc = mfma_bf16(a1, wq[1][kg], loacc);
-                loacc = mfma_bf16(a2, wq[0][kg], loacc);
-                loacc = mfma_bf16(a1, wq[2][kg], loacc);
-                loacc = mfma_bf16(a2, wq[1][kg], loacc);
-                loacc = mfma_bf16(a3, wq[0][kg], loacc);
+                    for (int kg = 0; kg < 12; ++kg) wq[q][kg] = gp[(((int64_t)ptile * 3 + q) * 12 + kg) * 64 + lane];
+                bias = gb[ptile * 32 + l31];
+                have_blk = cur.blk; have_xg = cur.xg;
+                // retire the loads here, visibly to the compiler: otherwise it places a vmcnt(0) at the first use, on the
+                // common path too, where it would wait for the window DMA and the stores of the previous item
+                __builtin_amdgcn_s_waitcnt(0x0F70);
             }
-            const int t0 = cur.t_begin + tile * 32;
-            const unsigned base = (unsigned)(t0 + 4 * hi) * (unsigned)fd::KREC;
-            if (t0 + 32 <= T) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) kout[base + (unsigned)(((r & 3) + 8 * (r >> 2)) * fd::KREC)] = hiacc[r] + loacc[r];
+            const bool more = (i + half + 1 < i1);
+            const GxItem nxt = advance(cur);
+            const bool full = (cur.chunk * 64 + 64 <= T);
+            if (half == 0) {
+                if (full) gx_item<0, true>(lds, cur, more, nxt, hx, kpack, wq, bias, aoff, B, T, R, wave_u, lane);
+                else gx_item<0, false>(lds, cur, more, nxt, hx, kpack, wq, bias, aoff, B, T, R, wave_u, lane);
             } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (t0 + drow(r, hi) < T) kout[base + (unsigned)(((r & 3) + 8 * (r >> 2)) * fd::KREC)] = hiacc[r] + loacc[r];
+                if (full) gx_item<1, true>(lds, cur, more, nxt, hx, kpack, wq, bias, aoff, B, T, R, wave_u, lane);
+                else gx_item<1, false>(lds, cur, more, nxt, hx, kpack, wq, bias, aoff, B, T, R, wave_u, lane);
             }
+            cur = nxt;
         }
-        if (more) FD_GX_COMMIT(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
-        cur = nxt;
     }
-#undef FD_GX_FETCH
-#undef FD_GX_COMMIT
-#undef FD_GX_SPLIT_STORE
 }
 
 // =================================================================================================
@@ -1017,11 +1088,17 @@ hipError_t fast_kp_gemm(const Launch &L, int B, int T)
     const int chunk_tiles = (tiles_per_utt + chunks_per_utt - 1) / chunks_per_utt;     // balanced, <= ct
     const int n_items = fd::NBLK * (fd::KREC / 128) * B * chunks_per_utt;
     const int grid = n_items < 2 * c->num_cus ? n_items : 2 * c->num_cus;              // persistent: 2 workgroups per CU
-    if (c->gemm_x3)
-        FD_LAUNCH(L, "kp_gemm_bf16x3", k_kp_gemm_x3, dim3(grid), dim3(256), 0, (const float *)c->ws.kp_hB, c->ws.kpack,
+    if (c->gemm_x3) {
+        const int R = gx_rows(T);
+        const int chunks = (T + 63) / 64, items = fd::NBLK * (fd::KREC / 128) * B * chunks;
+        const int grid3 = items < 2 * c->num_cus ? items : 2 * c->num_cus;
+        FD_LAUNCH(L, "h_split", k_h_split, dim3((32 * R + 255) / 256, fd::NBLK * B), dim3(256), 0, (const float *)c->ws.kp_hB,
+                  reinterpret_cast<unsigned *>(c->ws.h_x3), B, T, R);
+        FD_LAUNCH(L, "kp_gemm_bf16x3", k_kp_gemm_x3, dim3(grid3), dim3(256), 0, reinterpret_cast<const char *>(c->ws.h_x3), c->ws.kpack,
                   reinterpret_cast<const float4 *>(w.gemm_x3_pack[0]), reinterpret_cast<const float4 *>(w.gemm_x3_pack[1]),
-                  reinterpret_cast<const float4 *>(w.gemm_x3_pack[2]), w.gemm_bias[0], w.gemm_bias[1], w.gemm_bias[2], B, T,
-                  chunks_per_utt, chunk_tiles, n_items);
+                  reinterpret_cast<const float4 *>(w.gemm_x3_pack[2]), w.gemm_bias[0], w.gemm_bias[1], w.gemm_bias[2], B, T, R, chunks,
+                  items);
+    }
     else
         FD_LAUNCH(L, "kp_gemm", k_kp_gemm, dim3(grid), dim3(256), 0, (const float *)c->ws.kp_hB, c->ws.kpack, w.gemm_pack[0],
                   w.gemm_pack[1], w.gemm_pack[2], w.gemm_bias[0], w.gemm_bias[1], w.gemm_bias[2], B, T, chunks_per_utt,

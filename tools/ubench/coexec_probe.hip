@@ -3,8 +3,14 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifdef BF16_PIPE
+#define MFLOP 32768.0
+#else
+#define MFLOP 4096.0
+#endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 template <int NV, int KIND>
 __global__ void __launch_bounds__(256, 2) probe(float *out, int iters, float seed)
 {
@@ -17,7 +23,12 @@ __global__ void __launch_bounds__(256, 2) probe(float *out, int iters, float see
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
+#ifdef BF16_PIPE
+            { bf16x8 av, bv; for (int q = 0; q < 8; ++q) { av[q] = (__bf16)a; bv[q] = (__bf16)b; }
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0); }
+#else
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+#endif
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 if (KIND == 0) v[j & 15] = __builtin_fmaf(v[j & 15], a, b);
@@ -49,7 +60,7 @@ int run(float *out, int grid, const char *kind)
     // cycles per MFMA per SIMD assuming all waves of the grid are co-resident: waves/SIMD = grid*4/1024
     const double wps = grid * 4 / 1024.0;
     printf("%-8s NV=%2d grid=%4d (%.0f waves/SIMD): %7.3f ms  %6.1f TFLOP/s mfma  %5.1f ns per (MFMA + %d VALU) per wave\n", kind, NV, grid, wps, ms,
-           mfma * 4096 / ms / 1e9, ms * 1e6 / (iters * 32.0), NV);
+           mfma * MFLOP / ms / 1e9, ms * 1e6 / (iters * 32.0), NV);
     return 0;
 }
 
