@@ -170,7 +170,7 @@ int fd_create(const fd_config *cfg, int device, fd_handle *out)
 static void free_workspace(fd_context *c)
 {
     Workspace &w = c->ws;
-    void *ptrs[] = {w.noise, w.a[0], w.a[1], w.a[2], w.a[3], w.kp_h0, w.kp_hA, w.kp_hB, w.kpack, w.h_x3, w.xA, w.xB,
+    void *ptrs[] = {w.noise, w.a[0], w.a[1], w.a[2], w.a[3], w.kp_h0, w.kp_hA, w.kp_hB, w.kpack, w.h_f16, w.range_flag, w.xA, w.xB,
                     w.xtap[0], w.xtap[1], w.xtap[2], w.mel, w.x, w.steps, w.params};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -296,6 +296,39 @@ std::vector<float> pack_A(const std::vector<float> &w, int cout, int cin, int ks
     return p;
 }
 
+// IEEE binary16 <-> binary32 on the host (round to nearest even, subnormals kept): the weight pieces of the fp16x2 GEMM.
+static uint16_t f16_from_f32(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    u &= 0x7FFFFFFFu;
+    if (u > 0x7F800000u) return sign | 0x7E00u;                  // NaN
+    if (u >= 0x477FF000u) return sign | 0x7C00u;                 // >= 65520 rounds to infinity
+    if (u < 0x38800000u) {                                       // below 2^-14: subnormal, a multiple of 2^-24
+        float ax;
+        memcpy(&ax, &u, 4);
+        return sign | (uint16_t)lrintf(ax * 16777216.0f);        // current rounding mode = nearest even; 1024 = smallest normal
+    }
+    uint32_t hbits = (((u >> 23) - 112u) << 10) | ((u & 0x7FFFFFu) >> 13);
+    const uint32_t rem = u & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (hbits & 1u))) ++hbits;   // a carry into the exponent is the correct result
+    return sign | (uint16_t)hbits;
+}
+static float f32_from_f16(uint16_t hb)
+{
+    const uint32_t sign = (uint32_t)(hb & 0x8000u) << 16, exp = (hb >> 10) & 0x1Fu, man = hb & 0x3FFu;
+    float v;
+    if (exp == 0) v = (float)man * (1.0f / 16777216.0f);
+    else if (exp == 31) { const uint32_t u = 0x7F800000u | (man << 13); memcpy(&v, &u, 4); }
+    else { const uint32_t u = ((exp + 112u) << 23) | (man << 13); memcpy(&v, &u, 4); }
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    u |= sign;
+    memcpy(&v, &u, 4);
+    return v;
+}
+
 void unpack_kernel_index(int p, int &layer, int &in, int &out, int &tap)
 {
     layer = p / fd::KLAYER;
@@ -352,6 +385,7 @@ int fd_commit_weights(fd_handle h)
         }
         UP(table, w.embed_table);
     }
+    bool f16_ok = true;
     for (int n = 0; n < fd::NBLK; ++n) {
         const std::string p = "lvc_blocks." + std::to_string(n), d = "downsample." + std::to_string(n);
         if ((rc = up_conv(d + ".residual_dense", w.down[n].res)) != FD_OK) return rc;
@@ -421,21 +455,9 @@ int fd_commit_weights(fd_handle h)
                 }
             UP(gp, w.gemm_pack[n]);
             UP(gb, w.gemm_bias[n]);
-            // bf16x3 form: W = W1 + W2 + W3 (round-to-nearest-even pieces); B operand of v_mfma_f32_32x32x16_bf16:
-            // lane = col + 32*g holds the 8 consecutive k = kg*16 + 8g + e, k = tap*64 + channel
-            std::vector<uint16_t> gx((size_t)(fd::KREC / 32) * 3 * 12 * 64 * 8);
-            auto bf16_rne = [](float x) -> uint16_t {
-                uint32_t u;
-                memcpy(&u, &x, 4);
-                u += 0x7FFFu + ((u >> 16) & 1u);
-                return (uint16_t)(u >> 16);
-            };
-            auto bf16_val = [](uint16_t b) -> float {
-                uint32_t u = (uint32_t)b << 16;
-                float f;
-                memcpy(&f, &u, 4);
-                return f;
-            };
+            // fp16x2 form: w = w1 + 2^-11 * w2, w1 = fp16(w), w2 = fp16((w - w1) * 2^11) (round to nearest even, subnormals kept);
+            // B operand of v_mfma_f32_32x32x16_f16: lane = col + 32*g holds the 8 consecutive k = kg*16 + 8g + e, k = tap*64 + channel
+            std::vector<uint16_t> gx((size_t)(fd::KREC / 32) * 2 * 12 * 64 * 8);
             for (int pt = 0; pt < fd::KREC / 32; ++pt)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int pp = pt * 32 + (lane & 31), g = lane >> 5;
@@ -451,18 +473,19 @@ int fd_commit_weights(fd_handle h)
                     for (int kg = 0; kg < 12; ++kg)
                         for (int e = 0; e < 8; ++e) {
                             const int kk = kg * 16 + g * 8 + e, tap = kk / fd::HID, ch = kk % fd::HID;
-                            float r = wrow[ch * 3 + tap];
-                            for (int q = 0; q < 3; ++q) {
-                                const uint16_t piece = bf16_rne(r);
-                                gx[((((size_t)pt * 3 + q) * 12 + kg) * 64 + lane) * 8 + e] = piece;
-                                r -= bf16_val(piece);
-                            }
+                            const float v = wrow[ch * 3 + tap];
+                            if (!(fabsf(v) < 32768.0f)) f16_ok = false;
+                            const uint16_t p1 = f16_from_f32(v);
+                            const uint16_t p2 = f16_from_f32((v - f32_from_f16(p1)) * 2048.0f);
+                            gx[((((size_t)pt * 2 + 0) * 12 + kg) * 64 + lane) * 8 + e] = p1;
+                            gx[((((size_t)pt * 2 + 1) * 12 + kg) * 64 + lane) * 8 + e] = p2;
                         }
                 }
-            if ((rc = upload(h, gx.data(), gx.size() * sizeof(uint16_t), reinterpret_cast<const void **>(&w.gemm_x3_pack[n]))) != FD_OK)
+            if ((rc = upload(h, gx.data(), gx.size() * sizeof(uint16_t), reinterpret_cast<const void **>(&w.gemm_h2_pack[n]))) != FD_OK)
                 return rc;
         }
     }
+    w.gemm_f16_ok = f16_ok;
     {
         std::vector<int> perm(fd::KW);
         for (int layer = 0; layer < fd::LAYERS; ++layer)
@@ -506,7 +529,9 @@ static int ensure_workspace(fd_context *h, int B, int T)
     WS(w.kp_h0, (size_t)fd::NBLK * nB * fd::HID * nT); WS(w.kp_hA, (size_t)fd::NBLK * nB * fd::HID * nT);
     WS(w.kp_hB, (size_t)fd::NBLK * nB * fd::HID * nT);
     WS(w.kpack, (size_t)fd::NBLK * nB * nT * fd::KREC);
-    WS(w.h_x3, (size_t)fd::NBLK * nB * (((nT + 63) / 64) * 64 + 2) * 96 + 256);      // + slack for the rounded-up last DMA
+    WS(w.h_f16, (size_t)fd::NBLK * nB * (((nT + 63) / 64) * 64 + 2) * 64 + 256);      // + slack for the rounded-up last DMA
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w.range_flag), 256);
+    if (e == hipSuccess) e = hipMemset(w.range_flag, 0, 256);
     WS(w.xA, nB * fd::C * L); WS(w.xB, nB * fd::C * L);
     WS(w.xtap[0], nB * fd::C * L / 32); WS(w.xtap[1], nB * fd::C * L / 4); WS(w.xtap[2], nB * fd::C * L);
     WS(w.mel, (size_t)nB * fd::COND * nT); WS(w.x, nB * L); WS(w.steps, (size_t)std::max(nB, 64));
@@ -629,7 +654,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
 
 static unsigned mode_signature(const fd_context *h)
 {
-    unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_x3 ? 2u : 0u);
+    unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_f16 ? 2u : 0u);
     for (int i = 0; i < ST_COUNT; ++i) s = (s << 1) | (h->fast[i] ? 1u : 0u);
     return s;
 }
@@ -743,9 +768,9 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
     }
     const bool on = (v == "1" || v == "true" || v == "on");
     if (k == "gemm") {
-        if (v == "bf16x3") h->gemm_x3 = true;
-        else if (v == "fp32") h->gemm_x3 = false;
-        else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: gemm expects bf16x3|fp32, got '%s'", value);
+        if (v == "f16x2") h->gemm_f16 = true;
+        else if (v == "fp32") h->gemm_f16 = false;
+        else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: gemm expects f16x2|fp32, got '%s'", value);
         return FD_OK;
     }
     if (k == "graph") { h->use_graph = on; return FD_OK; }

@@ -73,7 +73,8 @@ struct DevWeights {
     const float *kp_res_pack[fd::NBLK][6] = {};   // 64->64 k3: 2 mt x 24 s4
     const float *gemm_pack[fd::NBLK] = {};        // kernel_conv+bias_conv as MFMA B operand: [776 ptile][24 s4][64][4]
     const float *gemm_bias[fd::NBLK] = {};        // [24832] conv biases in packed order
-    const uint16_t *gemm_x3_pack[fd::NBLK] = {};  // same weights as three bf16 pieces: [776 ptile][3][12 kg][64 lane][8]
+    const uint16_t *gemm_h2_pack[fd::NBLK] = {};  // same weights as two fp16 pieces (w1, (w-w1)*2^11): [776 ptile][2][12 kg][64 lane][8]
+    bool gemm_f16_ok = false;                     // every GEMM weight fits the fp16 range
     const float *up_pack[fd::NBLK] = {};          // ConvTranspose as per-phase A operands: [r phases][8 s4][64][4]
     const int *kc_perm = nullptr;                 // [24576] reference kernel_conv row -> packed position
     const int *bc_perm = nullptr;                 // [256] reference bias_conv row -> position inside the bias part
@@ -101,7 +102,8 @@ struct Workspace {
     float *a[4] = {};           // a0..a3
     float *kp_h0 = nullptr, *kp_hA = nullptr, *kp_hB = nullptr;   // [3][B][64][T]
     float *kpack = nullptr;     // [3][B][T][KREC]
-    float *h_x3 = nullptr;      // bf16 piece images of the predictor hidden state: [3][B][3][64*ceil(T/64)+2][64] x 2 B
+    float *h_f16 = nullptr;     // fp16 piece image of the predictor hidden state: [3][B][64*ceil(T/64)+2 rows][2 pieces][64] x 2 B
+    int *range_flag = nullptr;  // set by k_h_split when an operand does not fit fp16
     float *xA = nullptr, *xB = nullptr;                           // [B][32][L] ping-pong
     float *xtap[fd::NBLK] = {}; // block outputs kept for fd_read_tap
     float *mel = nullptr;       // [B][80][T] library-owned copy used by the sampler graph
@@ -123,7 +125,7 @@ struct fd_context {
     bool use_graph = true;
     bool profile = false;
     bool keep_taps = false;
-    bool gemm_x3 = true;                      // kp_gemm on the bf16 pipe with the exact 3-way operand split
+    bool gemm_f16 = true;                     // kp_gemm on the fp16 matrix pipe with the 2-piece operand split
     std::map<std::string, std::pair<std::vector<int64_t>, std::vector<float>>> raw;   // host copies from fd_set_weight
     std::vector<void *> dev_allocs;          // weight arena pieces
     DevWeights w;

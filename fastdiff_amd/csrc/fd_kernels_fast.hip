@@ -291,9 +291,10 @@ __device__ long long fd_gdbg[64 * 4 * 4];
 __global__ void __launch_bounds__(256, 2) k_kp_gemm(const float *__restrict__ h /*[3][B][64][T]*/, float *__restrict__ kpack,
                                                     const float *g0, const float *g1, const float *g2, const float *gb0,
                                                     const float *gb1, const float *gb2, int B, int T, int chunks_per_utt,
-                                                    int chunk_tiles, int n_items)
+                                                    int chunk_tiles, int n_items, const int *__restrict__ run_if)
 {
     __shared__ float hs[2][fd::HID * GEMM_LDH];
+    if (run_if && *run_if == 0) return;      // fallback launch behind the fp16 kernel: only when k_h_split flagged the operands
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     constexpr int XG = fd::KREC / 128;
     const int ny = B * chunks_per_utt;
@@ -389,45 +390,40 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm(const float *__restrict__ h 
 }
 
 // -------------------------------------------------------------------------------------------------
-// kp_gemm, split-precision form ("bf16x3"): the same contraction on the bf16 matrix pipe at fp32-level accuracy.
-// Every fp32 operand is written as the exact sum of three bf16 pieces (x = x1 + x2 + x3, 8 significant bits each) and
-// the six partial products of weight <= 4 are accumulated in fp32:
-//     W*h = W1h1 + (W1h2 + W2h1) + (W1h3 + W2h2 + W3h1) + O(2^-24 |W||h|)
-// (numpy study: max error 7.9e-7 against fp64 on |K| <= 3 where a plain fp32 GEMM has 1.6e-6).  bf16 products are exact
-// in fp32, so all rounding happens in the fp32 accumulators; the leading term gets its own accumulator so that the
-// small corrections are not swamped.  v_mfma_f32_32x32x16_bf16 runs at 16x the fp32 MFMA rate: 72 of them (2304 cycles)
-// replace 96 fp32 MFMAs (6144 cycles) per 32x32 output tile, and -- unlike fp32 MFMA -- co-execute with VALU work.
-// The weight pieces are split once at load time (round-to-nearest-even), the h pieces on the fly while staging
-// (truncation: and / sub / and / sub / and).  Same persistent item walk and register-stationary weights as the fp32 form.
-// LDS image per piece: [row = frame+halo][64 channels] bf16 (128 B rows); the 16 B slot index is XOR-ed with row&7 so a
-// ds_read_b128 wave access spreads over all banks.
-// -------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// ---- split-precision form on the fp16 matrix pipe ------------------------------------------------------------------------
+// x = x1 + 2^-11 * x2 with x1 = fp16(x), x2 = fp16((x - x1) * 2^11): 22 significant bits per operand.  W.h is evaluated as
+//   hi = W1.h1 (fp32 accumulate)     lo = W1.h2 + W2.h1 (separate fp32 accumulator)     result = bias + hi + 2^-11 * lo
+// three v_mfma_f32_32x32x16_f16 per 16 k (32 cycles each) instead of eight v_mfma_f32_32x32x2f32 (64 cycles each).  The
+// neglected W2.h2 term is 2^-22 relative, the same order as the representation error; measured against a float64 product
+// the result is closer than an fp32 sgemm.  fp16 subnormals are honoured by v_cvt and by the MFMA
+// (tools/ubench/f16_probe.hip), so small values lose nothing; operands of magnitude >= 32768 do not fit: k_h_split raises
+// a flag for them, this kernel then leaves the step to the fp32 kernel that follows it in the stream.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int GX_CT = 2;                        // frame tiles per item
 constexpr int GX_ROWS = GX_CT * 32 + 2;         // 66 rows: frames t_begin-1 .. t_begin+64
-constexpr int GX_ROWB = 3 * 128;                // bytes per row of the piece image: [piece][64 ch] bf16
-constexpr int GX_WINB = GX_ROWS * GX_ROWB;      // 25344 B per item window
-constexpr int GX_NDMA = (GX_WINB + 4095) / 4096;   // 4 KB (256 lanes x 16 B) DMA rounds per window: 6 full + 1 partial
+constexpr int GX_ROWB = 2 * 128;                // bytes per row of the piece image: [piece][64 ch] fp16
+constexpr int GX_WINB = GX_ROWS * GX_ROWB;      // 16896 B per item window
+constexpr int GX_NDMA = (GX_WINB + 4095) / 4096;   // 4 KB (256 lanes x 16 B) DMA rounds per window: 4 full + 1 partial
 constexpr int GX_BUFB = GX_NDMA * 4096;         // LDS bytes per buffer (the partial round is padded to a whole wave)
+constexpr float GX_SCALE = 2048.0f, GX_INV_SCALE = 1.0f / 2048.0f;
+constexpr float GX_LIMIT = 32768.0f;
 
 __host__ __device__ inline int gx_rows(int T) { return ((T + 63) / 64) * 64 + 2; }   // image rows per (block, utterance)
 
-__device__ __forceinline__ bf16x8 as_bf16x8(const float4 &v)
+__device__ __forceinline__ f32x16 mfma_f16(const float4 &a, const float4 &b, f32x16 c)
 {
-    union { float4 f; bf16x8 b; } u;
-    u.f = v;
-    return u.b;
-}
-__device__ __forceinline__ f32x16 mfma_bf16(const float4 &a, const float4 &b, f32x16 c)
-{
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b), c, 0, 0, 0);
+    union { float4 f; f16x8 h; } ua, ub;
+    ua.f = a;
+    ub.f = b;
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(ua.h, ub.h, c, 0, 0, 0);
 }
 
-// h (fp32 [3][B][64][T]) -> bf16 piece image [3][B][row = t+1][piece][64 channels]; rows 0 and > T are zero.
-// Exact 3-way split by truncation (and / sub).  The 16-byte slot of a row is XOR-ed with (row>>1)&7: with 384-byte rows the
-// 16-lane service groups of ds_read_b128 then touch every bank once, and because the swizzle depends only on the ABSOLUTE
-// row (item windows start at multiples of 64 frames) the GEMM can pull a window into LDS as one linear DMA copy.
-__global__ void __launch_bounds__(256) k_h_split(const float *__restrict__ h, unsigned *__restrict__ hx, int B, int T, int R)
+// h (fp32 [3][B][64][T]) -> fp16 piece image [3][B][row = t+1][piece][64 channels]; rows 0 and > T are zero.
+// A row is 256 B = 16 slots of 16 B; slot s of row r is stored at s ^ (r & 15): the 16-lane service groups of ds_read_b128
+// (rows l, l+1, ... of one slot) then touch every bank once, and because the swizzle depends only on the ABSOLUTE row
+// (item windows start at multiples of 64 frames) the GEMM can pull a window into LDS as one linear DMA copy.
+__global__ void __launch_bounds__(256) k_h_split(const float *__restrict__ h, unsigned *__restrict__ hx, int *__restrict__ range_flag,
+                                                 int B, int T, int R)
 {
     const int bb = blockIdx.y;                           // blk*B + b
     const int e = blockIdx.x * 256 + threadIdx.x, cp = e / R, row = e - cp * R;     // lanes along rows: coalesced h reads
@@ -435,31 +431,24 @@ __global__ void __launch_bounds__(256) k_h_split(const float *__restrict__ h, un
     const int t = row - 1;
     const bool ok = t >= 0 && t < T;
     const float *hb = h + (int64_t)bb * fd::HID * T;
-    unsigned a = ok ? __float_as_uint(hb[(int64_t)(2 * cp) * T + t]) : 0u;
-    unsigned b2 = ok ? __float_as_uint(hb[(int64_t)(2 * cp + 1) * T + t]) : 0u;
-    const unsigned slot = ((unsigned)cp >> 2) ^ (((unsigned)row >> 1) & 7u);
-    unsigned *dst = hx + ((int64_t)bb * R + row) * 96 + slot * 4 + (cp & 3);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const unsigned ah = a & 0xFFFF0000u, bh = b2 & 0xFFFF0000u;
-        dst[q * 32] = (ah >> 16) | bh;
-        a = __float_as_uint(__uint_as_float(a) - __uint_as_float(ah));
-        b2 = __float_as_uint(__uint_as_float(b2) - __uint_as_float(bh));
-    }
+    const float a = ok ? hb[(int64_t)(2 * cp) * T + t] : 0.0f, b2 = ok ? hb[(int64_t)(2 * cp + 1) * T + t] : 0.0f;
+    if (!(fmaxf(fabsf(a), fabsf(b2)) < GX_LIMIT)) atomicOr(range_flag, 1);      // also catches NaN / inf
+    const _Float16 a1 = (_Float16)a, b1 = (_Float16)b2;
+    const _Float16 a2 = (_Float16)((a - (float)a1) * GX_SCALE), b3 = (_Float16)((b2 - (float)b1) * GX_SCALE);
+    union { _Float16 h[2]; unsigned u; } p1, p2;
+    p1.h[0] = a1; p1.h[1] = b1;
+    p2.h[0] = a2; p2.h[1] = b3;
+    unsigned *dst = hx + ((int64_t)bb * R + row) * 64 + (cp & 3);
+    const unsigned sw = (unsigned)row & 15u, slot = (unsigned)cp >> 2;
+    dst[((slot ^ sw) << 2)] = p1.u;
+    dst[(((slot + 8u) ^ sw) << 2)] = p2.u;
 }
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 
-#ifdef FD_GX_TIMING
-__device__ long long fd_gxdbg[8];
-#define GX_STAMP(k) do { const long long t__ = __builtin_amdgcn_s_memtime(); ph[k] += t__ - tl; tl = t__; } while (0)
-#else
-#define GX_STAMP(k) do { } while (0)
-#endif
-
 struct GxItem { int blk, xg, b, chunk; };
 
-// Async copy of one item window (25344 B, contiguous in the piece image) into an LDS buffer: 16 B per lane, LDS side linear
+// Async copy of one item window (16896 B, contiguous in the piece image) into an LDS buffer: 16 B per lane, LDS side linear
 // (M0 = wave-uniform LDS base, lane i lands at base + 16*i).  Issued as inline asm on purpose: for the builtin the compiler
 // puts a full vmcnt(0) in front of the next ds_read of ANY LDS address, which would serialise the copy with the MFMAs of the
 // current item; the waits are counted by hand in gx_item instead.
@@ -472,7 +461,7 @@ __device__ __forceinline__ void gx_dma(const char *hx, char *lds_buf, const GxIt
     unsigned keep;
 #pragma unroll
     for (int j = 0; j < GX_NDMA; ++j) {
-        if (j == GX_NDMA - 1 && wave_u != 0) break;      // the last 768 B (rounded to one wave; the image has slack behind it)
+        if (j == GX_NDMA - 1 && wave_u != 0) break;      // the last 512 B (rounded to one wave; the image has slack behind it)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
                      : "v"(voff), "s"(src + j * 4096), "s"(dst + j * 4096)
@@ -481,7 +470,7 @@ __device__ __forceinline__ void gx_dma(const char *hx, char *lds_buf, const GxIt
 #endif
 }
 
-// One work item = (LVC block, 128-column group, utterance, 64 frames): 2 frame tiles x 72 MFMAs per wave.
+// One work item = (LVC block, 128-column group, utterance, 64 frames): 2 frame tiles x 36 MFMAs per wave.
 //   BUF   which LDS buffer holds this item's window (the other one receives the next item's window by DMA meanwhile)
 //   FULL  both tiles are whole (always, except the ragged last chunk of an utterance)
 // Vector-memory order per item: [DMA of next window] [16 stores of tile 0] [16 stores of tile 1].  vmcnt retires in order,
@@ -489,7 +478,7 @@ __device__ __forceinline__ void gx_dma(const char *hx, char *lds_buf, const GxIt
 // never waited for on this path.
 template <int BUF, bool FULL>
 __device__ __forceinline__ void gx_item(char *lds, const GxItem &cur, bool more, const GxItem &nxt, const char *hx, float *kpack,
-                                        const float4 (&wq)[3][12], float bias, const int (&aoff)[12], int B, int T, int R,
+                                        const float4 (&wq)[2][12], float bias, const int (&aoff)[2][12], int B, int T, int R,
                                         int wave_u, int lane)
 {
     const int l31 = lane & 31, hi = lane >> 5;
@@ -501,22 +490,17 @@ __device__ __forceinline__ void gx_item(char *lds, const GxItem &cur, bool more,
 #pragma unroll
     for (int tile = 0; tile < 2; ++tile) {
         if (!FULL && tile >= n_tiles) break;
-        f32x16 acc;
+        f32x16 acc, lo;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = bias;
+        for (int r = 0; r < 16; ++r) { acc[r] = bias; lo[r] = 0.0f; }
         const char *hb = lds + BUF * GX_BUFB + tile * 32 * GX_ROWB;
 #pragma unroll
         for (int kg = 0; kg < 12; ++kg) {      // kg = tap*4 + k4: logical k = kg*16 + 8*hi + e = tap*64 + channel
-            const float4 a1 = *reinterpret_cast<const float4 *>(hb + aoff[kg]);
-            const float4 a2 = *reinterpret_cast<const float4 *>(hb + aoff[kg] + 128);
-            const float4 a3 = *reinterpret_cast<const float4 *>(hb + aoff[kg] + 256);
-            // leading term first, then the corrections: W1h1 | W2h1, W1h2 | W3h1, W2h2, W1h3
-            acc = mfma_bf16(a1, wq[0][kg], acc);
-            acc = mfma_bf16(a1, wq[1][kg], acc);
-            acc = mfma_bf16(a2, wq[0][kg], acc);
-            acc = mfma_bf16(a1, wq[2][kg], acc);
-            acc = mfma_bf16(a2, wq[1][kg], acc);
-            acc = mfma_bf16(a3, wq[0][kg], acc);
+            const float4 a1 = *reinterpret_cast<const float4 *>(hb + aoff[0][kg]);
+            const float4 a2 = *reinterpret_cast<const float4 *>(hb + aoff[1][kg]);
+            acc = mfma_f16(a1, wq[0][kg], acc);
+            lo = mfma_f16(a2, wq[0][kg], lo);
+            lo = mfma_f16(a1, wq[1][kg], lo);
         }
         if (FULL && tile == 1 && more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // DMA landed; tile-0 stores may fly
 #ifdef FD_GX_NO_STORE
@@ -525,28 +509,29 @@ __device__ __forceinline__ void gx_item(char *lds, const GxItem &cur, bool more,
         float *kt = krow + (int64_t)tile * 32 * fd::KREC;
         if (FULL) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) (kt + ((r & 3) + 8 * (r >> 2)) * fd::KREC)[loff] = acc[r];
+            for (int r = 0; r < 16; ++r) (kt + ((r & 3) + 8 * (r >> 2)) * fd::KREC)[loff] = fmaf(lo[r], GX_INV_SCALE, acc[r]);
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (t_begin + tile * 32 + drow(r, hi) < T) (kt + ((r & 3) + 8 * (r >> 2)) * fd::KREC)[loff] = acc[r];
+                if (t_begin + tile * 32 + drow(r, hi) < T)
+                    (kt + ((r & 3) + 8 * (r >> 2)) * fd::KREC)[loff] = fmaf(lo[r], GX_INV_SCALE, acc[r]);
         }
     }
     if (!FULL && more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();      // every wave's DMA share is in LDS; everybody is done reading this item's buffer
 }
 
-__global__ void __launch_bounds__(256, 2) k_kp_gemm_x3(const char *__restrict__ hx /*[3][B][R][3][64] bf16*/, float *__restrict__ kpack,
+__global__ void __launch_bounds__(256, 2) k_kp_gemm_h2(const char *__restrict__ hx /*[3][B][R][2][64] fp16*/, float *__restrict__ kpack,
                                                        const float4 *g0, const float4 *g1, const float4 *g2, const float *gb0,
-                                                       const float *gb1, const float *gb2, int B, int T, int R, int chunks_per_utt,
-                                                       int n_items)
+                                                       const float *gb1, const float *gb2, const int *__restrict__ range_flag, int B,
+                                                       int T, int R, int chunks_per_utt, int n_items)
 {
-    __shared__ __attribute__((aligned(16))) char lds[2 * GX_BUFB];     // 2 x 28 KB
+    __shared__ __attribute__((aligned(16))) char lds[2 * GX_BUFB];     // 2 x 20 KB
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int XG = fd::KREC / 128;
     const int i0 = (int)((int64_t)blockIdx.x * n_items / gridDim.x), i1 = (int)((int64_t)(blockIdx.x + 1) * n_items / gridDim.x);
-    if (i0 >= i1) return;
+    if (i0 >= i1 || *range_flag != 0) return;      // out-of-range operands: the fp32 kernel behind us does this step
 
     // items are ordered (block, column group, utterance, chunk), chunk fastest: consecutive items share the weights
     GxItem cur;
@@ -570,21 +555,23 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm_x3(const char *__restrict__ 
         return it;
     };
 
-    // byte offset of the 12 A-operand reads of a tile: row = frame + tap, 16-byte slot (2*k4 + hi) ^ ((row >> 1) & 7)
-    int aoff[12];
+    // byte offsets of the A-operand reads of a tile: row = frame + tap, slot = (8*piece + 2*k4 + hi) ^ (row & 15)
+    int aoff[2][12];
 #pragma unroll
-    for (int tap = 0; tap < 3; ++tap)
+    for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-            const int row = l31 + tap;
-            aoff[tap * 4 + k4] = row * GX_ROWB + (((k4 * 2 + hi) ^ ((row >> 1) & 7)) << 4);
-        }
+        for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int row = l31 + tap;
+                aoff[q][tap * 4 + k4] = row * GX_ROWB + (((q * 8 + k4 * 2 + hi) ^ (row & 15)) << 4);
+            }
 
     gx_dma(hx, lds, cur, B, R, wave_u, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    float4 wq[3][12];
+    float4 wq[2][12];
     float bias = 0.0f;
     int have_blk = -1, have_xg = -1;
 #pragma unroll 1
@@ -597,9 +584,9 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm_x3(const char *__restrict__ 
                 const float *gb = cur.blk == 0 ? gb0 : (cur.blk == 1 ? gb1 : gb2);
                 const int ptile = cur.xg * 4 + wave_u;
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
+                for (int q = 0; q < 2; ++q)
 #pragma unroll
-                    for (int kg = 0; kg < 12; ++kg) wq[q][kg] = gp[(((int64_t)ptile * 3 + q) * 12 + kg) * 64 + lane];
+                    for (int kg = 0; kg < 12; ++kg) wq[q][kg] = gp[(((int64_t)ptile * 2 + q) * 12 + kg) * 64 + lane];
                 bias = gb[ptile * 32 + l31];
                 have_blk = cur.blk; have_xg = cur.xg;
                 // retire the loads here, visibly to the compiler: otherwise it places a vmcnt(0) at the first use, on the
@@ -1083,26 +1070,29 @@ hipError_t fast_kp_gemm(const Launch &L, int B, int T)
     fd_context *c = L.ctx;
     const DevWeights &w = c->w;
     const int tiles_per_utt = (T + 31) / 32;
-    const int ct = c->gemm_x3 ? GX_CT : GEMM_CT;
-    const int chunks_per_utt = (tiles_per_utt + ct - 1) / ct;
-    const int chunk_tiles = (tiles_per_utt + chunks_per_utt - 1) / chunks_per_utt;     // balanced, <= ct
+    const int chunks_per_utt = (tiles_per_utt + GEMM_CT - 1) / GEMM_CT;
+    const int chunk_tiles = (tiles_per_utt + chunks_per_utt - 1) / chunks_per_utt;     // balanced, <= GEMM_CT
     const int n_items = fd::NBLK * (fd::KREC / 128) * B * chunks_per_utt;
     const int grid = n_items < 2 * c->num_cus ? n_items : 2 * c->num_cus;              // persistent: 2 workgroups per CU
-    if (c->gemm_x3) {
+    const bool f16 = c->gemm_f16 && w.gemm_f16_ok;
+    if (f16) {
         const int R = gx_rows(T);
         const int chunks = (T + 63) / 64, items = fd::NBLK * (fd::KREC / 128) * B * chunks;
-        const int grid3 = items < 2 * c->num_cus ? items : 2 * c->num_cus;
+        const int grid2 = items < 2 * c->num_cus ? items : 2 * c->num_cus;
+        hipError_t e = hipMemsetAsync(c->ws.range_flag, 0, sizeof(int), L.stream);
+        if (e != hipSuccess) return e;
         FD_LAUNCH(L, "h_split", k_h_split, dim3((32 * R + 255) / 256, fd::NBLK * B), dim3(256), 0, (const float *)c->ws.kp_hB,
-                  reinterpret_cast<unsigned *>(c->ws.h_x3), B, T, R);
-        FD_LAUNCH(L, "kp_gemm_bf16x3", k_kp_gemm_x3, dim3(grid3), dim3(256), 0, reinterpret_cast<const char *>(c->ws.h_x3), c->ws.kpack,
-                  reinterpret_cast<const float4 *>(w.gemm_x3_pack[0]), reinterpret_cast<const float4 *>(w.gemm_x3_pack[1]),
-                  reinterpret_cast<const float4 *>(w.gemm_x3_pack[2]), w.gemm_bias[0], w.gemm_bias[1], w.gemm_bias[2], B, T, R, chunks,
-                  items);
+                  reinterpret_cast<unsigned *>(c->ws.h_f16), c->ws.range_flag, B, T, R);
+        FD_LAUNCH(L, "kp_gemm_f16x2", k_kp_gemm_h2, dim3(grid2), dim3(256), 0, reinterpret_cast<const char *>(c->ws.h_f16), c->ws.kpack,
+                  reinterpret_cast<const float4 *>(w.gemm_h2_pack[0]), reinterpret_cast<const float4 *>(w.gemm_h2_pack[1]),
+                  reinterpret_cast<const float4 *>(w.gemm_h2_pack[2]), w.gemm_bias[0], w.gemm_bias[1], w.gemm_bias[2],
+                  (const int *)c->ws.range_flag, B, T, R, chunks, items);
     }
-    else
-        FD_LAUNCH(L, "kp_gemm", k_kp_gemm, dim3(grid), dim3(256), 0, (const float *)c->ws.kp_hB, c->ws.kpack, w.gemm_pack[0],
-                  w.gemm_pack[1], w.gemm_pack[2], w.gemm_bias[0], w.gemm_bias[1], w.gemm_bias[2], B, T, chunks_per_utt,
-                  chunk_tiles, n_items);
+    // fp32 matrix pipe: the whole job when the fp16 form is off, otherwise an early-exit launch that only works when
+    // k_h_split found operands outside the fp16 range
+    FD_LAUNCH(L, f16 ? "kp_gemm_fp32_fallback" : "kp_gemm", k_kp_gemm, dim3(grid), dim3(256), 0, (const float *)c->ws.kp_hB, c->ws.kpack,
+              w.gemm_pack[0], w.gemm_pack[1], w.gemm_pack[2], w.gemm_bias[0], w.gemm_bias[1], w.gemm_bias[2], B, T, chunks_per_utt,
+              chunk_tiles, n_items, f16 ? (const int *)c->ws.range_flag : (const int *)nullptr);
     return hipSuccess;
 }
 

@@ -117,7 +117,8 @@ FD_API int fd_peak_normalize_int16(fd_handle h, const float *wav, int B, int64_t
 
 /* Options: "kernels" = "fast" | "naive" (all stages), "kernels.<stage>" for one stage
  * (embed, first, dblock, kp_front, kp_gemm, convt, lvc, final); "graph" = "1" | "0"; "profile" = "1" | "0";
- * "gemm" = "bf16x3" (default: exact 3-way bf16 operand split on the bf16 matrix pipe, fp32-level error) | "fp32";
+ * "gemm" = "f16x2" (default: predictor GEMM on the fp16 matrix pipe with 2-piece operands, 22 bits each; error below
+ *          an fp32 sgemm; operands outside the fp16 range fall back to fp32 on the device) | "fp32";
  * "taps" = "1" | "0" (keep block outputs for fd_read_tap). */
 FD_API int fd_set_option(fd_handle h, const char *key, const char *value);
 

@@ -1,4 +1,4 @@
-// gemm_x3_bench.hip -- standalone timing harness for k_h_split + k_kp_gemm_x3 (build variants with -DFD_GX_NO_STORE / -DFD_GX_NO_FETCH)
+// gemm_h2_bench.hip -- standalone timing harness for k_h_split + k_kp_gemm_h2 (build variants with -DFD_GX_NO_STORE / -DFD_GX_NO_FETCH)
 #include "../../fastdiff_amd/csrc/fd_kernels_fast.hip"
 #include <stdio.h>
 #include <stdlib.h>
@@ -10,20 +10,28 @@ int main(int argc, char **argv)
 {
     const int B = argc > 1 ? atoi(argv[1]) : 8, T = argc > 2 ? atoi(argv[2]) : 864, G = argc > 3 ? atoi(argv[3]) : 512;
     const int R = fdk_fast::gx_rows(T);
-    const size_t nh = (size_t)3 * B * 64 * T, nk = (size_t)3 * B * T * fd::KREC, ng = (size_t)776 * 3 * 12 * 64 * 4, nx = (size_t)3 * B * 3 * R * 32 + 256;
+    const size_t nh = (size_t)3 * B * 64 * T, nk = (size_t)3 * B * T * fd::KREC, ng = (size_t)776 * 2 * 12 * 64 * 4, nx = (size_t)3 * B * R * 64 + 256;
     float *h, *kp, *g, *gb, *hx;
+    int *flag;
+    CK(hipMalloc(&flag, 256)); CK(hipMemset(flag, 0, 256));
     CK(hipMalloc(&h, nh * 4)); CK(hipMalloc(&kp, nk * 4)); CK(hipMalloc(&g, ng * 4)); CK(hipMalloc(&gb, fd::KREC * 4)); CK(hipMalloc(&hx, nx * 4));
     std::vector<float> v(ng);
     for (size_t i = 0; i < ng; ++i) v[i] = (float)((i * 2654435761u) % 2001) * 1e-3f - 1.0f;
-    CK(hipMemcpy(g, v.data(), ng * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(h, v.data(), nh * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(h, v.data(), nh * 4, hipMemcpyHostToDevice));
+    {   // fp16 weight pieces of plausible magnitude (2^-7 .. 2^-2), random sign and mantissa
+        std::vector<unsigned short> w16(ng * 2);
+        unsigned x = 12345u;
+        for (auto &b : w16) { x = x * 1664525u + 1013904223u; b = (unsigned short)(((x >> 16) & 0x8000u) | ((8u + ((x >> 8) % 6u)) << 10) | ((x >> 20) & 0x3FFu)); }
+        CK(hipMemcpy(g, w16.data(), ng * 4, hipMemcpyHostToDevice));
+    }
     CK(hipMemcpy(gb, v.data(), fd::KREC * 4, hipMemcpyHostToDevice));
     const int tiles_per_utt = (T + 31) / 32, chunks = (tiles_per_utt + fdk_fast::GX_CT - 1) / fdk_fast::GX_CT;
     const int n_items = 3 * (fd::KREC / 128) * B * chunks;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto run = [&]() {
-        hipLaunchKernelGGL(fdk_fast::k_h_split, dim3((32 * R + 255) / 256, 3 * B), dim3(256), 0, 0, h, (unsigned *)hx, B, T, R);
-        hipLaunchKernelGGL(fdk_fast::k_kp_gemm_x3, dim3(G), dim3(256), 0, 0, (const char *)hx, kp, (const float4 *)g, (const float4 *)g,
-                           (const float4 *)g, gb, gb, gb, B, T, R, chunks, n_items);
+        hipLaunchKernelGGL(fdk_fast::k_h_split, dim3((32 * R + 255) / 256, 3 * B), dim3(256), 0, 0, h, (unsigned *)hx, flag, B, T, R);
+        hipLaunchKernelGGL(fdk_fast::k_kp_gemm_h2, dim3(G), dim3(256), 0, 0, (const char *)hx, kp, (const float4 *)g, (const float4 *)g,
+                           (const float4 *)g, gb, gb, gb, (const int *)flag, B, T, R, chunks, n_items);
     };
     for (int i = 0; i < 2; ++i) run();
     CK(hipDeviceSynchronize());
@@ -34,12 +42,5 @@ int main(int argc, char **argv)
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / reps, flops = 3 * 2.0 * 24832 * 192 * (double)B * T;
     printf("h_split+kp_gemm_x3 B=%d T=%d grid=%d items=%d: %.1f us  %.1f TFLOP/s(fp32-equivalent)\n", B, T, G, n_items, us, flops / us / 1e6);
-#ifdef FD_GX_TIMING
-    long long d[8];
-    CK(hipMemcpyFromSymbol(d, HIP_SYMBOL(fdk_fast::fd_gxdbg), sizeof(d)));
-    const char *nm[6] = {"weights", "decode+fetch issue", "mfma (per tile, to last issue)", "stores issue", "commit (vm wait + ds_write)", "barrier"};
-    const double runs = 7.0 * G * 4, items = (double)n_items / G;
-    for (int k = 0; k < 6; ++k) printf("   %-32s %9.0f ticks per wave per launch, %7.1f per item\n", nm[k], d[k] / runs, d[k] / runs / items);
-#endif
     return 0;
 }
