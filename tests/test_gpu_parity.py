@@ -99,6 +99,68 @@ def test_each_fast_stage_against_oracle(model, gc, oracle64, stage):
     assert gc.maxdiff(y, y_ref) < FWD_TOL
 
 
+def _predicted_kernel_error(model, gc, oracle64, audio, mel, steps, B, T):
+    """max |predicted kernels / biases - float64 oracle| over the three KernelPredictors, and the eps error."""
+    y_ref, ref = oracle64.forward(audio, mel, steps, taps=True)
+    model.set_option("taps", "1")
+    try:
+        y = gc.run_forward(model, audio, mel, steps)
+        taps = gc.read_taps(model, B, T)
+    finally:
+        model.set_option("taps", "0")
+    errs = [gc.maxdiff(taps[f"kernels{n}"], ref[f"kernels{n}"]) for n in range(3)]
+    errs += [gc.maxdiff(taps[f"bias{n}"], ref[f"bias{n}"]) for n in range(3)]
+    return max(errs), gc.maxdiff(y, y_ref)
+
+
+def test_predictor_gemm_f16x2_is_no_worse_than_fp32_pipe(model, gc, oracle64):
+    """The default predictor GEMM runs on the fp16 matrix pipe with 2-piece (22-bit) operands; the fp32-MFMA form is kept
+    behind option gemm=fp32.  Both must sit inside the forward tolerance, and the split form must not be the less accurate
+    one (it accumulates the small cross terms separately)."""
+    import synth
+    B, T = 2, 130                     # 2 full 64-frame items + a ragged one per utterance
+    mel, audio = synth.synth_mel(21, B, T), synth.synth_audio(21, B, T)
+    steps = np.array([1.0, 733.5], np.float32)
+    err = {}
+    try:
+        for mode in ("f16x2", "fp32"):
+            model.set_option("gemm", mode)
+            err[mode] = _predicted_kernel_error(model, gc, oracle64, audio, mel, steps, B, T)
+    finally:
+        model.set_option("gemm", "f16x2")
+    print("predicted-kernel / eps max error vs float64 oracle:", err)
+    for mode in err:
+        assert err[mode][0] < FWD_TOL and err[mode][1] < FWD_TOL, (mode, err[mode])
+    assert err["f16x2"][0] <= 1.5 * err["fp32"][0]
+
+
+def test_predictor_gemm_out_of_fp16_range_falls_back_on_device(gc, oracle64):
+    """|h| >= 32768 cannot be split into fp16 pieces: k_h_split flags it and the fp32 kernel behind the fp16 one does the
+    step (include/fastdiff_hip.h, option "gemm").  Forced here by scaling the last predictor residual conv of block 0."""
+    import synth
+    sd = synth.synth_state_dict(1234)
+    key = [k for k in sd if k.startswith("lvc_blocks.0.kernel_predictor.residual_conv") and k.endswith("weight_g")][-1]
+    sd = dict(sd)
+    sd[key] = (sd[key] * 3.0e5).astype(np.float32)
+    m = gc.fastdiff_amd.FastDiff()
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    m = m.cuda().eval()
+    o = type(oracle64)("f64")
+    o.set_weights(sd)
+    B, T = 1, 70
+    mel, audio = synth.synth_mel(5, B, T), synth.synth_audio(5, B, T)
+    steps = np.array([12.0], np.float32)
+    y_ref, ref = o.forward(audio, mel, steps, taps=True)
+    m.set_option("taps", "1")
+    y = gc.run_forward(m, audio, mel, steps)
+    taps = gc.read_taps(m, B, T)
+    scale = float(np.abs(ref["kernels0"]).max())
+    assert scale > 1.0e3                                   # the operands really were out of range
+    assert np.isfinite(y).all()
+    assert gc.maxdiff(taps["kernels0"], ref["kernels0"]) < 1e-5 * scale
+    assert gc.maxdiff(taps["kernels1"], ref["kernels1"]) < FWD_TOL      # blocks 1, 2 unaffected
+
+
 @pytest.mark.parametrize("B,T", [(1, 1), (3, 3), (1, 63), (2, 130)])
 def test_forward_ragged_sizes_against_oracle(model, gc, oracle64, B, T):
     import synth
