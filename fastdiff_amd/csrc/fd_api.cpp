@@ -332,8 +332,8 @@ static float f32_from_f16(uint16_t hb)
 void unpack_kernel_index(int p, int &layer, int &in, int &out, int &tap)
 {
     layer = p / fd::KLAYER;
-    const int q = p % fd::KLAYER, r = q & 3, lane = (q >> 2) & 63, ms = q >> 8;
-    const int mt = ms / 12, s4 = ms % 12, step = 4 * s4 + r, kk = 2 * step + (lane >> 5), row = lane & 31;
+    const int q = p % fd::KLAYER, e = q & 7, lane = (q >> 3) & 63, mk = q >> 9;
+    const int mt = mk / 6, kg = mk % 6, kk = kg * 16 + 8 * (lane >> 5) + e, row = lane & 31;
     tap = kk / fd::C; in = kk % fd::C;
     out = 16 * mt + (row & 15) + 32 * (row >> 4);      // inverse of kernel_tile / kernel_row
 }

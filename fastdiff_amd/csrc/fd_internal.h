@@ -41,9 +41,10 @@ __host__ __device__ inline int kernel_row(int out) { return (out & 15) + 16 * (o
 __host__ __device__ inline int kernel_tile(int out) { return (out & 31) >> 4; }
 __host__ __device__ inline int kernel_index(int layer, int in, int out, int tap)
 {
-    const int kk = tap * C + in, step = kk >> 1, hi = kk & 1;
-    const int s4 = step >> 2, r = step & 3, mt = kernel_tile(out), lane = kernel_row(out) + 32 * hi;
-    return layer * KLAYER + ((mt * 12 + s4) * 64 + lane) * 4 + r;
+    // A operand of a 32x32x16 MFMA: lane = row + 32*g holds the 8 consecutive k = 16*kg + 8*g + e, k = tap*32 + in
+    const int kk = tap * C + in, kg = kk >> 4, g = (kk >> 3) & 1, e = kk & 7;
+    const int mt = kernel_tile(out), lane = kernel_row(out) + 32 * g;
+    return layer * KLAYER + ((mt * 6 + kg) * 64 + lane) * 8 + e;
 }
 // Position of predicted bias (layer, out): same [mt][row] order as the kernel rows.
 __host__ __device__ inline int bias_index(int layer, int out) { return KW + layer * 64 + kernel_tile(out) * 32 + kernel_row(out); }

@@ -746,13 +746,13 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
         if (wave_valid) {
             const int f = (w0 + lcw) / HOP;
             const float *rec = kpack + ((int64_t)b * T + f) * fd::KREC;
-            const float4 *kp4 = reinterpret_cast<const float4 *>(rec + layer * fd::KLAYER) + lane;
+            const float4 *kp4 = reinterpret_cast<const float4 *>(rec + layer * fd::KLAYER) + 2 * lane;   // [mt][kg][lane][8 k]
             // D rows of a lane are {0..3, 8..11, 16..19, 24..27} + 4*hi: four 16 B loads per 32-row tile
             const float4 *kb4 = reinterpret_cast<const float4 *>(rec + fd::KW + layer * 64);
 #pragma unroll
             for (int m = 0; m < LT; ++m) {
 #pragma unroll
-                for (int i = 0; i < 12; ++i) ka[m][i] = kp4[((mt0 + m) * 12 + i) * 64];
+                for (int i = 0; i < 12; ++i) ka[m][i] = kp4[((mt0 + m) * 6 + (i >> 1)) * 128 + (i & 1)];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bz[m][j] = kb4[(mt0 + m) * 8 + 2 * j + hi];
             }
@@ -905,11 +905,12 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
             for (int m = 0; m < LT; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a[nt][m][r] = f4c(bz[m][r >> 2], r & 3);
-            const int yc = hi * YLD + lcw + nt * 32 + l31;             // y index = column + 1 + (tap - 1)
+            // k-step s <-> k = 16*(s>>3) + 8*hi + (s&7) (the record's lane order): tap = s>>4, channel = 16*((s>>3)&1) + 8*hi + (s&7)
+            const int yc = hi * 8 * YLD + lcw + nt * 32 + l31;         // y index = column + 1 + (tap - 1)
             const int yo[3] = {opaque(yc), opaque(yc + 1), opaque(yc + 2)};
 #pragma unroll
             for (int s = 0; s < 48; ++s) {
-                const int tap = s >> 4, c2 = (2 * s) & 31;
+                const int tap = s >> 4, c2 = 16 * ((s >> 3) & 1) + (s & 7);
                 const float v = ys[yo[tap] + c2 * YLD];
 #pragma unroll
                 for (int m = 0; m < LT; ++m) a[nt][m] = mfma32(f4c(ka[m][s >> 2], s & 3), v, a[nt][m]);
@@ -932,10 +933,10 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
             const int f = (w0 + cw) / HOP + fi;
             if (f >= T) break;                 // T need not be a multiple of 4: the last wave may own fewer frames
             const float *rec = kpack + ((int64_t)b * T + f) * fd::KREC;
-            const float4 *kp4 = reinterpret_cast<const float4 *>(rec + layer * fd::KLAYER) + (int64_t)mt * 12 * 64 + l31;
-            float4 ke[12], ko[12];   // even / odd kk of this lane's output row
+            const float4 *kp4 = reinterpret_cast<const float4 *>(rec + layer * fd::KLAYER) + (mt * 6 * 64 + l31) * 2;
+            float4 ke[12], ko[12];   // this row's k = 16*kg + e and 16*kg + 8 + e (e < 8): the two half-wave shares of the record
 #pragma unroll
-            for (int i = 0; i < 12; ++i) { ke[i] = kp4[i * 64]; ko[i] = kp4[i * 64 + 32]; }
+            for (int i = 0; i < 12; ++i) { ke[i] = kp4[(i >> 1) * 128 + (i & 1)]; ko[i] = kp4[(i >> 1) * 128 + 64 + (i & 1)]; }
             float z[8];
             const float bzv = rec[fd::KW + layer * 64 + lane];     // bias record is [mt][row] too
 #pragma unroll
@@ -950,8 +951,8 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
                 const float yv[10] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w, y2.x, y2.y};
 #pragma unroll
                 for (int tap = 0; tap < 3; ++tap) {
-                    const int kk = tap * 32 + in, step = kk >> 1;
-                    const float kv = (kk & 1) ? f4c(ko[step >> 2], step & 3) : f4c(ke[step >> 2], step & 3);
+                    const int kk = tap * 32 + in, kg = kk >> 4, e = kk & 7;
+                    const float kv = (kk & 8) ? f4c(ko[2 * kg + (e >> 2)], e & 3) : f4c(ke[2 * kg + (e >> 2)], e & 3);
 #pragma unroll
                     for (int c = 0; c < 8; ++c) z[c] += kv * yv[c + tap];
                 }
