@@ -385,7 +385,7 @@ int fd_commit_weights(fd_handle h)
         }
         UP(table, w.embed_table);
     }
-    bool f16_ok = true;
+    bool f16_ok = true, lvc_ok = true;
     for (int n = 0; n < fd::NBLK; ++n) {
         const std::string p = "lvc_blocks." + std::to_string(n), d = "downsample." + std::to_string(n);
         if ((rc = up_conv(d + ".residual_dense", w.down[n].res)) != FD_OK) return rc;
@@ -425,6 +425,22 @@ int fd_commit_weights(fd_handle h)
         for (int i = 0; i < fd::LAYERS; ++i) {
             if ((rc = up_conv(p + ".convs." + std::to_string(i), w.blk[n].convs[i])) != FD_OK) return rc;
             UP(pack_A(f[p + ".convs." + std::to_string(i)].w, fd::C, fd::C, 3), w.lvc_conv_pack[n][i]);
+            {   // fp16 pieces in 32x32x16 A-operand order: lane = out + 32*g holds k = 16*kg + 8*g + e, k = tap*32 + in
+                const std::vector<float> &cw = f[p + ".convs." + std::to_string(i)].w;      // [out][in][3]
+                std::vector<uint16_t> hp((size_t)2 * 6 * 64 * 8);
+                for (int kg = 0; kg < 6; ++kg)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int kk = kg * 16 + 8 * (lane >> 5) + e, tap = kk / fd::C, in = kk % fd::C, out = lane & 31;
+                            const float v = cw[((size_t)out * fd::C + in) * 3 + tap];
+                            if (!(fabsf(v) < 32768.0f)) lvc_ok = false;
+                            const uint16_t p1 = f16_from_f32(v);
+                            hp[((size_t)(0 * 6 + kg) * 64 + lane) * 8 + e] = p1;
+                            hp[((size_t)(1 * 6 + kg) * 64 + lane) * 8 + e] = f16_from_f32((v - f32_from_f16(p1)) * 2048.0f);
+                        }
+                if ((rc = upload(h, hp.data(), hp.size() * sizeof(uint16_t), reinterpret_cast<const void **>(&w.lvc_conv_h2[n][i]))) != FD_OK)
+                    return rc;
+            }
         }
         {   // GEMM B-operand pack: rows in packed-record order, kk = tap*64 + c
             const std::vector<float> &kc = f[p + ".kernel_predictor.kernel_conv"].w, &kcb = f[p + ".kernel_predictor.kernel_conv"].b;
@@ -486,6 +502,7 @@ int fd_commit_weights(fd_handle h)
         }
     }
     w.gemm_f16_ok = f16_ok;
+    w.lvc_f16_ok = lvc_ok;
     {
         std::vector<int> perm(fd::KW);
         for (int layer = 0; layer < fd::LAYERS; ++layer)
@@ -646,6 +663,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
     fdk::Launch L = {h, (hipStream_t)stream, false};
     StepIO io = {x, mel, steps, eps_out, 0};
     hipError_t e = fdk::embed(L, io, B, 1);
+    if (e == hipSuccess) e = fdk::clear_range_flags(L);
     if (e == hipSuccess) e = fdk::run_step(L, io, B, T);
     if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_forward: kernel launch failed: %s", hipGetErrorString(e));
     h->last_B = B; h->last_T = T;
@@ -654,7 +672,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
 
 static unsigned mode_signature(const fd_context *h)
 {
-    unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_f16 ? 2u : 0u);
+    unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_f16 ? 2u : 0u) | (h->lvc_f16 ? 4u : 0u);
     for (int i = 0; i < ST_COUNT; ++i) s = (s << 1) | (h->fast[i] ? 1u : 0u);
     return s;
 }
@@ -697,6 +715,7 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
 
     StepIO io = {ws.x, ws.mel, nullptr, nullptr, 1};
     if ((e = fdk::embed(L, io, B, N)) != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample: embed failed: %s", hipGetErrorString(e));
+    if ((e = fdk::clear_range_flags(L)) != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample: %s", hipGetErrorString(e));
 
     const bool graph = h->use_graph && !h->profile;
     if (graph) {
@@ -773,6 +792,12 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
         else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: gemm expects f16x2|fp32, got '%s'", value);
         return FD_OK;
     }
+    if (k == "lvc") {
+        if (v == "f16x2") h->lvc_f16 = true;
+        else if (v == "fp32") h->lvc_f16 = false;
+        else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: lvc expects f16x2|fp32, got '%s'", value);
+        return FD_OK;
+    }
     if (k == "graph") { h->use_graph = on; return FD_OK; }
     if (k == "profile") { h->profile = on; return FD_OK; }
     if (k == "taps") { h->keep_taps = on; return FD_OK; }
@@ -802,6 +827,8 @@ int64_t fd_read_tap(fd_handle h, const char *name, float *host_dst, int64_t capa
         if (!h->keep_taps) FD_FAIL(h, FD_ERR_STATE, "fd_read_tap: set option taps=1 before the forward to keep block outputs");
         const int blk = k[1] - '0';
         src = w.xtap[blk]; n = (int64_t)B * fd::C * T * fd::hop(blk);
+    } else if (k == "range_flags") {       // 16 int32 (bit patterns): fp16-range flags of the last step, see Workspace::range_flag
+        src = reinterpret_cast<const float *>(w.range_flag); n = 16;
     } else FD_FAIL(h, FD_ERR_INVALID, "fd_read_tap: unknown tap '%s'", name);
     if (!host_dst) return n;
     if (capacity < n) FD_FAIL(h, FD_ERR_INVALID, "fd_read_tap: capacity %lld < %lld", (long long)capacity, (long long)n);

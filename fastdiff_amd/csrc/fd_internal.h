@@ -70,6 +70,8 @@ struct DevWeights {
     // MFMA A-operand packs ([mt][s4][lane][4], kk = tap*Cin + in)
     const float *down_pack[fd::NBLK][4] = {};     // conv0..2 (K=96), res 1x1 (K=32)
     const float *lvc_conv_pack[fd::NBLK][fd::LAYERS] = {};
+    const uint16_t *lvc_conv_h2[fd::NBLK][fd::LAYERS] = {};   // the same as two fp16 pieces: [piece][6 kg][64 lane][8], k = tap*32 + in
+    bool lvc_f16_ok = false;                      // every LVC conv weight fits the fp16 range
     const float *kp_in_pack[fd::NBLK] = {};       // 80->64 k5: 2 mt x 50 s4
     const float *kp_res_pack[fd::NBLK][6] = {};   // 64->64 k3: 2 mt x 24 s4
     const float *gemm_pack[fd::NBLK] = {};        // kernel_conv+bias_conv as MFMA B operand: [776 ptile][24 s4][64][4]
@@ -104,7 +106,7 @@ struct Workspace {
     float *kp_h0 = nullptr, *kp_hA = nullptr, *kp_hB = nullptr;   // [3][B][64][T]
     float *kpack = nullptr;     // [3][B][T][KREC]
     float *h_f16 = nullptr;     // fp16 piece image of the predictor hidden state: [3][B][64*ceil(T/64)+2 rows][2 pieces][64] x 2 B
-    int *range_flag = nullptr;  // set by k_h_split when an operand does not fit fp16
+    int *range_flag = nullptr;  // [0] predictor GEMM, [1 + 4*block + layer] LVC layers: an operand did not fit fp16; zeroed every step
     float *xA = nullptr, *xB = nullptr;                           // [B][32][L] ping-pong
     float *xtap[fd::NBLK] = {}; // block outputs kept for fd_read_tap
     float *mel = nullptr;       // [B][80][T] library-owned copy used by the sampler graph
@@ -127,6 +129,7 @@ struct fd_context {
     bool profile = false;
     bool keep_taps = false;
     bool gemm_f16 = true;                     // kp_gemm on the fp16 matrix pipe with the 2-piece operand split
+    bool lvc_f16 = true;                      // LVC layers (hop 64, 256) likewise
     std::map<std::string, std::pair<std::vector<int64_t>, std::vector<float>>> raw;   // host copies from fd_set_weight
     std::vector<void *> dev_allocs;          // weight arena pieces
     DevWeights w;
@@ -166,6 +169,7 @@ hipError_t dblock(const Launch &L, int d, int B, int T);
 hipError_t kp_front(const Launch &L, const StepIO &io, int B, int T);
 hipError_t kp_gemm(const Launch &L, int B, int T);
 hipError_t advance_step(const Launch &L);
+hipError_t clear_range_flags(const Launch &L);     // before the first step of a call
 hipError_t init_noise(const Launch &L, float *x, int64_t n, unsigned long long seed);
 hipError_t peak_normalize_int16(const Launch &L, const float *wav, int B, int64_t len, int16_t *pcm);
 }  // namespace fdk

@@ -717,9 +717,10 @@ template <int HOP, int DIL>
 __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ xin, const float *__restrict__ skip,
                                                       float *__restrict__ xout, const float *__restrict__ kpack, int layer,
                                                       const float *__restrict__ wpack, const float *__restrict__ wref,
-                                                      const float *__restrict__ cbias, int T)
+                                                      const float *__restrict__ cbias, int T, const int *__restrict__ run_if)
 {
     using Cfg = LvcCfg<HOP, DIL>;
+    if (run_if && *run_if == 0) return;      // fallback launch behind k_lvc_h2: only when that kernel flagged its operands
     constexpr int WC = Cfg::WC, W = Cfg::W, H = Cfg::H, XLD = Cfg::XLD, YLD = Cfg::YLD, NT = WC / 32;
     // LVC work split (hop >= 64).  hop 256: the whole tile is ONE frame, so the waves split the 64 output rows instead of
     // re-loading the same kernel four times: wave = (row tile mt, column half), 4 column tiles each, 48 operand registers.
@@ -977,6 +978,276 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
 }
 
 // =================================================================================================
+// The same LVC layer on the fp16 matrix pipe (hop 64 and 256), 2-piece operands as in k_kp_gemm_h2:
+//   v = v1 + 2^-11 v2 (fp16 pieces, 22 bits);  A.B ~= A1.B1 + 2^-11 (A1.B2 + A2.B1), fp32 accumulation, the cross terms in
+//   their own accumulator.  Per 32x32 output tile and 96 k: 18 v_mfma_f32_32x32x16_f16 (576 cycles) instead of 48
+//   v_mfma_f32_32x32x2f32 (3072 cycles).  VALU pays for the splits (3 instructions per element with v_cvt_pk_f16_f32 and
+//   packed fp32 math): x' at staging, y after the conv, the predicted kernel after its load.
+// LDS images are [column][piece][32 channels] fp16, 128 B per column, 16 B slot s of row r stored at s ^ ((r >> 1) & 7):
+// a B operand (8 consecutive channels of one column) is one conflict-free ds_read_b128.
+// Operands of magnitude >= 32768 do not fit fp16: the kernel raises *range_flag and the fp32 kernel launched behind it
+// (k_lvc_layer with run_if) redoes the whole layer from the untouched inputs.
+// =================================================================================================
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
+{
+    const f2_t v = {a, b};
+    const h2_t h = __builtin_convertvector(v, h2_t);                       // v_cvt_pk_f16_f32, round to nearest even
+    const f2_t r = (v - __builtin_convertvector(h, f2_t)) * GX_SCALE;       // exact
+    const h2_t l = __builtin_convertvector(r, h2_t);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ void split8(const float (&v)[8], float4 &hi, float4 &lo)
+{
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split2(v[2 * i], v[2 * i + 1], h[i], l[i]);
+    hi = make_float4(__uint_as_float(h[0]), __uint_as_float(h[1]), __uint_as_float(h[2]), __uint_as_float(h[3]));
+    lo = make_float4(__uint_as_float(l[0]), __uint_as_float(l[1]), __uint_as_float(l[2]), __uint_as_float(l[3]));
+}
+__device__ __forceinline__ float amax4(float m, const float4 &v) { return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w))); }
+// byte offset of 16 B slot `slot` (piece*4 + channel/8) of row `row` in a [row][128 B] piece image
+__device__ __forceinline__ int h2_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+template <int HOP, int DIL>
+__global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin, const float *__restrict__ skip, float *__restrict__ xout,
+                                                   const float *__restrict__ kpack, int layer, const float4 *__restrict__ wpack16,
+                                                   const float *__restrict__ wref, const float *__restrict__ cbias,
+                                                   int *__restrict__ range_flag, int T)
+{
+    constexpr int W = 256, WC = 64, H = (DIL + 1 + 3) & ~3, XC = W + 2 * H, YC = W + 2;
+    constexpr int LT = (HOP == 256) ? 1 : 2;           // row tiles per wave   (hop 256: wave = (row tile, column half))
+    constexpr int LN = (HOP == 256) ? 4 : 2;           // column tiles per wave
+    constexpr bool K_EARLY = (HOP == 256);             // hop 64 has no registers to hold the kernel across the staging
+    __shared__ __attribute__((aligned(16))) char xs[XC * 128];       // lrelu(x + skip) pieces, row = column + H
+    __shared__ __attribute__((aligned(16))) char ys[YC * 128];       // first the raw x + skip of the centre (fp32 [32][256]), then
+    static_assert(YC * 128 >= fd::C * W * 4, "parking area");        // the conv output pieces, row = column + 1
+    const int Ln = T * HOP;
+    const int b = blockIdx.y, w0 = blockIdx.x * W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int cw = wave * WC;
+    const bool wave_valid = (w0 + cw) < Ln;
+    const int mt0 = (HOP == 256) ? (wave & 1) : 0;
+    const int lcw = (HOP == 256) ? 128 * (wave >> 1) : cw;     // first LVC column of this wave
+    float mx = 0.0f;                                            // largest operand magnitude seen by this thread
+
+    float4 ka[LT][12];
+    float4 bz[LT][4];
+    auto load_kernel = [&]() {
+        if (wave_valid) {
+            const int f = (w0 + lcw) / HOP;
+            const float *rec = kpack + ((int64_t)b * T + f) * fd::KREC;
+            const float4 *kp4 = reinterpret_cast<const float4 *>(rec + layer * fd::KLAYER) + 2 * lane;
+            const float4 *kb4 = reinterpret_cast<const float4 *>(rec + fd::KW + layer * 64);
+#pragma unroll
+            for (int m = 0; m < LT; ++m) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) ka[m][i] = kp4[((mt0 + m) * 6 + (i >> 1)) * 128 + (i & 1)];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bz[m][j] = kb4[(mt0 + m) * 8 + 2 * j + hi];
+            }
+        }
+    };
+    if constexpr (K_EARLY) load_kernel();
+    // conv weights: A operand pieces [piece][kg][lane] x 8 fp16, k = 16*kg + 8*hi + e = tap*32 + in
+    float4 wa[2][6];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int kg = 0; kg < 6; ++kg) wa[p][kg] = wpack16[(p * 6 + kg) * 64 + lane];
+    float4 cb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cb[j] = reinterpret_cast<const float4 *>(cbias)[2 * j + hi];
+
+    // ---- stage x + skip: a thread takes 8 channels x 4 columns, so that one column of it is one 16 B slot per piece -------
+    {
+        const float *xr = xin + (int64_t)b * fd::C * Ln, *sr = skip + (int64_t)b * fd::C * Ln;
+        constexpr int NQ = XC / 4, UNITS = 4 * NQ, NK = (UNITS + 255) / 256;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int idx = k * 256 + tid, cg = idx / NQ, q = idx - cg * NQ, g = w0 - H + 4 * q;
+            if (idx >= UNITS) break;
+            const bool ok = g >= 0 && g < Ln;                       // Ln is a multiple of 64: a quad is all in or all out
+            float4 xa[8], sa[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                xa[c] = ok ? *reinterpret_cast<const float4 *>(xr + (int64_t)(cg * 8 + c) * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                sa[c] = ok ? *reinterpret_cast<const float4 *>(sr + (int64_t)(cg * 8 + c) * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const bool centre = (q >= H / 4) && (q < H / 4 + W / 4);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                xa[c] = make_float4(xa[c].x + sa[c].x, xa[c].y + sa[c].y, xa[c].z + sa[c].z, xa[c].w + sa[c].w);
+                mx = amax4(mx, xa[c]);
+                if (centre) *reinterpret_cast<float4 *>(ys + ((cg * 8 + c) * W + 4 * q - H) * 4) = xa[c];      // the residual
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = lrelu(f4c(xa[c], j), 0.2f);
+                float4 ph, pl;
+                split8(v, ph, pl);
+                const int row = 4 * q + j;
+                *reinterpret_cast<float4 *>(xs + h2_off(row, cg)) = ph;
+                *reinterpret_cast<float4 *>(xs + h2_off(row, 4 + cg)) = pl;
+            }
+        }
+    }
+    if constexpr (!K_EARLY) load_kernel();
+    const int hside = tid >> 7, ho = (tid & 127) >> 2, hq = tid & 3;
+    __syncthreads();
+    // residual values of this lane's outputs: registers, so that ys can take the conv output
+    float resid[LN][8 * LT];
+    if (wave_valid) {
+#pragma unroll
+        for (int nt = 0; nt < LN; ++nt)
+#pragma unroll
+            for (int m = 0; m < LT; ++m)
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    resid[nt][m * 8 + r] =
+                        reinterpret_cast<const float *>(ys)[(16 * (mt0 + m) + (r & 3) + 8 * (r >> 2) + 4 * hi) * W + lcw + nt * 32 + l31];
+    }
+    __syncthreads();
+
+    // ---- dilated conv on the fp16 pipe; y = lrelu(conv) is split again and written as the B image of the LVC -------------
+    if (wave_valid) {
+        int xo_[3][2][2];
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            const int row = H + cw + l31 + (tap - 1) * DIL;         // + 32*ct rows: the swizzle term is the same
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) xo_[tap][p][c2] = h2_off(row, p * 4 + c2 * 2 + hi);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            f32x16 ah, al;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ah[r] = f4c(cb[r >> 2], r & 3); al[r] = 0.0f; }
+#pragma unroll
+            for (int kg = 0; kg < 6; ++kg) {
+                const float4 b1 = *reinterpret_cast<const float4 *>(xs + xo_[kg >> 1][0][kg & 1] + ct * 32 * 128);
+                const float4 b2 = *reinterpret_cast<const float4 *>(xs + xo_[kg >> 1][1][kg & 1] + ct * 32 * 128);
+                ah = mfma_f16(wa[0][kg], b1, ah);
+                al = mfma_f16(wa[0][kg], b2, al);
+                al = mfma_f16(wa[1][kg], b1, al);
+            }
+            const int cp = cw + ct * 32 + l31, yrow = cp + 1;
+            const bool inside = (w0 + cp) < Ln;                   // y is zero-padded for the LVC taps (modules.py:240)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                         // D rows 8j + 4hi + {0..3}: half a slot
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = inside ? lrelu(fmaf(al[4 * j + i], GX_INV_SCALE, ah[4 * j + i]), 0.2f) : 0.0f;
+                    mx = fmaxf(mx, fabsf(v[i]));
+                }
+                uint2 ph, pl;
+                split2(v[0], v[1], ph.x, pl.x);
+                split2(v[2], v[3], ph.y, pl.y);
+                *reinterpret_cast<uint2 *>(ys + h2_off(yrow, j) + 8 * hi) = ph;
+                *reinterpret_cast<uint2 *>(ys + h2_off(yrow, 4 + j) + 8 * hi) = pl;
+            }
+        }
+    } else {
+        // a wave past the end of the signal still owns y columns its left neighbour's taps read: they are zero padding
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) *reinterpret_cast<float4 *>(ys + (cw + 1 + lane) * 128 + s8 * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // ---- the two halo columns (-1 and W) the LVC taps reach: VALU on the reassembled x, 4 threads per output ----------------
+    {
+        float4 hwt[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) hwt[j] = reinterpret_cast<const float4 *>(wref + (ho * fd::C + 8 * hq) * 3)[j];
+        const float hbias = cbias[ho];
+        const int c = hside ? W : -1, g = w0 + c;
+        const bool ok = g >= 0 && g < Ln;
+        float accv = 0.0f;
+        if (ok) {
+            const float wv[24] = {hwt[0].x, hwt[0].y, hwt[0].z, hwt[0].w, hwt[1].x, hwt[1].y, hwt[1].z, hwt[1].w,
+                                  hwt[2].x, hwt[2].y, hwt[2].z, hwt[2].w, hwt[3].x, hwt[3].y, hwt[3].z, hwt[3].w,
+                                  hwt[4].x, hwt[4].y, hwt[4].z, hwt[4].w, hwt[5].x, hwt[5].y, hwt[5].z, hwt[5].w};
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) {
+                const int row = H + c + (tap - 1) * DIL;
+                union { float4 f; _Float16 h[8]; } p1, p2;
+                p1.f = *reinterpret_cast<const float4 *>(xs + h2_off(row, hq));
+                p2.f = *reinterpret_cast<const float4 *>(xs + h2_off(row, 4 + hq));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) accv += wv[j * 3 + tap] * fmaf((float)p2.h[j], GX_INV_SCALE, (float)p1.h[j]);
+            }
+        }
+        accv += __shfl_xor(accv, 1, 64);
+        accv += __shfl_xor(accv, 2, 64);
+        if (hq == 0) {
+            const float v = ok ? lrelu(accv + hbias, 0.2f) : 0.0f;
+            mx = fmaxf(mx, fabsf(v));
+            const _Float16 v1 = (_Float16)v, v2 = (_Float16)((v - (float)v1) * GX_SCALE);
+            const int yrow = c + 1;
+            *reinterpret_cast<_Float16 *>(ys + h2_off(yrow, ho >> 3) + (ho & 7) * 2) = v1;
+            *reinterpret_cast<_Float16 *>(ys + h2_off(yrow, 4 + (ho >> 3)) + (ho & 7) * 2) = v2;
+        }
+    }
+    __syncthreads();
+    if (wave_valid) {
+        // ---- LVC: A = the frame's predicted kernel (rows gate-paired: register r <-> sigmoid input, r+8 <-> tanh input of
+        //      channel 16*mt + drow(r), r < 8), split into pieces here ----------------------------------------------------
+        float4 kh[LT][6], kl[LT][6];
+#pragma unroll
+        for (int m = 0; m < LT; ++m)
+#pragma unroll
+            for (int kg = 0; kg < 6; ++kg) {
+                const float4 &a0 = ka[m][2 * kg], &a1 = ka[m][2 * kg + 1];
+                mx = amax4(amax4(mx, a0), a1);
+                const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                split8(v, kh[m][kg], kl[m][kg]);
+            }
+        int yo_[3][2][2];
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            const int row = lcw + l31 + tap;                        // y row = column + 1 + (tap - 1); + 32*nt rows
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) yo_[tap][p][c2] = h2_off(row, p * 4 + c2 * 2 + hi);
+        }
+        float *xo = xout + (int64_t)b * fd::C * Ln + (int64_t)(4 * hi) * Ln + w0 + lcw + l31;    // + channel*Ln + nt*32
+        const unsigned Lnu = (unsigned)Ln;
+#pragma unroll
+        for (int nt = 0; nt < LN; ++nt) {
+#pragma unroll
+            for (int m = 0; m < LT; ++m) {
+                f32x16 ah, al;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { ah[r] = f4c(bz[m][r >> 2], r & 3); al[r] = 0.0f; }
+#pragma unroll
+                for (int kg = 0; kg < 6; ++kg) {
+                    const float4 b1 = *reinterpret_cast<const float4 *>(ys + yo_[kg >> 1][0][kg & 1] + nt * 32 * 128);
+                    const float4 b2 = *reinterpret_cast<const float4 *>(ys + yo_[kg >> 1][1][kg & 1] + nt * 32 * 128);
+                    ah = mfma_f16(kh[m][kg], b1, ah);
+                    al = mfma_f16(kh[m][kg], b2, al);
+                    al = mfma_f16(kl[m][kg], b1, al);
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int chl = 16 * (mt0 + m) + (r & 3) + 8 * (r >> 2);     // channel minus 4*hi
+                    const float zs = fmaf(al[r], GX_INV_SCALE, ah[r]), zt = fmaf(al[r + 8], GX_INV_SCALE, ah[r + 8]);
+                    xo[(unsigned)chl * Lnu + (unsigned)(nt * 32)] = resid[nt][m * 8 + r] + gate(zs, zt);
+                }
+            }
+        }
+    }
+    if (!(mx < GX_LIMIT)) atomicOr(range_flag, 1);      // also inf; a NaN operand gives a NaN result on either path
+}
+
+// =================================================================================================
 // a10 + sampler: final_conv Conv1d(32,1,k7) (FastDiff_model.py:67-68,100) with the reverse-step update
 // (util.py:219-229) fused into its epilogue.  VALU; each thread produces 4 consecutive samples.
 // =================================================================================================
@@ -1080,8 +1351,6 @@ hipError_t fast_kp_gemm(const Launch &L, int B, int T)
         const int R = gx_rows(T);
         const int chunks = (T + 63) / 64, items = fd::NBLK * (fd::KREC / 128) * B * chunks;
         const int grid2 = items < 2 * c->num_cus ? items : 2 * c->num_cus;
-        hipError_t e = hipMemsetAsync(c->ws.range_flag, 0, sizeof(int), L.stream);
-        if (e != hipSuccess) return e;
         FD_LAUNCH(L, "h_split", k_h_split, dim3((32 * R + 255) / 256, fd::NBLK * B), dim3(256), 0, (const float *)c->ws.kp_hB,
                   reinterpret_cast<unsigned *>(c->ws.h_f16), c->ws.range_flag, B, T, R);
         FD_LAUNCH(L, "kp_gemm_f16x2", k_kp_gemm_h2, dim3(grid2), dim3(256), 0, reinterpret_cast<const char *>(c->ws.h_f16), c->ws.kpack,
@@ -1117,8 +1386,18 @@ static hipError_t launch_lvc(const Launch &L, const char *name, int n, int layer
     constexpr int W = LvcCfg<HOP, DIL>::W;
     const int Ln = T * HOP;
     const float *kp = c->ws.kpack + (int64_t)n * B * T * fd::KREC;
+    const int *run_if = nullptr;
+    if constexpr (HOP >= 64) {
+        if (c->lvc_f16 && w.lvc_f16_ok) {
+            int *flag = c->ws.range_flag + 1 + n * fd::LAYERS + layer;
+            FD_LAUNCH(L, name, (k_lvc_h2<HOP, DIL>), dim3((Ln + 255) / 256, B), dim3(256), 0, x_in, skip, x_out, kp, layer,
+                      reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]), w.blk[n].convs[layer].w, w.blk[n].convs[layer].b, flag, T);
+            run_if = flag;
+            name = "lvc_fp32_fallback";
+        }
+    }
     FD_LAUNCH(L, name, (k_lvc_layer<HOP, DIL>), dim3((Ln + W - 1) / W, B), dim3(256), 0, x_in, skip, x_out, kp, layer,
-              w.lvc_conv_pack[n][layer], w.blk[n].convs[layer].w, w.blk[n].convs[layer].b, T);
+              w.lvc_conv_pack[n][layer], w.blk[n].convs[layer].w, w.blk[n].convs[layer].b, T, run_if);
     return hipSuccess;
 }
 

@@ -335,11 +335,22 @@ hipError_t naive_update(const Launch &L, float *x, const float *eps, int64_t n)
     return hipSuccess;
 }
 
-__global__ void k_advance(StepParams *p) { p->step_idx += 1; }
+// End of a sampler step: next row of the step table; the fp16-range flags are cleared for the next step here rather than by a
+// memset node (a captured hipMemsetAsync wrote garbage on the second replay of the graph on ROCm 7.2).
+__global__ void k_advance(StepParams *p, int *range_flags, int inc)
+{
+    if (threadIdx.x == 0) p->step_idx += inc;
+    if (threadIdx.x < 16) range_flags[threadIdx.x] = 0;
+}
 
 hipError_t advance_step(const Launch &L)
 {
-    FD_LAUNCH(L, "advance_step", k_advance, dim3(1), dim3(1), 0, L.ctx->ws.params);
+    FD_LAUNCH(L, "advance_step", k_advance, dim3(1), dim3(64), 0, L.ctx->ws.params, L.ctx->ws.range_flag, 1);
+    return hipSuccess;
+}
+hipError_t clear_range_flags(const Launch &L)
+{
+    FD_LAUNCH(L, "clear_flags", k_advance, dim3(1), dim3(64), 0, L.ctx->ws.params, L.ctx->ws.range_flag, 0);
     return hipSuccess;
 }
 
