@@ -703,14 +703,15 @@ __device__ long long fd_dbg[64 * 4 * 8];
 #endif
 
 // sigmoid(a) * tanh(b) with two exponentials and one reciprocal:  (1 - v) / ((1 + u)(1 + v)),  u = e^-a, v = e^-2b.
-// The clamps keep u, v finite; beyond them sigmoid/tanh are saturated to fp32 precision anyway.
+// Only v needs a guard: v = inf (b << 0) would give inf/inf; u = inf or 0 and v = 0 are the correct saturated results.
 __device__ __forceinline__ float gate(float a, float b)
 {
-    a = __builtin_amdgcn_fmed3f(a, -30.0f, 30.0f);
-    b = __builtin_amdgcn_fmed3f(b, -15.0f, 15.0f);
-    const float u = __builtin_amdgcn_exp2f(a * -1.4426950408889634f);
-    const float v = __builtin_amdgcn_exp2f(b * -2.8853900817779268f);
-    return (1.0f - v) * __builtin_amdgcn_rcpf((1.0f + u) * (1.0f + v));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    b = fmaxf(b, -15.0f);
+    const f2 e = f2{a, b} * f2{-1.4426950408889634f, -2.8853900817779268f};
+    const f2 uv = f2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+    const f2 d = uv + 1.0f;
+    return (1.0f - uv.y) * __builtin_amdgcn_rcpf(d.x * d.y);
 }
 
 template <int HOP, int DIL>
@@ -1021,7 +1022,9 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
     constexpr int W = 256, WC = 64, H = (DIL + 1 + 3) & ~3, XC = W + 2 * H, YC = W + 2;
     constexpr int LT = (HOP == 256) ? 1 : 2;           // row tiles per wave   (hop 256: wave = (row tile, column half))
     constexpr int LN = (HOP == 256) ? 4 : 2;           // column tiles per wave
-    constexpr bool K_EARLY = (HOP == 256);             // hop 64 has no registers to hold the kernel across the staging
+    // the predicted kernel (HBM, the longest latency) is requested as early as the registers allow: hop 256 (one row tile per
+    // wave) before the staging; hop 64 (two row tiles) the first after the staging, the second after the conv
+    static_assert(2 * H <= 64, "one halo column per lane");
     __shared__ __attribute__((aligned(16))) char xs[XC * 128];       // lrelu(x + skip) pieces, row = column + H
     __shared__ __attribute__((aligned(16))) char ys[YC * 128];       // first the raw x + skip of the centre (fp32 [32][256]), then
     static_assert(YC * 128 >= fd::C * W * 4, "parking area");        // the conv output pieces, row = column + 1
@@ -1033,25 +1036,23 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
     const int mt0 = (HOP == 256) ? (wave & 1) : 0;
     const int lcw = (HOP == 256) ? 128 * (wave >> 1) : cw;     // first LVC column of this wave
     float mx = 0.0f;                                            // largest operand magnitude seen by this thread
+    FD_STAMP(0);
 
     float4 ka[LT][12];
     float4 bz[LT][4];
-    auto load_kernel = [&]() {
+    auto load_kernel = [&](int m) {
         if (wave_valid) {
             const int f = (w0 + lcw) / HOP;
             const float *rec = kpack + ((int64_t)b * T + f) * fd::KREC;
             const float4 *kp4 = reinterpret_cast<const float4 *>(rec + layer * fd::KLAYER) + 2 * lane;
             const float4 *kb4 = reinterpret_cast<const float4 *>(rec + fd::KW + layer * 64);
 #pragma unroll
-            for (int m = 0; m < LT; ++m) {
+            for (int i = 0; i < 12; ++i) ka[m][i] = kp4[((mt0 + m) * 6 + (i >> 1)) * 128 + (i & 1)];
 #pragma unroll
-                for (int i = 0; i < 12; ++i) ka[m][i] = kp4[((mt0 + m) * 6 + (i >> 1)) * 128 + (i & 1)];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bz[m][j] = kb4[(mt0 + m) * 8 + 2 * j + hi];
-            }
+            for (int j = 0; j < 4; ++j) bz[m][j] = kb4[(mt0 + m) * 8 + 2 * j + hi];
         }
     };
-    if constexpr (K_EARLY) load_kernel();
+    if constexpr (HOP == 256) load_kernel(0);
     // conv weights: A operand pieces [piece][kg][lane] x 8 fp16, k = 16*kg + 8*hi + e = tap*32 + in
     float4 wa[2][6];
 #pragma unroll
@@ -1062,48 +1063,66 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
 #pragma unroll
     for (int j = 0; j < 4; ++j) cb[j] = reinterpret_cast<const float4 *>(cbias)[2 * j + hi];
 
-    // ---- stage x + skip: a thread takes 8 channels x 4 columns, so that one column of it is one 16 B slot per piece -------
+    // ---- stage x + skip.  Centre: wave = channel group of 8, lane = 4 columns, so that one column of a thread is one 16 B
+    //      slot per piece.  Halo (2H columns): wave = channel group, lane = one column.  Every wave does the same work. --------
     {
-        const float *xr = xin + (int64_t)b * fd::C * Ln, *sr = skip + (int64_t)b * fd::C * Ln;
-        constexpr int NQ = XC / 4, UNITS = 4 * NQ, NK = (UNITS + 255) / 256;
+        const float *xr = xin + ((int64_t)b * fd::C + wave * 8) * Ln, *sr = skip + ((int64_t)b * fd::C + wave * 8) * Ln;
+        const int g = w0 + 4 * lane;
+        const bool ok = g < Ln;                                      // Ln is a multiple of 64: a quad is all in or all out
+        const int hc = lane, hg = (hc < H) ? w0 - H + hc : w0 + W + hc - H;
+        const bool hok = hc < 2 * H && hg >= 0 && hg < Ln;
+        float4 xa[8], sa[8];
+        float hx[8], hs[8];
 #pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const int idx = k * 256 + tid, cg = idx / NQ, q = idx - cg * NQ, g = w0 - H + 4 * q;
-            if (idx >= UNITS) break;
-            const bool ok = g >= 0 && g < Ln;                       // Ln is a multiple of 64: a quad is all in or all out
-            float4 xa[8], sa[8];
+        for (int c = 0; c < 8; ++c) {
+            xa[c] = ok ? *reinterpret_cast<const float4 *>(xr + (int64_t)c * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            sa[c] = ok ? *reinterpret_cast<const float4 *>(sr + (int64_t)c * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            hx[c] = hok ? xr[(int64_t)c * Ln + hg] : 0.0f;
+            hs[c] = hok ? sr[(int64_t)c * Ln + hg] : 0.0f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            xa[c] = make_float4(xa[c].x + sa[c].x, xa[c].y + sa[c].y, xa[c].z + sa[c].z, xa[c].w + sa[c].w);
+            mx = amax4(mx, xa[c]);
+            *reinterpret_cast<float4 *>(ys + ((wave * 8 + c) * W + 4 * lane) * 4) = xa[c];      // the residual, parked
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = lrelu(f4c(xa[c], j), 0.2f);
+            float4 ph, pl;
+            split8(v, ph, pl);
+            const int row = H + 4 * lane + j;
+            *reinterpret_cast<float4 *>(xs + h2_off(row, wave)) = ph;
+            *reinterpret_cast<float4 *>(xs + h2_off(row, 4 + wave)) = pl;
+        }
+        if (hc < 2 * H) {
+            float v[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                xa[c] = ok ? *reinterpret_cast<const float4 *>(xr + (int64_t)(cg * 8 + c) * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
-                sa[c] = ok ? *reinterpret_cast<const float4 *>(sr + (int64_t)(cg * 8 + c) * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float t = hx[c] + hs[c];
+                mx = fmaxf(mx, fabsf(t));
+                v[c] = lrelu(t, 0.2f);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            const bool centre = (q >= H / 4) && (q < H / 4 + W / 4);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                xa[c] = make_float4(xa[c].x + sa[c].x, xa[c].y + sa[c].y, xa[c].z + sa[c].z, xa[c].w + sa[c].w);
-                mx = amax4(mx, xa[c]);
-                if (centre) *reinterpret_cast<float4 *>(ys + ((cg * 8 + c) * W + 4 * q - H) * 4) = xa[c];      // the residual
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] = lrelu(f4c(xa[c], j), 0.2f);
-                float4 ph, pl;
-                split8(v, ph, pl);
-                const int row = 4 * q + j;
-                *reinterpret_cast<float4 *>(xs + h2_off(row, cg)) = ph;
-                *reinterpret_cast<float4 *>(xs + h2_off(row, 4 + cg)) = pl;
-            }
+            float4 ph, pl;
+            split8(v, ph, pl);
+            const int row = (hc < H) ? hc : W + hc;
+            *reinterpret_cast<float4 *>(xs + h2_off(row, wave)) = ph;
+            *reinterpret_cast<float4 *>(xs + h2_off(row, 4 + wave)) = pl;
         }
     }
-    if constexpr (!K_EARLY) load_kernel();
+    if constexpr (HOP != 256) load_kernel(0);
     const int hside = tid >> 7, ho = (tid & 127) >> 2, hq = tid & 3;
     __syncthreads();
+    FD_STAMP(1);
     // residual values of this lane's outputs: registers, so that ys can take the conv output
     float resid[LN][8 * LT];
-    if (wave_valid) {
+    {
 #pragma unroll
         for (int nt = 0; nt < LN; ++nt)
 #pragma unroll
@@ -1112,9 +1131,15 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
                 for (int r = 0; r < 8; ++r)
                     resid[nt][m * 8 + r] =
                         reinterpret_cast<const float *>(ys)[(16 * (mt0 + m) + (r & 3) + 8 * (r >> 2) + 4 * hi) * W + lcw + nt * 32 + l31];
+        __syncthreads();
     }
-    __syncthreads();
+    FD_STAMP(2);
 
+    // conv weights of the halo outputs (L2), requested ahead of the conv that hides their latency
+    float4 hwt[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) hwt[j] = reinterpret_cast<const float4 *>(wref + (ho * fd::C + 8 * hq) * 3)[j];
+    const float hbias = cbias[ho];
     // ---- dilated conv on the fp16 pipe; y = lrelu(conv) is split again and written as the B image of the LVC -------------
     if (wave_valid) {
         int xo_[3][2][2];
@@ -1161,12 +1186,10 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8) *reinterpret_cast<float4 *>(ys + (cw + 1 + lane) * 128 + s8 * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if constexpr (HOP != 256) load_kernel(1);
+    FD_STAMP(3);
     // ---- the two halo columns (-1 and W) the LVC taps reach: VALU on the reassembled x, 4 threads per output ----------------
     {
-        float4 hwt[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) hwt[j] = reinterpret_cast<const float4 *>(wref + (ho * fd::C + 8 * hq) * 3)[j];
-        const float hbias = cbias[ho];
         const int c = hside ? W : -1, g = w0 + c;
         const bool ok = g >= 0 && g < Ln;
         float accv = 0.0f;
@@ -1195,7 +1218,9 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
             *reinterpret_cast<_Float16 *>(ys + h2_off(yrow, 4 + (ho >> 3)) + (ho & 7) * 2) = v2;
         }
     }
+    FD_STAMP(4);
     __syncthreads();
+    FD_STAMP(5);
     if (wave_valid) {
         // ---- LVC: A = the frame's predicted kernel (rows gate-paired: register r <-> sigmoid input, r+8 <-> tanh input of
         //      channel 16*mt + drow(r), r < 8), split into pieces here ----------------------------------------------------
@@ -1218,7 +1243,9 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2) yo_[tap][p][c2] = h2_off(row, p * 4 + c2 * 2 + hi);
         }
-        float *xo = xout + (int64_t)b * fd::C * Ln + (int64_t)(4 * hi) * Ln + w0 + lcw + l31;    // + channel*Ln + nt*32
+        const int64_t ooff = (int64_t)b * fd::C * Ln + (int64_t)(4 * hi) * Ln + w0 + lcw + l31;    // + channel*Ln + nt*32
+        float *xo = xout + ooff;
+        FD_STAMP(6);
         const unsigned Lnu = (unsigned)Ln;
 #pragma unroll
         for (int nt = 0; nt < LN; ++nt) {
@@ -1245,6 +1272,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
         }
     }
     if (!(mx < GX_LIMIT)) atomicOr(range_flag, 1);      // also inf; a NaN operand gives a NaN result on either path
+    FD_STAMP(7);
 }
 
 // =================================================================================================
