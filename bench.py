@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 SR, HOP = 22050, 256
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix = fp32 vector peak
+MFMA_F16_PEAK_TFLOPS = 2500.0 # dense fp16/bf16 matrix peak (MI355X_MICROARCH.md)
 
 
 def kernel_model(name, B, T):
@@ -41,8 +42,12 @@ def kernel_model(name, B, T):
         # read x, skip (32 ch each), write x (32 ch) at rate hop*T; read the frame's 64x96 kernel + 64 biases
         return "hbm", 4.0 * B * T * (96 * hop + 6208), 2.0 * B * T * hop * (32 * 96 + 64 * 96)
     if name == "kp_gemm":
-        # all 3 LVC blocks in one launch: [24832 x 192] x [192 x B*T] each, output written once
+        # all 3 LVC blocks in one launch: [24832 x 192] x [192 x B*T] each, output written once (fp32 matrix pipe)
         return "mfma", 3 * 4.0 * (B * T * 24832 + 24832 * 192 + B * T * 64), 3 * 2.0 * 24832 * 192 * B * T
+    if name == "kp_gemm_f16x2":
+        # the same product as three fp16 MFMA passes (2-piece operands): 3x the flops on a 16x faster pipe -- the
+        # 2.06 GB of predicted kernels it writes is what bounds it
+        return "hbm", 3 * 4.0 * (B * T * 24832 + 24832 * 192 + B * T * 64), 3 * 3 * 2.0 * 24832 * 192 * B * T
     if name == "kp_front":
         # input conv (K=400) + six 64->64 k3 convs (K=192) for the three predictors, fused through LDS
         return "mfma", 3 * 4.0 * B * T * (80 + 64), 3 * 2.0 * 64 * (400 + 6 * 192) * B * T

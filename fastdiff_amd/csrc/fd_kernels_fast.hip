@@ -474,51 +474,81 @@ __device__ __forceinline__ void gx_dma(const char *hx, char *lds_buf, const GxIt
 //   BUF   which LDS buffer holds this item's window (the other one receives the next item's window by DMA meanwhile)
 //   FULL  both tiles are whole (always, except the ragged last chunk of an utterance)
 // Vector-memory order per item: [DMA of next window] [16 stores of tile 0] [16 stores of tile 1].  vmcnt retires in order,
-// so "vmcnt(16)" after the MFMAs of tile 1 waits for the DMA but not for the stores in flight; store acknowledgements are
-// never waited for on this path.
+// so "vmcnt(32)" at the end of the item waits for the DMA (and the previous item's stores, a whole item old by then) but
+// not for this item's stores.
+#ifdef FD_GX_TIMING
+__device__ long long fd_gxdbg[8];
+#define GX_STAMP(k) do { const long long t__ = __builtin_amdgcn_s_memtime(); ph[k] += t__ - tl; tl = t__; } while (0)
+#define GX_TIMING_ARGS , long long (&ph)[8], long long &tl
+#define GX_TIMING_PASS , ph, tl
+#else
+#define GX_STAMP(k) do { } while (0)
+#define GX_TIMING_ARGS
+#define GX_TIMING_PASS
+#endif
 template <int BUF, bool FULL>
 __device__ __forceinline__ void gx_item(char *lds, const GxItem &cur, bool more, const GxItem &nxt, const char *hx, float *kpack,
-                                        const float4 (&wq)[2][12], float bias, const int (&aoff)[2][12], int B, int T, int R,
-                                        int wave_u, int lane)
+                                        const float4 (&wq)[2][12], const f32x16 &bias_lo, const int (&aoff)[2][12], int B, int T, int R,
+                                        int wave_u, int lane GX_TIMING_ARGS)
 {
     const int l31 = lane & 31, hi = lane >> 5;
+    GX_STAMP(0);
     if (more) gx_dma(hx, lds + (BUF ^ 1) * GX_BUFB, nxt, B, R, wave_u, lane);
+    GX_STAMP(1);
     const int t_begin = cur.chunk * 64;
     float *krow = kpack + (((int64_t)cur.blk * B + cur.b) * T + t_begin) * fd::KREC + (cur.xg * 4 + wave_u) * 32;     // uniform
     const unsigned loff = (unsigned)(4 * hi) * (unsigned)fd::KREC + (unsigned)l31;
+    // stores of whole tiles go through a buffer descriptor: address = base (SGPRs) + per-lane offset (one VGPR, constant) + row
+    // offset (an SGPR literal), so that a store costs no VALU instruction next to the MFMAs of the other wave on this SIMD
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(krow, 0, 64 * fd::KREC * 4, 0x00020000);
     const int n_tiles = FULL ? 2 : ((T - t_begin + 31) >> 5);
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int tile = 0; tile < 2; ++tile) {
         if (!FULL && tile >= n_tiles) break;
-        f32x16 acc, lo;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[r] = bias; lo[r] = 0.0f; }
         const char *hb = lds + BUF * GX_BUFB + tile * 32 * GX_ROWB;
+        // kg = tap*4 + k4: logical k = kg*16 + 8*hi + e = tap*64 + channel.  The operands of step kg+1 are requested before
+        // the MFMAs of step kg.  acc starts from 0 (inline constant), lo from 2048*bias: the bias then comes out of the final fma.
+        f32x16 acc, lo;
+        float4 a1 = *reinterpret_cast<const float4 *>(hb + aoff[0][0]), a2 = *reinterpret_cast<const float4 *>(hb + aoff[1][0]);
 #pragma unroll
-        for (int kg = 0; kg < 12; ++kg) {      // kg = tap*4 + k4: logical k = kg*16 + 8*hi + e = tap*64 + channel
-            const float4 a1 = *reinterpret_cast<const float4 *>(hb + aoff[0][kg]);
-            const float4 a2 = *reinterpret_cast<const float4 *>(hb + aoff[1][kg]);
-            acc = mfma_f16(a1, wq[0][kg], acc);
-            lo = mfma_f16(a2, wq[0][kg], lo);
+        for (int kg = 0; kg < 12; ++kg) {
+            float4 n1 = a1, n2 = a2;
+            if (kg + 1 < 12) {
+                n1 = *reinterpret_cast<const float4 *>(hb + aoff[0][kg + 1]);
+                n2 = *reinterpret_cast<const float4 *>(hb + aoff[1][kg + 1]);
+            }
+            acc = mfma_f16(a1, wq[0][kg], kg == 0 ? zero : acc);
+            lo = mfma_f16(a2, wq[0][kg], kg == 0 ? bias_lo : lo);
             lo = mfma_f16(a1, wq[1][kg], lo);
+            a1 = n1;
+            a2 = n2;
         }
-        if (FULL && tile == 1 && more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // DMA landed; tile-0 stores may fly
+        GX_STAMP(2);
 #ifdef FD_GX_NO_STORE
         if (acc[0] != 12345.678f) continue;
 #endif
-        float *kt = krow + (int64_t)tile * 32 * fd::KREC;
         if (FULL) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) (kt + ((r & 3) + 8 * (r >> 2)) * fd::KREC)[loff] = fmaf(lo[r], GX_INV_SCALE, acc[r]);
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaf(lo[r], GX_INV_SCALE, acc[r])), rs, loff * 4u,
+                                                      (tile * 32 + (r & 3) + 8 * (r >> 2)) * fd::KREC * 4, 0);
         } else {
+            float *kt = krow + (int64_t)tile * 32 * fd::KREC;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (t_begin + tile * 32 + drow(r, hi) < T)
                     (kt + ((r & 3) + 8 * (r >> 2)) * fd::KREC)[loff] = fmaf(lo[r], GX_INV_SCALE, acc[r]);
         }
+        GX_STAMP(3);
     }
-    if (!FULL && more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (more) {
+        if (FULL) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");      // the DMA has landed; this item's 32 stores may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    GX_STAMP(4);
     __builtin_amdgcn_s_barrier();      // every wave's DMA share is in LDS; everybody is done reading this item's buffer
+    GX_STAMP(5);
 }
 
 __global__ void __launch_bounds__(256, 2) k_kp_gemm_h2(const char *__restrict__ hx /*[3][B][R][2][64] fp16*/, float *__restrict__ kpack,
@@ -571,8 +601,12 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm_h2(const char *__restrict__ 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
+#ifdef FD_GX_TIMING
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+    const long long t_start = tl, r_start = __builtin_amdgcn_s_memrealtime();
+#endif
     float4 wq[2][12];
-    float bias = 0.0f;
+    f32x16 bias_lo;      // 2048 * bias of this lane's column in all 16 registers: the C operand of the first cross-term MFMA
     int have_blk = -1, have_xg = -1;
 #pragma unroll 1
     for (int i = i0; i < i1; i += 2) {
@@ -587,7 +621,9 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm_h2(const char *__restrict__ 
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
                     for (int kg = 0; kg < 12; ++kg) wq[q][kg] = gp[(((int64_t)ptile * 2 + q) * 12 + kg) * 64 + lane];
-                bias = gb[ptile * 32 + l31];
+                const float bv = gb[ptile * 32 + l31] * GX_SCALE;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bias_lo[r] = bv;
                 have_blk = cur.blk; have_xg = cur.xg;
                 // retire the loads here, visibly to the compiler: otherwise it places a vmcnt(0) at the first use, on the
                 // common path too, where it would wait for the window DMA and the stores of the previous item
@@ -597,15 +633,21 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm_h2(const char *__restrict__ 
             const GxItem nxt = advance(cur);
             const bool full = (cur.chunk * 64 + 64 <= T);
             if (half == 0) {
-                if (full) gx_item<0, true>(lds, cur, more, nxt, hx, kpack, wq, bias, aoff, B, T, R, wave_u, lane);
-                else gx_item<0, false>(lds, cur, more, nxt, hx, kpack, wq, bias, aoff, B, T, R, wave_u, lane);
+                if (full) gx_item<0, true>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane GX_TIMING_PASS);
+                else gx_item<0, false>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane GX_TIMING_PASS);
             } else {
-                if (full) gx_item<1, true>(lds, cur, more, nxt, hx, kpack, wq, bias, aoff, B, T, R, wave_u, lane);
-                else gx_item<1, false>(lds, cur, more, nxt, hx, kpack, wq, bias, aoff, B, T, R, wave_u, lane);
+                if (full) gx_item<1, true>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane GX_TIMING_PASS);
+                else gx_item<1, false>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane GX_TIMING_PASS);
             }
             cur = nxt;
         }
     }
+#ifdef FD_GX_TIMING
+    ph[6] = __builtin_amdgcn_s_memtime() - t_start;
+    ph[7] = __builtin_amdgcn_s_memrealtime() - r_start;
+    if (lane == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd((unsigned long long *)&fd_gxdbg[k], (unsigned long long)ph[k]);
+#endif
 }
 
 // =================================================================================================

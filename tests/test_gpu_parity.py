@@ -161,6 +161,58 @@ def test_predictor_gemm_out_of_fp16_range_falls_back_on_device(gc, oracle64):
     assert gc.maxdiff(taps["kernels1"], ref["kernels1"]) < FWD_TOL      # blocks 1, 2 unaffected
 
 
+def test_lvc_f16x2_against_fp32_pipe_and_oracle(model, gc, oracle64):
+    """LVC layers of hop 64 / 256 run on the fp16 matrix pipe with 2-piece operands by default; option lvc=fp32 keeps the
+    fp32-MFMA kernels.  Every block output and eps must sit inside the forward tolerance in both modes."""
+    import synth
+    B, T = 2, 9                       # hop 64: 2.25 workgroup tiles (ragged); hop 256: 9 tiles
+    mel, audio = synth.synth_mel(31, B, T), synth.synth_audio(31, B, T)
+    steps = np.array([0.0, 999.0], np.float32)
+    y_ref, ref = oracle64.forward(audio, mel, steps, taps=True)
+    err = {}
+    try:
+        for mode in ("f16x2", "fp32"):
+            model.set_option("lvc", mode)
+            model.set_option("taps", "1")
+            y = gc.run_forward(model, audio, mel, steps)
+            taps = gc.read_taps(model, B, T)
+            assert not model.read_tap("range_flags").view(np.int32)[:13].any()
+            err[mode] = [gc.maxdiff(taps[k], ref[k]) for k in ("x0", "x1", "x2")] + [gc.maxdiff(y, y_ref)]
+    finally:
+        model.set_option("lvc", "f16x2")
+        model.set_option("taps", "0")
+    print("x0, x1, x2, eps max error vs float64 oracle:", err)
+    for mode in err:
+        assert max(err[mode]) < FWD_TOL, (mode, err[mode])
+
+
+def test_lvc_out_of_fp16_range_falls_back_on_device(gc, oracle64):
+    """|x + skip| >= 32768 in an LVC layer: k_lvc_h2 raises the layer's flag and the fp32 kernel launched behind it redoes
+    the layer.  Forced by a huge upsampler in block 2 (hop 256); blocks 0 and 1 stay on the fp16 pipe."""
+    import synth
+    sd = dict(synth.synth_state_dict(1234))
+    sd["lvc_blocks.2.upsample.weight"] = (sd["lvc_blocks.2.upsample.weight"] * 4.0e6).astype(np.float32)
+    m = gc.fastdiff_amd.FastDiff()
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    m = m.cuda().eval()
+    o = type(oracle64)("f64")
+    o.set_weights(sd)
+    B, T = 1, 5
+    mel, audio = synth.synth_mel(6, B, T), synth.synth_audio(6, B, T)
+    steps = np.array([77.0], np.float32)
+    y_ref, ref = o.forward(audio, mel, steps, taps=True)
+    m.set_option("taps", "1")
+    y = gc.run_forward(m, audio, mel, steps)
+    taps = gc.read_taps(m, B, T)
+    flags = m.read_tap("range_flags").view(np.int32)
+    assert not flags[:9].any() and flags[9:13].all(), flags[:13]        # [0] GEMM, [1..4] block 0, [5..8] block 1, [9..12] block 2
+    scale = float(np.abs(ref["x2"]).max())
+    assert scale > 32768.0
+    assert gc.maxdiff(taps["x1"], ref["x1"]) < FWD_TOL
+    assert gc.maxdiff(taps["x2"], ref["x2"]) < 2e-6 * scale
+    assert np.isfinite(y).all() and gc.maxdiff(y, y_ref) < 2e-6 * max(1.0, float(np.abs(y_ref).max()))
+
+
 @pytest.mark.parametrize("B,T", [(1, 1), (3, 3), (1, 63), (2, 130)])
 def test_forward_ragged_sizes_against_oracle(model, gc, oracle64, B, T):
     import synth

@@ -16,15 +16,18 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-BENCH_NAME = {"k_kp_gemm": "kp_gemm", "k_final": "final_conv_update", "k_first_conv": "first_conv", "k_embed": "embed",
+BENCH_NAME = {"k_kp_gemm": "kp_gemm_fp32", "k_kp_gemm_h2": "kp_gemm_f16x2", "k_h_split": "h_split", "k_final": "final_conv_update", "k_first_conv": "first_conv", "k_embed": "embed",
               "k_dblock": "dblock", "k_convt": "convt", "k_kp_front": "kp_front", "k_advance": "advance_step",
               "k_init_noise": "init_noise"}
 
 
 def fam(name):
-    m = re.search(r"k_lvc_layer<(\d+)", name)
+    m = re.search(r"k_lvc_h2<(\d+)", name)            # the fp16-pipe LVC layer (hop 64, 256)
     if m:
         return "lvc_layer_h" + m.group(1)
+    m = re.search(r"k_lvc_layer<(\d+)", name)         # fp32 kernel: the whole layer for hop 8, an early-exit fallback launch otherwise
+    if m:
+        return "lvc_layer_h8" if m.group(1) == "8" else "lvc_fp32_fallback"
     m = re.search(r"::(k_\w+)", name)
     return BENCH_NAME.get(m.group(1), m.group(1)) if m else name[:40]
 

@@ -42,5 +42,14 @@ int main(int argc, char **argv)
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / reps, flops = 3 * 2.0 * 24832 * 192 * (double)B * T;
     printf("h_split+kp_gemm_x3 B=%d T=%d grid=%d items=%d: %.1f us  %.1f TFLOP/s(fp32-equivalent)\n", B, T, G, n_items, us, flops / us / 1e6);
+#ifdef FD_GX_TIMING
+    long long d[8];
+    CK(hipMemcpyFromSymbol(d, HIP_SYMBOL(fdk_fast::fd_gxdbg), sizeof(d)));
+    const char *nm[6] = {"weights check / loop", "DMA issue", "MFMA (2 tiles)", "stores issue (2 tiles)", "wait vmcnt", "barrier"};
+    const double runs = 7.0 * G * 4, items = (double)n_items / G;
+    for (int k = 0; k < 6; ++k) printf("   %-28s %7.1f ticks per item per wave\n", nm[k], d[k] / runs / items);
+    printf("   whole kernel per wave: %.0f core ticks, %.1f us (s_memrealtime) -> %.0f MHz effective; loop share %.2f\n", d[6] / runs, d[7] / runs / 100.0,
+           (double)d[6] / d[7] * 100.0, (double)(d[0] + d[1] + d[2] + d[3] + d[4] + d[5]) / d[6]);
+#endif
     return 0;
 }
