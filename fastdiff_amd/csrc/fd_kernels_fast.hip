@@ -407,6 +407,9 @@ constexpr int GX_NDMA = (GX_WINB + 4095) / 4096;   // 4 KB (256 lanes x 16 B) DM
 constexpr int GX_BUFB = GX_NDMA * 4096;         // LDS bytes per buffer (the partial round is padded to a whole wave)
 constexpr float GX_SCALE = 2048.0f, GX_INV_SCALE = 1.0f / 2048.0f;
 constexpr float GX_LIMIT = 32768.0f;
+#ifndef FD_GX_STORE_AUX
+#define FD_GX_STORE_AUX 0      // cache policy bits of the predicted-kernel stores (2 = nt)
+#endif
 
 __host__ __device__ inline int gx_rows(int T) { return ((T + 63) / 64) * 64 + 2; }   // image rows per (block, utterance)
 
@@ -532,7 +535,7 @@ __device__ __forceinline__ void gx_item(char *lds, const GxItem &cur, bool more,
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaf(lo[r], GX_INV_SCALE, acc[r])), rs, loff * 4u,
-                                                      (tile * 32 + (r & 3) + 8 * (r >> 2)) * fd::KREC * 4, 0);
+                                                      (tile * 32 + (r & 3) + 8 * (r >> 2)) * fd::KREC * 4, FD_GX_STORE_AUX);
         } else {
             float *kt = krow + (int64_t)tile * 32 * fd::KREC;
 #pragma unroll
@@ -560,20 +563,28 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm_h2(const char *__restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int XG = fd::KREC / 128;
-    const int i0 = (int)((int64_t)blockIdx.x * n_items / gridDim.x), i1 = (int)((int64_t)(blockIdx.x + 1) * n_items / gridDim.x);
-    if (i0 >= i1 || *range_flag != 0) return;      // out-of-range operands: the fp32 kernel behind us does this step
+    if (*range_flag != 0) return;      // out-of-range operands: the fp32 kernel behind us does this step
 
-    // items are ordered (block, column group, utterance, chunk), chunk fastest: consecutive items share the weights
-    GxItem cur;
-    {
-        const int ny = B * chunks_per_utt;
-        cur.blk = i0 / (XG * ny);
-        const int rem = i0 - cur.blk * (XG * ny);
-        cur.xg = rem / ny;
-        const int yy = rem - cur.xg * ny;
-        cur.b = yy / chunks_per_utt;
-        cur.chunk = yy - cur.b * chunks_per_utt;
-    }
+    // Work items: id = ((block*XG + column group)*B + utterance)*chunks + chunk; a column group (128 columns, the weights a
+    // workgroup keeps in registers) spans ny = B*chunks consecutive ids, one per 64-frame window of the block's h image.
+    // Schedule: workgroup w first does whole groups w, w + #wg, ...: all workgroups then walk the windows in step, and a window
+    // is fetched from HBM once per XCD instead of once per workgroup (the 2 GB output stream turns L2 over every few
+    // microseconds).  The groups that do not divide evenly are cut into equal contiguous id ranges at the end.
+    const int ny = B * chunks_per_utt, n_wg = gridDim.x, w = blockIdx.x;
+    const int q = (3 * XG) / n_wg, base = q * n_wg * ny, rest = n_items - base;
+    const int r0 = (int)((int64_t)w * rest / n_wg), r1 = (int)((int64_t)(w + 1) * rest / n_wg);
+    const int n_mine = q * ny + (r1 - r0);
+    if (n_mine <= 0) return;
+    auto decode = [&](int id) {
+        GxItem it;
+        it.blk = id / (XG * ny);
+        const int rem = id - it.blk * (XG * ny);
+        it.xg = rem / ny;
+        const int yy = rem - it.xg * ny;
+        it.b = yy / chunks_per_utt;
+        it.chunk = yy - it.b * chunks_per_utt;
+        return it;
+    };
     auto advance = [&](GxItem it) {
         if (++it.chunk == chunks_per_utt) {
             it.chunk = 0;
@@ -584,6 +595,8 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm_h2(const char *__restrict__ 
         }
         return it;
     };
+    int run = 0, left = (q > 0) ? ny : (r1 - r0);          // ids of a run are consecutive; `left` counts the current item too
+    GxItem cur = decode((q > 0) ? w * ny : base + r0);
 
     // byte offsets of the A-operand reads of a tile: row = frame + tap, slot = (8*piece + 2*k4 + hi) ^ (row & 15)
     int aoff[2][12];
@@ -609,18 +622,18 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm_h2(const char *__restrict__ 
     f32x16 bias_lo;      // 2048 * bias of this lane's column in all 16 registers: the C operand of the first cross-term MFMA
     int have_blk = -1, have_xg = -1;
 #pragma unroll 1
-    for (int i = i0; i < i1; i += 2) {
+    for (int i = 0; i < n_mine; i += 2) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            if (half == 1 && i + 1 >= i1) break;
+            if (half == 1 && i + 1 >= n_mine) break;
             if (cur.blk != have_blk || cur.xg != have_xg) {      // new column group: (re)load the register-stationary weight pieces
                 const float4 *gp = cur.blk == 0 ? g0 : (cur.blk == 1 ? g1 : g2);
                 const float *gb = cur.blk == 0 ? gb0 : (cur.blk == 1 ? gb1 : gb2);
                 const int ptile = cur.xg * 4 + wave_u;
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
+                for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
-                    for (int kg = 0; kg < 12; ++kg) wq[q][kg] = gp[(((int64_t)ptile * 2 + q) * 12 + kg) * 64 + lane];
+                    for (int kg = 0; kg < 12; ++kg) wq[q2][kg] = gp[(((int64_t)ptile * 2 + q2) * 12 + kg) * 64 + lane];
                 const float bv = gb[ptile * 32 + l31] * GX_SCALE;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) bias_lo[r] = bv;
@@ -629,8 +642,17 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm_h2(const char *__restrict__ 
                 // common path too, where it would wait for the window DMA and the stores of the previous item
                 __builtin_amdgcn_s_waitcnt(0x0F70);
             }
-            const bool more = (i + half + 1 < i1);
-            const GxItem nxt = advance(cur);
+            const bool more = (i + half + 1 < n_mine);
+            GxItem nxt = cur;
+            if (more) {
+                if (left > 1) nxt = advance(cur);
+                else {                                           // next run: the next whole group, or the tail range
+                    ++run;
+                    nxt = decode(run < q ? (run * n_wg + w) * ny : base + r0);
+                    left = (run < q ? ny : r1 - r0) + 1;
+                }
+            }
+            --left;
             const bool full = (cur.chunk * 64 + 64 <= T);
             if (half == 0) {
                 if (full) gx_item<0, true>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane GX_TIMING_PASS);
