@@ -546,7 +546,7 @@ static int ensure_workspace(fd_context *h, int B, int T)
     WS(w.kp_h0, (size_t)fd::NBLK * nB * fd::HID * nT); WS(w.kp_hA, (size_t)fd::NBLK * nB * fd::HID * nT);
     WS(w.kp_hB, (size_t)fd::NBLK * nB * fd::HID * nT);
     WS(w.kpack, (size_t)fd::NBLK * nB * nT * fd::KREC);
-    WS(w.h_f16, (size_t)fd::NBLK * nB * (((nT + 63) / 64) * 64 + 2) * 64 + 256);      // + slack for the rounded-up last DMA
+    WS(w.h_f16, (size_t)fd::NBLK * nB * (((nT + 127) / 128) * 128 + 2) * 64 + 1024);  // rows = gx_rows(T), + slack for the rounded-up last DMA
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w.range_flag), 256);
     if (e == hipSuccess) e = hipMemset(w.range_flag, 0, 256);
     WS(w.xA, nB * fd::C * L); WS(w.xB, nB * fd::C * L);

@@ -399,11 +399,11 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm(const float *__restrict__ h 
 // (tools/ubench/f16_probe.hip), so small values lose nothing; operands of magnitude >= 32768 do not fit: k_h_split raises
 // a flag for them, this kernel then leaves the step to the fp32 kernel that follows it in the stream.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-constexpr int GX_CT = 2;                        // frame tiles per item
-constexpr int GX_ROWS = GX_CT * 32 + 2;         // 66 rows: frames t_begin-1 .. t_begin+64
+constexpr int GX_CT = 4;                        // frame tiles per item
+constexpr int GX_ROWS = GX_CT * 32 + 2;         // 130 rows: frames t_begin-1 .. t_begin+128
 constexpr int GX_ROWB = 2 * 128;                // bytes per row of the piece image: [piece][64 ch] fp16
-constexpr int GX_WINB = GX_ROWS * GX_ROWB;      // 16896 B per item window
-constexpr int GX_NDMA = (GX_WINB + 4095) / 4096;   // 4 KB (256 lanes x 16 B) DMA rounds per window: 4 full + 1 partial
+constexpr int GX_WINB = GX_ROWS * GX_ROWB;      // 33280 B per item window
+constexpr int GX_NDMA = (GX_WINB + 4095) / 4096;   // 4 KB (256 lanes x 16 B) DMA rounds per window: 8 full + 1 partial
 constexpr int GX_BUFB = GX_NDMA * 4096;         // LDS bytes per buffer (the partial round is padded to a whole wave)
 constexpr float GX_SCALE = 2048.0f, GX_INV_SCALE = 1.0f / 2048.0f;
 constexpr float GX_LIMIT = 32768.0f;
@@ -411,7 +411,7 @@ constexpr float GX_LIMIT = 32768.0f;
 #define FD_GX_STORE_AUX 0      // cache policy bits of the predicted-kernel stores (2 = nt)
 #endif
 
-__host__ __device__ inline int gx_rows(int T) { return ((T + 63) / 64) * 64 + 2; }   // image rows per (block, utterance)
+__host__ __device__ inline int gx_rows(int T) { return ((T + GX_CT * 32 - 1) / (GX_CT * 32)) * (GX_CT * 32) + 2; }   // image rows per (block, utterance)
 
 __device__ __forceinline__ f32x16 mfma_f16(const float4 &a, const float4 &b, f32x16 c)
 {
@@ -458,7 +458,7 @@ struct GxItem { int blk, xg, b, chunk; };
 __device__ __forceinline__ void gx_dma(const char *hx, char *lds_buf, const GxItem &it, int B, int R, int wave_u, int lane)
 {
 #ifndef FD_GX_NO_FETCH
-    const char *src = hx + (((int64_t)it.blk * B + it.b) * R + it.chunk * 64) * GX_ROWB + wave_u * 1024;    // uniform
+    const char *src = hx + (((int64_t)it.blk * B + it.b) * R + it.chunk * (GX_CT * 32)) * GX_ROWB + wave_u * 1024;    // uniform
     const unsigned dst = (unsigned)(uintptr_t)(lds_ptr_t)(lds_buf + wave_u * 1024);
     const unsigned voff = lane * 16;
     unsigned keep;
@@ -498,17 +498,17 @@ __device__ __forceinline__ void gx_item(char *lds, const GxItem &cur, bool more,
     GX_STAMP(0);
     if (more) gx_dma(hx, lds + (BUF ^ 1) * GX_BUFB, nxt, B, R, wave_u, lane);
     GX_STAMP(1);
-    const int t_begin = cur.chunk * 64;
+    const int t_begin = cur.chunk * (GX_CT * 32);
     float *krow = kpack + (((int64_t)cur.blk * B + cur.b) * T + t_begin) * fd::KREC + (cur.xg * 4 + wave_u) * 32;     // uniform
     const unsigned loff = (unsigned)(4 * hi) * (unsigned)fd::KREC + (unsigned)l31;
     // stores of whole tiles go through a buffer descriptor: address = base (SGPRs) + per-lane offset (one VGPR, constant) + row
     // offset (an SGPR literal), so that a store costs no VALU instruction next to the MFMAs of the other wave on this SIMD
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(krow, 0, 64 * fd::KREC * 4, 0x00020000);
-    const int n_tiles = FULL ? 2 : ((T - t_begin + 31) >> 5);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(krow, 0, GX_CT * 32 * fd::KREC * 4, 0x00020000);
+    const int n_tiles = min(GX_CT, (T - t_begin + 31) >> 5);       // FULL: every one of them is a whole tile
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int tile = 0; tile < 2; ++tile) {
-        if (!FULL && tile >= n_tiles) break;
+    for (int tile = 0; tile < GX_CT; ++tile) {
+        if (tile >= n_tiles) break;
         const char *hb = lds + BUF * GX_BUFB + tile * 32 * GX_ROWB;
         // kg = tap*4 + k4: logical k = kg*16 + 8*hi + e = tap*64 + channel.  The operands of step kg+1 are requested before
         // the MFMAs of step kg.  acc starts from 0 (inline constant), lo from 2048*bias: the bias then comes out of the final fma.
@@ -545,8 +545,11 @@ __device__ __forceinline__ void gx_item(char *lds, const GxItem &cur, bool more,
         }
         GX_STAMP(3);
     }
-    if (more) {
-        if (FULL) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");      // the DMA has landed; this item's 32 stores may still fly
+    if (more) {      // the DMA has landed; this item's 16 * n_tiles buffer stores may still fly
+        if (FULL && n_tiles == 4) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");       // 6-bit counter: 63 is its ceiling
+        else if (FULL && n_tiles == 3) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+        else if (FULL && n_tiles == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else if (FULL) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     GX_STAMP(4);
@@ -559,7 +562,7 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm_h2(const char *__restrict__ 
                                                        const float *gb1, const float *gb2, const int *__restrict__ range_flag, int B,
                                                        int T, int R, int chunks_per_utt, int n_items)
 {
-    __shared__ __attribute__((aligned(16))) char lds[2 * GX_BUFB];     // 2 x 20 KB
+    __shared__ __attribute__((aligned(16))) char lds[2 * GX_BUFB];     // 2 x 36 KB
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int XG = fd::KREC / 128;
@@ -653,7 +656,7 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm_h2(const char *__restrict__ 
                 }
             }
             --left;
-            const bool full = (cur.chunk * 64 + 64 <= T);
+            const bool full = (T % 32 == 0) || (cur.chunk * (GX_CT * 32) + GX_CT * 32 <= T);
             if (half == 0) {
                 if (full) gx_item<0, true>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane GX_TIMING_PASS);
                 else gx_item<0, false>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane GX_TIMING_PASS);
@@ -1441,7 +1444,7 @@ hipError_t fast_kp_gemm(const Launch &L, int B, int T)
     const bool f16 = c->gemm_f16 && w.gemm_f16_ok;
     if (f16) {
         const int R = gx_rows(T);
-        const int chunks = (T + 63) / 64, items = fd::NBLK * (fd::KREC / 128) * B * chunks;
+        const int chunks = (T + GX_CT * 32 - 1) / (GX_CT * 32), items = fd::NBLK * (fd::KREC / 128) * B * chunks;
         const int grid2 = items < 2 * c->num_cus ? items : 2 * c->num_cus;
         FD_LAUNCH(L, "h_split", k_h_split, dim3((32 * R + 255) / 256, fd::NBLK * B), dim3(256), 0, (const float *)c->ws.kp_hB,
                   reinterpret_cast<unsigned *>(c->ws.h_f16), c->ws.range_flag, B, T, R);

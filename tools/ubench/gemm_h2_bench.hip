@@ -10,7 +10,7 @@ int main(int argc, char **argv)
 {
     const int B = argc > 1 ? atoi(argv[1]) : 8, T = argc > 2 ? atoi(argv[2]) : 864, G = argc > 3 ? atoi(argv[3]) : 512;
     const int R = fdk_fast::gx_rows(T);
-    const size_t nh = (size_t)3 * B * 64 * T, nk = (size_t)3 * B * T * fd::KREC, ng = (size_t)776 * 2 * 12 * 64 * 4, nx = (size_t)3 * B * R * 64 + 256;
+    const size_t nh = (size_t)3 * B * 64 * T, nk = (size_t)3 * B * T * fd::KREC, ng = (size_t)776 * 2 * 12 * 64 * 4, nx = (size_t)3 * B * R * 64 + 1024;
     float *h, *kp, *g, *gb, *hx;
     int *flag;
     CK(hipMalloc(&flag, 256)); CK(hipMemset(flag, 0, 256));
