@@ -29,6 +29,30 @@ __global__ void k_mfma(long long *out, int n, float s)
     if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
     if (acc[0] == 12345.0f) out[2] = 1;
 }
+__global__ void k_mfma_rand(long long *out, int n, float s)
+{
+    // two operand sets with lane-dependent pseudo-random bit patterns, alternated: every MFMA sees fresh data
+    const unsigned l = threadIdx.x * 2654435761u + blockIdx.x * 40503u;
+    f16x8 a1, b1, a2, b2;
+    for (int q = 0; q < 8; ++q) {
+        a1[q] = (_Float16)(s * (float)((l >> (q + 3)) & 1023u) * 0.001f - 0.5f);
+        b1[q] = (_Float16)(s * (float)((l >> (q + 7)) & 1023u) * 0.001f - 0.5f);
+        a2[q] = (_Float16)(s * (float)((l >> (q + 11)) & 1023u) * 0.001f - 0.5f);
+        b2[q] = (_Float16)(s * (float)((l >> (q + 13)) & 1023u) * 0.001f - 0.5f);
+    }
+    const long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    f32x16 acc = {0};
+    for (int i = 0; i < n; ++i) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b2, acc, 0, 0, 0);
+        }
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
+    if (acc[0] == 12345.0f) out[2] = 1;
+}
 int main()
 {
     long long *d, h[3];
@@ -45,6 +69,19 @@ int main()
         const double ops = (mode < 2) ? 64.0 * n : 32.0 * n;
         printf("%s grid %4d: wall %.3f ms | s_memtime %lld ticks (%.2f per op) | s_memrealtime %lld ticks -> %.1f MHz realtime, memtime %.1f MHz\n",
                mode < 2 ? "valu chain" : "mfma chain", grid, ms, h[0], h[0] / ops, h[1], h[1] / (ms * 1e3), h[0] / (ms * 1e3));
+    }
+    for (int grid = 1; grid <= 2048; grid *= 2048) {
+        const int n = 20000;
+        hipLaunchKernelGGL(k_mfma_rand, dim3(grid), dim3(256), 0, 0, d, n, 1.0f);
+        hipDeviceSynchronize();
+        hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
+        printf("mfma chain, alternating random operands, grid %4d: block 0 ran at %.0f MHz (%lld core ticks / %lld x 10 ns)\n", grid, (double)h[0] / h[1] * 100.0, h[0], h[1]);
+    }
+    for (int grid = 1; grid <= 2048; grid *= 2048) {
+        hipLaunchKernelGGL(k_mfma, dim3(grid), dim3(256), 0, 0, d, 20000, 1.0f);
+        hipDeviceSynchronize();
+        hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
+        printf("mfma chain, constant operands,           grid %4d: block 0 ran at %.0f MHz\n", grid, (double)h[0] / h[1] * 100.0);
     }
     return 0;
 }
