@@ -115,7 +115,7 @@ def test_capi_exports_every_declared_symbol():
     # the gate pair (out, out+32) of a channel sits 16 rows apart in the same 32-row MFMA tile
     for o in range(32):
         a, b = lib.fd_kernel_index(0, 0, o, 0), lib.fd_kernel_index(0, 0, o + 32, 0)
-        assert b - a == 16 * 4 and lib.fd_bias_index(0, o + 32) - lib.fd_bias_index(0, o) == 16
+        assert b - a == 16 * 8 and lib.fd_bias_index(0, o + 32) - lib.fd_bias_index(0, o) == 16      # 8 k per lane
 
 
 def test_struct_sizes_match_header():
