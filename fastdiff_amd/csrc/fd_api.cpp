@@ -329,6 +329,25 @@ static float f32_from_f16(uint16_t hb)
     return v;
 }
 
+// fp16 pieces of a 32-row conv weight [32][cin][ks] in 32x32x16 A-operand order: [piece][kg][lane = out + 32*g][8],
+// k = 16*kg + 8*g + e = tap*cin + in.  *ok is cleared when a value does not fit the fp16 range.
+static std::vector<uint16_t> pack_A_h2(const std::vector<float> &w, int cin, int ks, bool *ok)
+{
+    const int nk = cin * ks, nkg = nk / 16;
+    std::vector<uint16_t> hp((size_t)2 * nkg * 64 * 8);
+    for (int kg = 0; kg < nkg; ++kg)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 8; ++e) {
+                const int kk = kg * 16 + 8 * (lane >> 5) + e, tap = kk / cin, in = kk % cin, out = lane & 31;
+                const float v = w[((size_t)out * cin + in) * ks + tap];
+                if (!(fabsf(v) < 32768.0f)) *ok = false;
+                const uint16_t p1 = f16_from_f32(v);
+                hp[((size_t)(0 * nkg + kg) * 64 + lane) * 8 + e] = p1;
+                hp[((size_t)(1 * nkg + kg) * 64 + lane) * 8 + e] = f16_from_f32((v - f32_from_f16(p1)) * 2048.0f);
+            }
+    return hp;
+}
+
 void unpack_kernel_index(int p, int &layer, int &in, int &out, int &tap)
 {
     layer = p / fd::KLAYER;
@@ -385,7 +404,7 @@ int fd_commit_weights(fd_handle h)
         }
         UP(table, w.embed_table);
     }
-    bool f16_ok = true, lvc_ok = true;
+    bool f16_ok = true, lvc_ok = true, dblock_ok = true;
     for (int n = 0; n < fd::NBLK; ++n) {
         const std::string p = "lvc_blocks." + std::to_string(n), d = "downsample." + std::to_string(n);
         if ((rc = up_conv(d + ".residual_dense", w.down[n].res)) != FD_OK) return rc;
@@ -394,6 +413,10 @@ int fd_commit_weights(fd_handle h)
             UP(pack_A(f[d + ".conv." + std::to_string(i)].w, fd::C, fd::C, 3), w.down_pack[n][i]);
         }
         UP(pack_A(f[d + ".residual_dense"].w, fd::C, fd::C, 1), w.down_pack[n][3]);
+        for (int i = 0; i < 4; ++i) {      // the same four matrices as fp16 pieces (conv 0..2: K = 96, residual 1x1: K = 32)
+            const std::vector<uint16_t> hp = pack_A_h2(f[i < 3 ? d + ".conv." + std::to_string(i) : d + ".residual_dense"].w, fd::C, i < 3 ? 3 : 1, &dblock_ok);
+            if ((rc = upload(h, hp.data(), hp.size() * sizeof(uint16_t), reinterpret_cast<const void **>(&w.down_h2[n][i]))) != FD_OK) return rc;
+        }
         if ((rc = up_conv(p + ".fc_t", w.blk[n].fc_t)) != FD_OK) return rc;
         UP(transpose(f[p + ".fc_t"].w, fd::COND, fd::E_OUT), w.fc_t_T[n]);
         w.fc_t_b[n] = w.blk[n].fc_t.b;
@@ -425,19 +448,8 @@ int fd_commit_weights(fd_handle h)
         for (int i = 0; i < fd::LAYERS; ++i) {
             if ((rc = up_conv(p + ".convs." + std::to_string(i), w.blk[n].convs[i])) != FD_OK) return rc;
             UP(pack_A(f[p + ".convs." + std::to_string(i)].w, fd::C, fd::C, 3), w.lvc_conv_pack[n][i]);
-            {   // fp16 pieces in 32x32x16 A-operand order: lane = out + 32*g holds k = 16*kg + 8*g + e, k = tap*32 + in
-                const std::vector<float> &cw = f[p + ".convs." + std::to_string(i)].w;      // [out][in][3]
-                std::vector<uint16_t> hp((size_t)2 * 6 * 64 * 8);
-                for (int kg = 0; kg < 6; ++kg)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int e = 0; e < 8; ++e) {
-                            const int kk = kg * 16 + 8 * (lane >> 5) + e, tap = kk / fd::C, in = kk % fd::C, out = lane & 31;
-                            const float v = cw[((size_t)out * fd::C + in) * 3 + tap];
-                            if (!(fabsf(v) < 32768.0f)) lvc_ok = false;
-                            const uint16_t p1 = f16_from_f32(v);
-                            hp[((size_t)(0 * 6 + kg) * 64 + lane) * 8 + e] = p1;
-                            hp[((size_t)(1 * 6 + kg) * 64 + lane) * 8 + e] = f16_from_f32((v - f32_from_f16(p1)) * 2048.0f);
-                        }
+            {
+                const std::vector<uint16_t> hp = pack_A_h2(f[p + ".convs." + std::to_string(i)].w, fd::C, 3, &lvc_ok);
                 if ((rc = upload(h, hp.data(), hp.size() * sizeof(uint16_t), reinterpret_cast<const void **>(&w.lvc_conv_h2[n][i]))) != FD_OK)
                     return rc;
             }
@@ -503,6 +515,7 @@ int fd_commit_weights(fd_handle h)
     }
     w.gemm_f16_ok = f16_ok;
     w.lvc_f16_ok = lvc_ok;
+    w.dblock_f16_ok = dblock_ok;
     {
         std::vector<int> perm(fd::KW);
         for (int layer = 0; layer < fd::LAYERS; ++layer)
@@ -672,7 +685,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
 
 static unsigned mode_signature(const fd_context *h)
 {
-    unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_f16 ? 2u : 0u) | (h->lvc_f16 ? 4u : 0u);
+    unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_f16 ? 2u : 0u) | (h->lvc_f16 ? 4u : 0u) | (h->conv_f16 ? 8u : 0u);
     for (int i = 0; i < ST_COUNT; ++i) s = (s << 1) | (h->fast[i] ? 1u : 0u);
     return s;
 }
@@ -796,6 +809,12 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
         if (v == "f16x2") h->lvc_f16 = true;
         else if (v == "fp32") h->lvc_f16 = false;
         else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: lvc expects f16x2|fp32, got '%s'", value);
+        return FD_OK;
+    }
+    if (k == "conv") {
+        if (v == "f16x2") h->conv_f16 = true;
+        else if (v == "fp32") h->conv_f16 = false;
+        else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: conv expects f16x2|fp32, got '%s'", value);
         return FD_OK;
     }
     if (k == "graph") { h->use_graph = on; return FD_OK; }

@@ -69,6 +69,8 @@ struct DevWeights {
     const float *embed_table = nullptr;           // [64] fp32 frequencies
     // MFMA A-operand packs ([mt][s4][lane][4], kk = tap*Cin + in)
     const float *down_pack[fd::NBLK][4] = {};     // conv0..2 (K=96), res 1x1 (K=32)
+    const uint16_t *down_h2[fd::NBLK][4] = {};    // the same as two fp16 pieces: [piece][kg][64 lane][8]
+    bool dblock_f16_ok = false;
     const float *lvc_conv_pack[fd::NBLK][fd::LAYERS] = {};
     const uint16_t *lvc_conv_h2[fd::NBLK][fd::LAYERS] = {};   // the same as two fp16 pieces: [piece][6 kg][64 lane][8], k = tap*32 + in
     bool lvc_f16_ok = false;                      // every LVC conv weight fits the fp16 range
@@ -106,7 +108,7 @@ struct Workspace {
     float *kp_h0 = nullptr, *kp_hA = nullptr, *kp_hB = nullptr;   // [3][B][64][T]
     float *kpack = nullptr;     // [3][B][T][KREC]
     float *h_f16 = nullptr;     // fp16 piece image of the predictor hidden state: [3][B][64*ceil(T/64)+2 rows][2 pieces][64] x 2 B
-    int *range_flag = nullptr;  // [0] predictor GEMM, [1 + 4*block + layer] LVC layers: an operand did not fit fp16; zeroed every step
+    int *range_flag = nullptr;  // [0] predictor GEMM, [1 + 4*block + layer] LVC layers, [13 + d] DBlocks: an operand did not fit fp16; zeroed every step
     float *xA = nullptr, *xB = nullptr;                           // [B][32][L] ping-pong
     float *xtap[fd::NBLK] = {}; // block outputs kept for fd_read_tap
     float *mel = nullptr;       // [B][80][T] library-owned copy used by the sampler graph
@@ -130,6 +132,7 @@ struct fd_context {
     bool keep_taps = false;
     bool gemm_f16 = true;                     // kp_gemm on the fp16 matrix pipe with the 2-piece operand split
     bool lvc_f16 = true;                      // LVC layers (hop 64, 256) likewise
+    bool conv_f16 = true;                     // DBlocks likewise
     std::map<std::string, std::pair<std::vector<int64_t>, std::vector<float>>> raw;   // host copies from fd_set_weight
     std::vector<void *> dev_allocs;          // weight arena pieces
     DevWeights w;

@@ -40,6 +40,43 @@ __device__ __forceinline__ float lrelu(float v, float s)   // 0 < s < 1:  max(v,
 }
 __device__ __forceinline__ float f4c(const float4 &v, int r) { return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w)); }
 
+// ---- 2-piece fp16 operands: v = v1 + 2^-11 v2, v1 = fp16(v), v2 = fp16((v - v1) * 2^11) ----------------
+constexpr float GX_SCALE = 2048.0f, GX_INV_SCALE = 1.0f / 2048.0f;
+constexpr float GX_LIMIT = 32768.0f;            // magnitudes from here on do not fit: the kernels raise a range flag
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_f16(const float4 &a, const float4 &b, f32x16 c)
+{
+    union { float4 f; f16x8 h; } ua, ub;
+    ua.f = a;
+    ub.f = b;
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(ua.h, ub.h, c, 0, 0, 0);
+}
+
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
+{
+    const f2_t v = {a, b};
+    const h2_t h = __builtin_convertvector(v, h2_t);                       // v_cvt_pk_f16_f32, round to nearest even
+    const f2_t r = (v - __builtin_convertvector(h, f2_t)) * GX_SCALE;       // exact
+    const h2_t l = __builtin_convertvector(r, h2_t);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ void split8(const float (&v)[8], float4 &hi, float4 &lo)
+{
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split2(v[2 * i], v[2 * i + 1], h[i], l[i]);
+    hi = make_float4(__uint_as_float(h[0]), __uint_as_float(h[1]), __uint_as_float(h[2]), __uint_as_float(h[3]));
+    lo = make_float4(__uint_as_float(l[0]), __uint_as_float(l[1]), __uint_as_float(l[2]), __uint_as_float(l[3]));
+}
+__device__ __forceinline__ float amax4(float m, const float4 &v) { return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w))); }
+// byte offset of 16 B slot `slot` (piece*4 + channel/8) of row `row` in a [row][128 B] piece image
+__device__ __forceinline__ int h2_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+
 // =================================================================================================
 // a3: first_audio_conv  Conv1d(1,32,k7,pad3)  (FastDiff_model.py:34-36,89)   -- VALU, HBM-write bound
 // =================================================================================================
@@ -98,9 +135,11 @@ __global__ void __launch_bounds__(256, 2) k_dblock(const float *__restrict__ xin
                                                    const float *__restrict__ p0, const float *__restrict__ p1,
                                                    const float *__restrict__ p2, const float *__restrict__ pr,
                                                    const float *__restrict__ b0, const float *__restrict__ b1,
-                                                   const float *__restrict__ b2, const float *__restrict__ br, int Lin, int Lo)
+                                                   const float *__restrict__ b2, const float *__restrict__ br, int Lin, int Lo,
+                                                   const int *__restrict__ run_if)
 {
     __shared__ __attribute__((aligned(16))) float xs[fd::C * DB_LD];
+    if (run_if && *run_if == 0) return;      // fallback launch behind k_dblock_h2: only when that kernel flagged its operands
     __shared__ __attribute__((aligned(16))) float hA[fd::C * DB_LD];
     __shared__ __attribute__((aligned(16))) float hB[fd::C * DB_LD];
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -163,6 +202,149 @@ __global__ void __launch_bounds__(256, 2) k_dblock(const float *__restrict__ xin
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[((int64_t)b * fd::C + drow(r, hi)) * Lo + p] = acc[r];
     }
+}
+
+// The same DBlock on the fp16 matrix pipe with 2-piece operands: 57 MFMAs of 32 cycles per wave
+// instead of 160 of 64.  Activations live in LDS as [column][piece][32 ch] fp16 images (128 B per column, slots swizzled as
+// in k_lvc_h2); an image holds leaky_relu of the layer output because that is the only form the next layer reads; the raw
+// pick of x gets its own image for the 1x1 residual.  Same tiling: 128 columns, 114 valid.
+constexpr int DBH_ROWS = 136;        // 128 columns + 4 zero guard columns each side (row = column + 4)
+
+template <int DIL>
+__device__ __forceinline__ void conv96_h2(f32x16 &ah, f32x16 &al, const float4 (&wa)[2][6], const char *img, int c, int hi)
+{
+    int off[3][2][2];
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) off[tap][p][c2] = h2_off(4 + c + (tap - 1) * DIL, p * 4 + c2 * 2 + hi);
+#pragma unroll
+    for (int kg = 0; kg < 6; ++kg) {
+        const float4 b1 = *reinterpret_cast<const float4 *>(img + off[kg >> 1][0][kg & 1]);
+        const float4 b2 = *reinterpret_cast<const float4 *>(img + off[kg >> 1][1][kg & 1]);
+        ah = mfma_f16(wa[0][kg], b1, ah);
+        al = mfma_f16(wa[0][kg], b2, al);
+        al = mfma_f16(wa[1][kg], b1, al);
+    }
+}
+// write leaky_relu(hi + 2^-11 lo) of a 32x32 tile (0 where `inside` is false) as the two pieces of column c
+__device__ __forceinline__ void store_act_h2(char *img, const f32x16 &ah, const f32x16 &al, int c, int hi, bool inside, float &mx)
+{
+    const int row = 4 + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                         // D rows 8j + 4hi + {0..3}: half a slot
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = inside ? lrelu(fmaf(al[4 * j + i], GX_INV_SCALE, ah[4 * j + i]), 0.2f) : 0.0f;
+            mx = fmaxf(mx, fabsf(v[i]));
+        }
+        uint2 ph, pl;
+        split2(v[0], v[1], ph.x, pl.x);
+        split2(v[2], v[3], ph.y, pl.y);
+        *reinterpret_cast<uint2 *>(img + h2_off(row, j) + 8 * hi) = ph;
+        *reinterpret_cast<uint2 *>(img + h2_off(row, 4 + j) + 8 * hi) = pl;
+    }
+}
+
+template <int F>
+__global__ void __launch_bounds__(256, 2) k_dblock_h2(const float *__restrict__ xin, float *__restrict__ out,
+                                                      const float4 *__restrict__ p0, const float4 *__restrict__ p1,
+                                                      const float4 *__restrict__ p2, const float4 *__restrict__ pr,
+                                                      const float *__restrict__ b0, const float *__restrict__ b1,
+                                                      const float *__restrict__ b2, const float *__restrict__ br, int Lin, int Lo,
+                                                      int *__restrict__ range_flag)
+{
+    __shared__ __attribute__((aligned(16))) char xl[DBH_ROWS * 128];      // leaky_relu(x pick); later the layer-2 output
+    __shared__ __attribute__((aligned(16))) char xr[DBH_ROWS * 128];      // raw x pick (1x1 residual)
+    __shared__ __attribute__((aligned(16))) char ha[DBH_ROWS * 128];      // layer-1 output
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int pbase = blockIdx.x * DB_STRIDE - 7;   // down-sampled position of tile column 0
+    float mx = 0.0f;
+    // ---- stage the strided pick x[..., ::F]: thread = (8-channel group, column), two columns per thread; zero outside [0, Lo)
+    {
+        float v[2][8];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int u = k * 256 + tid, cg = u >> 7, cc = u & 127, p = pbase + cc;
+            const bool ok = p >= 0 && p < Lo;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[k][c] = ok ? xin[((int64_t)b * fd::C + cg * 8 + c) * Lin + (int64_t)p * F] : 0.0f;
+        }
+        if (tid < 128) {        // the 8 guard columns of all three images: zeros
+            const int g = tid >> 4, row = g < 4 ? g : 128 + g, part = tid & 15;      // 16 x 8 B per 128 B row
+            *reinterpret_cast<uint2 *>(xl + row * 128 + part * 8) = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2 *>(xr + row * 128 + part * 8) = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2 *>(ha + row * 128 + part * 8) = make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int u = k * 256 + tid, cg = u >> 7, cc = u & 127;
+            float a[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { mx = fmaxf(mx, fabsf(v[k][c])); a[c] = lrelu(v[k][c], 0.2f); }
+            float4 ph, pl;
+            split8(v[k], ph, pl);
+            *reinterpret_cast<float4 *>(xr + h2_off(4 + cc, cg)) = ph;
+            *reinterpret_cast<float4 *>(xr + h2_off(4 + cc, 4 + cg)) = pl;
+            split8(a, ph, pl);
+            *reinterpret_cast<float4 *>(xl + h2_off(4 + cc, cg)) = ph;
+            *reinterpret_cast<float4 *>(xl + h2_off(4 + cc, 4 + cg)) = pl;
+        }
+    }
+    __syncthreads();
+    const int c = wave * 32 + l31;        // this lane's tile column
+    const int p = pbase + c;              // its down-sampled position
+    const bool inside = (p >= 0 && p < Lo);
+    float4 wa[2][6];
+    f32x16 ah, al;
+    auto load_w = [&](const float4 *pk) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int kg = 0; kg < 6; ++kg) wa[q][kg] = pk[(q * 6 + kg) * 64 + lane];
+    };
+    // layer 1: dil 1 on leaky_relu(x)
+    load_w(p0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ah[r] = b0[drow(r, hi)]; al[r] = 0.0f; }
+    conv96_h2<1>(ah, al, wa, xl, c, hi);
+    store_act_h2(ha, ah, al, c, hi, inside, mx);
+    __syncthreads();
+    // layer 2: dil 2
+    load_w(p1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ah[r] = b1[drow(r, hi)]; al[r] = 0.0f; }
+    conv96_h2<2>(ah, al, wa, ha, c, hi);
+    store_act_h2(xl, ah, al, c, hi, inside, mx);      // xl is free: layer 1 was its only reader
+    __syncthreads();
+    // layer 3: dil 4, plus the 1x1 residual on the raw pick (residual_dense commutes with the nearest pick)
+    load_w(p2);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ah[r] = b2[drow(r, hi)] + br[drow(r, hi)]; al[r] = 0.0f; }
+    conv96_h2<4>(ah, al, wa, xl, c, hi);
+    {
+        float4 wr[2][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int kg = 0; kg < 2; ++kg) wr[q][kg] = pr[(q * 2 + kg) * 64 + lane];
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {      // k = input channel: 16*kg + 8*hi + e
+            const float4 x1 = *reinterpret_cast<const float4 *>(xr + h2_off(4 + c, kg * 2 + hi));
+            const float4 x2 = *reinterpret_cast<const float4 *>(xr + h2_off(4 + c, 4 + kg * 2 + hi));
+            ah = mfma_f16(wr[0][kg], x1, ah);
+            al = mfma_f16(wr[0][kg], x2, al);
+            al = mfma_f16(wr[1][kg], x1, al);
+        }
+    }
+    if (inside && c >= 7 && c < 7 + DB_STRIDE) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[((int64_t)b * fd::C + drow(r, hi)) * Lo + p] = fmaf(al[r], GX_INV_SCALE, ah[r]);
+    }
+    if (!(mx < GX_LIMIT)) atomicOr(range_flag, 1);
 }
 
 // =================================================================================================
@@ -398,28 +580,18 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm(const float *__restrict__ h 
 // the result is closer than an fp32 sgemm.  fp16 subnormals are honoured by v_cvt and by the MFMA
 // (tools/ubench/f16_probe.hip), so small values lose nothing; operands of magnitude >= 32768 do not fit: k_h_split raises
 // a flag for them, this kernel then leaves the step to the fp32 kernel that follows it in the stream.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int GX_CT = 4;                        // frame tiles per item
 constexpr int GX_ROWS = GX_CT * 32 + 2;         // 130 rows: frames t_begin-1 .. t_begin+128
 constexpr int GX_ROWB = 2 * 128;                // bytes per row of the piece image: [piece][64 ch] fp16
 constexpr int GX_WINB = GX_ROWS * GX_ROWB;      // 33280 B per item window
 constexpr int GX_NDMA = (GX_WINB + 4095) / 4096;   // 4 KB (256 lanes x 16 B) DMA rounds per window: 8 full + 1 partial
 constexpr int GX_BUFB = GX_NDMA * 4096;         // LDS bytes per buffer (the partial round is padded to a whole wave)
-constexpr float GX_SCALE = 2048.0f, GX_INV_SCALE = 1.0f / 2048.0f;
-constexpr float GX_LIMIT = 32768.0f;
 #ifndef FD_GX_STORE_AUX
 #define FD_GX_STORE_AUX 0      // cache policy bits of the predicted-kernel stores (2 = nt)
 #endif
 
 __host__ __device__ inline int gx_rows(int T) { return ((T + GX_CT * 32 - 1) / (GX_CT * 32)) * (GX_CT * 32) + 2; }   // image rows per (block, utterance)
 
-__device__ __forceinline__ f32x16 mfma_f16(const float4 &a, const float4 &b, f32x16 c)
-{
-    union { float4 f; f16x8 h; } ua, ub;
-    ua.f = a;
-    ub.f = b;
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(ua.h, ub.h, c, 0, 0, 0);
-}
 
 // h (fp32 [3][B][64][T]) -> fp16 piece image [3][B][row = t+1][piece][64 channels]; rows 0 and > T are zero.
 // A row is 256 B = 16 slots of 16 B; slot s of row r is stored at s ^ (r & 15): the 16-lane service groups of ds_read_b128
@@ -1056,30 +1228,6 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
 // Operands of magnitude >= 32768 do not fit fp16: the kernel raises *range_flag and the fp32 kernel launched behind it
 // (k_lvc_layer with run_if) redoes the whole layer from the untouched inputs.
 // =================================================================================================
-typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-typedef float f2_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
-{
-    const f2_t v = {a, b};
-    const h2_t h = __builtin_convertvector(v, h2_t);                       // v_cvt_pk_f16_f32, round to nearest even
-    const f2_t r = (v - __builtin_convertvector(h, f2_t)) * GX_SCALE;       // exact
-    const h2_t l = __builtin_convertvector(r, h2_t);
-    hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, l);
-}
-__device__ __forceinline__ void split8(const float (&v)[8], float4 &hi, float4 &lo)
-{
-    unsigned h[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) split2(v[2 * i], v[2 * i + 1], h[i], l[i]);
-    hi = make_float4(__uint_as_float(h[0]), __uint_as_float(h[1]), __uint_as_float(h[2]), __uint_as_float(h[3]));
-    lo = make_float4(__uint_as_float(l[0]), __uint_as_float(l[1]), __uint_as_float(l[2]), __uint_as_float(l[3]));
-}
-__device__ __forceinline__ float amax4(float m, const float4 &v) { return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w))); }
-// byte offset of 16 B slot `slot` (piece*4 + channel/8) of row `row` in a [row][128 B] piece image
-__device__ __forceinline__ int h2_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
-
 template <int HOP, int DIL>
 __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin, const float *__restrict__ skip, float *__restrict__ xout,
                                                    const float *__restrict__ kpack, int layer, const float4 *__restrict__ wpack16,
@@ -1406,14 +1554,29 @@ hipError_t fast_dblock(const Launch &L, int d, int B, int T)
     for (int i = 0; i < d; ++i) Lin /= fd::down_factor(i);
     const int f = fd::down_factor(d), Lo = Lin / f;
     const dim3 grid((Lo + DB_STRIDE - 1) / DB_STRIDE, B);
+    const int *run_if = nullptr;
+    const char *n4 = "dblock_f4", *n8 = "dblock_f8";
+    if (c->conv_f16 && w.dblock_f16_ok) {
+        int *flag = c->ws.range_flag + 13 + d;
+        const float4 *q0 = reinterpret_cast<const float4 *>(w.down_h2[d][0]), *q1 = reinterpret_cast<const float4 *>(w.down_h2[d][1]),
+                     *q2 = reinterpret_cast<const float4 *>(w.down_h2[d][2]), *q3 = reinterpret_cast<const float4 *>(w.down_h2[d][3]);
+        if (f == 4)
+            FD_LAUNCH(L, n4, k_dblock_h2<4>, grid, dim3(256), 0, c->ws.a[d], c->ws.a[d + 1], q0, q1, q2, q3, w.down[d].conv[0].b,
+                      w.down[d].conv[1].b, w.down[d].conv[2].b, w.down[d].res.b, Lin, Lo, flag);
+        else
+            FD_LAUNCH(L, n8, k_dblock_h2<8>, grid, dim3(256), 0, c->ws.a[d], c->ws.a[d + 1], q0, q1, q2, q3, w.down[d].conv[0].b,
+                      w.down[d].conv[1].b, w.down[d].conv[2].b, w.down[d].res.b, Lin, Lo, flag);
+        run_if = flag;
+        n4 = n8 = "dblock_fp32_fallback";
+    }
     if (f == 4)
-        FD_LAUNCH(L, "dblock_f4", k_dblock<4>, grid, dim3(256), 0, c->ws.a[d], c->ws.a[d + 1], w.down_pack[d][0], w.down_pack[d][1],
+        FD_LAUNCH(L, n4, k_dblock<4>, grid, dim3(256), 0, c->ws.a[d], c->ws.a[d + 1], w.down_pack[d][0], w.down_pack[d][1],
                   w.down_pack[d][2], w.down_pack[d][3], w.down[d].conv[0].b, w.down[d].conv[1].b, w.down[d].conv[2].b,
-                  w.down[d].res.b, Lin, Lo);
+                  w.down[d].res.b, Lin, Lo, run_if);
     else
-        FD_LAUNCH(L, "dblock_f8", k_dblock<8>, grid, dim3(256), 0, c->ws.a[d], c->ws.a[d + 1], w.down_pack[d][0], w.down_pack[d][1],
+        FD_LAUNCH(L, n8, k_dblock<8>, grid, dim3(256), 0, c->ws.a[d], c->ws.a[d + 1], w.down_pack[d][0], w.down_pack[d][1],
                   w.down_pack[d][2], w.down_pack[d][3], w.down[d].conv[0].b, w.down[d].conv[1].b, w.down[d].conv[2].b,
-                  w.down[d].res.b, Lin, Lo);
+                  w.down[d].res.b, Lin, Lo, run_if);
     return hipSuccess;
 }
 
