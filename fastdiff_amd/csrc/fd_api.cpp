@@ -404,7 +404,7 @@ int fd_commit_weights(fd_handle h)
         }
         UP(table, w.embed_table);
     }
-    bool f16_ok = true, lvc_ok = true, dblock_ok = true;
+    bool f16_ok = true, lvc_ok = true, dblock_ok = true, convt_ok = true;
     for (int n = 0; n < fd::NBLK; ++n) {
         const std::string p = "lvc_blocks." + std::to_string(n), d = "downsample." + std::to_string(n);
         if ((rc = up_conv(d + ".residual_dense", w.down[n].res)) != FD_OK) return rc;
@@ -435,6 +435,21 @@ int fd_commit_weights(fd_handle h)
                             up[(((size_t)ph * 8 + s4) * 64 + lane) * 4 + q] = uw[((size_t)i * fd::C + o) * ks + k];
                         }
             UP(up, w.up_pack[n]);
+            // the same per-phase slices as fp16 pieces: [ph][piece][4 kg][64 lane = out + 32*g][8], k = 16*kg + 8*g + e = sel*32 + i
+            std::vector<uint16_t> hp((size_t)r * 2 * 4 * 64 * 8);
+            for (int ph = 0; ph < r; ++ph)
+                for (int kg = 0; kg < 4; ++kg)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int kk = kg * 16 + 8 * (lane >> 5) + e, sel = kk >> 5, i = kk & 31, o = lane & 31;
+                            const int kA = (ph < pd) ? ph + pd : ph - pd, k = sel ? kA + r : kA;
+                            const float v = uw[((size_t)i * fd::C + o) * ks + k];
+                            if (!(fabsf(v) < 32768.0f)) convt_ok = false;
+                            const uint16_t p1 = f16_from_f32(v);
+                            hp[((((size_t)ph * 2 + 0) * 4 + kg) * 64 + lane) * 8 + e] = p1;
+                            hp[((((size_t)ph * 2 + 1) * 4 + kg) * 64 + lane) * 8 + e] = f16_from_f32((v - f32_from_f16(p1)) * 2048.0f);
+                        }
+            if ((rc = upload(h, hp.data(), hp.size() * sizeof(uint16_t), reinterpret_cast<const void **>(&w.up_h2[n]))) != FD_OK) return rc;
         }
         if ((rc = up_conv(p + ".kernel_predictor.input_conv.0", w.blk[n].kp_in)) != FD_OK) return rc;
         UP(pack_A(f[p + ".kernel_predictor.input_conv.0"].w, fd::HID, fd::COND, 5), w.kp_in_pack[n]);
@@ -516,6 +531,7 @@ int fd_commit_weights(fd_handle h)
     w.gemm_f16_ok = f16_ok;
     w.lvc_f16_ok = lvc_ok;
     w.dblock_f16_ok = dblock_ok;
+    w.convt_f16_ok = convt_ok;
     {
         std::vector<int> perm(fd::KW);
         for (int layer = 0; layer < fd::LAYERS; ++layer)
@@ -846,8 +862,8 @@ int64_t fd_read_tap(fd_handle h, const char *name, float *host_dst, int64_t capa
         if (!h->keep_taps) FD_FAIL(h, FD_ERR_STATE, "fd_read_tap: set option taps=1 before the forward to keep block outputs");
         const int blk = k[1] - '0';
         src = w.xtap[blk]; n = (int64_t)B * fd::C * T * fd::hop(blk);
-    } else if (k == "range_flags") {       // 16 int32 (bit patterns): fp16-range flags of the last step, see Workspace::range_flag
-        src = reinterpret_cast<const float *>(w.range_flag); n = 16;
+    } else if (k == "range_flags") {       // 32 int32 (bit patterns): fp16-range flags of the last step, see Workspace::range_flag
+        src = reinterpret_cast<const float *>(w.range_flag); n = 32;
     } else FD_FAIL(h, FD_ERR_INVALID, "fd_read_tap: unknown tap '%s'", name);
     if (!host_dst) return n;
     if (capacity < n) FD_FAIL(h, FD_ERR_INVALID, "fd_read_tap: capacity %lld < %lld", (long long)capacity, (long long)n);

@@ -81,6 +81,8 @@ struct DevWeights {
     const uint16_t *gemm_h2_pack[fd::NBLK] = {};  // same weights as two fp16 pieces (w1, (w-w1)*2^11): [776 ptile][2][12 kg][64 lane][8]
     bool gemm_f16_ok = false;                     // every GEMM weight fits the fp16 range
     const float *up_pack[fd::NBLK] = {};          // ConvTranspose as per-phase A operands: [r phases][8 s4][64][4]
+    const uint16_t *up_h2[fd::NBLK] = {};         // ConvTranspose per-phase slices as fp16 pieces: [ph][piece][4 kg][64 lane][8]
+    bool convt_f16_ok = false;
     const int *kc_perm = nullptr;                 // [24576] reference kernel_conv row -> packed position
     const int *bc_perm = nullptr;                 // [256] reference bias_conv row -> position inside the bias part
 };
@@ -108,7 +110,8 @@ struct Workspace {
     float *kp_h0 = nullptr, *kp_hA = nullptr, *kp_hB = nullptr;   // [3][B][64][T]
     float *kpack = nullptr;     // [3][B][T][KREC]
     float *h_f16 = nullptr;     // fp16 piece image of the predictor hidden state: [3][B][64*ceil(T/64)+2 rows][2 pieces][64] x 2 B
-    int *range_flag = nullptr;  // [0] predictor GEMM, [1 + 4*block + layer] LVC layers, [13 + d] DBlocks: an operand did not fit fp16; zeroed every step
+    int *range_flag = nullptr;  // [0] predictor GEMM, [1 + 4*block + layer] LVC layers, [13 + d] DBlocks,
+                                // [16 + n] ConvTranspose of block n: an operand did not fit fp16; 32 words, zeroed every step
     float *xA = nullptr, *xB = nullptr;                           // [B][32][L] ping-pong
     float *xtap[fd::NBLK] = {}; // block outputs kept for fd_read_tap
     float *mel = nullptr;       // [B][80][T] library-owned copy used by the sampler graph
@@ -132,7 +135,7 @@ struct fd_context {
     bool keep_taps = false;
     bool gemm_f16 = true;                     // kp_gemm on the fp16 matrix pipe with the 2-piece operand split
     bool lvc_f16 = true;                      // LVC layers (hop 64, 256) likewise
-    bool conv_f16 = true;                     // DBlocks likewise
+    bool conv_f16 = true;                     // DBlocks and ConvTranspose upsamplers likewise
     std::map<std::string, std::pair<std::vector<int64_t>, std::vector<float>>> raw;   // host copies from fd_set_weight
     std::vector<void *> dev_allocs;          // weight arena pieces
     DevWeights w;

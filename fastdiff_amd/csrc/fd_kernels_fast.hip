@@ -857,9 +857,11 @@ constexpr int CT_LD = 132;     // 128 input positions + 1 halo each side, padded
 
 template <int R>
 __global__ void __launch_bounds__(256, 2) k_convt(const float *__restrict__ xin, const float *__restrict__ pack,
-                                               const float *__restrict__ bias, float *__restrict__ out, int Lin)
+                                               const float *__restrict__ bias, float *__restrict__ out, int Lin,
+                                               const int *__restrict__ run_if)
 {
     __shared__ float xs[fd::C * CT_LD];
+    if (run_if && *run_if == 0) return;      // fallback launch behind k_convt_h2
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int q0 = blockIdx.x * 128, Lout = Lin * R;
     {
@@ -911,6 +913,97 @@ __global__ void __launch_bounds__(256, 2) k_convt(const float *__restrict__ xin,
 #pragma unroll
             for (int p4 = 0; p4 < R; p4 += 4)
                 *reinterpret_cast<float4 *>(dst + p4) = make_float4(acc[p4][r], acc[p4 + 1][r], acc[p4 + 2][r], acc[p4 + 3][r]);
+        }
+    }
+}
+
+// The same ConvTranspose on the fp16 matrix pipe with 2-piece operands: 12 MFMAs of 32 cycles per
+// output phase instead of 32 of 64.  leaky_relu(x) is split once into a [position][piece][32 ch] fp16 image (row = q - q0 + 1).
+template <int R>
+__global__ void __launch_bounds__(256, 2) k_convt_h2(const float *__restrict__ xin, const float4 *__restrict__ pack16,
+                                                  const float *__restrict__ bias, float *__restrict__ out, int Lin,
+                                                  int *__restrict__ range_flag)
+{
+    __shared__ __attribute__((aligned(16))) char xs[130 * 128];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int q0 = blockIdx.x * 128, Lout = Lin * R;
+    float mx = 0.0f;
+    {   // thread = (8-channel group, position): 130 positions x 4 groups = 520 units
+        float v[3][8];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int u = k * 256 + tid, cg = u / 130, jj = u - cg * 130, j = q0 - 1 + jj;
+            const bool ok = u < 520 && j >= 0 && j < Lin;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[k][c] = ok ? xin[((int64_t)b * fd::C + cg * 8 + c) * Lin + j] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int u = k * 256 + tid, cg = u / 130, jj = u - cg * 130;
+            if (u < 520) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { mx = fmaxf(mx, fabsf(v[k][c])); v[k][c] = lrelu(v[k][c], 0.2f); }
+                float4 ph, pl;
+                split8(v[k], ph, pl);
+                *reinterpret_cast<float4 *>(xs + h2_off(jj, cg)) = ph;
+                *reinterpret_cast<float4 *>(xs + h2_off(jj, 4 + cg)) = pl;
+            }
+        }
+    }
+    if (!(mx < GX_LIMIT)) atomicOr(range_flag, 1);
+    __syncthreads();
+    const int ql = wave * 32 + l31, q = q0 + ql;
+    if (q0 + wave * 32 >= Lin) return;
+    float4 cb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cb[j] = reinterpret_cast<const float4 *>(bias)[2 * j + hi];
+    float *ob = out + ((int64_t)b * fd::C + 4 * hi) * Lout + (int64_t)q * R;
+    const unsigned Lu = (unsigned)Lout;
+    // B operands: rows ql (position q-1), ql+1 (q), ql+2 (q+1); two channel halves, two pieces each
+    float4 bx[3][2][2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bx[d][c2][p] = *reinterpret_cast<const float4 *>(xs + h2_off(ql + d, p * 4 + c2 * 2 + hi));
+    float4 wa[2][2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) wa[0][p][kg] = pack16[(p * 4 + kg) * 64 + lane];
+    // a lane ends up with the R consecutive outputs q*R .. q*R+R-1 of 16 channels: phases are done four at a time and
+    // leave as 16 B stores (32 lanes cover 32*R contiguous floats per channel)
+#pragma unroll
+    for (int pg = 0; pg < R; pg += 4) {
+        float res[4][16];
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi) {
+            const int ph = pg + pi;
+            if (ph + 1 < R) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int kg = 0; kg < 4; ++kg) wa[(ph + 1) & 1][p][kg] = pack16[(((ph + 1) * 2 + p) * 4 + kg) * 64 + lane];
+            }
+            const int offA = (ph < R / 2) ? 0 : 1, offB = offA - 1;      // sel 0 reads position q + offA, sel 1 position q + offB
+            f32x16 ah, al;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ah[r] = f4c(cb[r >> 2], r & 3); al[r] = 0.0f; }
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {          // k = 16*kg + 8*hi + e = sel*32 + i
+                const int d = 1 + ((kg >> 1) ? offB : offA), c2 = kg & 1;
+                ah = mfma_f16(wa[ph & 1][0][kg], bx[d][c2][0], ah);
+                al = mfma_f16(wa[ph & 1][0][kg], bx[d][c2][1], al);
+                al = mfma_f16(wa[ph & 1][1][kg], bx[d][c2][0], al);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) res[pi][r] = fmaf(al[r], GX_INV_SCALE, ah[r]);
+        }
+        if (q < Lin) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                *reinterpret_cast<float4 *>(ob + (unsigned)((r & 3) + 8 * (r >> 2)) * Lu + pg) = make_float4(res[0][r], res[1][r], res[2][r], res[3][r]);
         }
     }
 }
@@ -1628,10 +1721,22 @@ hipError_t fast_convt(const Launch &L, int n, const float *x_in, float *x_out, i
 {
     const DevWeights &w = L.ctx->w;
     const dim3 grid((Lin + 127) / 128, B);
+    fd_context *c = L.ctx;
+    const int *run_if = nullptr;
+    const char *n8 = "convt_r8", *n4 = "convt_r4";
+    if (c->conv_f16 && w.convt_f16_ok) {
+        int *flag = c->ws.range_flag + 16 + n;
+        if (fd::ratio(n) == 8)
+            FD_LAUNCH(L, n8, k_convt_h2<8>, grid, dim3(256), 0, x_in, reinterpret_cast<const float4 *>(w.up_h2[n]), w.blk[n].up.b, x_out, Lin, flag);
+        else
+            FD_LAUNCH(L, n4, k_convt_h2<4>, grid, dim3(256), 0, x_in, reinterpret_cast<const float4 *>(w.up_h2[n]), w.blk[n].up.b, x_out, Lin, flag);
+        run_if = flag;
+        n8 = n4 = "convt_fp32_fallback";
+    }
     if (fd::ratio(n) == 8)
-        FD_LAUNCH(L, "convt_r8", k_convt<8>, grid, dim3(256), 0, x_in, w.up_pack[n], w.blk[n].up.b, x_out, Lin);
+        FD_LAUNCH(L, n8, k_convt<8>, grid, dim3(256), 0, x_in, w.up_pack[n], w.blk[n].up.b, x_out, Lin, run_if);
     else
-        FD_LAUNCH(L, "convt_r4", k_convt<4>, grid, dim3(256), 0, x_in, w.up_pack[n], w.blk[n].up.b, x_out, Lin);
+        FD_LAUNCH(L, n4, k_convt<4>, grid, dim3(256), 0, x_in, w.up_pack[n], w.blk[n].up.b, x_out, Lin, run_if);
     return hipSuccess;
 }
 

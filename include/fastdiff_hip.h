@@ -120,6 +120,7 @@ FD_API int fd_peak_normalize_int16(fd_handle h, const float *wav, int B, int64_t
  * "gemm" = "f16x2" (default: predictor GEMM on the fp16 matrix pipe with 2-piece operands, 22 bits each; error below
  *          an fp32 sgemm; operands outside the fp16 range fall back to fp32 on the device) | "fp32";
  * "lvc"  = "f16x2" (default: the same for the LVC layers of hop 64 and 256) | "fp32";
+ * "conv" = "f16x2" (default: the same for the DBlocks and the ConvTranspose upsamplers) | "fp32";
  * "taps" = "1" | "0" (keep block outputs for fd_read_tap). */
 FD_API int fd_set_option(fd_handle h, const char *key, const char *value);
 
@@ -127,8 +128,9 @@ FD_API int fd_set_option(fd_handle h, const char *key, const char *value);
 
 /* Copies an intermediate of the LAST fd_forward to host (synchronises).  Names: "noise" [B,3,80], "a0".."a3",
  * "kp_h<n>" [B,64,T], "kpack<n>" [B,T,24832] (packed predicted kernels+bias of block n), "x<n>" [B,32,L_n],
- * "range_flags" (16 int32 bit patterns: [0] predictor GEMM, [1 + 4*block + layer] LVC layer -- set when an operand of
- * the last fd_forward did not fit fp16 and the fp32 kernel redid that launch; fd_sample clears them every step).
+ * "range_flags" (32 int32 bit patterns: [0] predictor GEMM, [1 + 4*block + layer] LVC layer, [13 + d] DBlock d,
+ * [16 + n] ConvTranspose of block n -- set when an operand of the last fd_forward did not fit fp16 and the fp32 kernel redid
+ * that launch; fd_sample clears them every step).
  * Returns the number of floats (also when host_dst is NULL), or a negative status. */
 FD_API int64_t fd_read_tap(fd_handle h, const char *name, float *host_dst, int64_t capacity);
 
