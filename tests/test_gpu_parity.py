@@ -213,6 +213,61 @@ def test_lvc_out_of_fp16_range_falls_back_on_device(gc, oracle64):
     assert np.isfinite(y).all() and gc.maxdiff(y, y_ref) < 2e-6 * max(1.0, float(np.abs(y_ref).max()))
 
 
+def test_conv_f16x2_against_fp32_pipe_and_oracle(model, gc, oracle64):
+    """DBlocks and ConvTranspose upsamplers: fp16 pipe with 2-piece operands (default) vs option conv=fp32."""
+    import synth
+    B, T = 2, 33
+    mel, audio = synth.synth_mel(41, B, T), synth.synth_audio(41, B, T)
+    steps = np.array([5.0, 640.25], np.float32)
+    y_ref, ref = oracle64.forward(audio, mel, steps, taps=True)
+    err = {}
+    try:
+        for mode in ("f16x2", "fp32"):
+            model.set_option("conv", mode)
+            model.set_option("taps", "1")
+            y = gc.run_forward(model, audio, mel, steps)
+            taps = gc.read_taps(model, B, T)
+            assert not model.read_tap("range_flags").view(np.int32).any()
+            err[mode] = [gc.maxdiff(taps[k], ref[k]) for k in ("a1", "a2", "a3", "x0", "x1", "x2")] + [gc.maxdiff(y, y_ref)]
+    finally:
+        model.set_option("conv", "f16x2")
+        model.set_option("taps", "0")
+    print("a1, a2, a3, x0, x1, x2, eps max error vs float64 oracle:", err)
+    for mode in err:
+        assert max(err[mode]) < FWD_TOL, (mode, err[mode])
+
+
+def test_everything_out_of_fp16_range_falls_back_on_device(gc, oracle64):
+    """A first conv scaled by 1e7 drives every activation past 32768: every fp16-pipe launch that sees them (DBlocks,
+    ConvTranspose, LVC layers) must raise its flag and be redone by the fp32 kernel behind it.  The result is compared
+    relative to its own scale."""
+    import synth
+    sd = dict(synth.synth_state_dict(1234))
+    sd["first_audio_conv.weight_g"] = (sd["first_audio_conv.weight_g"] * 1.0e7).astype(np.float32)
+    m = gc.fastdiff_amd.FastDiff()
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    m = m.cuda().eval()
+    o = type(oracle64)("f64")
+    o.set_weights(sd)
+    B, T = 1, 7
+    mel, audio = synth.synth_mel(8, B, T), synth.synth_audio(8, B, T)
+    steps = np.array([300.0], np.float32)
+    y_ref, ref = o.forward(audio, mel, steps, taps=True)
+    m.set_option("taps", "1")
+    y = gc.run_forward(m, audio, mel, steps)
+    taps = gc.read_taps(m, B, T)
+    flags = m.read_tap("range_flags").view(np.int32)
+    assert flags[0] == 0                                     # the predictor sees only the mel
+    assert flags[13:16].all() and flags[16:19].all()         # DBlocks, ConvTranspose
+    assert flags[1:13].reshape(3, 4)[1:].all()               # LVC layers of hop 64 and 256 (hop 8 has no fp16 kernel)
+    assert np.isfinite(y).all()
+    for k in ("a1", "a2", "a3", "x0", "x1", "x2"):
+        scale = float(np.abs(ref[k]).max())
+        assert scale > 32768.0, k
+        assert gc.maxdiff(taps[k], ref[k]) < 3e-6 * scale, k
+    assert gc.maxdiff(y, y_ref) < 3e-6 * float(np.abs(y_ref).max())
+
+
 @pytest.mark.parametrize("B,T", [(1, 1), (3, 3), (1, 63), (2, 130)])
 def test_forward_ragged_sizes_against_oracle(model, gc, oracle64, B, T):
     import synth
