@@ -329,22 +329,24 @@ static float f32_from_f16(uint16_t hb)
     return v;
 }
 
-// fp16 pieces of a 32-row conv weight [32][cin][ks] in 32x32x16 A-operand order: [piece][kg][lane = out + 32*g][8],
-// k = 16*kg + 8*g + e = tap*cin + in.  *ok is cleared when a value does not fit the fp16 range.
-static std::vector<uint16_t> pack_A_h2(const std::vector<float> &w, int cin, int ks, bool *ok)
+// fp16 pieces of a conv weight [cout][cin][ks] (cout a multiple of 32) in 32x32x16 A-operand order:
+// [mt = out/32][piece][kg][lane = out%32 + 32*g][8], k = 16*kg + 8*g + e = tap*cin + in.  *ok is cleared when a value does not
+// fit the fp16 range.
+static std::vector<uint16_t> pack_A_h2(const std::vector<float> &w, int cin, int ks, bool *ok, int cout = 32)
 {
-    const int nk = cin * ks, nkg = nk / 16;
-    std::vector<uint16_t> hp((size_t)2 * nkg * 64 * 8);
-    for (int kg = 0; kg < nkg; ++kg)
-        for (int lane = 0; lane < 64; ++lane)
-            for (int e = 0; e < 8; ++e) {
-                const int kk = kg * 16 + 8 * (lane >> 5) + e, tap = kk / cin, in = kk % cin, out = lane & 31;
-                const float v = w[((size_t)out * cin + in) * ks + tap];
-                if (!(fabsf(v) < 32768.0f)) *ok = false;
-                const uint16_t p1 = f16_from_f32(v);
-                hp[((size_t)(0 * nkg + kg) * 64 + lane) * 8 + e] = p1;
-                hp[((size_t)(1 * nkg + kg) * 64 + lane) * 8 + e] = f16_from_f32((v - f32_from_f16(p1)) * 2048.0f);
-            }
+    const int nk = cin * ks, nkg = nk / 16, nmt = cout / 32;
+    std::vector<uint16_t> hp((size_t)nmt * 2 * nkg * 64 * 8);
+    for (int mt = 0; mt < nmt; ++mt)
+        for (int kg = 0; kg < nkg; ++kg)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int kk = kg * 16 + 8 * (lane >> 5) + e, tap = kk / cin, in = kk % cin, out = mt * 32 + (lane & 31);
+                    const float v = w[((size_t)out * cin + in) * ks + tap];
+                    if (!(fabsf(v) < 32768.0f)) *ok = false;
+                    const uint16_t p1 = f16_from_f32(v);
+                    hp[((((size_t)mt * 2 + 0) * nkg + kg) * 64 + lane) * 8 + e] = p1;
+                    hp[((((size_t)mt * 2 + 1) * nkg + kg) * 64 + lane) * 8 + e] = f16_from_f32((v - f32_from_f16(p1)) * 2048.0f);
+                }
     return hp;
 }
 
@@ -404,7 +406,7 @@ int fd_commit_weights(fd_handle h)
         }
         UP(table, w.embed_table);
     }
-    bool f16_ok = true, lvc_ok = true, dblock_ok = true, convt_ok = true;
+    bool f16_ok = true, lvc_ok = true, dblock_ok = true, convt_ok = true, kpf_ok = true;
     for (int n = 0; n < fd::NBLK; ++n) {
         const std::string p = "lvc_blocks." + std::to_string(n), d = "downsample." + std::to_string(n);
         if ((rc = up_conv(d + ".residual_dense", w.down[n].res)) != FD_OK) return rc;
@@ -453,10 +455,16 @@ int fd_commit_weights(fd_handle h)
         }
         if ((rc = up_conv(p + ".kernel_predictor.input_conv.0", w.blk[n].kp_in)) != FD_OK) return rc;
         UP(pack_A(f[p + ".kernel_predictor.input_conv.0"].w, fd::HID, fd::COND, 5), w.kp_in_pack[n]);
+        {
+            const std::vector<uint16_t> hp = pack_A_h2(f[p + ".kernel_predictor.input_conv.0"].w, fd::COND, 5, &kpf_ok, fd::HID);
+            if ((rc = upload(h, hp.data(), hp.size() * sizeof(uint16_t), reinterpret_cast<const void **>(&w.kp_in_h2[n]))) != FD_OK) return rc;
+        }
         for (int j = 0; j < 6; ++j) {
             const std::string nm = p + ".kernel_predictor.residual_conv." + std::to_string(KP_RES_IDX[j]);
             if ((rc = up_conv(nm, w.blk[n].kp_res[j])) != FD_OK) return rc;
             UP(pack_A(f[nm].w, fd::HID, fd::HID, 3), w.kp_res_pack[n][j]);
+            const std::vector<uint16_t> hp = pack_A_h2(f[nm].w, fd::HID, 3, &kpf_ok, fd::HID);
+            if ((rc = upload(h, hp.data(), hp.size() * sizeof(uint16_t), reinterpret_cast<const void **>(&w.kp_res_h2[n][j]))) != FD_OK) return rc;
         }
         if ((rc = up_conv(p + ".kernel_predictor.kernel_conv", w.blk[n].kc)) != FD_OK) return rc;
         if ((rc = up_conv(p + ".kernel_predictor.bias_conv", w.blk[n].bc)) != FD_OK) return rc;
@@ -532,6 +540,7 @@ int fd_commit_weights(fd_handle h)
     w.lvc_f16_ok = lvc_ok;
     w.dblock_f16_ok = dblock_ok;
     w.convt_f16_ok = convt_ok;
+    w.kpf_f16_ok = kpf_ok;
     {
         std::vector<int> perm(fd::KW);
         for (int layer = 0; layer < fd::LAYERS; ++layer)
@@ -606,6 +615,7 @@ hipError_t first_conv(const Launch &L, const StepIO &io, int B, int T)
 hipError_t dblock(const Launch &L, int d, int B, int T) { return L.ctx->fast[ST_DBLOCK] ? fast_dblock(L, d, B, T) : naive_dblock(L, d, B, T); }
 hipError_t kp_front(const Launch &L, const StepIO &io, int B, int T)
 {
+    L.ctx->h_image_ready = false;      // only the fp16-pipe front writes the GEMM's h image itself
     return L.ctx->fast[ST_KP_FRONT] ? fast_kp_front(L, io, B, T) : naive_kp_front(L, io, B, T);
 }
 hipError_t kp_gemm(const Launch &L, int B, int T) { return L.ctx->fast[ST_KP_GEMM] ? fast_kp_gemm(L, B, T) : naive_kp_gemm(L, B, T); }

@@ -76,6 +76,9 @@ struct DevWeights {
     bool lvc_f16_ok = false;                      // every LVC conv weight fits the fp16 range
     const float *kp_in_pack[fd::NBLK] = {};       // 80->64 k5: 2 mt x 50 s4
     const float *kp_res_pack[fd::NBLK][6] = {};   // 64->64 k3: 2 mt x 24 s4
+    const uint16_t *kp_in_h2[fd::NBLK] = {};      // the same as fp16 pieces: [2 mt][piece][25 kg][64 lane][8]
+    const uint16_t *kp_res_h2[fd::NBLK][6] = {};  //                          [2 mt][piece][12 kg][64 lane][8]
+    bool kpf_f16_ok = false;
     const float *gemm_pack[fd::NBLK] = {};        // kernel_conv+bias_conv as MFMA B operand: [776 ptile][24 s4][64][4]
     const float *gemm_bias[fd::NBLK] = {};        // [24832] conv biases in packed order
     const uint16_t *gemm_h2_pack[fd::NBLK] = {};  // same weights as two fp16 pieces (w1, (w-w1)*2^11): [776 ptile][2][12 kg][64 lane][8]
@@ -111,7 +114,7 @@ struct Workspace {
     float *kpack = nullptr;     // [3][B][T][KREC]
     float *h_f16 = nullptr;     // fp16 piece image of the predictor hidden state: [3][B][64*ceil(T/64)+2 rows][2 pieces][64] x 2 B
     int *range_flag = nullptr;  // [0] predictor GEMM, [1 + 4*block + layer] LVC layers, [13 + d] DBlocks,
-                                // [16 + n] ConvTranspose of block n: an operand did not fit fp16; 32 words, zeroed every step
+                                // [16 + n] ConvTranspose of block n, [19] predictor front: an operand did not fit fp16; 32 words, zeroed every step
     float *xA = nullptr, *xB = nullptr;                           // [B][32][L] ping-pong
     float *xtap[fd::NBLK] = {}; // block outputs kept for fd_read_tap
     float *mel = nullptr;       // [B][80][T] library-owned copy used by the sampler graph
@@ -135,7 +138,8 @@ struct fd_context {
     bool keep_taps = false;
     bool gemm_f16 = true;                     // kp_gemm on the fp16 matrix pipe with the 2-piece operand split
     bool lvc_f16 = true;                      // LVC layers (hop 64, 256) likewise
-    bool conv_f16 = true;                     // DBlocks and ConvTranspose upsamplers likewise
+    bool conv_f16 = true;                     // DBlocks, ConvTranspose upsamplers and the predictor front likewise
+    bool h_image_ready = false;               // set by fast_kp_front when it wrote the GEMM's fp16 image of h for this step
     std::map<std::string, std::pair<std::vector<int64_t>, std::vector<float>>> raw;   // host copies from fd_set_weight
     std::vector<void *> dev_allocs;          // weight arena pieces
     DevWeights w;

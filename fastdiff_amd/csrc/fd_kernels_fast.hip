@@ -364,9 +364,10 @@ struct KpFrontW {
 
 __global__ void __launch_bounds__(256, 2) k_kp_front(const float *__restrict__ mel, float *__restrict__ hout, KpFrontW w,
                                                      const float *__restrict__ noise, const StepParams *params, int sampler,
-                                                     int B, int T)
+                                                     int B, int T, const int *__restrict__ run_if)
 {
     __shared__ float xin[fd::COND * KPF_LDI];     // mel + noise, columns <-> frames t0-10 .. t0+57
+    if (run_if && *run_if == 0) return;           // fallback launch behind k_kp_front_h2
     __shared__ float h0[fd::HID * KPF_LDH];       // input-conv output (kept for the skip add), column c at index c+1
     __shared__ float hA[fd::HID * KPF_LDH];
     __shared__ float hB[fd::HID * KPF_LDH];
@@ -447,6 +448,170 @@ __global__ void __launch_bounds__(256, 2) k_kp_front(const float *__restrict__ m
             }
         }
     }
+}
+
+// The same seven layers on the fp16 matrix pipe with 2-piece operands: 291 MFMAs of 32 cycles per
+// wave instead of 776 of 64.  Images: mel + noise as [column][piece][80 ch] fp16, 336 B per column (320 + 16: a row stride of
+// 84 dwords = 4 x odd spreads the 16-lane groups of ds_read_b128 over all banks without a swizzle); activations as
+// [column + 1][piece][64 ch], 256 B per column, slots swizzled by row & 15 -- the layout of the GEMM's h image, which the last
+// layer writes directly (k_h_split is not needed behind this kernel) next to the fp32 h the fallback kernels and the taps read.
+constexpr int KPF_XROW = 336;
+
+struct KpFrontW2 {
+    const float4 *in_pack[fd::NBLK];
+    const float *in_b[fd::NBLK];
+    const float4 *res_pack[fd::NBLK][6];
+    const float *res_b[fd::NBLK][6];
+};
+
+__device__ __forceinline__ int kpf_off(int row, int slot) { return row * 256 + ((slot ^ (row & 15)) << 4); }
+
+__global__ void __launch_bounds__(256, 2) k_kp_front_h2(const float *__restrict__ mel, float *__restrict__ hout, char *__restrict__ himg,
+                                                        KpFrontW2 w, const float *__restrict__ noise, const StepParams *params, int sampler,
+                                                        int B, int T, int R, int *__restrict__ range_flags)
+{
+    __shared__ __attribute__((aligned(16))) char xin[68 * KPF_XROW];      // columns <-> frames t0-10 .. t0+57
+    __shared__ __attribute__((aligned(16))) char hA[66 * 256];            // column c at row c+1; rows 0 and 65 stay zero
+    __shared__ __attribute__((aligned(16))) char hB[66 * 256];
+    const int blk = blockIdx.z, b = blockIdx.y, t0 = blockIdx.x * KPF_VALID;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int mt = wave & 1, nt = wave >> 1;
+    const int step = sampler ? params->step_idx : 0;
+    const float *nz = noise + (((int64_t)step * B + b) * fd::NBLK + blk) * fd::COND;
+    float mx = 0.0f;
+    {   // stage mel + noise: thread = (8-channel group of 10, column of 68) = 680 units; padding stays zero (modules.py:203)
+        const float *src = mel + (int64_t)b * fd::COND * T;
+        float v[3][8];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int u = k * 256 + tid, cg = u / 68, cc = u - cg * 68, t = t0 - 10 + cc;
+            const bool ok = u < 680 && t >= 0 && t < T;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[k][c] = ok ? src[(int64_t)(cg * 8 + c) * T + t] + nz[cg * 8 + c] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int u = k * 256 + tid, cg = u / 68, cc = u - cg * 68;
+            if (u < 680) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) mx = fmaxf(mx, fabsf(v[k][c]));
+                float4 ph, pl;
+                split8(v[k], ph, pl);
+                *reinterpret_cast<float4 *>(xin + cc * KPF_XROW + cg * 16) = ph;
+                *reinterpret_cast<float4 *>(xin + cc * KPF_XROW + 160 + cg * 16) = pl;
+            }
+        }
+        if (tid < 64) {         // guard rows 0 and 65 of both activation images
+            const int row = (tid & 32) ? 65 : 0, part = tid & 15;
+            char *img = (tid & 16) ? hB : hA;
+            *reinterpret_cast<float4 *>(img + row * 256 + part * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    const int c = nt * 32 + l31;                 // this lane's column; frame t0 - 8 + c
+    const int t = t0 - 8 + c;
+    const bool inside = (t >= 0 && t < T);
+    float h0v[16];                               // this lane's layer-0 outputs (fp32) for the skip add of the last layer
+    // write leaky_relu(hi + 2^-11 lo) (0 outside the utterance) as pieces of column c: D rows 32*mt + 8j + 4hi + {0..3}
+    auto store_act = [&](char *img, const f32x16 &ah, const f32x16 &al, float *keep) {
+        const int row = c + 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = inside ? lrelu(fmaf(al[4 * j + i], GX_INV_SCALE, ah[4 * j + i]), 0.1f) : 0.0f;
+                mx = fmaxf(mx, fabsf(v[i]));
+                if (keep) keep[4 * j + i] = v[i];
+            }
+            uint2 ph, pl;
+            split2(v[0], v[1], ph.x, pl.x);
+            split2(v[2], v[3], ph.y, pl.y);
+            *reinterpret_cast<uint2 *>(img + kpf_off(row, mt * 4 + j) + 8 * hi) = ph;
+            *reinterpret_cast<uint2 *>(img + kpf_off(row, 8 + mt * 4 + j) + 8 * hi) = pl;
+        }
+    };
+    // ---- layer 0: Conv1d(80,64,k5,pad2) + lrelu 0.1; k = 16*kg + 8*hi + e = tap*80 + ci, weights streamed from L2 --------------
+    {
+        const float4 *pa = w.in_pack[blk] + (int64_t)mt * 2 * 25 * 64 + lane;
+        f32x16 ah, al;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ah[r] = w.in_b[blk][mt * 32 + drow(r, hi)]; al[r] = 0.0f; }
+        const char *xb = xin + c * KPF_XROW + hi * 16;
+#pragma unroll 5
+        for (int kg = 0; kg < 25; ++kg) {
+            const float4 w1 = pa[kg * 64], w2 = pa[(25 + kg) * 64];
+            const int tap = (16 * kg) / fd::COND, o = ((16 * kg) % fd::COND) / 8;      // frame t + tap - 2 -> column c + tap
+            const float4 b1 = *reinterpret_cast<const float4 *>(xb + tap * KPF_XROW + o * 16);
+            const float4 b2 = *reinterpret_cast<const float4 *>(xb + tap * KPF_XROW + 160 + o * 16);
+            ah = mfma_f16(w1, b1, ah);
+            al = mfma_f16(w1, b2, al);
+            al = mfma_f16(w2, b1, al);
+        }
+        store_act(hA, ah, al, h0v);
+    }
+    __syncthreads();
+    // ---- six Conv1d(64,64,k3,pad1) + lrelu 0.1; the last one adds the layer-0 output and goes to HBM ------------------------
+    int off[3][2][4];
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) off[tap][p][k4] = kpf_off(c + tap, p * 8 + k4 * 2 + hi);      // column c + tap - 1 at row c + tap
+#pragma unroll 1
+    for (int l = 0; l < 6; ++l) {
+        const char *src = (l & 1) ? hB : hA;
+        char *dst = (l & 1) ? hA : hB;
+        const float4 *pa = w.res_pack[blk][l] + (int64_t)mt * 2 * 12 * 64 + lane;
+        float4 wa[2][12];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int kg = 0; kg < 12; ++kg) wa[p][kg] = pa[(p * 12 + kg) * 64];
+        f32x16 ah, al;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ah[r] = w.res_b[blk][l][mt * 32 + drow(r, hi)]; al[r] = 0.0f; }
+#pragma unroll
+        for (int kg = 0; kg < 12; ++kg) {           // k = 16*kg + 8*hi + e = tap*64 + ci
+            const float4 b1 = *reinterpret_cast<const float4 *>(src + off[kg >> 2][0][kg & 3]);
+            const float4 b2 = *reinterpret_cast<const float4 *>(src + off[kg >> 2][1][kg & 3]);
+            ah = mfma_f16(wa[0][kg], b1, ah);
+            al = mfma_f16(wa[0][kg], b2, al);
+            al = mfma_f16(wa[1][kg], b1, al);
+        }
+        if (l < 5) {
+            store_act(dst, ah, al, nullptr);
+            __syncthreads();
+        } else if (inside && c >= 8 && c < 8 + KPF_VALID) {
+            char *irow = himg + (((int64_t)blk * B + b) * R + (t + 1)) * 256;       // the GEMM's image: row = frame + 1
+            const int sw = (t + 1) & 15;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * j + i;
+                    v[i] = lrelu(fmaf(al[r], GX_INV_SCALE, ah[r]), 0.1f) + h0v[r];
+                    mx = fmaxf(mx, fabsf(v[i]));
+                    hout[(((int64_t)blk * B + b) * fd::HID + mt * 32 + drow(r, hi)) * T + t] = v[i];
+                }
+                uint2 ph, pl;
+                split2(v[0], v[1], ph.x, pl.x);
+                split2(v[2], v[3], ph.y, pl.y);
+                *reinterpret_cast<uint2 *>(irow + (((mt * 4 + j) ^ sw) << 4) + 8 * hi) = ph;
+                *reinterpret_cast<uint2 *>(irow + (((8 + mt * 4 + j) ^ sw) << 4) + 8 * hi) = pl;
+            }
+        }
+    }
+    // the image's padding rows (0 and T+1 .. R-1) must read as zeros: first and last tile of the utterance write them
+    {
+        char *ib = himg + ((int64_t)blk * B + b) * R * 256;
+        if (blockIdx.x == 0 && tid < 16) *reinterpret_cast<float4 *>(ib + tid * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (blockIdx.x == gridDim.x - 1)
+            for (int e = tid; e < (R - 1 - T) * 16; e += 256) *reinterpret_cast<float4 *>(ib + (T + 1) * 256 + e * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (!(mx < GX_LIMIT)) { atomicOr(range_flags + 19, 1); atomicOr(range_flags, 1); }      // [19] this kernel, [0] the GEMM behind it
 }
 
 // =================================================================================================
@@ -1677,14 +1842,29 @@ hipError_t fast_kp_front(const Launch &L, const StepIO &io, int B, int T)
 {
     fd_context *c = L.ctx;
     const DevWeights &w = c->w;
+    const dim3 grid((T + KPF_VALID - 1) / KPF_VALID, B, fd::NBLK);
+    const int *run_if = nullptr;
+    const char *name = "kp_front";
+    c->h_image_ready = false;
+    if (c->conv_f16 && w.kpf_f16_ok) {
+        KpFrontW2 k2;
+        for (int n = 0; n < fd::NBLK; ++n) {
+            k2.in_pack[n] = reinterpret_cast<const float4 *>(w.kp_in_h2[n]); k2.in_b[n] = w.blk[n].kp_in.b;
+            for (int l = 0; l < 6; ++l) { k2.res_pack[n][l] = reinterpret_cast<const float4 *>(w.kp_res_h2[n][l]); k2.res_b[n][l] = w.blk[n].kp_res[l].b; }
+        }
+        FD_LAUNCH(L, name, k_kp_front_h2, grid, dim3(256), 0, io.mel, c->ws.kp_hB, reinterpret_cast<char *>(c->ws.h_f16), k2,
+                  (const float *)c->ws.noise, (const StepParams *)c->ws.params, io.sampler, B, T, gx_rows(T), c->ws.range_flag);
+        c->h_image_ready = true;      // the GEMM's fp16 image of h is written (k_h_split not needed)
+        run_if = c->ws.range_flag + 19;
+        name = "kp_front_fp32_fallback";
+    }
     KpFrontW kw;
     for (int n = 0; n < fd::NBLK; ++n) {
         kw.in_pack[n] = w.kp_in_pack[n]; kw.in_b[n] = w.blk[n].kp_in.b;
         for (int l = 0; l < 6; ++l) { kw.res_pack[n][l] = w.kp_res_pack[n][l]; kw.res_b[n][l] = w.blk[n].kp_res[l].b; }
     }
-    const dim3 grid((T + KPF_VALID - 1) / KPF_VALID, B, fd::NBLK);
-    FD_LAUNCH(L, "kp_front", k_kp_front, grid, dim3(256), 0, io.mel, c->ws.kp_hB, kw, (const float *)c->ws.noise,
-              (const StepParams *)c->ws.params, io.sampler, B, T);
+    FD_LAUNCH(L, name, k_kp_front, grid, dim3(256), 0, io.mel, c->ws.kp_hB, kw, (const float *)c->ws.noise,
+              (const StepParams *)c->ws.params, io.sampler, B, T, run_if);
     return hipSuccess;
 }
 
@@ -1702,8 +1882,9 @@ hipError_t fast_kp_gemm(const Launch &L, int B, int T)
         const int R = gx_rows(T);
         const int chunks = (T + GX_CT * 32 - 1) / (GX_CT * 32), items = fd::NBLK * (fd::KREC / 128) * B * chunks;
         const int grid2 = items < 2 * c->num_cus ? items : 2 * c->num_cus;
-        FD_LAUNCH(L, "h_split", k_h_split, dim3((32 * R + 255) / 256, fd::NBLK * B), dim3(256), 0, (const float *)c->ws.kp_hB,
-                  reinterpret_cast<unsigned *>(c->ws.h_f16), c->ws.range_flag, B, T, R);
+        if (!c->h_image_ready)      // the fp16-pipe predictor front writes the image itself
+            FD_LAUNCH(L, "h_split", k_h_split, dim3((32 * R + 255) / 256, fd::NBLK * B), dim3(256), 0, (const float *)c->ws.kp_hB,
+                      reinterpret_cast<unsigned *>(c->ws.h_f16), c->ws.range_flag, B, T, R);
         FD_LAUNCH(L, "kp_gemm_f16x2", k_kp_gemm_h2, dim3(grid2), dim3(256), 0, reinterpret_cast<const char *>(c->ws.h_f16), c->ws.kpack,
                   reinterpret_cast<const float4 *>(w.gemm_h2_pack[0]), reinterpret_cast<const float4 *>(w.gemm_h2_pack[1]),
                   reinterpret_cast<const float4 *>(w.gemm_h2_pack[2]), w.gemm_bias[0], w.gemm_bias[1], w.gemm_bias[2],
