@@ -1502,7 +1502,12 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
     __shared__ __attribute__((aligned(16))) char ys[YC * 128];       // first the raw x + skip of the centre (fp32 [32][256]), then
     static_assert(YC * 128 >= fd::C * W * 4, "parking area");        // the conv output pieces, row = column + 1
     const int Ln = T * HOP;
-    const int b = blockIdx.y, w0 = blockIdx.x * W;
+    // workgroups go to the 8 XCDs round-robin (grid.x is a multiple of 8): give every XCD a contiguous run of tiles, so that the
+    // halo columns a tile shares with its neighbours are found in that XCD's L2 instead of being fetched from HBM twice
+    const int ntile = (T * HOP + W - 1) / W, per_xcd = (int)gridDim.x >> 3;
+    const int tile = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (tile >= ntile) return;
+    const int b = blockIdx.y, w0 = tile * W;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int cw = wave * WC;
     const bool wave_valid = (w0 + cw) < Ln;
@@ -1934,7 +1939,7 @@ static hipError_t launch_lvc(const Launch &L, const char *name, int n, int layer
     if constexpr (HOP >= 64) {
         if (c->lvc_f16 && w.lvc_f16_ok) {
             int *flag = c->ws.range_flag + 1 + n * fd::LAYERS + layer;
-            FD_LAUNCH(L, name, (k_lvc_h2<HOP, DIL>), dim3((Ln + 255) / 256, B), dim3(256), 0, x_in, skip, x_out, kp, layer,
+            FD_LAUNCH(L, name, (k_lvc_h2<HOP, DIL>), dim3(((Ln + 255) / 256 + 7) / 8 * 8, B), dim3(256), 0, x_in, skip, x_out, kp, layer,
                       reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]), w.blk[n].convs[layer].w, w.blk[n].convs[layer].b, flag, T);
             run_if = flag;
             name = "lvc_fp32_fallback";

@@ -28,7 +28,7 @@ int run(int B, int T, int reps)
         for (auto &v : w16) { s = s * 1664525u + 1013904223u; v = (unsigned short)(((s >> 16) & 0x8000u) | ((8u + ((s >> 8) % 6u)) << 10) | ((s >> 20) & 0x3FFu)); }
         CK(hipMemcpy(wpack, w16.data(), 6144 * 2, hipMemcpyHostToDevice));
     }
-    dim3 grid((Ln + 255) / 256, B);
+    dim3 grid(((Ln + 255) / 256 + 7) / 8 * 8, B);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((fdk_fast::k_lvc_h2<HOP, DIL>), grid, dim3(256), 0, 0, x, skip, out, kp, 1, (const float4 *)wpack, wref, cb, flag, T);
