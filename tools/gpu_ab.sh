@@ -1,0 +1,21 @@
+#!/bin/bash
+# A/B two builds of libfastdiff_hip.so inside ONE GPU session (box-to-box variation is +-4 %): tools/gpu_ab.sh A.so B.so [reps]
+set -u
+LIB=fastdiff_amd/lib/libfastdiff_hip.so
+cp $LIB /tmp/keep.so
+for i in $(seq 1 ${3:-3}); do
+  for v in $1 $2; do
+    cp $v $LIB
+    python bench.py --steps 10 --warmup 2 --no-cpu-baseline > /tmp/ab.log 2>&1
+    python - "$v" <<'PY'
+import json, sys
+for line in open('/tmp/ab.log'):
+    if line.startswith('{'):
+        d = json.loads(line)
+        k = d.get('kernels', {})
+        pick = {n: k[n]['avg_us'] for n in ('lvc_layer_h256', 'kp_gemm_f16x2', 'lvc_layer_h64', 'lvc_layer_h8', 'dblock_f4', 'kp_front', 'final_conv_update') if n in k}
+        print(f"{sys.argv[1]:28s} ms/step {d['ms_per_step']:.3f}  {pick}")
+PY
+  done
+done
+cp /tmp/keep.so $LIB
