@@ -1,0 +1,128 @@
+"""Test-time batching / collation / sharding glue: what `tasks/run.py --infer` does around the hot path.
+
+Reference behaviour restated (none of this is on the GPU path, so plain torch/numpy):
+  * `VocoderDataset.load_mel_inputs` (tasks/vocoder/dataset_utils.py:186-204): every `*.npy` under `test_input_dir`, sorted,
+    holds a mel of shape [T, 80]; item_name = path below the directory with "/" replaced by "_".
+  * `VocoderDataset.collater` at test time (dataset_utils.py:100-160, `batch_max_frames = 0`): the random crop degenerates to
+    frames [0, T-1) -- the LAST FRAME IS DROPPED (:116-125, interval_end = 1 so start_frame = 0); mels are zero-padded to the
+    longest item of the batch (`collate_2d`, utils/__init__.py:136-150) and transposed to [B, 80, T'].
+  * `DistributedSampler(shuffle=False)` (tasks/vocoder/vocoder_base.py:43-49): the index list is padded by wrap-around to a
+    multiple of the world size and rank r takes r::world; every rank writes its own wavs, no collective.
+  * `test_step` (modules/FastDiff/task/FastDiff.py:96-118): one `sampling_given_noise_schedule` call per batch, then per
+    item `wav / wav.abs().max()` and `save_wav` = *32767 -> int16 (utils/audio.py:11-16) as `<item_name>_pred.wav`.
+    The reference CLI runs B = 1 (config `max_sentences`); batching is this path's extension: a padded batch gives the padded
+    tensor's result (exactly what the reference computes for a collate_2d batch), cropped back to each item's own length.
+
+Entry points: load_mel_inputs, collate_test_batch, distributed_sampler_indices, synthesize, save_wavs and a small CLI
+(`python -m fastdiff_amd.infer --test_input_dir D --out_dir O [--N 4] [--ckpt model.ckpt]`).
+"""
+import argparse
+import glob
+import os
+from typing import Dict, List, Sequence
+
+import numpy as np
+import torch
+
+from . import schedules, shard
+from .sampler import compute_hyperparams_given_schedule, sampling_given_noise_schedule
+
+
+def load_mel_inputs(test_input_dir: str) -> List[dict]:
+    """[{item_name, mel: FloatTensor [T,80], len}] for every *.npy below the directory, in sorted path order."""
+    items = []
+    for path in sorted(glob.glob(f"{test_input_dir}/*.npy")):
+        mel = torch.FloatTensor(np.load(path))
+        if mel.dim() != 2:
+            raise ValueError(f"{path}: expected a [T, n_mels] array, got shape {tuple(mel.shape)}")
+        # the reference keeps the ".npy" suffix in the name (dataset_utils.py:200), so outputs are "<file>.npy_pred.wav"
+        items.append({"item_name": path[len(test_input_dir) + 1:].replace("/", "_"), "mel": mel, "len": mel.shape[0]})
+    return items
+
+
+def collate_test_batch(items: Sequence[dict], drop_last_frame: bool = True):
+    """mels [B, 80, T'] zero-padded, lens [B] (frames kept per item), item_names -- the test-time collater."""
+    mels, lens, names = [], [], []
+    for it in items:
+        c = it["mel"]
+        if drop_last_frame:
+            if c.shape[0] < 2:
+                continue                      # the reference prints "Removed short sample from batch" and skips it
+            c = c[: c.shape[0] - 1]
+        mels.append(c.transpose(0, 1).contiguous())       # [80, T']
+        lens.append(c.shape[0])
+        names.append(it["item_name"])
+    if not mels:
+        return None, [], []
+    return shard.pad_mels(mels), lens, names
+
+
+def distributed_sampler_indices(n_items: int, rank: int, world_size: int) -> List[int]:
+    """Indices torch's DistributedSampler(shuffle=False, drop_last=False) hands to `rank`."""
+    if n_items == 0:
+        return []
+    total = -(-n_items // world_size) * world_size
+    idx = list(range(n_items))
+    while len(idx) < total:                   # padded by repeating from the start (possibly several times)
+        idx += idx[: total - len(idx)]
+    return idx[rank:total:world_size]
+
+
+def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 8, seed: int = 0, drop_last_frame: bool = True,
+               noise_schedule=None, diffusion_hyperparams=None) -> Dict[str, np.ndarray]:
+    """item_name -> int16 PCM of its own length (hop 256 x frames), through length-sorted padded micro-batches."""
+    if diffusion_hyperparams is None:
+        diffusion_hyperparams = schedules.training_hyperparams()
+    if noise_schedule is None:
+        noise_schedule = schedules.noise_schedule_for(n_steps)
+    lengths = [it["len"] for it in items]
+    out: Dict[str, np.ndarray] = {}
+    for k, batch_idx in enumerate(shard.micro_batches(range(len(items)), lengths, max_batch)):
+        mels, lens, names = collate_test_batch([items[i] for i in batch_idx], drop_last_frame)
+        if mels is None:
+            continue
+        mels = mels.cuda()
+        B, _, T = mels.shape
+        wav = sampling_given_noise_schedule(model, (B, 1, T * model.hop_length), diffusion_hyperparams, noise_schedule,
+                                            condition=mels, ddim=False, return_sequence=False, seed=seed + k, verbose=False)
+        for b, (name, t) in enumerate(zip(names, lens)):
+            own = wav[b:b + 1, :, : t * model.hop_length]                      # crop the padding before the peak search
+            out[name] = model.peak_normalize_int16(own)[0].cpu().numpy()
+    return out
+
+
+def save_wavs(pcm: Dict[str, np.ndarray], out_dir: str, sample_rate: int = 22050) -> List[str]:
+    from scipy.io import wavfile
+    os.makedirs(out_dir, exist_ok=True)
+    paths = []
+    for name, data in pcm.items():
+        path = os.path.join(out_dir, f"{name}_pred.wav")
+        wavfile.write(path, sample_rate, data)
+        paths.append(path)
+    return paths
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--test_input_dir", required=True)
+    ap.add_argument("--out_dir", required=True)
+    ap.add_argument("--N", type=int, default=4, help="reverse steps: 3, 4, 6, 8, 200 or 1000 (FastDiff.py:76-93)")
+    ap.add_argument("--ckpt", default=None, help="reference checkpoint (state_dict under ['state_dict']['model'])")
+    ap.add_argument("--max_batch", type=int, default=8)
+    ap.add_argument("--seed", type=int, default=1234)
+    args = ap.parse_args(argv)
+    from . import FastDiff
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    torch.manual_seed(args.seed)
+    model = FastDiff().cuda().eval()
+    if args.ckpt:
+        model.load_state_dict(torch.load(args.ckpt, map_location="cpu")["state_dict"]["model"], strict=True)
+    items = load_mel_inputs(args.test_input_dir)
+    mine = [items[i] for i in sorted(set(distributed_sampler_indices(len(items), rank, world)))]
+    paths = save_wavs(synthesize(model, mine, args.N, args.max_batch, args.seed + rank), args.out_dir)
+    print(f"rank {rank}/{world}: wrote {len(paths)} files to {args.out_dir}")
+
+
+if __name__ == "__main__":
+    main()

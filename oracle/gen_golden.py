@@ -264,6 +264,23 @@ def gen_sample(dh):
         print(name, "max|y|", float(np.abs(out[key]).max()), "f32-vs-f64", float(np.abs(out[key] - out[k64]).max()) if k64 in out else None)
 
 
+def gen_collate():
+    """collate_2d (utils/__init__.py:136-150) cannot be imported (the package needs chardet): its definition is cut out of the
+    reference file with ast and executed as is."""
+    import ast
+    src = open(os.path.join(REF, "utils", "__init__.py")).read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "collate_2d")
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "collate_2d", "exec"), ns)
+    g = torch.Generator().manual_seed(77)
+    lens = [5, 9, 3, 9, 1]
+    mels = [torch.rand(t, 80, generator=g) * 13.5 - 11.5 for t in lens]          # Tacotron-range mels, [T, 80] as on disk
+    out = ns["collate_2d"](mels, 0).transpose(2, 1)                              # what the collater hands to the model
+    arrays = {f"mel{i}": m.numpy() for i, m in enumerate(mels)}
+    np.savez_compressed(os.path.join(GOLD, "collate.npz"), batch=out.contiguous().numpy(), lens=np.array(lens), **arrays)
+    print("collate", tuple(out.shape))
+
+
 def gen_statedict_manifest():
     """Key set + shapes of the reference module's state_dict, and a default-init digest, for the drop-in shim test."""
     torch.manual_seed(SEED)
@@ -279,7 +296,7 @@ def gen_statedict_manifest():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["schedule", "embed", "ops", "forward", "sample", "manifest"]
+    which = sys.argv[1:] or ["schedule", "embed", "ops", "forward", "sample", "manifest", "collate"]
     dh = gen_schedule()
     if "embed" in which:
         gen_embed()
@@ -291,4 +308,6 @@ if __name__ == "__main__":
         gen_sample(dh)
     if "manifest" in which:
         gen_statedict_manifest()
+    if "collate" in which:
+        gen_collate()
     print("golden fixtures written to", GOLD)

@@ -1,0 +1,94 @@
+"""Test-time collation / sharding glue: CPU checks against torch's DistributedSampler and a golden batch
+produced by the reference's own collate_2d (oracle/gen_golden.py: gen_collate); one GPU run through the whole driver."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from fastdiff_amd import infer, shard
+
+
+def test_distributed_sampler_indices_match_torch():
+    from torch.utils.data.distributed import DistributedSampler
+    for n in (1, 2, 3, 7, 8, 9, 17, 64):
+        data = list(range(n))
+        for world in (1, 2, 3, 4, 8):
+            seen = []
+            for rank in range(world):
+                ref = list(DistributedSampler(data, num_replicas=world, rank=rank, shuffle=False))
+                got = infer.distributed_sampler_indices(n, rank, world)
+                assert got == ref, (n, world, rank)
+                seen += got
+            assert set(seen) == set(range(n))                       # every utterance is synthesised by someone
+    assert infer.distributed_sampler_indices(0, 0, 4) == []
+
+
+def test_collate_matches_the_references_collate_2d():
+    g = load_golden("collate")
+    lens = g["lens"].tolist()
+    items = [{"item_name": f"u{i}.npy", "mel": torch.from_numpy(g[f"mel{i}"]), "len": t} for i, t in enumerate(lens)]
+    mels, kept, names = infer.collate_test_batch(items, drop_last_frame=False)
+    assert torch.equal(mels, torch.from_numpy(g["batch"])) and kept == lens and names == [it["item_name"] for it in items]
+    # test time: the collater drops the last frame of every item (dataset_utils.py:116-125) and skips one-frame items
+    mels, kept, names = infer.collate_test_batch(items, drop_last_frame=True)
+    assert kept == [4, 8, 2, 8] and names == ["u0.npy", "u1.npy", "u2.npy", "u3.npy"]
+    assert mels.shape == (4, 80, 8)
+    for b, t in enumerate(kept):
+        assert torch.equal(mels[b, :, :t], torch.from_numpy(g[f"mel{b}"])[:t].T)
+        assert not mels[b, :, t:].any()
+
+
+def test_load_mel_inputs_order_names_and_shapes(tmp_path):
+    rng = np.random.default_rng(0)
+    for name, t in (("b_second", 7), ("a_first", 5), ("c.third", 3)):
+        np.save(tmp_path / f"{name}.npy", rng.standard_normal((t, 80)).astype(np.float32))
+    np.save(tmp_path / "ignored.txt.npy.bak", np.zeros(3))                # not *.npy
+    os.rename(tmp_path / "ignored.txt.npy.bak.npy", tmp_path / "ignored.bak")
+    items = infer.load_mel_inputs(str(tmp_path))
+    assert [it["item_name"] for it in items] == ["a_first.npy", "b_second.npy", "c.third.npy"]      # sorted; suffix kept as in the reference
+    assert [it["len"] for it in items] == [5, 7, 3] and all(it["mel"].shape[1] == 80 for it in items)
+    np.save(tmp_path / "bad.npy", np.zeros(4, np.float32))
+    with pytest.raises(ValueError, match="expected a"):
+        infer.load_mel_inputs(str(tmp_path))
+
+
+def test_micro_batches_cover_every_item_once():
+    lens = [5, 9, 3, 9, 1, 4, 4]
+    batches = shard.micro_batches(range(len(lens)), lens, 3)
+    assert sorted(i for b in batches for i in b) == list(range(len(lens))) and all(len(b) <= 3 for b in batches)
+    assert [lens[i] for i in batches[0]] == [9, 9, 5]                      # longest first: padding waste stays small
+
+
+@pytest.mark.gpu
+def test_synthesize_directory_end_to_end(tmp_path):
+    """Three Tacotron-range mels on disk -> padded micro-batches -> int16 wavs named like the reference's outputs; every
+    utterance equals the crop of the padded-batch result (what the reference computes for a collate_2d batch)."""
+    import fastdiff_amd
+    from fastdiff_amd import schedules
+    from fastdiff_amd.sampler import sampling_given_noise_schedule
+    from scipy.io import wavfile
+    rng = np.random.default_rng(3)
+    src = tmp_path / "mels"
+    src.mkdir()
+    for name, t in (("x", 6), ("y", 10), ("z", 8)):
+        np.save(src / f"{name}.npy", (rng.random((t, 80)) * 13.5 - 11.5).astype(np.float32))
+    torch.manual_seed(1234)
+    model = fastdiff_amd.FastDiff().cuda().eval()
+    items = infer.load_mel_inputs(str(src))
+    pcm = infer.synthesize(model, items, n_steps=4, max_batch=2, seed=11)
+    assert {k: v.shape for k, v in pcm.items()} == {"x.npy": (5 * 256,), "y.npy": (9 * 256,), "z.npy": (7 * 256,)}
+    assert all(v.dtype == np.int16 and np.abs(v).max() == 32767 for v in pcm.values())
+    # the first micro-batch is (y, z): redo it by hand
+    mels, lens, names = infer.collate_test_batch([items[1], items[2]])
+    wav = sampling_given_noise_schedule(model, (2, 1, mels.shape[-1] * 256), schedules.training_hyperparams(),
+                                        schedules.noise_schedule_for(4), condition=mels.cuda(), seed=11, verbose=False)
+    for b, (name, t) in enumerate(zip(names, lens)):
+        own = wav[b, 0, : t * 256]
+        ref = (own / own.abs().max() * 32767).cpu().numpy().astype(np.int16)
+        assert np.array_equal(pcm[name], ref), name
+    paths = infer.save_wavs(pcm, str(tmp_path / "out"))
+    assert sorted(os.path.basename(p) for p in paths) == ["x.npy_pred.wav", "y.npy_pred.wav", "z.npy_pred.wav"]
+    sr, data = wavfile.read(paths[0])
+    assert sr == 22050 and np.array_equal(data, pcm[os.path.basename(paths[0])[:-9]])
