@@ -71,16 +71,16 @@ def family(name):
     return name
 
 
-def measure_roofline(model, mel, rows, B, T, nsteps):
+def measure_roofline(model, mel, rows, B, T, nsteps, lens=None):
     """Eager (graph off) profiled pass: per-kernel HIP-event timing on the launch stream."""
     model.set_option("profile", "1")
     try:
         with torch.no_grad():
-            model.sample(mel, rows, seed=1)
+            model.sample(mel, rows, seed=1, lens=lens)
             torch.cuda.synchronize()
             model.profile(reset=True)
             for _ in range(2):
-                model.sample(mel, rows, seed=1)
+                model.sample(mel, rows, seed=1, lens=lens)
             torch.cuda.synchronize()
         stats = model.profile(reset=True)
     finally:
@@ -160,6 +160,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--ragged", action="store_true",
+                    help="BASELINE config 4 style batch: T_i ~ U{200..frames}, zero-padded; RTF counts the valid audio only")
+    ap.add_argument("--no-lens", action="store_true", help="with --ragged: do not tell the library the lengths (padded compute)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -183,6 +186,13 @@ def main():
         model.set_option("graph", "0")
     torch.manual_seed(1234 + rank)
     mel = (torch.rand(B, 80, T) * 7.5 - 6.0).to(dev)    # uniform on [mel_vmin, mel_vmax]
+    lens = None
+    valid_frames = B * T
+    if args.ragged:
+        lens = torch.randint(200, T + 1, (B,)).tolist() if T > 200 else [T] * B
+        for b, t in enumerate(lens):
+            mel[b, :, t:] = 0.0                          # collate_2d padding
+        valid_frames = sum(lens)
     dh = schedules.training_hyperparams()
     rows = sampler.InferenceSchedule(dh, schedules.noise_schedule_for(N), verbose=False).rows()
 
@@ -192,24 +202,24 @@ def main():
 
     with torch.no_grad():
         for i in range(args.warmup):
-            out = model.sample(mel, rows, seed=i)
+            out = model.sample(mel, rows, seed=i, lens=None if args.no_lens else lens)
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            out = model.sample(mel, rows, seed=100 + i)
+            out = model.sample(mel, rows, seed=100 + i, lens=None if args.no_lens else lens)
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-    assert torch.isfinite(out).all()
+    assert torch.isfinite(out if lens is None else torch.stack([out[b, :, : lens[b] * HOP].abs().max() for b in range(B)])).all()
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    audio_s = world * B * T * HOP / SR
+    audio_s = world * valid_frames * HOP / SR      # (ragged: rank 0's draw stands for every rank)
     line = {
         "metric": "real-time factor (audio-sec/wall-sec), N=%d reverse steps, 80x%d mel" % (N, T),
         "value": round(audio_s / (ms_per_step / 1e3), 2),
@@ -220,11 +230,12 @@ def main():
         "config": {"workload": "BASELINE configs[1]: LJSpeech FastDiff.yaml shape, batch=%d utterances of 80x%d mel, "
                                "N=%d, HIP LVC/dilated-conv kernels + hipGraph sampler" % (B, T, N),
                    "batch_per_gpu": B, "frames": T, "reverse_steps": N, "sharding": "utterances/rank, no collective",
-                   "graph": not args.no_graph, "weights": "random init seed 1234 (no checkpoint offline)"},
+                   "graph": not args.no_graph, "weights": "random init seed 1234 (no checkpoint offline)",
+                   "ragged": (None if not args.ragged else {"lens": lens, "told_to_library": not args.no_lens})},
     }
     if rank == 0 and world == 1:
         if not args.no_roofline:
-            roof, table = measure_roofline(model, mel, rows, B, T, N)
+            roof, table = measure_roofline(model, mel, rows, B, T, N, None if args.no_lens else lens)
             line["roofline"] = roof
             line["kernels"] = table
         if not args.no_cpu_baseline:

@@ -170,7 +170,7 @@ int fd_create(const fd_config *cfg, int device, fd_handle *out)
 static void free_workspace(fd_context *c)
 {
     Workspace &w = c->ws;
-    void *ptrs[] = {w.noise, w.a[0], w.a[1], w.a[2], w.a[3], w.kp_h0, w.kp_hA, w.kp_hB, w.kpack, w.h_f16, w.range_flag, w.xA, w.xB,
+    void *ptrs[] = {w.noise, w.a[0], w.a[1], w.a[2], w.a[3], w.kp_h0, w.kp_hA, w.kp_hB, w.kpack, w.h_f16, w.range_flag, w.lens_dev, w.xA, w.xB,
                     w.xtap[0], w.xtap[1], w.xtap[2], w.mel, w.x, w.steps, w.params};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -575,7 +575,10 @@ static int ensure_workspace(fd_context *h, int B, int T)
     size_t total = 0;
     auto alloc = [&](float **p, size_t n) -> hipError_t {
         total += n * f;
-        return hipMalloc(reinterpret_cast<void **>(p), n * f);
+        hipError_t e1 = hipMalloc(reinterpret_cast<void **>(p), n * f);
+        // zero once: with ragged batches (lens) tiles behind an utterance are never written, and nothing a later kernel
+        // stages next to them (range checks run over whole tiles) should meet NaN bit patterns of a fresh allocation
+        return e1 == hipSuccess ? hipMemset(*p, 0, n * f) : e1;
     };
     hipError_t e = hipSuccess;
 #define WS(p, n) if (e == hipSuccess) e = alloc(&(p), (n))
@@ -585,6 +588,7 @@ static int ensure_workspace(fd_context *h, int B, int T)
     WS(w.kp_hB, (size_t)fd::NBLK * nB * fd::HID * nT);
     WS(w.kpack, (size_t)fd::NBLK * nB * nT * fd::KREC);
     WS(w.h_f16, (size_t)fd::NBLK * nB * (((nT + 127) / 128) * 128 + 2) * 64 + 1024);  // rows = gx_rows(T), + slack for the rounded-up last DMA
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w.lens_dev), sizeof(int) * (size_t)std::max(nB, 64));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w.range_flag), 256);
     if (e == hipSuccess) e = hipMemset(w.range_flag, 0, 256);
     WS(w.xA, nB * fd::C * L); WS(w.xB, nB * fd::C * L);
@@ -690,15 +694,32 @@ static int check_common(fd_handle h, int B, int T, const char *who)
     return FD_OK;
 }
 
+// `lens` (host, nullable): valid frames per utterance of a zero-padded batch, uploaded for the kernels.
+static int set_lens(fd_handle h, const int *lens, int B, int T, hipStream_t stream, const char *who)
+{
+    h->step_lens = nullptr;
+    if (!lens) return FD_OK;
+    bool ragged = false;
+    for (int b = 0; b < B; ++b) {
+        if (lens[b] < 1 || lens[b] > T) FD_FAIL(h, FD_ERR_INVALID, "%s: lens[%d] = %d outside [1, T=%d]", who, b, lens[b], T);
+        ragged = ragged || lens[b] < T;
+    }
+    if (!ragged) return FD_OK;                       // every utterance fills the batch: same launches as without lens
+    h->lens_host.assign(lens, lens + B);             // staging copy that outlives the asynchronous upload
+    FD_HIP(h, hipMemcpyAsync(h->ws.lens_dev, h->lens_host.data(), sizeof(int) * B, hipMemcpyHostToDevice, stream));
+    h->step_lens = h->ws.lens_dev;
+    return FD_OK;
+}
+
 int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps, int B, int T, const int *lens,
                float *eps_out, void *stream)
 {
     int rc = check_common(h, B, T, "fd_forward");
     if (rc != FD_OK) return rc;
-    (void)lens;   // results are those of the padded tensor (see header)
     if (!x || !mel || !steps || !eps_out) FD_FAIL(h, FD_ERR_INVALID, "fd_forward: null pointer");
     if (x == eps_out) FD_FAIL(h, FD_ERR_INVALID, "fd_forward: eps_out must not alias x");
     if ((rc = ensure_workspace(h, B, T)) != FD_OK) return rc;
+    if ((rc = set_lens(h, lens, B, T, (hipStream_t)stream, "fd_forward")) != FD_OK) return rc;
     fdk::Launch L = {h, (hipStream_t)stream, false};
     StepIO io = {x, mel, steps, eps_out, 0};
     hipError_t e = fdk::embed(L, io, B, 1);
@@ -711,7 +732,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
 
 static unsigned mode_signature(const fd_context *h)
 {
-    unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_f16 ? 2u : 0u) | (h->lvc_f16 ? 4u : 0u) | (h->conv_f16 ? 8u : 0u);
+    unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_f16 ? 2u : 0u) | (h->lvc_f16 ? 4u : 0u) | (h->conv_f16 ? 8u : 0u) | (h->step_lens ? 16u : 0u);
     for (int i = 0; i < ST_COUNT; ++i) s = (s << 1) | (h->fast[i] ? 1u : 0u);
     return s;
 }
@@ -721,11 +742,11 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
 {
     int rc = check_common(h, B, T, "fd_sample");
     if (rc != FD_OK) return rc;
-    (void)lens;
     if (!mel || !table || !out) FD_FAIL(h, FD_ERR_INVALID, "fd_sample: null pointer");
     if (N <= 0 || N > 1024) FD_FAIL(h, FD_ERR_INVALID, "fd_sample: N=%d outside 1..1024", N);
     if ((rc = ensure_workspace(h, B, T)) != FD_OK) return rc;
     hipStream_t stream = (hipStream_t)stream_;
+    if ((rc = set_lens(h, lens, B, T, stream, "fd_sample")) != FD_OK) return rc;
     Workspace &ws = h->ws;
     const size_t n_el = (size_t)B * T * fd::HOPT;
 

@@ -113,6 +113,7 @@ struct Workspace {
     float *kp_h0 = nullptr, *kp_hA = nullptr, *kp_hB = nullptr;   // [3][B][64][T]
     float *kpack = nullptr;     // [3][B][T][KREC]
     float *h_f16 = nullptr;     // fp16 piece image of the predictor hidden state: [3][B][64*ceil(T/64)+2 rows][2 pieces][64] x 2 B
+    int *lens_dev = nullptr;    // [B] valid frames per utterance of the current call (ragged batches)
     int *range_flag = nullptr;  // [0] predictor GEMM, [1 + 4*block + layer] LVC layers, [13 + d] DBlocks,
                                 // [16 + n] ConvTranspose of block n, [19] predictor front: an operand did not fit fp16; 32 words, zeroed every step
     float *xA = nullptr, *xB = nullptr;                           // [B][32][L] ping-pong
@@ -139,6 +140,8 @@ struct fd_context {
     bool gemm_f16 = true;                     // kp_gemm on the fp16 matrix pipe with the 2-piece operand split
     bool lvc_f16 = true;                      // LVC layers (hop 64, 256) likewise
     bool conv_f16 = true;                     // DBlocks, ConvTranspose upsamplers and the predictor front likewise
+    const int *step_lens = nullptr;           // device copy of the caller's `lens` for this call (ragged batch), or null
+    std::vector<int> lens_host;               // staging copy for the asynchronous upload
     bool h_image_ready = false;               // set by fast_kp_front when it wrote the GEMM's fp16 image of h for this step
     std::map<std::string, std::pair<std::vector<int64_t>, std::vector<float>>> raw;   // host copies from fd_set_weight
     std::vector<void *> dev_allocs;          // weight arena pieces

@@ -40,6 +40,12 @@ __device__ __forceinline__ float lrelu(float v, float s)   // 0 < s < 1:  max(v,
 }
 __device__ __forceinline__ float f4c(const float4 &v, int r) { return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w)); }
 
+// Ragged batches: `lens` (nullable, device) holds the valid frames of every utterance of a zero-padded batch.  Every kernel
+// then treats utterance b as if it were lens[b] frames long: positions behind it read as the zero padding a convolution sees
+// at the end of a signal, tiles behind it are skipped.  Inside [0, lens[b]) the result is bit-identical to running the
+// utterance alone (tests/test_gpu_parity.py); what the output buffers hold behind it is unspecified.
+__device__ __forceinline__ int frames_of(const int *lens, int b, int T) { return lens ? lens[b] : T; }
+
 // ---- 2-piece fp16 operands: v = v1 + 2^-11 v2, v1 = fp16(v), v2 = fp16((v - v1) * 2^11) ----------------
 constexpr float GX_SCALE = 2048.0f, GX_INV_SCALE = 1.0f / 2048.0f;
 constexpr float GX_LIMIT = 32768.0f;            // magnitudes from here on do not fit: the kernels raise a range flag
@@ -81,17 +87,19 @@ __device__ __forceinline__ int h2_off(int row, int slot) { return row * 128 + ((
 // a3: first_audio_conv  Conv1d(1,32,k7,pad3)  (FastDiff_model.py:34-36,89)   -- VALU, HBM-write bound
 // =================================================================================================
 __global__ void __launch_bounds__(256) k_first_conv(const float *__restrict__ x, const float *__restrict__ w,
-                                                    const float *__restrict__ bias, float *__restrict__ a0, int L)
+                                                    const float *__restrict__ bias, float *__restrict__ a0, int L,
+                                                    const int *__restrict__ lens)
 {
     const int b = blockIdx.y;
     const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (t0 >= L) return;
+    const int Lb = lens ? lens[b] * fd::HOPT : L;          // this utterance's own length (ragged batch)
+    if (t0 >= Lb) return;
     const float *xr = x + (int64_t)b * L;
     float xv[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
         const int p = t0 - 3 + i;
-        xv[i] = (p >= 0 && p < L) ? xr[p] : 0.0f;
+        xv[i] = (p >= 0 && p < Lb) ? xr[p] : 0.0f;
     }
 #pragma unroll 4
     for (int o = 0; o < fd::C; ++o) {
@@ -136,7 +144,7 @@ __global__ void __launch_bounds__(256, 2) k_dblock(const float *__restrict__ xin
                                                    const float *__restrict__ p2, const float *__restrict__ pr,
                                                    const float *__restrict__ b0, const float *__restrict__ b1,
                                                    const float *__restrict__ b2, const float *__restrict__ br, int Lin, int Lo,
-                                                   const int *__restrict__ run_if)
+                                                   const int *__restrict__ run_if, const int *__restrict__ lens, int per_frame)
 {
     __shared__ __attribute__((aligned(16))) float xs[fd::C * DB_LD];
     if (run_if && *run_if == 0) return;      // fallback launch behind k_dblock_h2: only when that kernel flagged its operands
@@ -144,6 +152,8 @@ __global__ void __launch_bounds__(256, 2) k_dblock(const float *__restrict__ xin
     __shared__ __attribute__((aligned(16))) float hB[fd::C * DB_LD];
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int pbase = blockIdx.x * DB_STRIDE - 7;   // down-sampled position of tile column 0
+    const int Lob = lens ? lens[b] * per_frame : Lo;      // this utterance's own length at the output rate
+    if (blockIdx.x * DB_STRIDE >= Lob) return;
     // stage the strided pick x[..., ::F]; zero outside [0, Lo) and in the guard columns (loads batched ahead of the writes)
     {
         constexpr int NK = fd::C * DB_LD / 256;     // 17
@@ -151,7 +161,7 @@ __global__ void __launch_bounds__(256, 2) k_dblock(const float *__restrict__ xin
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int idx = k * 256 + tid, ci = idx / DB_LD, cc = idx - ci * DB_LD, p = pbase + cc - 4;
-            v[k] = (cc >= 4 && cc < 132 && p >= 0 && p < Lo) ? xin[((int64_t)b * fd::C + ci) * Lin + (int64_t)p * F] : 0.0f;
+            v[k] = (cc >= 4 && cc < 132 && p >= 0 && p < Lob) ? xin[((int64_t)b * fd::C + ci) * Lin + (int64_t)p * F] : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
@@ -164,7 +174,7 @@ __global__ void __launch_bounds__(256, 2) k_dblock(const float *__restrict__ xin
     __syncthreads();
     const int c = wave * 32 + l31;        // this lane's tile column
     const int p = pbase + c;              // its down-sampled position
-    const bool inside = (p >= 0 && p < Lo);
+    const bool inside = (p >= 0 && p < Lob);
     float4 wa[12];
     f32x16 acc;
     // layer 1: dil 1 on leaky_relu(xs)
@@ -255,13 +265,15 @@ __global__ void __launch_bounds__(256, 2) k_dblock_h2(const float *__restrict__ 
                                                       const float4 *__restrict__ p2, const float4 *__restrict__ pr,
                                                       const float *__restrict__ b0, const float *__restrict__ b1,
                                                       const float *__restrict__ b2, const float *__restrict__ br, int Lin, int Lo,
-                                                      int *__restrict__ range_flag)
+                                                      int *__restrict__ range_flag, const int *__restrict__ lens, int per_frame)
 {
     __shared__ __attribute__((aligned(16))) char xl[DBH_ROWS * 128];      // leaky_relu(x pick); later the layer-2 output
     __shared__ __attribute__((aligned(16))) char xr[DBH_ROWS * 128];      // raw x pick (1x1 residual)
     __shared__ __attribute__((aligned(16))) char ha[DBH_ROWS * 128];      // layer-1 output
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int pbase = blockIdx.x * DB_STRIDE - 7;   // down-sampled position of tile column 0
+    const int Lob = lens ? lens[b] * per_frame : Lo;      // this utterance's own length at the output rate
+    if (blockIdx.x * DB_STRIDE >= Lob) return;
     float mx = 0.0f;
     // ---- stage the strided pick x[..., ::F]: thread = (8-channel group, column), two columns per thread; zero outside [0, Lo)
     {
@@ -269,7 +281,7 @@ __global__ void __launch_bounds__(256, 2) k_dblock_h2(const float *__restrict__ 
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int u = k * 256 + tid, cg = u >> 7, cc = u & 127, p = pbase + cc;
-            const bool ok = p >= 0 && p < Lo;
+            const bool ok = p >= 0 && p < Lob;
 #pragma unroll
             for (int c = 0; c < 8; ++c) v[k][c] = ok ? xin[((int64_t)b * fd::C + cg * 8 + c) * Lin + (int64_t)p * F] : 0.0f;
         }
@@ -297,7 +309,7 @@ __global__ void __launch_bounds__(256, 2) k_dblock_h2(const float *__restrict__ 
     __syncthreads();
     const int c = wave * 32 + l31;        // this lane's tile column
     const int p = pbase + c;              // its down-sampled position
-    const bool inside = (p >= 0 && p < Lo);
+    const bool inside = (p >= 0 && p < Lob);
     float4 wa[2][6];
     f32x16 ah, al;
     auto load_w = [&](const float4 *pk) {
@@ -364,7 +376,7 @@ struct KpFrontW {
 
 __global__ void __launch_bounds__(256, 2) k_kp_front(const float *__restrict__ mel, float *__restrict__ hout, KpFrontW w,
                                                      const float *__restrict__ noise, const StepParams *params, int sampler,
-                                                     int B, int T, const int *__restrict__ run_if)
+                                                     int B, int T, const int *__restrict__ run_if, const int *__restrict__ lens)
 {
     __shared__ float xin[fd::COND * KPF_LDI];     // mel + noise, columns <-> frames t0-10 .. t0+57
     if (run_if && *run_if == 0) return;           // fallback launch behind k_kp_front_h2
@@ -372,6 +384,8 @@ __global__ void __launch_bounds__(256, 2) k_kp_front(const float *__restrict__ m
     __shared__ float hA[fd::HID * KPF_LDH];
     __shared__ float hB[fd::HID * KPF_LDH];
     const int blk = blockIdx.z, b = blockIdx.y, t0 = blockIdx.x * KPF_VALID;
+    const int Tb = frames_of(lens, b, T);
+    if (t0 >= Tb) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int mt = wave & 1, nt = wave >> 1;
     const int step = sampler ? params->step_idx : 0;
@@ -383,7 +397,7 @@ __global__ void __launch_bounds__(256, 2) k_kp_front(const float *__restrict__ m
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int idx = k * 256 + tid, ci = idx / KPF_LDI, cc = idx - ci * KPF_LDI, t = t0 - 10 + cc;
-            v[k] = (idx < TOTAL && t >= 0 && t < T) ? src[(int64_t)ci * T + t] + nz[ci] : 0.0f;   // padding stays zero (modules.py:203)
+            v[k] = (idx < TOTAL && t >= 0 && t < Tb) ? src[(int64_t)ci * T + t] + nz[ci] : 0.0f;   // padding stays zero (modules.py:203)
         }
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
@@ -398,7 +412,7 @@ __global__ void __launch_bounds__(256, 2) k_kp_front(const float *__restrict__ m
     __syncthreads();
     const int c = nt * 32 + l31;                 // this lane's column; frame t0 - 8 + c
     const int t = t0 - 8 + c;
-    const bool inside = (t >= 0 && t < T);
+    const bool inside = (t >= 0 && t < Tb);
     // ---- layer 0: Conv1d(80,64,k5,pad2) + lrelu 0.1 -------------------------------------------------------------------
     {
         const float4 *pa = reinterpret_cast<const float4 *>(w.in_pack[blk]) + (int64_t)mt * 50 * 64 + lane;
@@ -468,12 +482,14 @@ __device__ __forceinline__ int kpf_off(int row, int slot) { return row * 256 + (
 
 __global__ void __launch_bounds__(256, 2) k_kp_front_h2(const float *__restrict__ mel, float *__restrict__ hout, char *__restrict__ himg,
                                                         KpFrontW2 w, const float *__restrict__ noise, const StepParams *params, int sampler,
-                                                        int B, int T, int R, int *__restrict__ range_flags)
+                                                        int B, int T, int R, int *__restrict__ range_flags, const int *__restrict__ lens)
 {
     __shared__ __attribute__((aligned(16))) char xin[68 * KPF_XROW];      // columns <-> frames t0-10 .. t0+57
     __shared__ __attribute__((aligned(16))) char hA[66 * 256];            // column c at row c+1; rows 0 and 65 stay zero
     __shared__ __attribute__((aligned(16))) char hB[66 * 256];
     const int blk = blockIdx.z, b = blockIdx.y, t0 = blockIdx.x * KPF_VALID;
+    const int Tb = frames_of(lens, b, T);
+    if (t0 > Tb) return;      // the tile holding frame Tb still runs: it writes the zero row the GEMM reads behind the utterance
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int mt = wave & 1, nt = wave >> 1;
     const int step = sampler ? params->step_idx : 0;
@@ -485,7 +501,7 @@ __global__ void __launch_bounds__(256, 2) k_kp_front_h2(const float *__restrict_
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int u = k * 256 + tid, cg = u / 68, cc = u - cg * 68, t = t0 - 10 + cc;
-            const bool ok = u < 680 && t >= 0 && t < T;
+            const bool ok = u < 680 && t >= 0 && t < Tb;
 #pragma unroll
             for (int c = 0; c < 8; ++c) v[k][c] = ok ? src[(int64_t)(cg * 8 + c) * T + t] + nz[cg * 8 + c] : 0.0f;
         }
@@ -510,7 +526,7 @@ __global__ void __launch_bounds__(256, 2) k_kp_front_h2(const float *__restrict_
     __syncthreads();
     const int c = nt * 32 + l31;                 // this lane's column; frame t0 - 8 + c
     const int t = t0 - 8 + c;
-    const bool inside = (t >= 0 && t < T);
+    const bool inside = (t >= 0 && t < Tb);
     float h0v[16];                               // this lane's layer-0 outputs (fp32) for the skip add of the last layer
     // write leaky_relu(hi + 2^-11 lo) (0 outside the utterance) as pieces of column c: D rows 32*mt + 8j + 4hi + {0..3}
     auto store_act = [&](char *img, const f32x16 &ah, const f32x16 &al, float *keep) {
@@ -583,7 +599,7 @@ __global__ void __launch_bounds__(256, 2) k_kp_front_h2(const float *__restrict_
         if (l < 5) {
             store_act(dst, ah, al, nullptr);
             __syncthreads();
-        } else if (inside && c >= 8 && c < 8 + KPF_VALID) {
+        } else if (t >= 0 && t < T && c >= 8 && c < 8 + KPF_VALID) {      // frames in [Tb, T) are written as zeros
             char *irow = himg + (((int64_t)blk * B + b) * R + (t + 1)) * 256;       // the GEMM's image: row = frame + 1
             const int sw = (t + 1) & 15;
 #pragma unroll
@@ -592,7 +608,7 @@ __global__ void __launch_bounds__(256, 2) k_kp_front_h2(const float *__restrict_
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = 4 * j + i;
-                    v[i] = lrelu(fmaf(al[r], GX_INV_SCALE, ah[r]), 0.1f) + h0v[r];
+                    v[i] = inside ? lrelu(fmaf(al[r], GX_INV_SCALE, ah[r]), 0.1f) + h0v[r] : 0.0f;
                     mx = fmaxf(mx, fabsf(v[i]));
                     hout[(((int64_t)blk * B + b) * fd::HID + mt * 32 + drow(r, hi)) * T + t] = v[i];
                 }
@@ -638,7 +654,7 @@ __device__ long long fd_gdbg[64 * 4 * 4];
 __global__ void __launch_bounds__(256, 2) k_kp_gemm(const float *__restrict__ h /*[3][B][64][T]*/, float *__restrict__ kpack,
                                                     const float *g0, const float *g1, const float *g2, const float *gb0,
                                                     const float *gb1, const float *gb2, int B, int T, int chunks_per_utt,
-                                                    int chunk_tiles, int n_items, const int *__restrict__ run_if)
+                                                    int chunk_tiles, int n_items, const int *__restrict__ run_if, const int *__restrict__ lens)
 {
     __shared__ float hs[2][fd::HID * GEMM_LDH];
     if (run_if && *run_if == 0) return;      // fallback launch behind the fp16 kernel: only when k_h_split flagged the operands
@@ -667,10 +683,10 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm(const float *__restrict__ h 
 #define FD_GEMM_FETCH(it)                                                                                              \
     do {                                                                                                               \
         const float *hb__ = h + (((int64_t)(it).blk * B + (it).b) * fd::HID + srow) * T + ((it).t_begin - 1);          \
-        const bool ok__ = ((it).t_begin - 1 + scol) >= 0 && ((it).t_begin - 1 + scol) < T;                             \
+        const bool ok__ = ((it).t_begin - 1 + scol) >= 0 && ((it).t_begin - 1 + scol) < frames_of(lens, (it).b, T);    \
         _Pragma("unroll") for (int j = 0; j < 32; ++j) v[j] = ok__ ? hb__[(int64_t)(2 * j) * T + scol] : 0.0f;         \
         const int t2__ = (it).t_begin + 127 + (tid & 1);     /* columns 128,129 of rows 0..63: threads 0..127 */          \
-        v[32] = (tid < 128 && t2__ < T) ? hb__[(int64_t)((tid >> 1) - srow) * T + 128 + (tid & 1)] : 0.0f;                \
+        v[32] = (tid < 128 && t2__ < frames_of(lens, (it).b, T)) ? hb__[(int64_t)((tid >> 1) - srow) * T + 128 + (tid & 1)] : 0.0f;                \
     } while (0)
 #define FD_GEMM_COMMIT(bufi)                                                                                           \
     do {                                                                                                               \
@@ -700,7 +716,8 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm(const float *__restrict__ h 
         Item nxt = cur;
         const bool more = (i + 1 < i1);
         if (more) { nxt = decode(i + 1); FD_GEMM_FETCH(nxt); }
-        const int n_frames = min(T - cur.t_begin, chunk_tiles * 32);
+        const int Tb = frames_of(lens, cur.b, T);
+        const int n_frames = min(Tb - cur.t_begin, chunk_tiles * 32);
         const int n_tiles = (n_frames + 31) >> 5;
         float *kout = kpack + ((int64_t)cur.blk * B + cur.b) * T * fd::KREC + (cur.xg * 4 + wave) * 32 + l31;   // + t*KREC
 #pragma unroll 1
@@ -720,13 +737,13 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm(const float *__restrict__ h 
 #ifdef FD_GX_NO_STORE
             if (acc[0] != 12345.678f) continue;
 #endif
-            if (t0 + 32 <= T) {
+            if (t0 + 32 <= Tb) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) kout[base + (unsigned)(((r & 3) + 8 * (r >> 2)) * fd::KREC)] = acc[r];
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (t0 + drow(r, hi) < T) kout[base + (unsigned)(((r & 3) + 8 * (r >> 2)) * fd::KREC)] = acc[r];
+                    if (t0 + drow(r, hi) < Tb) kout[base + (unsigned)(((r & 3) + 8 * (r >> 2)) * fd::KREC)] = acc[r];
             }
         }
         if (more) FD_GEMM_COMMIT(buf ^ 1);
@@ -763,13 +780,13 @@ __host__ __device__ inline int gx_rows(int T) { return ((T + GX_CT * 32 - 1) / (
 // (rows l, l+1, ... of one slot) then touch every bank once, and because the swizzle depends only on the ABSOLUTE row
 // (item windows start at multiples of 64 frames) the GEMM can pull a window into LDS as one linear DMA copy.
 __global__ void __launch_bounds__(256) k_h_split(const float *__restrict__ h, unsigned *__restrict__ hx, int *__restrict__ range_flag,
-                                                 int B, int T, int R)
+                                                 int B, int T, int R, const int *__restrict__ lens)
 {
     const int bb = blockIdx.y;                           // blk*B + b
     const int e = blockIdx.x * 256 + threadIdx.x, cp = e / R, row = e - cp * R;     // lanes along rows: coalesced h reads
     if (cp >= 32) return;
     const int t = row - 1;
-    const bool ok = t >= 0 && t < T;
+    const bool ok = t >= 0 && t < frames_of(lens, bb % B, T);
     const float *hb = h + (int64_t)bb * fd::HID * T;
     const float a = ok ? hb[(int64_t)(2 * cp) * T + t] : 0.0f, b2 = ok ? hb[(int64_t)(2 * cp + 1) * T + t] : 0.0f;
     if (!(fmaxf(fabsf(a), fabsf(b2)) < GX_LIMIT)) atomicOr(range_flag, 1);      // also catches NaN / inf
@@ -829,7 +846,7 @@ __device__ long long fd_gxdbg[8];
 template <int BUF, bool FULL>
 __device__ __forceinline__ void gx_item(char *lds, const GxItem &cur, bool more, const GxItem &nxt, const char *hx, float *kpack,
                                         const float4 (&wq)[2][12], const f32x16 &bias_lo, const int (&aoff)[2][12], int B, int T, int R,
-                                        int wave_u, int lane GX_TIMING_ARGS)
+                                        int wave_u, int lane, int Tb GX_TIMING_ARGS)
 {
     const int l31 = lane & 31, hi = lane >> 5;
     GX_STAMP(0);
@@ -841,7 +858,7 @@ __device__ __forceinline__ void gx_item(char *lds, const GxItem &cur, bool more,
     // stores of whole tiles go through a buffer descriptor: address = base (SGPRs) + per-lane offset (one VGPR, constant) + row
     // offset (an SGPR literal), so that a store costs no VALU instruction next to the MFMAs of the other wave on this SIMD
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(krow, 0, GX_CT * 32 * fd::KREC * 4, 0x00020000);
-    const int n_tiles = min(GX_CT, (T - t_begin + 31) >> 5);       // FULL: every one of them is a whole tile
+    const int n_tiles = max(0, min(GX_CT, (Tb - t_begin + 31) >> 5));      // Tb: frames of this utterance; FULL: all whole tiles
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int tile = 0; tile < GX_CT; ++tile) {
@@ -877,7 +894,7 @@ __device__ __forceinline__ void gx_item(char *lds, const GxItem &cur, bool more,
             float *kt = krow + (int64_t)tile * 32 * fd::KREC;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (t_begin + tile * 32 + drow(r, hi) < T)
+                if (t_begin + tile * 32 + drow(r, hi) < Tb)
                     (kt + ((r & 3) + 8 * (r >> 2)) * fd::KREC)[loff] = fmaf(lo[r], GX_INV_SCALE, acc[r]);
         }
         GX_STAMP(3);
@@ -886,7 +903,7 @@ __device__ __forceinline__ void gx_item(char *lds, const GxItem &cur, bool more,
         if (FULL && n_tiles == 4) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");       // 6-bit counter: 63 is its ceiling
         else if (FULL && n_tiles == 3) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
         else if (FULL && n_tiles == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        else if (FULL) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (FULL && n_tiles == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     GX_STAMP(4);
@@ -897,7 +914,7 @@ __device__ __forceinline__ void gx_item(char *lds, const GxItem &cur, bool more,
 __global__ void __launch_bounds__(256, 2) k_kp_gemm_h2(const char *__restrict__ hx /*[3][B][R][2][64] fp16*/, float *__restrict__ kpack,
                                                        const float4 *g0, const float4 *g1, const float4 *g2, const float *gb0,
                                                        const float *gb1, const float *gb2, const int *__restrict__ range_flag, int B,
-                                                       int T, int R, int chunks_per_utt, int n_items)
+                                                       int T, int R, int chunks_per_utt, int n_items, const int *__restrict__ lens)
 {
     __shared__ __attribute__((aligned(16))) char lds[2 * GX_BUFB];     // 2 x 36 KB
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -993,13 +1010,14 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm_h2(const char *__restrict__ 
                 }
             }
             --left;
-            const bool full = (T % 32 == 0) || (cur.chunk * (GX_CT * 32) + GX_CT * 32 <= T);
+            const int Tb = frames_of(lens, cur.b, T);
+            const bool full = (Tb % 32 == 0) || (cur.chunk * (GX_CT * 32) + GX_CT * 32 <= Tb);
             if (half == 0) {
-                if (full) gx_item<0, true>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane GX_TIMING_PASS);
-                else gx_item<0, false>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane GX_TIMING_PASS);
+                if (full) gx_item<0, true>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane, Tb GX_TIMING_PASS);
+                else gx_item<0, false>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane, Tb GX_TIMING_PASS);
             } else {
-                if (full) gx_item<1, true>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane GX_TIMING_PASS);
-                else gx_item<1, false>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane GX_TIMING_PASS);
+                if (full) gx_item<1, true>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane, Tb GX_TIMING_PASS);
+                else gx_item<1, false>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane, Tb GX_TIMING_PASS);
             }
             cur = nxt;
         }
@@ -1023,19 +1041,21 @@ constexpr int CT_LD = 132;     // 128 input positions + 1 halo each side, padded
 template <int R>
 __global__ void __launch_bounds__(256, 2) k_convt(const float *__restrict__ xin, const float *__restrict__ pack,
                                                const float *__restrict__ bias, float *__restrict__ out, int Lin,
-                                               const int *__restrict__ run_if)
+                                               const int *__restrict__ run_if, const int *__restrict__ lens, int per_frame)
 {
     __shared__ float xs[fd::C * CT_LD];
     if (run_if && *run_if == 0) return;      // fallback launch behind k_convt_h2
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int q0 = blockIdx.x * 128, Lout = Lin * R;
+    const int Lb = lens ? lens[b] * per_frame : Lin;      // this utterance's own input length
+    if (q0 >= Lb) return;
     {
         constexpr int TOTAL = fd::C * 130, NK = (TOTAL + 255) / 256;
         float v[NK];
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int idx = k * 256 + tid, ci = idx / 130, jj = idx - ci * 130, j = q0 - 1 + jj;
-            v[k] = (idx < TOTAL && j >= 0 && j < Lin) ? lrelu(xin[((int64_t)b * fd::C + ci) * Lin + j], 0.2f) : 0.0f;
+            v[k] = (idx < TOTAL && j >= 0 && j < Lb) ? lrelu(xin[((int64_t)b * fd::C + ci) * Lin + j], 0.2f) : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
@@ -1045,7 +1065,7 @@ __global__ void __launch_bounds__(256, 2) k_convt(const float *__restrict__ xin,
     }
     __syncthreads();
     const int ql = wave * 32 + l31, q = q0 + ql;
-    if (q0 + wave * 32 >= Lin) return;
+    if (q0 + wave * 32 >= Lb) return;
     float4 cb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) cb[j] = reinterpret_cast<const float4 *>(bias)[2 * j + hi];
@@ -1071,7 +1091,7 @@ __global__ void __launch_bounds__(256, 2) k_convt(const float *__restrict__ xin,
         }
     }
     // a lane holds the R consecutive outputs q*R .. q*R+R-1 of 16 channels: 16 B stores, 32 lanes cover 32*R contiguous floats
-    if (q < Lin) {
+    if (q < Lb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float *dst = ob + (unsigned)((r & 3) + 8 * (r >> 2)) * Lu;
@@ -1087,18 +1107,20 @@ __global__ void __launch_bounds__(256, 2) k_convt(const float *__restrict__ xin,
 template <int R>
 __global__ void __launch_bounds__(256, 2) k_convt_h2(const float *__restrict__ xin, const float4 *__restrict__ pack16,
                                                   const float *__restrict__ bias, float *__restrict__ out, int Lin,
-                                                  int *__restrict__ range_flag)
+                                                  int *__restrict__ range_flag, const int *__restrict__ lens, int per_frame)
 {
     __shared__ __attribute__((aligned(16))) char xs[130 * 128];
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int q0 = blockIdx.x * 128, Lout = Lin * R;
+    const int Lb = lens ? lens[b] * per_frame : Lin;      // this utterance's own input length
+    if (q0 >= Lb) return;
     float mx = 0.0f;
     {   // thread = (8-channel group, position): 130 positions x 4 groups = 520 units
         float v[3][8];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int u = k * 256 + tid, cg = u / 130, jj = u - cg * 130, j = q0 - 1 + jj;
-            const bool ok = u < 520 && j >= 0 && j < Lin;
+            const bool ok = u < 520 && j >= 0 && j < Lb;
 #pragma unroll
             for (int c = 0; c < 8; ++c) v[k][c] = ok ? xin[((int64_t)b * fd::C + cg * 8 + c) * Lin + j] : 0.0f;
         }
@@ -1118,7 +1140,7 @@ __global__ void __launch_bounds__(256, 2) k_convt_h2(const float *__restrict__ x
     if (!(mx < GX_LIMIT)) atomicOr(range_flag, 1);
     __syncthreads();
     const int ql = wave * 32 + l31, q = q0 + ql;
-    if (q0 + wave * 32 >= Lin) return;
+    if (q0 + wave * 32 >= Lb) return;
     float4 cb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) cb[j] = reinterpret_cast<const float4 *>(bias)[2 * j + hi];
@@ -1165,7 +1187,7 @@ __global__ void __launch_bounds__(256, 2) k_convt_h2(const float *__restrict__ x
 #pragma unroll
             for (int r = 0; r < 16; ++r) res[pi][r] = fmaf(al[r], GX_INV_SCALE, ah[r]);
         }
-        if (q < Lin) {
+        if (q < Lb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 *reinterpret_cast<float4 *>(ob + (unsigned)((r & 3) + 8 * (r >> 2)) * Lu + pg) = make_float4(res[0][r], res[1][r], res[2][r], res[3][r]);
@@ -1215,7 +1237,8 @@ template <int HOP, int DIL>
 __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ xin, const float *__restrict__ skip,
                                                       float *__restrict__ xout, const float *__restrict__ kpack, int layer,
                                                       const float *__restrict__ wpack, const float *__restrict__ wref,
-                                                      const float *__restrict__ cbias, int T, const int *__restrict__ run_if)
+                                                      const float *__restrict__ cbias, int T, const int *__restrict__ run_if,
+                                                      const int *__restrict__ lens)
 {
     using Cfg = LvcCfg<HOP, DIL>;
     if (run_if && *run_if == 0) return;      // fallback launch behind k_lvc_h2: only when that kernel flagged its operands
@@ -1228,11 +1251,13 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
     constexpr bool PREACT = (HOP == 256);              // xs holds leaky_relu(x'), the raw residual lives in registers (hop 64: no register room)
     __shared__ __attribute__((aligned(16))) float xs[fd::C * XLD];
     __shared__ __attribute__((aligned(16))) float ys[fd::C * YLD];
-    const int Ln = T * HOP;
+    const int Ln = T * HOP;                         // row stride of the activations
     const int b = blockIdx.y, w0 = blockIdx.x * W;
+    const int Tb = frames_of(lens, b, T), Lnb = Tb * HOP;      // this utterance's own length (ragged batch): every bound below
+    if (w0 >= Lnb) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int cw = wave * WC;                       // first conv column of this wave inside the tile
-    const bool wave_valid = (w0 + cw) < Ln;         // hop>=64: a wave owns whole frames; hop 8: checked per frame below
+    const bool wave_valid = (w0 + cw) < Lnb;         // hop>=64: a wave owns whole frames; hop 8: checked per frame below
     const int mt0 = (HOP == 256) ? (wave & 1) : 0;
     const int lcw = (HOP == 256) ? 128 * (wave >> 1) : cw;     // first LVC column of this wave
     FD_STAMP(0);
@@ -1275,7 +1300,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
 #pragma unroll
             for (int k = 0; k < KB; ++k) {
                 const int idx = (bt * KB + k) * 256 + tid, ci = idx / NF4, c4 = idx - ci * NF4, g = w0 - H + 4 * c4;
-                const bool ok = idx < TOTAL && g >= 0 && g < Ln;
+                const bool ok = idx < TOTAL && g >= 0 && g < Lnb;
                 xa[k] = ok ? *reinterpret_cast<const float4 *>(xr + (int64_t)ci * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
                 sa[k] = ok ? *reinterpret_cast<const float4 *>(sr + (int64_t)ci * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -1334,13 +1359,13 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
                 acc[ct] = mfma32(f4c(wa[s >> 2], s & 3), v, acc[ct]);
                 if (ct > 0 && s % 3 == 1) {             // write-back of the previous tile, one row per 3 k-steps
                     const int r = s / 3, cp = cw + (ct - 1) * 32 + l31;
-                    ys[drow(r, hi) * YLD + cp + 1] = (w0 + cp) < Ln ? lrelu(acc[ct - 1][r], 0.2f) : 0.0f;
+                    ys[drow(r, hi) * YLD + cp + 1] = (w0 + cp) < Lnb ? lrelu(acc[ct - 1][r], 0.2f) : 0.0f;
                 }
             }
         }
         {
             const int cp = cw + (NT - 1) * 32 + l31;
-            const bool inside = (w0 + cp) < Ln;          // y is zero-padded for the LVC taps (modules.py:240)
+            const bool inside = (w0 + cp) < Lnb;         // y is zero-padded for the LVC taps (modules.py:240)
 #pragma unroll
             for (int r = 0; r < 16; ++r) ys[drow(r, hi) * YLD + cp + 1] = inside ? lrelu(acc[NT - 1][r], 0.2f) : 0.0f;
         }
@@ -1360,7 +1385,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
         const float hbias = cbias[ho];
         const int c = hside ? W : -1, g = w0 + c;
         float accv = 0.0f;
-        if (g >= 0 && g < Ln) {
+        if (g >= 0 && g < Lnb) {
             const float wv[24] = {hwt[0].x, hwt[0].y, hwt[0].z, hwt[0].w, hwt[1].x, hwt[1].y, hwt[1].z, hwt[1].w,
                                   hwt[2].x, hwt[2].y, hwt[2].z, hwt[2].w, hwt[3].x, hwt[3].y, hwt[3].z, hwt[3].w,
                                   hwt[4].x, hwt[4].y, hwt[4].z, hwt[4].w, hwt[5].x, hwt[5].y, hwt[5].z, hwt[5].w};
@@ -1375,7 +1400,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
         }
         accv += __shfl_xor(accv, 1, 64);
         accv += __shfl_xor(accv, 2, 64);
-        if (hq == 0) ys[ho * YLD + c + 1] = (g >= 0 && g < Ln) ? lrelu(accv + hbias, 0.2f) : 0.0f;
+        if (hq == 0) ys[ho * YLD + c + 1] = (g >= 0 && g < Lnb) ? lrelu(accv + hbias, 0.2f) : 0.0f;
     }
     FD_STAMP(3);
     __syncthreads();
@@ -1430,7 +1455,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
 #pragma unroll 1
         for (int fi = 0; fi < WC / HOP; ++fi) {
             const int f = (w0 + cw) / HOP + fi;
-            if (f >= T) break;                 // T need not be a multiple of 4: the last wave may own fewer frames
+            if (f >= Tb) break;                // Tb need not be a multiple of 4: the last wave may own fewer frames
             const float *rec = kpack + ((int64_t)b * T + f) * fd::KREC;
             const float4 *kp4 = reinterpret_cast<const float4 *>(rec + layer * fd::KLAYER) + (mt * 6 * 64 + l31) * 2;
             float4 ke[12], ko[12];   // this row's k = 16*kg + e and 16*kg + 8 + e (e < 8): the two half-wave shares of the record
@@ -1490,7 +1515,7 @@ template <int HOP, int DIL>
 __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin, const float *__restrict__ skip, float *__restrict__ xout,
                                                    const float *__restrict__ kpack, int layer, const float4 *__restrict__ wpack16,
                                                    const float *__restrict__ wref, const float *__restrict__ cbias,
-                                                   int *__restrict__ range_flag, int T)
+                                                   int *__restrict__ range_flag, int T, const int *__restrict__ lens)
 {
     constexpr int W = 256, WC = 64, H = (DIL + 1 + 3) & ~3, XC = W + 2 * H, YC = W + 2;
     constexpr int LT = (HOP == 256) ? 1 : 2;           // row tiles per wave   (hop 256: wave = (row tile, column half))
@@ -1502,15 +1527,15 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
     __shared__ __attribute__((aligned(16))) char ys[YC * 128];       // first the raw x + skip of the centre (fp32 [32][256]), then
     static_assert(YC * 128 >= fd::C * W * 4, "parking area");        // the conv output pieces, row = column + 1
     const int Ln = T * HOP;
-    // workgroups go to the 8 XCDs round-robin (grid.x is a multiple of 8): give every XCD a contiguous run of tiles, so that the
-    // halo columns a tile shares with its neighbours are found in that XCD's L2 instead of being fetched from HBM twice
-    const int ntile = (T * HOP + W - 1) / W, per_xcd = (int)gridDim.x >> 3;
-    const int tile = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-    if (tile >= ntile) return;
+    // (an XCD-contiguous tile order was tried for L2 reuse of the halo columns: no measurable gain, and with ragged batches
+    // it leaves the XCDs that own the tail of every utterance idle)
+    const int ntile = (T * HOP + W - 1) / W, tile = blockIdx.x;
     const int b = blockIdx.y, w0 = tile * W;
+    const int Lnb = frames_of(lens, b, T) * HOP;      // this utterance's own length (ragged batch): every bound below; Ln = row stride
+    if (tile >= ntile || w0 >= Lnb) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int cw = wave * WC;
-    const bool wave_valid = (w0 + cw) < Ln;
+    const bool wave_valid = (w0 + cw) < Lnb;
     const int mt0 = (HOP == 256) ? (wave & 1) : 0;
     const int lcw = (HOP == 256) ? 128 * (wave >> 1) : cw;     // first LVC column of this wave
     float mx = 0.0f;                                            // largest operand magnitude seen by this thread
@@ -1546,9 +1571,9 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
     {
         const float *xr = xin + ((int64_t)b * fd::C + wave * 8) * Ln, *sr = skip + ((int64_t)b * fd::C + wave * 8) * Ln;
         const int g = w0 + 4 * lane;
-        const bool ok = g < Ln;                                      // Ln is a multiple of 64: a quad is all in or all out
+        const bool ok = g < Lnb;                                     // Lnb is a multiple of 64: a quad is all in or all out
         const int hc = lane, hg = (hc < H) ? w0 - H + hc : w0 + W + hc - H;
-        const bool hok = hc < 2 * H && hg >= 0 && hg < Ln;
+        const bool hok = hc < 2 * H && hg >= 0 && hg < Lnb;
         float4 xa[8], sa[8];
         float hx[8], hs[8];
 #pragma unroll
@@ -1643,7 +1668,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
                 al = mfma_f16(wa[1][kg], b1, al);
             }
             const int cp = cw + ct * 32 + l31, yrow = cp + 1;
-            const bool inside = (w0 + cp) < Ln;                   // y is zero-padded for the LVC taps (modules.py:240)
+            const bool inside = (w0 + cp) < Lnb;                  // y is zero-padded for the LVC taps (modules.py:240)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {                         // D rows 8j + 4hi + {0..3}: half a slot
                 float v[4];
@@ -1669,7 +1694,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
     // ---- the two halo columns (-1 and W) the LVC taps reach: VALU on the reassembled x, 4 threads per output ----------------
     {
         const int c = hside ? W : -1, g = w0 + c;
-        const bool ok = g >= 0 && g < Ln;
+        const bool ok = g >= 0 && g < Lnb;
         float accv = 0.0f;
         if (ok) {
             const float wv[24] = {hwt[0].x, hwt[0].y, hwt[0].z, hwt[0].w, hwt[1].x, hwt[1].y, hwt[1].z, hwt[1].w,
@@ -1760,11 +1785,12 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
 __global__ void __launch_bounds__(256) k_final(const float *__restrict__ x32, const float *__restrict__ w,
                                                const float *__restrict__ bias, float *__restrict__ eps_out,
                                                float *__restrict__ xstate, const StepParams *params, int sampler, int L,
-                                               int64_t n4_total)
+                                               int64_t n4_total, const int *__restrict__ lens)
 {
     const int b = blockIdx.y;
     const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (t0 >= L) return;
+    const int Lb = lens ? lens[b] * fd::HOPT : L;          // this utterance's own length (ragged batch)
+    if (t0 >= Lb) return;
     const float bv = bias[0];
     float4 acc = make_float4(bv, bv, bv, bv);
 #pragma unroll 8
@@ -1774,7 +1800,7 @@ __global__ void __launch_bounds__(256) k_final(const float *__restrict__ x32, co
         const float4 m = *reinterpret_cast<const float4 *>(xr + t0);
         float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi4 = lo;
         if (t0 >= 4) lo = *reinterpret_cast<const float4 *>(xr + t0 - 4);
-        if (t0 + 4 < L) hi4 = *reinterpret_cast<const float4 *>(xr + t0 + 4);
+        if (t0 + 4 < Lb) hi4 = *reinterpret_cast<const float4 *>(xr + t0 + 4);
         v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = m.x; v[5] = m.y; v[6] = m.z; v[7] = m.w;
         v[8] = hi4.x; v[9] = hi4.y; v[10] = hi4.z; v[11] = hi4.w;
 #pragma unroll
@@ -1805,7 +1831,7 @@ hipError_t fast_first_conv(const Launch &L, const StepIO &io, int B, int T)
     const DevWeights &w = L.ctx->w;
     const int Lf = T * fd::HOPT;
     FD_LAUNCH(L, "first_conv", k_first_conv, dim3((Lf + 1023) / 1024, B), dim3(256), 0, io.x_in, w.first.w, w.first.b,
-              L.ctx->ws.a[0], Lf);
+              L.ctx->ws.a[0], Lf, L.ctx->step_lens);
     return hipSuccess;
 }
 
@@ -1825,21 +1851,21 @@ hipError_t fast_dblock(const Launch &L, int d, int B, int T)
                      *q2 = reinterpret_cast<const float4 *>(w.down_h2[d][2]), *q3 = reinterpret_cast<const float4 *>(w.down_h2[d][3]);
         if (f == 4)
             FD_LAUNCH(L, n4, k_dblock_h2<4>, grid, dim3(256), 0, c->ws.a[d], c->ws.a[d + 1], q0, q1, q2, q3, w.down[d].conv[0].b,
-                      w.down[d].conv[1].b, w.down[d].conv[2].b, w.down[d].res.b, Lin, Lo, flag);
+                      w.down[d].conv[1].b, w.down[d].conv[2].b, w.down[d].res.b, Lin, Lo, flag, c->step_lens, Lo / T);
         else
             FD_LAUNCH(L, n8, k_dblock_h2<8>, grid, dim3(256), 0, c->ws.a[d], c->ws.a[d + 1], q0, q1, q2, q3, w.down[d].conv[0].b,
-                      w.down[d].conv[1].b, w.down[d].conv[2].b, w.down[d].res.b, Lin, Lo, flag);
+                      w.down[d].conv[1].b, w.down[d].conv[2].b, w.down[d].res.b, Lin, Lo, flag, c->step_lens, Lo / T);
         run_if = flag;
         n4 = n8 = "dblock_fp32_fallback";
     }
     if (f == 4)
         FD_LAUNCH(L, n4, k_dblock<4>, grid, dim3(256), 0, c->ws.a[d], c->ws.a[d + 1], w.down_pack[d][0], w.down_pack[d][1],
                   w.down_pack[d][2], w.down_pack[d][3], w.down[d].conv[0].b, w.down[d].conv[1].b, w.down[d].conv[2].b,
-                  w.down[d].res.b, Lin, Lo, run_if);
+                  w.down[d].res.b, Lin, Lo, run_if, c->step_lens, Lo / T);
     else
         FD_LAUNCH(L, n8, k_dblock<8>, grid, dim3(256), 0, c->ws.a[d], c->ws.a[d + 1], w.down_pack[d][0], w.down_pack[d][1],
                   w.down_pack[d][2], w.down_pack[d][3], w.down[d].conv[0].b, w.down[d].conv[1].b, w.down[d].conv[2].b,
-                  w.down[d].res.b, Lin, Lo, run_if);
+                  w.down[d].res.b, Lin, Lo, run_if, c->step_lens, Lo / T);
     return hipSuccess;
 }
 
@@ -1858,7 +1884,7 @@ hipError_t fast_kp_front(const Launch &L, const StepIO &io, int B, int T)
             for (int l = 0; l < 6; ++l) { k2.res_pack[n][l] = reinterpret_cast<const float4 *>(w.kp_res_h2[n][l]); k2.res_b[n][l] = w.blk[n].kp_res[l].b; }
         }
         FD_LAUNCH(L, name, k_kp_front_h2, grid, dim3(256), 0, io.mel, c->ws.kp_hB, reinterpret_cast<char *>(c->ws.h_f16), k2,
-                  (const float *)c->ws.noise, (const StepParams *)c->ws.params, io.sampler, B, T, gx_rows(T), c->ws.range_flag);
+                  (const float *)c->ws.noise, (const StepParams *)c->ws.params, io.sampler, B, T, gx_rows(T), c->ws.range_flag, c->step_lens);
         c->h_image_ready = true;      // the GEMM's fp16 image of h is written (k_h_split not needed)
         run_if = c->ws.range_flag + 19;
         name = "kp_front_fp32_fallback";
@@ -1869,7 +1895,7 @@ hipError_t fast_kp_front(const Launch &L, const StepIO &io, int B, int T)
         for (int l = 0; l < 6; ++l) { kw.res_pack[n][l] = w.kp_res_pack[n][l]; kw.res_b[n][l] = w.blk[n].kp_res[l].b; }
     }
     FD_LAUNCH(L, name, k_kp_front, grid, dim3(256), 0, io.mel, c->ws.kp_hB, kw, (const float *)c->ws.noise,
-              (const StepParams *)c->ws.params, io.sampler, B, T, run_if);
+              (const StepParams *)c->ws.params, io.sampler, B, T, run_if, c->step_lens);
     return hipSuccess;
 }
 
@@ -1889,17 +1915,17 @@ hipError_t fast_kp_gemm(const Launch &L, int B, int T)
         const int grid2 = items < 2 * c->num_cus ? items : 2 * c->num_cus;
         if (!c->h_image_ready)      // the fp16-pipe predictor front writes the image itself
             FD_LAUNCH(L, "h_split", k_h_split, dim3((32 * R + 255) / 256, fd::NBLK * B), dim3(256), 0, (const float *)c->ws.kp_hB,
-                      reinterpret_cast<unsigned *>(c->ws.h_f16), c->ws.range_flag, B, T, R);
+                      reinterpret_cast<unsigned *>(c->ws.h_f16), c->ws.range_flag, B, T, R, c->step_lens);
         FD_LAUNCH(L, "kp_gemm_f16x2", k_kp_gemm_h2, dim3(grid2), dim3(256), 0, reinterpret_cast<const char *>(c->ws.h_f16), c->ws.kpack,
                   reinterpret_cast<const float4 *>(w.gemm_h2_pack[0]), reinterpret_cast<const float4 *>(w.gemm_h2_pack[1]),
                   reinterpret_cast<const float4 *>(w.gemm_h2_pack[2]), w.gemm_bias[0], w.gemm_bias[1], w.gemm_bias[2],
-                  (const int *)c->ws.range_flag, B, T, R, chunks, items);
+                  (const int *)c->ws.range_flag, B, T, R, chunks, items, c->step_lens);
     }
     // fp32 matrix pipe: the whole job when the fp16 form is off, otherwise an early-exit launch that only works when
     // k_h_split found operands outside the fp16 range
     FD_LAUNCH(L, f16 ? "kp_gemm_fp32_fallback" : "kp_gemm", k_kp_gemm, dim3(grid), dim3(256), 0, (const float *)c->ws.kp_hB, c->ws.kpack,
               w.gemm_pack[0], w.gemm_pack[1], w.gemm_pack[2], w.gemm_bias[0], w.gemm_bias[1], w.gemm_bias[2], B, T, chunks_per_utt,
-              chunk_tiles, n_items, f16 ? (const int *)c->ws.range_flag : (const int *)nullptr);
+              chunk_tiles, n_items, f16 ? (const int *)c->ws.range_flag : (const int *)nullptr, c->step_lens);
     return hipSuccess;
 }
 
@@ -1913,16 +1939,16 @@ hipError_t fast_convt(const Launch &L, int n, const float *x_in, float *x_out, i
     if (c->conv_f16 && w.convt_f16_ok) {
         int *flag = c->ws.range_flag + 16 + n;
         if (fd::ratio(n) == 8)
-            FD_LAUNCH(L, n8, k_convt_h2<8>, grid, dim3(256), 0, x_in, reinterpret_cast<const float4 *>(w.up_h2[n]), w.blk[n].up.b, x_out, Lin, flag);
+            FD_LAUNCH(L, n8, k_convt_h2<8>, grid, dim3(256), 0, x_in, reinterpret_cast<const float4 *>(w.up_h2[n]), w.blk[n].up.b, x_out, Lin, flag, c->step_lens, fd::hop(n) / fd::ratio(n));
         else
-            FD_LAUNCH(L, n4, k_convt_h2<4>, grid, dim3(256), 0, x_in, reinterpret_cast<const float4 *>(w.up_h2[n]), w.blk[n].up.b, x_out, Lin, flag);
+            FD_LAUNCH(L, n4, k_convt_h2<4>, grid, dim3(256), 0, x_in, reinterpret_cast<const float4 *>(w.up_h2[n]), w.blk[n].up.b, x_out, Lin, flag, c->step_lens, fd::hop(n) / fd::ratio(n));
         run_if = flag;
         n8 = n4 = "convt_fp32_fallback";
     }
     if (fd::ratio(n) == 8)
-        FD_LAUNCH(L, n8, k_convt<8>, grid, dim3(256), 0, x_in, w.up_pack[n], w.blk[n].up.b, x_out, Lin, run_if);
+        FD_LAUNCH(L, n8, k_convt<8>, grid, dim3(256), 0, x_in, w.up_pack[n], w.blk[n].up.b, x_out, Lin, run_if, c->step_lens, fd::hop(n) / fd::ratio(n));
     else
-        FD_LAUNCH(L, n4, k_convt<4>, grid, dim3(256), 0, x_in, w.up_pack[n], w.blk[n].up.b, x_out, Lin, run_if);
+        FD_LAUNCH(L, n4, k_convt<4>, grid, dim3(256), 0, x_in, w.up_pack[n], w.blk[n].up.b, x_out, Lin, run_if, c->step_lens, fd::hop(n) / fd::ratio(n));
     return hipSuccess;
 }
 
@@ -1940,13 +1966,13 @@ static hipError_t launch_lvc(const Launch &L, const char *name, int n, int layer
         if (c->lvc_f16 && w.lvc_f16_ok) {
             int *flag = c->ws.range_flag + 1 + n * fd::LAYERS + layer;
             FD_LAUNCH(L, name, (k_lvc_h2<HOP, DIL>), dim3(((Ln + 255) / 256 + 7) / 8 * 8, B), dim3(256), 0, x_in, skip, x_out, kp, layer,
-                      reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]), w.blk[n].convs[layer].w, w.blk[n].convs[layer].b, flag, T);
+                      reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]), w.blk[n].convs[layer].w, w.blk[n].convs[layer].b, flag, T, c->step_lens);
             run_if = flag;
             name = "lvc_fp32_fallback";
         }
     }
     FD_LAUNCH(L, name, (k_lvc_layer<HOP, DIL>), dim3((Ln + W - 1) / W, B), dim3(256), 0, x_in, skip, x_out, kp, layer,
-              w.lvc_conv_pack[n][layer], w.blk[n].convs[layer].w, w.blk[n].convs[layer].b, T, run_if);
+              w.lvc_conv_pack[n][layer], w.blk[n].convs[layer].w, w.blk[n].convs[layer].b, T, run_if, c->step_lens);
     return hipSuccess;
 }
 
@@ -1971,7 +1997,7 @@ hipError_t fast_final(const Launch &L, const StepIO &io, const float *x32, int B
     const DevWeights &w = c->w;
     const int Lf = T * fd::HOPT;
     FD_LAUNCH(L, "final_conv_update", k_final, dim3((Lf + 1023) / 1024, B), dim3(256), 0, x32, w.final_.w, w.final_.b, io.eps_out,
-              c->ws.x, (const StepParams *)c->ws.params, io.sampler, Lf, (int64_t)B * Lf / 4);
+              c->ws.x, (const StepParams *)c->ws.params, io.sampler, Lf, (int64_t)B * Lf / 4, c->step_lens);
     return hipSuccess;
 }
 

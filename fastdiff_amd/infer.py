@@ -10,8 +10,8 @@ Reference behaviour restated (none of this is on the GPU path, so plain torch/nu
     multiple of the world size and rank r takes r::world; every rank writes its own wavs, no collective.
   * `test_step` (modules/FastDiff/task/FastDiff.py:96-118): one `sampling_given_noise_schedule` call per batch, then per
     item `wav / wav.abs().max()` and `save_wav` = *32767 -> int16 (utils/audio.py:11-16) as `<item_name>_pred.wav`.
-    The reference CLI runs B = 1 (config `max_sentences`); batching is this path's extension: a padded batch gives the padded
-    tensor's result (exactly what the reference computes for a collate_2d batch), cropped back to each item's own length.
+    The reference CLI runs B = 1 (config `max_sentences`); batching is this path's extension: the batch goes down with its
+    `lens`, so every item is computed exactly as if it ran alone (and the padding costs nothing), then cropped to its length.
 
 Entry points: load_mel_inputs, collate_test_batch, distributed_sampler_indices, synthesize, save_wavs and a small CLI
 (`python -m fastdiff_amd.infer --test_input_dir D --out_dir O [--N 4] [--ckpt model.ckpt]`).
@@ -84,7 +84,7 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
         mels = mels.cuda()
         B, _, T = mels.shape
         wav = sampling_given_noise_schedule(model, (B, 1, T * model.hop_length), diffusion_hyperparams, noise_schedule,
-                                            condition=mels, ddim=False, return_sequence=False, seed=seed + k, verbose=False)
+                                            condition=mels, ddim=False, return_sequence=False, seed=seed + k, verbose=False, lens=lens)
         for b, (name, t) in enumerate(zip(names, lens)):
             own = wav[b:b + 1, :, : t * model.hop_length]                      # crop the padding before the peak search
             out[name] = model.peak_normalize_int16(own)[0].cpu().numpy()

@@ -133,8 +133,9 @@ class FastDiff(nn.Module):
                 return
         self.apply(_remove)
 
-    def forward(self, data):
-        """eps = net((audio [B,1,L], c [B,80,T] or [80,T], diffusion_steps [B,1])) -- FastDiff_model.py:74-102."""
+    def forward(self, data, lens=None):
+        """eps = net((audio [B,1,L], c [B,80,T] or [80,T], diffusion_steps [B,1])) -- FastDiff_model.py:74-102.
+        lens (extension, optional): valid frames per utterance of a zero-padded batch, see sample()."""
         audio, c, diffusion_steps = data
         self._require_inference(audio, c)
         audio = audio.contiguous().float()
@@ -147,17 +148,20 @@ class FastDiff(nn.Module):
         assert steps.numel() == B
         out = torch.empty_like(audio)
         lib, h = self._ready(audio.device)
-        rc = lib.fd_forward(h, audio.data_ptr(), c.data_ptr(), steps.data_ptr(), B, T, None, out.data_ptr(),
+        lens_arr = None if lens is None else (ct.c_int * B)(*[int(v) for v in lens])
+        rc = lib.fd_forward(h, audio.data_ptr(), c.data_ptr(), steps.data_ptr(), B, T, lens_arr, out.data_ptr(),
                             self._stream(audio.device))
         _capi.check(lib, h, rc, "fd_forward")
         return out
 
     # ---- HIP-side entry used by fastdiff_amd.util.sampling_given_noise_schedule ---------------------------
-    def sample(self, condition, table, ddim=False, x_T=None, noise=None, seed=0, return_sequence=False):
+    def sample(self, condition, table, ddim=False, x_T=None, noise=None, seed=0, return_sequence=False, lens=None):
         """Run the N-step reverse loop on the device.
 
         table: list of dicts with keys t, c_eps, c_div, sigma, c1, c2, c3, add_noise (executed first -> last).
-        x_T [B,1,L] / noise [N,B,1,L] optional device tensors (None -> on-device Philox keyed by `seed`)."""
+        x_T [B,1,L] / noise [N,B,1,L] optional device tensors (None -> on-device Philox keyed by `seed`).
+        lens: optional valid frames per utterance of a zero-padded batch: utterance b is then computed as if it were alone
+        and lens[b] frames long (its first lens[b]*256 samples are exactly that result; the rest of its row is unspecified)."""
         B = condition.shape[0]
         self._require_inference(condition, condition)
         condition = condition.contiguous().float()
@@ -178,7 +182,8 @@ class FastDiff(nn.Module):
             noise = noise.to(device=dev, dtype=torch.float32).contiguous()
             assert tuple(noise.shape) == (N, B, 1, L)
         lib, h = self._ready(dev)
-        rc = lib.fd_sample(h, condition.data_ptr(), B, T, None, steps, N, int(bool(ddim)),
+        lens_arr = None if lens is None else (ct.c_int * B)(*[int(v) for v in lens])
+        rc = lib.fd_sample(h, condition.data_ptr(), B, T, lens_arr, steps, N, int(bool(ddim)),
                            None if x_T is None else x_T.data_ptr(), None if noise is None else noise.data_ptr(),
                            ct.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), out.data_ptr(),
                            None if seq is None else seq.data_ptr(), self._stream(dev))

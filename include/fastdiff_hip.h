@@ -91,8 +91,10 @@ FD_API int fd_commit_weights(fd_handle h);
 
 /* eps = FastDiff.forward((x, mel, steps))  -- FastDiff_model.py:74-102.
  *   x     [B,1,T*256] device     mel [B,80,T] device     steps [B] device (float; fractional allowed, util.py:217)
- *   lens  [B] host, nullable: valid frames per utterance of a zero-padded batch.  Results are those of running the
- *         whole padded tensor (what the reference does with a collate_2d batch, utils/__init__.py:136-150).
+ *   lens  [B] host, nullable: valid frames per utterance of a zero-padded batch (collate_2d, utils/__init__.py:136-150).
+ *         NULL: the whole padded tensor is computed, as the reference does.  Given: utterance b is computed as if it were
+ *         alone and lens[b] frames long -- the result in [0, lens[b]*256) is bit-identical to that single-utterance call,
+ *         work behind it is skipped and the output there is unspecified.  (kernels = naive ignores lens.)
  *   eps_out [B,1,T*256] device, must not alias x.
  * Errors: T*256 length mismatch is the reference's assert at modules.py:236. */
 FD_API int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps, int B, int T,

@@ -268,6 +268,48 @@ def test_everything_out_of_fp16_range_falls_back_on_device(gc, oracle64):
     assert gc.maxdiff(y, y_ref) < 3e-6 * float(np.abs(y_ref).max())
 
 
+def test_ragged_batch_with_lens_equals_each_utterance_alone(gc, sched):
+    """BASELINE config 4 in small: utterances of different length in one zero-padded batch.  With `lens` every utterance must
+    come out bit-identical to running it alone at its own length (forward, and the N-step sampler through the cached graph),
+    whatever stale data the skipped regions of the workspace hold; without `lens` the padded tensor is computed as is."""
+    import synth
+    m = gc.make_model()
+    B, T = 4, 300
+    lens = [300, 37, 150, 1]
+    mel = synth.synth_mel(51, B, T)
+    audio = synth.synth_audio(51, B, T)
+    for b, t in enumerate(lens):
+        mel[b, :, t:] = 0.0                                   # collate_2d padding
+    steps = np.array([3.0, 77.5, 500.0, 998.0], np.float32)
+    rows, _ = gc.table_rows(sched, 4)
+    N = len(rows)
+    x_T = synth.hash_normal(9, 1, B * T * 256).reshape(B, 1, T * 256)
+    z = np.stack([synth.hash_normal(9, 2 + k, B * T * 256).reshape(B, 1, T * 256) for k in range(N)])
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    with torch.no_grad():
+        alone, alone_s = [], []
+        for b, t in enumerate(lens):
+            alone.append(m((cu(audio[b:b + 1, :, : t * 256]), cu(mel[b:b + 1, :, :t]), cu(steps[b:b + 1].reshape(1, 1)))))
+            alone_s.append(m.sample(cu(mel[b:b + 1, :, :t]), rows, x_T=cu(x_T[b:b + 1, :, : t * 256]), noise=cu(z[:, b:b + 1, :, : t * 256])))
+        # leave different stale data in every workspace buffer, then the ragged calls
+        m((cu(synth.synth_audio(52, B, T)), cu(synth.synth_mel(52, B, T)), cu(steps.reshape(-1, 1))))
+        part = m((cu(audio), cu(mel), cu(steps.reshape(-1, 1))), lens=lens)
+        m.sample(cu(synth.synth_mel(53, B, T)), rows, seed=6)
+        part_s = m.sample(cu(mel), rows, x_T=cu(x_T), noise=cu(z), lens=lens)
+        part_s2 = m.sample(cu(mel), rows, x_T=cu(x_T), noise=cu(z), lens=lens)        # cached graph
+        full = m((cu(audio), cu(mel), cu(steps.reshape(-1, 1))))                        # no lens: the padded tensor
+    for b, t in enumerate(lens):
+        n = t * 256
+        assert torch.equal(part[b, :, :n], alone[b][0]), b
+        assert torch.equal(part_s[b, :, :n], alone_s[b][0]), b
+        assert torch.equal(part_s2[b, :, :n], alone_s[b][0]), b
+    assert torch.equal(full[0], alone[0][0])                                             # the full-length item is the same either way
+    assert not torch.equal(full[1, :, : 37 * 256], alone[1][0])                          # a padded item differs near its end: that is the reference's padded result
+    assert not m.read_tap("range_flags").view(np.int32).any()
+    with pytest.raises(Exception, match="lens"):
+        m((cu(audio), cu(mel), cu(steps.reshape(-1, 1))), lens=[300, 0, 150, 1])
+
+
 @pytest.mark.parametrize("B,T", [(1, 1), (3, 3), (1, 63), (2, 130)])
 def test_forward_ragged_sizes_against_oracle(model, gc, oracle64, B, T):
     import synth

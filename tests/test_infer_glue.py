@@ -63,8 +63,8 @@ def test_micro_batches_cover_every_item_once():
 
 @pytest.mark.gpu
 def test_synthesize_directory_end_to_end(tmp_path):
-    """Three Tacotron-range mels on disk -> padded micro-batches -> int16 wavs named like the reference's outputs; every
-    utterance equals the crop of the padded-batch result (what the reference computes for a collate_2d batch)."""
+    """Three Tacotron-range mels on disk -> padded micro-batches (with their lens, so every item is computed as if alone:
+    tests/test_gpu_parity.py pins that) -> int16 wavs named like the reference's outputs."""
     import fastdiff_amd
     from fastdiff_amd import schedules
     from fastdiff_amd.sampler import sampling_given_noise_schedule
@@ -83,7 +83,7 @@ def test_synthesize_directory_end_to_end(tmp_path):
     # the first micro-batch is (y, z): redo it by hand
     mels, lens, names = infer.collate_test_batch([items[1], items[2]])
     wav = sampling_given_noise_schedule(model, (2, 1, mels.shape[-1] * 256), schedules.training_hyperparams(),
-                                        schedules.noise_schedule_for(4), condition=mels.cuda(), seed=11, verbose=False)
+                                        schedules.noise_schedule_for(4), condition=mels.cuda(), seed=11, verbose=False, lens=lens)
     for b, (name, t) in enumerate(zip(names, lens)):
         own = wav[b, 0, : t * 256]
         ref = (own / own.abs().max() * 32767).cpu().numpy().astype(np.int16)

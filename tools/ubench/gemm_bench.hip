@@ -21,11 +21,11 @@ int main(int argc, char **argv)
     const int n_items = 3 * (fd::KREC / 128) * B * chunks;
     dim3 grid(512, 1, 1);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(fdk_fast::k_kp_gemm, grid, dim3(256), 0, 0, h, kp, g, g, g, gb, gb, gb, B, T, chunks, chunk_tiles, n_items);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(fdk_fast::k_kp_gemm, grid, dim3(256), 0, 0, h, kp, g, g, g, gb, gb, gb, B, T, chunks, chunk_tiles, n_items, (const int *)nullptr, (const int *)nullptr);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
     const int reps = 5;
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(fdk_fast::k_kp_gemm, grid, dim3(256), 0, 0, h, kp, g, g, g, gb, gb, gb, B, T, chunks, chunk_tiles, n_items);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(fdk_fast::k_kp_gemm, grid, dim3(256), 0, 0, h, kp, g, g, g, gb, gb, gb, B, T, chunks, chunk_tiles, n_items, (const int *)nullptr, (const int *)nullptr);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / reps, flops = 3 * 2.0 * 24832 * 192 * (double)B * T;

@@ -29,9 +29,9 @@ int main(int argc, char **argv)
     const int n_items = 3 * (fd::KREC / 128) * B * chunks;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto run = [&]() {
-        hipLaunchKernelGGL(fdk_fast::k_h_split, dim3((32 * R + 255) / 256, 3 * B), dim3(256), 0, 0, h, (unsigned *)hx, flag, B, T, R);
+        hipLaunchKernelGGL(fdk_fast::k_h_split, dim3((32 * R + 255) / 256, 3 * B), dim3(256), 0, 0, h, (unsigned *)hx, flag, B, T, R, (const int *)nullptr);
         hipLaunchKernelGGL(fdk_fast::k_kp_gemm_h2, dim3(G), dim3(256), 0, 0, (const char *)hx, kp, (const float4 *)g, (const float4 *)g,
-                           (const float4 *)g, gb, gb, gb, (const int *)flag, B, T, R, chunks, n_items);
+                           (const float4 *)g, gb, gb, gb, (const int *)flag, B, T, R, chunks, n_items, (const int *)nullptr);
     };
     for (int i = 0; i < 2; ++i) run();
     CK(hipDeviceSynchronize());
