@@ -1202,11 +1202,11 @@ __global__ void __launch_bounds__(256, 2) k_convt_h2(const float *__restrict__ x
 // Workgroup = 4 waves x WC columns.  Each wave: dilated conv on its WC columns + the 2 halo columns the
 // LVC taps need (one extra MFMA tile), y kept wave-private in LDS, then
 //   HOP >= 64: LVC on the matrix pipe, A = the frame's 64x96 predicted kernel (96 VGPRs), 2 row tiles share B
-//   HOP == 8 : LVC on VALU, lane = output channel (a 32-column MFMA tile would straddle 4 different kernels)
+//   (hop 8 has its own all-VALU kernel, k_lvc_h8)
 // =================================================================================================
 template <int HOP, int DIL>
 struct LvcCfg {
-    static constexpr int WC = (HOP == 8) ? 32 : 64;            // columns per wave
+    static constexpr int WC = 64;                               // columns per wave
     static constexpr int W = 4 * WC;                            // columns per workgroup
     static constexpr int H = (DIL + 1 + 3) & ~3;                // staged halo (multiple of 4 for 16 B loads)
     static constexpr int XLD = W + 2 * H;
@@ -1240,6 +1240,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
                                                       const float *__restrict__ cbias, int T, const int *__restrict__ run_if,
                                                       const int *__restrict__ lens)
 {
+    static_assert(HOP >= 64, "hop 8 has its own kernel (k_lvc_h8)");
     using Cfg = LvcCfg<HOP, DIL>;
     if (run_if && *run_if == 0) return;      // fallback launch behind k_lvc_h2: only when that kernel flagged its operands
     constexpr int WC = Cfg::WC, W = Cfg::W, H = Cfg::H, XLD = Cfg::XLD, YLD = Cfg::YLD, NT = WC / 32;
@@ -1449,54 +1450,6 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
 #pragma unroll
         for (int e = 0; e < EPI; ++e) epilogue_row(LN - 1, e / 8, e % 8);
         FD_STAMP(7);
-    } else {
-        // ---- LVC on VALU (hop 8): lane = output row (mt = lane/32, row = lane%32), 4 frames of 8 columns per wave ------------
-        const int mt = lane >> 5;
-#pragma unroll 1
-        for (int fi = 0; fi < WC / HOP; ++fi) {
-            const int f = (w0 + cw) / HOP + fi;
-            if (f >= Tb) break;                // Tb need not be a multiple of 4: the last wave may own fewer frames
-            const float *rec = kpack + ((int64_t)b * T + f) * fd::KREC;
-            const float4 *kp4 = reinterpret_cast<const float4 *>(rec + layer * fd::KLAYER) + (mt * 6 * 64 + l31) * 2;
-            float4 ke[12], ko[12];   // this row's k = 16*kg + e and 16*kg + 8 + e (e < 8): the two half-wave shares of the record
-#pragma unroll
-            for (int i = 0; i < 12; ++i) { ke[i] = kp4[(i >> 1) * 128 + (i & 1)]; ko[i] = kp4[(i >> 1) * 128 + 64 + (i & 1)]; }
-            float z[8];
-            const float bzv = rec[fd::KW + layer * 64 + lane];     // bias record is [mt][row] too
-#pragma unroll
-            for (int c = 0; c < 8; ++c) z[c] = bzv;
-#pragma unroll
-            for (int in = 0; in < fd::C; ++in) {
-                // y window of input channel `in`: tile columns cw+fi*8-1 .. +8  -> y index cw+fi*8 .. +9
-                const float *yr = ys + in * YLD + cw + fi * 8;
-                const float4 y0 = *reinterpret_cast<const float4 *>(yr);
-                const float4 y1 = *reinterpret_cast<const float4 *>(yr + 4);
-                const float2 y2 = *reinterpret_cast<const float2 *>(yr + 8);
-                const float yv[10] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w, y2.x, y2.y};
-#pragma unroll
-                for (int tap = 0; tap < 3; ++tap) {
-                    const int kk = tap * 32 + in, kg = kk >> 4, e = kk & 7;
-                    const float kv = (kk & 8) ? f4c(ko[2 * kg + (e >> 2)], e & 3) : f4c(ke[2 * kg + (e >> 2)], e & 3);
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) z[c] += kv * yv[c + tap];
-                }
-            }
-            // gate: rows 0..15 of a tile hold the sigmoid inputs, rows 16..31 the tanh inputs of the same channels
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float zt = __shfl_down(z[c], 16, 64);
-                z[c] = gate(z[c], zt);
-            }
-            if ((lane & 16) == 0) {
-                const int ch = 16 * mt + (lane & 15), c0 = cw + fi * 8;
-                float *dst = xout + orow + (int64_t)ch * Ln + w0 + c0;
-                const float *xr = xs + ch * XLD + H + c0;
-                const float4 o0 = make_float4(xr[0] + z[0], xr[1] + z[1], xr[2] + z[2], xr[3] + z[3]);
-                const float4 o1 = make_float4(xr[4] + z[4], xr[5] + z[5], xr[6] + z[6], xr[7] + z[7]);
-                *reinterpret_cast<float4 *>(dst) = o0;
-                *reinterpret_cast<float4 *>(dst + 4) = o1;
-            }
-        }
     }
 }
 
@@ -1779,6 +1732,129 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
 }
 
 // =================================================================================================
+// The hop-8 LVC layer (first block: 8 samples per frame), all VALU and one frame per wave.  At hop 8 a 32-column matrix tile
+// would straddle four different predicted kernels, and the work is tiny (6912 columns per utterance) but each frame drags a
+// 24.8 KB kernel record out of HBM: what matters is how many of those reads are in flight.  Workgroup = 32 columns = 4 frames,
+// wave = frame (1728 workgroups at B=8 instead of 432, no loop over frames).  The frame's record is requested first; the
+// dilated conv of the wave's own 10 columns (8 + the two the LVC taps reach) runs on VALU from a shared leaky_relu(x+skip)
+// window -- lane = (output channel, column half), weights from LDS -- while the record is on its way; y stays
+// wave-private in LDS; LVC: lane = output row, gate by a 16-lane shuffle.
+// =================================================================================================
+template <int DIL>
+__global__ void __launch_bounds__(256, 2) k_lvc_h8(const float *__restrict__ xin, const float *__restrict__ skip, float *__restrict__ xout,
+                                                   const float *__restrict__ kpack, int layer, const float *__restrict__ wref,
+                                                   const float *__restrict__ cbias, int T, const int *__restrict__ lens)
+{
+    constexpr int HOP = 8, W = 32, H = (DIL + 1 + 3) & ~3, XLD = W + 2 * H, YLD = 12;
+    __shared__ __attribute__((aligned(16))) float xs[fd::C * XLD];          // leaky_relu(x + skip), column c at index c + H
+    __shared__ __attribute__((aligned(16))) float xr[fd::C * W];            // raw x + skip of the centre: the residual
+    __shared__ __attribute__((aligned(16))) float ys[4][fd::C * YLD];       // per wave: y of columns 8*wave-1 .. 8*wave+8 (+2 pad)
+    __shared__ float wl[fd::C * 3 * fd::C];                                 // conv weights as [in*3 + k][out]: lane = out reads row by row
+    const int Ln = T * HOP;
+    const int b = blockIdx.y, w0 = blockIdx.x * W;
+    const int Tb = frames_of(lens, b, T), Lnb = Tb * HOP;
+    if (w0 >= Lnb) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int f = w0 / HOP + wave;                  // this wave's frame
+    const bool frame_valid = f < Tb;
+    // (a) the frame's predicted kernel: lane = output row (mt = hi, row = l31): its k = 16*kg + e and 16*kg + 8 + e shares
+    float4 ke[12], ko[12];
+    float bzv = 0.0f;
+    if (frame_valid) {
+        const float *rec = kpack + ((int64_t)b * T + f) * fd::KREC;
+        const float4 *kp4 = reinterpret_cast<const float4 *>(rec + layer * fd::KLAYER) + (hi * 6 * 64 + l31) * 2;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { ke[i] = kp4[(i >> 1) * 128 + (i & 1)]; ko[i] = kp4[(i >> 1) * 128 + 64 + (i & 1)]; }
+        bzv = rec[fd::KW + layer * 64 + lane];
+    }
+    // (b) conv weights w[o][i][k] (12 KB, L2) -> LDS transposed
+    float wst[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { const int idx = k * 256 + tid; wst[k] = wref[(idx & 31) * (fd::C * 3) + (idx >> 5)]; }
+    const float cbv = cbias[l31];
+    // (c) x + skip with halo: thread = (channel, 4 columns)
+    {
+        const float *xp = xin + (int64_t)b * fd::C * Ln, *sp = skip + (int64_t)b * fd::C * Ln;
+        constexpr int NF4 = XLD / 4, TOTAL = fd::C * NF4, NK = (TOTAL + 255) / 256;
+        float4 xa[NK], sa[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int idx = k * 256 + tid, ci = idx / NF4, c4 = idx - ci * NF4, g = w0 - H + 4 * c4;
+            const bool ok = idx < TOTAL && g >= 0 && g < Lnb;
+            xa[k] = ok ? *reinterpret_cast<const float4 *>(xp + (int64_t)ci * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            sa[k] = ok ? *reinterpret_cast<const float4 *>(sp + (int64_t)ci * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int idx = k * 256 + tid, ci = idx / NF4, c4 = idx - ci * NF4;
+            if (idx < TOTAL) {
+                const float4 r = make_float4(xa[k].x + sa[k].x, xa[k].y + sa[k].y, xa[k].z + sa[k].z, xa[k].w + sa[k].w);
+                *reinterpret_cast<float4 *>(xs + ci * XLD + 4 * c4) = make_float4(lrelu(r.x, 0.2f), lrelu(r.y, 0.2f), lrelu(r.z, 0.2f), lrelu(r.w, 0.2f));
+                if (c4 >= H / 4 && c4 < H / 4 + W / 4) *reinterpret_cast<float4 *>(xr + ci * W + 4 * c4 - H) = r;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) wl[k * 256 + tid] = wst[k];
+    __syncthreads();
+    if (!frame_valid) return;
+    // ---- dilated conv of columns 8*wave - 1 + {5*hi .. 5*hi + 4}: lane = (output channel l31, column half hi) ----------------
+    {
+        float acc[5] = {cbv, cbv, cbv, cbv, cbv};
+        const float *xb = xs + H + 8 * wave - 1 + 5 * hi;
+#pragma unroll 2
+        for (int in = 0; in < fd::C; ++in)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float wv = wl[(in * 3 + k) * fd::C + l31];
+                const float *xq = xb + in * XLD + (k - 1) * DIL;
+#pragma unroll
+                for (int c = 0; c < 5; ++c) acc[c] = fmaf(wv, xq[c], acc[c]);
+            }
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const int g = w0 + 8 * wave - 1 + 5 * hi + c;             // y is zero outside the signal (modules.py:240)
+            ys[wave][l31 * YLD + 5 * hi + c] = (g >= 0 && g < Lnb) ? lrelu(acc[c], 0.2f) : 0.0f;
+        }
+    }
+    // the y window is wave-private: the LDS writes above only have to be visible to this wave's own reads below
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- LVC: lane = output row (mt = hi, row = l31), 8 columns; y index = column + 1 + (tap - 1) ----------------------------
+    float z[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) z[c] = bzv;
+#pragma unroll
+    for (int in = 0; in < fd::C; ++in) {
+        const float *yr = ys[wave] + in * YLD;
+        const float4 y0 = *reinterpret_cast<const float4 *>(yr);
+        const float4 y1 = *reinterpret_cast<const float4 *>(yr + 4);
+        const float2 y2 = *reinterpret_cast<const float2 *>(yr + 8);
+        const float yv[10] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w, y2.x, y2.y};
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            const int kk = tap * 32 + in, kg = kk >> 4, e = kk & 7;
+            const float kv = (kk & 8) ? f4c(ko[2 * kg + (e >> 2)], e & 3) : f4c(ke[2 * kg + (e >> 2)], e & 3);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) z[c] = fmaf(kv, yv[c + tap], z[c]);
+        }
+    }
+    // gate: rows 0..15 of a tile hold the sigmoid inputs, rows 16..31 the tanh inputs of the same channels
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float zt = __shfl_down(z[c], 16, 64);
+        z[c] = gate(z[c], zt);
+    }
+    if ((lane & 16) == 0) {
+        const int ch = 16 * hi + (lane & 15), c0 = 8 * wave;
+        float *dst = xout + ((int64_t)b * fd::C + ch) * Ln + w0 + c0;
+        const float *rr = xr + ch * W + c0;
+        *reinterpret_cast<float4 *>(dst) = make_float4(rr[0] + z[0], rr[1] + z[1], rr[2] + z[2], rr[3] + z[3]);
+        *reinterpret_cast<float4 *>(dst + 4) = make_float4(rr[4] + z[4], rr[5] + z[5], rr[6] + z[6], rr[7] + z[7]);
+    }
+}
+
+// =================================================================================================
 // a10 + sampler: final_conv Conv1d(32,1,k7) (FastDiff_model.py:67-68,100) with the reverse-step update
 // (util.py:219-229) fused into its epilogue.  VALU; each thread produces 4 consecutive samples.
 // =================================================================================================
@@ -1985,7 +2061,24 @@ hipError_t fast_lvc_layer(const Launch &L, int n, int layer, const float *x_in, 
     case 2: return launch_lvc<HOP_, 9>(L, NAME_ "_d9", n, layer, x_in, skip, x_out, B, T);                           \
     default: return launch_lvc<HOP_, 27>(L, NAME_ "_d27", n, layer, x_in, skip, x_out, B, T);                        \
     }
-    if (n == 0) { FD_LVC_CASE(8, "lvc_layer_h8") }
+    if (n == 0) {
+        fd_context *c = L.ctx;
+        const DevWeights &w = c->w;
+        const int Ln = T * 8;
+        const float *kp = c->ws.kpack;
+        const dim3 grid((Ln + 31) / 32, B);
+#define FD_H8(DIL_, NAME_)                                                                                          \
+        FD_LAUNCH(L, NAME_, k_lvc_h8<DIL_>, grid, dim3(256), 0, x_in, skip, x_out, kp, layer, w.blk[0].convs[layer].w,    \
+                  w.blk[0].convs[layer].b, T, c->step_lens)
+        switch (layer) {
+        case 0: FD_H8(1, "lvc_layer_h8_d1"); break;
+        case 1: FD_H8(3, "lvc_layer_h8_d3"); break;
+        case 2: FD_H8(9, "lvc_layer_h8_d9"); break;
+        default: FD_H8(27, "lvc_layer_h8_d27"); break;
+        }
+#undef FD_H8
+        return hipSuccess;
+    }
     if (n == 1) { FD_LVC_CASE(64, "lvc_layer_h64") }
     FD_LVC_CASE(256, "lvc_layer_h256")
 #undef FD_LVC_CASE

@@ -26,9 +26,10 @@ def fam(name):
     m = re.search(r"k_lvc_h2<(\d+)", name)            # the fp16-pipe LVC layer (hop 64, 256)
     if m:
         return "lvc_layer_h" + m.group(1)
-    m = re.search(r"k_lvc_layer<(\d+)", name)         # fp32 kernel: the whole layer for hop 8, an early-exit fallback launch otherwise
-    if m:
-        return "lvc_layer_h8" if m.group(1) == "8" else "lvc_fp32_fallback"
+    if "k_lvc_h8<" in name:                           # the hop-8 layer: all VALU, one frame per wave
+        return "lvc_layer_h8"
+    if "k_lvc_layer<" in name:                        # fp32 kernel for hop 64 / 256: an early-exit fallback launch
+        return "lvc_fp32_fallback"
     m = re.search(r"::(k_\w+)", name)
     return BENCH_NAME.get(m.group(1), m.group(1)) if m else name[:40]
 
