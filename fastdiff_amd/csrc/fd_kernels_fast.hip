@@ -575,16 +575,21 @@ __global__ void __launch_bounds__(256, 2) k_kp_front_h2(const float *__restrict_
         for (int p = 0; p < 2; ++p)
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) off[tap][p][k4] = kpf_off(c + tap, p * 8 + k4 * 2 + hi);      // column c + tap - 1 at row c + tap
-#pragma unroll 1
-    for (int l = 0; l < 6; ++l) {
-        const char *src = (l & 1) ? hB : hA;
-        char *dst = (l & 1) ? hA : hB;
+    // the weights of layer l+1 are requested as soon as the MFMAs of layer l are issued: their L2 latency then hides behind
+    // the activation split / LDS write-back / barrier of layer l instead of stalling the next layer
+    float4 wa[2][12];
+    auto load_w = [&](int l) {
         const float4 *pa = w.res_pack[blk][l] + (int64_t)mt * 2 * 12 * 64 + lane;
-        float4 wa[2][12];
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
             for (int kg = 0; kg < 12; ++kg) wa[p][kg] = pa[(p * 12 + kg) * 64];
+    };
+    load_w(0);
+#pragma unroll 1
+    for (int l = 0; l < 6; ++l) {
+        const char *src = (l & 1) ? hB : hA;
+        char *dst = (l & 1) ? hA : hB;
         f32x16 ah, al;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { ah[r] = w.res_b[blk][l][mt * 32 + drow(r, hi)]; al[r] = 0.0f; }
@@ -596,6 +601,9 @@ __global__ void __launch_bounds__(256, 2) k_kp_front_h2(const float *__restrict_
             al = mfma_f16(wa[0][kg], b2, al);
             al = mfma_f16(wa[1][kg], b1, al);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (l < 5) load_w(l + 1);
+        __builtin_amdgcn_sched_barrier(0);
         if (l < 5) {
             store_act(dst, ah, al, nullptr);
             __syncthreads();
