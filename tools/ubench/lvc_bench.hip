@@ -60,5 +60,6 @@ int main(int argc, char **argv)
     run<256, 27>(B, T, 20);
     run<256, 1>(B, T, 20);
     run<64, 27>(B, T, 20);
+    run<8, 27>(B, T, 20);
     return 0;
 }
