@@ -1245,10 +1245,12 @@ template <int HOP, int DIL>
 __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ xin, const float *__restrict__ skip,
                                                       float *__restrict__ xout, const float *__restrict__ kpack, int layer,
                                                       const float *__restrict__ wpack, const float *__restrict__ wref,
-                                                      const float *__restrict__ cbias, int T, const int *__restrict__ lens)
+                                                      const float *__restrict__ cbias, int T, const int *__restrict__ run_if,
+                                                      const int *__restrict__ lens)
 {
     static_assert(HOP >= 64, "hop 8 has its own kernel (k_lvc_h8)");
     using Cfg = LvcCfg<HOP, DIL>;
+    if (run_if && *run_if == 0) return;      // fallback launch behind k_lvc_h2: only when that kernel flagged its operands
     constexpr int WC = Cfg::WC, W = Cfg::W, H = Cfg::H, XLD = Cfg::XLD, YLD = Cfg::YLD, NT = WC / 32;
     // LVC work split (hop >= 64).  hop 256: the whole tile is ONE frame, so the waves split the 64 output rows instead of
     // re-loading the same kernel four times: wave = (row tile mt, column half), 4 column tiles each, 48 operand registers.
@@ -2116,7 +2118,7 @@ static hipError_t launch_lvc(const Launch &L, const char *name, int n, int layer
         return hipSuccess;
     }
     FD_LAUNCH(L, name, (k_lvc_layer<HOP, DIL>), dim3((Ln + W - 1) / W, B), dim3(256), 0, x_in, skip, x_out, kp, layer,
-              w.lvc_conv_pack[n][layer], w.blk[n].convs[layer].w, w.blk[n].convs[layer].b, T, c->step_lens);
+              w.lvc_conv_pack[n][layer], w.blk[n].convs[layer].w, w.blk[n].convs[layer].b, T, (const int *)nullptr, c->step_lens);
     return hipSuccess;
 }
 

@@ -28,9 +28,8 @@ def fam(name):
         return "lvc_layer_h" + m.group(1)
     if "k_lvc_h8<" in name:                           # the hop-8 layer: all VALU, one frame per wave
         return "lvc_layer_h8"
-    m = re.search(r"k_lvc_layer<(\d+)", name)         # fp32 matrix-pipe kernel for hop 64 / 256 (option lvc=fp32 only)
-    if m:
-        return "lvc_layer_h" + m.group(1)
+    if "k_lvc_layer<" in name:                        # fp32 kernel for hop 64 / 256: an early-exit fallback launch
+        return "lvc_fp32_fallback"
     m = re.search(r"::(k_\w+)", name)
     return BENCH_NAME.get(m.group(1), m.group(1)) if m else name[:40]
 

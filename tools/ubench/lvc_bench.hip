@@ -26,10 +26,10 @@ int run(int B, int T, int reps)
     dim3 grid((Ln + Cfg::W - 1) / Cfg::W, B);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((fdk_fast::k_lvc_layer<HOP, DIL>), grid, dim3(256), 0, 0, x, skip, out, kp, 1, wpack, wref, cb, T, (const int *)nullptr);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((fdk_fast::k_lvc_layer<HOP, DIL>), grid, dim3(256), 0, 0, x, skip, out, kp, 1, wpack, wref, cb, T, (const int *)nullptr, (const int *)nullptr);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((fdk_fast::k_lvc_layer<HOP, DIL>), grid, dim3(256), 0, 0, x, skip, out, kp, 1, wpack, wref, cb, T, (const int *)nullptr);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((fdk_fast::k_lvc_layer<HOP, DIL>), grid, dim3(256), 0, 0, x, skip, out, kp, 1, wpack, wref, cb, T, (const int *)nullptr, (const int *)nullptr);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms = 0;
