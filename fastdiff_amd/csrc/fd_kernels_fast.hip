@@ -1469,58 +1469,9 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
 //   packed fp32 math): x' at staging, y after the conv, the predicted kernel after its load.
 // LDS images are [column][piece][32 channels] fp16, 128 B per column, 16 B slot s of row r stored at s ^ ((r >> 1) & 7):
 // a B operand (8 consecutive channels of one column) is one conflict-free ds_read_b128.
-// Operands of magnitude >= 32768 do not fit fp16: the workgroup that meets one (every operand of a tile is seen before its first
-// store) redoes the tile in plain fp32 (lvc_tile_cold) and raises *range_flag for diagnostics.
+// Operands of magnitude >= 32768 do not fit fp16: the kernel raises *range_flag and the fp32 kernel launched behind it
+// (k_lvc_layer with run_if) redoes the whole layer from the untouched inputs.
 // =================================================================================================
-// Cold path of k_lvc_h2: one tile of the layer in plain fp32 with a handful of registers (rolled loops, operands through the
-// workgroup's LDS), taken by a workgroup that met an operand outside the fp16 range.  xf: [32][XC] x + skip (raw), yf: [32][W+2].
-template <int HOP, int DIL>
-__device__ __forceinline__ void lvc_tile_cold(float *xf, float *yf, const float *xin, const float *skip, float *xout,
-                                                        const float *kpack, int layer, const float *wref, const float *cbias, int T,
-                                                        int Lnb, int b, int w0)
-{
-    constexpr int W = 256, H = (DIL + 1 + 3) & ~3, XC = W + 2 * H, YC = W + 2;
-    const int Ln = T * HOP, tid = threadIdx.x;
-    const float *xp = xin + (int64_t)b * fd::C * Ln, *sp = skip + (int64_t)b * fd::C * Ln;
-#pragma unroll 1
-    for (int idx = tid; idx < fd::C * XC; idx += 256) {
-        const int ci = idx / XC, c = idx - ci * XC, g = w0 - H + c;
-        xf[idx] = (g >= 0 && g < Lnb) ? xp[(int64_t)ci * Ln + g] + sp[(int64_t)ci * Ln + g] : 0.0f;
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int idx = tid; idx < fd::C * YC; idx += 256) {          // y = lrelu(conv(lrelu(x'))) for columns -1 .. W, zero outside the signal
-        const int o = idx / YC, yc = idx - o * YC, g = w0 + yc - 1;
-        float acc = 0.0f;
-        if (g >= 0 && g < Lnb) {
-            acc = cbias[o];
-#pragma unroll 1
-            for (int i = 0; i < fd::C; ++i)
-#pragma unroll 1
-                for (int k = 0; k < 3; ++k) acc = fmaf(wref[(o * fd::C + i) * 3 + k], lrelu(xf[i * XC + H + yc - 1 + (k - 1) * DIL], 0.2f), acc);
-            acc = lrelu(acc, 0.2f);
-        }
-        yf[idx] = acc;
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int idx = tid; idx < fd::C * W; idx += 256) {
-        const int ch = idx / W, col = idx - ch * W, g = w0 + col;
-        if (g >= Lnb) continue;
-        const float *rec = kpack + ((int64_t)b * T + g / HOP) * fd::KREC;
-        float zs = rec[fd::bias_index(layer, ch)], zt = rec[fd::bias_index(layer, ch + fd::C)];
-#pragma unroll 1
-        for (int i = 0; i < fd::C; ++i)
-#pragma unroll 1
-            for (int k = 0; k < 3; ++k) {
-                const float v = yf[i * YC + col + k];
-                zs = fmaf(v, rec[fd::kernel_index(layer, i, ch, k)], zs);
-                zt = fmaf(v, rec[fd::kernel_index(layer, i, ch + fd::C, k)], zt);
-            }
-        xout[((int64_t)b * fd::C + ch) * Ln + g] = xf[ch * XC + H + col] + gate(zs, zt);
-    }
-}
-
 template <int HOP, int DIL>
 __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin, const float *__restrict__ skip, float *__restrict__ xout,
                                                    const float *__restrict__ kpack, int layer, const float4 *__restrict__ wpack16,
@@ -1534,7 +1485,6 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
     // wave) before the staging; hop 64 (two row tiles) the first after the staging, the second after the conv
     static_assert(2 * H <= 64, "one halo column per lane");
     __shared__ __attribute__((aligned(16))) char xs[XC * 128];       // lrelu(x + skip) pieces, row = column + H
-    __shared__ int bad_tile;                                         // an operand of this tile does not fit fp16
     __shared__ __attribute__((aligned(16))) char ys[YC * 128];       // first the raw x + skip of the centre (fp32 [32][256]), then
     static_assert(YC * 128 >= fd::C * W * 4, "parking area");        // the conv output pieces, row = column + 1
     const int Ln = T * HOP;
@@ -1550,7 +1500,6 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
     const int mt0 = (HOP == 256) ? (wave & 1) : 0;
     const int lcw = (HOP == 256) ? 128 * (wave >> 1) : cw;     // first LVC column of this wave
     float mx = 0.0f;                                            // largest operand magnitude seen by this thread
-    if (tid == 0) bad_tile = 0;
     FD_STAMP(0);
 
     float4 ka[LT][12];
@@ -1733,26 +1682,9 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
             *reinterpret_cast<_Float16 *>(ys + h2_off(yrow, 4 + (ho >> 3)) + (ho & 7) * 2) = v2;
         }
     }
-    // every operand of this tile has been seen by now (x, y, and the predicted kernel, which arrived long ago): one that does
-    // not fit fp16 sends the whole workgroup to the plain-fp32 tile routine, in the same LDS, before anything was written
-    if (wave_valid) {
-#pragma unroll
-        for (int m = 0; m < LT; ++m)
-#pragma unroll
-            for (int i = 0; i < 12; ++i) mx = amax4(mx, ka[m][i]);
-    }
-    if (!(mx < GX_LIMIT)) {      // also inf; a NaN operand gives a NaN result on either path
-        bad_tile = 1;
-        atomicOr(range_flag, 1);                      // diagnostics (fd_read_tap "range_flags")
-    }
     FD_STAMP(4);
     __syncthreads();
     FD_STAMP(5);
-    if (bad_tile) {
-        lvc_tile_cold<HOP, DIL>(reinterpret_cast<float *>(xs), reinterpret_cast<float *>(ys), xin, skip, xout, kpack, layer, wref, cbias,
-                                T, Lnb, b, w0);
-        return;
-    }
     if (wave_valid) {
         // ---- LVC: A = the frame's predicted kernel (rows gate-paired: register r <-> sigmoid input, r+8 <-> tanh input of
         //      channel 16*mt + drow(r), r < 8), split into pieces here ----------------------------------------------------
@@ -1762,6 +1694,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
 #pragma unroll
             for (int kg = 0; kg < 6; ++kg) {
                 const float4 &a0 = ka[m][2 * kg], &a1 = ka[m][2 * kg + 1];
+                mx = amax4(amax4(mx, a0), a1);
                 const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
                 split8(v, kh[m][kg], kl[m][kg]);
             }
@@ -1802,6 +1735,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
             }
         }
     }
+    if (!(mx < GX_LIMIT)) atomicOr(range_flag, 1);      // also inf; a NaN operand gives a NaN result on either path
     FD_STAMP(7);
 }
 
@@ -2111,14 +2045,18 @@ static hipError_t launch_lvc(const Launch &L, const char *name, int n, int layer
     constexpr int W = LvcCfg<HOP, DIL>::W;
     const int Ln = T * HOP;
     const float *kp = c->ws.kpack + (int64_t)n * B * T * fd::KREC;
-    if (c->lvc_f16 && w.lvc_f16_ok) {      // fp16 pipe; a tile whose operands do not fit is redone in fp32 inside the kernel
-        FD_LAUNCH(L, name, (k_lvc_h2<HOP, DIL>), dim3((Ln + 255) / 256, B), dim3(256), 0, x_in, skip, x_out, kp, layer,
-                  reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]), w.blk[n].convs[layer].w, w.blk[n].convs[layer].b,
-                  c->ws.range_flag + 1 + n * fd::LAYERS + layer, T, c->step_lens);
-        return hipSuccess;
+    const int *run_if = nullptr;
+    if constexpr (HOP >= 64) {
+        if (c->lvc_f16 && w.lvc_f16_ok) {
+            int *flag = c->ws.range_flag + 1 + n * fd::LAYERS + layer;
+            FD_LAUNCH(L, name, (k_lvc_h2<HOP, DIL>), dim3(((Ln + 255) / 256 + 7) / 8 * 8, B), dim3(256), 0, x_in, skip, x_out, kp, layer,
+                      reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]), w.blk[n].convs[layer].w, w.blk[n].convs[layer].b, flag, T, c->step_lens);
+            run_if = flag;
+            name = "lvc_fp32_fallback";
+        }
     }
     FD_LAUNCH(L, name, (k_lvc_layer<HOP, DIL>), dim3((Ln + W - 1) / W, B), dim3(256), 0, x_in, skip, x_out, kp, layer,
-              w.lvc_conv_pack[n][layer], w.blk[n].convs[layer].w, w.blk[n].convs[layer].b, T, (const int *)nullptr, c->step_lens);
+              w.lvc_conv_pack[n][layer], w.blk[n].convs[layer].w, w.blk[n].convs[layer].b, T, run_if, c->step_lens);
     return hipSuccess;
 }
 
