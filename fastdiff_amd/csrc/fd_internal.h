@@ -115,7 +115,8 @@ struct Workspace {
     float *h_f16 = nullptr;     // fp16 piece image of the predictor hidden state: [3][B][64*ceil(T/64)+2 rows][2 pieces][64] x 2 B
     int *lens_dev = nullptr;    // [B] valid frames per utterance of the current call (ragged batches)
     int *range_flag = nullptr;  // [0] predictor GEMM, [1 + 4*block + layer] LVC layers, [13 + d] DBlocks,
-                                // [16 + n] ConvTranspose of block n, [19] predictor front: an operand did not fit fp16; 32 words, zeroed every step
+                                // [16 + n] ConvTranspose of block n, [19] predictor front: an operand did not fit fp16; 32 words, zeroed every step;
+                                // words 32..63: the same flags of the previous sampler step (skip_after_previous_overflow)
     float *xA = nullptr, *xB = nullptr;                           // [B][32][L] ping-pong
     float *xtap[fd::NBLK] = {}; // block outputs kept for fd_read_tap
     float *mel = nullptr;       // [B][80][T] library-owned copy used by the sampler graph

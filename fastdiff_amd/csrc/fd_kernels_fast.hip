@@ -46,6 +46,17 @@ __device__ __forceinline__ float f4c(const float4 &v, int r) { return r == 0 ? v
 // utterance alone (tests/test_gpu_parity.py); what the output buffers hold behind it is unspecified.
 __device__ __forceinline__ int frames_of(const int *lens, int b, int T) { return lens ? lens[b] : T; }
 
+// Range flags (Workspace::range_flag): word i = "an operand of fp16-pipe launch i did not fit in this step", word 32 + i = the
+// same for the previous step of the sampler (copied by k_advance).  A launch whose flag was raised in the previous step does
+// not try again: it raises its flag at once and leaves the step to the fp32 kernel behind it -- a trajectory that has left the
+// fp16 range (an untrained network over 1000 steps does) then costs the fp32 kernels only, not both.
+__device__ __forceinline__ bool skip_after_previous_overflow(int *flag)
+{
+    if (flag[32] == 0) return false;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) atomicOr(flag, 1);
+    return true;
+}
+
 // ---- 2-piece fp16 operands: v = v1 + 2^-11 v2, v1 = fp16(v), v2 = fp16((v - v1) * 2^11) ----------------
 constexpr float GX_SCALE = 2048.0f, GX_INV_SCALE = 1.0f / 2048.0f;
 constexpr float GX_LIMIT = 32768.0f;            // magnitudes from here on do not fit: the kernels raise a range flag
@@ -273,7 +284,7 @@ __global__ void __launch_bounds__(256, 2) k_dblock_h2(const float *__restrict__ 
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int pbase = blockIdx.x * DB_STRIDE - 7;   // down-sampled position of tile column 0
     const int Lob = lens ? lens[b] * per_frame : Lo;      // this utterance's own length at the output rate
-    if (blockIdx.x * DB_STRIDE >= Lob) return;
+    if (blockIdx.x * DB_STRIDE >= Lob || skip_after_previous_overflow(range_flag)) return;
     float mx = 0.0f;
     // ---- stage the strided pick x[..., ::F]: thread = (8-channel group, column), two columns per thread; zero outside [0, Lo)
     {
@@ -489,6 +500,10 @@ __global__ void __launch_bounds__(256, 2) k_kp_front_h2(const float *__restrict_
     __shared__ __attribute__((aligned(16))) char hB[66 * 256];
     const int blk = blockIdx.z, b = blockIdx.y, t0 = blockIdx.x * KPF_VALID;
     const int Tb = frames_of(lens, b, T);
+    if (range_flags[32 + 19] | range_flags[32]) {      // did not fit in the previous step: fp32 front and fp32 GEMM take this one
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) { atomicOr(range_flags + 19, 1); atomicOr(range_flags, 1); }
+        return;
+    }
     if (t0 > Tb) return;      // the tile holding frame Tb still runs: it writes the zero row the GEMM reads behind the utterance
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int mt = wave & 1, nt = wave >> 1;
@@ -793,6 +808,10 @@ __global__ void __launch_bounds__(256) k_h_split(const float *__restrict__ h, un
     const int bb = blockIdx.y;                           // blk*B + b
     const int e = blockIdx.x * 256 + threadIdx.x, cp = e / R, row = e - cp * R;     // lanes along rows: coalesced h reads
     if (cp >= 32) return;
+    if (range_flag[32] != 0) {      // h did not fit in the previous step: the fp32 GEMM takes this one as well
+        if (e == 0 && bb == 0) atomicOr(range_flag, 1);
+        return;
+    }
     const int t = row - 1;
     const bool ok = t >= 0 && t < frames_of(lens, bb % B, T);
     const float *hb = h + (int64_t)bb * fd::HID * T;
@@ -928,7 +947,7 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm_h2(const char *__restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int XG = fd::KREC / 128;
-    if (*range_flag != 0) return;      // out-of-range operands: the fp32 kernel behind us does this step
+    if (*range_flag != 0) return;      // out-of-range operands (raised by the producer of h): the fp32 kernel behind us does this step
 
     // Work items: id = ((block*XG + column group)*B + utterance)*chunks + chunk; a column group (128 columns, the weights a
     // workgroup keeps in registers) spans ny = B*chunks consecutive ids, one per 64-frame window of the block's h image.
@@ -1121,7 +1140,7 @@ __global__ void __launch_bounds__(256, 2) k_convt_h2(const float *__restrict__ x
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int q0 = blockIdx.x * 128, Lout = Lin * R;
     const int Lb = lens ? lens[b] * per_frame : Lin;      // this utterance's own input length
-    if (q0 >= Lb) return;
+    if (q0 >= Lb || skip_after_previous_overflow(range_flag)) return;
     float mx = 0.0f;
     {   // thread = (8-channel group, position): 130 positions x 4 groups = 520 units
         float v[3][8];
@@ -1493,7 +1512,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
     const int ntile = (T * HOP + W - 1) / W, tile = blockIdx.x;
     const int b = blockIdx.y, w0 = tile * W;
     const int Lnb = frames_of(lens, b, T) * HOP;      // this utterance's own length (ragged batch): every bound below; Ln = row stride
-    if (tile >= ntile || w0 >= Lnb) return;
+    if (tile >= ntile || w0 >= Lnb || skip_after_previous_overflow(range_flag)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int cw = wave * WC;
     const bool wave_valid = (w0 + cw) < Lnb;

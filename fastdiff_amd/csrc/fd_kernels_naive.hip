@@ -340,7 +340,10 @@ hipError_t naive_update(const Launch &L, float *x, const float *eps, int64_t n)
 __global__ void k_advance(StepParams *p, int *range_flags, int inc)
 {
     if (threadIdx.x == 0) p->step_idx += inc;
-    if (threadIdx.x < 32) range_flags[threadIdx.x] = 0;
+    if (threadIdx.x < 32) {      // this step's flags become "previous step" (inc == 0: start of a call, both cleared)
+        range_flags[32 + threadIdx.x] = inc ? range_flags[threadIdx.x] : 0;
+        range_flags[threadIdx.x] = 0;
+    }
 }
 
 hipError_t advance_step(const Launch &L)
