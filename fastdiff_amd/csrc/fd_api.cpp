@@ -195,6 +195,7 @@ int fd_destroy(fd_handle h)
     free_workspace(h);
     for (void *p : h->dev_allocs) hipFree(p);
     if (h->scratch) hipFree(h->scratch);
+    for (void *p : h->mel_allocs) hipFree(p);
     if (h->cap_stream) hipStreamDestroy(h->cap_stream);
     delete h;
     return FD_OK;
@@ -806,6 +807,70 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
     }
     FD_HIP(h, hipMemcpyAsync(out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
     h->last_B = B; h->last_T = T;
+    return FD_OK;
+}
+
+// Tables of the mel front-end, in double precision: twiddles, periodic Hann window, and librosa.filters.mel(22050, 1024, 80, 80,
+// 7600) restated (Slaney mel scale, triangular weights on the FFT bin centres, each filter scaled by 2 / (f[m+2] - f[m])).
+static int ensure_mel_tables(fd_handle h)
+{
+    if (h->mel.tab) return FD_OK;
+    const int NF = 1024, NB = NF / 2 + 1, NM = 80;
+    const double sr = 22050.0, fmin = 80.0, fmax = 7600.0, pi = 3.14159265358979323846;
+    std::vector<float> tab(3 * NF);
+    for (int i = 0; i < NF; ++i) {
+        tab[i] = (float)cos(2.0 * pi * i / NF);
+        tab[NF + i] = (float)sin(2.0 * pi * i / NF);
+        tab[2 * NF + i] = (float)(0.5 - 0.5 * cos(2.0 * pi * i / NF));
+    }
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
+    auto hz_to_mel = [&](double f) { return f >= min_log_hz ? min_log_mel + log(f / min_log_hz) / logstep : f / f_sp; };
+    auto mel_to_hz = [&](double m) { return m >= min_log_mel ? min_log_hz * exp(logstep * (m - min_log_mel)) : f_sp * m; };
+    std::vector<double> mf(NM + 2);
+    const double m0 = hz_to_mel(fmin), m1 = hz_to_mel(fmax);
+    for (int i = 0; i < NM + 2; ++i) mf[i] = mel_to_hz(m0 + (m1 - m0) * i / (NM + 1));
+    std::vector<int> lo(NM), cnt(NM), off(NM);
+    std::vector<float> wts;
+    for (int m = 0; m < NM; ++m) {
+        lo[m] = 0; cnt[m] = 0; off[m] = (int)wts.size();
+        const double enorm = 2.0 / (mf[m + 2] - mf[m]);
+        for (int k = 0; k < NB; ++k) {
+            const double fk = (sr / 2.0) * k / (NB - 1);
+            const double lower = (fk - mf[m]) / (mf[m + 1] - mf[m]), upper = (mf[m + 2] - fk) / (mf[m + 2] - mf[m + 1]);
+            const double wv = std::max(0.0, std::min(lower, upper));
+            if (wv > 0.0) {
+                if (cnt[m] == 0) lo[m] = k;
+                wts.push_back((float)(wv * enorm));
+                ++cnt[m];
+            }
+        }
+    }
+    auto up = [&](const void *src, size_t bytes, const void **dst) -> int {
+        void *d = nullptr;
+        FD_HIP(h, hipMalloc(&d, bytes));
+        h->mel_allocs.push_back(d);
+        FD_HIP(h, hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+        *dst = d;
+        return FD_OK;
+    };
+    int rc;
+    if ((rc = up(lo.data(), lo.size() * sizeof(int), reinterpret_cast<const void **>(&h->mel.fb_lo))) != FD_OK) return rc;
+    if ((rc = up(cnt.data(), cnt.size() * sizeof(int), reinterpret_cast<const void **>(&h->mel.fb_n))) != FD_OK) return rc;
+    if ((rc = up(off.data(), off.size() * sizeof(int), reinterpret_cast<const void **>(&h->mel.fb_off))) != FD_OK) return rc;
+    if ((rc = up(wts.data(), wts.size() * sizeof(float), reinterpret_cast<const void **>(&h->mel.fb_w))) != FD_OK) return rc;
+    return up(tab.data(), tab.size() * sizeof(float), reinterpret_cast<const void **>(&h->mel.tab));      // last: marks the tables ready
+}
+
+int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_samples, float *mel, int T, void *stream)
+{
+    if (!h || !wav || !mel || B <= 0 || n_samples <= 0 || B > 65535) return FD_ERR_INVALID;
+    if (T < 1 || T > 1 + n_samples / 256) FD_FAIL(h, FD_ERR_INVALID, "fd_mel_spectrogram: T=%d outside 1..1+n_samples/256=%lld", T, (long long)(1 + n_samples / 256));
+    FD_HIP(h, hipSetDevice(h->device));
+    int rc = ensure_mel_tables(h);
+    if (rc != FD_OK) return rc;
+    fdk::Launch L = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::mel_frontend(L, wav, B, n_samples, mel, T);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_mel_spectrogram: %s", hipGetErrorString(e));
     return FD_OK;
 }
 

@@ -128,6 +128,13 @@ struct Workspace {
 
 struct ProfEntry { std::string name; hipEvent_t e0, e1; };
 
+// Constant tables of the mel front-end (fd_kernels_mel.hip), built in double precision at fd_create.
+struct MelTables {
+    const float *tab = nullptr;      // cos[1024], sin[1024] of 2*pi*i/1024, periodic Hann window [1024]
+    const int *fb_lo = nullptr, *fb_n = nullptr, *fb_off = nullptr;      // per mel filter: first FFT bin, #bins, offset into fb_w
+    const float *fb_w = nullptr;     // the non-zero weights of librosa.filters.mel(22050, 1024, 80, 80, 7600), filter after filter
+};
+
 struct fd_context {
     fd_config cfg;
     int device = 0;
@@ -148,6 +155,8 @@ struct fd_context {
     std::vector<void *> dev_allocs;          // weight arena pieces
     DevWeights w;
     Workspace ws;
+    MelTables mel;
+    std::vector<void *> mel_allocs;           // device memory behind `mel` (built on first use, freed at fd_destroy)
     int last_B = 0, last_T = 0;
     hipStream_t cap_stream = nullptr;
     hipGraph_t graph = nullptr;
@@ -184,6 +193,7 @@ hipError_t kp_front(const Launch &L, const StepIO &io, int B, int T);
 hipError_t kp_gemm(const Launch &L, int B, int T);
 hipError_t advance_step(const Launch &L);
 hipError_t clear_range_flags(const Launch &L);     // before the first step of a call
+hipError_t mel_frontend(const Launch &L, const float *wav, int B, int64_t n_samples, float *mel, int T);
 hipError_t init_noise(const Launch &L, float *x, int64_t n, unsigned long long seed);
 hipError_t peak_normalize_int16(const Launch &L, const float *wav, int B, int64_t len, int16_t *pcm);
 }  // namespace fdk

@@ -13,7 +13,7 @@ Reference behaviour restated (none of this is on the GPU path, so plain torch/nu
     The reference CLI runs B = 1 (config `max_sentences`); batching is this path's extension: the batch goes down with its
     `lens`, so every item is computed exactly as if it ran alone (and the padding costs nothing), then cropped to its length.
 
-Entry points: load_mel_inputs, collate_test_batch, distributed_sampler_indices, synthesize, save_wavs and a small CLI
+Entry points: load_mel_inputs, load_wav_inputs (device mel front-end), collate_test_batch, distributed_sampler_indices, synthesize, save_wavs and a small CLI
 (`python -m fastdiff_amd.infer --test_input_dir D --out_dir O [--N 4] [--ckpt model.ckpt]`).
 """
 import argparse
@@ -36,6 +36,25 @@ def load_mel_inputs(test_input_dir: str) -> List[dict]:
         if mel.dim() != 2:
             raise ValueError(f"{path}: expected a [T, n_mels] array, got shape {tuple(mel.shape)}")
         # the reference keeps the ".npy" suffix in the name (dataset_utils.py:200), so outputs are "<file>.npy_pred.wav"
+        items.append({"item_name": path[len(test_input_dir) + 1:].replace("/", "_"), "mel": mel, "len": mel.shape[0]})
+    return items
+
+
+def load_wav_inputs(model, test_input_dir: str, sample_rate: int = 22050) -> List[dict]:
+    """Copy-synthesis inputs (`test_input_dir` with recordings, tasks/vocoder/dataset_utils.py:162-184): every *.wav below the
+    directory, in sorted order, through the device mel front-end (`FastDiff.mel_spectrogram` = process_utterance of
+    data_gen/tts/data_gen_utils.py:93-147).  int16 PCM is scaled by 1/32768 as librosa.core.load does; the sample rate must
+    already be the model's (no resampler here)."""
+    from scipy.io import wavfile
+    items = []
+    for path in sorted(glob.glob(f"{test_input_dir}/*.wav")):
+        sr, pcm = wavfile.read(path)
+        if sr != sample_rate:
+            raise ValueError(f"{path}: sample rate {sr}, expected {sample_rate}")
+        if pcm.ndim != 1:
+            raise ValueError(f"{path}: expected mono audio, got shape {pcm.shape}")
+        wav = pcm.astype(np.float32) / 32768.0 if pcm.dtype == np.int16 else pcm.astype(np.float32)
+        mel = model.mel_spectrogram(torch.from_numpy(wav).cuda())[0].transpose(0, 1).contiguous().cpu()      # [T, 80] as on disk
         items.append({"item_name": path[len(test_input_dir) + 1:].replace("/", "_"), "mel": mel, "len": mel.shape[0]})
     return items
 
@@ -104,7 +123,8 @@ def save_wavs(pcm: Dict[str, np.ndarray], out_dir: str, sample_rate: int = 22050
 
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
-    ap.add_argument("--test_input_dir", required=True)
+    ap.add_argument("--test_input_dir", required=True, help="directory of [T,80] .npy mels, or of .wav recordings with --from_wav")
+    ap.add_argument("--from_wav", action="store_true", help="inputs are recordings: compute the mels on the device first")
     ap.add_argument("--out_dir", required=True)
     ap.add_argument("--N", type=int, default=4, help="reverse steps: 3, 4, 6, 8, 200 or 1000 (FastDiff.py:76-93)")
     ap.add_argument("--ckpt", default=None, help="reference checkpoint (state_dict under ['state_dict']['model'])")
@@ -118,7 +138,7 @@ def main(argv=None):
     model = FastDiff().cuda().eval()
     if args.ckpt:
         model.load_state_dict(torch.load(args.ckpt, map_location="cpu")["state_dict"]["model"], strict=True)
-    items = load_mel_inputs(args.test_input_dir)
+    items = load_wav_inputs(model, args.test_input_dir) if args.from_wav else load_mel_inputs(args.test_input_dir)
     mine = [items[i] for i in sorted(set(distributed_sampler_indices(len(items), rank, world)))]
     paths = save_wavs(synthesize(model, mine, args.N, args.max_batch, args.seed + rank), args.out_dir)
     print(f"rank {rank}/{world}: wrote {len(paths)} files to {args.out_dir}")

@@ -204,6 +204,20 @@ class FastDiff(nn.Module):
         _capi.check(lib, h, rc, "fd_peak_normalize_int16")
         return pcm
 
+    def mel_spectrogram(self, wav, n_frames=None):
+        """wav [B, n] float32 in [-1, 1) (int16 PCM / 32768) -> log-mel [B, 80, T], T = 1 + n // 256 by default: the reference's
+        process_utterance(..., vocoder='pwg') (data_gen/tts/data_gen_utils.py:93-147) on the device."""
+        self._require_inference(wav, wav)
+        wav = wav.contiguous().float()
+        if wav.dim() == 1:
+            wav = wav.unsqueeze(0)
+        B, n = wav.shape
+        T = 1 + n // self.hop_length if n_frames is None else int(n_frames)
+        mel = torch.empty((B, 80, T), device=wav.device, dtype=torch.float32)
+        lib, h = self._ready(wav.device)
+        _capi.check(lib, h, lib.fd_mel_spectrogram(h, wav.data_ptr(), B, n, mel.data_ptr(), T, self._stream(wav.device)), "fd_mel_spectrogram")
+        return mel
+
     # ---- options / introspection (tests, bench) ---------------------------------------------------------
     def set_option(self, key, value):
         self._options[key] = str(value)

@@ -117,6 +117,13 @@ FD_API int fd_sample(fd_handle h, const float *mel, int B, int T, const int *len
  * (utils/audio.py:11-16).  wav [B,1,L] device -> pcm [B,L] device int16. */
 FD_API int fd_peak_normalize_int16(fd_handle h, const float *wav, int B, int64_t L, int16_t *pcm, void *stream);
 
+/* Mel front-end in front of the vocoder: process_utterance(..., vocoder='pwg') of
+ * data_gen/tts/data_gen_utils.py:93-147 = librosa.stft(n_fft 1024, hop 256, win 1024, "hann", center, pad_mode "constant") ->
+ * magnitude -> librosa.filters.mel(22050, 1024, 80, fmin 80, fmax 7600) -> log10(max(1e-6, .)).
+ *   wav [B][n_samples] device, float (int16 PCM / 32768, as librosa.core.load scales it)
+ *   mel [B][80][T] device, T <= 1 + n_samples/256 frames (librosa's frame count; the test-time collater then drops the last one). */
+FD_API int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_samples, float *mel, int T, void *stream);
+
 /* Options: "kernels" = "fast" | "naive" (all stages), "kernels.<stage>" for one stage
  * (embed, first, dblock, kp_front, kp_gemm, convt, lvc, final); "graph" = "1" | "0"; "profile" = "1" | "0";
  * "gemm" = "f16x2" (default: predictor GEMM on the fp16 matrix pipe with 2-piece operands, 22 bits each; error below

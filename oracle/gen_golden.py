@@ -281,6 +281,20 @@ def gen_collate():
     print("collate", tuple(out.shape))
 
 
+def gen_frontend():
+    """Realistic-audio fixture for the mel front-end: the shortest of the reference's sample recordings (egs/audios, LJSpeech,
+    public domain) as int16 PCM, with the log-mel the restated front-end (oracle/mel_frontend.py) gives for it."""
+    from scipy.io import wavfile
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mel_frontend as mf
+    sr, pcm = wavfile.read(os.path.join(REF, "egs", "audios", "LJ001-0002_gt.wav"))
+    assert sr == mf.SR and pcm.dtype == np.int16
+    wav = pcm.astype(np.float64) / 32768.0                   # librosa.core.load scaling
+    mel = mf.log_mel(wav)
+    np.savez_compressed(os.path.join(GOLD, "frontend_lj001_0002.npz"), pcm=pcm, mel_f64=mel)
+    print("frontend", pcm.shape, mel.shape, float(mel.min()), float(mel.max()))
+
+
 def gen_statedict_manifest():
     """Key set + shapes of the reference module's state_dict, and a default-init digest, for the drop-in shim test."""
     torch.manual_seed(SEED)
@@ -296,7 +310,7 @@ def gen_statedict_manifest():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["schedule", "embed", "ops", "forward", "sample", "manifest", "collate"]
+    which = sys.argv[1:] or ["schedule", "embed", "ops", "forward", "sample", "manifest", "collate", "frontend"]
     dh = gen_schedule()
     if "embed" in which:
         gen_embed()
@@ -310,4 +324,6 @@ if __name__ == "__main__":
         gen_statedict_manifest()
     if "collate" in which:
         gen_collate()
+    if "frontend" in which:
+        gen_frontend()
     print("golden fixtures written to", GOLD)

@@ -92,3 +92,21 @@ def test_synthesize_directory_end_to_end(tmp_path):
     assert sorted(os.path.basename(p) for p in paths) == ["x.npy_pred.wav", "y.npy_pred.wav", "z.npy_pred.wav"]
     sr, data = wavfile.read(paths[0])
     assert sr == 22050 and np.array_equal(data, pcm[os.path.basename(paths[0])[:-9]])
+
+
+@pytest.mark.gpu
+def test_copy_synthesis_from_a_recording(tmp_path):
+    """wav -> device mel front-end -> vocoder -> wav, through the directory driver (the reference's test_input_dir path)."""
+    import fastdiff_amd
+    from scipy.io import wavfile
+    g = load_golden("frontend_lj001_0002")
+    src = tmp_path / "wavs"
+    src.mkdir()
+    wavfile.write(src / "LJ001-0002.wav", 22050, g["pcm"])
+    torch.manual_seed(1234)
+    model = fastdiff_amd.FastDiff().cuda().eval()
+    items = infer.load_wav_inputs(model, str(src))
+    assert [it["item_name"] for it in items] == ["LJ001-0002.wav"] and items[0]["mel"].shape == (164, 80)
+    assert np.abs(items[0]["mel"].numpy().T - g["mel_f64"])[g["mel_f64"] > -4.0].max() < 2e-4
+    pcm = infer.synthesize(model, items, n_steps=4, max_batch=4, seed=3)
+    assert pcm["LJ001-0002.wav"].shape == (163 * 256,) and pcm["LJ001-0002.wav"].dtype == np.int16      # last frame dropped by the collater
