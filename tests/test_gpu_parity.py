@@ -310,6 +310,21 @@ def test_ragged_batch_with_lens_equals_each_utterance_alone(gc, sched):
         m((cu(audio), cu(mel), cu(steps.reshape(-1, 1))), lens=[300, 0, 150, 1])
 
 
+def test_forward_on_the_mel_of_a_real_recording(model, gc, oracle64):
+    """SURVEY 8c pin (4): a realistic conditioning -- the log-mel of the reference's sample recording LJ001-0002 (163 frames
+    after the collater drops the last one), whose statistics differ from the uniform synthetic mels (silences at -4.8, peaks
+    at +0.6) -- through the whole denoiser against the float64 oracle."""
+    import synth
+    g = load_golden("frontend_lj001_0002")
+    mel = np.ascontiguousarray(g["mel_f64"][None, :, :163]).astype(np.float32)
+    audio = synth.synth_audio(77, 1, 163)
+    steps = np.array([498.0537], np.float32)                      # the N=4 schedule's first mapped step
+    y_ref = oracle64.forward(audio, mel, steps)
+    y = gc.run_forward(model, audio, mel, steps)
+    assert gc.maxdiff(y, y_ref) < FWD_TOL
+    assert not model.read_tap("range_flags").view(np.int32).any()
+
+
 @pytest.mark.parametrize("B,T", [(1, 1), (3, 3), (1, 63), (2, 130)])
 def test_forward_ragged_sizes_against_oracle(model, gc, oracle64, B, T):
     import synth
