@@ -1,5 +1,5 @@
 """Stage-isolation diagnostic (run on the GPU box): all-naive vs oracle, then one fast stage at a time.
-Writes gpurun_out/stage_report.json.   python tools/gpu_diag.py [B T]"""
+Writes gpurun_out/stage_report.json.   python tests/diag_stages.py [B T]"""
 import json
 import os
 import sys
