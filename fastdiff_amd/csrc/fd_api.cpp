@@ -810,40 +810,19 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
     return FD_OK;
 }
 
-// Tables of the mel front-end, in double precision: twiddles, periodic Hann window, and librosa.filters.mel(22050, 1024, 80, 80,
-// 7600) restated (Slaney mel scale, triangular weights on the FFT bin centres, each filter scaled by 2 / (f[m+2] - f[m])).
+// Tables of the mel front-end, in double precision: twiddles, periodic Hann window, and librosa.filters.mel(22050, 1024, 80, fmin,
+// fmax) restated (Slaney mel scale, triangular weights on the FFT bin centres, each filter scaled by 2 / (f[m+2] - f[m])) for the
+// two front-ends of the reference: 'pwg' (fmin 80, fmax 7600; base.yaml:8-9) and Tacotron (0, 8000; FastDiff_tacotron.yaml:20-21).
 static int ensure_mel_tables(fd_handle h)
 {
-    if (h->mel.tab) return FD_OK;
+    if (h->mel[MEL_VARIANTS - 1].tab) return FD_OK;
     const int NF = 1024, NB = NF / 2 + 1, NM = 80;
-    const double sr = 22050.0, fmin = 80.0, fmax = 7600.0, pi = 3.14159265358979323846;
+    const double sr = 22050.0, pi = 3.14159265358979323846;
     std::vector<float> tab(3 * NF);
     for (int i = 0; i < NF; ++i) {
         tab[i] = (float)cos(2.0 * pi * i / NF);
         tab[NF + i] = (float)sin(2.0 * pi * i / NF);
         tab[2 * NF + i] = (float)(0.5 - 0.5 * cos(2.0 * pi * i / NF));
-    }
-    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
-    auto hz_to_mel = [&](double f) { return f >= min_log_hz ? min_log_mel + log(f / min_log_hz) / logstep : f / f_sp; };
-    auto mel_to_hz = [&](double m) { return m >= min_log_mel ? min_log_hz * exp(logstep * (m - min_log_mel)) : f_sp * m; };
-    std::vector<double> mf(NM + 2);
-    const double m0 = hz_to_mel(fmin), m1 = hz_to_mel(fmax);
-    for (int i = 0; i < NM + 2; ++i) mf[i] = mel_to_hz(m0 + (m1 - m0) * i / (NM + 1));
-    std::vector<int> lo(NM), cnt(NM), off(NM);
-    std::vector<float> wts;
-    for (int m = 0; m < NM; ++m) {
-        lo[m] = 0; cnt[m] = 0; off[m] = (int)wts.size();
-        const double enorm = 2.0 / (mf[m + 2] - mf[m]);
-        for (int k = 0; k < NB; ++k) {
-            const double fk = (sr / 2.0) * k / (NB - 1);
-            const double lower = (fk - mf[m]) / (mf[m + 1] - mf[m]), upper = (mf[m + 2] - fk) / (mf[m + 2] - mf[m + 1]);
-            const double wv = std::max(0.0, std::min(lower, upper));
-            if (wv > 0.0) {
-                if (cnt[m] == 0) lo[m] = k;
-                wts.push_back((float)(wv * enorm));
-                ++cnt[m];
-            }
-        }
     }
     auto up = [&](const void *src, size_t bytes, const void **dst) -> int {
         void *d = nullptr;
@@ -853,18 +832,50 @@ static int ensure_mel_tables(fd_handle h)
         *dst = d;
         return FD_OK;
     };
+    const float *tab_dev = nullptr;
     int rc;
-    if ((rc = up(lo.data(), lo.size() * sizeof(int), reinterpret_cast<const void **>(&h->mel.fb_lo))) != FD_OK) return rc;
-    if ((rc = up(cnt.data(), cnt.size() * sizeof(int), reinterpret_cast<const void **>(&h->mel.fb_n))) != FD_OK) return rc;
-    if ((rc = up(off.data(), off.size() * sizeof(int), reinterpret_cast<const void **>(&h->mel.fb_off))) != FD_OK) return rc;
-    if ((rc = up(wts.data(), wts.size() * sizeof(float), reinterpret_cast<const void **>(&h->mel.fb_w))) != FD_OK) return rc;
-    return up(tab.data(), tab.size() * sizeof(float), reinterpret_cast<const void **>(&h->mel.tab));      // last: marks the tables ready
+    if ((rc = up(tab.data(), tab.size() * sizeof(float), reinterpret_cast<const void **>(&tab_dev))) != FD_OK) return rc;
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
+    auto hz_to_mel = [&](double f) { return f >= min_log_hz ? min_log_mel + log(f / min_log_hz) / logstep : f / f_sp; };
+    auto mel_to_hz = [&](double m) { return m >= min_log_mel ? min_log_hz * exp(logstep * (m - min_log_mel)) : f_sp * m; };
+    const double band[MEL_VARIANTS][2] = {{80.0, 7600.0}, {0.0, 8000.0}};
+    for (int v = 0; v < MEL_VARIANTS; ++v) {
+        std::vector<double> mf(NM + 2);
+        const double m0 = hz_to_mel(band[v][0]), m1 = hz_to_mel(band[v][1]);
+        for (int i = 0; i < NM + 2; ++i) mf[i] = mel_to_hz(m0 + (m1 - m0) * i / (NM + 1));
+        std::vector<int> lo(NM), cnt(NM), off(NM);
+        std::vector<float> wts;
+        for (int m = 0; m < NM; ++m) {
+            lo[m] = 0; cnt[m] = 0; off[m] = (int)wts.size();
+            const double enorm = 2.0 / (mf[m + 2] - mf[m]);
+            for (int k = 0; k < NB; ++k) {
+                const double fk = (sr / 2.0) * k / (NB - 1);
+                const double lower = (fk - mf[m]) / (mf[m + 1] - mf[m]), upper = (mf[m + 2] - fk) / (mf[m + 2] - mf[m + 1]);
+                const double wv = std::max(0.0, std::min(lower, upper));
+                if (wv > 0.0) {
+                    if (cnt[m] == 0) lo[m] = k;
+                    wts.push_back((float)(wv * enorm));
+                    ++cnt[m];
+                }
+            }
+        }
+        if (wts.empty()) wts.push_back(0.0f);
+        MelTables &t = h->mel[v];
+        if ((rc = up(lo.data(), lo.size() * sizeof(int), reinterpret_cast<const void **>(&t.fb_lo))) != FD_OK) return rc;
+        if ((rc = up(cnt.data(), cnt.size() * sizeof(int), reinterpret_cast<const void **>(&t.fb_n))) != FD_OK) return rc;
+        if ((rc = up(off.data(), off.size() * sizeof(int), reinterpret_cast<const void **>(&t.fb_off))) != FD_OK) return rc;
+        if ((rc = up(wts.data(), wts.size() * sizeof(float), reinterpret_cast<const void **>(&t.fb_w))) != FD_OK) return rc;
+        t.tab = tab_dev;                                   // last: marks this variant ready
+    }
+    return FD_OK;
 }
 
 int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_samples, float *mel, int T, void *stream)
 {
     if (!h || !wav || !mel || B <= 0 || n_samples <= 0 || B > 65535) return FD_ERR_INVALID;
     if (T < 1 || T > 1 + n_samples / 256) FD_FAIL(h, FD_ERR_INVALID, "fd_mel_spectrogram: T=%d outside 1..1+n_samples/256=%lld", T, (long long)(1 + n_samples / 256));
+    if (h->mel_variant == MEL_TACOTRON && n_samples <= 512)      // F.pad(mode='reflect') needs pad < length (tacotron/stft.py:84-88)
+        FD_FAIL(h, FD_ERR_INVALID, "fd_mel_spectrogram: reflect padding of 512 needs more than 512 samples, got %lld", (long long)n_samples);
     FD_HIP(h, hipSetDevice(h->device));
     int rc = ensure_mel_tables(h);
     if (rc != FD_OK) return rc;
@@ -927,6 +938,12 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
         if (v == "f16x2") h->conv_f16 = true;
         else if (v == "fp32") h->conv_f16 = false;
         else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: conv expects f16x2|fp32, got '%s'", value);
+        return FD_OK;
+    }
+    if (k == "mel") {
+        if (v == "pwg") h->mel_variant = MEL_PWG;
+        else if (v == "tacotron") h->mel_variant = MEL_TACOTRON;
+        else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: mel expects pwg|tacotron, got '%s'", value);
         return FD_OK;
     }
     if (k == "graph") { h->use_graph = on; return FD_OK; }

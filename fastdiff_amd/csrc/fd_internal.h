@@ -132,8 +132,9 @@ struct ProfEntry { std::string name; hipEvent_t e0, e1; };
 struct MelTables {
     const float *tab = nullptr;      // cos[1024], sin[1024] of 2*pi*i/1024, periodic Hann window [1024]
     const int *fb_lo = nullptr, *fb_n = nullptr, *fb_off = nullptr;      // per mel filter: first FFT bin, #bins, offset into fb_w
-    const float *fb_w = nullptr;     // the non-zero weights of librosa.filters.mel(22050, 1024, 80, 80, 7600), filter after filter
+    const float *fb_w = nullptr;     // the non-zero weights of librosa.filters.mel(22050, 1024, 80, fmin, fmax), filter after filter
 };
+enum MelVariant { MEL_PWG = 0, MEL_TACOTRON = 1, MEL_VARIANTS = 2 };
 
 struct fd_context {
     fd_config cfg;
@@ -155,7 +156,8 @@ struct fd_context {
     std::vector<void *> dev_allocs;          // weight arena pieces
     DevWeights w;
     Workspace ws;
-    MelTables mel;
+    MelTables mel[MEL_VARIANTS];             // [MEL_PWG]: fmin 80, fmax 7600; [MEL_TACOTRON]: fmin 0, fmax 8000 (twiddles/window shared)
+    int mel_variant = MEL_PWG;               // option "mel"
     std::vector<void *> mel_allocs;           // device memory behind `mel` (built on first use, freed at fd_destroy)
     int last_B = 0, last_T = 0;
     hipStream_t cap_stream = nullptr;

@@ -8,11 +8,16 @@
 // two passes of 32-term sums through LDS (every table index is an exact integer product mod 32 / 1024; no recurrences), ~700 FMAs per
 // thread instead of the ~4000 LDS-bound ones of a direct DFT (1.29 ms -> see DESIGN.md for B=8 x 864 frames).  The 513 magnitudes go
 // back to LDS and 80 threads apply their triangular filter and the log.
+//
+// TACO = the Tacotron front-end (data_gen/tts/tacotron/layers.py:42-80 TacotronSTFT.mel_spectrogram over tacotron/stft.py:78-104
+// STFT.transform, driven by vocoder_binarizer_tacotron.py:110-116): the same transform with the signal REFLECT-padded by 512
+// (stft.py:84-88), filters.mel(22050, 1024, 80, 0, 8000) and ln(clamp(., 1e-5)) (audio_processing.py:78-84).
 #include "fd_internal.h"
 #include "fd_kernels.h"
 
 namespace fdk {
 
+template <bool TACO>
 __global__ void __launch_bounds__(256) k_mel_frontend(const float *__restrict__ wav, float *__restrict__ mel, const float *__restrict__ tab,
                                                       const int *__restrict__ fb_lo, const int *__restrict__ fb_n,
                                                       const int *__restrict__ fb_off, const float *__restrict__ fb_w, int64_t n_samples,
@@ -24,7 +29,8 @@ __global__ void __launch_bounds__(256) k_mel_frontend(const float *__restrict__ 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = j * 256 + tid;
-        const int64_t p = (int64_t)t * 256 + n - 512;                 // center=True: n_fft/2 zeros in front (pad_mode="constant")
+        int64_t p = (int64_t)t * 256 + n - 512;                       // center=True: n_fft/2 zeros in front (pad_mode="constant")
+        if (TACO) p = p < 0 ? -p : (p >= n_samples ? 2 * (n_samples - 1) - p : p);      // ... or the signal mirrored about its end samples
         ct[n] = tab[n];
         st[n] = tab[1024 + n];
         xw[n] = (p >= 0 && p < n_samples) ? w[p] * tab[2048 + n] : 0.0f;      // periodic Hann window
@@ -77,14 +83,17 @@ __global__ void __launch_bounds__(256) k_mel_frontend(const float *__restrict__ 
         const float *mg = mag + fb_lo[tid];
         float acc = 0.0f;
         for (int j = 0; j < fb_n[tid]; ++j) acc = fmaf(wv[j], mg[j], acc);
-        mel[((int64_t)b * 80 + tid) * T + t] = log10f(fmaxf(1e-6f, acc));
+        mel[((int64_t)b * 80 + tid) * T + t] = TACO ? logf(fmaxf(1e-5f, acc)) : log10f(fmaxf(1e-6f, acc));
     }
 }
 
 hipError_t mel_frontend(const Launch &L, const float *wav, int B, int64_t n_samples, float *mel, int T)
 {
-    const MelTables &m = L.ctx->mel;
-    FD_LAUNCH(L, "mel_frontend", k_mel_frontend, dim3(T, B), dim3(256), 0, wav, mel, m.tab, m.fb_lo, m.fb_n, m.fb_off, m.fb_w, n_samples, T);
+    const MelTables &m = L.ctx->mel[L.ctx->mel_variant];
+    if (L.ctx->mel_variant == MEL_TACOTRON)
+        FD_LAUNCH(L, "mel_frontend_tacotron", k_mel_frontend<true>, dim3(T, B), dim3(256), 0, wav, mel, m.tab, m.fb_lo, m.fb_n, m.fb_off, m.fb_w, n_samples, T);
+    else
+        FD_LAUNCH(L, "mel_frontend", k_mel_frontend<false>, dim3(T, B), dim3(256), 0, wav, mel, m.tab, m.fb_lo, m.fb_n, m.fb_off, m.fb_w, n_samples, T);
     return hipSuccess;
 }
 

@@ -40,11 +40,12 @@ def load_mel_inputs(test_input_dir: str) -> List[dict]:
     return items
 
 
-def load_wav_inputs(model, test_input_dir: str, sample_rate: int = 22050) -> List[dict]:
+def load_wav_inputs(model, test_input_dir: str, sample_rate: int = 22050, mel_variant: str = "pwg") -> List[dict]:
     """Copy-synthesis inputs (`test_input_dir` with recordings, tasks/vocoder/dataset_utils.py:162-184): every *.wav below the
     directory, in sorted order, through the device mel front-end (`FastDiff.mel_spectrogram` = process_utterance of
-    data_gen/tts/data_gen_utils.py:93-147).  int16 PCM is scaled by 1/32768 as librosa.core.load does; the sample rate must
-    already be the model's (no resampler here)."""
+    data_gen/tts/data_gen_utils.py:93-147, or with mel_variant="tacotron" the TacotronSTFT of vocoder_binarizer_tacotron.py:110-116
+    for models trained on FastDiff_tacotron.yaml features).  int16 PCM is scaled by 1/32768 as librosa.core.load does; the sample
+    rate must already be the model's (no resampler here)."""
     from scipy.io import wavfile
     items = []
     for path in sorted(glob.glob(f"{test_input_dir}/*.wav")):
@@ -54,7 +55,7 @@ def load_wav_inputs(model, test_input_dir: str, sample_rate: int = 22050) -> Lis
         if pcm.ndim != 1:
             raise ValueError(f"{path}: expected mono audio, got shape {pcm.shape}")
         wav = pcm.astype(np.float32) / 32768.0 if pcm.dtype == np.int16 else pcm.astype(np.float32)
-        mel = model.mel_spectrogram(torch.from_numpy(wav).cuda())[0].transpose(0, 1).contiguous().cpu()      # [T, 80] as on disk
+        mel = model.mel_spectrogram(torch.from_numpy(wav).cuda(), variant=mel_variant)[0].transpose(0, 1).contiguous().cpu()      # [T, 80] as on disk
         items.append({"item_name": path[len(test_input_dir) + 1:].replace("/", "_"), "mel": mel, "len": mel.shape[0]})
     return items
 
@@ -125,6 +126,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--test_input_dir", required=True, help="directory of [T,80] .npy mels, or of .wav recordings with --from_wav")
     ap.add_argument("--from_wav", action="store_true", help="inputs are recordings: compute the mels on the device first")
+    ap.add_argument("--mel_variant", default="pwg", choices=("pwg", "tacotron"), help="front-end for --from_wav (base.yaml / FastDiff_tacotron.yaml features)")
     ap.add_argument("--out_dir", required=True)
     ap.add_argument("--N", type=int, default=4, help="reverse steps: 3, 4, 6, 8, 200 or 1000 (FastDiff.py:76-93)")
     ap.add_argument("--ckpt", default=None, help="reference checkpoint (state_dict under ['state_dict']['model'])")
@@ -138,7 +140,7 @@ def main(argv=None):
     model = FastDiff().cuda().eval()
     if args.ckpt:
         model.load_state_dict(torch.load(args.ckpt, map_location="cpu")["state_dict"]["model"], strict=True)
-    items = load_wav_inputs(model, args.test_input_dir) if args.from_wav else load_mel_inputs(args.test_input_dir)
+    items = load_wav_inputs(model, args.test_input_dir, mel_variant=args.mel_variant) if args.from_wav else load_mel_inputs(args.test_input_dir)
     mine = [items[i] for i in sorted(set(distributed_sampler_indices(len(items), rank, world)))]
     paths = save_wavs(synthesize(model, mine, args.N, args.max_batch, args.seed + rank), args.out_dir)
     print(f"rank {rank}/{world}: wrote {len(paths)} files to {args.out_dir}")

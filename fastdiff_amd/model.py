@@ -204,17 +204,25 @@ class FastDiff(nn.Module):
         _capi.check(lib, h, rc, "fd_peak_normalize_int16")
         return pcm
 
-    def mel_spectrogram(self, wav, n_frames=None):
-        """wav [B, n] float32 in [-1, 1) (int16 PCM / 32768) -> log-mel [B, 80, T], T = 1 + n // 256 by default: the reference's
-        process_utterance(..., vocoder='pwg') (data_gen/tts/data_gen_utils.py:93-147) on the device."""
+    def mel_spectrogram(self, wav, n_frames=None, variant="pwg"):
+        """wav [B, n] float32 in [-1, 1] (int16 PCM / 32768) -> log-mel [B, 80, T], T = 1 + n // 256 by default, on the device.
+        variant "pwg": the reference's process_utterance(..., vocoder='pwg') (data_gen/tts/data_gen_utils.py:93-147): zero padding,
+        filters 80-7600 Hz, log10(max(1e-6, .)).  variant "tacotron": TacotronSTFT.mel_spectrogram (data_gen/tts/tacotron/layers.py:
+        42-80): reflect padding, filters 0-8000 Hz, ln(clamp(., 1e-5)); asserts the range [-1, 1] like the reference (layers.py:70-71)."""
+        if variant not in ("pwg", "tacotron"):
+            raise ValueError(f"mel_spectrogram: variant must be 'pwg' or 'tacotron', got {variant!r}")
         self._require_inference(wav, wav)
         wav = wav.contiguous().float()
         if wav.dim() == 1:
             wav = wav.unsqueeze(0)
         B, n = wav.shape
+        if variant == "tacotron":
+            assert torch.min(wav) >= -1
+            assert torch.max(wav) <= 1
         T = 1 + n // self.hop_length if n_frames is None else int(n_frames)
         mel = torch.empty((B, 80, T), device=wav.device, dtype=torch.float32)
         lib, h = self._ready(wav.device)
+        _capi.check(lib, h, lib.fd_set_option(h, b"mel", variant.encode()), "fd_set_option")
         _capi.check(lib, h, lib.fd_mel_spectrogram(h, wav.data_ptr(), B, n, mel.data_ptr(), T, self._stream(wav.device)), "fd_mel_spectrogram")
         return mel
 

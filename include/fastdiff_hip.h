@@ -121,7 +121,10 @@ FD_API int fd_peak_normalize_int16(fd_handle h, const float *wav, int B, int64_t
  * data_gen/tts/data_gen_utils.py:93-147 = librosa.stft(n_fft 1024, hop 256, win 1024, "hann", center, pad_mode "constant") ->
  * magnitude -> librosa.filters.mel(22050, 1024, 80, fmin 80, fmax 7600) -> log10(max(1e-6, .)).
  *   wav [B][n_samples] device, float (int16 PCM / 32768, as librosa.core.load scales it)
- *   mel [B][80][T] device, T <= 1 + n_samples/256 frames (librosa's frame count; the test-time collater then drops the last one). */
+ *   mel [B][80][T] device, T <= 1 + n_samples/256 frames (librosa's frame count; the test-time collater then drops the last one).
+ * With option "mel" = "tacotron": TacotronSTFT.mel_spectrogram of data_gen/tts/tacotron/layers.py:42-80 (over tacotron/stft.py:78-104,
+ * as vocoder_binarizer_tacotron.py:110-116 drives it for FastDiff_tacotron.yaml): the signal reflect-padded by 512 instead of
+ * zero-padded (needs n_samples > 512), filters.mel(22050, 1024, 80, 0, 8000), ln(clamp(., 1e-5)). */
 FD_API int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_samples, float *mel, int T, void *stream);
 
 /* Options: "kernels" = "fast" | "naive" (all stages), "kernels.<stage>" for one stage
@@ -130,6 +133,7 @@ FD_API int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_sa
  *          an fp32 sgemm; operands outside the fp16 range fall back to fp32 on the device) | "fp32";
  * "lvc"  = "f16x2" (default: the same for the LVC layers of hop 64 and 256) | "fp32";
  * "conv" = "f16x2" (default: the same for the DBlocks and the ConvTranspose upsamplers) | "fp32";
+ * "mel"  = "pwg" (default) | "tacotron": which of the reference's two mel front-ends fd_mel_spectrogram computes;
  * "taps" = "1" | "0" (keep block outputs for fd_read_tap). */
 FD_API int fd_set_option(fd_handle h, const char *key, const char *value);
 

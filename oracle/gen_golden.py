@@ -295,6 +295,32 @@ def gen_frontend():
     print("frontend", pcm.shape, mel.shape, float(mel.min()), float(mel.max()))
 
 
+def gen_frontend_tacotron():
+    """The same recording through the reference's OWN Tacotron front-end classes (data_gen/tts/tacotron/{layers,stft}.py), executed
+    here.  librosa is absent, so a stand-in module supplies the three names those files import from it: pad_center (identity for
+    win == n_fft), tiny (unused by transform) and filters.mel (the restated filter bank of oracle/mel_frontend.py)."""
+    import types
+    from scipy.io import wavfile
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mel_frontend as mf
+    lib = types.ModuleType("librosa"); lib.util = types.ModuleType("librosa.util"); lib.filters = types.ModuleType("librosa.filters")
+    lib.util.pad_center = lambda w, size, **kw: (w if len(w) == size else np.pad(w, ((size - len(w)) // 2, size - len(w) - (size - len(w)) // 2)))
+    lib.util.tiny = lambda x: np.finfo(np.float32).tiny
+    lib.util.normalize = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError)
+    lib.filters.mel = lambda sr, n_fft, n_mels, fmin, fmax: mf.mel_basis(sr, n_fft, n_mels, fmin, fmax).astype(np.float32)
+    for name, mod in (("librosa", lib), ("librosa.util", lib.util), ("librosa.filters", lib.filters)):
+        sys.modules.setdefault(name, mod)
+    from data_gen.tts.tacotron.layers import TacotronSTFT
+    sr, pcm = wavfile.read(os.path.join(REF, "egs", "audios", "LJ001-0002_gt.wav"))
+    stft = TacotronSTFT(1024, 256, 1024, 80, 22050, 0.0, 8000.0)
+    audio_norm = torch.from_numpy(pcm.astype(np.float32)) / 32768.0              # vocoder_binarizer_tacotron.py:113
+    with torch.no_grad():
+        mel = stft.mel_spectrogram(audio_norm.unsqueeze(0))[0].numpy()
+    ours = mf.tacotron_log_mel(pcm.astype(np.float64) / 32768.0)
+    print("frontend_tacotron", mel.shape, float(mel.min()), float(mel.max()), "restatement max|diff|", float(np.abs(np.exp(mel) - np.exp(ours)).max()))
+    np.savez_compressed(os.path.join(GOLD, "frontend_tacotron_lj001_0002.npz"), mel_ref_f32=mel)
+
+
 def gen_statedict_manifest():
     """Key set + shapes of the reference module's state_dict, and a default-init digest, for the drop-in shim test."""
     torch.manual_seed(SEED)
@@ -310,7 +336,7 @@ def gen_statedict_manifest():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["schedule", "embed", "ops", "forward", "sample", "manifest", "collate", "frontend"]
+    which = sys.argv[1:] or ["schedule", "embed", "ops", "forward", "sample", "manifest", "collate", "frontend", "frontend_tacotron"]
     dh = gen_schedule()
     if "embed" in which:
         gen_embed()
@@ -326,4 +352,6 @@ if __name__ == "__main__":
         gen_collate()
     if "frontend" in which:
         gen_frontend()
+    if "frontend_tacotron" in which:
+        gen_frontend_tacotron()
     print("golden fixtures written to", GOLD)

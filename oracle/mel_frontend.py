@@ -60,3 +60,25 @@ def stft_mag(wav, dtype=np.float64):
 def log_mel(wav, dtype=np.float64):
     """[80, T] log10(max(1e-6, mel_basis @ |STFT|))."""
     return np.log10(np.maximum(EPS, mel_basis().astype(dtype) @ stft_mag(wav, dtype)))
+
+
+# ---- the Tacotron front-end -------------------------------------------------------------------------------------------------------
+# Reference: data_gen/tts/tacotron/layers.py:42-80 (TacotronSTFT, built at vocoder_binarizer_tacotron.py:44-47 with fft 1024, hop 256,
+# win 1024, 80 bins, 22050 Hz, mel_fmin 0, mel_fmax 8000 -- FastDiff_tacotron.yaml:20-21) over tacotron/stft.py:41-104 (STFT):
+#     y reflect-padded by n_fft // 2 (stft.py:84-88); conv1d with the windowed DFT basis, stride hop (:90-94) = the same centered STFT;
+#     magnitude = sqrt(re^2 + im^2) (:100); mel = mel_basis @ magnitude (layers.py:77); log(clamp(mel, min=1e-5)) (audio_processing.py:78-84).
+# PINNED by executing those reference classes (oracle/gen_golden.py gen_frontend_tacotron, with stand-ins for the two absent librosa
+# helpers: pad_center is the identity for win == n_fft, filters.mel is mel_basis() above -- so the filter bank itself stays unpinned).
+TACO_FMIN, TACO_FMAX, TACO_CLIP = 0.0, 8000.0, 1e-5
+
+
+def stft_mag_reflect(wav, dtype=np.float64):
+    y = np.pad(np.asarray(wav, dtype), N_FFT // 2, mode="reflect")
+    T = 1 + (len(y) - N_FFT) // HOP
+    frames = np.lib.stride_tricks.as_strided(y, (T, N_FFT), (y.strides[0] * HOP, y.strides[0]))
+    return np.abs(np.fft.rfft(frames * hann_periodic().astype(dtype), axis=1)).T
+
+
+def tacotron_log_mel(wav, dtype=np.float64):
+    """[80, T] ln(max(1e-5, mel_basis(fmin 0, fmax 8000) @ |STFT of the reflect-padded signal|))."""
+    return np.log(np.maximum(TACO_CLIP, mel_basis(fmin=TACO_FMIN, fmax=TACO_FMAX).astype(dtype) @ stft_mag_reflect(wav, dtype)))

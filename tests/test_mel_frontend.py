@@ -63,6 +63,52 @@ def test_golden_fixture_is_what_the_oracle_gives():
     assert mel.shape == (80, 164) and np.abs(mel - g["mel_f64"]).max() < 1e-12
 
 
+def test_tacotron_restatement_matches_the_reference_classes():
+    """frontend_tacotron_lj001_0002 was produced by EXECUTING the reference's TacotronSTFT / STFT classes (oracle/gen_golden.py
+    gen_frontend_tacotron; float32 conv1d DFT) on the sample recording: the float64 restatement must agree to float32 rounding."""
+    g, t = load_golden("frontend_lj001_0002"), load_golden("frontend_tacotron_lj001_0002")
+    ours = mf.tacotron_log_mel(g["pcm"].astype(np.float64) / 32768.0)
+    ref = t["mel_ref_f32"].astype(np.float64)
+    assert ours.shape == ref.shape == (80, 164)
+    assert np.abs(np.exp(ours) - np.exp(ref)).max() < 1e-5 * np.exp(ref).max()           # linear domain, relative to the loudest bin
+    loud = ref > -7.0                                                                      # mel > 1e-3, two decades above the 1e-5 clamp
+    assert np.abs(ours - ref)[loud].max() < 2e-4
+    # reflect padding really differs from zero padding at the edges, and only there
+    a, b = mf.stft_mag_reflect(g["pcm"] / 32768.0), mf.stft_mag(g["pcm"] / 32768.0)
+    assert np.abs(a - b)[:, 2:-3].max() < 1e-12 and np.abs(a - b)[:, :2].max() > 1e-6
+
+
+@pytest.mark.gpu
+def test_device_tacotron_front_end_matches_the_oracle():
+    import fastdiff_amd
+    torch.manual_seed(1234)
+    model = fastdiff_amd.FastDiff().cuda().eval()
+    g, t = load_golden("frontend_lj001_0002"), load_golden("frontend_tacotron_lj001_0002")
+    rng = np.random.default_rng(6)
+    cases = {"speech": g["pcm"].astype(np.float32) / 32768.0, "noise": (rng.standard_normal(7777) * 0.05).astype(np.float32),
+             "short": (rng.standard_normal(513) * 0.1).astype(np.float32)}
+    for name, wav in cases.items():
+        ref = mf.tacotron_log_mel(wav.astype(np.float64))
+        got = model.mel_spectrogram(torch.from_numpy(wav).cuda(), variant="tacotron")[0].cpu().numpy()
+        assert got.shape == ref.shape
+        lin = np.abs(np.exp(got.astype(np.float64)) - np.exp(ref))
+        loud = ref > -7.0
+        print(name, "max |d ln mel| loud bins %.2e, max |d mel| %.2e" % (np.abs(got - ref)[loud].max(), lin.max()))
+        assert np.abs(got - ref)[loud].max() < 5e-4 and lin.max() < 2e-6 * max(1.0, float(np.exp(ref).max()))
+    # against what the reference's own classes produced for the recording (float32 direct DFT there)
+    got = model.mel_spectrogram(torch.from_numpy(cases["speech"]).cuda(), variant="tacotron")[0].cpu().numpy()
+    assert np.abs(np.exp(got.astype(np.float64)) - np.exp(t["mel_ref_f32"].astype(np.float64))).max() < 1e-5 * float(np.exp(t["mel_ref_f32"]).max())
+    # the default variant is untouched by the option, and the reference's checks are mirrored
+    pwg = model.mel_spectrogram(torch.from_numpy(cases["speech"]).cuda())[0].cpu().numpy()
+    assert np.abs(pwg - mf.log_mel(cases["speech"].astype(np.float64)))[mf.log_mel(cases["speech"].astype(np.float64)) > -4.0].max() < 2e-4
+    with pytest.raises(AssertionError):
+        model.mel_spectrogram(torch.full((1, 4000), 1.5).cuda(), variant="tacotron")       # layers.py:70-71
+    with pytest.raises(Exception, match="reflect"):
+        model.mel_spectrogram(torch.zeros(1, 512).cuda(), variant="tacotron")              # F.pad(reflect) needs pad < length
+    with pytest.raises(ValueError):
+        model.mel_spectrogram(torch.zeros(1, 4000).cuda(), variant="hifigan")
+
+
 @pytest.mark.gpu
 def test_device_front_end_matches_the_oracle():
     import fastdiff_amd
