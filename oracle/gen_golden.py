@@ -264,6 +264,36 @@ def gen_sample(dh):
         print(name, "max|y|", float(np.abs(out[key]).max()), "f32-vs-f64", float(np.abs(out[key] - out[k64]).max()) if k64 in out else None)
 
 
+def gen_noise_scheduling(dh):
+    """util.py:237-288 run on the reference module with synth.stub_noise_pred attached as `noise_pred` (the reference ships no such
+    network) and std_normal replaying a recorded x_T: the schedule it finds, for the DDPM and the "ddim" update."""
+    B, T, N = 1, 5, 8
+    mel = synth.synth_mel(SEED + 300, B, T)
+    x_T = synth.hash_normal(SEED + 300, 1, B * T * 256).reshape(B, 1, T * 256)
+    out = {"mel": mel, "x_T": x_T, "N": np.int64(N), "betaN": np.float64(0.5), "alphaN": np.float64(0.2), "rho": np.float64(1e-3)}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        model = make_model(dt)
+        model.noise_pred = synth.stub_noise_pred
+        fwd = model.forward
+        if dt == torch.float64:
+            model.forward = lambda data: fwd((data[0], data[1].double(), data[2].double()))
+        for ddim in (False, True):
+            orig = ref_util.std_normal
+            ref_util.std_normal = lambda size: torch.from_numpy(x_T.copy()).to(dt).view(*size).clone()
+            stdout, sys.stdout = sys.stdout, open(os.devnull, "w")
+            try:
+                betas = ref_util.noise_scheduling(model, (B, 1, T * 256), {"N": N, "betaN": 0.5, "alphaN": 0.2, "rho": 1e-3, "alpha": dh["alpha"]},
+                                                  condition=torch.from_numpy(mel).to(dt), ddim=ddim)
+            finally:
+                sys.stdout = stdout
+                ref_util.std_normal = orig
+            out[f"betas_{'ddim' if ddim else 'ddpm'}_{tag}"] = betas.double().numpy()
+    np.savez_compressed(os.path.join(GOLD, "noise_scheduling.npz"), **out)
+    for k in sorted(out):
+        if k.startswith("betas"):
+            print(k, out[k])
+
+
 def gen_collate():
     """collate_2d (utils/__init__.py:136-150) cannot be imported (the package needs chardet): its definition is cut out of the
     reference file with ast and executed as is."""
@@ -336,7 +366,7 @@ def gen_statedict_manifest():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["schedule", "embed", "ops", "forward", "sample", "manifest", "collate", "frontend", "frontend_tacotron"]
+    which = sys.argv[1:] or ["schedule", "embed", "ops", "forward", "sample", "manifest", "collate", "frontend", "frontend_tacotron", "noise_scheduling"]
     dh = gen_schedule()
     if "embed" in which:
         gen_embed()
@@ -352,6 +382,8 @@ if __name__ == "__main__":
         gen_collate()
     if "frontend" in which:
         gen_frontend()
+    if "noise_scheduling" in which:
+        gen_noise_scheduling(dh)
     if "frontend_tacotron" in which:
         gen_frontend_tacotron()
     print("golden fixtures written to", GOLD)

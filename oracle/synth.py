@@ -103,3 +103,13 @@ def synth_mel(seed: int, B: int, T: int, lo: float = -6.0, hi: float = 1.5) -> n
 
 def synth_audio(seed: int, B: int, T: int, stream: int = 900002) -> np.ndarray:
     return hash_normal(seed, stream, B * T * 256).reshape(B, 1, T * 256)
+
+
+def stub_noise_pred(x, cond):
+    """A stand-in for the BDDM scheduling network the reference calls but does not ship (`net.noise_pred`, util.py:284-285;
+    SURVEY.md 3.5): any deterministic, smooth function of (x, beta_next, 1 - alpha^2) exercises noise_scheduling's arithmetic.
+    x [B, L]; cond = (beta_next [1,1], delta [1,1]) -> beta [1,1,1] in (0, min(beta_next, delta))."""
+    import torch
+    beta_next, delta = cond
+    ratio = 0.3 + 0.2 * torch.tanh(x.abs().mean())
+    return torch.minimum(beta_next * ratio, delta * 0.9).view(1, 1, 1)

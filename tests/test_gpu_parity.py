@@ -442,6 +442,33 @@ def test_drop_in_sampling_function(model, gc, sched, oracle64):
     assert torch.equal(r1, r2)
 
 
+def test_noise_scheduling_on_the_hip_denoiser(model, gc, sched, monkeypatch):
+    """noise_scheduling (util.py:237-288) with the HIP module as `net` and a stand-in `noise_pred` attached to it: the schedule
+    found must be the one the reference function finds on the reference module (golden: gen_noise_scheduling)."""
+    import fastdiff_amd
+    import synth
+    from fastdiff_amd import sampler
+    g = load_golden("noise_scheduling")
+    monkeypatch.setattr(sampler, "std_normal", lambda size: torch.from_numpy(g["x_T"].copy()).view(*size).cuda())
+    dh = {"N": int(g["N"]), "betaN": float(g["betaN"]), "alphaN": float(g["alphaN"]), "rho": float(g["rho"]),
+          "alpha": torch.from_numpy(sched["train_alpha"])}
+    size = (1, 1, g["x_T"].shape[-1])
+    with pytest.raises(AttributeError):                        # the reference's FastDiff has no noise_pred either (SURVEY.md 3.5)
+        fastdiff_amd.noise_scheduling(model, size, dh, condition=torch.from_numpy(g["mel"]).cuda())
+    model.noise_pred = synth.stub_noise_pred
+    try:
+        for ddim in (False, True):
+            betas = fastdiff_amd.noise_scheduling(model, size, dh, condition=torch.from_numpy(g["mel"]).cuda(), ddim=ddim)
+            key = "betas_ddim" if ddim else "betas_ddpm"
+            assert betas.is_cuda and betas.shape == g[key + "_f32"].shape
+            d64 = np.abs(betas.double().cpu().numpy() - g[key + "_f64"]).max()
+            ref = np.abs(g[key + "_f32"] - g[key + "_f64"]).max()
+            print(key, "max |d beta| vs f64 reference %.2e (fp32 reference: %.2e)" % (d64, ref))
+            assert d64 < 1e-5 * g[key + "_f64"].max()
+    finally:
+        del model.noise_pred
+
+
 def test_philox_noise_statistics(model):
     import fastdiff_amd
     B, T = 4, 16

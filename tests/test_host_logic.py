@@ -166,3 +166,34 @@ def test_foreign_net_host_loop_matches_oracle_update(oracle64):
         if r["add_noise"]:
             x = x + r["sigma"] * noise[k]
         torch.testing.assert_close(seq[k + 1], x)
+
+
+def test_noise_scheduling_host_arithmetic_matches_the_reference(monkeypatch, oracle64):
+    """noise_scheduling (util.py:237-288) with a stand-in noise_pred: golden = the reference function run on the reference module
+    (oracle/gen_golden.py gen_noise_scheduling).  Here the denoiser is the float64 oracle, so what is under test is the host side:
+    step mapping, the DDPM / "ddim" update, the alpha/beta recursion, the stop rules and the order of the returned betas."""
+    import synth
+    from fastdiff_amd import sampler
+    g = load_golden("noise_scheduling")
+    sch = load_golden("schedule")
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)          # the reference (and the shim) hard-code .cuda()
+    monkeypatch.setattr(sampler, "std_normal", lambda size: torch.from_numpy(g["x_T"].copy()).double().view(*size))
+
+    class Net:
+        noise_pred = staticmethod(synth.stub_noise_pred)
+
+        def __call__(self, data):
+            x, c, steps = data
+            return torch.from_numpy(oracle64.forward(x.numpy(), c.numpy(), steps.numpy().reshape(-1)))
+
+    dh = {"N": int(g["N"]), "betaN": float(g["betaN"]), "alphaN": float(g["alphaN"]), "rho": float(g["rho"]), "alpha": torch.from_numpy(sch["train_alpha"])}
+    for ddim in (False, True):
+        betas = sampler.noise_scheduling(Net(), (1, 1, g["x_T"].shape[-1]), dh, condition=torch.from_numpy(g["mel"]).double(), ddim=ddim)
+        ref = g["betas_ddim_f64" if ddim else "betas_ddpm_f64"]
+        assert betas.dtype == torch.float32 and betas.shape == ref.shape
+        assert np.abs(betas.double().numpy() - ref).max() < 1e-6 * ref.max()
+    # the reference's FastDiff has no noise_pred: AttributeError after the first denoiser evaluation, there as here
+    class Bare(Net):
+        noise_pred = property(lambda self: (_ for _ in ()).throw(AttributeError("noise_pred")))
+    with pytest.raises(AttributeError):
+        sampler.noise_scheduling(Bare(), (1, 1, g["x_T"].shape[-1]), dh, condition=torch.from_numpy(g["mel"]).double())
