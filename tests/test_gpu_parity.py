@@ -540,6 +540,68 @@ def test_full_size_sampler_n4(model, gc, sched):
     assert a.shape == (B, 1, T * 256)
 
 
+def test_config4_batch64_ragged_n6(gc, sched):
+    """BASELINE config 4 at one GPU's share and beyond: B=64 zero-padded utterances with T_i ~ U{200..864} (seeded), the N=6
+    schedule (FastDiff.py:86-87), `lens` given.  Properties: finite inside every utterance, reproducible, and sampled utterances
+    (the shortest, the longest, one in the middle of the batch) bit-identical to running them alone."""
+    import synth
+    m = gc.make_model()
+    B, T = 64, 864
+    rng = np.random.default_rng(4)
+    lens = rng.integers(200, 865, B).tolist()
+    lens[17] = 864
+    mel = synth.synth_mel(61, B, T)
+    for b, t in enumerate(lens):
+        mel[b, :, t:] = 0.0
+    rows, _ = gc.table_rows(sched, 6)
+    assert len(rows) == 6
+    x_T = synth.hash_normal(13, 1, B * T * 256).reshape(B, 1, T * 256)
+    melc, xc = torch.from_numpy(mel).cuda(), torch.from_numpy(x_T).cuda()
+    with torch.no_grad():
+        y = m.sample(melc, rows, x_T=xc, seed=5, lens=lens)
+        y2 = m.sample(melc, rows, x_T=xc, seed=5, lens=lens)
+        for b, t in enumerate(lens):
+            assert torch.isfinite(y[b, :, : t * 256]).all(), b
+            assert torch.equal(y[b, :, : t * 256], y2[b, :, : t * 256]), b
+    # Philox noise is indexed by the position in the padded batch, so the alone-runs inject the noise explicitly
+    N = len(rows)
+    picks = [int(np.argmin(lens)), 17, 40]
+    z = np.stack([synth.hash_normal(14, 2 + k, len(picks) * T * 256).reshape(len(picks), 1, T * 256) for k in range(N)])
+    zfull = torch.zeros(N, B, 1, T * 256)
+    for i, b in enumerate(picks):
+        zfull[:, b] = torch.from_numpy(z[:, i])
+    with torch.no_grad():
+        yb = m.sample(melc, rows, x_T=xc, noise=zfull.cuda(), lens=lens)
+        for i, b in enumerate(picks):
+            t = lens[b]
+            alone = m.sample(melc[b:b + 1, :, :t].contiguous(), rows, x_T=xc[b:b + 1, :, : t * 256].contiguous(),
+                             noise=torch.from_numpy(np.ascontiguousarray(z[:, i:i + 1, :, : t * 256])).cuda())
+            assert torch.equal(yb[b, :, : t * 256], alone[0]), b
+    assert not m.read_tap("range_flags").view(np.int32).any()
+
+
+def test_long_utterance_beyond_the_benchmark_length(model, gc):
+    """One 58 s utterance (T = 5000 frames, 1.28 M samples): the tuned kernels against the one-thread-per-output set, and the
+    receptive-field property at the far end (index arithmetic past 2^20 samples per channel, 32 channels -> past 2^25 floats)."""
+    import synth
+    B, T = 1, 5000
+    mel, audio = synth.synth_mel(71, B, T), synth.synth_audio(71, B, T)
+    steps = np.array([23.4676], np.float32)
+    y = gc.run_forward(model, audio, mel, steps)
+    assert np.isfinite(y).all()
+    model.set_option("kernels", "naive")
+    try:
+        y_naive = gc.run_forward(model, audio, mel, steps)
+    finally:
+        model.set_option("kernels", "fast")
+    assert gc.maxdiff(y, y_naive) < FWD_TOL
+    mel2 = mel.copy()
+    mel2[0, :, 4990] -= 1.0
+    d = np.abs(gc.run_forward(model, audio, mel2, steps) - y)[0, 0]
+    changed = np.nonzero(d > 0)[0]
+    assert changed.size > 0 and changed.min() >= (4990 - 16) * 256
+
+
 # ------------------------------------------------------------------------------------------------ epilogue (8f row 1)
 def test_peak_normalize_int16_bit_exact(model, oracle64):
     rng = np.random.default_rng(3)
