@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--ragged", action="store_true",
                     help="BASELINE config 4 style batch: T_i ~ U{200..frames}, zero-padded; RTF counts the valid audio only")
     ap.add_argument("--no-lens", action="store_true", help="with --ragged: do not tell the library the lengths (padded compute)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="library option (fd_set_option), repeatable")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,6 +185,8 @@ def main():
     model = fastdiff_amd.FastDiff().to(dev).eval()
     if args.no_graph:
         model.set_option("graph", "0")
+    for kv in args.opt:
+        model.set_option(*kv.split("=", 1))
     torch.manual_seed(1234 + rank)
     mel = (torch.rand(B, 80, T) * 7.5 - 6.0).to(dev)    # uniform on [mel_vmin, mel_vmax]
     lens = None
