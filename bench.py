@@ -149,6 +149,28 @@ def cpu_baseline(T, rows):
             "samples_per_s": round(T * HOP / dt, 1)}
 
 
+def host_inclusive(model, mel, rows, lens, audio_s, reps=5):
+    """SURVEY.md 8d's wall clock: mel resident on the HOST -> int16 waveform resident on the HOST (pinned buffers, PCIe both ways,
+    the waveform epilogue on the device).  Reported beside `value`, never as `value`: the boundary takes device pointers."""
+    mel_h = mel.cpu().pin_memory()
+    B, _, T = mel.shape
+    pcm_h = torch.empty((B, T * HOP), dtype=torch.int16).pin_memory()
+    with torch.no_grad():
+        def one(i):
+            m = mel_h.to(mel.device, non_blocking=True)
+            pcm = model.peak_normalize_int16(model.sample(m, rows, seed=i, lens=lens))
+            pcm_h.copy_(pcm, non_blocking=True)
+        one(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(reps):
+            one(1 + i)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+    return {"ms_per_step": round(ms, 4), "value": round(audio_s / (ms / 1e3), 2), "unit": "x real-time",
+            "path": "pinned host mel -> device -> fd_sample -> fd_peak_normalize_int16 -> pinned host int16 PCM"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,6 +185,7 @@ def main():
     ap.add_argument("--ragged", action="store_true",
                     help="BASELINE config 4 style batch: T_i ~ U{200..frames}, zero-padded; RTF counts the valid audio only")
     ap.add_argument("--no-lens", action="store_true", help="with --ragged: do not tell the library the lengths (padded compute)")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the extra host-to-host (PCIe-inclusive) measurement")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="library option (fd_set_option), repeatable")
     args = ap.parse_args()
 
@@ -236,6 +259,8 @@ def main():
                    "graph": not args.no_graph, "weights": "random init seed 1234 (no checkpoint offline)",
                    "ragged": (None if not args.ragged else {"lens": lens, "told_to_library": not args.no_lens})},
     }
+    if rank == 0 and world == 1 and not args.no_host_io:
+        line["host_inclusive"] = host_inclusive(model, mel, rows, None if args.no_lens else lens, audio_s)
     if rank == 0 and world == 1:
         if not args.no_roofline:
             roof, table = measure_roofline(model, mel, rows, B, T, N, None if args.no_lens else lens)

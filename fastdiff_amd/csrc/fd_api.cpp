@@ -617,7 +617,10 @@ hipError_t first_conv(const Launch &L, const StepIO &io, int B, int T)
 {
     return L.ctx->fast[ST_FIRST] ? fast_first_conv(L, io, B, T) : naive_first_conv(L, io, B, T);
 }
-hipError_t dblock(const Launch &L, int d, int B, int T) { return L.ctx->fast[ST_DBLOCK] ? fast_dblock(L, d, B, T) : naive_dblock(L, d, B, T); }
+hipError_t dblock(const Launch &L, const StepIO &io, int d, int B, int T)
+{
+    return L.ctx->fast[ST_DBLOCK] ? fast_dblock(L, d, B, T, io.x_in) : naive_dblock(L, d, B, T);
+}
 hipError_t kp_front(const Launch &L, const StepIO &io, int B, int T)
 {
     L.ctx->h_image_ready = false;      // only the fp16-pipe front writes the GEMM's h image itself
@@ -660,7 +663,7 @@ static hipError_t run_step(const Launch &L, const StepIO &io, int B, int T)
     hipError_t e;
     if ((e = first_conv(L, io, B, T)) != hipSuccess) return e;
     for (int d = 0; d < fd::NBLK; ++d)
-        if ((e = dblock(L, d, B, T)) != hipSuccess) return e;
+        if ((e = dblock(L, io, d, B, T)) != hipSuccess) return e;
     if ((e = kp_front(L, io, B, T)) != hipSuccess) return e;
     if ((e = kp_gemm(L, B, T)) != hipSuccess) return e;
     float *x = ws.a[3];

@@ -190,7 +190,7 @@ struct Launch {
 };
 hipError_t embed(const Launch &L, const StepIO &io, int B, int n_steps);
 hipError_t first_conv(const Launch &L, const StepIO &io, int B, int T);
-hipError_t dblock(const Launch &L, int d, int B, int T);
+hipError_t dblock(const Launch &L, const StepIO &io, int d, int B, int T);
 hipError_t kp_front(const Launch &L, const StepIO &io, int B, int T);
 hipError_t kp_gemm(const Launch &L, int B, int T);
 hipError_t advance_step(const Launch &L);

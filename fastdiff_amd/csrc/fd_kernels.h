@@ -14,7 +14,7 @@ hipError_t naive_final_eps(const Launch &L, const float *x32, float *eps, int B,
 hipError_t naive_update(const Launch &L, float *x, const float *eps, int64_t n);
 // fast set (fd_kernels_fast.hip)
 hipError_t fast_first_conv(const Launch &L, const StepIO &io, int B, int T);
-hipError_t fast_dblock(const Launch &L, int d, int B, int T);
+hipError_t fast_dblock(const Launch &L, int d, int B, int T, const float *audio);
 hipError_t fast_kp_front(const Launch &L, const StepIO &io, int B, int T);
 hipError_t fast_kp_gemm(const Launch &L, int B, int T);
 hipError_t fast_convt(const Launch &L, int n, const float *x_in, float *x_out, int B, int Lin);

@@ -270,13 +270,19 @@ __device__ __forceinline__ void store_act_h2(char *img, const f32x16 &ah, const 
     }
 }
 
-template <int F>
+// AUDIO (first DBlock only): its input is first_audio_conv(x), a 1 -> 32 channel k7 conv of which it uses every F-th column.  Those
+// columns are recomputed from the audio (7 samples, 56 FMAs per 8 channels; same operation order as k_first_conv, so the same
+// bits) instead of picked out of the 32-channel tensor: a stride-F pick of fp32 fetches every cache line of it, 226 MB at the
+// benchmark size against 7 MB of audio.
+template <int F, bool AUDIO>
 __global__ void __launch_bounds__(256, 2) k_dblock_h2(const float *__restrict__ xin, float *__restrict__ out,
                                                       const float4 *__restrict__ p0, const float4 *__restrict__ p1,
                                                       const float4 *__restrict__ p2, const float4 *__restrict__ pr,
                                                       const float *__restrict__ b0, const float *__restrict__ b1,
                                                       const float *__restrict__ b2, const float *__restrict__ br, int Lin, int Lo,
-                                                      int *__restrict__ range_flag, const int *__restrict__ lens, int per_frame)
+                                                      int *__restrict__ range_flag, const int *__restrict__ lens, int per_frame,
+                                                      const float *__restrict__ audio, const float *__restrict__ fw,
+                                                      const float *__restrict__ fb)
 {
     __shared__ __attribute__((aligned(16))) char xl[DBH_ROWS * 128];      // leaky_relu(x pick); later the layer-2 output
     __shared__ __attribute__((aligned(16))) char xr[DBH_ROWS * 128];      // raw x pick (1x1 residual)
@@ -293,8 +299,24 @@ __global__ void __launch_bounds__(256, 2) k_dblock_h2(const float *__restrict__ 
         for (int k = 0; k < 2; ++k) {
             const int u = k * 256 + tid, cg = u >> 7, cc = u & 127, p = pbase + cc;
             const bool ok = p >= 0 && p < Lob;
+            if (AUDIO) {
+                const int Lb = Lob * F, t = p * F;                // the utterance's audio length; this column's sample
+                const float *xa = audio + (int64_t)b * Lin;
+                float xv[7];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) v[k][c] = ok ? xin[((int64_t)b * fd::C + cg * 8 + c) * Lin + (int64_t)p * F] : 0.0f;
+                for (int i = 0; i < 7; ++i) xv[i] = (ok && t - 3 + i >= 0 && t - 3 + i < Lb) ? xa[t - 3 + i] : 0.0f;
+                const int o0 = __builtin_amdgcn_readfirstlane(cg) * 8;     // the channel group is uniform over a wave
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    float r = fb[o0 + c];
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) r += fw[(o0 + c) * 7 + i] * xv[i];
+                    v[k][c] = ok ? r : 0.0f;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[k][c] = ok ? xin[((int64_t)b * fd::C + cg * 8 + c) * Lin + (int64_t)p * F] : 0.0f;
+            }
         }
         if (tid < 128) {        // the 8 guard columns of all three images: zeros
             const int g = tid >> 4, row = g < 4 ? g : 128 + g, part = tid & 15;      // 16 x 8 B per 128 B row
@@ -1938,7 +1960,7 @@ hipError_t fast_first_conv(const Launch &L, const StepIO &io, int B, int T)
     return hipSuccess;
 }
 
-hipError_t fast_dblock(const Launch &L, int d, int B, int T)
+hipError_t fast_dblock(const Launch &L, int d, int B, int T, const float *audio)
 {
     fd_context *c = L.ctx;
     const DevWeights &w = c->w;
@@ -1952,12 +1974,17 @@ hipError_t fast_dblock(const Launch &L, int d, int B, int T)
         int *flag = c->ws.range_flag + 13 + d;
         const float4 *q0 = reinterpret_cast<const float4 *>(w.down_h2[d][0]), *q1 = reinterpret_cast<const float4 *>(w.down_h2[d][1]),
                      *q2 = reinterpret_cast<const float4 *>(w.down_h2[d][2]), *q3 = reinterpret_cast<const float4 *>(w.down_h2[d][3]);
-        if (f == 4)
-            FD_LAUNCH(L, n4, k_dblock_h2<4>, grid, dim3(256), 0, c->ws.a[d], c->ws.a[d + 1], q0, q1, q2, q3, w.down[d].conv[0].b,
-                      w.down[d].conv[1].b, w.down[d].conv[2].b, w.down[d].res.b, Lin, Lo, flag, c->step_lens, Lo / T);
+        const float *none = nullptr;
+        if (f == 4 && d == 0 && audio)      // a[0] = first_audio_conv(audio): recomputed at the picked columns, not read
+            FD_LAUNCH(L, n4, (k_dblock_h2<4, true>), grid, dim3(256), 0, c->ws.a[d], c->ws.a[d + 1], q0, q1, q2, q3, w.down[d].conv[0].b,
+                      w.down[d].conv[1].b, w.down[d].conv[2].b, w.down[d].res.b, Lin, Lo, flag, c->step_lens, Lo / T, audio,
+                      (const float *)w.first.w, (const float *)w.first.b);
+        else if (f == 4)
+            FD_LAUNCH(L, n4, (k_dblock_h2<4, false>), grid, dim3(256), 0, c->ws.a[d], c->ws.a[d + 1], q0, q1, q2, q3, w.down[d].conv[0].b,
+                      w.down[d].conv[1].b, w.down[d].conv[2].b, w.down[d].res.b, Lin, Lo, flag, c->step_lens, Lo / T, none, none, none);
         else
-            FD_LAUNCH(L, n8, k_dblock_h2<8>, grid, dim3(256), 0, c->ws.a[d], c->ws.a[d + 1], q0, q1, q2, q3, w.down[d].conv[0].b,
-                      w.down[d].conv[1].b, w.down[d].conv[2].b, w.down[d].res.b, Lin, Lo, flag, c->step_lens, Lo / T);
+            FD_LAUNCH(L, n8, (k_dblock_h2<8, false>), grid, dim3(256), 0, c->ws.a[d], c->ws.a[d + 1], q0, q1, q2, q3, w.down[d].conv[0].b,
+                      w.down[d].conv[1].b, w.down[d].conv[2].b, w.down[d].res.b, Lin, Lo, flag, c->step_lens, Lo / T, none, none, none);
         run_if = flag;
         n4 = n8 = "dblock_fp32_fallback";
     }
