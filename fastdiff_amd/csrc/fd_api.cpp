@@ -171,7 +171,7 @@ static void free_workspace(fd_context *c)
 {
     Workspace &w = c->ws;
     void *ptrs[] = {w.noise, w.a[0], w.a[1], w.a[2], w.a[3], w.kp_h0, w.kp_hA, w.kp_hB, w.kpack, w.h_f16, w.range_flag, w.lens_dev, w.xA, w.xB,
-                    w.xtap[0], w.xtap[1], w.xtap[2], w.mel, w.x, w.steps, w.params};
+                    w.xtap[0], w.xtap[1], w.xtap[2], w.mel, w.x, w.eps_acc, w.steps, w.params};
     for (void *p : ptrs)
         if (p) hipFree(p);
     w = Workspace();
@@ -387,6 +387,14 @@ int fd_commit_weights(fd_handle h)
     };
     if ((rc = up_conv("first_audio_conv", w.first)) != FD_OK) return rc;
     if ((rc = up_conv("final_conv.0", w.final_)) != FD_OK) return rc;
+    {   // the same weights in the order the last LVC layer holds its outputs: channel = 16 mt + 4 hi + (r & 3) + 8 (r >> 2)
+        const std::vector<float> &fw = f["final_conv.0"].w;
+        std::vector<float> ff(4 * 8 * 8, 0.0f);
+        for (int part = 0; part < 4; ++part)
+            for (int r = 0; r < 8; ++r)
+                for (int k = 0; k < 7; ++k) ff[(part * 8 + r) * 8 + k] = fw[(16 * (part >> 1) + 4 * (part & 1) + (r & 3) + 8 * (r >> 2)) * 7 + k];
+        UP(ff, w.final_fuse);
+    }
     // embed MLP, transposed
     auto transpose = [](const std::vector<float> &m, int rows, int cols) {
         std::vector<float> t((size_t)rows * cols);
@@ -594,7 +602,7 @@ static int ensure_workspace(fd_context *h, int B, int T)
     if (e == hipSuccess) e = hipMemset(w.range_flag, 0, 256);
     WS(w.xA, nB * fd::C * L); WS(w.xB, nB * fd::C * L);
     WS(w.xtap[0], nB * fd::C * L / 32); WS(w.xtap[1], nB * fd::C * L / 4); WS(w.xtap[2], nB * fd::C * L);
-    WS(w.mel, (size_t)nB * fd::COND * nT); WS(w.x, nB * L); WS(w.steps, (size_t)std::max(nB, 64));
+    WS(w.mel, (size_t)nB * fd::COND * nT); WS(w.x, nB * L); WS(w.eps_acc, nB * L); WS(w.steps, (size_t)std::max(nB, 64));
 #undef WS
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w.params), sizeof(StepParams));
     if (e == hipSuccess) e = hipMemset(w.params, 0, sizeof(StepParams));
@@ -949,6 +957,7 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
         else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: mel expects pwg|tacotron, got '%s'", value);
         return FD_OK;
     }
+    if (k == "fuse_final") { h->fuse_final = on; drop_graph(h); return FD_OK; }
     if (k == "graph") { h->use_graph = on; return FD_OK; }
     if (k == "profile") { h->profile = on; return FD_OK; }
     if (k == "taps") { h->keep_taps = on; return FD_OK; }

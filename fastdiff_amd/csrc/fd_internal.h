@@ -86,6 +86,7 @@ struct DevWeights {
     const float *up_pack[fd::NBLK] = {};          // ConvTranspose as per-phase A operands: [r phases][8 s4][64][4]
     const uint16_t *up_h2[fd::NBLK] = {};         // ConvTranspose per-phase slices as fp16 pieces: [ph][piece][4 kg][64 lane][8]
     bool convt_f16_ok = false;
+    const float *final_fuse = nullptr;            // final_conv weights in the last LVC layer's register order: [mt*2 + hi][8 r][8] (7 taps + pad)
     const int *kc_perm = nullptr;                 // [24576] reference kernel_conv row -> packed position
     const int *bc_perm = nullptr;                 // [256] reference bias_conv row -> position inside the bias part
 };
@@ -121,6 +122,7 @@ struct Workspace {
     float *xtap[fd::NBLK] = {}; // block outputs kept for fd_read_tap
     float *mel = nullptr;       // [B][80][T] library-owned copy used by the sampler graph
     float *x = nullptr;         // [B][L] running x_t of the sampler
+    float *eps_acc = nullptr;   // [B][L] final_conv sums written by the last LVC layer (k_lvc_h2 FINAL); all zero between steps
     float *steps = nullptr;     // [B] step values for fd_forward
     StepParams *params = nullptr;
     size_t bytes = 0;
@@ -156,6 +158,8 @@ struct fd_context {
     std::vector<void *> dev_allocs;          // weight arena pieces
     DevWeights w;
     Workspace ws;
+    bool fuse_final = true;                  // option "fuse_final": final_conv inside the last LVC layer
+    bool final_fused = false;                // set by the last LVC layer's launch, consumed by fast_final
     MelTables mel[MEL_VARIANTS];             // [MEL_PWG]: fmin 80, fmax 7600; [MEL_TACOTRON]: fmin 0, fmax 8000 (twiddles/window shared)
     int mel_variant = MEL_PWG;               // option "mel"
     std::vector<void *> mel_allocs;           // device memory behind `mel` (built on first use, freed at fd_destroy)

@@ -1513,12 +1513,20 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
 // Operands of magnitude >= 32768 do not fit fp16: the kernel raises *range_flag and the fp32 kernel launched behind it
 // (k_lvc_layer with run_if) redoes the whole layer from the untouched inputs.
 // =================================================================================================
-template <int HOP, int DIL>
+// FINAL (the last layer of the last block): the layer's output has one reader, final_conv (Conv1d 32 -> 1, k7).  Instead of writing
+// 32 channels for that kernel to read back, the workgroup applies the conv to its own 256 columns: every lane folds its 8 channels
+// into 7 per-tap partial sums per column, the four lane groups that share a column meet in LDS (the x image is dead by then), one
+// thread per column adds them in a fixed order and stores the sum to eps_acc; the 3 + 3 columns at each tile edge get the missing
+// taps from the neighbour tile, both sides with one atomic add onto a zeroed word (two addends: the order cannot change the bits).
+// k_final_acc turns eps_acc (+ bias) into eps / the sampler update and leaves it zeroed.
+template <int HOP, int DIL, bool FINAL>
 __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin, const float *__restrict__ skip, float *__restrict__ xout,
                                                    const float *__restrict__ kpack, int layer, const float4 *__restrict__ wpack16,
                                                    const float *__restrict__ wref, const float *__restrict__ cbias,
-                                                   int *__restrict__ range_flag, int T, const int *__restrict__ lens)
+                                                   int *__restrict__ range_flag, int T, const int *__restrict__ lens,
+                                                   float *__restrict__ eps_acc, const float4 *__restrict__ ffuse)
 {
+    static_assert(!FINAL || HOP == 256, "the fused final conv relies on whole-tile utterance lengths");
     constexpr int W = 256, WC = 64, H = (DIL + 1 + 3) & ~3, XC = W + 2 * H, YC = W + 2;
     constexpr int LT = (HOP == 256) ? 1 : 2;           // row tiles per wave   (hop 256: wave = (row tile, column half))
     constexpr int LN = (HOP == 256) ? 4 : 2;           // column tiles per wave
@@ -1771,13 +1779,82 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
                 for (int r = 0; r < 8; ++r) {
                     const int chl = 16 * (mt0 + m) + (r & 3) + 8 * (r >> 2);     // channel minus 4*hi
                     const float zs = fmaf(al[r], GX_INV_SCALE, ah[r]), zt = fmaf(al[r + 8], GX_INV_SCALE, ah[r + 8]);
-                    xo[(unsigned)chl * Lnu + (unsigned)(nt * 32)] = resid[nt][m * 8 + r] + gate(zs, zt);
+                    if constexpr (FINAL) resid[nt][m * 8 + r] += gate(zs, zt);
+                    else xo[(unsigned)chl * Lnu + (unsigned)(nt * 32)] = resid[nt][m * 8 + r] + gate(zs, zt);
                 }
             }
         }
     }
+    if constexpr (FINAL) {
+        // hop 256: utterance lengths are whole tiles, so every wave of a live workgroup is valid and reaches the barrier
+        float *pb = reinterpret_cast<float *>(xs);                   // [part = 2 mt + hi][7 taps][256 columns]
+        {
+            const int part = 2 * mt0 + hi;
+            float fw[8][8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float4 lo4 = ffuse[(part * 8 + r) * 2], hi4 = ffuse[(part * 8 + r) * 2 + 1];
+                fw[r][0] = lo4.x; fw[r][1] = lo4.y; fw[r][2] = lo4.z; fw[r][3] = lo4.w; fw[r][4] = hi4.x; fw[r][5] = hi4.y; fw[r][6] = hi4.z;
+            }
+#pragma unroll
+            for (int nt = 0; nt < LN; ++nt)
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    float pk = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) pk = fmaf(fw[r][k], resid[nt][r], pk);
+                    pb[(part * 7 + k) * W + lcw + nt * 32 + l31] = pk;
+                }
+        }
+        __syncthreads();
+        auto column_sum = [&](int t) {      // eps[t] = sum_k w[k] . out[t + k - 3], restricted to this tile's columns
+            float e = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const int col = t + k - 3;
+                if (col >= 0 && col < W) {
+#pragma unroll
+                    for (int part = 0; part < 4; ++part) e += pb[(part * 7 + k) * W + col];
+                }
+            }
+            return e;
+        };
+        float *ea = eps_acc + (int64_t)b * Ln + w0;
+        const float e = column_sum(tid);
+        if (tid >= 3 && tid < W - 3) ea[tid] = e;
+        else atomicAdd(ea + tid, e);
+        if (tid >= 64 && tid < 70) {         // the taps of the neighbour tiles' edge columns that fall on this tile
+            const int j = tid - 64, t = j < 3 ? j - 3 : W + j - 3;
+            if (w0 + t >= 0 && w0 + t < Lnb) atomicAdd(ea + t, column_sum(t));
+        }
+    }
     if (!(mx < GX_LIMIT)) atomicOr(range_flag, 1);      // also inf; a NaN operand gives a NaN result on either path
     FD_STAMP(7);
+}
+
+// eps_acc (the final_conv sums of k_lvc_h2<..., FINAL>) -> eps = sum + bias -> eps_out or the reverse-step update; eps_acc is left
+// zeroed for the next step.  If that LVC launch flagged its operands the sums are meaningless: they are only cleared here, and the
+// plain k_final behind this launch (run_if) redoes the conv from the fp32 kernel's output.
+__global__ void __launch_bounds__(256) k_final_acc(float *__restrict__ eps_acc, const float *__restrict__ bias, float *__restrict__ eps_out,
+                                                   float *__restrict__ xstate, const StepParams *params, int sampler, int L,
+                                                   int64_t n4_total, const int *__restrict__ lens, const int *__restrict__ overflow)
+{
+    const int b = blockIdx.y;
+    const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int Lb = lens ? lens[b] * fd::HOPT : L;
+    if (t0 >= Lb) return;
+    const int64_t i4 = ((int64_t)b * L + t0) >> 2;
+    float4 acc = reinterpret_cast<const float4 *>(eps_acc)[i4];
+    reinterpret_cast<float4 *>(eps_acc)[i4] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (*overflow) return;
+    const float bv = bias[0];
+    acc = make_float4(acc.x + bv, acc.y + bv, acc.z + bv, acc.w + bv);
+    if (!sampler) {
+        reinterpret_cast<float4 *>(eps_out)[i4] = acc;
+    } else {
+        const float4 xv = reinterpret_cast<const float4 *>(xstate)[i4];
+        reinterpret_cast<float4 *>(xstate)[i4] = fdk::sampler_update4(xv, acc, params, i4, n4_total);
+    }
 }
 
 // =================================================================================================
@@ -1910,8 +1987,9 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h8(const float *__restrict__ xin
 __global__ void __launch_bounds__(256) k_final(const float *__restrict__ x32, const float *__restrict__ w,
                                                const float *__restrict__ bias, float *__restrict__ eps_out,
                                                float *__restrict__ xstate, const StepParams *params, int sampler, int L,
-                                               int64_t n4_total, const int *__restrict__ lens)
+                                               int64_t n4_total, const int *__restrict__ lens, const int *__restrict__ run_if)
 {
+    if (run_if && *run_if == 0) return;      // fallback launch behind k_final_acc: only when the fused last layer flagged its operands
     const int b = blockIdx.y;
     const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
     const int Lb = lens ? lens[b] * fd::HOPT : L;          // this utterance's own length (ragged batch)
@@ -2095,8 +2173,19 @@ static hipError_t launch_lvc(const Launch &L, const char *name, int n, int layer
     if constexpr (HOP >= 64) {
         if (c->lvc_f16 && w.lvc_f16_ok) {
             int *flag = c->ws.range_flag + 1 + n * fd::LAYERS + layer;
-            FD_LAUNCH(L, name, (k_lvc_h2<HOP, DIL>), dim3(((Ln + 255) / 256 + 7) / 8 * 8, B), dim3(256), 0, x_in, skip, x_out, kp, layer,
-                      reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]), w.blk[n].convs[layer].w, w.blk[n].convs[layer].b, flag, T, c->step_lens);
+            // the last layer of the last block feeds final_conv only: fused unless someone wants to look at the block output
+            c->final_fused = false;
+            if constexpr (HOP == 256 && DIL == 27) c->final_fused = c->fast[ST_FINAL] && !c->keep_taps && c->fuse_final;
+            if constexpr (HOP == 256 && DIL == 27) {
+                if (c->final_fused)
+                    FD_LAUNCH(L, name, (k_lvc_h2<HOP, DIL, true>), dim3(((Ln + 255) / 256 + 7) / 8 * 8, B), dim3(256), 0, x_in, skip, x_out, kp,
+                              layer, reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]), w.blk[n].convs[layer].w,
+                              w.blk[n].convs[layer].b, flag, T, c->step_lens, c->ws.eps_acc, reinterpret_cast<const float4 *>(w.final_fuse));
+            }
+            if (!c->final_fused)
+                FD_LAUNCH(L, name, (k_lvc_h2<HOP, DIL, false>), dim3(((Ln + 255) / 256 + 7) / 8 * 8, B), dim3(256), 0, x_in, skip, x_out, kp,
+                          layer, reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]), w.blk[n].convs[layer].w,
+                          w.blk[n].convs[layer].b, flag, T, c->step_lens, (float *)nullptr, (const float4 *)nullptr);
             run_if = flag;
             name = "lvc_fp32_fallback";
         }
@@ -2143,8 +2232,18 @@ hipError_t fast_final(const Launch &L, const StepIO &io, const float *x32, int B
     fd_context *c = L.ctx;
     const DevWeights &w = c->w;
     const int Lf = T * fd::HOPT;
-    FD_LAUNCH(L, "final_conv_update", k_final, dim3((Lf + 1023) / 1024, B), dim3(256), 0, x32, w.final_.w, w.final_.b, io.eps_out,
-              c->ws.x, (const StepParams *)c->ws.params, io.sampler, Lf, (int64_t)B * Lf / 4, c->step_lens);
+    const int *run_if = nullptr;
+    const char *name = "final_conv_update";
+    if (c->final_fused) {       // the last LVC layer already left the conv sums in eps_acc
+        const int *flag = c->ws.range_flag + 1 + 2 * fd::LAYERS + 3;
+        FD_LAUNCH(L, "final_update", k_final_acc, dim3((Lf + 1023) / 1024, B), dim3(256), 0, c->ws.eps_acc, w.final_.b, io.eps_out, c->ws.x,
+                  (const StepParams *)c->ws.params, io.sampler, Lf, (int64_t)B * Lf / 4, c->step_lens, flag);
+        run_if = flag;
+        name = "final_conv_fallback";
+        c->final_fused = false;
+    }
+    FD_LAUNCH(L, name, k_final, dim3((Lf + 1023) / 1024, B), dim3(256), 0, x32, w.final_.w, w.final_.b, io.eps_out,
+              c->ws.x, (const StepParams *)c->ws.params, io.sampler, Lf, (int64_t)B * Lf / 4, c->step_lens, run_if);
     return hipSuccess;
 }
 

@@ -133,6 +133,8 @@ FD_API int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_sa
  *          an fp32 sgemm; operands outside the fp16 range fall back to fp32 on the device) | "fp32";
  * "lvc"  = "f16x2" (default: the same for the LVC layers of hop 64 and 256) | "fp32";
  * "conv" = "f16x2" (default: the same for the DBlocks and the ConvTranspose upsamplers) | "fp32";
+ * "fuse_final" = "1" (default: the last LVC layer applies final_conv to its own tile instead of writing 32 channels for a separate
+ *          kernel to read back; off automatically with "taps") | "0";
  * "mel"  = "pwg" (default) | "tacotron": which of the reference's two mel front-ends fd_mel_spectrogram computes;
  * "taps" = "1" | "0" (keep block outputs for fd_read_tap). */
 FD_API int fd_set_option(fd_handle h, const char *key, const char *value);

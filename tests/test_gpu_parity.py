@@ -213,6 +213,35 @@ def test_lvc_out_of_fp16_range_falls_back_on_device(gc, oracle64):
     assert np.isfinite(y).all() and gc.maxdiff(y, y_ref) < 2e-6 * max(1.0, float(np.abs(y_ref).max()))
 
 
+def test_final_conv_fused_into_the_last_lvc_layer(model, gc, oracle64):
+    """By default the last LVC layer applies final_conv to its own tile and leaves the sums in a zeroed accumulator (two atomic
+    addends per tile-edge word): against the oracle and the unfused pair of kernels (option fuse_final=0); bit-reproducible; an
+    operand outside the fp16 range in that layer falls back to the fp32 layer + the plain final_conv, and the accumulator is
+    clean again for the next call."""
+    import synth
+    B, T = 2, 9                                             # 9 tiles of 256 columns per utterance: 8 inner tile edges each
+    mel, audio = synth.synth_mel(44, B, T), synth.synth_audio(44, B, T)
+    steps = np.array([12.5, 803.0], np.float32)
+    y_ref = oracle64.forward(audio, mel, steps)
+    y_f = gc.run_forward(model, audio, mel, steps)
+    assert not model.read_tap("range_flags").view(np.int32).any()
+    try:
+        model.set_option("fuse_final", "0")
+        y_u = gc.run_forward(model, audio, mel, steps)
+    finally:
+        model.set_option("fuse_final", "1")
+    print("eps max error vs float64 oracle: fused %.2e, unfused %.2e" % (gc.maxdiff(y_f, y_ref), gc.maxdiff(y_u, y_ref)))
+    assert gc.maxdiff(y_f, y_ref) < FWD_TOL and gc.maxdiff(y_u, y_ref) < FWD_TOL
+    assert np.array_equal(gc.run_forward(model, audio, mel, steps), y_f)
+    big = (audio * 3.0e7).astype(np.float32)                # drives every activation of the audio path past 32768
+    y_big_ref = oracle64.forward(big, mel, steps)
+    y_big = gc.run_forward(model, big, mel, steps)
+    flags = model.read_tap("range_flags").view(np.int32)
+    assert flags[12] and flags[0] == 0, flags[:20]
+    assert np.isfinite(y_big).all() and gc.maxdiff(y_big, y_big_ref) < 3e-6 * float(np.abs(y_big_ref).max())
+    assert np.array_equal(gc.run_forward(model, audio, mel, steps), y_f)
+
+
 def test_conv_f16x2_against_fp32_pipe_and_oracle(model, gc, oracle64):
     """DBlocks and ConvTranspose upsamplers: fp16 pipe with 2-piece operands (default) vs option conv=fp32."""
     import synth

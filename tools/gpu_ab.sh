@@ -13,7 +13,7 @@ for line in open('/tmp/ab.log'):
     if line.startswith('{'):
         d = json.loads(line)
         k = d.get('kernels', {})
-        pick = {n: k[n]['avg_us'] for n in ('lvc_layer_h256', 'kp_gemm_f16x2', 'lvc_layer_h64', 'lvc_layer_h8', 'dblock_f4', 'kp_front', 'final_conv_update') if n in k}
+        pick = {n: k[n]['avg_us'] for n in ('lvc_layer_h256', 'kp_gemm_f16x2', 'lvc_layer_h64', 'lvc_layer_h8', 'dblock_f4', 'kp_front', 'final_conv_update', 'final_update') if n in k}
         print(f"{sys.argv[1]:28s} ms/step {d['ms_per_step']:.3f}  {pick}")
 PY
   done
