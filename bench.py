@@ -57,7 +57,7 @@ def kernel_model(name, B, T):
         return "hbm", None, None
     if name == "first_conv":
         return "hbm", 4.0 * B * L * 33, 2.0 * 7 * 32 * B * L
-    if name in ("final_conv_update", "final_conv_fallback"):
+    if name == "final_conv_update":
         return "hbm", 4.0 * B * L * 34, 2.0 * 7 * 32 * B * L
     if name == "final_update":      # the conv itself ran inside the last LVC layer: read + clear the sums, read + write x
         return "hbm", 4.0 * B * L * 4, 0.0

@@ -358,14 +358,18 @@ hipError_t clear_range_flags(const Launch &L)
 }
 
 // ---- waveform epilogue: per-utterance abs-max, then /max * 32767 -> int16 (FastDiff.py:110; utils/audio.py:11-16)
-__global__ void k_absmax(const float *wav, int64_t len, unsigned int *maxbits)
+__global__ void __launch_bounds__(256) k_absmax(const float *wav, int64_t len, unsigned int *maxbits)
 {
+    __shared__ float wm[4];
     const int b = blockIdx.y;
     float m = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x)
         m = fmaxf(m, fabsf(wav[(int64_t)b * len + i]));
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(maxbits + b, __float_as_uint(m));   // non-negative floats order like uints
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    // one atomic per workgroup: thousands of them on B words serialise (measured 43 us for 7 MB with one per wave)
+    if (threadIdx.x == 0) atomicMax(maxbits + b, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));   // non-negative floats order like uints
 }
 
 __global__ void k_to_int16(const float *wav, int64_t len, const unsigned int *maxbits, int16_t *pcm)
@@ -384,7 +388,7 @@ hipError_t peak_normalize_int16(const Launch &L, const float *wav, int B, int64_
     hipError_t e = hipMemsetAsync(maxbits, 0, sizeof(unsigned int) * B, L.stream);
     if (e != hipSuccess) return e;
     const unsigned gx = (unsigned)((len + 256 * 8 - 1) / (256 * 8));
-    FD_LAUNCH(L, "absmax", k_absmax, dim3(gx, B), dim3(256), 0, wav, len, maxbits);
+    FD_LAUNCH(L, "absmax", k_absmax, dim3((gx + 3) / 4, B), dim3(256), 0, wav, len, maxbits);
     FD_LAUNCH(L, "to_int16", k_to_int16, dim3(gx, B), dim3(256), 0, wav, len, (const unsigned int *)maxbits, pcm);
     return hipSuccess;
 }
