@@ -162,6 +162,29 @@ def sampling_given_noise_schedule(net, size, diffusion_hyperparams, inference_no
     return trajectory if return_sequence else x
 
 
+def theta_timestep_loss(net, X, diffusion_hyperparams, reverse=False):
+    """MSE(eps_theta(x_t, mel, t), z) at a random training step per item; same signature as util.py:291-325.
+
+    This is the quantity FastDiffTask.validation_step reports (FastDiff.py:52-57): one denoiser evaluation, no autograd, so it runs
+    on the HIP module as is.  _training_step (FastDiff.py:44-49) calls the same function with gradients enabled: the HIP module
+    has no backward and says so (NotImplementedError from FastDiff.forward) -- training stays on the PyTorch module.
+    Random draws follow the reference order: torch.randint for the steps, then std_normal for z (both on the CPU generator)."""
+    assert type(X) == tuple and len(X) == 2
+    mel_spectrogram, audio = X
+    T_train, alpha = diffusion_hyperparams["T"], diffusion_hyperparams["alpha"]
+    n_items = audio.shape[0]
+    ts = torch.randint(T_train, size=(n_items, 1, 1)).cuda()
+    z = std_normal(audio.shape)
+    alpha_t = alpha.to(ts.device)[ts]
+    delta = (1 - alpha_t ** 2.).sqrt()
+    x_t = alpha_t * audio + delta * z                       # a draw of q(x_t | x_0)
+    eps = net((x_t, mel_spectrogram, ts.view(n_items, 1)))
+    loss = torch.nn.functional.mse_loss(eps, z)
+    if reverse:
+        return loss, (x_t - delta * eps) / alpha_t
+    return loss
+
+
 def noise_scheduling(net, size, diffusion_hyperparams, condition=None, ddim=False):
     """Greedy search of an inference schedule with a learned noise predictor; same signature as util.py:237.
 

@@ -294,6 +294,33 @@ def gen_noise_scheduling(dh):
             print(k, out[k])
 
 
+def gen_theta_loss(dh):
+    """util.py:291-325 on the reference module (what validation_step reports, FastDiff.py:52-57): the random steps and z are
+    recorded (torch.randint / std_normal replaced by replays), loss and the x_0 estimate of reverse=True stored."""
+    B, T = 3, 6
+    mel = synth.synth_mel(SEED + 400, B, T)
+    audio = (0.3 * synth.hash_normal(SEED + 400, 1, B * T * 256)).reshape(B, 1, T * 256).astype(np.float32)
+    z = synth.hash_normal(SEED + 400, 2, B * T * 256).reshape(B, 1, T * 256)
+    ts = np.array([0, 437, 999], np.int64).reshape(B, 1, 1)
+    out = {"mel": mel, "audio": audio, "z": z, "ts": ts}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        model = make_model(dt)
+        net = model if dt == torch.float32 else (lambda data: model((data[0], data[1], data[2].double())))
+        orig_n, orig_r = ref_util.std_normal, torch.randint
+        ref_util.std_normal = lambda size: torch.from_numpy(z.copy()).to(dt).view(*size)
+        torch.randint = lambda *a, **k: torch.from_numpy(ts.copy())
+        try:
+            with torch.no_grad():
+                loss, x0 = ref_util.theta_timestep_loss(net, (torch.from_numpy(mel).to(dt), torch.from_numpy(audio).to(dt)),
+                                                        {"T": dh["T"], "alpha": dh["alpha"].to(dt)}, reverse=True)
+        finally:
+            ref_util.std_normal, torch.randint = orig_n, orig_r
+        out[f"loss_{tag}"] = np.float64(loss.item())
+        out[f"x0_{tag}"] = x0.double().numpy()
+        print("theta_loss", tag, loss.item(), float(x0.abs().max()))
+    np.savez_compressed(os.path.join(GOLD, "theta_loss.npz"), **out)
+
+
 def gen_collate():
     """collate_2d (utils/__init__.py:136-150) cannot be imported (the package needs chardet): its definition is cut out of the
     reference file with ast and executed as is."""
@@ -366,7 +393,7 @@ def gen_statedict_manifest():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["schedule", "embed", "ops", "forward", "sample", "manifest", "collate", "frontend", "frontend_tacotron", "noise_scheduling"]
+    which = sys.argv[1:] or ["schedule", "embed", "ops", "forward", "sample", "manifest", "collate", "frontend", "frontend_tacotron", "noise_scheduling", "theta_loss"]
     dh = gen_schedule()
     if "embed" in which:
         gen_embed()
@@ -382,6 +409,8 @@ if __name__ == "__main__":
         gen_collate()
     if "frontend" in which:
         gen_frontend()
+    if "theta_loss" in which:
+        gen_theta_loss(dh)
     if "noise_scheduling" in which:
         gen_noise_scheduling(dh)
     if "frontend_tacotron" in which:

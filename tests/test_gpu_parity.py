@@ -498,6 +498,29 @@ def test_noise_scheduling_on_the_hip_denoiser(model, gc, sched, monkeypatch):
         del model.noise_pred
 
 
+def test_validation_loss_on_the_hip_denoiser(model, gc, sched, monkeypatch):
+    """FastDiffTask.validation_step = theta_timestep_loss(model, (mels, wavs), dh) (FastDiff.py:52-57), forward only: with the HIP
+    module as `net` the loss and the x_0 estimate must be the reference's (golden: gen_theta_loss, steps and z replayed).  With
+    gradients enabled (_training_step) the HIP module refuses instead of silently returning a constant."""
+    import fastdiff_amd
+    from fastdiff_amd import sampler
+    g = load_golden("theta_loss")
+    monkeypatch.setattr(sampler, "std_normal", lambda size: torch.from_numpy(g["z"].copy()).view(*size).cuda())
+    monkeypatch.setattr(torch, "randint", lambda *a, **k: torch.from_numpy(g["ts"].copy()))
+    dh = {"T": 1000, "alpha": torch.from_numpy(sched["train_alpha"]).cuda()}
+    X = (torch.from_numpy(g["mel"]).cuda(), torch.from_numpy(g["audio"]).cuda())
+    with torch.no_grad():
+        loss, x0 = fastdiff_amd.theta_timestep_loss(model, X, dh, reverse=True)
+    ref_gap = abs(float(g["loss_f32"]) - float(g["loss_f64"]))
+    print("loss %.9f, |d| vs f64 reference %.2e (fp32 reference: %.2e)" % (loss.item(), abs(loss.item() - float(g["loss_f64"])), ref_gap))
+    assert abs(loss.item() - float(g["loss_f64"])) < 1e-6 * float(g["loss_f64"])
+    # x_0 = (x_t - delta eps) / alpha_t: at t = 999 alpha_t is 0.08, so eps errors are amplified 12x
+    assert gc.maxdiff(x0.cpu().numpy(), g["x0_f64"]) < 12.5 * FWD_TOL
+    audio = X[1].clone().requires_grad_(True)
+    with pytest.raises(NotImplementedError, match="inference path only"):
+        fastdiff_amd.theta_timestep_loss(model, (X[0], audio), dh)
+
+
 def test_philox_noise_statistics(model):
     import fastdiff_amd
     B, T = 4, 16

@@ -197,3 +197,23 @@ def test_noise_scheduling_host_arithmetic_matches_the_reference(monkeypatch, ora
         noise_pred = property(lambda self: (_ for _ in ()).throw(AttributeError("noise_pred")))
     with pytest.raises(AttributeError):
         sampler.noise_scheduling(Bare(), (1, 1, g["x_T"].shape[-1]), dh, condition=torch.from_numpy(g["mel"]).double())
+
+
+def test_theta_timestep_loss_host_arithmetic_matches_the_reference(monkeypatch, oracle64):
+    """theta_timestep_loss (util.py:291-325; what validation_step reports): golden = the reference function on the reference
+    module with the random steps and z replayed.  Denoiser = float64 oracle here, so the q(x_t|x_0) mix, the MSE and the x_0
+    estimate of reverse=True are what is under test."""
+    from fastdiff_amd import sampler
+    g, sch = load_golden("theta_loss"), load_golden("schedule")
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    monkeypatch.setattr(sampler, "std_normal", lambda size: torch.from_numpy(g["z"].copy()).double().view(*size))
+    monkeypatch.setattr(torch, "randint", lambda *a, **k: torch.from_numpy(g["ts"].copy()))
+    net = lambda data: torch.from_numpy(oracle64.forward(data[0].numpy(), data[1].numpy(), data[2].numpy().reshape(-1).astype(np.float64)))
+    dh = {"T": 1000, "alpha": torch.from_numpy(sch["train_alpha"]).double()}
+    X = (torch.from_numpy(g["mel"]).double(), torch.from_numpy(g["audio"]).double())
+    loss, x0 = sampler.theta_timestep_loss(net, X, dh, reverse=True)
+    assert abs(loss.item() - float(g["loss_f64"])) < 1e-9 * float(g["loss_f64"])
+    assert np.abs(x0.numpy() - g["x0_f64"]).max() < 1e-9 * np.abs(g["x0_f64"]).max()
+    assert sampler.theta_timestep_loss(net, X, dh).item() == loss.item()
+    with pytest.raises(AssertionError):
+        sampler.theta_timestep_loss(net, [X[0], X[1]], dh)                # util.py:306: X must be a 2-tuple
