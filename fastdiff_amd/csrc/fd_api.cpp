@@ -170,7 +170,7 @@ int fd_create(const fd_config *cfg, int device, fd_handle *out)
 static void free_workspace(fd_context *c)
 {
     Workspace &w = c->ws;
-    void *ptrs[] = {w.noise, w.a[0], w.a[1], w.a[2], w.a[3], w.kp_h0, w.kp_hA, w.kp_hB, w.kpack, w.h_f16, w.range_flag, w.lens_dev, w.xA, w.xB,
+    void *ptrs[] = {w.noise, w.embed_h2, w.a[0], w.a[1], w.a[2], w.a[3], w.kp_h0, w.kp_hA, w.kp_hB, w.kpack, w.h_f16, w.range_flag, w.lens_dev, w.xA, w.xB,
                     w.xtap[0], w.xtap[1], w.xtap[2], w.mel, w.x, w.eps_acc, w.steps, w.params};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -592,6 +592,7 @@ static int ensure_workspace(fd_context *h, int B, int T)
     hipError_t e = hipSuccess;
 #define WS(p, n) if (e == hipSuccess) e = alloc(&(p), (n))
     WS(w.noise, (size_t)1024 * nB * fd::NBLK * fd::COND);
+    WS(w.embed_h2, (size_t)std::max(1024, nB) * fd::E_OUT);
     WS(w.a[0], nB * fd::C * L); WS(w.a[1], nB * fd::C * L / 4); WS(w.a[2], nB * fd::C * L / 32); WS(w.a[3], (size_t)nB * fd::C * nT);
     WS(w.kp_h0, (size_t)fd::NBLK * nB * fd::HID * nT); WS(w.kp_hA, (size_t)fd::NBLK * nB * fd::HID * nT);
     WS(w.kp_hB, (size_t)fd::NBLK * nB * fd::HID * nT);

@@ -110,6 +110,7 @@ enum Stage { ST_EMBED = 0, ST_FIRST, ST_DBLOCK, ST_KP_FRONT, ST_KP_GEMM, ST_CONV
 struct Workspace {
     int B = 0, T = 0;           // capacity
     float *noise = nullptr;     // [1024][B][3][80]
+    float *embed_h2 = nullptr;  // [max(1024, B)][512] second MLP layer of the step embedding, between the two embed kernels
     float *a[4] = {};           // a0..a3
     float *kp_h0 = nullptr, *kp_hA = nullptr, *kp_hB = nullptr;   // [3][B][64][T]
     float *kpack = nullptr;     // [3][B][T][KREC]

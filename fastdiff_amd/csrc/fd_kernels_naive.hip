@@ -260,15 +260,17 @@ hipError_t naive_final_eps(const Launch &L, const float *x32, float *eps, int B,
 namespace fdk {
 
 // a1 + a2: step embedding, 2-layer swish MLP, per-block fc_t  (util.py:407-432; FastDiff_model.py:85-87; modules.py:202)
-// grid (B, n_steps); noise[s][b][blk][80]
-__global__ void __launch_bounds__(512) k_embed(const float *table, const float *w1T, const float *b1, const float *w2T,
-                                              const float *b2, const float *wt0, const float *bt0, const float *wt1,
-                                              const float *bt1, const float *wt2, const float *bt2, const float *steps,
-                                              const StepParams *params, int sampler, float *noise, int B)
+// noise[s][b][blk][80].  A row is one distinct step value: the sampler's step s (the same for every utterance), or utterance b of
+// fd_forward.  The MLP is 1.8 MB of weights against a few hundred outputs: one workgroup per row spent 57 us pulling them through
+// one CU, so the second layer is spread over 8 workgroups per row (each redoes the small first layer) with the k range split
+// over the waves, and the per-block layer runs as a second launch.
+__global__ void __launch_bounds__(512) k_embed_mlp(const float *table, const float *w1T, const float *b1, const float *w2T,
+                                                  const float *b2, const float *steps, const StepParams *params, int sampler,
+                                                  float *h2g)
 {
-    __shared__ float emb[fd::E_IN], h1[fd::E_MID], h2[fd::E_OUT];
-    const int b = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
-    const float t = sampler ? params->table[s].t : steps[b];
+    __shared__ float emb[fd::E_IN], h1[fd::E_MID], part[8][64];
+    const int slice = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
+    const float t = sampler ? params->table[r].t : steps[r];
     if (tid < 64) {
         const float arg = t * table[tid];
         emb[tid] = sinf(arg);
@@ -282,27 +284,58 @@ __global__ void __launch_bounds__(512) k_embed(const float *table, const float *
     }
     __syncthreads();
     {
-        float acc = b2[tid];
-        for (int i = 0; i < fd::E_MID; ++i) acc += w2T[i * fd::E_OUT + tid] * h1[i];
-        h2[tid] = acc / (1.0f + expf(-acc));
+        const int o = slice * 64 + (tid & 63), kp = tid >> 6;
+        float acc = 0.0f;
+#pragma unroll 8
+        for (int i = kp * 64; i < kp * 64 + 64; ++i) acc += w2T[i * fd::E_OUT + o] * h1[i];
+        part[kp][tid & 63] = acc;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float acc = b2[slice * 64 + tid];
+#pragma unroll
+        for (int kp = 0; kp < 8; ++kp) acc += part[kp][tid];
+        h2g[r * fd::E_OUT + slice * 64 + tid] = acc / (1.0f + expf(-acc));
+    }
+}
+
+// per-block fc_t on the rows of k_embed_mlp: thread = (k quarter, output); sampler rows are written for every utterance
+__global__ void __launch_bounds__(1024) k_embed_fct(const float *h2g, const float *wt0, const float *bt0, const float *wt1,
+                                                   const float *bt1, const float *wt2, const float *bt2, int sampler, float *noise, int B)
+{
+    __shared__ float h2[fd::E_OUT], part[4][256];
+    const int r = blockIdx.x, tid = threadIdx.x, o240 = tid & 255, kp = tid >> 8;
+    if (tid < fd::E_OUT) h2[tid] = h2g[r * fd::E_OUT + tid];
+    __syncthreads();
+    const int blk = o240 / fd::COND, o = o240 % fd::COND;
+    if (o240 < fd::NBLK * fd::COND) {
+        const float *wt = blk == 0 ? wt0 : (blk == 1 ? wt1 : wt2);
+        float acc = 0.0f;
+#pragma unroll 8
+        for (int i = kp * 128; i < kp * 128 + 128; ++i) acc += wt[i * fd::COND + o] * h2[i];
+        part[kp][o240] = acc;
     }
     __syncthreads();
     if (tid < fd::NBLK * fd::COND) {
-        const int blk = tid / fd::COND, o = tid % fd::COND;
-        const float *wt = blk == 0 ? wt0 : (blk == 1 ? wt1 : wt2);
         const float *bt = blk == 0 ? bt0 : (blk == 1 ? bt1 : bt2);
-        float acc = bt[o];
-        for (int i = 0; i < fd::E_OUT; ++i) acc += wt[i * fd::COND + o] * h2[i];
-        noise[(((int64_t)s * B + b) * fd::NBLK + blk) * fd::COND + o] = acc;
+        const float v = bt[o] + part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+        if (sampler) {
+            for (int b = 0; b < B; ++b) noise[(((int64_t)r * B + b) * fd::NBLK + blk) * fd::COND + o] = v;
+        } else {
+            noise[((int64_t)r * fd::NBLK + blk) * fd::COND + o] = v;      // s = 0, b = r
+        }
     }
 }
 
 hipError_t embed(const Launch &L, const StepIO &io, int B, int n_steps)
 {
     const DevWeights &w = L.ctx->w;
-    FD_LAUNCH(L, "embed", k_embed, dim3(B, n_steps), dim3(512), 0, w.embed_table, w.fc_t1_T, w.fc_t1_b, w.fc_t2_T, w.fc_t2_b,
-              w.fc_t_T[0], w.fc_t_b[0], w.fc_t_T[1], w.fc_t_b[1], w.fc_t_T[2], w.fc_t_b[2], io.steps, L.ctx->ws.params,
-              io.sampler, L.ctx->ws.noise, B);
+    const int rows = io.sampler ? n_steps : B;
+    float *h2g = L.ctx->ws.embed_h2;        // [max(1024, B) rows][512]
+    FD_LAUNCH(L, "embed", k_embed_mlp, dim3(8, rows), dim3(512), 0, w.embed_table, w.fc_t1_T, w.fc_t1_b, w.fc_t2_T, w.fc_t2_b, io.steps,
+              (const StepParams *)L.ctx->ws.params, io.sampler, h2g);
+    FD_LAUNCH(L, "embed_fct", k_embed_fct, dim3(rows), dim3(1024), 0, (const float *)h2g, w.fc_t_T[0], w.fc_t_b[0], w.fc_t_T[1],
+              w.fc_t_b[1], w.fc_t_T[2], w.fc_t_b[2], io.sampler, L.ctx->ws.noise, B);
     return hipSuccess;
 }
 
