@@ -179,9 +179,11 @@ static void free_workspace(fd_context *c)
 
 static void drop_graph(fd_context *c)
 {
-    if (c->graph_exec) { hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
-    if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
-    c->graph_B = c->graph_T = 0;
+    for (auto &g : c->graphs) {
+        if (g.exec) hipGraphExecDestroy(g.exec);
+        if (g.graph) hipGraphDestroy(g.graph);
+    }
+    c->graphs.clear();
 }
 
 int fd_destroy(fd_handle h)
@@ -793,8 +795,20 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
     const bool graph = h->use_graph && !h->profile;
     if (graph) {
         const unsigned sig = mode_signature(h);
-        if (!h->graph_exec || h->graph_B != B || h->graph_T != T || h->graph_sig != sig) {
-            drop_graph(h);
+        fd_context::StepGraph *sg = nullptr;
+        for (auto &g : h->graphs)
+            if (g.B == B && g.T == T && g.sig == sig) sg = &g;
+        if (!sg) {
+            constexpr size_t FD_MAX_GRAPHS = 16;
+            if (h->graphs.size() >= FD_MAX_GRAPHS) {        // evict the least recently used one (it may still be running)
+                size_t lru = 0;
+                for (size_t i = 1; i < h->graphs.size(); ++i)
+                    if (h->graphs[i].last_use < h->graphs[lru].last_use) lru = i;
+                FD_HIP(h, hipStreamSynchronize(stream));
+                hipGraphExecDestroy(h->graphs[lru].exec);
+                hipGraphDestroy(h->graphs[lru].graph);
+                h->graphs.erase(h->graphs.begin() + lru);
+            }
             FD_HIP(h, hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
             fdk::Launch Lc = {h, h->cap_stream, true};
             e = fdk::run_step(Lc, io, B, T);
@@ -805,11 +819,17 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
                 if (g) hipGraphDestroy(g);
                 FD_FAIL(h, FD_ERR_HIP, "fd_sample: graph capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
             }
-            h->graph = g;
-            FD_HIP(h, hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
-            h->graph_B = B; h->graph_T = T; h->graph_sig = sig;
+            hipGraphExec_t ex = nullptr;
+            hipError_t e3 = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+            if (e3 != hipSuccess) {
+                hipGraphDestroy(g);
+                FD_FAIL(h, FD_ERR_HIP, "fd_sample: hipGraphInstantiate: %s", hipGetErrorString(e3));
+            }
+            h->graphs.push_back({B, T, sig, g, ex, 0});
+            sg = &h->graphs.back();
         }
-        for (int k = 0; k < N; ++k) FD_HIP(h, hipGraphLaunch(h->graph_exec, stream));
+        sg->last_use = ++h->graph_clock;
+        for (int k = 0; k < N; ++k) FD_HIP(h, hipGraphLaunch(sg->exec, stream));
     } else {
         for (int k = 0; k < N; ++k) {
             e = fdk::run_step(L, io, B, T);

@@ -166,10 +166,10 @@ struct fd_context {
     std::vector<void *> mel_allocs;           // device memory behind `mel` (built on first use, freed at fd_destroy)
     int last_B = 0, last_T = 0;
     hipStream_t cap_stream = nullptr;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    int graph_B = 0, graph_T = 0;
-    unsigned graph_sig = 0;
+    // captured denoiser steps, one per (B, T, mode): micro-batches of different padded length alternate without re-capturing
+    struct StepGraph { int B, T; unsigned sig; hipGraph_t graph; hipGraphExec_t exec; unsigned long long last_use; };
+    std::vector<StepGraph> graphs;           // at most FD_MAX_GRAPHS, least recently used evicted
+    unsigned long long graph_clock = 0;
     StepParams *host_params = nullptr;       // pinned staging
     void *scratch = nullptr;                 // 64 KB device scratch (abs-max words, ...)
     std::vector<ProfEntry> prof_pending;

@@ -424,6 +424,27 @@ def test_sampler_graph_replay_equals_eager(model, gc, sched):
     assert torch.equal(a, b) and torch.equal(a, a2)
 
 
+def test_graph_cache_alternating_shapes(gc, sched):
+    """One captured step per (B, T, mode) is kept (micro-batches of different padded length alternate in infer.py): results with
+    the cache warm, after other shapes ran in between, and after more shapes than the cache holds (eviction) must equal the
+    first, freshly captured run bit for bit."""
+    import synth
+    m = gc.make_model()
+    rows, _ = gc.table_rows(sched, 4)
+    shapes = [(2, 5), (1, 9), (3, 2)] + [(1, t) for t in range(10, 30)]          # 23 shapes > 16 cache entries
+    first = {}
+    with torch.no_grad():
+        for rnd in range(2):
+            for (B, T) in shapes if rnd == 0 else shapes[:3] + shapes[-2:] + shapes[:3]:
+                mel = torch.from_numpy(synth.synth_mel(300 + 10 * B + T, B, T)).cuda()
+                y = m.sample(mel, rows, seed=B * 100 + T)
+                if (B, T) in first:
+                    assert torch.equal(y, first[(B, T)]), (rnd, B, T)
+                else:
+                    first[(B, T)] = y.clone()
+    assert all(torch.isfinite(v).all() for v in first.values())
+
+
 def test_n1000_full_schedule_drift(model, gc, sched):
     """BASELINE config 3 (long-loop hipGraph stress): N=1000, drift bounded by 10x the fp32 reference's own."""
     g = load_golden("sample_s4")
