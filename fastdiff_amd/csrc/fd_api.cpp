@@ -158,6 +158,7 @@ int fd_create(const fd_config *cfg, int device, fd_handle *out)
     }
     for (int i = 0; i < ST_COUNT; ++i) c->fast[i] = true;
     if ((e = hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipHostMalloc(reinterpret_cast<void **>(&c->host_params), sizeof(StepParams) * fd_context::PARAM_SLOTS, hipHostMallocDefault)) != hipSuccess ||
         (e = hipMalloc(&c->scratch, 65536)) != hipSuccess) {
         g_create_error = std::string("fd_create: ") + hipGetErrorString(e);
         delete c;
@@ -197,6 +198,9 @@ int fd_destroy(fd_handle h)
     free_workspace(h);
     for (void *p : h->dev_allocs) hipFree(p);
     if (h->scratch) hipFree(h->scratch);
+    if (h->host_params) hipHostFree(h->host_params);
+    for (hipEvent_t ev : h->param_done)
+        if (ev) hipEventDestroy(ev);
     for (void *p : h->mel_allocs) hipFree(p);
     if (h->cap_stream) hipStreamDestroy(h->cap_stream);
     delete h;
@@ -765,20 +769,23 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
     Workspace &ws = h->ws;
     const size_t n_el = (size_t)B * T * fd::HOPT;
 
-    // per-call parameters -> device block the captured kernels read
+    // per-call parameters -> device block the captured kernels read.  Staged through a ring of pinned slots: the call returns
+    // without waiting for the stream, so the host prepares the next call while this one runs.
     {
-        std::vector<char> blob(sizeof(StepParams));
-        StepParams *p = reinterpret_cast<StepParams *>(blob.data());
-        memset(p, 0, sizeof(StepParams));
+        const unsigned slot = h->param_slot++ % fd_context::PARAM_SLOTS;
+        hipEvent_t &done = h->param_done[slot];
+        if (done) FD_HIP(h, hipEventSynchronize(done));            // the upload that last used this slot (8 calls ago)
+        else FD_HIP(h, hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        StepParams *p = h->host_params + slot;
         memcpy(p->table, table, sizeof(fd_step) * N);
-        p->z = z; p->seq = seq_out; p->seed = seed; p->n_steps = N; p->ddim = ddim ? 1 : 0; p->step_idx = 0;
+        p->z = z; p->seq = seq_out; p->seed = seed; p->n_steps = N; p->ddim = ddim ? 1 : 0; p->step_idx = 0; p->pad = 0;
         // only the used prefix of the table plus the trailer needs to travel
         const size_t head = sizeof(fd_step) * N;
         FD_HIP(h, hipMemcpyAsync(ws.params, p, head, hipMemcpyHostToDevice, stream));
         const size_t off = offsetof(StepParams, z);
-        FD_HIP(h, hipMemcpyAsync(reinterpret_cast<char *>(ws.params) + off, blob.data() + off, sizeof(StepParams) - off,
+        FD_HIP(h, hipMemcpyAsync(reinterpret_cast<char *>(ws.params) + off, reinterpret_cast<const char *>(p) + off, sizeof(StepParams) - off,
                                  hipMemcpyHostToDevice, stream));
-        FD_HIP(h, hipStreamSynchronize(stream));   // blob is a stack-lifetime staging buffer
+        FD_HIP(h, hipEventRecord(done, stream));
     }
     FD_HIP(h, hipMemcpyAsync(ws.mel, mel, sizeof(float) * (size_t)B * fd::COND * T, hipMemcpyDeviceToDevice, stream));
     fdk::Launch L = {h, stream, false};

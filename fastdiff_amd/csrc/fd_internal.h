@@ -170,7 +170,10 @@ struct fd_context {
     struct StepGraph { int B, T; unsigned sig; hipGraph_t graph; hipGraphExec_t exec; unsigned long long last_use; };
     std::vector<StepGraph> graphs;           // at most FD_MAX_GRAPHS, least recently used evicted
     unsigned long long graph_clock = 0;
-    StepParams *host_params = nullptr;       // pinned staging
+    static constexpr int PARAM_SLOTS = 8;
+    StepParams *host_params = nullptr;       // pinned staging ring: PARAM_SLOTS per-call parameter blocks, so fd_sample never waits for the stream
+    hipEvent_t param_done[PARAM_SLOTS] = {}; // recorded behind the upload of a slot; waited for before the slot is rewritten
+    unsigned param_slot = 0;
     void *scratch = nullptr;                 // 64 KB device scratch (abs-max words, ...)
     std::vector<ProfEntry> prof_pending;
     std::vector<hipEvent_t> event_pool;
