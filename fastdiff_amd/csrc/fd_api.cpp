@@ -802,9 +802,12 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
     const bool graph = h->use_graph && !h->profile;
     if (graph) {
         const unsigned sig = mode_signature(h);
+        // short schedules are captured whole (one launch per call: ~9 us between two graph launches otherwise); long ones replay
+        // a one-step graph N times
+        const int per_launch = (N <= 8) ? N : 1;
         fd_context::StepGraph *sg = nullptr;
         for (auto &g : h->graphs)
-            if (g.B == B && g.T == T && g.sig == sig) sg = &g;
+            if (g.B == B && g.T == T && g.sig == sig && g.steps == per_launch) sg = &g;
         if (!sg) {
             constexpr size_t FD_MAX_GRAPHS = 16;
             if (h->graphs.size() >= FD_MAX_GRAPHS) {        // evict the least recently used one (it may still be running)
@@ -818,8 +821,10 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
             }
             FD_HIP(h, hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
             fdk::Launch Lc = {h, h->cap_stream, true};
-            e = fdk::run_step(Lc, io, B, T);
-            if (e == hipSuccess) e = fdk::advance_step(Lc);
+            for (int k = 0; k < per_launch && e == hipSuccess; ++k) {
+                e = fdk::run_step(Lc, io, B, T);
+                if (e == hipSuccess) e = fdk::advance_step(Lc);
+            }
             hipGraph_t g = nullptr;
             hipError_t e2 = hipStreamEndCapture(h->cap_stream, &g);
             if (e != hipSuccess || e2 != hipSuccess) {
@@ -832,11 +837,11 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
                 hipGraphDestroy(g);
                 FD_FAIL(h, FD_ERR_HIP, "fd_sample: hipGraphInstantiate: %s", hipGetErrorString(e3));
             }
-            h->graphs.push_back({B, T, sig, g, ex, 0});
+            h->graphs.push_back({B, T, per_launch, sig, g, ex, 0});
             sg = &h->graphs.back();
         }
         sg->last_use = ++h->graph_clock;
-        for (int k = 0; k < N; ++k) FD_HIP(h, hipGraphLaunch(sg->exec, stream));
+        for (int k = 0; k < N; k += per_launch) FD_HIP(h, hipGraphLaunch(sg->exec, stream));
     } else {
         for (int k = 0; k < N; ++k) {
             e = fdk::run_step(L, io, B, T);

@@ -167,7 +167,7 @@ struct fd_context {
     int last_B = 0, last_T = 0;
     hipStream_t cap_stream = nullptr;
     // captured denoiser steps, one per (B, T, mode): micro-batches of different padded length alternate without re-capturing
-    struct StepGraph { int B, T; unsigned sig; hipGraph_t graph; hipGraphExec_t exec; unsigned long long last_use; };
+    struct StepGraph { int B, T, steps; unsigned sig; hipGraph_t graph; hipGraphExec_t exec; unsigned long long last_use; };   // `steps` denoiser steps per launch
     std::vector<StepGraph> graphs;           // at most FD_MAX_GRAPHS, least recently used evicted
     unsigned long long graph_clock = 0;
     static constexpr int PARAM_SLOTS = 8;
