@@ -151,6 +151,29 @@ def cpu_baseline(T, rows):
             "samples_per_s": round(T * HOP / dt, 1)}
 
 
+def torch_eager_baseline(mel, rows, audio_s, reps=3):
+    """The same N-step sampling as plain PyTorch-ROCm eager ops on the same GPU (oracle/torch_eager.py: conv1d / conv_transpose1d /
+    unfold + einsum through MIOpen and rocBLAS, fp32, weights from the same seed): what running the reference's PyTorch code on
+    this box amounts to.  A reported baseline like cpu_baseline, never the thing measured."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import synth
+    from torch_eager import EagerFastDiff
+    m = EagerFastDiff(synth.synth_state_dict(1234), device=mel.device)
+    B, _, T = mel.shape
+    with torch.no_grad():
+        x_T = torch.randn(B, 1, T * HOP, device=mel.device)
+        m.sample(mel, rows, x_T)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = m.sample(mel, rows, x_T)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+    assert torch.isfinite(out).all()
+    return {"ms_per_step": round(ms, 3), "value": round(audio_s / (ms / 1e3), 2), "unit": "x real-time", "kind": "port",
+            "sample": "oracle/torch_eager.py, torch %s eager fp32 on this GPU, B=%d T=%d N=%d, %d repetitions" % (torch.__version__, B, T, len(rows), reps)}
+
+
 def host_inclusive(model, mel, rows, lens, audio_s, reps=5):
     """SURVEY.md 8d's wall clock: mel resident on the HOST -> int16 waveform resident on the HOST (pinned buffers, PCIe both ways,
     the waveform epilogue on the device).  Reported beside `value`, never as `value`: the boundary takes device pointers."""
@@ -187,6 +210,8 @@ def main():
     ap.add_argument("--ragged", action="store_true",
                     help="BASELINE config 4 style batch: T_i ~ U{200..frames}, zero-padded; RTF counts the valid audio only")
     ap.add_argument("--no-lens", action="store_true", help="with --ragged: do not tell the library the lengths (padded compute)")
+    ap.add_argument("--torch-eager-baseline", action="store_true",
+                    help="also time the plain PyTorch-ROCm eager restatement of the same sampling on this GPU (off by default)")
     ap.add_argument("--no-host-io", action="store_true", help="skip the extra host-to-host (PCIe-inclusive) measurement")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="library option (fd_set_option), repeatable")
     args = ap.parse_args()
@@ -268,6 +293,11 @@ def main():
             roof, table = measure_roofline(model, mel, rows, B, T, N, None if args.no_lens else lens)
             line["roofline"] = roof
             line["kernels"] = table
+        if args.torch_eager_baseline:
+            try:
+                line["torch_eager_baseline"] = torch_eager_baseline(mel, rows, audio_s)
+            except Exception as e:
+                line["torch_eager_baseline"] = {"error": repr(e)}
         if not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(T, rows)
