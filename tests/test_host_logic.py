@@ -217,3 +217,28 @@ def test_theta_timestep_loss_host_arithmetic_matches_the_reference(monkeypatch, 
     assert sampler.theta_timestep_loss(net, X, dh).item() == loss.item()
     with pytest.raises(AssertionError):
         sampler.theta_timestep_loss(net, [X[0], X[1]], dh)                # util.py:306: X must be a 2-tuple
+
+
+def test_product_never_touches_the_oracle_or_the_reference():
+    """The shipped package (fastdiff_amd/, bench.py's measured path aside from its baseline legs) must not import, link or open
+    anything under oracle/ or /root/reference: the checker is not the product."""
+    pkg = os.path.join(ROOT, "fastdiff_amd")
+    offenders = []
+    for dirpath, _, files in os.walk(pkg):
+        if os.sep + "build" in dirpath or os.sep + "lib" in dirpath or "__pycache__" in dirpath:
+            continue
+        for fn in files:
+            if not fn.endswith((".py", ".cpp", ".hip", ".h")):
+                continue
+            text = open(os.path.join(dirpath, fn), encoding="utf-8", errors="replace").read()
+            for needle in ("/root/reference", "fdoracle", "import oracle", "from oracle", "torch_eager", "mel_frontend import", "import synth"):
+                if needle in text:
+                    offenders.append((os.path.relpath(os.path.join(dirpath, fn), ROOT), needle))
+    assert not offenders, offenders
+    # and the library links nothing but the HIP runtime and the C/C++ runtime
+    lib = os.path.join(pkg, "lib", "libfastdiff_hip.so")
+    if os.path.exists(lib):
+        import subprocess
+        needed = [l.split("[")[1].rstrip("]\n") for l in subprocess.run(["readelf", "-d", lib], capture_output=True, text=True).stdout.splitlines()
+                  if "(NEEDED)" in l]
+        assert needed and all(n.startswith(("libamdhip64", "libstdc++", "libm.", "libgcc_s", "libc.", "libdl", "libpthread", "librt", "ld-linux")) for n in needed), needed
