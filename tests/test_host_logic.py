@@ -242,3 +242,20 @@ def test_product_never_touches_the_oracle_or_the_reference():
         needed = [l.split("[")[1].rstrip("]\n") for l in subprocess.run(["readelf", "-d", lib], capture_output=True, text=True).stdout.splitlines()
                   if "(NEEDED)" in l]
         assert needed and all(n.startswith(("libamdhip64", "libstdc++", "libm.", "libgcc_s", "libc.", "libdl", "libpthread", "librt", "ld-linux")) for n in needed), needed
+
+
+def test_roofline_numerators_are_the_surveys_algorithmic_figures():
+    """bench.py's `roofline.achieved` = kernel_model bytes / measured time: the bytes must be SURVEY.md 8d's per-call figures
+    (LVC layer: the formula 4*B*T*(96*hop + 6208); the table there quotes 23.94 / 42.73 / 106.39 MB at B=1, T=864, the first two
+    rounded 0.7 % / 0.1 % below the formula) and scale linearly with the batch."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for name, mb, gflop in (("lvc_layer_h8", 23.94, 0.085), ("lvc_layer_h64", 42.73, 0.680), ("lvc_layer_h256", 106.39, 2.718)):
+        bound, nbytes, flops = bench.kernel_model(name, 1, 864)
+        hop = int(name.split("_h")[1])
+        assert bound == "hbm" and nbytes == 4.0 * 864 * (96 * hop + 6208) and abs(nbytes / 1e6 / mb - 1.0) < 0.01, (name, nbytes)
+        assert flops >= gflop * 1e9                               # the fused layer also counts its dilated conv
+        assert bench.kernel_model(name, 8, 864)[1] == 8 * nbytes
+    assert bench.HBM_PEAK_GBS == 8000.0
