@@ -802,13 +802,15 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
     const bool graph = h->use_graph && !h->profile;
     if (graph) {
         const unsigned sig = mode_signature(h);
-        // short schedules are captured whole (one launch per call: ~9 us between two graph launches otherwise); long ones replay
-        // a one-step graph N times
-        const int per_launch = (N <= 8) ? N : 1;
-        fd_context::StepGraph *sg = nullptr;
-        for (auto &g : h->graphs)
-            if (g.B == B && g.T == T && g.sig == sig && g.steps == per_launch) sg = &g;
-        if (!sg) {
+        // A graph holds up to 8 consecutive denoiser steps (there are ~9 us between two graph launches): a short schedule is one
+        // launch per call, a long one a series of 8-step launches and a shorter one for the remainder.
+        auto graph_of = [&](int steps, hipGraphExec_t *out) -> int {
+            for (auto &g : h->graphs)
+                if (g.B == B && g.T == T && g.sig == sig && g.steps == steps) {
+                    g.last_use = ++h->graph_clock;
+                    *out = g.exec;
+                    return FD_OK;
+                }
             constexpr size_t FD_MAX_GRAPHS = 16;
             if (h->graphs.size() >= FD_MAX_GRAPHS) {        // evict the least recently used one (it may still be running)
                 size_t lru = 0;
@@ -821,15 +823,16 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
             }
             FD_HIP(h, hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
             fdk::Launch Lc = {h, h->cap_stream, true};
-            for (int k = 0; k < per_launch && e == hipSuccess; ++k) {
-                e = fdk::run_step(Lc, io, B, T);
-                if (e == hipSuccess) e = fdk::advance_step(Lc);
+            hipError_t ec = hipSuccess;
+            for (int k = 0; k < steps && ec == hipSuccess; ++k) {
+                ec = fdk::run_step(Lc, io, B, T);
+                if (ec == hipSuccess) ec = fdk::advance_step(Lc);
             }
             hipGraph_t g = nullptr;
             hipError_t e2 = hipStreamEndCapture(h->cap_stream, &g);
-            if (e != hipSuccess || e2 != hipSuccess) {
+            if (ec != hipSuccess || e2 != hipSuccess) {
                 if (g) hipGraphDestroy(g);
-                FD_FAIL(h, FD_ERR_HIP, "fd_sample: graph capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+                FD_FAIL(h, FD_ERR_HIP, "fd_sample: graph capture failed: %s", hipGetErrorString(ec != hipSuccess ? ec : e2));
             }
             hipGraphExec_t ex = nullptr;
             hipError_t e3 = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
@@ -837,11 +840,20 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
                 hipGraphDestroy(g);
                 FD_FAIL(h, FD_ERR_HIP, "fd_sample: hipGraphInstantiate: %s", hipGetErrorString(e3));
             }
-            h->graphs.push_back({B, T, per_launch, sig, g, ex, 0});
-            sg = &h->graphs.back();
+            h->graphs.push_back({B, T, steps, sig, g, ex, ++h->graph_clock});
+            *out = ex;
+            return FD_OK;
+        };
+        constexpr int CHUNK = 8;
+        hipGraphExec_t g_chunk = nullptr, g_rest = nullptr;
+        if (N >= CHUNK && (rc = graph_of(CHUNK, &g_chunk)) != FD_OK) return rc;
+        if (N % CHUNK && (rc = graph_of(N % CHUNK, &g_rest)) != FD_OK) return rc;
+        if (N >= CHUNK && (N % CHUNK)) {      // the second capture may have evicted the first (full cache): look it up again
+            if ((rc = graph_of(CHUNK, &g_chunk)) != FD_OK) return rc;
+            if ((rc = graph_of(N % CHUNK, &g_rest)) != FD_OK) return rc;
         }
-        sg->last_use = ++h->graph_clock;
-        for (int k = 0; k < N; k += per_launch) FD_HIP(h, hipGraphLaunch(sg->exec, stream));
+        for (int k = 0; k + CHUNK <= N; k += CHUNK) FD_HIP(h, hipGraphLaunch(g_chunk, stream));
+        if (N % CHUNK) FD_HIP(h, hipGraphLaunch(g_rest, stream));
     } else {
         for (int k = 0; k < N; ++k) {
             e = fdk::run_step(L, io, B, T);

@@ -108,8 +108,8 @@ FD_API int fd_forward(fd_handle h, const float *x, const float *mel, const float
  *           (the reference draws std_normal on the CPU each step, util.py:63-68,229).  NULL -> Philox.
  *   out     [B,1,L] device result x_0.
  *   seq_out nullable, [N+1,B,1,L] device: x after each step, seq_out[0] = x_T (return_sequence=True, util.py:212-214,230-234).
- * The N-step loop is replayed from a hipGraph (one captured denoiser step per (B, T), up to 16 kept; step scalars are read from a
- * device table, so the graph does not depend on N, the schedule or the caller's pointers). */
+ * The N-step loop is replayed from hipGraphs of up to 8 captured denoiser steps (kept per (B, T), 16 at most; step scalars are read
+ * from a device table, so a graph does not depend on the schedule or the caller's pointers). */
 FD_API int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, const fd_step *table, int N,
                      int ddim, const float *x_T, const float *z, uint64_t seed, float *out, float *seq_out,
                      void *stream);
