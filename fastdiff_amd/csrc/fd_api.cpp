@@ -941,14 +941,28 @@ int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_samples, 
     return FD_OK;
 }
 
-int fd_peak_normalize_int16(fd_handle h, const float *wav, int B, int64_t len, int16_t *pcm, void *stream)
+int fd_peak_normalize_int16_ragged(fd_handle h, const float *wav, int B, int64_t len, const int64_t *valid, int16_t *pcm, void *stream)
 {
-    if (!h || !wav || !pcm || B <= 0 || len <= 0 || B > 16384) return FD_ERR_INVALID;
+    if (!h || !wav || !pcm || B <= 0 || len <= 0 || B > 4096) return FD_ERR_INVALID;
     FD_HIP(h, hipSetDevice(h->device));
+    const long long *valid_dev = nullptr;
+    if (valid) {
+        for (int b = 0; b < B; ++b)
+            if (valid[b] < 1 || valid[b] > len) FD_FAIL(h, FD_ERR_INVALID, "fd_peak_normalize_int16_ragged: valid[%d] = %lld outside [1, %lld]", b, (long long)valid[b], (long long)len);
+        h->valid_host.assign(valid, valid + B);          // staging copy that outlives the asynchronous upload
+        long long *dst = reinterpret_cast<long long *>(reinterpret_cast<char *>(h->scratch) + 32768);      // behind the abs-max words
+        FD_HIP(h, hipMemcpyAsync(dst, h->valid_host.data(), sizeof(long long) * B, hipMemcpyHostToDevice, (hipStream_t)stream));
+        valid_dev = dst;
+    }
     fdk::Launch L = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::peak_normalize_int16(L, wav, B, len, pcm);
+    hipError_t e = fdk::peak_normalize_int16(L, wav, B, len, pcm, valid_dev);
     if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_peak_normalize_int16: %s", hipGetErrorString(e));
     return FD_OK;
+}
+
+int fd_peak_normalize_int16(fd_handle h, const float *wav, int B, int64_t len, int16_t *pcm, void *stream)
+{
+    return fd_peak_normalize_int16_ragged(h, wav, B, len, nullptr, pcm, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -163,6 +163,7 @@ struct fd_context {
     bool final_fused = false;                // set by the last LVC layer's launch, consumed by fast_final
     MelTables mel[MEL_VARIANTS];             // [MEL_PWG]: fmin 80, fmax 7600; [MEL_TACOTRON]: fmin 0, fmax 8000 (twiddles/window shared)
     int mel_variant = MEL_PWG;               // option "mel"
+    std::vector<long long> valid_host;       // staging of fd_peak_normalize_int16_ragged's per-utterance sample counts
     std::vector<void *> mel_allocs;           // device memory behind `mel` (built on first use, freed at fd_destroy)
     int last_B = 0, last_T = 0;
     hipStream_t cap_stream = nullptr;
@@ -205,7 +206,7 @@ hipError_t advance_step(const Launch &L);
 hipError_t clear_range_flags(const Launch &L);     // before the first step of a call
 hipError_t mel_frontend(const Launch &L, const float *wav, int B, int64_t n_samples, float *mel, int T);
 hipError_t init_noise(const Launch &L, float *x, int64_t n, unsigned long long seed);
-hipError_t peak_normalize_int16(const Launch &L, const float *wav, int B, int64_t len, int16_t *pcm);
+hipError_t peak_normalize_int16(const Launch &L, const float *wav, int B, int64_t len, int16_t *pcm, const long long *valid_dev);
 }  // namespace fdk
 
 // profiling-aware launch helper

@@ -391,12 +391,13 @@ hipError_t clear_range_flags(const Launch &L)
 }
 
 // ---- waveform epilogue: per-utterance abs-max, then /max * 32767 -> int16 (FastDiff.py:110; utils/audio.py:11-16)
-__global__ void __launch_bounds__(256) k_absmax(const float *wav, int64_t len, unsigned int *maxbits)
+__global__ void __launch_bounds__(256) k_absmax(const float *wav, int64_t len, unsigned int *maxbits, const long long *valid)
 {
     __shared__ float wm[4];
     const int b = blockIdx.y;
+    const int64_t n = valid ? (int64_t)valid[b] : len;          // ragged batch: only the utterance's own samples count
     float m = 0.0f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         m = fmaxf(m, fabsf(wav[(int64_t)b * len + i]));
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
@@ -405,24 +406,25 @@ __global__ void __launch_bounds__(256) k_absmax(const float *wav, int64_t len, u
     if (threadIdx.x == 0) atomicMax(maxbits + b, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));   // non-negative floats order like uints
 }
 
-__global__ void k_to_int16(const float *wav, int64_t len, const unsigned int *maxbits, int16_t *pcm)
+__global__ void k_to_int16(const float *wav, int64_t len, const unsigned int *maxbits, int16_t *pcm, const long long *valid)
 {
     const int b = blockIdx.y;
     const float m = __uint_as_float(maxbits[b]);
+    const int64_t n = valid ? (int64_t)valid[b] : len;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
         const float v = wav[(int64_t)b * len + i] / m;
-        pcm[(int64_t)b * len + i] = (int16_t)(v * 32767.0f);
+        pcm[(int64_t)b * len + i] = i < n ? (int16_t)(v * 32767.0f) : (int16_t)0;      // silence behind a padded utterance
     }
 }
 
-hipError_t peak_normalize_int16(const Launch &L, const float *wav, int B, int64_t len, int16_t *pcm)
+hipError_t peak_normalize_int16(const Launch &L, const float *wav, int B, int64_t len, int16_t *pcm, const long long *valid_dev)
 {
     unsigned int *maxbits = reinterpret_cast<unsigned int *>(L.ctx->scratch);   // [B] words
     hipError_t e = hipMemsetAsync(maxbits, 0, sizeof(unsigned int) * B, L.stream);
     if (e != hipSuccess) return e;
     const unsigned gx = (unsigned)((len + 256 * 8 - 1) / (256 * 8));
-    FD_LAUNCH(L, "absmax", k_absmax, dim3((gx + 3) / 4, B), dim3(256), 0, wav, len, maxbits);
-    FD_LAUNCH(L, "to_int16", k_to_int16, dim3(gx, B), dim3(256), 0, wav, len, (const unsigned int *)maxbits, pcm);
+    FD_LAUNCH(L, "absmax", k_absmax, dim3((gx + 3) / 4, B), dim3(256), 0, wav, len, maxbits, valid_dev);
+    FD_LAUNCH(L, "to_int16", k_to_int16, dim3(gx, B), dim3(256), 0, wav, len, (const unsigned int *)maxbits, pcm, valid_dev);
     return hipSuccess;
 }
 

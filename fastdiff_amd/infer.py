@@ -97,17 +97,33 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
         noise_schedule = schedules.noise_schedule_for(n_steps)
     lengths = [it["len"] for it in items]
     out: Dict[str, np.ndarray] = {}
+    pending = None                 # (event, pinned PCM, names, lens) of the micro-batch still on its way to the host
+
+    def collect(p):
+        done, host, names, lens = p
+        done.synchronize()
+        for b, (name, t) in enumerate(zip(names, lens)):
+            out[name] = host[b, : t * model.hop_length].numpy().copy()
+
     for k, batch_idx in enumerate(shard.micro_batches(range(len(items)), lengths, max_batch)):
         mels, lens, names = collate_test_batch([items[i] for i in batch_idx], drop_last_frame)
         if mels is None:
             continue
-        mels = mels.cuda()
+        mels = mels.pin_memory().cuda(non_blocking=True)
         B, _, T = mels.shape
         wav = sampling_given_noise_schedule(model, (B, 1, T * model.hop_length), diffusion_hyperparams, noise_schedule,
                                             condition=mels, ddim=False, return_sequence=False, seed=seed + k, verbose=False, lens=lens)
-        for b, (name, t) in enumerate(zip(names, lens)):
-            own = wav[b:b + 1, :, : t * model.hop_length]                      # crop the padding before the peak search
-            out[name] = model.peak_normalize_int16(own)[0].cpu().numpy()
+        # one epilogue call and one asynchronous copy per micro-batch; the previous batch is unpacked on the host while this one runs
+        pcm = model.peak_normalize_int16(wav, valid=[t * model.hop_length for t in lens])
+        host = torch.empty(pcm.shape, dtype=torch.int16).pin_memory()
+        host.copy_(pcm, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        if pending is not None:
+            collect(pending)
+        pending = (done, host, names, lens)
+    if pending is not None:
+        collect(pending)
     return out
 
 

@@ -192,15 +192,18 @@ class FastDiff(nn.Module):
             return [seq[k] for k in range(N + 1)]
         return out
 
-    def peak_normalize_int16(self, wav):
-        """wav [B,1,L] float32 -> int16 PCM [B,L]: wav/abs(wav).max() * 32767 (FastDiff.py:110; utils/audio.py:11-16)."""
+    def peak_normalize_int16(self, wav, valid=None):
+        """wav [B,1,L] float32 -> int16 PCM [B,L]: wav/abs(wav).max() * 32767 (FastDiff.py:110; utils/audio.py:11-16).
+        valid (optional, [B] sample counts of a zero-padded batch): each utterance's peak is searched over its own samples only
+        and the PCM behind them is 0 -- one call and one device-to-host copy per micro-batch instead of one per utterance."""
         self._require_inference(wav, wav)
         wav = wav.contiguous().float()
         B = wav.shape[0]
         L = wav.numel() // B
         pcm = torch.empty((B, L), device=wav.device, dtype=torch.int16)
         lib, h = self._ready(wav.device)
-        rc = lib.fd_peak_normalize_int16(h, wav.data_ptr(), B, L, pcm.data_ptr(), self._stream(wav.device))
+        varr = None if valid is None else (ct.c_int64 * B)(*[int(v) for v in valid])
+        rc = lib.fd_peak_normalize_int16_ragged(h, wav.data_ptr(), B, L, varr, pcm.data_ptr(), self._stream(wav.device))
         _capi.check(lib, h, rc, "fd_peak_normalize_int16")
         return pcm
 

@@ -117,6 +117,11 @@ FD_API int fd_sample(fd_handle h, const float *mel, int B, int T, const int *len
 /* Waveform epilogue: wav/abs(wav).max() per utterance (FastDiff.py:110), *32767 -> int16
  * (utils/audio.py:11-16).  wav [B,1,L] device -> pcm [B,L] device int16. */
 FD_API int fd_peak_normalize_int16(fd_handle h, const float *wav, int B, int64_t L, int16_t *pcm, void *stream);
+/* The same for a zero-padded batch (fd_sample with lens): valid [B] host = samples of each utterance (lens[b]*256); the peak is
+ * searched over the utterance's own samples only -- what FastDiff.py:110 sees for a batch of one -- and pcm behind them is 0.
+ * valid NULL = the call above.  B <= 4096. */
+FD_API int fd_peak_normalize_int16_ragged(fd_handle h, const float *wav, int B, int64_t L, const int64_t *valid, int16_t *pcm,
+                                          void *stream);
 
 /* Mel front-end in front of the vocoder: process_utterance(..., vocoder='pwg') of
  * data_gen/tts/data_gen_utils.py:93-147 = librosa.stft(n_fft 1024, hop 256, win 1024, "hann", center, pad_mode "constant") ->

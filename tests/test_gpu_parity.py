@@ -682,3 +682,21 @@ def test_peak_normalize_int16_bit_exact(model, oracle64):
     pcm = model.peak_normalize_int16(torch.from_numpy(wav).cuda()).cpu().numpy()
     ref = oracle64.peak_normalize_int16(wav).reshape(3, 4096)
     assert np.array_equal(pcm, ref)
+
+
+def test_peak_normalize_int16_ragged_equals_each_utterance_alone(model, oracle64):
+    """fd_peak_normalize_int16_ragged: the peak of every utterance of a zero-padded batch is searched over its own samples only
+    (garbage, even NaN, behind them must not matter) and the PCM behind them is silence."""
+    rng = np.random.default_rng(4)
+    L, valid = 5000, [5000, 1, 2048, 3333]
+    wav = (rng.standard_normal((4, 1, L)) * rng.uniform(0.1, 5.0, (4, 1, 1))).astype(np.float32)
+    dirty = wav.copy()
+    for b, n in enumerate(valid):
+        dirty[b, 0, n:] = np.nan if b % 2 else 1.0e9
+    pcm = model.peak_normalize_int16(torch.from_numpy(dirty).cuda(), valid=valid).cpu().numpy()
+    for b, n in enumerate(valid):
+        ref = oracle64.peak_normalize_int16(wav[b:b + 1, :, :n]).reshape(n)
+        assert np.array_equal(pcm[b, :n], ref), b
+        assert not pcm[b, n:].any(), b
+    with pytest.raises(Exception, match="valid"):
+        model.peak_normalize_int16(torch.from_numpy(wav).cuda(), valid=[5000, 0, 1, 1])
