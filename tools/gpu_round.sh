@@ -5,9 +5,11 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1
+(rocm-smi --showclocks --showpower --showperflevel --showmaxpower --showmemvendor 2>&1 | grep -v "^=\|^$" | head -30) > gpurun_out/box_state.txt
 echo "== pytest gpu" ; timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1 ; echo "pytest rc=$?" ; tail -4 gpurun_out/pytest_gpu.log
 echo "== smoke" ; timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1 ; echo "smoke rc=$?" ; tail -1 gpurun_out/smoke.log
 echo "== bench" ; timeout 900 python bench.py > gpurun_out/bench.log 2>&1 ; echo "bench rc=$?" ; grep '^{' gpurun_out/bench.log | cut -c1-900
+(rocm-smi --showclocks --showpower 2>&1 | grep -i "sclk\|power (W)" | head -4) >> gpurun_out/box_state.txt
 echo "== bench N=1000 B=1 (config 3)" ; timeout 900 python bench.py --batch 1 --nsteps 1000 --steps 2 --warmup 1 --no-roofline --no-cpu-baseline > gpurun_out/bench_n1000.log 2>&1 ; grep '^{' gpurun_out/bench_n1000.log | cut -c1-400
 echo "== bench B=1 N=4" ; timeout 900 python bench.py --batch 1 --steps 20 --no-cpu-baseline > gpurun_out/bench_b1.log 2>&1 ; grep '^{' gpurun_out/bench_b1.log | cut -c1-400
 echo "== rocprof kernel-trace"
