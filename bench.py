@@ -1,24 +1,38 @@
 #!/usr/bin/env python
-"""bench.py -- FastDiff vocoder inference on MI355X: real-time factor of the N=4 reverse sampler.
+"""bench.py -- FastDiff vocoder inference on MI355X: real-time factor of the N-step reverse sampler.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload configs1|config4]
 
-One "step" = one pass of the hot path over one batch: fd_sample() of B=8 utterances of 80x864 mel (10.03 s each)
-through N=4 reverse steps (BASELINE.json configs[1]), mel resident in HBM, waveform left in HBM.  With N GPUs every
-rank runs its own batch (independent utterances, no data-path collective): weak scaling, value = whole-job audio
-seconds per wall second.  Prints ONE JSON line on rank 0.
+`--gpus N` with N > 1 launches the N ranks itself (one process per GPU under torch.distributed.run, the reference's own
+one-process-per-GPU model: utils/trainer.py:94-107 mp.spawn) unless it already runs under a launcher (WORLD_SIZE set).  It refuses
+to run when the box has fewer than N GPUs: it never prints a line for a world it did not measure.  `n_gpus` in the line is the live
+RCCL world size (an all-reduce of ones), not the flag.
 
-Extra objects in the line:
-  roofline     -- the dominant kernel of the step, timed live with HIP events on the launch stream (library option
-                  "profile"), algorithmic bytes/flops per launch from DESIGN.md;
-  cpu_baseline -- the CPU oracle (a C port of the reference algorithm, oracle/) timed on this host on a bounded
-                  sample: one utterance (B=1, T=864), N=4.  The reference's own PyTorch CPU path cannot be timed on the
-                  GPU box (/root/reference is absent there); its timing in the build container is in DESIGN.md.
+Workloads
+  configs1 (default) -- BASELINE.json configs[1], the configuration the metric is quoted on: every rank runs fd_sample() on its own
+            batch of B=8 utterances of 80x864 mel (10.03 s each), N=4; mel resident in HBM, waveform left in HBM; weak scaling, no
+            data-path collective.  One "step" = one fd_sample call.
+  config4 -- BASELINE.json configs[3] as north_star words it: rank 0 holds 64 ragged utterances (T_i ~ U{200..864}, N=6) on the
+            HOST; one step = length-balanced partition -> scatter of the mels (one packed RCCL message per peer) -> per-rank padded
+            micro-batches through fd_sample + the int16 epilogue -> gather of the PCM on rank 0's host.  Total work is fixed:
+            strong scaling; the time is host-to-host.
+
+Extra objects in the JSON line (rank 0, N=1 only where they need one GPU):
+  roofline       -- the dominant kernel of the step, timed live with HIP events on the launch stream (library option "profile"),
+                    algorithmic bytes/flops per launch from DESIGN.md section 3;
+  host_inclusive -- SURVEY.md 8(d)'s wall clock for the same batch: pinned host mel -> device -> fd_sample -> int16 epilogue ->
+                    pinned host PCM (PCIe both ways);
+  fp32_pipe      -- the same step with every contraction on the exact-fp32 matrix instruction (options gemm/lvc/conv = fp32):
+                    what the default pipe (2-piece fp16 operands, fp32 accumulation) buys;
+  parity         -- max |difference| of both pipes to the float64 CPU oracle on one utterance (B=1, T=864, N=4, injected x_T);
+  cpu_baseline   -- the CPU restatement of the reference (kind "port": /root/reference does not exist on the GPU box) timed on
+                    this host on a bounded sample: one utterance (B=1, T=864), N=4.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,11 +46,15 @@ SR, HOP = 22050, 256
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix = fp32 vector peak
 MFMA_F16_PEAK_TFLOPS = 2500.0 # dense fp16/bf16 matrix peak (MI355X_MICROARCH.md)
+DTYPE = "f32 (results fp32; contractions as 2-piece fp16 operands, 22 significant bits, on v_mfma_f32_32x32x16_f16 with fp32 accumulation; exact-fp32 MFMA fallback on the device)"
 
 
 def kernel_model(name, B, T):
-    """Algorithmic work of ONE launch of a kernel family (DESIGN.md section 5): (bound, bytes, flops)."""
+    """Algorithmic work of ONE launch of a kernel family (DESIGN.md section 3): (bound, bytes, flops)."""
     L = T * HOP
+    if name.startswith("lvc_block_h8"):
+        # the four hop-8 layers of block 0 in one launch: per layer read x+skip, the frame's record; write x
+        return "hbm", 4 * 4.0 * B * T * (96 * 8 + 6208), 4 * 2.0 * B * T * 8 * (32 * 96 + 64 * 96)
     if name.startswith("lvc_layer_h"):
         hop = int(name.split("_h")[1].split("_")[0])
         # read x, skip (32 ch each), write x (32 ch) at rate hop*T; read the frame's 64x96 kernel + 64 biases
@@ -100,6 +118,7 @@ def measure_roofline(model, mel, rows, B, T, nsteps, lens=None):
         e = {"launches": launches, "avg_us": round(avg_ms * 1e3, 2), "share": round(ms / total_ms, 4)}
         if nbytes:
             e["GBps"] = round(nbytes / (avg_ms * 1e-3) / 1e9, 1)
+            e["hbm_frac"] = round(nbytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         if flops:
             e["TFLOPs"] = round(flops / (avg_ms * 1e-3) / 1e12, 2)
         table[name] = e
@@ -114,14 +133,33 @@ def measure_roofline(model, mel, rows, B, T, nsteps, lens=None):
                 "unit": "GB/s"}
     roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
     roof["avg_launch_us"] = round(avg_s * 1e6, 2)
+    # HBM bytes per launch come from rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, each its own run: tools/gpu_round.sh), which
+    # cannot run inside this process: the committed summary of the same command is quoted, with its source, or null
     roof["traffic"] = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # filled from rocprofv3 --pmc passes, see profiles/README.md
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            roof["traffic"] = json.load(open(pmc)).get(dom)
+            d = json.load(open(pmc))
+            if d.get(dom) is not None:
+                roof["traffic"] = d.get(dom)
+                roof["traffic_source"] = "profiles/pmc_traffic.json (%s)" % d.get("_source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command")
         except Exception:
             pass
+    # the LVC layers time-weighted (north_star's ">= 50 % of HBM roofline in the LVC kernel" spans all twelve launches)
+    lvc = [(k, v) for k, v in fam.items() if k.startswith("lvc_layer_h") or k.startswith("lvc_block_h")]
+    if lvc:
+        by = sum(kernel_model(k, B, T)[1] * v[0] for k, v in lvc)
+        ms = sum(v[1] for _, v in lvc)
+        roof["lvc_all_layers"] = {"GBps": round(by / (ms * 1e-3) / 1e9, 1), "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  "ms_per_sample_call": round(ms / 2, 4)}
     return roof, table
+
+
+def _oracle_table(rows):
+    ex = rows[::-1]   # oracle tables are indexed by reverse index n
+    return {"steps": [r["t"] for r in ex], "c_eps": [r["c_eps"] for r in ex], "c_div": [r["c_div"] for r in ex],
+            "sigma_hat": [r["sigma"] for r in ex], "c1": [r["c1"] for r in ex], "c2": [r["c2"] for r in ex],
+            "c3": [r["c3"] for r in ex]}
 
 
 def cpu_baseline(T, rows):
@@ -159,19 +197,68 @@ def cpu_baseline(T, rows):
     mel = synth.synth_mel(1, 1, T)
     x_T = synth.hash_normal(1, 1, T * HOP).reshape(1, 1, T * HOP)
     z = np.zeros((N, 1, 1, T * HOP), np.float32)
-    ex = rows[::-1]   # oracle tables are indexed by reverse index n
-    table = {"steps": [r["t"] for r in ex], "c_eps": [r["c_eps"] for r in ex], "c_div": [r["c_div"] for r in ex],
-             "sigma_hat": [r["sigma"] for r in ex], "c1": [r["c1"] for r in ex], "c2": [r["c2"] for r in ex],
-             "c3": [r["c3"] for r in ex]}
+    table = _oracle_table(rows)
     o.forward(synth.synth_audio(1, 1, 16), synth.synth_mel(1, 1, 16), np.zeros(1, np.float32))   # warm the thread pool
     t0 = time.perf_counter()
     o.sample(mel, table, x_T, z)
     dt = time.perf_counter() - t0
     return {"value": round(audio_s / dt_t, 3), "unit": "x real-time", "cores": threads_t, "kind": "port",
-            "sample": f"oracle/torch_eager.py (torch {torch.__version__} CPU ops, fp32, {threads_t} threads of {cores} cores) B=1 T={T} N={N}: {dt_t:.2f} s wall",
+            "sample": f"oracle/torch_eager.py (a port: torch {torch.__version__} CPU ops, fp32, {threads_t} threads of {cores} cores) B=1 T={T} N={N}: {dt_t:.2f} s wall",
             "samples_per_s": round(T * HOP / dt_t, 1),
             "c_port": {"value": round(audio_s / dt, 3), "cores": threads,
                        "sample": f"oracle/fastdiff_oracle.c (fp32, OpenMP {threads} threads) B=1 T={T} N={N}: {dt:.2f} s wall"}}
+
+
+def parity_vs_oracle(T, rows, dev):
+    """Both pipes of the product against the float64 CPU oracle on ONE utterance at the benchmark length (B=1, T frames, N steps,
+    injected x_T, zero z): the error figure that belongs next to the `dtype` string.  The oracle is the checker, outside any timing."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import synth
+    from oracle import Oracle
+    import fastdiff_amd
+    N = len(rows)
+    sd = synth.synth_state_dict(1234)
+    o = Oracle("f64")
+    o.set_threads(min(os.cpu_count() or 1, 32))
+    o.set_weights(sd)
+    mel = synth.synth_mel(1, 1, T)
+    x_T = synth.hash_normal(1, 1, T * HOP).reshape(1, 1, T * HOP)
+    ref = o.sample(mel, _oracle_table(rows), x_T, np.zeros((N, 1, 1, T * HOP), np.float32))
+    out = {"sample": f"B=1 T={T} N={N}, synthetic weights (oracle/synth.py seed 1234), injected x_T, z = 0; float64 oracle; max|x_0| = {float(np.abs(ref).max()):.3f}"}
+    m = fastdiff_amd.FastDiff()
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    m = m.to(dev).eval()
+    zeros = torch.zeros((N, 1, 1, T * HOP), device=dev)
+    for label, opts in (("f16x2", {"gemm": "f16x2", "lvc": "f16x2", "conv": "f16x2"}), ("fp32", {"gemm": "fp32", "lvc": "fp32", "conv": "fp32"})):
+        for k, v in opts.items():
+            m.set_option(k, v)
+        with torch.no_grad():
+            y = m.sample(torch.from_numpy(mel).to(dev), rows, x_T=torch.from_numpy(x_T).to(dev), noise=zeros)
+        torch.cuda.synchronize()
+        out["max_abs_diff_" + label] = float(np.abs(y.cpu().numpy().astype(np.float64) - ref).max())
+    del m
+    return out
+
+
+def fp32_pipe(model, mel, rows, lens, audio_s, reps=5):
+    """The same sample call with every contraction on v_mfma_f32_32x32x2_f32 (bitwise an fp32 fma chain)."""
+    for k in ("gemm", "lvc", "conv"):
+        model.set_option(k, "fp32")
+    try:
+        with torch.no_grad():
+            model.sample(mel, rows, seed=0, lens=lens)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(reps):
+                model.sample(mel, rows, seed=1 + i, lens=lens)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / reps * 1e3
+    finally:
+        for k in ("gemm", "lvc", "conv"):
+            model.set_option(k, "f16x2")
+    return {"ms_per_step": round(ms, 4), "value": round(audio_s / (ms / 1e3), 2), "unit": "x real-time",
+            "options": "gemm=fp32 lvc=fp32 conv=fp32"}
 
 
 def torch_eager_baseline(mel, rows, audio_s, reps=3):
@@ -219,16 +306,95 @@ def host_inclusive(model, mel, rows, lens, audio_s, reps=5):
             "path": "pinned host mel -> device -> fd_sample -> fd_peak_normalize_int16 -> pinned host int16 PCM"}
 
 
+def box_state():
+    """Clocks / power of this rank's GPU as rocm-smi reports them (the pool's boxes differ by +-7 %: a number without them
+    cannot be compared with another session's)."""
+    try:
+        r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showperflevel", "--json"], capture_output=True, text=True, timeout=20)
+        d = json.loads(r.stdout)
+        card = d.get("card0", next(iter(d.values())))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if "sclk" in kl or "mclk" in kl or "power" in kl or "performance level" in kl:
+                keep[k] = v
+        return keep
+    except Exception as e:      # noqa: BLE001 -- diagnostics only
+        return {"error": repr(e)}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_spawn(n):
+    """Re-execute this command under torch.distributed.run with one rank per GPU and return its exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def config4_items(seed=1234, n=64, t_lo=200, t_hi=864):
+    """BASELINE configs[3] / SURVEY.md 8(d): 64 utterances, T_i ~ U{200..864} (seeded), mels uniform on [mel_vmin, mel_vmax], stored
+    [T, 80] as on disk (tasks/vocoder/dataset_utils.py:186-204)."""
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(t_lo, t_hi + 1, (n,), generator=g).tolist()
+    return [{"item_name": "utt%03d" % i, "mel": torch.rand(t, 80, generator=g) * 7.5 - 6.0, "len": t} for i, t in enumerate(lens)]
+
+
+def run_config4(args, model, rank, world, local_rank, dev):
+    """One step = the whole sharded job, host to host (see the module docstring)."""
+    from fastdiff_amd import infer
+    items = config4_items() if rank == 0 else None
+    N = args.nsteps
+    stage_dev = dev if world > 1 else None
+
+    def one(i):
+        return infer.synthesize_sharded(model, items, n_steps=N, max_batch=args.batch, seed=1234 + i, drop_last_frame=False, src=0, device=stage_dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    for i in range(args.warmup):
+        out = one(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one(100 + i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    frames = 0
+    if rank == 0:
+        assert sorted(out) == sorted(it["item_name"] for it in items)
+        for it in items:
+            assert out[it["item_name"]].shape == (it["len"] * HOP,) and int(abs(out[it["item_name"]]).max()) == 32767
+        frames = sum(it["len"] for it in items)
+    return elapsed, frames
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--workload", default="configs1", choices=("configs1", "config4"))
+    ap.add_argument("--batch", type=int, default=8, help="utterances per fd_sample call (config4: micro-batch size)")
     ap.add_argument("--frames", type=int, default=864)
-    ap.add_argument("--nsteps", type=int, default=4, help="reverse steps N (3,4,6,8,200,1000)")
+    ap.add_argument("--nsteps", type=int, default=None, help="reverse steps N (3,4,6,8,200,1000); default 4 (config4: 6)")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (cpu_baseline and parity)")
+    ap.add_argument("--no-fp32-pipe", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--ragged", action="store_true",
                     help="BASELINE config 4 style batch: T_i ~ U{200..frames}, zero-padded; RTF counts the valid audio only")
@@ -238,17 +404,36 @@ def main():
     ap.add_argument("--no-host-io", action="store_true", help="skip the extra host-to-host (PCIe-inclusive) measurement")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="library option (fd_set_option), repeatable")
     args = ap.parse_args()
+    if args.nsteps is None:
+        args.nsteps = 6 if args.workload == "config4" else 4
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: fastdiff_amd has no CPU path")
+    n_dev = torch.cuda.device_count()
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > n_dev:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but this box has {n_dev} GPU(s): refusing to print a line for a world that was not measured")
+        if args.gpus > 1:
+            sys.exit(self_spawn(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: fastdiff_amd has no CPU path")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if local_rank >= n_dev:
+        raise SystemExit(f"bench.py: rank {rank} (local {local_rank}) has no GPU of its own: {n_dev} visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_ranks = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == world == dist.get_world_size(), (rccl_ranks, world)
 
     import fastdiff_amd
     from fastdiff_amd import sampler, schedules
@@ -260,15 +445,6 @@ def main():
         model.set_option("graph", "0")
     for kv in args.opt:
         model.set_option(*kv.split("=", 1))
-    torch.manual_seed(1234 + rank)
-    mel = (torch.rand(B, 80, T) * 7.5 - 6.0).to(dev)    # uniform on [mel_vmin, mel_vmax]
-    lens = None
-    valid_frames = B * T
-    if args.ragged:
-        lens = torch.randint(200, T + 1, (B,)).tolist() if T > 200 else [T] * B
-        for b, t in enumerate(lens):
-            mel[b, :, t:] = 0.0                          # collate_2d padding
-        valid_frames = sum(lens)
     dh = schedules.training_hyperparams()
     rows = sampler.InferenceSchedule(dh, schedules.noise_schedule_for(N), verbose=False).rows()
 
@@ -276,55 +452,92 @@ def main():
         if world > 1:
             dist.barrier(device_ids=[local_rank])
 
-    with torch.no_grad():
-        for i in range(args.warmup):
-            out = model.sample(mel, rows, seed=i, lens=None if args.no_lens else lens)
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            out = model.sample(mel, rows, seed=100 + i, lens=None if args.no_lens else lens)
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-    assert torch.isfinite(out if lens is None else torch.stack([out[b, :, : lens[b] * HOP].abs().max() for b in range(B)])).all()
+    lens = None
+    if args.workload == "config4":
+        elapsed, frames = run_config4(args, model, rank, world, local_rank, dev)
+        total_frames, padded_frames = frames, frames
+        scaling = "strong"
+        workload = ("BASELINE configs[3]: 64 utterances T_i~U{200..864} on rank 0's host, N=%d, LPT partition -> scatter -> padded "
+                    "micro-batches of <=%d per rank -> int16 epilogue -> gather on rank 0's host" % (N, B))
+    else:
+        torch.manual_seed(1234 + rank)
+        mel = (torch.rand(B, 80, T) * 7.5 - 6.0).to(dev)    # uniform on [mel_vmin, mel_vmax]
+        valid_frames = B * T
+        if args.ragged:
+            lens = torch.randint(200, T + 1, (B,)).tolist() if T > 200 else [T] * B
+            for b, t in enumerate(lens):
+                mel[b, :, t:] = 0.0                          # collate_2d padding
+            valid_frames = sum(lens)
+        use_lens = None if args.no_lens else lens
+        with torch.no_grad():
+            for i in range(args.warmup):
+                out = model.sample(mel, rows, seed=i, lens=use_lens)
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                out = model.sample(mel, rows, seed=100 + i, lens=use_lens)
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+        assert torch.isfinite(out if lens is None else torch.stack([out[b, :, : lens[b] * HOP].abs().max() for b in range(B)])).all()
+        total_frames = world * valid_frames        # (ragged: rank 0's draw stands for every rank)
+        padded_frames = world * B * T
+        scaling = "weak"
+        workload = ("BASELINE configs[1]: LJSpeech FastDiff.yaml shape, batch=%d utterances of 80x%d mel per GPU, "
+                    "N=%d, HIP LVC/dilated-conv kernels + hipGraph sampler" % (B, T, N))
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    audio_s = world * valid_frames * HOP / SR      # (ragged: rank 0's draw stands for every rank)
+    audio_s = total_frames * HOP / SR
     line = {
         "metric": "real-time factor (audio-sec/wall-sec), N=%d reverse steps, 80x%d mel" % (N, T),
         "value": round(audio_s / (ms_per_step / 1e3), 2),
         "unit": "x real-time",
-        "samples_per_s": round(world * B * T * HOP / (ms_per_step / 1e3), 1),
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: LJSpeech FastDiff.yaml shape, batch=%d utterances of 80x%d mel, "
-                               "N=%d, HIP LVC/dilated-conv kernels + hipGraph sampler" % (B, T, N),
-                   "batch_per_gpu": B, "frames": T, "reverse_steps": N, "sharding": "utterances/rank, no collective",
+        "samples_per_s": round(padded_frames * HOP / (ms_per_step / 1e3), 1),
+        "n_gpus": rccl_ranks if world > 1 else 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        "config": {"workload": workload,
+                   "batch_per_gpu": B, "frames": T, "reverse_steps": N,
+                   "sharding": "utterances/rank, no data-path collective" if args.workload == "configs1" else "LPT partition, one packed p2p message per peer each way (RCCL)",
+                   "value_is": ("mel resident in HBM -> waveform resident in HBM (the boundary takes device pointers); the host-to-host "
+                                "rate of the same batch is `host_inclusive`") if args.workload == "configs1" else "host mel -> host int16 PCM (rank 0)",
                    "graph": not args.no_graph, "weights": "random init seed 1234 (no checkpoint offline)",
+                   "world_size": world, "gpus_visible": n_dev,
                    "ragged": (None if not args.ragged else {"lens": lens, "told_to_library": not args.no_lens})},
     }
-    if rank == 0 and world == 1 and not args.no_host_io:
-        line["host_inclusive"] = host_inclusive(model, mel, rows, None if args.no_lens else lens, audio_s)
-    if rank == 0 and world == 1:
+    if rank == 0:
+        line["box"] = box_state()
+    if rank == 0 and world == 1 and args.workload == "configs1":
+        use_lens = None if args.no_lens else lens
+        if not args.no_host_io:
+            line["host_inclusive"] = host_inclusive(model, mel, rows, use_lens, audio_s)
         if not args.no_roofline:
-            roof, table = measure_roofline(model, mel, rows, B, T, N, None if args.no_lens else lens)
+            roof, table = measure_roofline(model, mel, rows, B, T, N, use_lens)
             line["roofline"] = roof
             line["kernels"] = table
+        if not args.no_fp32_pipe:
+            try:
+                line["fp32_pipe"] = fp32_pipe(model, mel, rows, use_lens, audio_s)
+            except Exception as e:      # noqa: BLE001
+                line["fp32_pipe"] = {"error": repr(e)}
         if args.torch_eager_baseline:
             try:
                 line["torch_eager_baseline"] = torch_eager_baseline(mel, rows, audio_s)
-            except Exception as e:
+            except Exception as e:      # noqa: BLE001
                 line["torch_eager_baseline"] = {"error": repr(e)}
         if not args.no_cpu_baseline:
             try:
+                line["parity"] = parity_vs_oracle(T, rows, dev)
+            except Exception as e:      # noqa: BLE001 -- the checker is optional for the measurement
+                line["parity"] = {"error": repr(e)}
+            try:
                 line["cpu_baseline"] = cpu_baseline(T, rows)
-            except Exception as e:   # the checker is optional for the measurement
+            except Exception as e:      # noqa: BLE001
                 line["cpu_baseline"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(line), flush=True)

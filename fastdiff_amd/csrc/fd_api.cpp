@@ -11,6 +11,9 @@
 
 static std::string g_create_error;
 
+// rows of the predictor GEMM's fp16 image per utterance (gx_rows in fd_kernels_fast.hip: 128-frame windows + 2 halo rows)
+static inline int gx_rows_host(int T) { return ((T + 127) / 128) * 128 + 2; }
+
 #define FD_FAIL(h, code, ...)                                   \
     do {                                                        \
         char buf__[512];                                        \
@@ -158,7 +161,6 @@ int fd_create(const fd_config *cfg, int device, fd_handle *out)
     }
     for (int i = 0; i < ST_COUNT; ++i) c->fast[i] = true;
     if ((e = hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipHostMalloc(reinterpret_cast<void **>(&c->host_params), sizeof(StepParams) * fd_context::PARAM_SLOTS, hipHostMallocDefault)) != hipSuccess ||
         (e = hipMalloc(&c->scratch, 65536)) != hipSuccess) {
         g_create_error = std::string("fd_create: ") + hipGetErrorString(e);
         delete c;
@@ -171,7 +173,7 @@ int fd_create(const fd_config *cfg, int device, fd_handle *out)
 static void free_workspace(fd_context *c)
 {
     Workspace &w = c->ws;
-    void *ptrs[] = {w.noise, w.embed_h2, w.a[0], w.a[1], w.a[2], w.a[3], w.kp_h0, w.kp_hA, w.kp_hB, w.kpack, w.h_f16, w.range_flag, w.lens_dev, w.xA, w.xB,
+    void *ptrs[] = {w.noise, w.embed_h2, w.a[0], w.a[1], w.a[2], w.a[3], w.kp_h0, w.kp_hA, w.kp_hB, w.kpack, w.h_f16, w.range_flag, w.lens_dev, w.uid_dev, w.xA, w.xB,
                     w.xtap[0], w.xtap[1], w.xtap[2], w.mel, w.x, w.eps_acc, w.steps, w.params};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -198,9 +200,10 @@ int fd_destroy(fd_handle h)
     free_workspace(h);
     for (void *p : h->dev_allocs) hipFree(p);
     if (h->scratch) hipFree(h->scratch);
-    if (h->host_params) hipHostFree(h->host_params);
-    for (hipEvent_t ev : h->param_done)
-        if (ev) hipEventDestroy(ev);
+    for (auto &sl : h->stage) {
+        if (sl.host) hipHostFree(sl.host);
+        if (sl.done) hipEventDestroy(sl.done);
+    }
     for (void *p : h->mel_allocs) hipFree(p);
     if (h->cap_stream) hipStreamDestroy(h->cap_stream);
     delete h;
@@ -578,15 +581,13 @@ int fd_commit_weights(fd_handle h)
 // ------------------------------------------------------------------------------------------------
 // workspace
 // ------------------------------------------------------------------------------------------------
-static int ensure_workspace(fd_context *h, int B, int T)
+// Buffers scale with three quantities of a call: B (per-utterance arrays), B*T (every activation, the predicted kernels) and
+// B*gx_rows(T) (the GEMM's fp16 image, padded per utterance).  Capacity is tracked in exactly those terms, so a handle that served
+// (B=64, T=864) and then meets (B=1, T=20000) needs room for max(64*864, 20000) frames -- not for 64 x 20000.
+static hipError_t allocate_workspace(fd_context *h, int64_t capB, int64_t frames, int64_t rows, size_t *total_out)
 {
     Workspace &w = h->ws;
-    if (w.B >= B && w.T >= T && w.params) return FD_OK;
-    FD_HIP(h, hipDeviceSynchronize());
-    drop_graph(h);
-    const int nB = std::max(B, w.B), nT = std::max(T, w.T);
-    free_workspace(h);
-    const size_t L = (size_t)nT * fd::HOPT, f = sizeof(float);
+    const size_t f = sizeof(float), FL = (size_t)frames * fd::HOPT;      // FL: samples of all utterances together
     size_t total = 0;
     auto alloc = [&](float **p, size_t n) -> hipError_t {
         total += n * f;
@@ -597,28 +598,51 @@ static int ensure_workspace(fd_context *h, int B, int T)
     };
     hipError_t e = hipSuccess;
 #define WS(p, n) if (e == hipSuccess) e = alloc(&(p), (n))
-    WS(w.noise, (size_t)1024 * nB * fd::NBLK * fd::COND);
-    WS(w.embed_h2, (size_t)std::max(1024, nB) * fd::E_OUT);
-    WS(w.a[0], nB * fd::C * L); WS(w.a[1], nB * fd::C * L / 4); WS(w.a[2], nB * fd::C * L / 32); WS(w.a[3], (size_t)nB * fd::C * nT);
-    WS(w.kp_h0, (size_t)fd::NBLK * nB * fd::HID * nT); WS(w.kp_hA, (size_t)fd::NBLK * nB * fd::HID * nT);
-    WS(w.kp_hB, (size_t)fd::NBLK * nB * fd::HID * nT);
-    WS(w.kpack, (size_t)fd::NBLK * nB * nT * fd::KREC);
-    WS(w.h_f16, (size_t)fd::NBLK * nB * (((nT + 127) / 128) * 128 + 2) * 64 + 1024);  // rows = gx_rows(T), + slack for the rounded-up last DMA
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w.lens_dev), sizeof(int) * (size_t)std::max(nB, 64));
+    WS(w.noise, (size_t)1024 * capB * fd::NBLK * fd::COND);
+    WS(w.embed_h2, (size_t)std::max<int64_t>(1024, capB) * fd::E_OUT);
+    WS(w.a[0], fd::C * FL); WS(w.a[1], fd::C * FL / 4); WS(w.a[2], fd::C * FL / 32); WS(w.a[3], (size_t)fd::C * frames);
+    WS(w.kp_h0, (size_t)fd::NBLK * fd::HID * frames); WS(w.kp_hA, (size_t)fd::NBLK * fd::HID * frames);
+    WS(w.kp_hB, (size_t)fd::NBLK * fd::HID * frames);
+    WS(w.kpack, (size_t)fd::NBLK * frames * fd::KREC);
+    WS(w.h_f16, (size_t)fd::NBLK * rows * 64 + 1024);      // + slack for the rounded-up last DMA
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w.lens_dev), sizeof(int) * (size_t)std::max<int64_t>(capB, 64));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w.uid_dev), sizeof(unsigned long long) * (size_t)std::max<int64_t>(capB, 64));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w.range_flag), 256);
     if (e == hipSuccess) e = hipMemset(w.range_flag, 0, 256);
-    WS(w.xA, nB * fd::C * L); WS(w.xB, nB * fd::C * L);
-    WS(w.xtap[0], nB * fd::C * L / 32); WS(w.xtap[1], nB * fd::C * L / 4); WS(w.xtap[2], nB * fd::C * L);
-    WS(w.mel, (size_t)nB * fd::COND * nT); WS(w.x, nB * L); WS(w.eps_acc, nB * L); WS(w.steps, (size_t)std::max(nB, 64));
+    WS(w.xA, fd::C * FL); WS(w.xB, fd::C * FL);
+    WS(w.xtap[0], fd::C * FL / 32); WS(w.xtap[1], fd::C * FL / 4); WS(w.xtap[2], fd::C * FL);
+    WS(w.mel, (size_t)fd::COND * frames); WS(w.x, FL); WS(w.eps_acc, FL); WS(w.steps, (size_t)std::max<int64_t>(capB, 64));
 #undef WS
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w.params), sizeof(StepParams));
     if (e == hipSuccess) e = hipMemset(w.params, 0, sizeof(StepParams));
-    if (e != hipSuccess) {
+    *total_out = total;
+    return e;
+}
+
+static int ensure_workspace(fd_context *h, int B, int T)
+{
+    Workspace &w = h->ws;
+    const int64_t frames = (int64_t)B * T, rows = (int64_t)B * gx_rows_host(T);
+    if (w.B >= B && w.frames >= frames && w.rows >= rows && w.params) return FD_OK;
+    FD_HIP(h, hipDeviceSynchronize());
+    drop_graph(h);
+    // grow to the largest of each quantity seen so far, so that alternating shapes settle; if that does not fit, this call's own
+    // needs alone are tried before giving up
+    const int64_t want[2][3] = {{std::max<int64_t>(B, w.B), std::max(frames, w.frames), std::max(rows, w.rows)}, {B, frames, rows}};
+    size_t total = 0;
+    hipError_t e = hipSuccess;
+    for (int attempt = 0; attempt < 2; ++attempt) {
         free_workspace(h);
-        FD_FAIL(h, FD_ERR_HIP, "workspace allocation for B=%d T=%d (%.1f MB) failed: %s", nB, nT, total / 1e6, hipGetErrorString(e));
+        e = allocate_workspace(h, want[attempt][0], want[attempt][1], want[attempt][2], &total);
+        if (e == hipSuccess) {
+            w.B = (int)want[attempt][0]; w.frames = want[attempt][1]; w.rows = want[attempt][2]; w.bytes = total;
+            return FD_OK;
+        }
+        (void)hipGetLastError();
+        if (want[0][0] == want[1][0] && want[0][1] == want[1][1] && want[0][2] == want[1][2]) break;
     }
-    w.B = nB; w.T = nT; w.bytes = total;
-    return FD_OK;
+    free_workspace(h);
+    FD_FAIL(h, FD_ERR_HIP, "workspace allocation for B=%d T=%d (%.1f MB) failed: %s", B, T, total / 1e6, hipGetErrorString(e));
 }
 
 }  // extern "C"
@@ -713,8 +737,31 @@ static int check_common(fd_handle h, int B, int T, const char *who)
     return FD_OK;
 }
 
-// `lens` (host, nullable): valid frames per utterance of a zero-padded batch, uploaded for the kernels.
-static int set_lens(fd_handle h, const int *lens, int B, int T, hipStream_t stream, const char *who)
+// Pinned staging (fd_context::stage): the next slot of the ring with room for `bytes`, free to be written by the host.
+static int stage_acquire(fd_handle h, size_t bytes, fd_context::StageSlot **out)
+{
+    fd_context::StageSlot &sl = h->stage[h->stage_next++ % fd_context::STAGE_SLOTS];
+    if (sl.done) FD_HIP(h, hipEventSynchronize(sl.done));             // the uploads that last used this slot (8 calls ago)
+    else FD_HIP(h, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    if (sl.cap < bytes) {
+        if (sl.host) hipHostFree(sl.host);
+        sl.host = nullptr; sl.cap = 0;
+        const size_t cap = (bytes + 4095) & ~(size_t)4095;
+        FD_HIP(h, hipHostMalloc(reinterpret_cast<void **>(&sl.host), cap, hipHostMallocDefault));
+        sl.cap = cap;
+    }
+    *out = &sl;
+    return FD_OK;
+}
+// ... and the mark behind the copies that read it
+static int stage_commit(fd_handle h, fd_context::StageSlot *sl, hipStream_t stream)
+{
+    FD_HIP(h, hipEventRecord(sl->done, stream));
+    return FD_OK;
+}
+
+// `lens` (host, nullable): valid frames per utterance of a zero-padded batch, uploaded for the kernels from the pinned area `staged`.
+static int set_lens(fd_handle h, const int *lens, int B, int T, hipStream_t stream, const char *who, int *staged)
 {
     h->step_lens = nullptr;
     if (!lens) return FD_OK;
@@ -724,8 +771,8 @@ static int set_lens(fd_handle h, const int *lens, int B, int T, hipStream_t stre
         ragged = ragged || lens[b] < T;
     }
     if (!ragged) return FD_OK;                       // every utterance fills the batch: same launches as without lens
-    h->lens_host.assign(lens, lens + B);             // staging copy that outlives the asynchronous upload
-    FD_HIP(h, hipMemcpyAsync(h->ws.lens_dev, h->lens_host.data(), sizeof(int) * B, hipMemcpyHostToDevice, stream));
+    memcpy(staged, lens, sizeof(int) * B);
+    FD_HIP(h, hipMemcpyAsync(h->ws.lens_dev, staged, sizeof(int) * B, hipMemcpyHostToDevice, stream));
     h->step_lens = h->ws.lens_dev;
     return FD_OK;
 }
@@ -738,7 +785,14 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
     if (!x || !mel || !steps || !eps_out) FD_FAIL(h, FD_ERR_INVALID, "fd_forward: null pointer");
     if (x == eps_out) FD_FAIL(h, FD_ERR_INVALID, "fd_forward: eps_out must not alias x");
     if ((rc = ensure_workspace(h, B, T)) != FD_OK) return rc;
-    if ((rc = set_lens(h, lens, B, T, (hipStream_t)stream, "fd_forward")) != FD_OK) return rc;
+    if (lens) {
+        fd_context::StageSlot *sl = nullptr;
+        if ((rc = stage_acquire(h, sizeof(int) * B, &sl)) != FD_OK) return rc;
+        if ((rc = set_lens(h, lens, B, T, (hipStream_t)stream, "fd_forward", reinterpret_cast<int *>(sl->host))) != FD_OK) return rc;
+        if ((rc = stage_commit(h, sl, (hipStream_t)stream)) != FD_OK) return rc;
+    } else {
+        h->step_lens = nullptr;
+    }
     fdk::Launch L = {h, (hipStream_t)stream, false};
     StepIO io = {x, mel, steps, eps_out, 0};
     hipError_t e = fdk::embed(L, io, B, 1);
@@ -765,33 +819,41 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
     if (N <= 0 || N > 1024) FD_FAIL(h, FD_ERR_INVALID, "fd_sample: N=%d outside 1..1024", N);
     if ((rc = ensure_workspace(h, B, T)) != FD_OK) return rc;
     hipStream_t stream = (hipStream_t)stream_;
-    if ((rc = set_lens(h, lens, B, T, stream, "fd_sample")) != FD_OK) return rc;
     Workspace &ws = h->ws;
     const size_t n_el = (size_t)B * T * fd::HOPT;
+    std::vector<unsigned long long> ids;
+    ids.swap(h->noise_ids);                      // one-shot: fd_set_noise_streams applies to this call only
+    if (!ids.empty() && (int)ids.size() != B)
+        FD_FAIL(h, FD_ERR_INVALID, "fd_sample: fd_set_noise_streams gave %d stream ids but B=%d", (int)ids.size(), B);
 
-    // per-call parameters -> device block the captured kernels read.  Staged through a ring of pinned slots: the call returns
+    // per-call parameters -> device block the captured kernels read.  Staged through the pinned ring: the call returns
     // without waiting for the stream, so the host prepares the next call while this one runs.
     {
-        const unsigned slot = h->param_slot++ % fd_context::PARAM_SLOTS;
-        hipEvent_t &done = h->param_done[slot];
-        if (done) FD_HIP(h, hipEventSynchronize(done));            // the upload that last used this slot (8 calls ago)
-        else FD_HIP(h, hipEventCreateWithFlags(&done, hipEventDisableTiming));
-        StepParams *p = h->host_params + slot;
+        fd_context::StageSlot *sl = nullptr;
+        const size_t off_lens = sizeof(StepParams), off_ids = off_lens + ((sizeof(int) * B + 7) & ~(size_t)7);
+        if ((rc = stage_acquire(h, off_ids + sizeof(unsigned long long) * B, &sl)) != FD_OK) return rc;
+        if ((rc = set_lens(h, lens, B, T, stream, "fd_sample", reinterpret_cast<int *>(sl->host + off_lens))) != FD_OK) return rc;
+        if (!ids.empty()) {
+            memcpy(sl->host + off_ids, ids.data(), sizeof(unsigned long long) * B);
+            FD_HIP(h, hipMemcpyAsync(ws.uid_dev, sl->host + off_ids, sizeof(unsigned long long) * B, hipMemcpyHostToDevice, stream));
+        }
+        StepParams *p = reinterpret_cast<StepParams *>(sl->host);
         memcpy(p->table, table, sizeof(fd_step) * N);
-        p->z = z; p->seq = seq_out; p->seed = seed; p->n_steps = N; p->ddim = ddim ? 1 : 0; p->step_idx = 0; p->pad = 0;
+        p->z = z; p->seq = seq_out; p->seed = seed; p->n_steps = N; p->ddim = ddim ? 1 : 0; p->step_idx = 0; p->l4 = T * (fd::HOPT / 4);
+        p->uids = ids.empty() ? nullptr : ws.uid_dev;
         // only the used prefix of the table plus the trailer needs to travel
         const size_t head = sizeof(fd_step) * N;
         FD_HIP(h, hipMemcpyAsync(ws.params, p, head, hipMemcpyHostToDevice, stream));
         const size_t off = offsetof(StepParams, z);
         FD_HIP(h, hipMemcpyAsync(reinterpret_cast<char *>(ws.params) + off, reinterpret_cast<const char *>(p) + off, sizeof(StepParams) - off,
                                  hipMemcpyHostToDevice, stream));
-        FD_HIP(h, hipEventRecord(done, stream));
+        if ((rc = stage_commit(h, sl, stream)) != FD_OK) return rc;
     }
     FD_HIP(h, hipMemcpyAsync(ws.mel, mel, sizeof(float) * (size_t)B * fd::COND * T, hipMemcpyDeviceToDevice, stream));
     fdk::Launch L = {h, stream, false};
     hipError_t e = hipSuccess;
     if (x_T) FD_HIP(h, hipMemcpyAsync(ws.x, x_T, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
-    else if ((e = fdk::init_noise(L, ws.x, (int64_t)n_el, seed)) != hipSuccess)
+    else if ((e = fdk::init_noise(L, ws.x, (int64_t)n_el, seed, ids.empty() ? nullptr : ws.uid_dev, T * (fd::HOPT / 4))) != hipSuccess)
         FD_FAIL(h, FD_ERR_HIP, "fd_sample: init_noise failed: %s", hipGetErrorString(e));
     if (seq_out) FD_HIP(h, hipMemcpyAsync(seq_out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
 
@@ -863,6 +925,13 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
     }
     FD_HIP(h, hipMemcpyAsync(out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
     h->last_B = B; h->last_T = T;
+    return FD_OK;
+}
+
+int fd_set_noise_streams(fd_handle h, const uint64_t *stream_ids, int B)
+{
+    if (!h || B < 0 || (B > 0 && !stream_ids)) return FD_ERR_INVALID;
+    h->noise_ids.assign(stream_ids, stream_ids + B);
     return FD_OK;
 }
 
@@ -949,9 +1018,13 @@ int fd_peak_normalize_int16_ragged(fd_handle h, const float *wav, int B, int64_t
     if (valid) {
         for (int b = 0; b < B; ++b)
             if (valid[b] < 1 || valid[b] > len) FD_FAIL(h, FD_ERR_INVALID, "fd_peak_normalize_int16_ragged: valid[%d] = %lld outside [1, %lld]", b, (long long)valid[b], (long long)len);
-        h->valid_host.assign(valid, valid + B);          // staging copy that outlives the asynchronous upload
+        fd_context::StageSlot *sl = nullptr;
+        int rc = stage_acquire(h, sizeof(long long) * B, &sl);
+        if (rc != FD_OK) return rc;
+        for (int b = 0; b < B; ++b) reinterpret_cast<long long *>(sl->host)[b] = valid[b];
         long long *dst = reinterpret_cast<long long *>(reinterpret_cast<char *>(h->scratch) + 32768);      // behind the abs-max words
-        FD_HIP(h, hipMemcpyAsync(dst, h->valid_host.data(), sizeof(long long) * B, hipMemcpyHostToDevice, (hipStream_t)stream));
+        FD_HIP(h, hipMemcpyAsync(dst, sl->host, sizeof(long long) * B, hipMemcpyHostToDevice, (hipStream_t)stream));
+        if ((rc = stage_commit(h, sl, (hipStream_t)stream)) != FD_OK) return rc;
         valid_dev = dst;
     }
     fdk::Launch L = {h, (hipStream_t)stream, false};

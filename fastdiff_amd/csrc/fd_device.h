@@ -18,10 +18,13 @@ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-__device__ inline float4 philox_normal4(unsigned long long seed, uint32_t stream, uint64_t idx4)
+// Four N(0,1) draws: key = seed, counter = (float4 index, utterance stream id, step stream).  Without per-utterance ids (uid = 0,
+// idx4 = the flat index into the batch) a draw depends on where the utterance sits in the batch; with them (fd_set_noise_streams:
+// idx4 = the index inside the utterance, uid = its id) an utterance gets the same noise however it is batched or sharded.
+__device__ inline float4 philox_normal4(unsigned long long seed, uint32_t stream, uint64_t idx4, unsigned long long uid = 0ull)
 {
     uint32_t r[4];
-    philox4x32_10((uint32_t)idx4, (uint32_t)(idx4 >> 32), stream, 0x5EEDu, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    philox4x32_10((uint32_t)idx4, (uint32_t)(idx4 >> 32) ^ (uint32_t)uid, stream, 0x5EEDu ^ (uint32_t)(uid >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
     const float u0 = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
     const float u1 = ((float)(r[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
     const float u2 = ((float)(r[2] >> 8) + 0.5f) * (1.0f / 16777216.0f);
@@ -52,7 +55,10 @@ __device__ inline float4 sampler_update4(float4 x, float4 e, const StepParams *p
         if (st.add_noise) {
             float4 z;
             if (p->z) z = reinterpret_cast<const float4 *>(p->z)[(int64_t)k * n4_total + i4];
-            else z = philox_normal4(p->seed, (uint32_t)k, (uint64_t)i4);
+            else if (p->uids) {
+                const int b = (int)(i4 / p->l4);
+                z = philox_normal4(p->seed, (uint32_t)k, (uint64_t)(i4 - (int64_t)b * p->l4), p->uids[b]);
+            } else z = philox_normal4(p->seed, (uint32_t)k, (uint64_t)i4);
             o.x += st.sigma * z.x; o.y += st.sigma * z.y; o.z += st.sigma * z.z; o.w += st.sigma * z.w;
         }
     }

@@ -102,13 +102,16 @@ struct StepParams {
     int n_steps;
     int ddim;
     int step_idx;          // advanced on device at the end of every captured step
-    int pad;
+    int l4;                // samples / 4 of one (padded) utterance of this call: splits a flat float4 index into (utterance, offset)
+    const unsigned long long *uids;   // [B] per-utterance noise stream ids (fd_set_noise_streams) or null: see philox_normal4
 };
 
 enum Stage { ST_EMBED = 0, ST_FIRST, ST_DBLOCK, ST_KP_FRONT, ST_KP_GEMM, ST_CONVT, ST_LVC, ST_FINAL, ST_COUNT };
 
 struct Workspace {
-    int B = 0, T = 0;           // capacity
+    int B = 0;                  // capacity: utterances (per-utterance arrays),
+    int64_t frames = 0;         //           B*T frames (activations, predicted kernels),
+    int64_t rows = 0;           //           B*gx_rows(T) rows of the GEMM's fp16 image
     float *noise = nullptr;     // [1024][B][3][80]
     float *embed_h2 = nullptr;  // [max(1024, B)][512] second MLP layer of the step embedding, between the two embed kernels
     float *a[4] = {};           // a0..a3
@@ -116,6 +119,7 @@ struct Workspace {
     float *kpack = nullptr;     // [3][B][T][KREC]
     float *h_f16 = nullptr;     // fp16 piece image of the predictor hidden state: [3][B][64*ceil(T/64)+2 rows][2 pieces][64] x 2 B
     int *lens_dev = nullptr;    // [B] valid frames per utterance of the current call (ragged batches)
+    unsigned long long *uid_dev = nullptr;   // [B] noise stream ids of the current call (fd_set_noise_streams)
     int *range_flag = nullptr;  // [0] predictor GEMM, [1 + 4*block + layer] LVC layers, [13 + d] DBlocks,
                                 // [16 + n] ConvTranspose of block n, [19] predictor front: an operand did not fit fp16; 32 words, zeroed every step;
                                 // words 32..63: the same flags of the previous sampler step (skip_after_previous_overflow)
@@ -153,7 +157,7 @@ struct fd_context {
     bool lvc_f16 = true;                      // LVC layers (hop 64, 256) likewise
     bool conv_f16 = true;                     // DBlocks, ConvTranspose upsamplers and the predictor front likewise
     const int *step_lens = nullptr;           // device copy of the caller's `lens` for this call (ragged batch), or null
-    std::vector<int> lens_host;               // staging copy for the asynchronous upload
+    std::vector<unsigned long long> noise_ids; // fd_set_noise_streams: consumed by the next fd_sample
     bool h_image_ready = false;               // set by fast_kp_front when it wrote the GEMM's fp16 image of h for this step
     std::map<std::string, std::pair<std::vector<int64_t>, std::vector<float>>> raw;   // host copies from fd_set_weight
     std::vector<void *> dev_allocs;          // weight arena pieces
@@ -163,7 +167,6 @@ struct fd_context {
     bool final_fused = false;                // set by the last LVC layer's launch, consumed by fast_final
     MelTables mel[MEL_VARIANTS];             // [MEL_PWG]: fmin 80, fmax 7600; [MEL_TACOTRON]: fmin 0, fmax 8000 (twiddles/window shared)
     int mel_variant = MEL_PWG;               // option "mel"
-    std::vector<long long> valid_host;       // staging of fd_peak_normalize_int16_ragged's per-utterance sample counts
     std::vector<void *> mel_allocs;           // device memory behind `mel` (built on first use, freed at fd_destroy)
     int last_B = 0, last_T = 0;
     hipStream_t cap_stream = nullptr;
@@ -171,10 +174,13 @@ struct fd_context {
     struct StepGraph { int B, T, steps; unsigned sig; hipGraph_t graph; hipGraphExec_t exec; unsigned long long last_use; };   // `steps` denoiser steps per launch
     std::vector<StepGraph> graphs;           // at most FD_MAX_GRAPHS, least recently used evicted
     unsigned long long graph_clock = 0;
-    static constexpr int PARAM_SLOTS = 8;
-    StepParams *host_params = nullptr;       // pinned staging ring: PARAM_SLOTS per-call parameter blocks, so fd_sample never waits for the stream
-    hipEvent_t param_done[PARAM_SLOTS] = {}; // recorded behind the upload of a slot; waited for before the slot is rewritten
-    unsigned param_slot = 0;
+    // Pinned staging ring for everything a call uploads from the host (step table, lens, noise stream ids, valid counts): a slot
+    // is rewritten only after the event recorded behind its last upload has completed, so no call waits for the stream and no
+    // asynchronous copy ever reads memory the next call has already overwritten.
+    static constexpr int STAGE_SLOTS = 8;
+    struct StageSlot { char *host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; };
+    StageSlot stage[STAGE_SLOTS];
+    unsigned stage_next = 0;
     void *scratch = nullptr;                 // 64 KB device scratch (abs-max words, ...)
     std::vector<ProfEntry> prof_pending;
     std::vector<hipEvent_t> event_pool;
@@ -205,7 +211,7 @@ hipError_t kp_gemm(const Launch &L, int B, int T);
 hipError_t advance_step(const Launch &L);
 hipError_t clear_range_flags(const Launch &L);     // before the first step of a call
 hipError_t mel_frontend(const Launch &L, const float *wav, int B, int64_t n_samples, float *mel, int T);
-hipError_t init_noise(const Launch &L, float *x, int64_t n, unsigned long long seed);
+hipError_t init_noise(const Launch &L, float *x, int64_t n, unsigned long long seed, const unsigned long long *uids, int l4);
 hipError_t peak_normalize_int16(const Launch &L, const float *wav, int B, int64_t len, int16_t *pcm, const long long *valid_dev);
 }  // namespace fdk
 

@@ -339,16 +339,22 @@ hipError_t embed(const Launch &L, const StepIO &io, int B, int n_steps)
     return hipSuccess;
 }
 
-__global__ void k_init_noise(float *x, int64_t n4, unsigned long long seed)
+__global__ void k_init_noise(float *x, int64_t n4, unsigned long long seed, const unsigned long long *uids, int l4)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n4) reinterpret_cast<float4 *>(x)[i] = philox_normal4(seed, 0xFFFFFFFFu, (uint64_t)i);
+    if (i >= n4) return;
+    if (uids) {
+        const int b = (int)(i / l4);
+        reinterpret_cast<float4 *>(x)[i] = philox_normal4(seed, 0xFFFFFFFFu, (uint64_t)(i - (int64_t)b * l4), uids[b]);
+    } else {
+        reinterpret_cast<float4 *>(x)[i] = philox_normal4(seed, 0xFFFFFFFFu, (uint64_t)i);
+    }
 }
 
-hipError_t init_noise(const Launch &L, float *x, int64_t n, unsigned long long seed)
+hipError_t init_noise(const Launch &L, float *x, int64_t n, unsigned long long seed, const unsigned long long *uids, int l4)
 {
     const int64_t n4 = n / 4;   // n = B*T*256 is a multiple of 4
-    FD_LAUNCH(L, "init_noise", k_init_noise, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, x, n4, seed);
+    FD_LAUNCH(L, "init_noise", k_init_noise, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, x, n4, seed, uids, l4);
     return hipSuccess;
 }
 

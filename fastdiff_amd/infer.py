@@ -40,12 +40,28 @@ def load_mel_inputs(test_input_dir: str) -> List[dict]:
     return items
 
 
+def pcm_to_float(pcm: np.ndarray, what: str = "wav") -> np.ndarray:
+    """Samples of a RIFF file as float32 in [-1, 1), the way librosa.core.load (soundfile) hands them to process_utterance
+    (data_gen/tts/data_gen_utils.py:100): every integer width is divided by its full scale (uint8 is offset binary, 24-bit PCM
+    arrives from scipy left-aligned in int32), float files pass through.  Anything else is refused rather than guessed."""
+    if pcm.dtype == np.uint8:
+        return (pcm.astype(np.float32) - 128.0) / 128.0
+    if pcm.dtype in (np.int16, np.int32):
+        return pcm.astype(np.float32) / float(-int(np.iinfo(pcm.dtype).min))
+    if pcm.dtype in (np.float32, np.float64):
+        wav = pcm.astype(np.float32)
+        if wav.size and float(np.abs(wav).max()) > 1.0 + 1e-6:
+            raise ValueError(f"{what}: float samples outside [-1, 1] (peak {float(np.abs(wav).max()):.3g})")
+        return wav
+    raise ValueError(f"{what}: unsupported sample type {pcm.dtype}")
+
+
 def load_wav_inputs(model, test_input_dir: str, sample_rate: int = 22050, mel_variant: str = "pwg") -> List[dict]:
     """Copy-synthesis inputs (`test_input_dir` with recordings, tasks/vocoder/dataset_utils.py:162-184): every *.wav below the
     directory, in sorted order, through the device mel front-end (`FastDiff.mel_spectrogram` = process_utterance of
     data_gen/tts/data_gen_utils.py:93-147, or with mel_variant="tacotron" the TacotronSTFT of vocoder_binarizer_tacotron.py:110-116
-    for models trained on FastDiff_tacotron.yaml features).  int16 PCM is scaled by 1/32768 as librosa.core.load does; the sample
-    rate must already be the model's (no resampler here)."""
+    for models trained on FastDiff_tacotron.yaml features).  Integer PCM is scaled by its full range as librosa.core.load does
+    (pcm_to_float); the sample rate must already be the model's (no resampler here)."""
     from scipy.io import wavfile
     items = []
     for path in sorted(glob.glob(f"{test_input_dir}/*.wav")):
@@ -54,7 +70,7 @@ def load_wav_inputs(model, test_input_dir: str, sample_rate: int = 22050, mel_va
             raise ValueError(f"{path}: sample rate {sr}, expected {sample_rate}")
         if pcm.ndim != 1:
             raise ValueError(f"{path}: expected mono audio, got shape {pcm.shape}")
-        wav = pcm.astype(np.float32) / 32768.0 if pcm.dtype == np.int16 else pcm.astype(np.float32)
+        wav = pcm_to_float(pcm, path)
         mel = model.mel_spectrogram(torch.from_numpy(wav).cuda(), variant=mel_variant)[0].transpose(0, 1).contiguous().cpu()      # [T, 80] as on disk
         items.append({"item_name": path[len(test_input_dir) + 1:].replace("/", "_"), "mel": mel, "len": mel.shape[0]})
     return items
@@ -90,7 +106,10 @@ def distributed_sampler_indices(n_items: int, rank: int, world_size: int) -> Lis
 
 def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 8, seed: int = 0, drop_last_frame: bool = True,
                noise_schedule=None, diffusion_hyperparams=None) -> Dict[str, np.ndarray]:
-    """item_name -> int16 PCM of its own length (hop 256 x frames), through length-sorted padded micro-batches."""
+    """item_name -> int16 PCM of its own length (hop 256 x frames), through length-sorted padded micro-batches.
+    Noise: utterance `it` draws x_T and z from Philox stream (seed, it["uid"]) over its own samples (fd_set_noise_streams); "uid"
+    defaults to the item's position in `items`, callers that shard a job put the utterance's index in the WHOLE job there, so a
+    waveform does not depend on the micro-batch, rank or world size that produced it."""
     if diffusion_hyperparams is None:
         diffusion_hyperparams = schedules.training_hyperparams()
     if noise_schedule is None:
@@ -109,10 +128,12 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
         mels, lens, names = collate_test_batch([items[i] for i in batch_idx], drop_last_frame)
         if mels is None:
             continue
+        uid_of = {items[i]["item_name"]: int(items[i].get("uid", i)) for i in batch_idx}
         mels = mels.pin_memory().cuda(non_blocking=True)
         B, _, T = mels.shape
         wav = sampling_given_noise_schedule(model, (B, 1, T * model.hop_length), diffusion_hyperparams, noise_schedule,
-                                            condition=mels, ddim=False, return_sequence=False, seed=seed + k, verbose=False, lens=lens)
+                                            condition=mels, ddim=False, return_sequence=False, seed=seed, verbose=False, lens=lens,
+                                            stream_ids=[uid_of[n] for n in names])
         # one epilogue call and one asynchronous copy per micro-batch; the previous batch is unpacked on the host while this one runs
         pcm = model.peak_normalize_int16(wav, valid=[t * model.hop_length for t in lens])
         host = torch.empty(pcm.shape, dtype=torch.int16).pin_memory()
@@ -125,6 +146,38 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
     if pending is not None:
         collect(pending)
     return out
+
+
+def synthesize_sharded(model, items, n_steps: int = 4, max_batch: int = 8, seed: int = 0, drop_last_frame: bool = True, src: int = 0,
+                       device=None) -> Dict[str, np.ndarray]:
+    """BASELINE config 4 as north_star words it: rank `src` holds all utterances (items; None elsewhere) -> length-balanced
+    partition (shard.partition_utterances) -> scatter of the mels -> every rank vocodes its share in padded micro-batches on its
+    own GPU -> gather of the int16 PCM on `src`, which returns item_name -> PCM (the other ranks return {}).  The process group
+    must be initialised; `device` is where the messages are staged (the GPU for RCCL, None = host for gloo).  Without a process
+    group (one process) this is synthesize()."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return synthesize(model, items, n_steps, max_batch, seed, drop_last_frame)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    meta = [None]
+    if rank == src:      # the collater's view of every item: [80, T'] with the last frame dropped, too-short items left out
+        kept = [it for it in items if not drop_last_frame or it["mel"].shape[0] >= 2]
+        mels = [(it["mel"][: it["mel"].shape[0] - 1] if drop_last_frame else it["mel"]).transpose(0, 1).contiguous() for it in kept]
+        meta = [[it["item_name"] for it in kept]]
+    dist.broadcast_object_list(meta, src=src)
+    names = meta[0]
+    lens_src = [m.shape[-1] for m in mels] if rank == src else [0] * len(names)
+    lens_t = torch.tensor(lens_src, dtype=torch.int64, device=device)
+    dist.broadcast(lens_t, src=src)
+    parts = shard.partition_utterances(lens_t.tolist(), world)
+    mine, lens = shard.scatter_utterances(mels if rank == src else None, parts, src=src, device=device)
+    local = [{"item_name": str(i), "mel": m.transpose(0, 1), "len": m.shape[-1], "uid": i} for i, m in mine]
+    pcm = synthesize(model, local, n_steps, max_batch, seed, drop_last_frame=False)
+    wavs = [(i, torch.from_numpy(pcm[str(i)]).to(device) if device is not None else torch.from_numpy(pcm[str(i)])) for i, _ in mine]
+    out = shard.gather_waveforms(wavs, lens, parts, hop=model.hop_length, dst=src, device=device, dtype=torch.int16)
+    if rank != src:
+        return {}
+    return {names[i]: out[i].cpu().numpy() for i in range(len(names))}
 
 
 def save_wavs(pcm: Dict[str, np.ndarray], out_dir: str, sample_rate: int = 22050) -> List[str]:
@@ -157,8 +210,8 @@ def main(argv=None):
     if args.ckpt:
         model.load_state_dict(torch.load(args.ckpt, map_location="cpu")["state_dict"]["model"], strict=True)
     items = load_wav_inputs(model, args.test_input_dir, mel_variant=args.mel_variant) if args.from_wav else load_mel_inputs(args.test_input_dir)
-    mine = [items[i] for i in sorted(set(distributed_sampler_indices(len(items), rank, world)))]
-    paths = save_wavs(synthesize(model, mine, args.N, args.max_batch, args.seed + rank), args.out_dir)
+    mine = [dict(items[i], uid=i) for i in sorted(set(distributed_sampler_indices(len(items), rank, world)))]
+    paths = save_wavs(synthesize(model, mine, args.N, args.max_batch, args.seed), args.out_dir)
     print(f"rank {rank}/{world}: wrote {len(paths)} files to {args.out_dir}")
 
 

@@ -155,13 +155,15 @@ class FastDiff(nn.Module):
         return out
 
     # ---- HIP-side entry used by fastdiff_amd.util.sampling_given_noise_schedule ---------------------------
-    def sample(self, condition, table, ddim=False, x_T=None, noise=None, seed=0, return_sequence=False, lens=None):
+    def sample(self, condition, table, ddim=False, x_T=None, noise=None, seed=0, return_sequence=False, lens=None, stream_ids=None):
         """Run the N-step reverse loop on the device.
 
         table: list of dicts with keys t, c_eps, c_div, sigma, c1, c2, c3, add_noise (executed first -> last).
         x_T [B,1,L] / noise [N,B,1,L] optional device tensors (None -> on-device Philox keyed by `seed`).
         lens: optional valid frames per utterance of a zero-padded batch: utterance b is then computed as if it were alone
-        and lens[b] frames long (its first lens[b]*256 samples are exactly that result; the rest of its row is unspecified)."""
+        and lens[b] frames long (its first lens[b]*256 samples are exactly that result; the rest of its row is unspecified).
+        stream_ids: optional [B] integers (fd_set_noise_streams): utterance b draws its noise from Philox stream (seed, stream_ids[b])
+        over its own samples, i.e. independently of its place in the batch."""
         B = condition.shape[0]
         self._require_inference(condition, condition)
         condition = condition.contiguous().float()
@@ -183,6 +185,10 @@ class FastDiff(nn.Module):
             assert tuple(noise.shape) == (N, B, 1, L)
         lib, h = self._ready(dev)
         lens_arr = None if lens is None else (ct.c_int * B)(*[int(v) for v in lens])
+        if stream_ids is not None:
+            assert len(stream_ids) == B
+            ids = (ct.c_uint64 * B)(*[int(v) & 0xFFFFFFFFFFFFFFFF for v in stream_ids])
+            _capi.check(lib, h, lib.fd_set_noise_streams(h, ids, B), "fd_set_noise_streams")
         rc = lib.fd_sample(h, condition.data_ptr(), B, T, lens_arr, steps, N, int(bool(ddim)),
                            None if x_T is None else x_T.data_ptr(), None if noise is None else noise.data_ptr(),
                            ct.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), out.data_ptr(),

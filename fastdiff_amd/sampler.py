@@ -116,7 +116,7 @@ def _apply_row(x, eps, row, ddim, z):
 
 def sampling_given_noise_schedule(net, size, diffusion_hyperparams, inference_noise_schedule, condition=None,
                                   ddim=False, return_sequence=False, *, x_T=None, noise=None, seed=None,
-                                  noise_source="device", verbose=True, lens=None):
+                                  noise_source="device", verbose=True, lens=None, stream_ids=None):
     """x_0 ~ p(x_0|x_T) under a given inference schedule; same positional signature as util.py:158-165.
 
     `net` a fastdiff_amd.FastDiff: the whole loop runs on the MI355X (one captured denoiser step replayed N times).
@@ -125,6 +125,7 @@ def sampling_given_noise_schedule(net, size, diffusion_hyperparams, inference_no
     noise_source="reference" draws them with std_normal in the reference's order, so a seeded run reproduces the
     reference's random stream.  Any other callable `net` is driven step by step from the host with the same tables.
     lens (FastDiff nets only): valid frames per utterance of a zero-padded batch; every utterance is then computed as if alone.
+    stream_ids (FastDiff nets only): per-utterance noise streams, see FastDiff.sample.
     Returns the tensor of shape `size`, or the list of N+1 intermediate tensors when return_sequence=True."""
     assert len(size) == 3
     sched = InferenceSchedule(diffusion_hyperparams, inference_noise_schedule, verbose)
@@ -145,7 +146,7 @@ def sampling_given_noise_schedule(net, size, diffusion_hyperparams, inference_no
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         with torch.no_grad():
             return net.sample(cond.cuda(), rows, ddim=ddim, x_T=x_T, noise=noise, seed=seed,
-                              return_sequence=return_sequence, lens=lens)
+                              return_sequence=return_sequence, lens=lens, stream_ids=stream_ids)
 
     # a denoiser this package does not own: drive it from the host
     x = std_normal(size) if x_T is None else x_T.clone()

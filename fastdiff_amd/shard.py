@@ -4,8 +4,9 @@ The reference shards inference the same way: one process per GPU (utils/trainer.
 utterances `r::world` of a DistributedSampler(shuffle=False) (tasks/vocoder/vocoder_base.py:43-49) and there is no
 collective on the data path.  Here the partition is length-balanced (longest-processing-time greedy) because padded
 micro-batches cost max(T_i); the optional scatter/gather moves mels out and waveforms back point-to-point over
-torch.distributed (RCCL over xGMI on the GPUs, gloo in the CPU tests) -- messages are <1 MB per utterance, there is
-no all-reduce anywhere.
+torch.distributed (RCCL over xGMI on the GPUs, gloo in the CPU tests): one packed message per peer each way, posted as one
+grouped send/recv (dist.batch_isend_irecv) -- <= 2.2 MB out and 3.5 MB back per peer for BASELINE config 4; there is no
+all-reduce anywhere.
 """
 from typing import List, Sequence
 
@@ -45,49 +46,76 @@ def pad_mels(mels: Sequence[torch.Tensor], pad_value: float = 0.0) -> torch.Tens
     return out
 
 
+def _as_bytes(t: torch.Tensor) -> torch.Tensor:
+    """A flat uint8 view of a contiguous tensor: the one element type every backend moves (RCCL has no int16)."""
+    return t.contiguous().view(-1).view(torch.uint8)
+
+
+def _exchange(ops):
+    """Post all point-to-point operations of this rank as ONE group (ncclGroupStart/End on RCCL, plain isend/irecv on gloo)
+    and wait for them.  Messages between a pair of ranks are matched in posting order; no tags (RCCL ignores them)."""
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
 def scatter_utterances(mels: Sequence[torch.Tensor], parts: List[List[int]], src: int = 0, device=None):
     """Rank `src` holds all mels ([80,T_i] each); afterwards every rank holds its own (index, mel) list.
-    Point-to-point isend/irecv; lengths travel first as one small broadcast."""
+    Lengths travel first as one small broadcast; then ONE packed message per peer (its utterances back to back, in the order of
+    parts[r]) in a single grouped send/recv -- at most world-1 messages leave `src`, whatever the number of utterances."""
     rank, world = dist.get_rank(), dist.get_world_size()
     n = sum(len(p) for p in parts)
     lens = torch.zeros(n, dtype=torch.int64, device=device)
     if rank == src:
         lens = torch.tensor([m.shape[-1] for m in mels], dtype=torch.int64, device=device)
     dist.broadcast(lens, src=src)
+    lens_l = [int(v) for v in lens.tolist()]
     mine = []
     if rank == src:
-        reqs = []
+        ops, keep = [], []
         for r in range(world):
-            for i in parts[r]:
-                if r == src:
-                    mine.append((i, mels[i].to(device) if device is not None else mels[i]))
-                else:
-                    reqs.append(dist.isend(mels[i].contiguous().to(device) if device is not None else mels[i].contiguous(), dst=r, tag=i))
-        for q in reqs:
-            q.wait()
-    else:
+            if r == src:
+                mine = [(i, mels[i].to(device) if device is not None else mels[i]) for i in parts[r]]
+            elif parts[r]:
+                buf = torch.cat([mels[i].reshape(-1).float() for i in parts[r]])
+                buf = buf.to(device) if device is not None else buf.contiguous()
+                keep.append(buf)
+                ops.append(dist.P2POp(dist.isend, buf, r))
+        _exchange(ops)
+    elif parts[rank]:
+        buf = torch.empty(80 * sum(lens_l[i] for i in parts[rank]), dtype=torch.float32, device=device)
+        _exchange([dist.P2POp(dist.irecv, buf, src)])
+        off = 0
         for i in parts[rank]:
-            buf = torch.empty((80, int(lens[i])), dtype=torch.float32, device=device)
-            dist.recv(buf, src=src, tag=i)
-            mine.append((i, buf))
-    return mine, lens.tolist()
+            mine.append((i, buf[off: off + 80 * lens_l[i]].view(80, lens_l[i])))
+            off += 80 * lens_l[i]
+    return mine, lens_l
 
 
-def gather_waveforms(mine, lens: Sequence[int], parts: List[List[int]], hop: int = 256, dst: int = 0, device=None):
-    """Inverse of scatter_utterances: rank `dst` ends up with the list of waveforms ([T_i*hop] each) in index order."""
+def gather_waveforms(mine, lens: Sequence[int], parts: List[List[int]], hop: int = 256, dst: int = 0, device=None,
+                     dtype: torch.dtype = torch.float32):
+    """Inverse of scatter_utterances: rank `dst` ends up with the list of waveforms ([T_i*hop] each, float32 or the int16 PCM of
+    the device epilogue) in index order.  One packed message per peer, all receives of `dst` posted as one group."""
     rank, world = dist.get_rank(), dist.get_world_size()
     if rank != dst:
-        for i, wav in mine:
-            dist.send(wav.contiguous(), dst=dst, tag=i)
+        if mine:
+            by_idx = dict(mine)
+            buf = torch.cat([by_idx[i].reshape(-1).to(dtype) for i in parts[rank]])
+            _exchange([dist.P2POp(dist.isend, _as_bytes(buf), dst)])
         return None
     out = [None] * len(lens)
     for i, wav in mine:
         out[i] = wav
+    ops, bufs = [], {}
     for r in range(world):
-        if r == dst:
+        if r == dst or not parts[r]:
             continue
+        bufs[r] = torch.empty(sum(int(lens[i]) * hop for i in parts[r]), dtype=dtype, device=device)
+        ops.append(dist.P2POp(dist.irecv, _as_bytes(bufs[r]), r))
+    _exchange(ops)
+    for r, buf in bufs.items():
+        off = 0
         for i in parts[r]:
-            buf = torch.empty(int(lens[i]) * hop, dtype=torch.float32, device=device)
-            dist.recv(buf, src=r, tag=i)
-            out[i] = buf
+            out[i] = buf[off: off + int(lens[i]) * hop]
+            off += int(lens[i]) * hop
     return out

@@ -114,6 +114,13 @@ FD_API int fd_sample(fd_handle h, const float *mel, int B, int T, const int *len
                      int ddim, const float *x_T, const float *z, uint64_t seed, float *out, float *seq_out,
                      void *stream);
 
+/* Per-utterance noise streams for the NEXT fd_sample call (one-shot; the reference draws std_normal per batch on the CPU,
+ * util.py:63-68, so it has no counterpart there).  stream_ids [B] host: utterance b's x_T and z are then drawn from Philox stream
+ * (seed, stream_ids[b]) with the counter running over the utterance's own samples -- the draw no longer depends on the position in
+ * the batch or on the padded length, so an utterance gets the same waveform however a job is batched or sharded over GPUs
+ * (fastdiff_amd/infer.py keys it on the utterance's index in the job).  Ignored for injected x_T / z. */
+FD_API int fd_set_noise_streams(fd_handle h, const uint64_t *stream_ids, int B);
+
 /* Waveform epilogue: wav/abs(wav).max() per utterance (FastDiff.py:110), *32767 -> int16
  * (utils/audio.py:11-16).  wav [B,1,L] device -> pcm [B,L] device int16. */
 FD_API int fd_peak_normalize_int16(fd_handle h, const float *wav, int B, int64_t L, int16_t *pcm, void *stream);
