@@ -161,17 +161,17 @@ def synthesize_sharded(model, items, n_steps: int = 4, max_batch: int = 8, seed:
     rank, world = dist.get_rank(), dist.get_world_size()
     meta = [None]
     if rank == src:      # the collater's view of every item: [80, T'] with the last frame dropped, too-short items left out
-        kept = [it for it in items if not drop_last_frame or it["mel"].shape[0] >= 2]
-        mels = [(it["mel"][: it["mel"].shape[0] - 1] if drop_last_frame else it["mel"]).transpose(0, 1).contiguous() for it in kept]
-        meta = [[it["item_name"] for it in kept]]
+        kept = [(i, it) for i, it in enumerate(items) if not drop_last_frame or it["mel"].shape[0] >= 2]
+        mels = [(it["mel"][: it["mel"].shape[0] - 1] if drop_last_frame else it["mel"]).transpose(0, 1).contiguous() for _, it in kept]
+        meta = [([it["item_name"] for _, it in kept], [int(it.get("uid", i)) for i, it in kept])]
     dist.broadcast_object_list(meta, src=src)
-    names = meta[0]
+    names, uids = meta[0]
     lens_src = [m.shape[-1] for m in mels] if rank == src else [0] * len(names)
     lens_t = torch.tensor(lens_src, dtype=torch.int64, device=device)
     dist.broadcast(lens_t, src=src)
     parts = shard.partition_utterances(lens_t.tolist(), world)
     mine, lens = shard.scatter_utterances(mels if rank == src else None, parts, src=src, device=device)
-    local = [{"item_name": str(i), "mel": m.transpose(0, 1), "len": m.shape[-1], "uid": i} for i, m in mine]
+    local = [{"item_name": str(i), "mel": m.transpose(0, 1), "len": m.shape[-1], "uid": uids[i]} for i, m in mine]
     pcm = synthesize(model, local, n_steps, max_batch, seed, drop_last_frame=False)
     wavs = [(i, torch.from_numpy(pcm[str(i)]).to(device) if device is not None else torch.from_numpy(pcm[str(i)])) for i, _ in mine]
     out = shard.gather_waveforms(wavs, lens, parts, hop=model.hop_length, dst=src, device=device, dtype=torch.int16)

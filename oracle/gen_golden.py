@@ -378,6 +378,108 @@ def gen_frontend_tacotron():
     np.savez_compressed(os.path.join(GOLD, "frontend_tacotron_lj001_0002.npz"), mel_ref_f32=mel)
 
 
+def _ast_pick(path, *, functions=(), klass=None, methods=()):
+    """Definitions cut out of a reference file that cannot be imported here (absent third-party modules at its top)."""
+    import ast
+    tree = ast.parse(open(path).read())
+    out = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in functions]
+    if klass:
+        c = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == klass)
+        body = [n for n in c.body if isinstance(n, ast.FunctionDef) and n.name in methods]
+        out.append(ast.ClassDef(name=klass, bases=[], keywords=[], body=body, decorator_list=[]))
+    return ast.fix_missing_locations(ast.Module(body=out, type_ignores=[]))
+
+
+def gen_collater():
+    """The reference's OWN test-time path from a mel directory to the batch the model sees, executed here:
+    VocoderDataset.load_mel_inputs -> __getitem__ -> collater (tasks/vocoder/dataset_utils.py:186-204, 80-98, 100-160) with
+    VocoderBinarizer.process_mel_item (data_gen/tts/vocoder_binarizer.py:115-122) and utils.collate_2d.  Neither file imports here
+    (resemblyzer, chardet, tensorboard, librosa are absent), so the method bodies are cut out with ast and run unmodified against
+    stand-ins for what they reach: `hparams` (use_wav False, test-time values), `utils.collate_2d` (the reference's own, also
+    cut out), a registered module holding the binarizer class."""
+    import glob as _glob, importlib, tempfile, types
+    ns_u = {"torch": torch}
+    exec(compile(_ast_pick(os.path.join(REF, "utils", "__init__.py"), functions=("collate_1d", "collate_2d")), "utils", "exec"), ns_u)
+    utils_stub = types.SimpleNamespace(collate_2d=ns_u["collate_2d"], collate_1d=ns_u["collate_1d"])
+    ns_b = {"np": np}
+    exec(compile(_ast_pick(os.path.join(REF, "data_gen", "tts", "vocoder_binarizer.py"), klass="VocoderBinarizer", methods=("process_mel_item",)),
+                 "vocoder_binarizer", "exec"), ns_b)
+    mod = types.ModuleType("fd_ref_binarizer")
+    mod.VocoderBinarizer = ns_b["VocoderBinarizer"]
+    sys.modules["fd_ref_binarizer"] = mod
+    hp = {"use_wav": False, "binarizer_cls": "fd_ref_binarizer.VocoderBinarizer", "binarization_args": {}, "use_spk_embed": False,
+          "use_emo_embed": False}
+    ns_d = {"np": np, "torch": torch, "glob": _glob, "importlib": importlib, "utils": utils_stub, "hparams": hp}
+    exec(compile(_ast_pick(os.path.join(REF, "tasks", "vocoder", "dataset_utils.py"), klass="VocoderDataset",
+                           methods=("load_mel_inputs", "collater", "__getitem__", "_get_item")), "dataset_utils", "exec"), ns_d)
+    ds = ns_d["VocoderDataset"].__new__(ns_d["VocoderDataset"])
+    # the attributes VocoderDataset.__init__ sets for prefix == 'test' (dataset_utils.py:50-58; base.yaml: aux_context_window 0)
+    ds.hparams, ds.batch_max_frames, ds.aux_context_window, ds.hop_size = hp, 0, 0, 256
+    g = torch.Generator().manual_seed(78)
+    # sorted(glob('*.npy')) sees only the top level.  (A one-frame mel is not in the set: `.squeeze(0)` at dataset_utils.py:110
+    # turns [1, 80] into [80] and collate_2d then fails its numel assert -- the reference cannot collate it.)
+    files = {"b/x.npy": 7, "a.npy": 5, "c.npy": 12, "sub_dir.npy": 2}
+    arrays = {}
+    with tempfile.TemporaryDirectory() as d:
+        for name, t in files.items():
+            os.makedirs(os.path.dirname(os.path.join(d, name)), exist_ok=True)
+            m = (torch.rand(t, 80, generator=g) * 13.5 - 11.5).numpy()
+            np.save(os.path.join(d, name), m)
+            arrays["in_" + name.replace("/", "__")] = m
+        ds.indexed_ds, ds.sizes = ds.load_mel_inputs(d)
+        ds.avail_idxs = list(range(len(ds.sizes)))
+        samples = [ds[i] for i in range(len(ds.sizes))]
+    np.random.seed(0)
+    batch = ds.collater(samples)
+    assert batch["wavs"] == [] and batch["z"] == []
+    mels = batch["mels"].contiguous().numpy()
+    lens = [s["mel"].shape[0] for s in samples]
+    print("collater", mels.shape, batch["item_name"], "sizes", ds.sizes)
+    np.savez_compressed(os.path.join(GOLD, "collater.npz"), mels=mels, item_names=np.array(batch["item_name"]), sizes=np.array(ds.sizes),
+                        in_lens=np.array(lens), file_names=np.array(list(files)), **arrays)
+
+
+def gen_frontend_pwg():
+    """The reference's OWN process_utterance (data_gen/tts/data_gen_utils.py:93-147, vocoder='pwg'), cut out with ast (the file's
+    imports need parselmouth, webrtcvad, skimage, pyloudnorm, librosa) and executed on the sample recording.  What it reaches is
+    supplied by stand-ins: `audio.librosa_pad_lr` is the reference's own (utils/audio.py:67-76, cut out too); `librosa.stft` is
+    torch.stft with the arguments librosa documents for this call (centered, zero padding, periodic Hann, onesided) -- an
+    independent implementation of the same definition; `librosa.filters.mel` returns the restated filter bank of
+    oracle/mel_frontend.py: THE FILTER VALUES REMAIN RESTATED, everything around them (magnitude, the matrix product, the log10
+    clamp at 1e-6, the frame count, the padding and trimming of the returned wav) is the reference's code."""
+    import types
+    from scipy.io import wavfile
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mel_frontend as mf
+
+    def stft(y, n_fft, hop_length, win_length, window, pad_mode):
+        assert window == "hann" and pad_mode == "constant" and win_length == n_fft
+        w = torch.hann_window(win_length, periodic=True, dtype=torch.float64).to(torch.from_numpy(np.asarray(y)).dtype)
+        X = torch.stft(torch.from_numpy(np.asarray(y)), n_fft, hop_length, win_length, w, center=True, pad_mode="constant",
+                       onesided=True, return_complex=True)
+        return X.numpy()
+
+    lib = types.SimpleNamespace(stft=stft, filters=types.SimpleNamespace(
+        mel=lambda sr, n_fft, n_mels, fmin, fmax: mf.mel_basis(sr, n_fft, n_mels, fmin, fmax).astype(np.float32)))
+    ns_a = {"np": np}
+    exec(compile(_ast_pick(os.path.join(REF, "utils", "audio.py"), functions=("librosa_pad_lr",)), "audio", "exec"), ns_a)
+    ns = {"np": np, "librosa": lib, "audio": types.SimpleNamespace(librosa_pad_lr=ns_a["librosa_pad_lr"])}
+    exec(compile(_ast_pick(os.path.join(REF, "data_gen", "tts", "data_gen_utils.py"), functions=("process_utterance",)), "data_gen_utils", "exec"), ns)
+    sr, pcm = wavfile.read(os.path.join(REF, "egs", "audios", "LJ001-0002_gt.wav"))
+    wav32 = (pcm.astype(np.float32) / 32768.0)                  # what librosa.core.load returns: float32 in [-1, 1)
+    out = {}
+    for tag, wav in (("f32", wav32), ("f64", wav32.astype(np.float64))):
+        # the keyword values of PWG.wav2spec (vocoders/pwg.py:107-123) under base.yaml:4-16
+        wav_out, mel = ns["process_utterance"](wav, fft_size=1024, hop_size=256, win_length=1024, num_mels=80, fmin=80, fmax=7600,
+                                               sample_rate=22050, loud_norm=False, min_level_db=-100, return_linear=False, vocoder="pwg")
+        out["mel_ref_" + tag] = mel
+        out["wav_len_" + tag] = np.int64(len(wav_out))
+    ours = mf.log_mel(wav32.astype(np.float64))
+    print("frontend_pwg", out["mel_ref_f64"].shape, "restatement max|d log10 mel| =", float(np.abs(out["mel_ref_f64"] - ours).max()),
+          " f32 run:", float(np.abs(out["mel_ref_f32"] - ours).max()))
+    np.savez_compressed(os.path.join(GOLD, "frontend_pwg_lj001_0002.npz"), **out)
+
+
 def gen_statedict_manifest():
     """Key set + shapes of the reference module's state_dict, and a default-init digest, for the drop-in shim test."""
     torch.manual_seed(SEED)
@@ -393,7 +495,8 @@ def gen_statedict_manifest():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["schedule", "embed", "ops", "forward", "sample", "manifest", "collate", "frontend", "frontend_tacotron", "noise_scheduling", "theta_loss"]
+    which = sys.argv[1:] or ["schedule", "embed", "ops", "forward", "sample", "manifest", "collate", "collater", "frontend", "frontend_tacotron",
+                             "frontend_pwg", "noise_scheduling", "theta_loss"]
     dh = gen_schedule()
     if "embed" in which:
         gen_embed()
@@ -407,6 +510,10 @@ if __name__ == "__main__":
         gen_statedict_manifest()
     if "collate" in which:
         gen_collate()
+    if "collater" in which:
+        gen_collater()
+    if "frontend_pwg" in which:
+        gen_frontend_pwg()
     if "frontend" in which:
         gen_frontend()
     if "theta_loss" in which:

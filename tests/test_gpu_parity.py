@@ -613,6 +613,88 @@ def test_full_size_sampler_n4(model, gc, sched):
     assert a.shape == (B, 1, T * 256)
 
 
+@pytest.mark.parametrize("ddim", [False, True])
+def test_full_size_sampler_against_oracle(model, gc, sched, oracle64, ddim):
+    """BASELINE shape through the whole reverse loop: B=1, T=864 (221,184 samples), N=4, injected x_T and z, against the float64
+    oracle's sampling_given_noise_schedule (util.py:158-235), DDPM and "ddim" branches.  Tolerance: the N<=8 loop bar, 1e-4."""
+    import synth
+    B, T, N = 1, 864, 4
+    mel = synth.synth_mel(21, B, T)
+    x_T = synth.hash_normal(21, 1, B * T * 256).reshape(B, 1, T * 256)
+    z = gc.noise_from_seed(21, B, T, N)
+    rows, table = gc.table_rows(sched, N)
+    ref = oracle64.sample(mel, table, x_T, z, ddim=ddim)
+    with torch.no_grad():
+        y = model.sample(torch.from_numpy(mel).cuda(), rows, ddim=ddim, x_T=torch.from_numpy(x_T).cuda(),
+                         noise=torch.from_numpy(gc.exec_order_noise(z)).cuda())
+    d = gc.maxdiff(y.cpu().numpy(), ref)
+    print(f"full-size N=4 sampler (ddim={ddim}): max|d| = {d:.3e}, max|x_0| = {np.abs(ref).max():.3f}")
+    assert d < LOOP_TOL
+    assert not model.read_tap("range_flags").view(np.int32).any()      # the fp16x2 pipe did this, not the fp32 fallback
+
+
+def test_full_size_batch_sampler_items_equal_alone_runs(model, gc, sched):
+    """B=8, T=864, N=4 on device Philox noise with per-utterance streams: two items of the batch are bit-equal to their own B=1
+    runs (so the B=1 oracle comparison above speaks for every item of the benchmark batch)."""
+    import synth
+    B, T = 8, 864
+    mel = torch.from_numpy(synth.synth_mel(5, B, T)).cuda()
+    rows, _ = gc.table_rows(sched, 4)
+    with torch.no_grad():
+        y = model.sample(mel, rows, seed=77, stream_ids=list(range(100, 100 + B)))
+        for b in (2, 7):
+            alone = model.sample(mel[b:b + 1].contiguous(), rows, seed=77, stream_ids=[100 + b])
+            assert torch.equal(y[b], alone[0]), b
+        other = model.sample(mel[2:3].contiguous(), rows, seed=77, stream_ids=[107])
+        assert not torch.equal(other[0], y[2])                          # the stream id, not the batch position, picks the noise
+
+
+def device_noise(model, T, N, seed, uid):
+    """The exact x_T and z_k the device draws for one utterance of noise stream (seed, uid): the sampler run with c_eps = 0,
+    c_div = 1 on a zero mel, so that x never sees the network.  z[k] is the draw of executed step k (zeros where add_noise = 0)."""
+    L = T * 256
+    idle = {"t": 0.0, "c_eps": 0.0, "c_div": 1.0, "sigma": 0.0, "c1": 1.0, "c2": 0.0, "c3": 0.0, "add_noise": 0}
+    mel0 = torch.zeros(1, 80, T).cuda()
+    with torch.no_grad():
+        x_T = model.sample(mel0, [idle] * N, seed=seed, stream_ids=[uid], return_sequence=True)[0].cpu().numpy()
+        z = np.zeros((N, 1, 1, L), np.float32)
+        for k in range(N - 1):
+            rows = [dict(idle) for _ in range(N)]
+            rows[k]["sigma"], rows[k]["add_noise"] = 1.0, 1
+            z[k] = model.sample(mel0, rows, seed=seed, stream_ids=[uid], x_T=torch.zeros(1, 1, L).cuda()).cpu().numpy()
+    return x_T, z
+
+
+def test_config5_tacotron_batch16_through_the_driver(gc, sched, oracle64):
+    """BASELINE configs[4]: 16 Tacotron-range mels (rand*13.5 - 11.5, the range of ln(clamp(., 1e-5))), stored [T, 80] as on disk,
+    through infer.synthesize (test-time collater incl. the dropped last frame, one padded batch of 16 with `lens`, device Philox
+    noise, device int16 epilogue), N=4.  Three items -- the shortest, the longest, one in between -- against the float64 oracle's
+    N=4 output for the SAME noise (read back from the device), peak-normalised to int16: within 1 LSB."""
+    from fastdiff_amd import infer
+    m = gc.make_model()
+    rng = np.random.default_rng(50)
+    lens = rng.integers(300, 865, 16).tolist()
+    lens[3], lens[11] = 300, 864
+    items = [{"item_name": f"taco{i:02d}.npy", "mel": torch.from_numpy((rng.random((t, 80)) * 13.5 - 11.5).astype(np.float32)), "len": t}
+             for i, t in enumerate(lens)]
+    pcm = infer.synthesize(m, items, n_steps=4, max_batch=16, seed=2024)
+    assert sorted(pcm) == sorted(it["item_name"] for it in items)
+    rows, table = gc.table_rows(sched, 4)
+    worst = 0
+    for i in (3, 11, 6):
+        t = lens[i] - 1                                         # the collater drops the last frame (dataset_utils.py:116-125)
+        assert pcm[items[i]["item_name"]].shape == (t * 256,)
+        x_T, z_exec = device_noise(m, t, 4, 2024, i)
+        mel = np.ascontiguousarray(items[i]["mel"].numpy()[:t].T)[None]
+        ref = oracle64.sample(mel, table, x_T, np.ascontiguousarray(z_exec[::-1]))
+        ref16 = oracle64.peak_normalize_int16(ref.astype(np.float32)).reshape(-1)
+        d = np.abs(pcm[items[i]["item_name"]].astype(np.int32) - ref16.astype(np.int32))
+        worst = max(worst, int(d.max()))
+        print(f"config5 item {i} (T={t}): int16 max|d| = {int(d.max())}, differing samples {int((d > 0).sum())} of {d.size}")
+        assert d.max() <= 1, i
+    assert not m.read_tap("range_flags").view(np.int32).any()
+
+
 def test_config4_batch64_ragged_n6(gc, sched):
     """BASELINE config 4 at one GPU's share and beyond: B=64 zero-padded utterances with T_i ~ U{200..864} (seeded), the N=6
     schedule (FastDiff.py:86-87), `lens` given.  Properties: finite inside every utterance, reproducible, and sampled utterances
@@ -636,7 +718,7 @@ def test_config4_batch64_ragged_n6(gc, sched):
         for b, t in enumerate(lens):
             assert torch.isfinite(y[b, :, : t * 256]).all(), b
             assert torch.equal(y[b, :, : t * 256], y2[b, :, : t * 256]), b
-    # Philox noise is indexed by the position in the padded batch, so the alone-runs inject the noise explicitly
+    # (without fd_set_noise_streams) Philox noise is indexed by the position in the padded batch, so the alone-runs inject it
     N = len(rows)
     picks = [int(np.argmin(lens)), 17, 40]
     z = np.stack([synth.hash_normal(14, 2 + k, len(picks) * T * 256).reshape(len(picks), 1, T * 256) for k in range(N)])

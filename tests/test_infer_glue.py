@@ -40,6 +40,24 @@ def test_collate_matches_the_references_collate_2d():
         assert not mels[b, :, t:].any()
 
 
+def test_directory_to_batch_matches_the_references_own_collater(tmp_path):
+    """collater.npz was produced by EXECUTING the reference's VocoderDataset.load_mel_inputs -> __getitem__ -> collater
+    (tasks/vocoder/dataset_utils.py:186-204, 80-98, 100-160) with VocoderBinarizer.process_mel_item and collate_2d (oracle/
+    gen_golden.py gen_collater) on a directory of [T, 80] mels: same files here -> same item names, sizes and batch tensor."""
+    g = load_golden("collater")
+    for name in g["file_names"].tolist():
+        path = tmp_path / name
+        os.makedirs(path.parent, exist_ok=True)
+        np.save(path, g["in_" + name.replace("/", "__")])
+    items = infer.load_mel_inputs(str(tmp_path))
+    assert [it["item_name"] for it in items] == g["item_names"].tolist()          # top level only, sorted, ".npy" kept
+    assert [it["len"] for it in items] == g["sizes"].tolist()
+    mels, lens, names = infer.collate_test_batch(items)                            # test time: batch_max_frames = 0
+    assert names == g["item_names"].tolist()
+    assert lens == [t - 1 for t in g["in_lens"].tolist()]                          # the dropped last frame (dataset_utils.py:116-125)
+    assert mels.dtype == torch.float32 and torch.equal(mels, torch.from_numpy(g["mels"]))
+
+
 def test_load_mel_inputs_order_names_and_shapes(tmp_path):
     rng = np.random.default_rng(0)
     for name, t in (("b_second", 7), ("a_first", 5), ("c.third", 3)):
@@ -82,8 +100,10 @@ def test_synthesize_directory_end_to_end(tmp_path):
     assert all(v.dtype == np.int16 and np.abs(v).max() == 32767 for v in pcm.values())
     # the first micro-batch is (y, z): redo it by hand
     mels, lens, names = infer.collate_test_batch([items[1], items[2]])
+    assert names == ["y.npy", "z.npy"]          # items 1 and 2 of the sorted directory: their noise streams
     wav = sampling_given_noise_schedule(model, (2, 1, mels.shape[-1] * 256), schedules.training_hyperparams(),
-                                        schedules.noise_schedule_for(4), condition=mels.cuda(), seed=11, verbose=False, lens=lens)
+                                        schedules.noise_schedule_for(4), condition=mels.cuda(), seed=11, verbose=False, lens=lens,
+                                        stream_ids=[1, 2])
     for b, (name, t) in enumerate(zip(names, lens)):
         own = wav[b, 0, : t * 256]
         ref = (own / own.abs().max() * 32767).cpu().numpy().astype(np.int16)

@@ -78,6 +78,33 @@ def test_tacotron_restatement_matches_the_reference_classes():
     assert np.abs(a - b)[:, 2:-3].max() < 1e-12 and np.abs(a - b)[:, :2].max() > 1e-6
 
 
+def test_pwg_restatement_matches_the_references_process_utterance():
+    """frontend_pwg_lj001_0002 was produced by EXECUTING the reference's process_utterance (data_gen_utils.py:93-147, cut out with
+    ast; oracle/gen_golden.py gen_frontend_pwg) on the sample recording, its librosa.stft served by torch.stft and its
+    librosa.filters.mel by the restated bank -- so this pins everything of the 'pwg' front-end except the filter values themselves
+    (magnitude, matrix product, log10 clamp at 1e-6, frame count, returned-wav length): the restatement must be that function."""
+    g, r = load_golden("frontend_lj001_0002"), load_golden("frontend_pwg_lj001_0002")
+    ours = mf.log_mel(g["pcm"].astype(np.float64) / 32768.0)
+    assert ours.shape == r["mel_ref_f64"].shape == (80, 164)
+    assert np.abs(ours - r["mel_ref_f64"]).max() < 1e-6                  # float64 run of the reference function (mel_basis is float32 there)
+    loud = r["mel_ref_f64"] > -4.0
+    assert np.abs(ours - r["mel_ref_f32"])[loud].max() < 2e-4            # float32 run: what librosa.core.load + librosa.stft would feed it
+    assert int(r["wav_len_f64"]) == 164 * 256                            # wav padded to the frame grid and trimmed (data_gen_utils.py:137-139)
+
+
+@pytest.mark.gpu
+def test_device_pwg_front_end_matches_the_references_process_utterance():
+    import fastdiff_amd
+    torch.manual_seed(1234)
+    model = fastdiff_amd.FastDiff().cuda().eval()
+    g, r = load_golden("frontend_lj001_0002"), load_golden("frontend_pwg_lj001_0002")
+    got = model.mel_spectrogram(torch.from_numpy(g["pcm"].astype(np.float32) / 32768.0).cuda())[0].cpu().numpy().astype(np.float64)
+    ref = r["mel_ref_f64"]
+    assert got.shape == ref.shape
+    assert np.abs(got - ref)[ref > -4.0].max() < 2e-4
+    assert np.abs(10.0 ** got - 10.0 ** ref).max() < 2e-6 * max(1.0, float((10.0 ** ref).max()))
+
+
 @pytest.mark.gpu
 def test_device_tacotron_front_end_matches_the_oracle():
     import fastdiff_amd
