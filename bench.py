@@ -302,8 +302,21 @@ def host_inclusive(model, mel, rows, lens, audio_s, reps=5):
             one(1 + i)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / reps * 1e3
+        # the two PCIe legs on their own (boxes of the pool differ here by an order of magnitude)
+        pcm_d = torch.empty((B, T * HOP), dtype=torch.int16, device=mel.device)
+        legs = {}
+        for name, fn, nbytes in (("h2d_mel", lambda: mel_h.to(mel.device, non_blocking=True), mel_h.numel() * 4),
+                                 ("d2h_pcm", lambda: pcm_h.copy_(pcm_d, non_blocking=True), pcm_h.numel() * 2)):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 10
+            legs[name] = {"ms": round(dt * 1e3, 4), "GBps": round(nbytes / dt / 1e9, 2)}
     return {"ms_per_step": round(ms, 4), "value": round(audio_s / (ms / 1e3), 2), "unit": "x real-time",
-            "path": "pinned host mel -> device -> fd_sample -> fd_peak_normalize_int16 -> pinned host int16 PCM"}
+            "path": "pinned host mel -> device -> fd_sample -> fd_peak_normalize_int16 -> pinned host int16 PCM", "pcie": legs}
 
 
 def box_state():
