@@ -10,6 +10,7 @@
 #include "fd_kernels.h"
 
 static std::string g_create_error;
+static int settle(fd_handle h);      // fallback = host: look at the flags of a pending fd_sample before touching device state
 
 // rows of the predictor GEMM's fp16 image per utterance (gx_rows in fd_kernels_fast.hip: 128-frame windows + 2 halo rows)
 static inline int gx_rows_host(int T) { return ((T + 127) / 128) * 128 + 2; }
@@ -166,6 +167,16 @@ int fd_create(const fd_config *cfg, int device, fd_handle *out)
         delete c;
         return FD_ERR_HIP;
     }
+    if ((e = hipHostMalloc(reinterpret_cast<void **>(&c->flags_host), 256, hipHostMallocDefault)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->flags_done, hipEventDisableTiming)) != hipSuccess) {
+        if (c->flags_host) hipHostFree(c->flags_host);
+        hipFree(c->scratch);
+        hipStreamDestroy(c->cap_stream);
+        g_create_error = std::string("fd_create: ") + hipGetErrorString(e);
+        delete c;
+        return FD_ERR_HIP;
+    }
+    memset(c->flags_host, 0, 256);
     // the staging ring is allocated here (64 KB per slot covers the step table and a few thousand utterances): a call only
     // allocates pinned memory again for a larger batch than that
     for (auto &sl : c->stage) {
@@ -188,7 +199,7 @@ int fd_create(const fd_config *cfg, int device, fd_handle *out)
 static void free_workspace(fd_context *c)
 {
     Workspace &w = c->ws;
-    void *ptrs[] = {w.noise, w.embed_h2, w.a[0], w.a[1], w.a[2], w.a[3], w.kp_h0, w.kp_hA, w.kp_hB, w.kpack, w.h_f16, w.range_flag, w.lens_dev, w.uid_dev, w.xA, w.xB,
+    void *ptrs[] = {w.noise, w.embed_h2, w.a[0], w.a[1], w.a[2], w.a[3], w.kp_h0, w.kp_hA, w.kp_hB, w.kpack, w.h_f16, w.range_flag, w.lens_dev, w.uid_dev, w.xsave, w.xA, w.xB,
                     w.xtap[0], w.xtap[1], w.xtap[2], w.mel, w.x, w.eps_acc, w.steps, w.params};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -208,8 +219,11 @@ int fd_destroy(fd_handle h)
 {
     if (!h) return FD_ERR_INVALID;
     hipSetDevice(h->device);
+    settle(h);
     hipDeviceSynchronize();
     prof_drain(h);
+    if (h->flags_host) hipHostFree(h->flags_host);
+    if (h->flags_done) hipEventDestroy(h->flags_done);
     for (auto ev : h->event_pool) hipEventDestroy(ev);
     drop_graph(h);
     free_workspace(h);
@@ -630,11 +644,11 @@ static hipError_t allocate_workspace(fd_context *h, int64_t capB, int64_t frames
     WS(w.h_f16, (size_t)fd::NBLK * rows * 64 + 1024);      // + slack for the rounded-up last DMA
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w.lens_dev), sizeof(int) * (size_t)std::max<int64_t>(capB, 64));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w.uid_dev), sizeof(unsigned long long) * (size_t)std::max<int64_t>(capB, 64));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w.range_flag), 256);
-    if (e == hipSuccess) e = hipMemset(w.range_flag, 0, 256);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w.range_flag), 512);
+    if (e == hipSuccess) e = hipMemset(w.range_flag, 0, 512);
     WS(w.xA, fd::C * FL); WS(w.xB, fd::C * FL);
     WS(w.xtap[0], fd::C * FL / 32); WS(w.xtap[1], fd::C * FL / 4); WS(w.xtap[2], fd::C * FL);
-    WS(w.mel, (size_t)fd::COND * frames); WS(w.x, FL); WS(w.eps_acc, FL); WS(w.steps, (size_t)std::max<int64_t>(capB, 64));
+    WS(w.mel, (size_t)fd::COND * frames); WS(w.x, FL); WS(w.xsave, FL); WS(w.eps_acc, FL); WS(w.steps, (size_t)std::max<int64_t>(capB, 64));
 #undef WS
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w.params), sizeof(StepParams));
     if (e == hipSuccess) e = hipMemset(w.params, 0, sizeof(StepParams));
@@ -692,7 +706,8 @@ hipError_t kp_gemm(const Launch &L, int B, int T)
 {
     fd_context *c = L.ctx;
     // blocks 1 and 2 get their predicted kernels as packed fp16 pairs when both ends are the fp16x2 kernels
-    c->kfmt = (c->fast[ST_KP_GEMM] && c->fast[ST_LVC] && c->gemm_f16 && c->w.gemm_f16_ok && c->lvc_f16 && c->w.lvc_f16_ok) ? KFMT_PACKED : KFMT_F32;
+    c->kfmt = (c->fast[ST_KP_GEMM] && c->fast[ST_LVC] && c->gemm_f16 && c->w.gemm_f16_ok && c->lvc_f16 && c->w.lvc_f16_ok && !(c->fp32_mask & 1u))
+                  ? KFMT_PACKED : KFMT_F32;
     return c->fast[ST_KP_GEMM] ? fast_kp_gemm(L, B, T) : naive_kp_gemm(L, B, T);
 }
 
@@ -755,6 +770,8 @@ static hipError_t run_step(const Launch &L, const StepIO &io, int B, int T)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
+static int settle(fd_handle h);
+
 static int check_common(fd_handle h, int B, int T, const char *who)
 {
     if (!h) return FD_ERR_INVALID;
@@ -811,6 +828,8 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
 {
     int rc = check_common(h, B, T, "fd_forward");
     if (rc != FD_OK) return rc;
+    if ((rc = settle(h)) != FD_OK) return rc;
+    h->inline_fallback = true; h->fp32_mask = 0;      // a single forward always carries its fallbacks inline
     if (!x || !mel || !steps || !eps_out) FD_FAIL(h, FD_ERR_INVALID, "fd_forward: null pointer");
     if (x == eps_out) FD_FAIL(h, FD_ERR_INVALID, "fd_forward: eps_out must not alias x");
     if ((rc = ensure_workspace(h, B, T)) != FD_OK) return rc;
@@ -834,9 +853,121 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
 
 static unsigned mode_signature(const fd_context *h)
 {
-    unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_f16 ? 2u : 0u) | (h->lvc_f16 ? 4u : 0u) | (h->conv_f16 ? 8u : 0u) | (h->step_lens ? 16u : 0u);
+    unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_f16 ? 2u : 0u) | (h->lvc_f16 ? 4u : 0u) | (h->conv_f16 ? 8u : 0u) | (h->step_lens ? 16u : 0u) |
+                 (h->inline_fallback ? 32u : 0u);
     for (int i = 0; i < ST_COUNT; ++i) s = (s << 1) | (h->fast[i] ? 1u : 0u);
-    return s;
+    return s ^ (h->fp32_mask * 2654435761u);
+}
+
+static int resolve_pending(fd_handle h, unsigned *mask);
+// Every entry point that touches device state first settles a pending fallback = host check (no-op otherwise).
+static int settle(fd_handle h)
+{
+    if (!h->pending.active) return FD_OK;
+    unsigned mask = 0;
+    const int rc = resolve_pending(h, &mask);
+    return rc < 0 ? rc : FD_OK;
+}
+
+// `count` consecutive denoiser steps of the current call on `stream`, starting at the device step counter: replayed from captured
+// graphs of up to 8 steps (kept per (B, T, mode): there are ~9 us between two graph launches, so a short schedule is one launch
+// per call, a long one a series of 8-step launches and a shorter one for the remainder), or launched one by one (options graph = 0,
+// profile = 1).  fp32_mask / inline_fallback: fd_internal.h (fd_pipe).
+static int enqueue_steps(fd_handle h, int B, int T, int count, unsigned fp32_mask, bool inline_fallback, hipStream_t stream)
+{
+    Workspace &ws = h->ws;
+    h->fp32_mask = fp32_mask;
+    h->inline_fallback = inline_fallback;
+    StepIO io = {ws.x, ws.mel, nullptr, nullptr, 1};
+    struct Restore { fd_handle h; ~Restore() { h->fp32_mask = 0; h->inline_fallback = true; } } restore{h};
+    if (!(h->use_graph && !h->profile)) {
+        fdk::Launch L = {h, stream, false};
+        for (int k = 0; k < count; ++k) {
+            hipError_t e = fdk::run_step(L, io, B, T);
+            if (e == hipSuccess) e = fdk::advance_step(L);
+            if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample: step %d failed: %s", k, hipGetErrorString(e));
+        }
+        return FD_OK;
+    }
+    const unsigned sig = mode_signature(h);
+    auto graph_of = [&](int steps, hipGraphExec_t *out) -> int {
+        for (auto &g : h->graphs)
+            if (g.B == B && g.T == T && g.sig == sig && g.steps == steps) {
+                g.last_use = ++h->graph_clock;
+                *out = g.exec;
+                return FD_OK;
+            }
+        constexpr size_t FD_MAX_GRAPHS = 16;
+        if (h->graphs.size() >= FD_MAX_GRAPHS) {        // evict the least recently used one (it may still be running)
+            size_t lru = 0;
+            for (size_t i = 1; i < h->graphs.size(); ++i)
+                if (h->graphs[i].last_use < h->graphs[lru].last_use) lru = i;
+            FD_HIP(h, hipStreamSynchronize(stream));
+            hipGraphExecDestroy(h->graphs[lru].exec);
+            hipGraphDestroy(h->graphs[lru].graph);
+            h->graphs.erase(h->graphs.begin() + lru);
+        }
+        FD_HIP(h, hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+        fdk::Launch Lc = {h, h->cap_stream, true};
+        hipError_t ec = hipSuccess;
+        for (int k = 0; k < steps && ec == hipSuccess; ++k) {
+            ec = fdk::run_step(Lc, io, B, T);
+            if (ec == hipSuccess) ec = fdk::advance_step(Lc);
+        }
+        hipGraph_t g = nullptr;
+        hipError_t e2 = hipStreamEndCapture(h->cap_stream, &g);
+        if (ec != hipSuccess || e2 != hipSuccess) {
+            if (g) hipGraphDestroy(g);
+            FD_FAIL(h, FD_ERR_HIP, "fd_sample: graph capture failed: %s", hipGetErrorString(ec != hipSuccess ? ec : e2));
+        }
+        hipGraphExec_t ex = nullptr;
+        hipError_t e3 = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+        if (e3 != hipSuccess) {
+            hipGraphDestroy(g);
+            FD_FAIL(h, FD_ERR_HIP, "fd_sample: hipGraphInstantiate: %s", hipGetErrorString(e3));
+        }
+        h->graphs.push_back({B, T, steps, sig, g, ex, ++h->graph_clock});
+        *out = ex;
+        return FD_OK;
+    };
+    constexpr int CHUNK = 8;
+    int rc;
+    hipGraphExec_t g_chunk = nullptr, g_rest = nullptr;
+    if (count >= CHUNK && (rc = graph_of(CHUNK, &g_chunk)) != FD_OK) return rc;
+    if (count % CHUNK && (rc = graph_of(count % CHUNK, &g_rest)) != FD_OK) return rc;
+    if (count >= CHUNK && (count % CHUNK)) {      // the second capture may have evicted the first (full cache): look it up again
+        if ((rc = graph_of(CHUNK, &g_chunk)) != FD_OK) return rc;
+        if ((rc = graph_of(count % CHUNK, &g_rest)) != FD_OK) return rc;
+    }
+    for (int k = 0; k + CHUNK <= count; k += CHUNK) FD_HIP(h, hipGraphLaunch(g_chunk, stream));
+    if (count % CHUNK) FD_HIP(h, hipGraphLaunch(g_rest, stream));
+    return FD_OK;
+}
+
+// fallback = host: waits for the pending piece of work, looks at its range flags and, if one was raised, runs that piece again from
+// the saved x with the flagged stages on their fp32 kernels (and every other stage with its fallback inline: the second pass is
+// always right).  Returns 1 if it redid the work, 0 if not; *mask receives the flagged stages (sticky for the rest of a long call).
+static int resolve_pending(fd_handle h, unsigned *mask)
+{
+    fd_context::PendingCall p = h->pending;
+    h->pending.active = false;
+    FD_HIP(h, hipEventSynchronize(h->flags_done));
+    unsigned m = 0;
+    for (int i = 0; i < 32; ++i)
+        if (h->flags_host[i] && i != FLAG_KFMT_F32) m |= 1u << i;
+    if (m & (1u << 19)) m |= 1u;                 // the predictor front feeds the GEMM: both go
+    *mask |= m;
+    if (m == 0) return 0;
+    Workspace &ws = h->ws;
+    const size_t n_el = (size_t)p.B * p.T * fd::HOPT;
+    FD_HIP(h, hipMemcpyAsync(ws.x, ws.xsave, sizeof(float) * n_el, hipMemcpyDeviceToDevice, p.stream));
+    fdk::Launch L = {h, p.stream, false};
+    hipError_t e = fdk::clear_range_flags(L, p.first);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample_check: %s", hipGetErrorString(e));
+    int rc = enqueue_steps(h, p.B, p.T, p.count, *mask, true, p.stream);
+    if (rc != FD_OK) return rc;
+    if (p.first + p.count == p.N) FD_HIP(h, hipMemcpyAsync(p.out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, p.stream));
+    return 1;
 }
 
 int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, const fd_step *table, int N, int ddim,
@@ -844,6 +975,7 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
 {
     int rc = check_common(h, B, T, "fd_sample");
     if (rc != FD_OK) return rc;
+    if ((rc = settle(h)) != FD_OK) return rc;
     if (!mel || !table || !out) FD_FAIL(h, FD_ERR_INVALID, "fd_sample: null pointer");
     if (N <= 0 || N > 1024) FD_FAIL(h, FD_ERR_INVALID, "fd_sample: N=%d outside 1..1024", N);
     if ((rc = ensure_workspace(h, B, T)) != FD_OK) return rc;
@@ -890,71 +1022,41 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
     if ((e = fdk::embed(L, io, B, N)) != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample: embed failed: %s", hipGetErrorString(e));
     if ((e = fdk::clear_range_flags(L)) != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample: %s", hipGetErrorString(e));
 
-    const bool graph = h->use_graph && !h->profile;
-    if (graph) {
-        const unsigned sig = mode_signature(h);
-        // A graph holds up to 8 consecutive denoiser steps (there are ~9 us between two graph launches): a short schedule is one
-        // launch per call, a long one a series of 8-step launches and a shorter one for the remainder.
-        auto graph_of = [&](int steps, hipGraphExec_t *out) -> int {
-            for (auto &g : h->graphs)
-                if (g.B == B && g.T == T && g.sig == sig && g.steps == steps) {
-                    g.last_use = ++h->graph_clock;
-                    *out = g.exec;
-                    return FD_OK;
-                }
-            constexpr size_t FD_MAX_GRAPHS = 16;
-            if (h->graphs.size() >= FD_MAX_GRAPHS) {        // evict the least recently used one (it may still be running)
-                size_t lru = 0;
-                for (size_t i = 1; i < h->graphs.size(); ++i)
-                    if (h->graphs[i].last_use < h->graphs[lru].last_use) lru = i;
-                FD_HIP(h, hipStreamSynchronize(stream));
-                hipGraphExecDestroy(h->graphs[lru].exec);
-                hipGraphDestroy(h->graphs[lru].graph);
-                h->graphs.erase(h->graphs.begin() + lru);
-            }
-            FD_HIP(h, hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-            fdk::Launch Lc = {h, h->cap_stream, true};
-            hipError_t ec = hipSuccess;
-            for (int k = 0; k < steps && ec == hipSuccess; ++k) {
-                ec = fdk::run_step(Lc, io, B, T);
-                if (ec == hipSuccess) ec = fdk::advance_step(Lc);
-            }
-            hipGraph_t g = nullptr;
-            hipError_t e2 = hipStreamEndCapture(h->cap_stream, &g);
-            if (ec != hipSuccess || e2 != hipSuccess) {
-                if (g) hipGraphDestroy(g);
-                FD_FAIL(h, FD_ERR_HIP, "fd_sample: graph capture failed: %s", hipGetErrorString(ec != hipSuccess ? ec : e2));
-            }
-            hipGraphExec_t ex = nullptr;
-            hipError_t e3 = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-            if (e3 != hipSuccess) {
-                hipGraphDestroy(g);
-                FD_FAIL(h, FD_ERR_HIP, "fd_sample: hipGraphInstantiate: %s", hipGetErrorString(e3));
-            }
-            h->graphs.push_back({B, T, steps, sig, g, ex, ++h->graph_clock});
-            *out = ex;
-            return FD_OK;
-        };
+    if (h->host_fallback) {
+        // fallback = host: no fp32 launch trails the fp16x2 kernels; their flags accumulate on the device, and the call (or, for a
+        // long schedule, each 8-step piece of it) is redone with the flagged stages on their fp32 kernels once the host has seen them
+        FD_HIP(h, hipMemcpyAsync(ws.xsave, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
         constexpr int CHUNK = 8;
-        hipGraphExec_t g_chunk = nullptr, g_rest = nullptr;
-        if (N >= CHUNK && (rc = graph_of(CHUNK, &g_chunk)) != FD_OK) return rc;
-        if (N % CHUNK && (rc = graph_of(N % CHUNK, &g_rest)) != FD_OK) return rc;
-        if (N >= CHUNK && (N % CHUNK)) {      // the second capture may have evicted the first (full cache): look it up again
-            if ((rc = graph_of(CHUNK, &g_chunk)) != FD_OK) return rc;
-            if ((rc = graph_of(N % CHUNK, &g_rest)) != FD_OK) return rc;
+        unsigned mask = 0;
+        for (int first = 0; first < N; first += CHUNK) {
+            const int count = std::min(CHUNK, N - first);
+            const bool last = first + count == N;
+            if (first > 0 && mask == 0) FD_HIP(h, hipMemcpyAsync(ws.xsave, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
+            if ((rc = enqueue_steps(h, B, T, count, mask, /*inline_fallback=*/mask != 0, stream)) != FD_OK) return rc;
+            if (mask != 0) continue;              // already on the safe path: nothing to look at
+            FD_HIP(h, hipMemcpyAsync(h->flags_host, ws.range_flag + 64, sizeof(int) * 32, hipMemcpyDeviceToHost, stream));
+            FD_HIP(h, hipEventRecord(h->flags_done, stream));
+            h->pending = {true, B, T, N, first, count, out, stream};
+            if (last) break;                      // the caller's fd_sample_check (or the next call on this handle) looks at it
+            int redone = resolve_pending(h, &mask);
+            if (redone < 0) return redone;
         }
-        for (int k = 0; k + CHUNK <= N; k += CHUNK) FD_HIP(h, hipGraphLaunch(g_chunk, stream));
-        if (N % CHUNK) FD_HIP(h, hipGraphLaunch(g_rest, stream));
+        FD_HIP(h, hipMemcpyAsync(out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));      // (provisional while a check is pending)
     } else {
-        for (int k = 0; k < N; ++k) {
-            e = fdk::run_step(L, io, B, T);
-            if (e == hipSuccess) e = fdk::advance_step(L);
-            if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample: step %d failed: %s", k, hipGetErrorString(e));
-        }
+        if ((rc = enqueue_steps(h, B, T, N, 0u, true, stream)) != FD_OK) return rc;
+        FD_HIP(h, hipMemcpyAsync(out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
     }
-    FD_HIP(h, hipMemcpyAsync(out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
     h->last_B = B; h->last_T = T;
     return FD_OK;
+}
+
+int fd_sample_check(fd_handle h)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!h->pending.active) return 0;
+    FD_HIP(h, hipSetDevice(h->device));
+    unsigned mask = 0;
+    return resolve_pending(h, &mask);
 }
 
 int fd_set_noise_streams(fd_handle h, const uint64_t *stream_ids, int B)
@@ -1031,7 +1133,9 @@ int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_samples, 
     if (h->mel_variant == MEL_TACOTRON && n_samples <= 512)      // F.pad(mode='reflect') needs pad < length (tacotron/stft.py:84-88)
         FD_FAIL(h, FD_ERR_INVALID, "fd_mel_spectrogram: reflect padding of 512 needs more than 512 samples, got %lld", (long long)n_samples);
     FD_HIP(h, hipSetDevice(h->device));
-    int rc = ensure_mel_tables(h);
+    int rc = settle(h);
+    if (rc != FD_OK) return rc;
+    rc = ensure_mel_tables(h);
     if (rc != FD_OK) return rc;
     fdk::Launch L = {h, (hipStream_t)stream, false};
     hipError_t e = fdk::mel_frontend(L, wav, B, n_samples, mel, T);
@@ -1043,6 +1147,10 @@ int fd_peak_normalize_int16_ragged(fd_handle h, const float *wav, int B, int64_t
 {
     if (!h || !wav || !pcm || B <= 0 || len <= 0 || B > 4096) return FD_ERR_INVALID;
     FD_HIP(h, hipSetDevice(h->device));
+    {
+        const int rcs = settle(h);
+        if (rcs != FD_OK) return rcs;
+    }
     const long long *valid_dev = nullptr;
     if (valid) {
         for (int b = 0; b < B; ++b)
@@ -1073,6 +1181,10 @@ int fd_peak_normalize_int16(fd_handle h, const float *wav, int B, int64_t len, i
 int fd_set_option(fd_handle h, const char *key, const char *value)
 {
     if (!h || !key || !value) return FD_ERR_INVALID;
+    {
+        const int rcs = settle(h);
+        if (rcs != FD_OK) return rcs;
+    }
     const std::string k(key), v(value);
     static const char *stage_names[ST_COUNT] = {"embed", "first", "dblock", "kp_front", "kp_gemm", "convt", "lvc", "final"};
     auto parse_mode = [&](bool &dst) -> int {
@@ -1118,6 +1230,19 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
         else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: mel expects pwg|tacotron, got '%s'", value);
         return FD_OK;
     }
+    if (k == "lvc_waves") {
+        if (v == "8") h->lvc_w8 = true;
+        else if (v == "4") h->lvc_w8 = false;
+        else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: lvc_waves expects 8|4, got '%s'", value);
+        drop_graph(h);
+        return FD_OK;
+    }
+    if (k == "fallback") {
+        if (v == "host") h->host_fallback = true;
+        else if (v == "graph") h->host_fallback = false;
+        else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: fallback expects graph|host, got '%s'", value);
+        return FD_OK;
+    }
     if (k == "fuse_final") { h->fuse_final = on; drop_graph(h); return FD_OK; }
     if (k == "graph") { h->use_graph = on; return FD_OK; }
     if (k == "profile") { h->profile = on; return FD_OK; }
@@ -1128,6 +1253,10 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
 int64_t fd_read_tap(fd_handle h, const char *name, float *host_dst, int64_t capacity)
 {
     if (!h || !name) return FD_ERR_INVALID;
+    {
+        const int rcs = settle(h);
+        if (rcs != FD_OK) return rcs;
+    }
     const int B = h->last_B, T = h->last_T;
     if (B == 0) FD_FAIL(h, FD_ERR_STATE, "fd_read_tap: no forward has run yet");
     const Workspace &w = h->ws;
@@ -1150,6 +1279,8 @@ int64_t fd_read_tap(fd_handle h, const char *name, float *host_dst, int64_t capa
         src = w.xtap[blk]; n = (int64_t)B * fd::C * T * fd::hop(blk);
     } else if (k == "range_flags") {       // 32 int32 (bit patterns): fp16-range flags of the last step, see Workspace::range_flag
         src = reinterpret_cast<const float *>(w.range_flag); n = 32;
+    } else if (k == "range_flags_call") {  // the same, OR-ed over every step since the start of the last call (words 64..95)
+        src = reinterpret_cast<const float *>(w.range_flag + 64); n = 32;
     } else FD_FAIL(h, FD_ERR_INVALID, "fd_read_tap: unknown tap '%s'", name);
     if (!host_dst) return n;
     if (capacity < n) FD_FAIL(h, FD_ERR_INVALID, "fd_read_tap: capacity %lld < %lld", (long long)capacity, (long long)n);

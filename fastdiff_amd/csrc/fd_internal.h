@@ -139,9 +139,11 @@ struct Workspace {
     float *h_f16 = nullptr;     // fp16 piece image of the predictor hidden state: [3][B][64*ceil(T/64)+2 rows][2 pieces][64] x 2 B
     int *lens_dev = nullptr;    // [B] valid frames per utterance of the current call (ragged batches)
     unsigned long long *uid_dev = nullptr;   // [B] noise stream ids of the current call (fd_set_noise_streams)
-    int *range_flag = nullptr;  // [0] predictor GEMM, [1 + 4*block + layer] LVC layers, [13 + d] DBlocks,
+    float *xsave = nullptr;     // [B][L] x at the start of the call / of the current graph chunk (option fallback = host: what a redo starts from)
+    int *range_flag = nullptr;  // (128 words) [0] predictor GEMM, [1 + 4*block + layer] LVC layers, [13 + d] DBlocks,
                                 // [16 + n] ConvTranspose of block n, [19] predictor front: an operand did not fit fp16; 32 words, zeroed every step;
-                                // words 32..63: the same flags of the previous sampler step (skip_after_previous_overflow)
+                                // words 32..63: the same flags of the previous sampler step (skip_after_previous_overflow);
+                                // words 64..95: OR over all steps since the last clear (what option fallback = host reads back)
     float *xA = nullptr, *xB = nullptr;                           // [B][32][L] ping-pong
     float *xtap[fd::NBLK] = {}; // block outputs kept for fd_read_tap
     float *mel = nullptr;       // [B][80][T] library-owned copy used by the sampler graph
@@ -177,6 +179,16 @@ struct fd_context {
     bool conv_f16 = true;                     // DBlocks, ConvTranspose upsamplers and the predictor front likewise
     const int *step_lens = nullptr;           // device copy of the caller's `lens` for this call (ragged batch), or null
     std::vector<unsigned long long> noise_ids; // fd_set_noise_streams: consumed by the next fd_sample
+    // How a stage that has an fp16x2 kernel is launched (fd_pipe below):
+    //   inline_fallback  the fp32 kernel is enqueued right behind the fp16x2 one and exits at once unless that one raised its flag
+    //                    (fully asynchronous, works inside a captured graph; ~2 us per stage and step)
+    //   !inline_fallback only the fp16x2 kernel; flags accumulate in range_flag[64..95] and the HOST redoes the work with
+    //                    fp32_mask set (option fallback = host: fd_sample_check)
+    //   fp32_mask        bit i set: the stage whose flag word is i runs its fp32 kernel outright
+    bool lvc_w8 = true;                       // option "lvc_waves" = "8": the fp16x2 LVC layers run as 8-wave workgroups (k_lvc_w8)
+    bool host_fallback = false;               // option "fallback" = "host"
+    bool inline_fallback = true;
+    unsigned fp32_mask = 0;
     int kfmt = KFMT_F32;                      // format of the predicted kernels of blocks 1, 2 in this step's records (set by kp_gemm)
     bool h_image_ready = false;               // set by fast_kp_front when it wrote the GEMM's fp16 image of h for this step
     std::map<std::string, std::pair<std::vector<int64_t>, std::vector<float>>> raw;   // host copies from fd_set_weight
@@ -201,11 +213,27 @@ struct fd_context {
     struct StageSlot { char *host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; };
     StageSlot stage[STAGE_SLOTS];
     unsigned stage_next = 0;
+    // option fallback = host: the fd_sample call whose range flags have not been looked at yet (fd_sample_check)
+    struct PendingCall {
+        bool active = false;
+        int B = 0, T = 0, N = 0, first = 0, count = 0;      // steps [first, first + count) were enqueued without fallbacks
+        float *out = nullptr;
+        hipStream_t stream = nullptr;
+    } pending;
+    int *flags_host = nullptr;               // pinned, 32 words: the sticky flags of the pending call
+    hipEvent_t flags_done = nullptr;
     void *scratch = nullptr;                 // 64 KB device scratch (abs-max words, ...)
     std::vector<ProfEntry> prof_pending;
     std::vector<hipEvent_t> event_pool;
     std::map<std::string, std::pair<int64_t, double>> prof_acc;
 };
+
+enum Pipe { PIPE_F16_THEN_F32, PIPE_F16_ONLY, PIPE_F32_ONLY };
+inline Pipe fd_pipe(const fd_context *c, bool f16_possible, int flag_word)
+{
+    if (!f16_possible || ((c->fp32_mask >> flag_word) & 1u)) return PIPE_F32_ONLY;
+    return c->inline_fallback ? PIPE_F16_THEN_F32 : PIPE_F16_ONLY;
+}
 
 // Arguments of one denoiser step (all device pointers)
 struct StepIO {
@@ -229,7 +257,7 @@ hipError_t dblock(const Launch &L, const StepIO &io, int d, int B, int T);
 hipError_t kp_front(const Launch &L, const StepIO &io, int B, int T);
 hipError_t kp_gemm(const Launch &L, int B, int T);
 hipError_t advance_step(const Launch &L);
-hipError_t clear_range_flags(const Launch &L);     // before the first step of a call
+hipError_t clear_range_flags(const Launch &L, int set_step = 0);     // before the first step of a call / of a redo: step counter := set_step
 hipError_t mel_frontend(const Launch &L, const float *wav, int B, int64_t n_samples, float *mel, int T);
 hipError_t init_noise(const Launch &L, float *x, int64_t n, unsigned long long seed, const unsigned long long *uids, int l4);
 hipError_t peak_normalize_int16(const Launch &L, const float *wav, int B, int64_t len, int16_t *pcm, const long long *valid_dev);

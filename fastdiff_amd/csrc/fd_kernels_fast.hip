@@ -1732,7 +1732,6 @@ __global__ void __launch_bounds__(256, 2) k_lvc_f16(const float *__restrict__ xi
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             xa[c] = make_float4(xa[c].x + sa[c].x, xa[c].y + sa[c].y, xa[c].z + sa[c].z, xa[c].w + sa[c].w);
-            mx = amax4(mx, xa[c]);
             *reinterpret_cast<float4 *>(ys + ((wave * 8 + c) * W + 4 * lane) * 4) = xa[c];      // the residual, parked
         }
 #pragma unroll
@@ -1740,6 +1739,9 @@ __global__ void __launch_bounds__(256, 2) k_lvc_f16(const float *__restrict__ xi
             float v[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) v[c] = act_in(f4c(xa[c], j));
+            // the range check looks at what is split: the ACTIVATED value (2.5 leaky_relu reaches the fp16 limit 2.5x earlier)
+            mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))),
+                                 fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7])))));
             float4 ph, pl;
             split8x(v, ph, pl);
             const int row = H + 4 * lane + j;
@@ -1751,8 +1753,8 @@ __global__ void __launch_bounds__(256, 2) k_lvc_f16(const float *__restrict__ xi
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const float t = hx[c] + hs[c];
-                mx = fmaxf(mx, fabsf(t));
                 v[c] = act_in(t);
+                mx = fmaxf(mx, fabsf(v[c]));
             }
             float4 ph, pl;
             split8x(v, ph, pl);
@@ -1983,6 +1985,301 @@ __global__ void __launch_bounds__(256, 2) k_lvc_f16(const float *__restrict__ xi
     FD_STAMP(7);
 }
 
+// =================================================================================================
+// The same layer with EIGHT waves per workgroup (KFMT_PACKED records only).  A wave issues one VALU instruction per ~5 cycles however
+// many of them are independent (tools/ubench/valu_rate_probe.hip), so what a workgroup's compute costs in time is the length of ONE
+// wave's instruction stream: with the tile's work spread over eight waves instead of four that stream is half as long, and a SIMD
+// interleaves four waves instead of two.  Same tile (256 columns), same LDS images, same arithmetic as k_lvc_f16<.., KPRE = true>
+// (only the two halo columns are summed by 8 instead of 4 threads).  128 registers per lane:
+//   staging   wave = 4 channels, lane = 4 columns (8 loads of 16 B);
+//   conv      wave = one 32-column tile, A (the layer's 0.4 w pieces) in 48 registers;
+//   LVC       wave = (row tile, 64-column quarter) for hop 256, (row tile, frame) for hop 64: one predicted row tile in 48 registers
+//             (requested after the conv, its 128 B lines touched at the start so that it comes out of L2), two column tiles.
+// =================================================================================================
+template <int HOP, int DIL, bool FINAL>
+__global__ void __launch_bounds__(512, 4) k_lvc_w8(const float *__restrict__ xin, const float *__restrict__ skip, float *__restrict__ xout,
+                                                   const float *__restrict__ kpack, int layer, const float4 *__restrict__ wpack16,
+                                                   const float *__restrict__ wref, const float *__restrict__ cbias,
+                                                   int *__restrict__ range_flag, const int *__restrict__ kfmt_f32, int T,
+                                                   const int *__restrict__ lens, float *__restrict__ eps_acc, const float4 *__restrict__ ffuse)
+{
+    static_assert(!FINAL || HOP == 256, "the fused final conv relies on whole-tile utterance lengths");
+    constexpr int W = 256, H = (DIL + 1 + 3) & ~3, XC = W + 2 * H, YC = W + 2;
+    static_assert(2 * H <= 64, "one halo column per lane");
+    __shared__ __attribute__((aligned(16))) char xs[XC * 128];       // act(x + skip) pieces, row = column + H
+    __shared__ __attribute__((aligned(16))) char ys[YC * 128];       // first the raw x + skip of the centre (fp32 [32][256]), then
+    static_assert(YC * 128 >= fd::C * W * 4, "parking area");        // the conv output pieces, row = column + 1
+    __shared__ __attribute__((aligned(16))) float bzs[(W / HOP) * 64];   // the predicted biases of the tile's frames
+    const int Ln = T * HOP;
+    const int ntile = (T * HOP + W - 1) / W, tile = blockIdx.x;
+    const int b = blockIdx.y, w0 = tile * W;
+    const int Lnb = frames_of(lens, b, T) * HOP;
+    if (tile >= ntile || w0 >= Lnb || skip_after_previous_overflow(range_flag)) return;
+    if (*kfmt_f32 != 0) {      // the fp32 GEMM redid this step: the record holds plain fp32 kernels, the fp32 layer behind us reads those
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicOr(range_flag, 1);
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int cw = wave * 32;                                   // this wave's conv columns
+    const bool conv_valid = (w0 + cw) < Lnb;                    // (Lnb is a multiple of 64)
+    const int mt0 = wave & 1, lcw = 64 * (wave >> 1);           // this wave's LVC row tile and first column
+    const bool lvc_valid = (w0 + lcw) < Lnb;
+    float mx = 0.0f;
+    // one dword of each 128 B line of this wave's row tile of the frame's kernel (96 lines): pulls it from HBM into L2 now
+    unsigned ktouch = 0u;
+    const float *krec = kpack + ((int64_t)b * T + (w0 + lcw) / HOP) * fd::KREC;
+    if (lvc_valid) {
+        const unsigned *kt = reinterpret_cast<const unsigned *>(krec + layer * fd::KLAYER) + mt0 * 3072;
+        ktouch = kt[lane * 32] | kt[(64 + l31) * 32];
+    }
+    // the predicted biases of the tile's frames (64 per frame) travel through LDS: thread = (frame of the tile, output row)
+    float bzv = 0.0f;
+    if (tid < (W / HOP) * 64) {
+        const int f = w0 / HOP + (tid >> 6);
+        if (f < frames_of(lens, b, T)) bzv = kpack[((int64_t)b * T + f) * fd::KREC + fd::KW + layer * 64 + (tid & 63)];
+    }
+
+    // ---- stage x + skip.  Centre: wave = channel quad, lane = 4 columns: one column of a thread is HALF a 16 B slot per piece.
+    //      Halo (2H columns): wave = channel quad, lane = one column. ---------------------------------------------------------
+    {
+        const float *xr = xin + ((int64_t)b * fd::C + wave * 4) * Ln, *sr = skip + ((int64_t)b * fd::C + wave * 4) * Ln;
+        const int g = w0 + 4 * lane;
+        const bool ok = g < Lnb;
+        const int hc = lane, hg = (hc < H) ? w0 - H + hc : w0 + W + hc - H;
+        const bool hok = hc < 2 * H && hg >= 0 && hg < Lnb;
+        float4 xa[4], sa[4];
+        float hx[4], hs[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            xa[c] = ok ? *reinterpret_cast<const float4 *>(xr + (int64_t)c * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            sa[c] = ok ? *reinterpret_cast<const float4 *>(sr + (int64_t)c * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            hx[c] = hok ? xr[(int64_t)c * Ln + hg] : 0.0f;
+            hs[c] = hok ? sr[(int64_t)c * Ln + hg] : 0.0f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            xa[c] = make_float4(xa[c].x + sa[c].x, xa[c].y + sa[c].y, xa[c].z + sa[c].z, xa[c].w + sa[c].w);
+            *reinterpret_cast<float4 *>(ys + ((wave * 4 + c) * W + 4 * lane) * 4) = xa[c];      // the residual, parked
+        }
+        if (tid < (W / HOP) * 64) bzs[tid] = bzv;
+        const int slot = wave >> 1, half = (wave & 1) * 8;       // channels 4 wave .. 4 wave + 3 = half of slot wave / 2
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { v[c] = act_in(f4c(xa[c], j)); mx = fmaxf(mx, fabsf(v[c])); }
+            uint2 ph, pl;
+            split2x(v[0], v[1], ph.x, pl.x);
+            split2x(v[2], v[3], ph.y, pl.y);
+            const int row = H + 4 * lane + j;
+            *reinterpret_cast<uint2 *>(xs + h2_off(row, slot) + half) = ph;
+            *reinterpret_cast<uint2 *>(xs + h2_off(row, 4 + slot) + half) = pl;
+        }
+        if (hc < 2 * H) {
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { v[c] = act_in(hx[c] + hs[c]); mx = fmaxf(mx, fabsf(v[c])); }
+            uint2 ph, pl;
+            split2x(v[0], v[1], ph.x, pl.x);
+            split2x(v[2], v[3], ph.y, pl.y);
+            const int row = (hc < H) ? hc : W + hc;
+            *reinterpret_cast<uint2 *>(xs + h2_off(row, slot) + half) = ph;
+            *reinterpret_cast<uint2 *>(xs + h2_off(row, 4 + slot) + half) = pl;
+        }
+    }
+    __syncthreads();
+    // residual values of this lane's outputs: registers, so that ys can take the conv output
+    float resid[2][8];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            resid[nt][r] = reinterpret_cast<const float *>(ys)[(16 * mt0 + (r & 3) + 8 * (r >> 2) + 4 * hi) * W + lcw + nt * 32 + l31];
+    __syncthreads();
+
+    // ---- dilated conv of this wave's 32 columns on the fp16 pipe; y = act(conv) is split again into the B image of the LVC ------
+    if (conv_valid) {
+        // conv weights: A operand pieces [piece][kg][lane] x 8 fp16 (0.4 w, L2), k = 16*kg + 8*hi + e = tap*32 + in
+        float4 wa[2][6];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int kg = 0; kg < 6; ++kg) wa[p][kg] = wpack16[(p * 6 + kg) * 64 + lane];
+        float4 cb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cb[j] = reinterpret_cast<const float4 *>(cbias)[2 * j + hi];
+        f32x16 ah, al;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ah[r] = f4c(cb[r >> 2], r & 3); al[r] = 0.0f; }
+#pragma unroll
+        for (int kg = 0; kg < 6; ++kg) {
+            const int row = H + cw + l31 + ((kg >> 1) - 1) * DIL;
+            const float4 b1 = *reinterpret_cast<const float4 *>(xs + h2_off(row, (kg & 1) * 2 + hi));
+            const float4 b2 = *reinterpret_cast<const float4 *>(xs + h2_off(row, 4 + (kg & 1) * 2 + hi));
+            ah = mfma_f16(wa[0][kg], b1, ah);
+            al = mfma_f16(wa[0][kg], b2, al);
+            al = mfma_f16(wa[1][kg], b1, al);
+        }
+        const int cp = cw + l31, yrow = cp + 1;
+        const bool inside = (w0 + cp) < Lnb;                  // y is zero-padded for the LVC taps (modules.py:240)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                         // D rows 8j + 4hi + {0..3}: half a slot
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = inside ? act_in(fmaf(al[4 * j + i], GX_INV_SCALE, ah[4 * j + i])) : 0.0f;
+                mx = fmaxf(mx, fabsf(v[i]));
+            }
+            uint2 ph, pl;
+            split2x(v[0], v[1], ph.x, pl.x);
+            split2x(v[2], v[3], ph.y, pl.y);
+            *reinterpret_cast<uint2 *>(ys + h2_off(yrow, j) + 8 * hi) = ph;
+            *reinterpret_cast<uint2 *>(ys + h2_off(yrow, 4 + j) + 8 * hi) = pl;
+        }
+    } else {
+        // a wave past the end of the signal still owns y columns its left neighbour's taps read: they are zero padding
+        if (lane < 32) {
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) *reinterpret_cast<float4 *>(ys + (cw + 1 + lane) * 128 + s8 * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    // ---- the frame's predicted kernel: one row tile, (h | l << 16) dwords; lands under the halo columns and the barrier ----------
+    float4 ka[12];
+    if (lvc_valid) {
+        const float4 *kp4 = reinterpret_cast<const float4 *>(krec + layer * fd::KLAYER) + 2 * lane;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) ka[i] = kp4[(mt0 * 6 + (i >> 1)) * 128 + (i & 1)];
+    }
+    // ---- the two halo columns (-1 and W) the LVC taps reach: VALU on the reassembled x image, 8 threads per output ----------
+    {
+        const int hside = tid >> 8, ho = (tid & 255) >> 3, he = tid & 7;      // he: input channels 4 he .. 4 he + 3
+        const float4 *hw4 = reinterpret_cast<const float4 *>(wref + (ho * fd::C + 4 * he) * 3);
+        const float4 w0_ = hw4[0], w1_ = hw4[1], w2_ = hw4[2];
+        const float wv[12] = {w0_.x, w0_.y, w0_.z, w0_.w, w1_.x, w1_.y, w1_.z, w1_.w, w2_.x, w2_.y, w2_.z, w2_.w};      // [ci][tap]
+        const float hbias = cbias[ho];
+        const int c = hside ? W : -1, g = w0 + c;
+        const bool ok = g >= 0 && g < Lnb;
+        float accv = 0.0f;
+        if (ok) {
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) {
+                const int row = H + c + (tap - 1) * DIL;
+                union { uint2 u; _Float16 h[4]; } p1, p2;
+                p1.u = *reinterpret_cast<const uint2 *>(xs + h2_off(row, he >> 1) + (he & 1) * 8);
+                p2.u = *reinterpret_cast<const uint2 *>(xs + h2_off(row, 4 + (he >> 1)) + (he & 1) * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) accv += wv[j * 3 + tap] * fmaf((float)p2.h[j], GX_INV_SCALE, (float)p1.h[j]);
+            }
+        }
+        accv += __shfl_xor(accv, 1, 64);
+        accv += __shfl_xor(accv, 2, 64);
+        accv += __shfl_xor(accv, 4, 64);
+        if (he == 0) {
+            const float v = ok ? act_in(fmaf(accv, LVC_ACT_SCALE, hbias)) : 0.0f;
+            mx = fmaxf(mx, fabsf(v));
+            const _Float16 v1 = (_Float16)v, v2 = (_Float16)((v - (float)v1) * GX_SCALE);
+            const int yrow = c + 1;
+            *reinterpret_cast<_Float16 *>(ys + h2_off(yrow, ho >> 3) + (ho & 7) * 2) = v1;
+            *reinterpret_cast<_Float16 *>(ys + h2_off(yrow, 4 + (ho >> 3)) + (ho & 7) * 2) = v2;
+        }
+    }
+    __syncthreads();
+    if (lvc_valid) {
+        // ---- LVC: A = the frame's predicted kernel (rows gate-paired: register r <-> sigmoid input, r+8 <-> tanh input of
+        //      channel 16*mt + drow(r), r < 8) -----------------------------------------------------------------------------------
+        float *xo = xout + (int64_t)b * fd::C * Ln + (int64_t)(4 * hi) * Ln + w0 + lcw + l31;      // + channel*Ln + nt*32
+        const unsigned Lnu = (unsigned)Ln;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            f32x16 ah, al;
+            {      // D rows of a lane are {0..3, 8..11, 16..19, 24..27} + 4*hi of the row tile
+                const float4 *bz4 = reinterpret_cast<const float4 *>(bzs) + ((lcw + nt * 32) / HOP) * 16 + mt0 * 8 + hi;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 bj = bz4[2 * j];
+                    ah[4 * j] = bj.x; ah[4 * j + 1] = bj.y; ah[4 * j + 2] = bj.z; ah[4 * j + 3] = bj.w;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) al[r] = 0.0f;
+#pragma unroll
+            for (int kg = 0; kg < 6; ++kg) {
+                const float4 &d0 = ka[2 * kg], &d1 = ka[2 * kg + 1];      // 8 dwords (h | l << 16) -> the 8 hi halves and the 8 lo halves
+                const unsigned u[8] = {__float_as_uint(d0.x), __float_as_uint(d0.y), __float_as_uint(d0.z), __float_as_uint(d0.w),
+                                       __float_as_uint(d1.x), __float_as_uint(d1.y), __float_as_uint(d1.z), __float_as_uint(d1.w)};
+                const float4 a1 = make_float4(__uint_as_float(__builtin_amdgcn_perm(u[1], u[0], PERM_HI)), __uint_as_float(__builtin_amdgcn_perm(u[3], u[2], PERM_HI)),
+                                              __uint_as_float(__builtin_amdgcn_perm(u[5], u[4], PERM_HI)), __uint_as_float(__builtin_amdgcn_perm(u[7], u[6], PERM_HI)));
+                const float4 a2 = make_float4(__uint_as_float(__builtin_amdgcn_perm(u[1], u[0], PERM_LO)), __uint_as_float(__builtin_amdgcn_perm(u[3], u[2], PERM_LO)),
+                                              __uint_as_float(__builtin_amdgcn_perm(u[5], u[4], PERM_LO)), __uint_as_float(__builtin_amdgcn_perm(u[7], u[6], PERM_LO)));
+                const int row = lcw + nt * 32 + l31 + (kg >> 1);           // y row = column + 1 + (tap - 1)
+                const float4 b1 = *reinterpret_cast<const float4 *>(ys + h2_off(row, (kg & 1) * 2 + hi));
+                const float4 b2 = *reinterpret_cast<const float4 *>(ys + h2_off(row, 4 + (kg & 1) * 2 + hi));
+                ah = mfma_f16(a1, b1, ah);
+                al = mfma_f16(a1, b2, al);
+                al = mfma_f16(a2, b1, al);
+                __builtin_amdgcn_sched_barrier(0);      // 128 registers: keep the operand fetches of later steps from piling up here
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int chl = 16 * mt0 + (r & 3) + 8 * (r >> 2);     // channel minus 4*hi
+                const float zs = fmaf(al[r], GX_INV_SCALE, ah[r]), zt = fmaf(al[r + 8], GX_INV_SCALE, ah[r + 8]);
+                if constexpr (FINAL) resid[nt][r] += gate(zs, zt);
+                else xo[(unsigned)chl * Lnu + (unsigned)(nt * 32)] = resid[nt][r] + gate(zs, zt);
+            }
+        }
+    }
+    if constexpr (FINAL) {
+        // hop 256: utterance lengths are whole tiles, so every wave of a live workgroup is valid and reaches the barrier
+        float *pb = reinterpret_cast<float *>(xs);                   // [part = 2 mt + hi][7 taps][256 columns]; the x image is dead
+        {
+            const int part = 2 * mt0 + hi;
+            float fw[8][8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float4 lo4 = ffuse[(part * 8 + r) * 2], hi4 = ffuse[(part * 8 + r) * 2 + 1];
+                fw[r][0] = lo4.x; fw[r][1] = lo4.y; fw[r][2] = lo4.z; fw[r][3] = lo4.w; fw[r][4] = hi4.x; fw[r][5] = hi4.y; fw[r][6] = hi4.z;
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    float pk = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) pk = fmaf(fw[r][k], resid[nt][r], pk);
+                    pb[(part * 7 + k) * W + lcw + nt * 32 + l31] = pk;
+                }
+        }
+        __syncthreads();
+        auto column_sum = [&](int t) {      // eps[t] = sum_k w[k] . out[t + k - 3], restricted to this tile's columns
+            float e = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const int col = t + k - 3;
+                if (col >= 0 && col < W) {
+#pragma unroll
+                    for (int part = 0; part < 4; ++part) e += pb[(part * 7 + k) * W + col];
+                }
+            }
+            return e;
+        };
+        float *ea = eps_acc + (int64_t)b * Ln + w0;
+        if (tid < W) {
+            const float e = column_sum(tid);
+            if (tid >= 3 && tid < W - 3) ea[tid] = e;
+            else atomicAdd(ea + tid, e);
+        } else if (tid < W + 6) {            // the taps of the neighbour tiles' edge columns that fall on this tile
+            const int j = tid - W, t = j < 3 ? j - 3 : W + j - 3;
+            if (w0 + t >= 0 && w0 + t < Lnb) atomicAdd(ea + t, column_sum(t));
+        }
+    }
+    if (!(mx < GX_LIMIT)) atomicOr(range_flag, 1);      // also inf; a NaN operand gives a NaN result on either path
+    if (ktouch == 0x7FC01234u) atomicOr(range_flag, 0);   // keeps the touch loads alive; changes nothing
+}
+
 // eps_acc (the final_conv sums of k_lvc_f16<..., FINAL>) -> eps = sum + bias -> eps_out or the reverse-step update; eps_acc is left
 // zeroed for the next step.  If that LVC launch flagged its operands the sums are meaningless: they are only cleared here, and the
 // plain k_final behind this launch (run_if) redoes the conv from the fp32 kernel's output.
@@ -2199,7 +2496,8 @@ hipError_t fast_dblock(const Launch &L, int d, int B, int T, const float *audio)
     const dim3 grid((Lo + DB_STRIDE - 1) / DB_STRIDE, B);
     const int *run_if = nullptr;
     const char *n4 = "dblock_f4", *n8 = "dblock_f8";
-    if (c->conv_f16 && w.dblock_f16_ok) {
+    const Pipe pipe = fd_pipe(c, c->conv_f16 && w.dblock_f16_ok, 13 + d);
+    if (pipe != PIPE_F32_ONLY) {
         int *flag = c->ws.range_flag + 13 + d;
         const float4 *q0 = reinterpret_cast<const float4 *>(w.down_h2[d][0]), *q1 = reinterpret_cast<const float4 *>(w.down_h2[d][1]),
                      *q2 = reinterpret_cast<const float4 *>(w.down_h2[d][2]), *q3 = reinterpret_cast<const float4 *>(w.down_h2[d][3]);
@@ -2216,6 +2514,7 @@ hipError_t fast_dblock(const Launch &L, int d, int B, int T, const float *audio)
                       w.down[d].conv[1].b, w.down[d].conv[2].b, w.down[d].res.b, Lin, Lo, flag, c->step_lens, Lo / T, none, none, none);
         run_if = flag;
         n4 = n8 = "dblock_fp32_fallback";
+        if (pipe == PIPE_F16_ONLY) return hipSuccess;
     }
     if (f == 4)
         FD_LAUNCH(L, n4, k_dblock<4>, grid, dim3(256), 0, c->ws.a[d], c->ws.a[d + 1], w.down_pack[d][0], w.down_pack[d][1],
@@ -2236,7 +2535,8 @@ hipError_t fast_kp_front(const Launch &L, const StepIO &io, int B, int T)
     const int *run_if = nullptr;
     const char *name = "kp_front";
     c->h_image_ready = false;
-    if (c->conv_f16 && w.kpf_f16_ok) {
+    const Pipe pipe = fd_pipe(c, c->conv_f16 && w.kpf_f16_ok, 19);
+    if (pipe != PIPE_F32_ONLY) {
         KpFrontW2 k2;
         for (int n = 0; n < fd::NBLK; ++n) {
             k2.in_pack[n] = reinterpret_cast<const float4 *>(w.kp_in_h2[n]); k2.in_b[n] = w.blk[n].kp_in.b;
@@ -2247,6 +2547,7 @@ hipError_t fast_kp_front(const Launch &L, const StepIO &io, int B, int T)
         c->h_image_ready = true;      // the GEMM's fp16 image of h is written (k_h_split not needed)
         run_if = c->ws.range_flag + 19;
         name = "kp_front_fp32_fallback";
+        if (pipe == PIPE_F16_ONLY) return hipSuccess;
     }
     KpFrontW kw;
     for (int n = 0; n < fd::NBLK; ++n) {
@@ -2267,7 +2568,8 @@ hipError_t fast_kp_gemm(const Launch &L, int B, int T)
     const int chunk_tiles = (tiles_per_utt + chunks_per_utt - 1) / chunks_per_utt;     // balanced, <= GEMM_CT
     const int n_items = fd::NBLK * (fd::KREC / 128) * B * chunks_per_utt;
     const int grid = n_items < 2 * c->num_cus ? n_items : 2 * c->num_cus;              // persistent: 2 workgroups per CU
-    const bool f16 = c->gemm_f16 && w.gemm_f16_ok;
+    const Pipe pipe = fd_pipe(c, c->gemm_f16 && w.gemm_f16_ok, 0);
+    const bool f16 = pipe != PIPE_F32_ONLY;
     if (f16) {
         const int R = gx_rows(T);
         const int chunks = (T + GX_CT * 32 - 1) / (GX_CT * 32), items = fd::NBLK * (fd::KREC / 128) * B * chunks;
@@ -2279,6 +2581,7 @@ hipError_t fast_kp_gemm(const Launch &L, int B, int T)
                   reinterpret_cast<const float4 *>(w.gemm_h2_pack[0]), reinterpret_cast<const float4 *>(w.gemm_h2_pack[1]),
                   reinterpret_cast<const float4 *>(w.gemm_h2_pack[2]), w.gemm_bias_h2[0], w.gemm_bias_h2[1], w.gemm_bias_h2[2],
                   c->ws.range_flag, B, T, R, chunks, items, c->step_lens, c->kfmt);
+        if (pipe == PIPE_F16_ONLY) return hipSuccess;
     }
     // fp32 matrix pipe: the whole job when the fp16 form is off, otherwise an early-exit launch that only works when
     // k_h_split found operands outside the fp16 range
@@ -2296,7 +2599,8 @@ hipError_t fast_convt(const Launch &L, int n, const float *x_in, float *x_out, i
     fd_context *c = L.ctx;
     const int *run_if = nullptr;
     const char *n8 = "convt_r8", *n4 = "convt_r4";
-    if (c->conv_f16 && w.convt_f16_ok) {
+    const Pipe pipe = fd_pipe(c, c->conv_f16 && w.convt_f16_ok, 16 + n);
+    if (pipe != PIPE_F32_ONLY) {
         int *flag = c->ws.range_flag + 16 + n;
         if (fd::ratio(n) == 8)
             FD_LAUNCH(L, n8, k_convt_h2<8>, grid, dim3(256), 0, x_in, reinterpret_cast<const float4 *>(w.up_h2[n]), w.blk[n].up.b, x_out, Lin, flag, c->step_lens, fd::hop(n) / fd::ratio(n));
@@ -2304,6 +2608,7 @@ hipError_t fast_convt(const Launch &L, int n, const float *x_in, float *x_out, i
             FD_LAUNCH(L, n4, k_convt_h2<4>, grid, dim3(256), 0, x_in, reinterpret_cast<const float4 *>(w.up_h2[n]), w.blk[n].up.b, x_out, Lin, flag, c->step_lens, fd::hop(n) / fd::ratio(n));
         run_if = flag;
         n8 = n4 = "convt_fp32_fallback";
+        if (pipe == PIPE_F16_ONLY) return hipSuccess;
     }
     if (fd::ratio(n) == 8)
         FD_LAUNCH(L, n8, k_convt<8>, grid, dim3(256), 0, x_in, w.up_pack[n], w.blk[n].up.b, x_out, Lin, run_if, c->step_lens, fd::hop(n) / fd::ratio(n));
@@ -2323,8 +2628,10 @@ static hipError_t launch_lvc(const Launch &L, const char *name, int n, int layer
     const float *kp = c->ws.kpack + (int64_t)n * B * T * fd::KREC;
     const int *run_if = nullptr;
     const int *kf = c->ws.range_flag + FLAG_KFMT_F32;
+    if constexpr (HOP == 256 && DIL == 27) c->final_fused = false;
     if constexpr (HOP >= 64) {
-        if (c->lvc_f16 && w.lvc_f16_ok) {
+        const Pipe pipe = fd_pipe(c, c->lvc_f16 && w.lvc_f16_ok, 1 + n * fd::LAYERS + layer);
+        if (pipe != PIPE_F32_ONLY) {
             int *flag = c->ws.range_flag + 1 + n * fd::LAYERS + layer;
             const dim3 grid(((Ln + 255) / 256 + 7) / 8 * 8, B);
             const float4 *wp = reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]);
@@ -2333,19 +2640,23 @@ static hipError_t launch_lvc(const Launch &L, const char *name, int n, int layer
             // the last layer of the last block feeds final_conv only: fused unless someone wants to look at the block output
             c->final_fused = false;
             if constexpr (HOP == 256 && DIL == 27) c->final_fused = c->fast[ST_FINAL] && !c->keep_taps && c->fuse_final;
+            const bool w8 = kpre && c->lvc_w8;      // eight waves per workgroup (KFMT_PACKED records only)
             if constexpr (HOP == 256 && DIL == 27) {
                 if (c->final_fused) {
                     const float4 *ff = reinterpret_cast<const float4 *>(w.final_fuse);
-                    if (kpre) FD_LAUNCH(L, name, (k_lvc_f16<HOP, DIL, true, true>), grid, dim3(256), 0, x_in, skip, x_out, kp, layer, wp, wr, cb, flag, kf, T, c->step_lens, c->ws.eps_acc, ff);
+                    if (w8) FD_LAUNCH(L, name, (k_lvc_w8<HOP, DIL, true>), grid, dim3(512), 0, x_in, skip, x_out, kp, layer, wp, wr, cb, flag, kf, T, c->step_lens, c->ws.eps_acc, ff);
+                    else if (kpre) FD_LAUNCH(L, name, (k_lvc_f16<HOP, DIL, true, true>), grid, dim3(256), 0, x_in, skip, x_out, kp, layer, wp, wr, cb, flag, kf, T, c->step_lens, c->ws.eps_acc, ff);
                     else FD_LAUNCH(L, name, (k_lvc_f16<HOP, DIL, true, false>), grid, dim3(256), 0, x_in, skip, x_out, kp, layer, wp, wr, cb, flag, kf, T, c->step_lens, c->ws.eps_acc, ff);
                 }
             }
             if (!c->final_fused) {
-                if (kpre) FD_LAUNCH(L, name, (k_lvc_f16<HOP, DIL, false, true>), grid, dim3(256), 0, x_in, skip, x_out, kp, layer, wp, wr, cb, flag, kf, T, c->step_lens, (float *)nullptr, (const float4 *)nullptr);
+                if (w8) FD_LAUNCH(L, name, (k_lvc_w8<HOP, DIL, false>), grid, dim3(512), 0, x_in, skip, x_out, kp, layer, wp, wr, cb, flag, kf, T, c->step_lens, (float *)nullptr, (const float4 *)nullptr);
+                else if (kpre) FD_LAUNCH(L, name, (k_lvc_f16<HOP, DIL, false, true>), grid, dim3(256), 0, x_in, skip, x_out, kp, layer, wp, wr, cb, flag, kf, T, c->step_lens, (float *)nullptr, (const float4 *)nullptr);
                 else FD_LAUNCH(L, name, (k_lvc_f16<HOP, DIL, false, false>), grid, dim3(256), 0, x_in, skip, x_out, kp, layer, wp, wr, cb, flag, kf, T, c->step_lens, (float *)nullptr, (const float4 *)nullptr);
             }
             run_if = flag;
             name = "lvc_fp32_fallback";
+            if (pipe == PIPE_F16_ONLY) return hipSuccess;
         }
     }
     FD_LAUNCH(L, name, (k_lvc_layer<HOP, DIL>), dim3((Ln + W - 1) / W, B), dim3(256), 0, x_in, skip, x_out, kp, layer,
@@ -2399,6 +2710,7 @@ hipError_t fast_final(const Launch &L, const StepIO &io, const float *x32, int B
         run_if = flag;
         name = "final_conv_fallback";
         c->final_fused = false;
+        if (!c->inline_fallback) return hipSuccess;      // fallback = host: a flagged last layer is redone from the host
     }
     FD_LAUNCH(L, name, k_final, dim3((Lf + 1023) / 1024, B), dim3(256), 0, x32, w.final_.w, w.final_.b, io.eps_out,
               c->ws.x, (const StepParams *)c->ws.params, io.sampler, Lf, (int64_t)B * Lf / 4, c->step_lens, run_if);

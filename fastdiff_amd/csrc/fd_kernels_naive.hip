@@ -376,23 +376,25 @@ hipError_t naive_update(const Launch &L, float *x, const float *eps, int64_t n)
 
 // End of a sampler step: next row of the step table; the fp16-range flags are cleared for the next step here rather than by a
 // memset node (a captured hipMemsetAsync wrote garbage on the second replay of the graph on ROCm 7.2).
-__global__ void k_advance(StepParams *p, int *range_flags, int inc)
+__global__ void k_advance(StepParams *p, int *range_flags, int inc, int set_step)
 {
-    if (threadIdx.x == 0) p->step_idx += inc;
-    if (threadIdx.x < 32) {      // this step's flags become "previous step" (inc == 0: start of a call, both cleared)
-        range_flags[32 + threadIdx.x] = inc ? range_flags[threadIdx.x] : 0;
+    if (threadIdx.x == 0) p->step_idx = inc ? p->step_idx + inc : set_step;
+    if (threadIdx.x < 32) {      // this step's flags become "previous step" (inc == 0: start of a call or of a redo, all cleared)
+        const int f = range_flags[threadIdx.x];
+        range_flags[32 + threadIdx.x] = inc ? f : 0;
+        range_flags[64 + threadIdx.x] = inc ? (range_flags[64 + threadIdx.x] | f) : 0;      // sticky over the call: what the host looks at
         range_flags[threadIdx.x] = 0;
     }
 }
 
 hipError_t advance_step(const Launch &L)
 {
-    FD_LAUNCH(L, "advance_step", k_advance, dim3(1), dim3(64), 0, L.ctx->ws.params, L.ctx->ws.range_flag, 1);
+    FD_LAUNCH(L, "advance_step", k_advance, dim3(1), dim3(64), 0, L.ctx->ws.params, L.ctx->ws.range_flag, 1, 0);
     return hipSuccess;
 }
-hipError_t clear_range_flags(const Launch &L)
+hipError_t clear_range_flags(const Launch &L, int set_step)
 {
-    FD_LAUNCH(L, "clear_flags", k_advance, dim3(1), dim3(64), 0, L.ctx->ws.params, L.ctx->ws.range_flag, 0);
+    FD_LAUNCH(L, "clear_flags", k_advance, dim3(1), dim3(64), 0, L.ctx->ws.params, L.ctx->ws.range_flag, 0, set_step);
     return hipSuccess;
 }
 

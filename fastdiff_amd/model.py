@@ -116,6 +116,7 @@ class FastDiff(nn.Module):
         self._handle = None
         self._handle_device = None
         self._synced_state = None
+        self._keepalive = None
         self._options = {}
 
     # ---- reference API --------------------------------------------------------------------------------
@@ -155,7 +156,8 @@ class FastDiff(nn.Module):
         return out
 
     # ---- HIP-side entry used by fastdiff_amd.util.sampling_given_noise_schedule ---------------------------
-    def sample(self, condition, table, ddim=False, x_T=None, noise=None, seed=0, return_sequence=False, lens=None, stream_ids=None):
+    def sample(self, condition, table, ddim=False, x_T=None, noise=None, seed=0, return_sequence=False, lens=None, stream_ids=None,
+               defer_check=False):
         """Run the N-step reverse loop on the device.
 
         table: list of dicts with keys t, c_eps, c_div, sigma, c1, c2, c3, add_noise (executed first -> last).
@@ -163,7 +165,10 @@ class FastDiff(nn.Module):
         lens: optional valid frames per utterance of a zero-padded batch: utterance b is then computed as if it were alone
         and lens[b] frames long (its first lens[b]*256 samples are exactly that result; the rest of its row is unspecified).
         stream_ids: optional [B] integers (fd_set_noise_streams): utterance b draws its noise from Philox stream (seed, stream_ids[b])
-        over its own samples, i.e. independently of its place in the batch."""
+        over its own samples, i.e. independently of its place in the batch.
+        defer_check: with the library option fallback = "host" (set_option; the default is "graph") the result is final only after
+        check() (fd_sample_check: one stream synchronisation and, rarely, a second pass on the fp32 kernels); sample() runs it
+        before returning unless told to defer -- then call check(), or any other method of the module, before reading the tensor."""
         B = condition.shape[0]
         self._require_inference(condition, condition)
         condition = condition.contiguous().float()
@@ -194,9 +199,22 @@ class FastDiff(nn.Module):
                            ct.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), out.data_ptr(),
                            None if seq is None else seq.data_ptr(), self._stream(dev))
         _capi.check(lib, h, rc, "fd_sample")
+        self._keepalive = (condition, x_T, noise)       # inputs of a deferred check
+        if not defer_check:
+            self.check()
         if return_sequence:
             return [seq[k] for k in range(N + 1)]
         return out
+
+    def check(self):
+        """Settle the last sample() under fallback = "host" (no-op otherwise).  Returns True if it had to be redone."""
+        if self._handle is None:
+            return False
+        lib = _capi.load()
+        rc = lib.fd_sample_check(self._handle)
+        _capi.check(lib, self._handle, rc, "fd_sample_check")
+        self._keepalive = None
+        return rc == 1
 
     def peak_normalize_int16(self, wav, valid=None):
         """wav [B,1,L] float32 -> int16 PCM [B,L]: wav/abs(wav).max() * 32767 (FastDiff.py:110; utils/audio.py:11-16).

@@ -114,6 +114,16 @@ FD_API int fd_sample(fd_handle h, const float *mel, int B, int T, const int *len
                      int ddim, const float *x_T, const float *z, uint64_t seed, float *out, float *seq_out,
                      void *stream);
 
+/* Option "fallback" = "host": fd_sample enqueues only the fp16x2 kernels (no early-exit fp32 launch behind each of them: 17 launches
+ * per reverse step less); whether an operand left the fp16 range is then known on the HOST, after the work has run:
+ *   fd_sample_check waits for the last fd_sample of this handle and, if one of its kernels raised a range flag, runs it again from
+ *   the saved start with the flagged stages on their fp32 kernels.  Returns 1 if the call was redone, 0 if not, < 0 on error.
+ * Until it has returned, `out` / `seq_out` of that fd_sample are provisional and its `z` must stay valid.  Every later call on the
+ * handle settles a pending check first, so nothing is ever lost -- but a caller that reads `out` itself must call fd_sample_check
+ * before.  Schedules longer than 8 steps are checked (with a stream synchronisation) every 8 steps inside fd_sample.
+ * With the default ("graph") fd_sample_check is a no-op returning 0. */
+FD_API int fd_sample_check(fd_handle h);
+
 /* Per-utterance noise streams for the NEXT fd_sample call (one-shot; the reference draws std_normal per batch on the CPU,
  * util.py:63-68, so it has no counterpart there).  stream_ids [B] host: utterance b's x_T and z are then drawn from Philox stream
  * (seed, stream_ids[b]) with the counter running over the utterance's own samples -- the draw no longer depends on the position in
@@ -149,6 +159,9 @@ FD_API int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_sa
  * "fuse_final" = "1" (default: the last LVC layer applies final_conv to its own tile instead of writing 32 channels for a separate
  *          kernel to read back; off automatically with "taps") | "0";
  * "mel"  = "pwg" (default) | "tacotron": which of the reference's two mel front-ends fd_mel_spectrogram computes;
+ * "lvc_waves" = "8" (default: the fp16x2 LVC layers run as 8-wave workgroups, half the instruction stream per wave) | "4";
+ * "fallback" = "graph" (default: every fp16x2 kernel is followed by its fp32 twin, which exits at once unless the first raised its
+ *          range flag -- no host round trip, fully asynchronous) | "host" (see fd_sample_check);
  * "taps" = "1" | "0" (keep block outputs for fd_read_tap). */
 FD_API int fd_set_option(fd_handle h, const char *key, const char *value);
 
@@ -158,7 +171,7 @@ FD_API int fd_set_option(fd_handle h, const char *key, const char *value);
  * "kp_h<n>" [B,64,T], "kpack<n>" [B,T,24832] (packed predicted kernels+bias of block n), "x<n>" [B,32,L_n],
  * "range_flags" (32 int32 bit patterns: [0] predictor GEMM, [1 + 4*block + layer] LVC layer, [13 + d] DBlock d,
  * [16 + n] ConvTranspose of block n -- set when an operand of the last fd_forward did not fit fp16 and the fp32 kernel redid
- * that launch; fd_sample clears them every step).
+ * that launch; fd_sample clears them every step), "range_flags_call" (the same 32 words OR-ed over all steps of the last fd_sample).
  * Returns the number of floats (also when host_dst is NULL), or a negative status. */
 FD_API int64_t fd_read_tap(fd_handle h, const char *name, float *host_dst, int64_t capacity);
 

@@ -424,6 +424,83 @@ def test_sampler_graph_replay_equals_eager(model, gc, sched):
     assert torch.equal(a, b) and torch.equal(a, a2)
 
 
+def test_host_checked_fallback_equals_inline_fallback(gc, sched, oracle64):
+    """Option fallback = "host": the sampler enqueues no fp32 launch behind its fp16x2 kernels; the range
+    flags are read back after the call and a flagged call is redone with those stages on fp32.  With weights that drive the
+    activations past the fp16 range the result must be the inline-fallback result (option "graph") up to fp32 rounding, the
+    float64 oracle's relative to its scale, and check() must say that it redid the call; with ordinary weights nothing is redone
+    and both modes agree bit for bit."""
+    import synth
+    rows, table = gc.table_rows(sched, 4)
+    B, T, N = 2, 7, 4
+    mel = synth.synth_mel(31, B, T)
+    x_T = synth.hash_normal(31, 1, B * T * 256).reshape(B, 1, T * 256)
+    z = gc.noise_from_seed(31, B, T, N)
+    args = dict(x_T=torch.from_numpy(x_T).cuda(), noise=torch.from_numpy(gc.exec_order_noise(z)).cuda())
+    melc = torch.from_numpy(mel).cuda()
+    # ordinary weights: no redo, identical bits
+    m = gc.make_model()
+    m.set_option("fallback", "host")
+    with torch.no_grad():
+        a = m.sample(melc, rows, defer_check=True, **args)
+        assert m.check() is False
+        m.set_option("fallback", "graph")
+        b = m.sample(melc, rows, **args)
+        m.set_option("fallback", "host")
+    assert torch.equal(a, b)
+    # a first conv scaled by 3e5: DBlocks, ConvTranspose and the LVC layers of hop 64 / 256 leave the fp16 range
+    sd = dict(synth.synth_state_dict(1234))
+    sd["first_audio_conv.weight_g"] = (sd["first_audio_conv.weight_g"] * 3.0e5).astype(np.float32)
+    m2 = gc.fastdiff_amd.FastDiff()
+    m2.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    m2 = m2.cuda().eval()
+    m2.set_option("fallback", "host")
+    o = type(oracle64)("f64")
+    o.set_weights(sd)
+    ref = o.sample(mel, table, x_T, z)
+    with torch.no_grad():
+        h1 = m2.sample(melc, rows, defer_check=True, **args)
+        assert m2.check() is True                                      # flags were raised: the call ran a second time
+        h2 = m2.sample(melc, rows, **args)                             # the same with the check inside sample()
+        m2.set_option("fallback", "graph")
+        g = m2.sample(melc, rows, **args)
+        m2.set_option("fallback", "host")
+    scale = float(np.abs(ref).max())
+    assert np.isfinite(h1.cpu().numpy()).all() and torch.equal(h1, h2)
+    assert gc.maxdiff(h1.cpu().numpy(), ref) < 1e-5 * scale and gc.maxdiff(g.cpu().numpy(), ref) < 1e-5 * scale
+    # a later call on the handle settles a deferred check by itself
+    with torch.no_grad():
+        h3 = m2.sample(melc, rows, defer_check=True, **args)
+        pcm = m2.peak_normalize_int16(h3)                              # settles, then reads the final h3
+    assert torch.equal(h3, h1) and pcm.shape == (B, T * 256)
+
+
+def test_host_checked_fallback_long_schedule(gc, sched):
+    """N = 20 > 8: under fallback = host the schedule runs as 8-step pieces, each checked before the next starts; an overflow that
+    appears in the middle (a table whose c_div = 0.4 lets x grow 2.5x per step: past the fp16 range around step 10) costs one
+    repeated piece, the rest runs with the flagged kernels on fp32.  Against the inline-fallback run of the same call."""
+    import synth
+    m = gc.make_model()
+    m.set_option("fallback", "host")
+    B, T, N = 1, 6, 20
+    mel = torch.from_numpy(synth.synth_mel(41, B, T)).cuda()
+    x_T = torch.from_numpy(synth.hash_normal(41, 1, B * T * 256).reshape(B, 1, T * 256)).cuda()
+    rows = [{"t": 400.0 - 10 * k, "c_eps": 0.01, "c_div": 0.4, "sigma": 0.1, "c1": 1.0, "c2": 0.0, "c3": 0.0, "add_noise": int(k < N - 1)} for k in range(N)]
+    noise = torch.from_numpy(np.stack([synth.hash_normal(41, 2 + k, B * T * 256).reshape(B, 1, T * 256) for k in range(N)])).cuda()
+    with torch.no_grad():
+        a = m.sample(mel, rows, x_T=x_T, noise=noise, return_sequence=True)
+        m.set_option("fallback", "graph")
+        b = m.sample(mel, rows, x_T=x_T, noise=noise, return_sequence=True)
+        flags = m.read_tap("range_flags_call").view(np.int32)
+    peak = [float(v.abs().max()) for v in b]
+    assert peak[-1] > 1.0e6 and peak[4] < 3.0e3, peak[::4]             # the range is left somewhere in the middle
+    assert flags[13:19].all()                                          # ... and the inline run did fall back at the end
+    for k in range(N + 1):
+        assert torch.isfinite(a[k]).all()
+        assert float((a[k] - b[k]).abs().max()) <= 1e-4 * max(1.0, peak[k]), k
+    assert torch.equal(a[1], b[1])                                     # before anything overflows the two modes run the same kernels
+
+
 def test_graph_cache_alternating_shapes(gc, sched):
     """One captured step per (B, T, mode) is kept (micro-batches of different padded length alternate in infer.py): results with
     the cache warm, after other shapes ran in between, and after more shapes than the cache holds (eviction) must equal the

@@ -1,5 +1,5 @@
 // lvc_h2_bench.hip -- standalone timing harness for k_lvc_f16 (phase stamps with s_memtime when FD_LVC_TIMING is set)
-// usage: lvc_h2_bench [B] [T] [kpre = 1|0]
+// usage: lvc_h2_bench [B] [T] [kpre = 1|0] [waves = 4|8]   (8 waves: k_lvc_w8, packed records only)
 #include "../../fastdiff_amd/csrc/fd_kernels_fast.hip"
 #include <stdio.h>
 #include <stdlib.h>
@@ -9,7 +9,7 @@ void fd_prof_begin(const fdk::Launch &, const char *) {}
 void fd_prof_end(const fdk::Launch &) {}
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-template <int HOP, int DIL, bool KPRE>
+template <int HOP, int DIL, bool KPRE, bool W8 = false>
 int run(int B, int T, int reps)
 {
     const int Ln = T * HOP;
@@ -44,10 +44,14 @@ int run(int B, int T, int reps)
     dim3 grid(((Ln + 255) / 256 + 7) / 8 * 8, B);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((fdk_fast::k_lvc_f16<HOP, DIL, false, KPRE>), grid, dim3(256), 0, 0, x, skip, out, kp, 1, (const float4 *)wpack, wref, cb, flag, (const int *)(flag + 20), T, (const int *)nullptr, (float *)nullptr, (const float4 *)nullptr);
+    auto launch = [&]() {
+        if constexpr (W8) hipLaunchKernelGGL((fdk_fast::k_lvc_w8<HOP, DIL, false>), grid, dim3(512), 0, 0, x, skip, out, kp, 1, (const float4 *)wpack, wref, cb, flag, (const int *)(flag + 20), T, (const int *)nullptr, (float *)nullptr, (const float4 *)nullptr);
+        else hipLaunchKernelGGL((fdk_fast::k_lvc_f16<HOP, DIL, false, KPRE>), grid, dim3(256), 0, 0, x, skip, out, kp, 1, (const float4 *)wpack, wref, cb, flag, (const int *)(flag + 20), T, (const int *)nullptr, (float *)nullptr, (const float4 *)nullptr);
+    };
+    for (int i = 0; i < 3; ++i) launch();
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((fdk_fast::k_lvc_f16<HOP, DIL, false, KPRE>), grid, dim3(256), 0, 0, x, skip, out, kp, 1, (const float4 *)wpack, wref, cb, flag, (const int *)(flag + 20), T, (const int *)nullptr, (float *)nullptr, (const float4 *)nullptr);
+    for (int i = 0; i < reps; ++i) launch();
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms = 0;
@@ -55,7 +59,7 @@ int run(int B, int T, int reps)
     const double us = ms * 1e3 / reps;
     const double flops = 2.0 * B * T * HOP * (32 * 96 + 64 * 96), bytes = 4.0 * B * T * (96.0 * HOP + 6208);
     int hf = 0; CK(hipMemcpy(&hf, flag, 4, hipMemcpyDeviceToHost));
-    printf("lvc_f16<%d,%d,kpre=%d> B=%d T=%d: %.1f us  %.1f TFLOP/s(fp32-equivalent)  %.0f GB/s (algorithmic)  flag=%d\n", HOP, DIL, (int)KPRE, B, T, us, flops / us / 1e6, bytes / us / 1e3, hf);
+    printf("lvc<%d,%d,kpre=%d,waves=%d> B=%d T=%d: %.1f us  %.1f TFLOP/s(fp32-equivalent)  %.0f GB/s (algorithmic)  flag=%d\n", HOP, DIL, (int)KPRE, W8 ? 8 : 4, B, T, us, flops / us / 1e6, bytes / us / 1e3, hf);
 #ifdef FD_LVC_TIMING
     std::vector<long long> d(64 * 4 * 8);
     CK(hipMemcpyFromSymbol(d.data(), HIP_SYMBOL(fdk_fast::fd_dbg), d.size() * 8));
@@ -74,7 +78,9 @@ int main(int argc, char **argv)
 {
     const int B = argc > 1 ? atoi(argv[1]) : 8, T = argc > 2 ? atoi(argv[2]) : 864;
     const bool kpre = argc > 3 ? atoi(argv[3]) != 0 : true;
-    if (kpre) { run<256, 27, true>(B, T, 20); run<256, 1, true>(B, T, 20); run<64, 27, true>(B, T, 20); run<64, 1, true>(B, T, 20); }
+    const bool w8 = argc > 4 ? atoi(argv[4]) == 8 : false;
+    if (w8) { run<256, 27, true, true>(B, T, 20); run<256, 1, true, true>(B, T, 20); run<64, 27, true, true>(B, T, 20); run<64, 1, true, true>(B, T, 20); }
+    else if (kpre) { run<256, 27, true>(B, T, 20); run<256, 1, true>(B, T, 20); run<64, 27, true>(B, T, 20); run<64, 1, true>(B, T, 20); }
     else { run<256, 27, false>(B, T, 20); run<256, 1, false>(B, T, 20); run<64, 27, false>(B, T, 20); run<64, 1, false>(B, T, 20); }
     return 0;
 }
