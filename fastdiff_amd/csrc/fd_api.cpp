@@ -519,9 +519,7 @@ int fd_commit_weights(fd_handle h)
             if ((rc = up_conv(p + ".convs." + std::to_string(i), w.blk[n].convs[i])) != FD_OK) return rc;
             UP(pack_A(f[p + ".convs." + std::to_string(i)].w, fd::C, fd::C, 3), w.lvc_conv_pack[n][i]);
             {
-                std::vector<float> ws = f[p + ".convs." + std::to_string(i)].w;      // 0.4 w: the activations arrive as 2.5 leaky_relu
-                for (float &v : ws) v *= fd::LVC_ACT_SCALE;
-                const std::vector<uint16_t> hp = pack_A_h2(ws, fd::C, 3, &lvc_ok);
+                const std::vector<uint16_t> hp = pack_A_h2(f[p + ".convs." + std::to_string(i)].w, fd::C, 3, &lvc_ok);
                 if ((rc = upload(h, hp.data(), hp.size() * sizeof(uint16_t), reinterpret_cast<const void **>(&w.lvc_conv_h2[n][i]))) != FD_OK)
                     return rc;
             }
@@ -557,16 +555,10 @@ int fd_commit_weights(fd_handle h)
             UP(gb, w.gemm_bias[n]);
             // fp16x2 form: w = w1 + 2^-11 * w2, w1 = fp16(w), w2 = fp16((w - w1) * 2^11) (round to nearest even, subnormals kept);
             // B operand of v_mfma_f32_32x32x16_f16: lane = col + 32*g holds the 8 consecutive k = kg*16 + 8g + e, k = tap*64 + channel
-            // The kernel rows of blocks 1 and 2 carry the factor 0.4 of lrelu25 (fd_kernels_fast.hip): the GEMM then leaves 0.4 K.
             std::vector<uint16_t> gx((size_t)(fd::KREC / 32) * 2 * 12 * 64 * 8);
-            std::vector<float> gbs(gb);
-            for (int pp = 0; pp < fd::KW; ++pp)
-                if (n >= 1) gbs[pp] = gb[pp] * fd::LVC_ACT_SCALE;
-            UP(gbs, w.gemm_bias_h2[n]);
             for (int pt = 0; pt < fd::KREC / 32; ++pt)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int pp = pt * 32 + (lane & 31), g = lane >> 5;
-                    const float sc = (n >= 1 && pp < fd::KW) ? fd::LVC_ACT_SCALE : 1.0f;
                     const float *wrow;
                     if (pp < fd::KW) {
                         int layer, in, out, tap;
@@ -579,7 +571,7 @@ int fd_commit_weights(fd_handle h)
                     for (int kg = 0; kg < 12; ++kg)
                         for (int e = 0; e < 8; ++e) {
                             const int kk = kg * 16 + g * 8 + e, tap = kk / fd::HID, ch = kk % fd::HID;
-                            const float v = wrow[ch * 3 + tap] * sc;
+                            const float v = wrow[ch * 3 + tap];
                             if (!(fabsf(v) < 32768.0f)) f16_ok = false;
                             const uint16_t p1 = f16_from_f32(v);
                             const uint16_t p2 = f16_from_f32((v - f32_from_f16(p1)) * 2048.0f);
@@ -702,14 +694,7 @@ hipError_t kp_front(const Launch &L, const StepIO &io, int B, int T)
     L.ctx->h_image_ready = false;      // only the fp16-pipe front writes the GEMM's h image itself
     return L.ctx->fast[ST_KP_FRONT] ? fast_kp_front(L, io, B, T) : naive_kp_front(L, io, B, T);
 }
-hipError_t kp_gemm(const Launch &L, int B, int T)
-{
-    fd_context *c = L.ctx;
-    // blocks 1 and 2 get their predicted kernels as packed fp16 pairs when both ends are the fp16x2 kernels
-    c->kfmt = (c->fast[ST_KP_GEMM] && c->fast[ST_LVC] && c->gemm_f16 && c->w.gemm_f16_ok && c->lvc_f16 && c->w.lvc_f16_ok && !(c->fp32_mask & 1u))
-                  ? KFMT_PACKED : KFMT_F32;
-    return c->fast[ST_KP_GEMM] ? fast_kp_gemm(L, B, T) : naive_kp_gemm(L, B, T);
-}
+hipError_t kp_gemm(const Launch &L, int B, int T) { return L.ctx->fast[ST_KP_GEMM] ? fast_kp_gemm(L, B, T) : naive_kp_gemm(L, B, T); }
 
 // One TimeAware_LVCBlock (modules.py:190-218) given the packed kernels of kp_gemm.  x_in: [B,32,Lin].
 static hipError_t lvc_block_run(const Launch &L, int n, const float *x_in, int B, int T, float **x_out)
@@ -954,7 +939,7 @@ static int resolve_pending(fd_handle h, unsigned *mask)
     FD_HIP(h, hipEventSynchronize(h->flags_done));
     unsigned m = 0;
     for (int i = 0; i < 32; ++i)
-        if (h->flags_host[i] && i != FLAG_KFMT_F32) m |= 1u << i;
+        if (h->flags_host[i]) m |= 1u << i;
     if (m & (1u << 19)) m |= 1u;                 // the predictor front feeds the GEMM: both go
     *mask |= m;
     if (m == 0) return 0;
@@ -1143,6 +1128,46 @@ int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_samples, 
     return FD_OK;
 }
 
+static int check_lvc_op(fd_handle h, int B, int Cin, int Cout, int ks, int T, int hop, const char *who)
+{
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || hop <= 0 || ks <= 0 || (ks & 1) == 0)
+        FD_FAIL(h, FD_ERR_INVALID, "%s: B=%d Cin=%d Cout=%d ks=%d T=%d hop=%d must be positive, ks odd", who, B, Cin, Cout, ks, T, hop);
+    if ((int64_t)Cin * Cout * ks > 8192 || Cout > 256)
+        FD_FAIL(h, FD_ERR_UNSUPPORTED, "%s: Cin*Cout*ks = %lld > 8192 (or Cout > 256) has no kernel", who, (long long)Cin * Cout * ks);
+    if ((int64_t)B * std::max(Cin, Cout) * T * hop >= (int64_t)1 << 31)
+        FD_FAIL(h, FD_ERR_INVALID, "%s: tensor too large for one call", who);
+    if (B > 65535 || std::max(Cin, Cout) > 65535) FD_FAIL(h, FD_ERR_INVALID, "%s: B, channels <= 65535", who);
+    return FD_OK;
+}
+
+int fd_lvc_forward(fd_handle h, const float *x, const float *kernel, const float *bias, int B, int Cin, int Cout, int ks, int T, int hop,
+                   float *out, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!x || !kernel || !bias || !out) FD_FAIL(h, FD_ERR_INVALID, "fd_lvc_forward: null pointer");
+    int rc = check_lvc_op(h, B, Cin, Cout, ks, T, hop, "fd_lvc_forward");
+    if (rc != FD_OK) return rc;
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch L = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::lvc_op_forward(L, x, kernel, bias, out, B, Cin, Cout, ks, T, hop);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_lvc_forward: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+int fd_lvc_backward(fd_handle h, const float *x, const float *kernel, const float *dout, int B, int Cin, int Cout, int ks, int T, int hop,
+                    float *dx, float *dkernel, float *dbias, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!dout || ((dkernel || dbias) && !x) || (dx && !kernel)) FD_FAIL(h, FD_ERR_INVALID, "fd_lvc_backward: null pointer");
+    int rc = check_lvc_op(h, B, Cin, Cout, ks, T, hop, "fd_lvc_backward");
+    if (rc != FD_OK) return rc;
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch L = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::lvc_op_backward(L, x, kernel, dout, dx, dkernel, dbias, B, Cin, Cout, ks, T, hop);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_lvc_backward: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
 int fd_peak_normalize_int16_ragged(fd_handle h, const float *wav, int B, int64_t len, const int64_t *valid, int16_t *pcm, void *stream)
 {
     if (!h || !wav || !pcm || B <= 0 || len <= 0 || B > 4096) return FD_ERR_INVALID;
@@ -1230,13 +1255,6 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
         else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: mel expects pwg|tacotron, got '%s'", value);
         return FD_OK;
     }
-    if (k == "lvc_waves") {
-        if (v == "8") h->lvc_w8 = true;
-        else if (v == "4") h->lvc_w8 = false;
-        else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: lvc_waves expects 8|4, got '%s'", value);
-        drop_graph(h);
-        return FD_OK;
-    }
     if (k == "fallback") {
         if (v == "host") h->host_fallback = true;
         else if (v == "graph") h->host_fallback = false;
@@ -1287,20 +1305,6 @@ int64_t fd_read_tap(fd_handle h, const char *name, float *host_dst, int64_t capa
     FD_HIP(h, hipSetDevice(h->device));
     FD_HIP(h, hipDeviceSynchronize());
     FD_HIP(h, hipMemcpy(host_dst, src, sizeof(float) * n, hipMemcpyDeviceToHost));
-    if (k.size() == 6 && k.compare(0, 5, "kpack") == 0 && k[5] >= '1' && h->kfmt == KFMT_PACKED) {
-        // blocks 1, 2 in KFMT_PACKED: every kernel element is the dword (h | l << 16) of 0.4 K -- handed out as the fp32 kernels they stand for
-        int f32_after_all = 0;
-        FD_HIP(h, hipMemcpy(&f32_after_all, w.range_flag + FLAG_KFMT_F32, sizeof(int), hipMemcpyDeviceToHost));
-        if (!f32_after_all)
-            for (int64_t fr = 0; fr < (int64_t)B * T; ++fr) {
-                float *rec = host_dst + fr * fd::KREC;
-                for (int p = 0; p < fd::KW; ++p) {
-                    uint32_t u;
-                    memcpy(&u, rec + p, 4);
-                    rec[p] = (f32_from_f16((uint16_t)(u & 0xFFFFu)) + f32_from_f16((uint16_t)(u >> 16)) * (1.0f / 2048.0f)) * (1.0f / fd::LVC_ACT_SCALE);
-                }
-            }
-    }
     return n;
 }
 

@@ -24,14 +24,6 @@ constexpr int KLAYER = 2 * C * C * 3;        // 6144 predicted-kernel floats per
 constexpr int KW = KLAYER * LAYERS;          // 24576
 constexpr int KB = 2 * C * LAYERS;           // 256 predicted biases per frame
 constexpr int KREC = KW + KB;                // 24832 floats: one frame's packed record
-// The fp16x2 LVC layers (hop 64, 256) write 2.5 * leaky_relu(v, 0.2) = 1.5 v + |v| (one v_fma_f32) into their operand images; the
-// factor 0.4 that undoes it is folded, at load time, into the weights that multiply those images: the layers' conv weights and the
-// kernel rows of the predictor GEMM of blocks 1 and 2 (so a predicted kernel of those blocks is 0.4 K wherever the fp16x2 GEMM
-// produced it; the GEMM multiplies it out again when it writes plain fp32).  FD_LVC_LRELU25 = 0 builds without the fold.
-#ifndef FD_LVC_LRELU25
-#define FD_LVC_LRELU25 1
-#endif
-constexpr float LVC_ACT_SCALE = FD_LVC_LRELU25 ? 0.4f : 1.0f;
 __host__ __device__ constexpr int ratio(int n) { return n == 2 ? 4 : 8; }        // upsample_ratios [8,8,4]
 __host__ __device__ constexpr int hop(int n) { return n == 0 ? 8 : (n == 1 ? 64 : 256); }
 __host__ __device__ constexpr int down_factor(int d) { return d == 0 ? 4 : 8; }   // reversed ratios (FastDiff_model.py:63)
@@ -80,7 +72,7 @@ struct DevWeights {
     const uint16_t *down_h2[fd::NBLK][4] = {};    // the same as two fp16 pieces: [piece][kg][64 lane][8]
     bool dblock_f16_ok = false;
     const float *lvc_conv_pack[fd::NBLK][fd::LAYERS] = {};
-    const uint16_t *lvc_conv_h2[fd::NBLK][fd::LAYERS] = {};   // 0.4 w (lrelu25) as two fp16 pieces: [piece][6 kg][64 lane][8], k = tap*32 + in
+    const uint16_t *lvc_conv_h2[fd::NBLK][fd::LAYERS] = {};   // the same as two fp16 pieces: [piece][6 kg][64 lane][8], k = tap*32 + in
     bool lvc_f16_ok = false;                      // every LVC conv weight fits the fp16 range
     const float *kp_in_pack[fd::NBLK] = {};       // 80->64 k5: 2 mt x 50 s4
     const float *kp_res_pack[fd::NBLK][6] = {};   // 64->64 k3: 2 mt x 24 s4
@@ -89,9 +81,7 @@ struct DevWeights {
     bool kpf_f16_ok = false;
     const float *gemm_pack[fd::NBLK] = {};        // kernel_conv+bias_conv as MFMA B operand: [776 ptile][24 s4][64][4]
     const float *gemm_bias[fd::NBLK] = {};        // [24832] conv biases in packed order
-    const uint16_t *gemm_h2_pack[fd::NBLK] = {};  // same weights as two fp16 pieces (w1, (w-w1)*2^11): [776 ptile][2][12 kg][64 lane][8];
-                                                  // blocks 1, 2: the kernel rows carry the factor 0.4 (KFMT_PACKED / lrelu25)
-    const float *gemm_bias_h2[fd::NBLK] = {};     // [24832] conv biases for that pack (kernel part of blocks 1, 2 times 0.4)
+    const uint16_t *gemm_h2_pack[fd::NBLK] = {};  // same weights as two fp16 pieces (w1, (w-w1)*2^11): [776 ptile][2][12 kg][64 lane][8]
     bool gemm_f16_ok = false;                     // every GEMM weight fits the fp16 range
     const float *up_pack[fd::NBLK] = {};          // ConvTranspose as per-phase A operands: [r phases][8 s4][64][4]
     const uint16_t *up_h2[fd::NBLK] = {};         // ConvTranspose per-phase slices as fp16 pieces: [ph][piece][4 kg][64 lane][8]
@@ -115,15 +105,6 @@ struct StepParams {
     int l4;                // samples / 4 of one (padded) utterance of this call: splits a flat float4 index into (utterance, offset)
     const unsigned long long *uids;   // [B] per-utterance noise stream ids (fd_set_noise_streams) or null: see philox_normal4
 };
-
-// Format of the predicted kernels of LVC blocks 1 and 2 (hop 64, 256) inside a frame record.  Block 0 and all biases are always fp32.
-//   KFMT_F32     plain fp32 (the reference's values)
-//   KFMT_PACKED  every element as the dword (h | l << 16) with 0.4 K = h + l * 2^-11 (fp16 pieces): exactly the A operand of the
-//                fp16x2 LVC layer, which also folds the 0.4 of its 1-instruction leaky-relu (fd_kernels_fast.hip: lrelu25).
-//                Written by the fp16x2 GEMM when the fp16x2 LVC kernels are its consumers; if an element does not fit, or the
-//                fp32 GEMM had to redo the step, the record holds KFMT_F32 instead and range_flag[FLAG_KFMT_F32] says so.
-enum KFormat { KFMT_F32 = 0, KFMT_PACKED = 1 };
-constexpr int FLAG_KFMT_F32 = 20;      // word of Workspace::range_flag
 
 enum Stage { ST_EMBED = 0, ST_FIRST, ST_DBLOCK, ST_KP_FRONT, ST_KP_GEMM, ST_CONVT, ST_LVC, ST_FINAL, ST_COUNT };
 
@@ -185,11 +166,9 @@ struct fd_context {
     //   !inline_fallback only the fp16x2 kernel; flags accumulate in range_flag[64..95] and the HOST redoes the work with
     //                    fp32_mask set (option fallback = host: fd_sample_check)
     //   fp32_mask        bit i set: the stage whose flag word is i runs its fp32 kernel outright
-    bool lvc_w8 = true;                       // option "lvc_waves" = "8": the fp16x2 LVC layers run as 8-wave workgroups (k_lvc_w8)
     bool host_fallback = false;               // option "fallback" = "host"
     bool inline_fallback = true;
     unsigned fp32_mask = 0;
-    int kfmt = KFMT_F32;                      // format of the predicted kernels of blocks 1, 2 in this step's records (set by kp_gemm)
     bool h_image_ready = false;               // set by fast_kp_front when it wrote the GEMM's fp16 image of h for this step
     std::map<std::string, std::pair<std::vector<int64_t>, std::vector<float>>> raw;   // host copies from fd_set_weight
     std::vector<void *> dev_allocs;          // weight arena pieces

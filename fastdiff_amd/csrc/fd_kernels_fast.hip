@@ -93,49 +93,6 @@ __device__ __forceinline__ float amax4(float m, const float4 &v) { return fmaxf(
 // byte offset of 16 B slot `slot` (piece*4 + channel/8) of row `row` in a [row][128 B] piece image
 __device__ __forceinline__ int h2_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
-// The same split with the mixed-precision FMA forms (5 instructions per pair instead of 6-8): h = cvt_pk(a, b); a - h and b - h come
-// out of v_fma_mix_f32 reading the fp16 halves directly (exact), v_fma_mixlo/hi_f16 scale by 2^11 and round to fp16 (nearest even)
-// into the two halves of `lo`.  Same bits as split2.  (Inline asm: its results only ever go to LDS or global stores, never
-// straight into an MFMA operand -- hipcc pads no VALU->MFMA wait states around asm outputs.)
-__device__ __forceinline__ void split2m(float a, float b, unsigned &hi, unsigned &lo)
-{
-    const f2_t v = {a, b};
-    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2_t));
-    float ta, tb;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ta) : "v"(hi), "v"(a));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(tb) : "v"(hi), "v"(b));
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(lo) : "v"(ta), "s"(GX_SCALE));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(lo) : "v"(tb), "s"(GX_SCALE));
-}
-__device__ __forceinline__ void split8m(const float (&v)[8], float4 &hi, float4 &lo)
-{
-    unsigned h[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) split2m(v[2 * i], v[2 * i + 1], h[i], l[i]);
-    hi = make_float4(__uint_as_float(h[0]), __uint_as_float(h[1]), __uint_as_float(h[2]), __uint_as_float(h[3]));
-    lo = make_float4(__uint_as_float(l[0]), __uint_as_float(l[1]), __uint_as_float(l[2]), __uint_as_float(l[3]));
-}
-// One value as the dword (h | l << 16), h = fp16(v), l = fp16((v - h) * 2^11): the packed form of a predicted-kernel element
-// (three instructions; fd_internal.h: KFMT_PACKED).
-__device__ __forceinline__ unsigned pack_hl(float v)
-{
-    unsigned d;
-    float t;
-    asm("v_fma_mixlo_f16 %0, %1, 1.0, 0" : "=v"(d) : "v"(v));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(t) : "v"(d), "v"(v));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(d) : "v"(t), "s"(GX_SCALE));
-    return d;
-}
-// 2.5 * leaky_relu(v, 0.2) = 1.5 v + |v| in ONE instruction; the factor 0.4 is folded into the weights that multiply the result
-// (the LVC layers' conv weights and predicted kernels, LVC_ACT_SCALE).  Only on the fp16x2 pipe: the fp32 kernels keep max(v, 0.2 v).
-constexpr float LVC_ACT_SCALE = fd::LVC_ACT_SCALE, LVC_ACT_INV = 1.0f / fd::LVC_ACT_SCALE;
-__device__ __forceinline__ float lrelu25(float v)
-{
-    float r;
-    asm("v_fma_f32 %0, %1, %2, |%1|" : "=v"(r) : "v"(v), "s"(1.5f));      // (1.5 is not an inline constant: it rides in an SGPR)
-    return r;
-}
-
 
 // =================================================================================================
 // a3: first_audio_conv  Conv1d(1,32,k7,pad3)  (FastDiff_model.py:34-36,89)   -- VALU, HBM-write bound
@@ -317,8 +274,11 @@ __device__ __forceinline__ void store_act_h2(char *img, const f32x16 &ah, const 
 // columns are recomputed from the audio (7 samples, 56 FMAs per 8 channels; same operation order as k_first_conv, so the same
 // bits) instead of picked out of the 32-channel tensor: a stride-F pick of fp32 fetches every cache line of it, 226 MB at the
 // benchmark size against 7 MB of audio.
+#ifndef FD_DBLOCK_OCC
+#define FD_DBLOCK_OCC 3      // waves per SIMD the register allocation is held to: three workgroups per CU fit the 52 KB of LDS, and the kernel is
+#endif                       // a chain of three dependent layers with barriers between them (A/B in one session: 73.2 -> 69.9 us at B=8, 18.2 -> 15.4 at B=1)
 template <int F, bool AUDIO>
-__global__ void __launch_bounds__(256, 2) k_dblock_h2(const float *__restrict__ xin, float *__restrict__ out,
+__global__ void __launch_bounds__(256, FD_DBLOCK_OCC) k_dblock_h2(const float *__restrict__ xin, float *__restrict__ out,
                                                       const float4 *__restrict__ p0, const float4 *__restrict__ p1,
                                                       const float4 *__restrict__ p2, const float4 *__restrict__ pr,
                                                       const float *__restrict__ b0, const float *__restrict__ b1,
@@ -742,13 +702,10 @@ __device__ long long fd_gdbg[64 * 4 * 4];
 __global__ void __launch_bounds__(256, 2) k_kp_gemm(const float *__restrict__ h /*[3][B][64][T]*/, float *__restrict__ kpack,
                                                     const float *g0, const float *g1, const float *g2, const float *gb0,
                                                     const float *gb1, const float *gb2, int B, int T, int chunks_per_utt,
-                                                    int chunk_tiles, int n_items, const int *__restrict__ run_if, const int *__restrict__ lens,
-                                                    int *__restrict__ fmt_flag)
+                                                    int chunk_tiles, int n_items, const int *__restrict__ run_if, const int *__restrict__ lens)
 {
     __shared__ float hs[2][fd::HID * GEMM_LDH];
-    if (run_if && *run_if == 0) return;      // fallback launch behind the fp16 kernel: only when that one flagged its operands or results
-    // redoing a KFMT_PACKED step: this kernel writes plain fp32 kernels, and says so to the LVC layers behind it
-    if (fmt_flag && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(fmt_flag, 1);
+    if (run_if && *run_if == 0) return;      // fallback launch behind the fp16 kernel: only when k_h_split flagged the operands
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     constexpr int XG = fd::KREC / 128;
     const int ny = B * chunks_per_utt;
@@ -938,14 +895,10 @@ __device__ long long fd_gxdbg[8];
 #define GX_TIMING_ARGS
 #define GX_TIMING_PASS
 #endif
-// `pack` (uniform per wave): this item's 32 columns are predicted-KERNEL positions of block 1 or 2 in KFMT_PACKED mode: each value
-// (already 0.4 K: the weights carry LVC_ACT_SCALE) leaves as the dword (h | l << 16) the LVC layer's A operand is made of, and its
-// magnitude is tracked in `mx` (the LVC layers no longer look at K).  `unscale`: the same columns when the consumer wants plain
-// fp32 kernels (the 0.4 comes out again).
 template <int BUF, bool FULL>
 __device__ __forceinline__ void gx_item(char *lds, const GxItem &cur, bool more, const GxItem &nxt, const char *hx, float *kpack,
                                         const float4 (&wq)[2][12], const f32x16 &bias_lo, const int (&aoff)[2][12], int B, int T, int R,
-                                        int wave_u, int lane, int Tb, bool pack, bool unscale, float &mx GX_TIMING_ARGS)
+                                        int wave_u, int lane, int Tb GX_TIMING_ARGS)
 {
     const int l31 = lane & 31, hi = lane >> 5;
     GX_STAMP(0);
@@ -985,35 +938,16 @@ __device__ __forceinline__ void gx_item(char *lds, const GxItem &cur, bool more,
         if (acc[0] != 12345.678f) continue;
 #endif
         if (FULL) {
-            if (pack) {
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const float v0 = fmaf(lo[r], GX_INV_SCALE, acc[r]), v1 = fmaf(lo[r + 1], GX_INV_SCALE, acc[r + 1]);
-                    mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)));
-                    __builtin_amdgcn_raw_buffer_store_b32(pack_hl(v0), rs, loff * 4u, (tile * 32 + (r & 3) + 8 * (r >> 2)) * fd::KREC * 4, FD_GX_STORE_AUX);
-                    __builtin_amdgcn_raw_buffer_store_b32(pack_hl(v1), rs, loff * 4u, (tile * 32 + ((r + 1) & 3) + 8 * ((r + 1) >> 2)) * fd::KREC * 4, FD_GX_STORE_AUX);
-                }
-            } else {
-                const float us = unscale ? LVC_ACT_INV : 1.0f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaf(lo[r], GX_INV_SCALE, acc[r]) * us), rs, loff * 4u,
-                                                          (tile * 32 + (r & 3) + 8 * (r >> 2)) * fd::KREC * 4, FD_GX_STORE_AUX);
-            }
-        } else {
-            float *kt = krow + (int64_t)tile * 32 * fd::KREC;
-            const float us = unscale ? LVC_ACT_INV : 1.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (t_begin + tile * 32 + drow(r, hi) < Tb) {
-                    const float v = fmaf(lo[r], GX_INV_SCALE, acc[r]);
-                    if (pack) {
-                        mx = __builtin_fmaxf(mx, __builtin_fabsf(v));
-                        reinterpret_cast<unsigned *>(kt + ((r & 3) + 8 * (r >> 2)) * fd::KREC)[loff] = pack_hl(v);
-                    } else {
-                        (kt + ((r & 3) + 8 * (r >> 2)) * fd::KREC)[loff] = v * us;
-                    }
-                }
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaf(lo[r], GX_INV_SCALE, acc[r])), rs, loff * 4u,
+                                                      (tile * 32 + (r & 3) + 8 * (r >> 2)) * fd::KREC * 4, FD_GX_STORE_AUX);
+        } else {
+            float *kt = krow + (int64_t)tile * 32 * fd::KREC;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (t_begin + tile * 32 + drow(r, hi) < Tb)
+                    (kt + ((r & 3) + 8 * (r >> 2)) * fd::KREC)[loff] = fmaf(lo[r], GX_INV_SCALE, acc[r]);
         }
         GX_STAMP(3);
     }
@@ -1029,12 +963,10 @@ __device__ __forceinline__ void gx_item(char *lds, const GxItem &cur, bool more,
     GX_STAMP(5);
 }
 
-// kfmt (fd_internal.h): KFMT_PACKED -- blocks 1 and 2 leave their predicted kernels as (h, l) fp16 pairs of 0.4 K, range-checked here
-// (word 0 of range_flag: "this GEMM's result is not usable", which makes the fp32 GEMM behind it redo the step in plain fp32).
 __global__ void __launch_bounds__(256, 2) k_kp_gemm_h2(const char *__restrict__ hx /*[3][B][R][2][64] fp16*/, float *__restrict__ kpack,
                                                        const float4 *g0, const float4 *g1, const float4 *g2, const float *gb0,
-                                                       const float *gb1, const float *gb2, int *__restrict__ range_flag, int B,
-                                                       int T, int R, int chunks_per_utt, int n_items, const int *__restrict__ lens, int kfmt)
+                                                       const float *gb1, const float *gb2, const int *__restrict__ range_flag, int B,
+                                                       int T, int R, int chunks_per_utt, int n_items, const int *__restrict__ lens)
 {
     __shared__ __attribute__((aligned(16))) char lds[2 * GX_BUFB];     // 2 x 36 KB
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -1098,7 +1030,6 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm_h2(const char *__restrict__ 
     float4 wq[2][12];
     f32x16 bias_lo;      // 2048 * bias of this lane's column in all 16 registers: the C operand of the first cross-term MFMA
     int have_blk = -1, have_xg = -1;
-    float mx = 0.0f;     // largest packed magnitude this thread produced
 #pragma unroll 1
     for (int i = 0; i < n_mine; i += 2) {
 #pragma unroll
@@ -1133,20 +1064,16 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm_h2(const char *__restrict__ 
             --left;
             const int Tb = frames_of(lens, cur.b, T);
             const bool full = (Tb % 32 == 0) || (cur.chunk * (GX_CT * 32) + GX_CT * 32 <= Tb);
-            // columns [0, KW) of blocks 1 and 2 are predicted kernels (0.4-scaled weights); the last 8 column tiles are the biases
-            const bool scaled = cur.blk >= 1 && (cur.xg * 4 + wave_u) * 32 < fd::KW;
-            const bool pack = scaled && kfmt == KFMT_PACKED, unscale = scaled && kfmt != KFMT_PACKED;
             if (half == 0) {
-                if (full) gx_item<0, true>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane, Tb, pack, unscale, mx GX_TIMING_PASS);
-                else gx_item<0, false>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane, Tb, pack, unscale, mx GX_TIMING_PASS);
+                if (full) gx_item<0, true>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane, Tb GX_TIMING_PASS);
+                else gx_item<0, false>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane, Tb GX_TIMING_PASS);
             } else {
-                if (full) gx_item<1, true>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane, Tb, pack, unscale, mx GX_TIMING_PASS);
-                else gx_item<1, false>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane, Tb, pack, unscale, mx GX_TIMING_PASS);
+                if (full) gx_item<1, true>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane, Tb GX_TIMING_PASS);
+                else gx_item<1, false>(lds, cur, more, nxt, hx, kpack, wq, bias_lo, aoff, B, T, R, wave_u, lane, Tb GX_TIMING_PASS);
             }
             cur = nxt;
         }
     }
-    if (!(mx < GX_LIMIT)) atomicOr(range_flag, 1);      // a packed kernel element did not fit fp16: the fp32 GEMM redoes the step
 #ifdef FD_GX_TIMING
     ph[6] = __builtin_amdgcn_s_memtime() - t_start;
     ph[7] = __builtin_amdgcn_s_memrealtime() - r_start;
@@ -1363,14 +1290,11 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
                                                       float *__restrict__ xout, const float *__restrict__ kpack, int layer,
                                                       const float *__restrict__ wpack, const float *__restrict__ wref,
                                                       const float *__restrict__ cbias, int T, const int *__restrict__ run_if,
-                                                      const int *__restrict__ lens, int kfmt, const int *__restrict__ kfmt_f32)
+                                                      const int *__restrict__ lens)
 {
     static_assert(HOP >= 64, "hop 8 has its own kernel (k_lvc_h8)");
     using Cfg = LvcCfg<HOP, DIL>;
-    if (run_if && *run_if == 0) return;      // fallback launch behind k_lvc_f16: only when that kernel flagged its operands
-    // KFMT_PACKED step whose fp16x2 layer could not run (x out of range): the record holds (h, l) pairs of 0.4 K -- decoded below;
-    // if the fp32 GEMM redid the step (kfmt_f32 set) it holds plain fp32 after all
-    const bool k_packed = kfmt == KFMT_PACKED && *kfmt_f32 == 0;
+    if (run_if && *run_if == 0) return;      // fallback launch behind k_lvc_h2: only when that kernel flagged its operands
     constexpr int WC = Cfg::WC, W = Cfg::W, H = Cfg::H, XLD = Cfg::XLD, YLD = Cfg::YLD, NT = WC / 32;
     // LVC work split (hop >= 64).  hop 256: the whole tile is ONE frame, so the waves split the 64 output rows instead of
     // re-loading the same kernel four times: wave = (row tile mt, column half), 4 column tiles each, 48 operand registers.
@@ -1408,17 +1332,6 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
                 for (int i = 0; i < 12; ++i) ka[m][i] = kp4[((mt0 + m) * 6 + (i >> 1)) * 128 + (i & 1)];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bz[m][j] = kb4[(mt0 + m) * 8 + 2 * j + hi];
-            }
-            if (k_packed) {      // cold path: K = 2.5 (h + 2^-11 l)
-                auto dec = [](float d) {
-                    const unsigned u = __float_as_uint(d);
-                    const h2_t p = __builtin_bit_cast(h2_t, u);
-                    return fmaf((float)p.y, GX_INV_SCALE, (float)p.x) * LVC_ACT_INV;
-                };
-#pragma unroll
-                for (int m = 0; m < LT; ++m)
-#pragma unroll
-                    for (int i = 0; i < 12; ++i) ka[m][i] = make_float4(dec(ka[m][i].x), dec(ka[m][i].y), dec(ka[m][i].z), dec(ka[m][i].w));
             }
         }
     }
@@ -1596,51 +1509,25 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
 // The same LVC layer on the fp16 matrix pipe (hop 64 and 256), 2-piece operands as in k_kp_gemm_h2:
 //   v = v1 + 2^-11 v2 (fp16 pieces, 22 bits);  A.B ~= A1.B1 + 2^-11 (A1.B2 + A2.B1), fp32 accumulation, the cross terms in
 //   their own accumulator.  Per 32x32 output tile and 96 k: 18 v_mfma_f32_32x32x16_f16 (576 cycles) instead of 48
-//   v_mfma_f32_32x32x2f32 (3072 cycles).
-// The SIMDs of a CU are issue-bound in this kernel (tools/ubench/lvc_h2_bench.hip: with three workgroups per CU every phase of a
-// wave takes 3/2 as long as with two), so what counts is the number and kind of instructions per wave:
-//   * KPRE: the predicted kernel arrives from the GEMM as (h, l) fp16 pairs of 0.4 K (KFMT_PACKED): no split and no range check
-//     here -- a lane turns 8 dwords into its A operand with 8 v_perm_b32 right before the MFMAs (no second register set either);
-//   * leaky_relu is one instruction (lrelu25 = 2.5 leaky_relu; the 0.4 sits in the conv weights and in the packed kernels);
-//   * activations are split with the mixed-precision FMA forms (5 instructions per pair).
+//   v_mfma_f32_32x32x2f32 (3072 cycles).  VALU pays for the splits (3 instructions per element with v_cvt_pk_f16_f32 and
+//   packed fp32 math): x' at staging, y after the conv, the predicted kernel after its load.
 // LDS images are [column][piece][32 channels] fp16, 128 B per column, 16 B slot s of row r stored at s ^ ((r >> 1) & 7):
 // a B operand (8 consecutive channels of one column) is one conflict-free ds_read_b128.
 // Operands of magnitude >= 32768 do not fit fp16: the kernel raises *range_flag and the fp32 kernel launched behind it
 // (k_lvc_layer with run_if) redoes the whole layer from the untouched inputs.
-// !KPRE (the record holds plain fp32 kernels: option gemm=fp32, or the naive GEMM stage): the kernel is scaled and split here.
 // =================================================================================================
 // FINAL (the last layer of the last block): the layer's output has one reader, final_conv (Conv1d 32 -> 1, k7).  Instead of writing
 // 32 channels for that kernel to read back, the workgroup applies the conv to its own 256 columns: every lane folds its 8 channels
-// into 7 per-tap partial sums per column, the four lane groups that share a column meet in LDS (the y image is dead by then), one
+// into 7 per-tap partial sums per column, the four lane groups that share a column meet in LDS (the x image is dead by then), one
 // thread per column adds them in a fixed order and stores the sum to eps_acc; the 3 + 3 columns at each tile edge get the missing
 // taps from the neighbour tile, both sides with one atomic add onto a zeroed word (two addends: the order cannot change the bits).
 // k_final_acc turns eps_acc (+ bias) into eps / the sampler update and leaves it zeroed.
-constexpr unsigned PERM_HI = 0x05040100u, PERM_LO = 0x07060302u;      // v_perm_b32 selectors: low / high halves of (S1, S0)
-
-// Build-time switches of the instruction diet (each can be turned off for an A/B in tools/ubench/lvc_h2_bench.hip):
-//   FD_LVC_LRELU25 (fd_internal.h)  the activation written to the images is lrelu25 (one instruction) and the 0.4 sits in the weights
-//   FD_LVC_MIXSPLIT                 activations are split with the v_fma_mix forms (split2m) instead of cvt / sub / mul / cvt
-#ifndef FD_LVC_MIXSPLIT
-#define FD_LVC_MIXSPLIT 1
-#endif
-__device__ __forceinline__ float act_in(float v) { return FD_LVC_LRELU25 ? lrelu25(v) : lrelu(v, 0.2f); }
-__device__ __forceinline__ void split2x(float a, float b, unsigned &hi, unsigned &lo)
-{
-    if (FD_LVC_MIXSPLIT) split2m(a, b, hi, lo);
-    else split2(a, b, hi, lo);
-}
-__device__ __forceinline__ void split8x(const float (&v)[8], float4 &hi, float4 &lo)
-{
-    if (FD_LVC_MIXSPLIT) split8m(v, hi, lo);
-    else split8(v, hi, lo);
-}
-
-template <int HOP, int DIL, bool FINAL, bool KPRE>
-__global__ void __launch_bounds__(256, 2) k_lvc_f16(const float *__restrict__ xin, const float *__restrict__ skip, float *__restrict__ xout,
-                                                    const float *__restrict__ kpack, int layer, const float4 *__restrict__ wpack16,
-                                                    const float *__restrict__ wref, const float *__restrict__ cbias,
-                                                    int *__restrict__ range_flag, const int *__restrict__ kfmt_f32, int T,
-                                                    const int *__restrict__ lens, float *__restrict__ eps_acc, const float4 *__restrict__ ffuse)
+template <int HOP, int DIL, bool FINAL>
+__global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin, const float *__restrict__ skip, float *__restrict__ xout,
+                                                   const float *__restrict__ kpack, int layer, const float4 *__restrict__ wpack16,
+                                                   const float *__restrict__ wref, const float *__restrict__ cbias,
+                                                   int *__restrict__ range_flag, int T, const int *__restrict__ lens,
+                                                   float *__restrict__ eps_acc, const float4 *__restrict__ ffuse)
 {
     static_assert(!FINAL || HOP == 256, "the fused final conv relies on whole-tile utterance lengths");
     constexpr int W = 256, WC = 64, H = (DIL + 1 + 3) & ~3, XC = W + 2 * H, YC = W + 2;
@@ -1659,21 +1546,12 @@ __global__ void __launch_bounds__(256, 2) k_lvc_f16(const float *__restrict__ xi
     const int b = blockIdx.y, w0 = tile * W;
     const int Lnb = frames_of(lens, b, T) * HOP;      // this utterance's own length (ragged batch): every bound below; Ln = row stride
     if (tile >= ntile || w0 >= Lnb || skip_after_previous_overflow(range_flag)) return;
-    if (KPRE && *kfmt_f32 != 0) {      // the fp32 GEMM redid this step: the record holds plain fp32 kernels, the fp32 layer behind us reads those
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicOr(range_flag, 1);
-        return;
-    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int cw = wave * WC;
     const bool wave_valid = (w0 + cw) < Lnb;
     const int mt0 = (HOP == 256) ? (wave & 1) : 0;
     const int lcw = (HOP == 256) ? 128 * (wave >> 1) : cw;     // first LVC column of this wave
     float mx = 0.0f;                                            // largest operand magnitude seen by this thread
-#ifdef FD_LVC_STAGGER      // experiment (tools/ubench/lvc_h2_bench.hip): the second workgroup of every CU starts half a lifetime late
-    if (blockIdx.y * gridDim.x + blockIdx.x < 512u && (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 1)) {
-        for (int k = 0; k < FD_LVC_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     FD_STAMP(0);
 
     float4 ka[LT][12];
@@ -1685,12 +1563,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_f16(const float *__restrict__ xi
             const float4 *kp4 = reinterpret_cast<const float4 *>(rec + layer * fd::KLAYER) + 2 * lane;
             const float4 *kb4 = reinterpret_cast<const float4 *>(rec + fd::KW + layer * 64);
 #pragma unroll
-            for (int i = 0; i < 12; ++i)
-#ifdef FD_LVC_NOLOAD
-                ka[m][i] = make_float4(__uint_as_float(0x00012C00u + lane), __uint_as_float(0x00022E00u + i), __uint_as_float(0x00013000u), __uint_as_float(0x0001B000u));
-#else
-                ka[m][i] = kp4[((mt0 + m) * 6 + (i >> 1)) * 128 + (i & 1)];
-#endif
+            for (int i = 0; i < 12; ++i) ka[m][i] = kp4[((mt0 + m) * 6 + (i >> 1)) * 128 + (i & 1)];
 #pragma unroll
             for (int j = 0; j < 4; ++j) bz[m][j] = kb4[(mt0 + m) * 8 + 2 * j + hi];
         }
@@ -1702,6 +1575,9 @@ __global__ void __launch_bounds__(256, 2) k_lvc_f16(const float *__restrict__ xi
     for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int kg = 0; kg < 6; ++kg) wa[p][kg] = wpack16[(p * 6 + kg) * 64 + lane];
+    float4 cb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cb[j] = reinterpret_cast<const float4 *>(cbias)[2 * j + hi];
 
     // ---- stage x + skip.  Centre: wave = channel group of 8, lane = 4 columns, so that one column of a thread is one 16 B
     //      slot per piece.  Halo (2H columns): wave = channel group, lane = one column.  Every wave does the same work. --------
@@ -1715,13 +1591,8 @@ __global__ void __launch_bounds__(256, 2) k_lvc_f16(const float *__restrict__ xi
         float hx[8], hs[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-#ifdef FD_LVC_NOLOAD      // experiment: the compute of the layer without its HBM reads
-            xa[c] = make_float4(0.001f * lane, 0.002f * c, 0.5f, -0.25f);
-            sa[c] = make_float4(0.003f * wave, 0.1f, -0.2f, 0.001f * lane);
-#else
             xa[c] = ok ? *reinterpret_cast<const float4 *>(xr + (int64_t)c * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
             sa[c] = ok ? *reinterpret_cast<const float4 *>(sr + (int64_t)c * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -1732,18 +1603,16 @@ __global__ void __launch_bounds__(256, 2) k_lvc_f16(const float *__restrict__ xi
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             xa[c] = make_float4(xa[c].x + sa[c].x, xa[c].y + sa[c].y, xa[c].z + sa[c].z, xa[c].w + sa[c].w);
+            mx = amax4(mx, xa[c]);
             *reinterpret_cast<float4 *>(ys + ((wave * 8 + c) * W + 4 * lane) * 4) = xa[c];      // the residual, parked
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float v[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] = act_in(f4c(xa[c], j));
-            // the range check looks at what is split: the ACTIVATED value (2.5 leaky_relu reaches the fp16 limit 2.5x earlier)
-            mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))),
-                                 fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7])))));
+            for (int c = 0; c < 8; ++c) v[c] = lrelu(f4c(xa[c], j), 0.2f);
             float4 ph, pl;
-            split8x(v, ph, pl);
+            split8(v, ph, pl);
             const int row = H + 4 * lane + j;
             *reinterpret_cast<float4 *>(xs + h2_off(row, wave)) = ph;
             *reinterpret_cast<float4 *>(xs + h2_off(row, 4 + wave)) = pl;
@@ -1753,11 +1622,11 @@ __global__ void __launch_bounds__(256, 2) k_lvc_f16(const float *__restrict__ xi
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const float t = hx[c] + hs[c];
-                v[c] = act_in(t);
-                mx = fmaxf(mx, fabsf(v[c]));
+                mx = fmaxf(mx, fabsf(t));
+                v[c] = lrelu(t, 0.2f);
             }
             float4 ph, pl;
-            split8x(v, ph, pl);
+            split8(v, ph, pl);
             const int row = (hc < H) ? hc : W + hc;
             *reinterpret_cast<float4 *>(xs + h2_off(row, wave)) = ph;
             *reinterpret_cast<float4 *>(xs + h2_off(row, 4 + wave)) = pl;
@@ -1782,9 +1651,6 @@ __global__ void __launch_bounds__(256, 2) k_lvc_f16(const float *__restrict__ xi
     }
     FD_STAMP(2);
 
-    float4 cb[4];      // conv bias of this lane's 16 output rows (L2; asked for here, not at the top: the registers are needed there)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) cb[j] = reinterpret_cast<const float4 *>(cbias)[2 * j + hi];
     // conv weights of the halo outputs (L2), requested ahead of the conv that hides their latency
     float4 hwt[6];
 #pragma unroll
@@ -1821,12 +1687,12 @@ __global__ void __launch_bounds__(256, 2) k_lvc_f16(const float *__restrict__ xi
                 float v[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    v[i] = inside ? act_in(fmaf(al[4 * j + i], GX_INV_SCALE, ah[4 * j + i])) : 0.0f;
+                    v[i] = inside ? lrelu(fmaf(al[4 * j + i], GX_INV_SCALE, ah[4 * j + i]), 0.2f) : 0.0f;
                     mx = fmaxf(mx, fabsf(v[i]));
                 }
                 uint2 ph, pl;
-                split2x(v[0], v[1], ph.x, pl.x);
-                split2x(v[2], v[3], ph.y, pl.y);
+                split2(v[0], v[1], ph.x, pl.x);
+                split2(v[2], v[3], ph.y, pl.y);
                 *reinterpret_cast<uint2 *>(ys + h2_off(yrow, j) + 8 * hi) = ph;
                 *reinterpret_cast<uint2 *>(ys + h2_off(yrow, 4 + j) + 8 * hi) = pl;
             }
@@ -1860,7 +1726,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_f16(const float *__restrict__ xi
         accv += __shfl_xor(accv, 1, 64);
         accv += __shfl_xor(accv, 2, 64);
         if (hq == 0) {
-            const float v = ok ? act_in(fmaf(accv, LVC_ACT_SCALE, hbias)) : 0.0f;      // (the image holds act_in(x): LVC_ACT_INV leaky_relu)
+            const float v = ok ? lrelu(accv + hbias, 0.2f) : 0.0f;
             mx = fmaxf(mx, fabsf(v));
             const _Float16 v1 = (_Float16)v, v2 = (_Float16)((v - (float)v1) * GX_SCALE);
             const int yrow = c + 1;
@@ -1874,19 +1740,16 @@ __global__ void __launch_bounds__(256, 2) k_lvc_f16(const float *__restrict__ xi
     if (wave_valid) {
         // ---- LVC: A = the frame's predicted kernel (rows gate-paired: register r <-> sigmoid input, r+8 <-> tanh input of
         //      channel 16*mt + drow(r), r < 8), split into pieces here ----------------------------------------------------
-        float4 kh[KPRE ? 1 : LT][KPRE ? 1 : 6], kl[KPRE ? 1 : LT][KPRE ? 1 : 6];
-        if constexpr (!KPRE) {      // plain fp32 kernels in the record: scaled and split here
+        float4 kh[LT][6], kl[LT][6];
 #pragma unroll
-            for (int m = 0; m < LT; ++m)
+        for (int m = 0; m < LT; ++m)
 #pragma unroll
-                for (int kg = 0; kg < 6; ++kg) {
-                    const float4 &a0 = ka[m][2 * kg], &a1 = ka[m][2 * kg + 1];
-                    mx = amax4(amax4(mx, a0), a1);
-                    const float v[8] = {a0.x * LVC_ACT_SCALE, a0.y * LVC_ACT_SCALE, a0.z * LVC_ACT_SCALE, a0.w * LVC_ACT_SCALE,
-                                        a1.x * LVC_ACT_SCALE, a1.y * LVC_ACT_SCALE, a1.z * LVC_ACT_SCALE, a1.w * LVC_ACT_SCALE};
-                    split8(v, kh[m][kg], kl[m][kg]);
-                }
-        }
+            for (int kg = 0; kg < 6; ++kg) {
+                const float4 &a0 = ka[m][2 * kg], &a1 = ka[m][2 * kg + 1];
+                mx = amax4(amax4(mx, a0), a1);
+                const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                split8(v, kh[m][kg], kl[m][kg]);
+            }
         int yo_[3][2][2];
 #pragma unroll
         for (int tap = 0; tap < 3; ++tap) {
@@ -1909,24 +1772,11 @@ __global__ void __launch_bounds__(256, 2) k_lvc_f16(const float *__restrict__ xi
                 for (int r = 0; r < 16; ++r) { ah[r] = f4c(bz[m][r >> 2], r & 3); al[r] = 0.0f; }
 #pragma unroll
                 for (int kg = 0; kg < 6; ++kg) {
-                    float4 a1, a2;
-                    if constexpr (KPRE) {      // 8 dwords (h | l << 16) -> the 8 hi halves and the 8 lo halves: 8 v_perm_b32
-                        const float4 &d0 = ka[m][2 * kg], &d1 = ka[m][2 * kg + 1];
-                        const unsigned u[8] = {__float_as_uint(d0.x), __float_as_uint(d0.y), __float_as_uint(d0.z), __float_as_uint(d0.w),
-                                               __float_as_uint(d1.x), __float_as_uint(d1.y), __float_as_uint(d1.z), __float_as_uint(d1.w)};
-                        a1 = make_float4(__uint_as_float(__builtin_amdgcn_perm(u[1], u[0], PERM_HI)), __uint_as_float(__builtin_amdgcn_perm(u[3], u[2], PERM_HI)),
-                                         __uint_as_float(__builtin_amdgcn_perm(u[5], u[4], PERM_HI)), __uint_as_float(__builtin_amdgcn_perm(u[7], u[6], PERM_HI)));
-                        a2 = make_float4(__uint_as_float(__builtin_amdgcn_perm(u[1], u[0], PERM_LO)), __uint_as_float(__builtin_amdgcn_perm(u[3], u[2], PERM_LO)),
-                                         __uint_as_float(__builtin_amdgcn_perm(u[5], u[4], PERM_LO)), __uint_as_float(__builtin_amdgcn_perm(u[7], u[6], PERM_LO)));
-                    } else {
-                        a1 = kh[m][kg];
-                        a2 = kl[m][kg];
-                    }
                     const float4 b1 = *reinterpret_cast<const float4 *>(ys + yo_[kg >> 1][0][kg & 1] + nt * 32 * 128);
                     const float4 b2 = *reinterpret_cast<const float4 *>(ys + yo_[kg >> 1][1][kg & 1] + nt * 32 * 128);
-                    ah = mfma_f16(a1, b1, ah);
-                    al = mfma_f16(a1, b2, al);
-                    al = mfma_f16(a2, b1, al);
+                    ah = mfma_f16(kh[m][kg], b1, ah);
+                    al = mfma_f16(kh[m][kg], b2, al);
+                    al = mfma_f16(kl[m][kg], b1, al);
                 }
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
@@ -1985,302 +1835,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_f16(const float *__restrict__ xi
     FD_STAMP(7);
 }
 
-// =================================================================================================
-// The same layer with EIGHT waves per workgroup (KFMT_PACKED records only).  A wave issues one VALU instruction per ~5 cycles however
-// many of them are independent (tools/ubench/valu_rate_probe.hip), so what a workgroup's compute costs in time is the length of ONE
-// wave's instruction stream: with the tile's work spread over eight waves instead of four that stream is half as long, and a SIMD
-// interleaves four waves instead of two.  Same tile (256 columns), same LDS images, same arithmetic as k_lvc_f16<.., KPRE = true>
-// (only the two halo columns are summed by 8 instead of 4 threads).  128 registers per lane:
-//   staging   wave = 4 channels, lane = 4 columns (8 loads of 16 B);
-//   conv      wave = one 32-column tile, A (the layer's 0.4 w pieces) in 48 registers;
-//   LVC       wave = (row tile, 64-column quarter) for hop 256, (row tile, frame) for hop 64: one predicted row tile in 48 registers
-//             (requested after the conv, its 128 B lines touched at the start so that it comes out of L2), two column tiles.
-// =================================================================================================
-template <int HOP, int DIL, bool FINAL>
-__global__ void __launch_bounds__(512, 4) k_lvc_w8(const float *__restrict__ xin, const float *__restrict__ skip, float *__restrict__ xout,
-                                                   const float *__restrict__ kpack, int layer, const float4 *__restrict__ wpack16,
-                                                   const float *__restrict__ wref, const float *__restrict__ cbias,
-                                                   int *__restrict__ range_flag, const int *__restrict__ kfmt_f32, int T,
-                                                   const int *__restrict__ lens, float *__restrict__ eps_acc, const float4 *__restrict__ ffuse)
-{
-    static_assert(!FINAL || HOP == 256, "the fused final conv relies on whole-tile utterance lengths");
-    constexpr int W = 256, H = (DIL + 1 + 3) & ~3, XC = W + 2 * H, YC = W + 2;
-    static_assert(2 * H <= 64, "one halo column per lane");
-    __shared__ __attribute__((aligned(16))) char xs[XC * 128];       // act(x + skip) pieces, row = column + H
-    __shared__ __attribute__((aligned(16))) char ys[YC * 128];       // first the raw x + skip of the centre (fp32 [32][256]), then
-    static_assert(YC * 128 >= fd::C * W * 4, "parking area");        // the conv output pieces, row = column + 1
-    __shared__ __attribute__((aligned(16))) float bzs[(W / HOP) * 64];   // the predicted biases of the tile's frames
-    const int Ln = T * HOP;
-    const int ntile = (T * HOP + W - 1) / W, tile = blockIdx.x;
-    const int b = blockIdx.y, w0 = tile * W;
-    const int Lnb = frames_of(lens, b, T) * HOP;
-    if (tile >= ntile || w0 >= Lnb || skip_after_previous_overflow(range_flag)) return;
-    if (*kfmt_f32 != 0) {      // the fp32 GEMM redid this step: the record holds plain fp32 kernels, the fp32 layer behind us reads those
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicOr(range_flag, 1);
-        return;
-    }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-    const int cw = wave * 32;                                   // this wave's conv columns
-    const bool conv_valid = (w0 + cw) < Lnb;                    // (Lnb is a multiple of 64)
-    const int mt0 = wave & 1, lcw = 64 * (wave >> 1);           // this wave's LVC row tile and first column
-    const bool lvc_valid = (w0 + lcw) < Lnb;
-    float mx = 0.0f;
-    // one dword of each 128 B line of this wave's row tile of the frame's kernel (96 lines): pulls it from HBM into L2 now
-    unsigned ktouch = 0u;
-    const float *krec = kpack + ((int64_t)b * T + (w0 + lcw) / HOP) * fd::KREC;
-    if (lvc_valid) {
-        const unsigned *kt = reinterpret_cast<const unsigned *>(krec + layer * fd::KLAYER) + mt0 * 3072;
-        ktouch = kt[lane * 32] | kt[(64 + l31) * 32];
-    }
-    // the predicted biases of the tile's frames (64 per frame) travel through LDS: thread = (frame of the tile, output row)
-    float bzv = 0.0f;
-    if (tid < (W / HOP) * 64) {
-        const int f = w0 / HOP + (tid >> 6);
-        if (f < frames_of(lens, b, T)) bzv = kpack[((int64_t)b * T + f) * fd::KREC + fd::KW + layer * 64 + (tid & 63)];
-    }
-
-    // ---- stage x + skip.  Centre: wave = channel quad, lane = 4 columns: one column of a thread is HALF a 16 B slot per piece.
-    //      Halo (2H columns): wave = channel quad, lane = one column. ---------------------------------------------------------
-    {
-        const float *xr = xin + ((int64_t)b * fd::C + wave * 4) * Ln, *sr = skip + ((int64_t)b * fd::C + wave * 4) * Ln;
-        const int g = w0 + 4 * lane;
-        const bool ok = g < Lnb;
-        const int hc = lane, hg = (hc < H) ? w0 - H + hc : w0 + W + hc - H;
-        const bool hok = hc < 2 * H && hg >= 0 && hg < Lnb;
-        float4 xa[4], sa[4];
-        float hx[4], hs[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            xa[c] = ok ? *reinterpret_cast<const float4 *>(xr + (int64_t)c * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
-            sa[c] = ok ? *reinterpret_cast<const float4 *>(sr + (int64_t)c * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            hx[c] = hok ? xr[(int64_t)c * Ln + hg] : 0.0f;
-            hs[c] = hok ? sr[(int64_t)c * Ln + hg] : 0.0f;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            xa[c] = make_float4(xa[c].x + sa[c].x, xa[c].y + sa[c].y, xa[c].z + sa[c].z, xa[c].w + sa[c].w);
-            *reinterpret_cast<float4 *>(ys + ((wave * 4 + c) * W + 4 * lane) * 4) = xa[c];      // the residual, parked
-        }
-        if (tid < (W / HOP) * 64) bzs[tid] = bzv;
-        const int slot = wave >> 1, half = (wave & 1) * 8;       // channels 4 wave .. 4 wave + 3 = half of slot wave / 2
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float v[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { v[c] = act_in(f4c(xa[c], j)); mx = fmaxf(mx, fabsf(v[c])); }
-            uint2 ph, pl;
-            split2x(v[0], v[1], ph.x, pl.x);
-            split2x(v[2], v[3], ph.y, pl.y);
-            const int row = H + 4 * lane + j;
-            *reinterpret_cast<uint2 *>(xs + h2_off(row, slot) + half) = ph;
-            *reinterpret_cast<uint2 *>(xs + h2_off(row, 4 + slot) + half) = pl;
-        }
-        if (hc < 2 * H) {
-            float v[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { v[c] = act_in(hx[c] + hs[c]); mx = fmaxf(mx, fabsf(v[c])); }
-            uint2 ph, pl;
-            split2x(v[0], v[1], ph.x, pl.x);
-            split2x(v[2], v[3], ph.y, pl.y);
-            const int row = (hc < H) ? hc : W + hc;
-            *reinterpret_cast<uint2 *>(xs + h2_off(row, slot) + half) = ph;
-            *reinterpret_cast<uint2 *>(xs + h2_off(row, 4 + slot) + half) = pl;
-        }
-    }
-    __syncthreads();
-    // residual values of this lane's outputs: registers, so that ys can take the conv output
-    float resid[2][8];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-            resid[nt][r] = reinterpret_cast<const float *>(ys)[(16 * mt0 + (r & 3) + 8 * (r >> 2) + 4 * hi) * W + lcw + nt * 32 + l31];
-    __syncthreads();
-
-    // ---- dilated conv of this wave's 32 columns on the fp16 pipe; y = act(conv) is split again into the B image of the LVC ------
-    if (conv_valid) {
-        // conv weights: A operand pieces [piece][kg][lane] x 8 fp16 (0.4 w, L2), k = 16*kg + 8*hi + e = tap*32 + in
-        float4 wa[2][6];
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int kg = 0; kg < 6; ++kg) wa[p][kg] = wpack16[(p * 6 + kg) * 64 + lane];
-        float4 cb[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) cb[j] = reinterpret_cast<const float4 *>(cbias)[2 * j + hi];
-        f32x16 ah, al;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { ah[r] = f4c(cb[r >> 2], r & 3); al[r] = 0.0f; }
-#pragma unroll
-        for (int kg = 0; kg < 6; ++kg) {
-            const int row = H + cw + l31 + ((kg >> 1) - 1) * DIL;
-            const float4 b1 = *reinterpret_cast<const float4 *>(xs + h2_off(row, (kg & 1) * 2 + hi));
-            const float4 b2 = *reinterpret_cast<const float4 *>(xs + h2_off(row, 4 + (kg & 1) * 2 + hi));
-            ah = mfma_f16(wa[0][kg], b1, ah);
-            al = mfma_f16(wa[0][kg], b2, al);
-            al = mfma_f16(wa[1][kg], b1, al);
-        }
-        const int cp = cw + l31, yrow = cp + 1;
-        const bool inside = (w0 + cp) < Lnb;                  // y is zero-padded for the LVC taps (modules.py:240)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {                         // D rows 8j + 4hi + {0..3}: half a slot
-            float v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[i] = inside ? act_in(fmaf(al[4 * j + i], GX_INV_SCALE, ah[4 * j + i])) : 0.0f;
-                mx = fmaxf(mx, fabsf(v[i]));
-            }
-            uint2 ph, pl;
-            split2x(v[0], v[1], ph.x, pl.x);
-            split2x(v[2], v[3], ph.y, pl.y);
-            *reinterpret_cast<uint2 *>(ys + h2_off(yrow, j) + 8 * hi) = ph;
-            *reinterpret_cast<uint2 *>(ys + h2_off(yrow, 4 + j) + 8 * hi) = pl;
-        }
-    } else {
-        // a wave past the end of the signal still owns y columns its left neighbour's taps read: they are zero padding
-        if (lane < 32) {
-#pragma unroll
-            for (int s8 = 0; s8 < 8; ++s8) *reinterpret_cast<float4 *>(ys + (cw + 1 + lane) * 128 + s8 * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-    // ---- the frame's predicted kernel: one row tile, (h | l << 16) dwords; lands under the halo columns and the barrier ----------
-    float4 ka[12];
-    if (lvc_valid) {
-        const float4 *kp4 = reinterpret_cast<const float4 *>(krec + layer * fd::KLAYER) + 2 * lane;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) ka[i] = kp4[(mt0 * 6 + (i >> 1)) * 128 + (i & 1)];
-    }
-    // ---- the two halo columns (-1 and W) the LVC taps reach: VALU on the reassembled x image, 8 threads per output ----------
-    {
-        const int hside = tid >> 8, ho = (tid & 255) >> 3, he = tid & 7;      // he: input channels 4 he .. 4 he + 3
-        const float4 *hw4 = reinterpret_cast<const float4 *>(wref + (ho * fd::C + 4 * he) * 3);
-        const float4 w0_ = hw4[0], w1_ = hw4[1], w2_ = hw4[2];
-        const float wv[12] = {w0_.x, w0_.y, w0_.z, w0_.w, w1_.x, w1_.y, w1_.z, w1_.w, w2_.x, w2_.y, w2_.z, w2_.w};      // [ci][tap]
-        const float hbias = cbias[ho];
-        const int c = hside ? W : -1, g = w0 + c;
-        const bool ok = g >= 0 && g < Lnb;
-        float accv = 0.0f;
-        if (ok) {
-#pragma unroll
-            for (int tap = 0; tap < 3; ++tap) {
-                const int row = H + c + (tap - 1) * DIL;
-                union { uint2 u; _Float16 h[4]; } p1, p2;
-                p1.u = *reinterpret_cast<const uint2 *>(xs + h2_off(row, he >> 1) + (he & 1) * 8);
-                p2.u = *reinterpret_cast<const uint2 *>(xs + h2_off(row, 4 + (he >> 1)) + (he & 1) * 8);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) accv += wv[j * 3 + tap] * fmaf((float)p2.h[j], GX_INV_SCALE, (float)p1.h[j]);
-            }
-        }
-        accv += __shfl_xor(accv, 1, 64);
-        accv += __shfl_xor(accv, 2, 64);
-        accv += __shfl_xor(accv, 4, 64);
-        if (he == 0) {
-            const float v = ok ? act_in(fmaf(accv, LVC_ACT_SCALE, hbias)) : 0.0f;
-            mx = fmaxf(mx, fabsf(v));
-            const _Float16 v1 = (_Float16)v, v2 = (_Float16)((v - (float)v1) * GX_SCALE);
-            const int yrow = c + 1;
-            *reinterpret_cast<_Float16 *>(ys + h2_off(yrow, ho >> 3) + (ho & 7) * 2) = v1;
-            *reinterpret_cast<_Float16 *>(ys + h2_off(yrow, 4 + (ho >> 3)) + (ho & 7) * 2) = v2;
-        }
-    }
-    __syncthreads();
-    if (lvc_valid) {
-        // ---- LVC: A = the frame's predicted kernel (rows gate-paired: register r <-> sigmoid input, r+8 <-> tanh input of
-        //      channel 16*mt + drow(r), r < 8) -----------------------------------------------------------------------------------
-        float *xo = xout + (int64_t)b * fd::C * Ln + (int64_t)(4 * hi) * Ln + w0 + lcw + l31;      // + channel*Ln + nt*32
-        const unsigned Lnu = (unsigned)Ln;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            f32x16 ah, al;
-            {      // D rows of a lane are {0..3, 8..11, 16..19, 24..27} + 4*hi of the row tile
-                const float4 *bz4 = reinterpret_cast<const float4 *>(bzs) + ((lcw + nt * 32) / HOP) * 16 + mt0 * 8 + hi;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 bj = bz4[2 * j];
-                    ah[4 * j] = bj.x; ah[4 * j + 1] = bj.y; ah[4 * j + 2] = bj.z; ah[4 * j + 3] = bj.w;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) al[r] = 0.0f;
-#pragma unroll
-            for (int kg = 0; kg < 6; ++kg) {
-                const float4 &d0 = ka[2 * kg], &d1 = ka[2 * kg + 1];      // 8 dwords (h | l << 16) -> the 8 hi halves and the 8 lo halves
-                const unsigned u[8] = {__float_as_uint(d0.x), __float_as_uint(d0.y), __float_as_uint(d0.z), __float_as_uint(d0.w),
-                                       __float_as_uint(d1.x), __float_as_uint(d1.y), __float_as_uint(d1.z), __float_as_uint(d1.w)};
-                const float4 a1 = make_float4(__uint_as_float(__builtin_amdgcn_perm(u[1], u[0], PERM_HI)), __uint_as_float(__builtin_amdgcn_perm(u[3], u[2], PERM_HI)),
-                                              __uint_as_float(__builtin_amdgcn_perm(u[5], u[4], PERM_HI)), __uint_as_float(__builtin_amdgcn_perm(u[7], u[6], PERM_HI)));
-                const float4 a2 = make_float4(__uint_as_float(__builtin_amdgcn_perm(u[1], u[0], PERM_LO)), __uint_as_float(__builtin_amdgcn_perm(u[3], u[2], PERM_LO)),
-                                              __uint_as_float(__builtin_amdgcn_perm(u[5], u[4], PERM_LO)), __uint_as_float(__builtin_amdgcn_perm(u[7], u[6], PERM_LO)));
-                const int row = lcw + nt * 32 + l31 + (kg >> 1);           // y row = column + 1 + (tap - 1)
-                const float4 b1 = *reinterpret_cast<const float4 *>(ys + h2_off(row, (kg & 1) * 2 + hi));
-                const float4 b2 = *reinterpret_cast<const float4 *>(ys + h2_off(row, 4 + (kg & 1) * 2 + hi));
-                ah = mfma_f16(a1, b1, ah);
-                al = mfma_f16(a1, b2, al);
-                al = mfma_f16(a2, b1, al);
-                __builtin_amdgcn_sched_barrier(0);      // 128 registers: keep the operand fetches of later steps from piling up here
-            }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int chl = 16 * mt0 + (r & 3) + 8 * (r >> 2);     // channel minus 4*hi
-                const float zs = fmaf(al[r], GX_INV_SCALE, ah[r]), zt = fmaf(al[r + 8], GX_INV_SCALE, ah[r + 8]);
-                if constexpr (FINAL) resid[nt][r] += gate(zs, zt);
-                else xo[(unsigned)chl * Lnu + (unsigned)(nt * 32)] = resid[nt][r] + gate(zs, zt);
-            }
-        }
-    }
-    if constexpr (FINAL) {
-        // hop 256: utterance lengths are whole tiles, so every wave of a live workgroup is valid and reaches the barrier
-        float *pb = reinterpret_cast<float *>(xs);                   // [part = 2 mt + hi][7 taps][256 columns]; the x image is dead
-        {
-            const int part = 2 * mt0 + hi;
-            float fw[8][8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const float4 lo4 = ffuse[(part * 8 + r) * 2], hi4 = ffuse[(part * 8 + r) * 2 + 1];
-                fw[r][0] = lo4.x; fw[r][1] = lo4.y; fw[r][2] = lo4.z; fw[r][3] = lo4.w; fw[r][4] = hi4.x; fw[r][5] = hi4.y; fw[r][6] = hi4.z;
-            }
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int k = 0; k < 7; ++k) {
-                    float pk = 0.0f;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) pk = fmaf(fw[r][k], resid[nt][r], pk);
-                    pb[(part * 7 + k) * W + lcw + nt * 32 + l31] = pk;
-                }
-        }
-        __syncthreads();
-        auto column_sum = [&](int t) {      // eps[t] = sum_k w[k] . out[t + k - 3], restricted to this tile's columns
-            float e = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                const int col = t + k - 3;
-                if (col >= 0 && col < W) {
-#pragma unroll
-                    for (int part = 0; part < 4; ++part) e += pb[(part * 7 + k) * W + col];
-                }
-            }
-            return e;
-        };
-        float *ea = eps_acc + (int64_t)b * Ln + w0;
-        if (tid < W) {
-            const float e = column_sum(tid);
-            if (tid >= 3 && tid < W - 3) ea[tid] = e;
-            else atomicAdd(ea + tid, e);
-        } else if (tid < W + 6) {            // the taps of the neighbour tiles' edge columns that fall on this tile
-            const int j = tid - W, t = j < 3 ? j - 3 : W + j - 3;
-            if (w0 + t >= 0 && w0 + t < Lnb) atomicAdd(ea + t, column_sum(t));
-        }
-    }
-    if (!(mx < GX_LIMIT)) atomicOr(range_flag, 1);      // also inf; a NaN operand gives a NaN result on either path
-    if (ktouch == 0x7FC01234u) atomicOr(range_flag, 0);   // keeps the touch loads alive; changes nothing
-}
-
-// eps_acc (the final_conv sums of k_lvc_f16<..., FINAL>) -> eps = sum + bias -> eps_out or the reverse-step update; eps_acc is left
+// eps_acc (the final_conv sums of k_lvc_h2<..., FINAL>) -> eps = sum + bias -> eps_out or the reverse-step update; eps_acc is left
 // zeroed for the next step.  If that LVC launch flagged its operands the sums are meaningless: they are only cleared here, and the
 // plain k_final behind this launch (run_if) redoes the conv from the fp32 kernel's output.
 __global__ void __launch_bounds__(256) k_final_acc(float *__restrict__ eps_acc, const float *__restrict__ bias, float *__restrict__ eps_out,
@@ -2579,16 +2134,15 @@ hipError_t fast_kp_gemm(const Launch &L, int B, int T)
                       reinterpret_cast<unsigned *>(c->ws.h_f16), c->ws.range_flag, B, T, R, c->step_lens);
         FD_LAUNCH(L, "kp_gemm_f16x2", k_kp_gemm_h2, dim3(grid2), dim3(256), 0, reinterpret_cast<const char *>(c->ws.h_f16), c->ws.kpack,
                   reinterpret_cast<const float4 *>(w.gemm_h2_pack[0]), reinterpret_cast<const float4 *>(w.gemm_h2_pack[1]),
-                  reinterpret_cast<const float4 *>(w.gemm_h2_pack[2]), w.gemm_bias_h2[0], w.gemm_bias_h2[1], w.gemm_bias_h2[2],
-                  c->ws.range_flag, B, T, R, chunks, items, c->step_lens, c->kfmt);
+                  reinterpret_cast<const float4 *>(w.gemm_h2_pack[2]), w.gemm_bias[0], w.gemm_bias[1], w.gemm_bias[2],
+                  (const int *)c->ws.range_flag, B, T, R, chunks, items, c->step_lens);
         if (pipe == PIPE_F16_ONLY) return hipSuccess;
     }
     // fp32 matrix pipe: the whole job when the fp16 form is off, otherwise an early-exit launch that only works when
     // k_h_split found operands outside the fp16 range
     FD_LAUNCH(L, f16 ? "kp_gemm_fp32_fallback" : "kp_gemm", k_kp_gemm, dim3(grid), dim3(256), 0, (const float *)c->ws.kp_hB, c->ws.kpack,
               w.gemm_pack[0], w.gemm_pack[1], w.gemm_pack[2], w.gemm_bias[0], w.gemm_bias[1], w.gemm_bias[2], B, T, chunks_per_utt,
-              chunk_tiles, n_items, f16 ? (const int *)c->ws.range_flag : (const int *)nullptr, c->step_lens,
-              (f16 && c->kfmt == KFMT_PACKED) ? c->ws.range_flag + FLAG_KFMT_F32 : (int *)nullptr);
+              chunk_tiles, n_items, f16 ? (const int *)c->ws.range_flag : (const int *)nullptr, c->step_lens);
     return hipSuccess;
 }
 
@@ -2627,40 +2181,31 @@ static hipError_t launch_lvc(const Launch &L, const char *name, int n, int layer
     const int Ln = T * HOP;
     const float *kp = c->ws.kpack + (int64_t)n * B * T * fd::KREC;
     const int *run_if = nullptr;
-    const int *kf = c->ws.range_flag + FLAG_KFMT_F32;
     if constexpr (HOP == 256 && DIL == 27) c->final_fused = false;
     if constexpr (HOP >= 64) {
         const Pipe pipe = fd_pipe(c, c->lvc_f16 && w.lvc_f16_ok, 1 + n * fd::LAYERS + layer);
         if (pipe != PIPE_F32_ONLY) {
             int *flag = c->ws.range_flag + 1 + n * fd::LAYERS + layer;
-            const dim3 grid(((Ln + 255) / 256 + 7) / 8 * 8, B);
-            const float4 *wp = reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]);
-            const float *wr = w.blk[n].convs[layer].w, *cb = w.blk[n].convs[layer].b;
-            const bool kpre = c->kfmt == KFMT_PACKED;
             // the last layer of the last block feeds final_conv only: fused unless someone wants to look at the block output
             c->final_fused = false;
             if constexpr (HOP == 256 && DIL == 27) c->final_fused = c->fast[ST_FINAL] && !c->keep_taps && c->fuse_final;
-            const bool w8 = kpre && c->lvc_w8;      // eight waves per workgroup (KFMT_PACKED records only)
             if constexpr (HOP == 256 && DIL == 27) {
-                if (c->final_fused) {
-                    const float4 *ff = reinterpret_cast<const float4 *>(w.final_fuse);
-                    if (w8) FD_LAUNCH(L, name, (k_lvc_w8<HOP, DIL, true>), grid, dim3(512), 0, x_in, skip, x_out, kp, layer, wp, wr, cb, flag, kf, T, c->step_lens, c->ws.eps_acc, ff);
-                    else if (kpre) FD_LAUNCH(L, name, (k_lvc_f16<HOP, DIL, true, true>), grid, dim3(256), 0, x_in, skip, x_out, kp, layer, wp, wr, cb, flag, kf, T, c->step_lens, c->ws.eps_acc, ff);
-                    else FD_LAUNCH(L, name, (k_lvc_f16<HOP, DIL, true, false>), grid, dim3(256), 0, x_in, skip, x_out, kp, layer, wp, wr, cb, flag, kf, T, c->step_lens, c->ws.eps_acc, ff);
-                }
+                if (c->final_fused)
+                    FD_LAUNCH(L, name, (k_lvc_h2<HOP, DIL, true>), dim3(((Ln + 255) / 256 + 7) / 8 * 8, B), dim3(256), 0, x_in, skip, x_out, kp,
+                              layer, reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]), w.blk[n].convs[layer].w,
+                              w.blk[n].convs[layer].b, flag, T, c->step_lens, c->ws.eps_acc, reinterpret_cast<const float4 *>(w.final_fuse));
             }
-            if (!c->final_fused) {
-                if (w8) FD_LAUNCH(L, name, (k_lvc_w8<HOP, DIL, false>), grid, dim3(512), 0, x_in, skip, x_out, kp, layer, wp, wr, cb, flag, kf, T, c->step_lens, (float *)nullptr, (const float4 *)nullptr);
-                else if (kpre) FD_LAUNCH(L, name, (k_lvc_f16<HOP, DIL, false, true>), grid, dim3(256), 0, x_in, skip, x_out, kp, layer, wp, wr, cb, flag, kf, T, c->step_lens, (float *)nullptr, (const float4 *)nullptr);
-                else FD_LAUNCH(L, name, (k_lvc_f16<HOP, DIL, false, false>), grid, dim3(256), 0, x_in, skip, x_out, kp, layer, wp, wr, cb, flag, kf, T, c->step_lens, (float *)nullptr, (const float4 *)nullptr);
-            }
+            if (!c->final_fused)
+                FD_LAUNCH(L, name, (k_lvc_h2<HOP, DIL, false>), dim3(((Ln + 255) / 256 + 7) / 8 * 8, B), dim3(256), 0, x_in, skip, x_out, kp,
+                          layer, reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]), w.blk[n].convs[layer].w,
+                          w.blk[n].convs[layer].b, flag, T, c->step_lens, (float *)nullptr, (const float4 *)nullptr);
             run_if = flag;
             name = "lvc_fp32_fallback";
             if (pipe == PIPE_F16_ONLY) return hipSuccess;
         }
     }
     FD_LAUNCH(L, name, (k_lvc_layer<HOP, DIL>), dim3((Ln + W - 1) / W, B), dim3(256), 0, x_in, skip, x_out, kp, layer,
-              w.lvc_conv_pack[n][layer], w.blk[n].convs[layer].w, w.blk[n].convs[layer].b, T, run_if, c->step_lens, c->kfmt, kf);
+              w.lvc_conv_pack[n][layer], w.blk[n].convs[layer].w, w.blk[n].convs[layer].b, T, run_if, c->step_lens);
     return hipSuccess;
 }
 

@@ -1,0 +1,81 @@
+"""The location-variable convolution as a differentiable operator on the MI355X.
+
+`location_variable_convolution(x, kernel, bias, dilation, hop_size)` has the signature, tensor layouts and assert of
+`TimeAware_LVCBlock.location_variable_convolution` (modules/FastDiff/module/modules.py:220-253); forward and backward run as HIP
+kernels behind the C ABI (fd_lvc_forward / fd_lvc_backward, include/fastdiff_hip.h), everything around it stays on PyTorch autograd.
+Binding it in the reference is one line:
+
+    TimeAware_LVCBlock.location_variable_convolution = lambda self, x, k, b, d, h: fastdiff_amd.location_variable_convolution(x, k, b, d, h)
+
+which puts the twelve LVC calls of every training forward/backward (theta_timestep_loss, util.py:291-325) on these kernels.
+There is no CPU path: CPU tensors raise.
+"""
+import ctypes as ct
+
+import torch
+
+from . import _capi
+
+_handles = {}
+
+
+def _handle(device):
+    """One library handle per device: the operator is stateless, the handle supplies the device and the error text."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _handles:
+        lib = _capi.load()
+        cfg = _capi.FdConfig()
+        lib.fd_default_config(ct.byref(cfg))
+        h = ct.c_void_p()
+        _capi.check(lib, None, lib.fd_create(ct.byref(cfg), idx, ct.byref(h)), "fd_create")
+        _handles[idx] = h
+    return _capi.load(), _handles[idx]
+
+
+def _stream(device):
+    return ct.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _LVC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kernel, bias, hop_size):
+        if not (x.is_cuda and kernel.is_cuda and bias.is_cuda):
+            raise RuntimeError("fastdiff_amd.location_variable_convolution runs only on a HIP device (no CPU fallback)")
+        x, kernel, bias = x.contiguous().float(), kernel.contiguous().float(), bias.contiguous().float()
+        B, Cin, L = x.shape
+        _, _, Cout, ks, T = kernel.shape
+        out = torch.empty((B, Cout, L), device=x.device, dtype=torch.float32)
+        lib, h = _handle(x.device)
+        _capi.check(lib, h, lib.fd_lvc_forward(h, x.data_ptr(), kernel.data_ptr(), bias.data_ptr(), B, Cin, Cout, ks, T, int(hop_size),
+                                               out.data_ptr(), _stream(x.device)), "fd_lvc_forward")
+        ctx.save_for_backward(x, kernel)
+        ctx.hop = int(hop_size)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, kernel = ctx.saved_tensors
+        dout = dout.contiguous().float()
+        B, Cin, L = x.shape
+        _, _, Cout, ks, T = kernel.shape
+        need_x, need_k, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        dx = torch.empty_like(x) if need_x else None
+        dk = torch.empty_like(kernel) if need_k else None
+        db = torch.empty((B, Cout, T), device=x.device, dtype=torch.float32) if need_b else None
+        lib, h = _handle(x.device)
+        _capi.check(lib, h, lib.fd_lvc_backward(h, x.data_ptr(), kernel.data_ptr(), dout.data_ptr(), B, Cin, Cout, ks, T, ctx.hop,
+                                                None if dx is None else dx.data_ptr(), None if dk is None else dk.data_ptr(),
+                                                None if db is None else db.data_ptr(), _stream(x.device)), "fd_lvc_backward")
+        return dx, dk, db, None
+
+
+def location_variable_convolution(x, kernel, bias, dilation=1, hop_size=256):
+    """(batch, in_channels, in_length), (batch, in_channels, out_channels, kernel_size, kernel_length), (batch, out_channels,
+    kernel_length) -> (batch, out_channels, in_length); same assert as the reference (modules.py:236).  dilation must be 1: it is
+    the only value the model ever passes (modules.py:216)."""
+    batch, in_channels, in_length = x.shape
+    batch, in_channels, out_channels, kernel_size, kernel_length = kernel.shape
+    assert in_length == (kernel_length * hop_size), "length of (x, kernel) is not matched"
+    if dilation != 1:
+        raise NotImplementedError("location_variable_convolution: the HIP operator implements dilation = 1 (modules.py:216)")
+    return _LVC.apply(x, kernel, bias, hop_size)

@@ -140,6 +140,18 @@ FD_API int fd_peak_normalize_int16(fd_handle h, const float *wav, int B, int64_t
 FD_API int fd_peak_normalize_int16_ragged(fd_handle h, const float *wav, int B, int64_t L, const int64_t *valid, int16_t *pcm,
                                           void *stream);
 
+/* Training side: TimeAware_LVCBlock.location_variable_convolution (modules/FastDiff/module/modules.py:220-253,
+ * dilation = 1 as at its only call site, modules.py:216) as a differentiable operator in the reference's own tensor layouts, so that
+ * theta_timestep_loss (util.py:291-325) can differentiate through it while the rest of the module stays on PyTorch autograd:
+ *   out[b,o,q] = bias[b,o,q/hop] + sum_{i,k} xpad[b,i,q+k-(ks-1)/2] * kernel[b,i,o,k,q/hop]
+ *   x [B,Cin,T*hop]   kernel [B,Cin,Cout,ks,T]   bias [B,Cout,T]   out, dout [B,Cout,T*hop]      (all device, float32, contiguous)
+ * fd_lvc_backward writes the gradients whose pointer is not NULL: dx (needs kernel), dkernel and dbias (need x).
+ * Any handle of the device will do (it supplies the device and the error text); Cin*Cout*ks <= 8192, ks odd. */
+FD_API int fd_lvc_forward(fd_handle h, const float *x, const float *kernel, const float *bias, int B, int Cin, int Cout, int ks, int T,
+                          int hop, float *out, void *stream);
+FD_API int fd_lvc_backward(fd_handle h, const float *x, const float *kernel, const float *dout, int B, int Cin, int Cout, int ks, int T,
+                           int hop, float *dx, float *dkernel, float *dbias, void *stream);
+
 /* Mel front-end in front of the vocoder: process_utterance(..., vocoder='pwg') of
  * data_gen/tts/data_gen_utils.py:93-147 = librosa.stft(n_fft 1024, hop 256, win 1024, "hann", center, pad_mode "constant") ->
  * magnitude -> librosa.filters.mel(22050, 1024, 80, fmin 80, fmax 7600) -> log10(max(1e-6, .)).
@@ -159,7 +171,6 @@ FD_API int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_sa
  * "fuse_final" = "1" (default: the last LVC layer applies final_conv to its own tile instead of writing 32 channels for a separate
  *          kernel to read back; off automatically with "taps") | "0";
  * "mel"  = "pwg" (default) | "tacotron": which of the reference's two mel front-ends fd_mel_spectrogram computes;
- * "lvc_waves" = "8" (default: the fp16x2 LVC layers run as 8-wave workgroups, half the instruction stream per wave) | "4";
  * "fallback" = "graph" (default: every fp16x2 kernel is followed by its fp32 twin, which exits at once unless the first raised its
  *          range flag -- no host round trip, fully asynchronous) | "host" (see fd_sample_check);
  * "taps" = "1" | "0" (keep block outputs for fd_read_tap). */

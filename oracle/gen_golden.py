@@ -480,6 +480,35 @@ def gen_frontend_pwg():
     np.savez_compressed(os.path.join(GOLD, "frontend_pwg_lj001_0002.npz"), **out)
 
 
+def gen_lvc_grad():
+    """TimeAware_LVCBlock.location_variable_convolution (modules.py:220-253) executed on the reference module in float64, forward and
+    -- through torch.autograd -- backward, for the three hop sizes of the model on small tensors (Cin 32, Cout 64, ks 3)."""
+    blk = ref_modules.TimeAware_LVCBlock(in_channels=32, cond_channels=80, upsample_ratio=8, conv_layers=4, conv_kernel_size=3,
+                                         cond_hop_length=8, kpnet_hidden_channels=64, kpnet_conv_size=3, kpnet_dropout=0.0,
+                                         noise_scale_embed_dim_out=512)
+    out = {}
+    for hop, T, B in ((8, 5, 2), (64, 3, 2), (256, 2, 1)):
+        L = T * hop
+        x = synth.hash_normal(SEED + 500 + hop, 1, B * 32 * L).reshape(B, 32, L).astype(np.float64)
+        K = (0.1 * synth.hash_normal(SEED + 500 + hop, 2, B * 32 * 64 * 3 * T)).reshape(B, 32, 64, 3, T).astype(np.float64)
+        bias = (0.1 * synth.hash_normal(SEED + 500 + hop, 3, B * 64 * T)).reshape(B, 64, T).astype(np.float64)
+        dout = synth.hash_normal(SEED + 500 + hop, 4, B * 64 * L).reshape(B, 64, L).astype(np.float64)
+        xt, Kt, bt = (torch.from_numpy(a.copy()).requires_grad_(True) for a in (x, K, bias))
+        y = blk.location_variable_convolution(xt, Kt, bt, 1, hop)
+        y.backward(torch.from_numpy(dout))
+        tag = f"h{hop}_"
+        out.update({tag + "x": x.astype(np.float32), tag + "K": K.astype(np.float32), tag + "bias": bias.astype(np.float32),
+                    tag + "dout": dout.astype(np.float32)})
+        # gradients of the float32-rounded inputs, in float64 (what the fp32 kernels are compared with)
+        xt, Kt, bt = (torch.from_numpy(out[tag + n].astype(np.float64)).requires_grad_(True) for n in ("x", "K", "bias"))
+        y = blk.location_variable_convolution(xt, Kt, bt, 1, hop)
+        y.backward(torch.from_numpy(out[tag + "dout"].astype(np.float64)))
+        out.update({tag + "out": y.detach().numpy().astype(np.float32), tag + "dx": xt.grad.numpy().astype(np.float32),
+                    tag + "dK": Kt.grad.numpy().astype(np.float32), tag + "dbias": bt.grad.numpy().astype(np.float32)})      # (computed in float64)
+        print("lvc_grad hop", hop, y.shape, float(np.abs(out[tag + "dK"]).max()))
+    np.savez_compressed(os.path.join(GOLD, "lvc_grad.npz"), **out)
+
+
 def gen_statedict_manifest():
     """Key set + shapes of the reference module's state_dict, and a default-init digest, for the drop-in shim test."""
     torch.manual_seed(SEED)
@@ -496,7 +525,7 @@ def gen_statedict_manifest():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["schedule", "embed", "ops", "forward", "sample", "manifest", "collate", "collater", "frontend", "frontend_tacotron",
-                             "frontend_pwg", "noise_scheduling", "theta_loss"]
+                             "frontend_pwg", "noise_scheduling", "theta_loss", "lvc_grad"]
     dh = gen_schedule()
     if "embed" in which:
         gen_embed()
@@ -510,6 +539,8 @@ if __name__ == "__main__":
         gen_statedict_manifest()
     if "collate" in which:
         gen_collate()
+    if "lvc_grad" in which:
+        gen_lvc_grad()
     if "collater" in which:
         gen_collater()
     if "frontend_pwg" in which:

@@ -1,0 +1,101 @@
+"""The LVC operator with its gradients: oracle/lvc_grad.py (numpy) and the HIP operator behind
+fastdiff_amd.location_variable_convolution against tests/golden/lvc_grad.npz -- TimeAware_LVCBlock.location_variable_convolution
+(modules.py:220-253) executed on the reference module in float64, forward and, through torch.autograd, backward."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import lvc_grad as lg   # noqa: E402
+
+HOPS = (8, 64, 256)
+
+
+def _case(g, hop):
+    t = f"h{hop}_"
+    return {k: g[t + k] for k in ("x", "K", "bias", "dout", "out", "dx", "dK", "dbias")}
+
+
+@pytest.mark.parametrize("hop", HOPS)
+def test_oracle_restatement_matches_the_reference_function_and_its_autograd(hop):
+    c = _case(load_golden("lvc_grad"), hop)
+    x, K, b, d = (c[k].astype(np.float64) for k in ("x", "K", "bias", "dout"))
+    out = lg.lvc_forward(x, K, b, hop)
+    dx, dK, db = lg.lvc_backward(x, K, d, hop)
+    for name, got in (("out", out), ("dx", dx), ("dK", dK), ("dbias", db)):
+        ref = c[name].astype(np.float64)
+        assert got.shape == ref.shape, name
+        assert np.abs(got - ref).max() <= 2e-7 * max(1.0, np.abs(ref).max()), name      # the fixture is float32 of a float64 run
+
+
+def test_oracle_gradients_against_finite_differences():
+    rng = np.random.default_rng(0)
+    B, Cin, Cout, ks, T, hop = 1, 3, 4, 3, 3, 5
+    x, K, b = rng.standard_normal((B, Cin, T * hop)), rng.standard_normal((B, Cin, Cout, ks, T)), rng.standard_normal((B, Cout, T))
+    d = rng.standard_normal((B, Cout, T * hop))
+    dx, dK, db = lg.lvc_backward(x, K, d, hop)
+    f = lambda x_, K_, b_: float((lg.lvc_forward(x_, K_, b_, hop) * d).sum())      # noqa: E731
+    eps = 1e-6
+    for arr, grad, which in ((x, dx, 0), (K, dK, 1), (b, db, 2)):
+        for idx in [tuple(rng.integers(0, s) for s in arr.shape) for _ in range(12)]:
+            ap, am = arr.copy(), arr.copy()
+            ap[idx] += eps
+            am[idx] -= eps
+            args_p, args_m = [x, K, b], [x, K, b]
+            args_p[which], args_m[which] = ap, am
+            num = (f(*args_p) - f(*args_m)) / (2 * eps)
+            assert abs(num - grad[idx]) < 1e-6 * max(1.0, abs(num)), (which, idx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hop", HOPS)
+def test_hip_operator_forward_and_backward_match_the_reference(hop):
+    import fastdiff_amd
+    c = _case(load_golden("lvc_grad"), hop)
+    x, K, b = (torch.from_numpy(c[k]).cuda().requires_grad_(True) for k in ("x", "K", "bias"))
+    y = fastdiff_amd.location_variable_convolution(x, K, b, 1, hop)
+    y.backward(torch.from_numpy(c["dout"]).cuda())
+    for name, got in (("out", y.detach()), ("dx", x.grad), ("dK", K.grad), ("dbias", b.grad)):
+        ref = c[name].astype(np.float64)
+        err = np.abs(got.cpu().numpy().astype(np.float64) - ref).max()
+        print(f"hop {hop} {name}: max|d| {err:.2e} of {np.abs(ref).max():.2f}")
+        assert got.shape == ref.shape and err <= 2e-6 * max(1.0, np.abs(ref).max()), name      # fp32 sums of <= 256 products
+
+
+@pytest.mark.gpu
+def test_hip_operator_in_place_of_the_reference_method_under_autograd():
+    """The operator dropped into a small autograd graph the way the reference uses it (a conv in front, the gate behind,
+    modules.py:208-217): gradients of the conv weight and of the predicted kernels against the numpy oracle chain."""
+    import fastdiff_amd
+    torch.manual_seed(3)
+    B, T, hop = 2, 4, 8
+    conv = torch.nn.Conv1d(32, 32, 3, padding=1).cuda()
+    xin = torch.randn(B, 32, T * hop, device="cuda")
+    K = (0.1 * torch.randn(B, 32, 64, 3, T, device="cuda")).requires_grad_(True)
+    bias = torch.zeros(B, 64, T, device="cuda", requires_grad=True)
+    y = torch.nn.functional.leaky_relu(conv(torch.nn.functional.leaky_relu(xin, 0.2)), 0.2)
+    z = fastdiff_amd.location_variable_convolution(y, K, bias, 1, hop)
+    out = xin + torch.sigmoid(z[:, :32]) * torch.tanh(z[:, 32:])
+    loss = (out ** 2).mean()
+    loss.backward()
+    # the same graph with the operator replaced by its numpy restatement (forward value and backward through lg.lvc_backward)
+    yn, Kn, bn = y.detach().cpu().double().numpy(), K.detach().cpu().double().numpy(), bias.detach().cpu().double().numpy()
+    zn = torch.from_numpy(lg.lvc_forward(yn, Kn, bn, hop)).requires_grad_(True)
+    outn = xin.detach().cpu().double() + torch.sigmoid(zn[:, :32]) * torch.tanh(zn[:, 32:])
+    (outn ** 2).mean().backward()
+    dy, dK, db = lg.lvc_backward(yn, Kn, zn.grad.numpy(), hop)
+    assert np.abs(K.grad.cpu().numpy() - dK).max() <= 1e-5 * max(1e-3, np.abs(dK).max())
+    assert np.abs(bias.grad.cpu().numpy() - db).max() <= 1e-5 * max(1e-3, np.abs(db).max())
+    assert conv.weight.grad is not None and torch.isfinite(conv.weight.grad).all() and float(conv.weight.grad.abs().max()) > 0
+    with pytest.raises(AssertionError, match="not matched"):
+        fastdiff_amd.location_variable_convolution(y, K, bias, 1, hop + 1)            # modules.py:236
+    with pytest.raises(NotImplementedError):
+        fastdiff_amd.location_variable_convolution(y, K, bias, 2, hop)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        fastdiff_amd.location_variable_convolution(y.cpu(), K.cpu(), bias.cpu(), 1, hop)

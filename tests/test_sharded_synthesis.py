@@ -103,6 +103,10 @@ def _gpu_worker(rank, world, port, ret):
             single = infer.synthesize(model, items, n_steps=4, max_batch=4, seed=77, drop_last_frame=True)
             assert sorted(out) == sorted(single)
             for name in single:
+                if not np.array_equal(out[name], single[name]):
+                    d = np.abs(out[name].astype(np.int32) - single[name].astype(np.int32))
+                    idx = np.nonzero(d)[0]
+                    print(f"MISMATCH {name}: {idx.size} of {d.size} samples, max |d| {d.max()}, first {idx[0]}, last {idx[-1]}", flush=True)
                 assert out[name].dtype == np.int16 and np.array_equal(out[name], single[name]), name
             other = infer.synthesize(model, items, n_steps=4, max_batch=4, seed=78, drop_last_frame=True)
             assert not np.array_equal(other[items[0]["item_name"]], single[items[0]["item_name"]])      # the seed matters

@@ -1,15 +1,13 @@
-// lvc_h2_bench.hip -- standalone timing harness for k_lvc_f16 (phase stamps with s_memtime when FD_LVC_TIMING is set)
-// usage: lvc_h2_bench [B] [T] [kpre = 1|0] [waves = 4|8]   (8 waves: k_lvc_w8, packed records only)
+// lvc_h2_bench.hip -- standalone timing harness for k_lvc_h2 (phase stamps with s_memtime when FD_LVC_TIMING is set)
 #include "../../fastdiff_amd/csrc/fd_kernels_fast.hip"
 #include <stdio.h>
 #include <stdlib.h>
-#include <string.h>
 #include <vector>
 void fd_prof_begin(const fdk::Launch &, const char *) {}
 void fd_prof_end(const fdk::Launch &) {}
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-template <int HOP, int DIL, bool KPRE, bool W8 = false>
+template <int HOP, int DIL>
 int run(int B, int T, int reps)
 {
     const int Ln = T * HOP;
@@ -17,22 +15,11 @@ int run(int B, int T, int reps)
     float *x, *skip, *out, *kp, *wpack, *wref, *cb;
     int *flag;
     CK(hipMalloc(&x, nx * 4)); CK(hipMalloc(&skip, nx * 4)); CK(hipMalloc(&out, nx * 4)); CK(hipMalloc(&kp, nk * 4));
-    CK(hipMalloc(&wpack, 3072 * 4)); CK(hipMalloc(&wref, 3072 * 4)); CK(hipMalloc(&cb, 32 * 4)); CK(hipMalloc(&flag, 512)); CK(hipMemset(flag, 0, 512));
+    CK(hipMalloc(&wpack, 3072 * 4)); CK(hipMalloc(&wref, 3072 * 4)); CK(hipMalloc(&cb, 32 * 4)); CK(hipMalloc(&flag, 256)); CK(hipMemset(flag, 0, 256));
     std::vector<float> h(std::max(nx, nk));
     for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 2001) * 1e-3f - 1.0f;
     CK(hipMemcpy(x, h.data(), nx * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(skip, h.data(), nx * 4, hipMemcpyHostToDevice));
     for (size_t i = 0; i < nk; ++i) h[i] *= 0.05f;
-    if (KPRE) {      // predicted kernels as (h | l << 16) pairs (KFMT_PACKED)
-        for (size_t i = 0; i < nk; ++i) {
-            if (i % fd::KREC >= (size_t)fd::KW) continue;      // the biases stay fp32
-            const float v = h[i];
-            const _Float16 h1 = (_Float16)v, l1 = (_Float16)((v - (float)h1) * 2048.0f);
-            unsigned short hb, lb;
-            memcpy(&hb, &h1, 2); memcpy(&lb, &l1, 2);
-            const unsigned u = (unsigned)hb | ((unsigned)lb << 16);
-            memcpy(&h[i], &u, 4);
-        }
-    }
     CK(hipMemcpy(kp, h.data(), nk * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(wref, h.data(), 3072 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(cb, h.data(), 32 * 4, hipMemcpyHostToDevice));
     {   // fp16 weight pieces of plausible magnitude
@@ -44,14 +31,10 @@ int run(int B, int T, int reps)
     dim3 grid(((Ln + 255) / 256 + 7) / 8 * 8, B);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto launch = [&]() {
-        if constexpr (W8) hipLaunchKernelGGL((fdk_fast::k_lvc_w8<HOP, DIL, false>), grid, dim3(512), 0, 0, x, skip, out, kp, 1, (const float4 *)wpack, wref, cb, flag, (const int *)(flag + 20), T, (const int *)nullptr, (float *)nullptr, (const float4 *)nullptr);
-        else hipLaunchKernelGGL((fdk_fast::k_lvc_f16<HOP, DIL, false, KPRE>), grid, dim3(256), 0, 0, x, skip, out, kp, 1, (const float4 *)wpack, wref, cb, flag, (const int *)(flag + 20), T, (const int *)nullptr, (float *)nullptr, (const float4 *)nullptr);
-    };
-    for (int i = 0; i < 3; ++i) launch();
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((fdk_fast::k_lvc_h2<HOP, DIL, false>), grid, dim3(256), 0, 0, x, skip, out, kp, 1, (const float4 *)wpack, wref, cb, flag, T, (const int *)nullptr, (float *)nullptr, (const float4 *)nullptr);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < reps; ++i) launch();
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((fdk_fast::k_lvc_h2<HOP, DIL, false>), grid, dim3(256), 0, 0, x, skip, out, kp, 1, (const float4 *)wpack, wref, cb, flag, T, (const int *)nullptr, (float *)nullptr, (const float4 *)nullptr);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms = 0;
@@ -59,13 +42,13 @@ int run(int B, int T, int reps)
     const double us = ms * 1e3 / reps;
     const double flops = 2.0 * B * T * HOP * (32 * 96 + 64 * 96), bytes = 4.0 * B * T * (96.0 * HOP + 6208);
     int hf = 0; CK(hipMemcpy(&hf, flag, 4, hipMemcpyDeviceToHost));
-    printf("lvc<%d,%d,kpre=%d,waves=%d> B=%d T=%d: %.1f us  %.1f TFLOP/s(fp32-equivalent)  %.0f GB/s (algorithmic)  flag=%d\n", HOP, DIL, (int)KPRE, W8 ? 8 : 4, B, T, us, flops / us / 1e6, bytes / us / 1e3, hf);
+    printf("lvc_h2<%d,%d> B=%d T=%d: %.1f us  %.1f TFLOP/s(fp32-equivalent)  %.0f GB/s (algorithmic)  flag=%d\n", HOP, DIL, B, T, us, flops / us / 1e6, bytes / us / 1e3, hf);
 #ifdef FD_LVC_TIMING
     std::vector<long long> d(64 * 4 * 8);
     CK(hipMemcpyFromSymbol(d.data(), HIP_SYMBOL(fdk_fast::fd_dbg), d.size() * 8));
     double acc[8] = {0}, accw[4][8] = {{0}};
     for (int w = 0; w < 256; ++w) for (int i = 1; i < 8; ++i) { acc[i] += (double)(d[w * 8 + i] - d[w * 8 + i - 1]); accw[w % 4][i] += (double)(d[w * 8 + i] - d[w * 8 + i - 1]); }
-    const char *names[8] = {"", "loads+park+barrier", "resid, x image, barrier", "conv MFMA + y split", "halo VALU", "barrier, y image, barrier", "K split / offsets", "LVC + epilogue"};
+    const char *names[8] = {"", "loads+stage+barrier", "resid + barrier", "conv MFMA + y split", "halo VALU", "barrier", "K split", "LVC + epilogue"};
     double tot = 0;
     for (int i = 1; i < 8; ++i) { printf("   %-22s %9.0f ticks   (wave0 %7.0f  wave1 %7.0f  wave2 %7.0f  wave3 %7.0f)\n", names[i], acc[i] / 256, accw[0][i] / 64, accw[1][i] / 64, accw[2][i] / 64, accw[3][i] / 64); tot += acc[i] / 256; }
     printf("   total %9.0f ticks per wave (s_memtime ticks)\n", tot);
@@ -77,10 +60,9 @@ int run(int B, int T, int reps)
 int main(int argc, char **argv)
 {
     const int B = argc > 1 ? atoi(argv[1]) : 8, T = argc > 2 ? atoi(argv[2]) : 864;
-    const bool kpre = argc > 3 ? atoi(argv[3]) != 0 : true;
-    const bool w8 = argc > 4 ? atoi(argv[4]) == 8 : false;
-    if (w8) { run<256, 27, true, true>(B, T, 20); run<256, 1, true, true>(B, T, 20); run<64, 27, true, true>(B, T, 20); run<64, 1, true, true>(B, T, 20); }
-    else if (kpre) { run<256, 27, true>(B, T, 20); run<256, 1, true>(B, T, 20); run<64, 27, true>(B, T, 20); run<64, 1, true>(B, T, 20); }
-    else { run<256, 27, false>(B, T, 20); run<256, 1, false>(B, T, 20); run<64, 27, false>(B, T, 20); run<64, 1, false>(B, T, 20); }
+    run<256, 27>(B, T, 20);
+    run<256, 1>(B, T, 20);
+    run<64, 27>(B, T, 20);
+    run<64, 1>(B, T, 20);
     return 0;
 }
