@@ -518,6 +518,22 @@ int fd_commit_weights(fd_handle h)
         for (int i = 0; i < fd::LAYERS; ++i) {
             if ((rc = up_conv(p + ".convs." + std::to_string(i), w.blk[n].convs[i])) != FD_OK) return rc;
             UP(pack_A(f[p + ".convs." + std::to_string(i)].w, fd::C, fd::C, 3), w.lvc_conv_pack[n][i]);
+            if (n == 0) {      // hop 8: 16x16x32 tiles: lane = out%16 + 16*g holds k = tap*32 + 8g + e, i.e. input channels 8g .. 8g+7 of one tap
+                const std::vector<float> &cw = f[p + ".convs." + std::to_string(i)].w;
+                std::vector<uint16_t> hp((size_t)2 * 3 * 2 * 64 * 8);
+                for (int rt = 0; rt < 2; ++rt)
+                    for (int tap = 0; tap < 3; ++tap)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 8; ++e) {
+                                const int out = 16 * rt + (lane & 15), in = 8 * (lane >> 4) + e;
+                                const float v = cw[((size_t)out * fd::C + in) * 3 + tap];
+                                if (!(fabsf(v) < 32768.0f)) lvc_ok = false;
+                                const uint16_t p1 = f16_from_f32(v);
+                                hp[((((size_t)rt * 3 + tap) * 2 + 0) * 64 + lane) * 8 + e] = p1;
+                                hp[((((size_t)rt * 3 + tap) * 2 + 1) * 64 + lane) * 8 + e] = f16_from_f32((v - f32_from_f16(p1)) * 2048.0f);
+                            }
+                if ((rc = upload(h, hp.data(), hp.size() * sizeof(uint16_t), reinterpret_cast<const void **>(&w.lvc_conv_h16[i]))) != FD_OK) return rc;
+            }
             {
                 const std::vector<uint16_t> hp = pack_A_h2(f[p + ".convs." + std::to_string(i)].w, fd::C, 3, &lvc_ok);
                 if ((rc = upload(h, hp.data(), hp.size() * sizeof(uint16_t), reinterpret_cast<const void **>(&w.lvc_conv_h2[n][i]))) != FD_OK)
@@ -839,7 +855,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
 static unsigned mode_signature(const fd_context *h)
 {
     unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_f16 ? 2u : 0u) | (h->lvc_f16 ? 4u : 0u) | (h->conv_f16 ? 8u : 0u) | (h->step_lens ? 16u : 0u) |
-                 (h->inline_fallback ? 32u : 0u);
+                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u);
     for (int i = 0; i < ST_COUNT; ++i) s = (s << 1) | (h->fast[i] ? 1u : 0u);
     return s ^ (h->fp32_mask * 2654435761u);
 }
@@ -1253,6 +1269,13 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
         if (v == "pwg") h->mel_variant = MEL_PWG;
         else if (v == "tacotron") h->mel_variant = MEL_TACOTRON;
         else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: mel expects pwg|tacotron, got '%s'", value);
+        return FD_OK;
+    }
+    if (k == "lvc_h8") {
+        if (v == "mfma") h->lvc_h8_mfma = true;
+        else if (v == "valu") h->lvc_h8_mfma = false;
+        else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: lvc_h8 expects mfma|valu, got '%s'", value);
+        drop_graph(h);
         return FD_OK;
     }
     if (k == "fallback") {

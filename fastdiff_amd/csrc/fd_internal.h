@@ -73,6 +73,7 @@ struct DevWeights {
     bool dblock_f16_ok = false;
     const float *lvc_conv_pack[fd::NBLK][fd::LAYERS] = {};
     const uint16_t *lvc_conv_h2[fd::NBLK][fd::LAYERS] = {};   // the same as two fp16 pieces: [piece][6 kg][64 lane][8], k = tap*32 + in
+    const uint16_t *lvc_conv_h16[fd::LAYERS] = {};        // block 0 (hop 8): A operands of v_mfma_f32_16x16x32_f16: [row tile 2][tap 3][piece 2][64 lane][8]
     bool lvc_f16_ok = false;                      // every LVC conv weight fits the fp16 range
     const float *kp_in_pack[fd::NBLK] = {};       // 80->64 k5: 2 mt x 50 s4
     const float *kp_res_pack[fd::NBLK][6] = {};   // 64->64 k3: 2 mt x 24 s4
@@ -166,6 +167,7 @@ struct fd_context {
     //   !inline_fallback only the fp16x2 kernel; flags accumulate in range_flag[64..95] and the HOST redoes the work with
     //                    fp32_mask set (option fallback = host: fd_sample_check)
     //   fp32_mask        bit i set: the stage whose flag word is i runs its fp32 kernel outright
+    bool lvc_h8_mfma = true;                  // option "lvc_h8" = "mfma": the hop-8 layers on 16x16x32 fp16 tiles (k_lvc_h8m) | "valu" (k_lvc_h8)
     bool host_fallback = false;               // option "fallback" = "host"
     bool inline_fallback = true;
     unsigned fp32_mask = 0;

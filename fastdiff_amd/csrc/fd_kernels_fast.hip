@@ -1872,9 +1872,11 @@ __global__ void __launch_bounds__(256) k_final_acc(float *__restrict__ eps_acc, 
 template <int DIL>
 __global__ void __launch_bounds__(256, 2) k_lvc_h8(const float *__restrict__ xin, const float *__restrict__ skip, float *__restrict__ xout,
                                                    const float *__restrict__ kpack, int layer, const float *__restrict__ wref,
-                                                   const float *__restrict__ cbias, int T, const int *__restrict__ lens)
+                                                   const float *__restrict__ cbias, int T, const int *__restrict__ lens,
+                                                   const int *__restrict__ run_if)
 {
     constexpr int HOP = 8, W = 32, H = (DIL + 1 + 3) & ~3, XLD = W + 2 * H, YLD = 12;
+    if (run_if && *run_if == 0) return;      // fallback launch behind k_lvc_h8m: only when that kernel flagged its operands
     __shared__ __attribute__((aligned(16))) float xs[fd::C * XLD];          // leaky_relu(x + skip), column c at index c + H
     __shared__ __attribute__((aligned(16))) float xr[fd::C * W];            // raw x + skip of the centre: the residual
     __shared__ __attribute__((aligned(16))) float ys[4][fd::C * YLD];       // per wave: y of columns 8*wave-1 .. 8*wave+8 (+2 pad)
@@ -1981,6 +1983,210 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h8(const float *__restrict__ xin
         *reinterpret_cast<float4 *>(dst) = make_float4(rr[0] + z[0], rr[1] + z[1], rr[2] + z[2], rr[3] + z[3]);
         *reinterpret_cast<float4 *>(dst + 4) = make_float4(rr[4] + z[4], rr[5] + z[5], rr[6] + z[6], rr[7] + z[7]);
     }
+}
+
+// =================================================================================================
+// The hop-8 layer on the matrix pipe.  A frame is only 8 columns wide, so the 32x32 tiles of the other layers do not fit (one tile
+// would straddle four predicted kernels); v_mfma_f32_16x16x32_f16 does: rows = 16 output channels, cols = 16 columns of which a
+// frame uses 8, k = one tap x 32 input channels.  With the 2-piece fp16 operands of the rest of the pipe:
+//   conv   32 -> 32 channels over the workgroup's 32 columns = four 16x16 tiles, one per wave: 9 MFMAs (3 taps x 3 piece products);
+//   LVC    wave = frame: Z[64 x 8] = K_f[64 x 96] Y[96 x 8] = four 16-row tiles x 3 taps x 3 piece products = 36 MFMAs; the frame
+//          record's layout ([mt][kg][row32 + 32 g][8], fd_internal.h) already is the A operand of this instruction: lane (r, g4) of
+//          tile (mt, half) finds its 8 consecutive k at ((mt*6 + 2 tap + g4/2)*64 + 16 half + r + 32 (g4 & 1))*8; sigmoid and tanh
+//          inputs of a channel are the SAME register of the two tiles (mt, 0) and (mt, 1), so the gate stays lane-local.
+// ~45 MFMAs of 16 cycles and ~550 VALU instructions per wave instead of ~1600 VALU (k_lvc_h8, which stays as the fp32 fallback).
+// =================================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16(const float4 &a, const float4 &b, f32x4 c)
+{
+    union { float4 f; f16x8 h; } ua, ub;
+    ua.f = a;
+    ub.f = b;
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(ua.h, ub.h, c, 0, 0, 0);
+}
+
+template <int DIL>
+__global__ void __launch_bounds__(256, 2) k_lvc_h8m(const float *__restrict__ xin, const float *__restrict__ skip, float *__restrict__ xout,
+                                                    const float *__restrict__ kpack, int layer, const float4 *__restrict__ wpack16,
+                                                    const float *__restrict__ wref, const float *__restrict__ cbias,
+                                                    int *__restrict__ range_flag, int T, const int *__restrict__ lens)
+{
+    constexpr int HOP = 8, W = 32, H = (DIL + 1 + 3) & ~3, XC = W + 2 * H, NQ = XC / 4;
+    static_assert(8 * NQ <= 256, "one (channel quad, column quad) unit per thread");
+    __shared__ __attribute__((aligned(16))) char xs[XC * 128];          // leaky_relu(x + skip) pieces, row = column + H
+    __shared__ __attribute__((aligned(16))) char ys[(W + 2) * 128];     // conv output pieces, row = column + 1
+    __shared__ __attribute__((aligned(16))) float xr[fd::C * W];        // raw x + skip of the centre: the residual
+    const int Ln = T * HOP;
+    const int b = blockIdx.y, w0 = blockIdx.x * W;
+    const int Tb = frames_of(lens, b, T), Lnb = Tb * HOP;
+    if (w0 >= Lnb || skip_after_previous_overflow(range_flag)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, g4 = lane >> 4;
+    const int f = w0 / HOP + wave;                  // this wave's frame
+    const bool frame_valid = f < Tb;
+    float mx = 0.0f;
+    // (a) the frame's predicted kernel, fp32, in the A-operand order of the 16x16x32 tiles: [mt][half][tap] x 8 consecutive k
+    float4 ka[2][2][3][2];
+    float4 bz[2][2];
+    if (frame_valid) {
+        const float *rec = kpack + ((int64_t)b * T + f) * fd::KREC;
+        const float4 *kp4 = reinterpret_cast<const float4 *>(rec + layer * fd::KLAYER);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+                for (int tap = 0; tap < 3; ++tap) {
+                    const int e8 = (mt * 6 + 2 * tap + (g4 >> 1)) * 64 + 16 * hf + c16 + 32 * (g4 & 1);
+                    ka[mt][hf][tap][0] = kp4[2 * e8];
+                    ka[mt][hf][tap][1] = kp4[2 * e8 + 1];
+                }
+                bz[mt][hf] = *reinterpret_cast<const float4 *>(rec + fd::KW + layer * 64 + mt * 32 + 16 * hf + 4 * g4);
+            }
+    }
+    // (b) x + skip with halo: thread = (channel quad, column quad)
+    {
+        const int q = tid / NQ, c4 = tid - q * NQ, g = w0 - H + 4 * c4;
+        const bool unit = tid < 8 * NQ, ok = unit && g >= 0 && g < Lnb;      // (Lnb, w0, H are multiples of 4: a quad is all in or all out)
+        const float *xp = xin + ((int64_t)b * fd::C + 4 * q) * Ln, *sp = skip + ((int64_t)b * fd::C + 4 * q) * Ln;
+        float4 xa[4], sa[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            xa[c] = ok ? *reinterpret_cast<const float4 *>(xp + (int64_t)c * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            sa[c] = ok ? *reinterpret_cast<const float4 *>(sp + (int64_t)c * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (unit) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                xa[c] = make_float4(xa[c].x + sa[c].x, xa[c].y + sa[c].y, xa[c].z + sa[c].z, xa[c].w + sa[c].w);
+                if (c4 >= H / 4 && c4 < H / 4 + W / 4) *reinterpret_cast<float4 *>(xr + (4 * q + c) * W + 4 * c4 - H) = xa[c];
+            }
+            const int slot = q >> 1, half8 = (q & 1) * 8;       // channels 4q .. 4q+3 = half of the 16 B slot q/2
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { v[c] = lrelu(f4c(xa[c], j), 0.2f); mx = fmaxf(mx, fabsf(v[c])); }
+                uint2 ph, pl;
+                split2(v[0], v[1], ph.x, pl.x);
+                split2(v[2], v[3], ph.y, pl.y);
+                const int row = 4 * c4 + j;
+                *reinterpret_cast<uint2 *>(xs + h2_off(row, slot) + half8) = ph;
+                *reinterpret_cast<uint2 *>(xs + h2_off(row, 4 + slot) + half8) = pl;
+            }
+        }
+    }
+    // (c) conv weights of this wave's 16-row tile: A operand pieces [row tile][tap][piece][lane] x 8 fp16 (L2)
+    const int rt = wave & 1, ctl = wave >> 1;
+    float4 wa[3][2];
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) wa[tap][p] = wpack16[((rt * 3 + tap) * 2 + p) * 64 + lane];
+    const float4 cb4 = *reinterpret_cast<const float4 *>(cbias + 16 * rt + 4 * g4);
+    const int hside = tid >> 7, ho = (tid & 127) >> 2, hq = tid & 3;
+    float4 hwt[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) hwt[j] = reinterpret_cast<const float4 *>(wref + (ho * fd::C + 8 * hq) * 3)[j];
+    const float hbias = cbias[ho];
+    __syncthreads();
+    // ---- dilated conv: wave = (16 output channels, 16 columns); y = leaky_relu(conv) goes to the y image as pieces ----------------
+    {
+        f32x4 ah = {cb4.x, cb4.y, cb4.z, cb4.w}, al = {0.f, 0.f, 0.f, 0.f};
+        const int col = 16 * ctl + c16;
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            const int row = H + col + (tap - 1) * DIL;
+            const float4 b1 = *reinterpret_cast<const float4 *>(xs + h2_off(row, g4));
+            const float4 b2 = *reinterpret_cast<const float4 *>(xs + h2_off(row, 4 + g4));
+            ah = mfma16(wa[tap][0], b1, ah);
+            al = mfma16(wa[tap][0], b2, al);
+            al = mfma16(wa[tap][1], b1, al);
+        }
+        const bool inside = (w0 + col) < Lnb;                  // y is zero outside the signal (modules.py:240)
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] = inside ? lrelu(fmaf(al[r], GX_INV_SCALE, ah[r]), 0.2f) : 0.0f;
+            mx = fmaxf(mx, fabsf(v[r]));
+        }
+        uint2 ph, pl;
+        split2(v[0], v[1], ph.x, pl.x);
+        split2(v[2], v[3], ph.y, pl.y);
+        // D rows 4 g4 + r of row tile rt = channels 16 rt + 4 g4 + r: half of slot 2 rt + g4 / 2
+        *reinterpret_cast<uint2 *>(ys + h2_off(col + 1, 2 * rt + (g4 >> 1)) + (g4 & 1) * 8) = ph;
+        *reinterpret_cast<uint2 *>(ys + h2_off(col + 1, 4 + 2 * rt + (g4 >> 1)) + (g4 & 1) * 8) = pl;
+    }
+    // ---- the two halo columns (-1 and W) the LVC taps reach: VALU on the reassembled x image, 4 threads per output ----------------
+    {
+        const int c = hside ? W : -1, g = w0 + c;
+        const bool ok = g >= 0 && g < Lnb;
+        float accv = 0.0f;
+        if (ok) {
+            const float wv[24] = {hwt[0].x, hwt[0].y, hwt[0].z, hwt[0].w, hwt[1].x, hwt[1].y, hwt[1].z, hwt[1].w,
+                                  hwt[2].x, hwt[2].y, hwt[2].z, hwt[2].w, hwt[3].x, hwt[3].y, hwt[3].z, hwt[3].w,
+                                  hwt[4].x, hwt[4].y, hwt[4].z, hwt[4].w, hwt[5].x, hwt[5].y, hwt[5].z, hwt[5].w};
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) {
+                const int row = H + c + (tap - 1) * DIL;
+                union { float4 f; _Float16 h[8]; } p1, p2;
+                p1.f = *reinterpret_cast<const float4 *>(xs + h2_off(row, hq));
+                p2.f = *reinterpret_cast<const float4 *>(xs + h2_off(row, 4 + hq));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) accv += wv[j * 3 + tap] * fmaf((float)p2.h[j], GX_INV_SCALE, (float)p1.h[j]);
+            }
+        }
+        accv += __shfl_xor(accv, 1, 64);
+        accv += __shfl_xor(accv, 2, 64);
+        if (hq == 0) {
+            const float v = ok ? lrelu(accv + hbias, 0.2f) : 0.0f;
+            mx = fmaxf(mx, fabsf(v));
+            const _Float16 v1 = (_Float16)v, v2 = (_Float16)((v - (float)v1) * GX_SCALE);
+            const int yrow = c + 1;
+            *reinterpret_cast<_Float16 *>(ys + h2_off(yrow, ho >> 3) + (ho & 7) * 2) = v1;
+            *reinterpret_cast<_Float16 *>(ys + h2_off(yrow, 4 + (ho >> 3)) + (ho & 7) * 2) = v2;
+        }
+    }
+    __syncthreads();
+    if (frame_valid) {
+        // ---- LVC of this wave's frame: columns 8 wave .. 8 wave + 7 are MFMA columns 0..7 (columns 8..15 repeat column 7: never stored)
+        const int ycol = 8 * wave + min(c16, 7);
+        float4 yb[3][2];
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            yb[tap][0] = *reinterpret_cast<const float4 *>(ys + h2_off(ycol + tap, g4));          // y row = column + 1 + (tap - 1)
+            yb[tap][1] = *reinterpret_cast<const float4 *>(ys + h2_off(ycol + tap, 4 + g4));
+        }
+        float *xo = xout + ((int64_t)b * fd::C + 4 * g4) * Ln + w0 + 8 * wave + c16;
+        const float *rr = xr + (4 * g4) * W + 8 * wave + c16;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x4 zh[2], zl[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                zh[hf] = f32x4{bz[mt][hf].x, bz[mt][hf].y, bz[mt][hf].z, bz[mt][hf].w};
+                zl[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int tap = 0; tap < 3; ++tap) {
+                    const float4 &a0 = ka[mt][hf][tap][0], &a1 = ka[mt][hf][tap][1];
+                    mx = amax4(amax4(mx, a0), a1);
+                    const float kv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    float4 kh, kl;
+                    split8(kv, kh, kl);
+                    zh[hf] = mfma16(kh, yb[tap][0], zh[hf]);
+                    zl[hf] = mfma16(kh, yb[tap][1], zl[hf]);
+                    zl[hf] = mfma16(kl, yb[tap][0], zl[hf]);
+                }
+            }
+            if (c16 < 8) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {      // channel 16 mt + 4 g4 + r: sigmoid input in tile (mt, 0), tanh input in tile (mt, 1)
+                    const float zs = fmaf(zl[0][r], GX_INV_SCALE, zh[0][r]), zt = fmaf(zl[1][r], GX_INV_SCALE, zh[1][r]);
+                    xo[(int64_t)(16 * mt + r) * Ln] = rr[(16 * mt + r) * W] + gate(zs, zt);
+                }
+            }
+        }
+    }
+    if (!(mx < GX_LIMIT)) atomicOr(range_flag, 1);
 }
 
 // =================================================================================================
@@ -2224,9 +2430,16 @@ hipError_t fast_lvc_layer(const Launch &L, int n, int layer, const float *x_in, 
         const int Ln = T * 8;
         const float *kp = c->ws.kpack;
         const dim3 grid((Ln + 31) / 32, B);
+        const Pipe pipe = fd_pipe(c, c->lvc_f16 && w.lvc_f16_ok && c->lvc_h8_mfma, 1 + layer);
+        int *flag = c->ws.range_flag + 1 + layer;
 #define FD_H8(DIL_, NAME_)                                                                                          \
-        FD_LAUNCH(L, NAME_, k_lvc_h8<DIL_>, grid, dim3(256), 0, x_in, skip, x_out, kp, layer, w.blk[0].convs[layer].w,    \
-                  w.blk[0].convs[layer].b, T, c->step_lens)
+        if (pipe != PIPE_F32_ONLY)                                                                                   \
+            FD_LAUNCH(L, NAME_, k_lvc_h8m<DIL_>, grid, dim3(256), 0, x_in, skip, x_out, kp, layer,                     \
+                      reinterpret_cast<const float4 *>(w.lvc_conv_h16[layer]), w.blk[0].convs[layer].w, w.blk[0].convs[layer].b, flag, T, \
+                      c->step_lens);                                                                                 \
+        if (pipe != PIPE_F16_ONLY)                                                                                   \
+            FD_LAUNCH(L, pipe == PIPE_F32_ONLY ? NAME_ : "lvc_fp32_fallback", k_lvc_h8<DIL_>, grid, dim3(256), 0, x_in, skip, x_out, kp, layer, \
+                      w.blk[0].convs[layer].w, w.blk[0].convs[layer].b, T, c->step_lens, pipe == PIPE_F32_ONLY ? (const int *)nullptr : (const int *)flag)
         switch (layer) {
         case 0: FD_H8(1, "lvc_layer_h8_d1"); break;
         case 1: FD_H8(3, "lvc_layer_h8_d3"); break;

@@ -171,6 +171,8 @@ FD_API int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_sa
  * "fuse_final" = "1" (default: the last LVC layer applies final_conv to its own tile instead of writing 32 channels for a separate
  *          kernel to read back; off automatically with "taps") | "0";
  * "mel"  = "pwg" (default) | "tacotron": which of the reference's two mel front-ends fd_mel_spectrogram computes;
+ * "lvc_h8" = "mfma" (default: the hop-8 LVC layers on 16x16x32 fp16 matrix tiles, 2-piece operands; needs "lvc" = "f16x2") | "valu"
+ *          (the all-VALU fp32 kernel, which is also the fallback);
  * "fallback" = "graph" (default: every fp16x2 kernel is followed by its fp32 twin, which exits at once unless the first raised its
  *          range flag -- no host round trip, fully asynchronous) | "host" (see fd_sample_check);
  * "taps" = "1" | "0" (keep block outputs for fd_read_tap). */
