@@ -366,14 +366,15 @@ def run_config4(args, model, rank, world, local_rank, dev):
     from fastdiff_amd import infer
     items = config4_items() if rank == 0 else None
     N = args.nsteps
-    stage_dev = dev if world > 1 else None
+    oversub = dist.is_initialized() and dist.get_backend() == "gloo"
+    stage_dev = dev if (world > 1 and not oversub) else None      # RCCL moves device buffers, gloo host buffers
 
     def one(i):
         return infer.synthesize_sharded(model, items, n_steps=N, max_batch=args.batch, seed=1234 + i, drop_last_frame=False, src=0, device=stage_dev)
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier() if oversub else dist.barrier(device_ids=[local_rank])
 
     for i in range(args.warmup):
         out = one(i)
@@ -425,8 +426,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: fastdiff_amd has no CPU path")
     n_dev = torch.cuda.device_count()
+    # FD_BENCH_OVERSUBSCRIBE=1 (tests of the multi-rank code path on a box with fewer GPUs): ranks share GPUs, the process group runs on
+    # gloo, and the line says so ("n_gpus" stays the number of GPUs actually used, "oversubscribed": true) -- never a scaling number.
+    oversub = os.environ.get("FD_BENCH_OVERSUBSCRIBE") == "1" and args.gpus > n_dev
     if "WORLD_SIZE" not in os.environ:
-        if args.gpus > n_dev:
+        if args.gpus > n_dev and not oversub:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but this box has {n_dev} GPU(s): refusing to print a line for a world that was not measured")
         if args.gpus > 1:
             sys.exit(self_spawn(args.gpus))
@@ -435,15 +439,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    if local_rank >= n_dev:
+    if local_rank >= n_dev and not oversub:
         raise SystemExit(f"bench.py: rank {rank} (local {local_rank}) has no GPU of its own: {n_dev} visible")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    gpu_index = local_rank % n_dev
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
     rccl_ranks = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        ones = torch.ones(1, device=dev)
+        if oversub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            ones = torch.ones(1)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)
         rccl_ranks = int(ones.item())
         assert rccl_ranks == world == dist.get_world_size(), (rccl_ranks, world)
@@ -463,7 +472,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier() if oversub else dist.barrier(device_ids=[local_rank])
 
     lens = None
     if args.workload == "config4":
@@ -501,7 +510,7 @@ def main():
         scaling = "weak"
         workload = ("BASELINE configs[1]: LJSpeech FastDiff.yaml shape, batch=%d utterances of 80x%d mel per GPU, "
                     "N=%d, HIP LVC/dilated-conv kernels + hipGraph sampler" % (B, T, N))
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=None if oversub else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -512,7 +521,7 @@ def main():
         "value": round(audio_s / (ms_per_step / 1e3), 2),
         "unit": "x real-time",
         "samples_per_s": round(padded_frames * HOP / (ms_per_step / 1e3), 1),
-        "n_gpus": rccl_ranks if world > 1 else 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "n_gpus": (min(rccl_ranks, n_dev) if oversub else rccl_ranks) if world > 1 else 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": workload,
                    "batch_per_gpu": B, "frames": T, "reverse_steps": N,
@@ -520,7 +529,7 @@ def main():
                    "value_is": ("mel resident in HBM -> waveform resident in HBM (the boundary takes device pointers); the host-to-host "
                                 "rate of the same batch is `host_inclusive`") if args.workload == "configs1" else "host mel -> host int16 PCM (rank 0)",
                    "graph": not args.no_graph, "weights": "random init seed 1234 (no checkpoint offline)",
-                   "world_size": world, "gpus_visible": n_dev,
+                   "world_size": world, "gpus_visible": n_dev, "oversubscribed": bool(oversub),
                    "ragged": (None if not args.ragged else {"lens": lens, "told_to_library": not args.no_lens})},
     }
     if rank == 0:

@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from . import schedules, shard
-from .sampler import compute_hyperparams_given_schedule, sampling_given_noise_schedule
+from .sampler import InferenceSchedule, compute_hyperparams_given_schedule, sampling_given_noise_schedule
 
 
 def load_mel_inputs(test_input_dir: str) -> List[dict]:
@@ -114,6 +114,9 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
         diffusion_hyperparams = schedules.training_hyperparams()
     if noise_schedule is None:
         noise_schedule = schedules.noise_schedule_for(n_steps)
+    # the step table depends on the schedule only: derived once (sampling_given_noise_schedule derives it on every call, as the
+    # reference does -- 6 ms of host arithmetic per call for N = 6), the same rows then drive every micro-batch
+    rows = InferenceSchedule(diffusion_hyperparams, noise_schedule, verbose=False).rows()
     lengths = [it["len"] for it in items]
     out: Dict[str, np.ndarray] = {}
     pending = None                 # (event, pinned PCM, names, lens) of the micro-batch still on its way to the host
@@ -131,9 +134,8 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
         uid_of = {items[i]["item_name"]: int(items[i].get("uid", i)) for i in batch_idx}
         mels = mels.pin_memory().cuda(non_blocking=True)
         B, _, T = mels.shape
-        wav = sampling_given_noise_schedule(model, (B, 1, T * model.hop_length), diffusion_hyperparams, noise_schedule,
-                                            condition=mels, ddim=False, return_sequence=False, seed=seed, verbose=False, lens=lens,
-                                            stream_ids=[uid_of[n] for n in names])
+        with torch.no_grad():
+            wav = model.sample(mels, rows, ddim=False, seed=seed, lens=lens, stream_ids=[uid_of[n] for n in names])
         # one epilogue call and one asynchronous copy per micro-batch; the previous batch is unpacked on the host while this one runs
         pcm = model.peak_normalize_int16(wav, valid=[t * model.hop_length for t in lens])
         host = torch.empty(pcm.shape, dtype=torch.int16).pin_memory()

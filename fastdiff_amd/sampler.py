@@ -37,7 +37,28 @@ def compute_hyperparams_given_schedule(beta):
 def map_noise_scale_to_time_step(alpha_infer, alpha):
     """Fractional training step whose noise level equals alpha_infer (util.py:394-404).
 
-    Clamps to the ends of the table, returns -1 when no bracket [alpha[t+1], alpha[t]] contains the value."""
+    Clamps to the ends of the table, returns -1 when no bracket [alpha[t+1], alpha[t]] contains the value.  The reference walks
+    the table with a Python loop of 0-d tensor comparisons (10 ms per call at T = 1000); here the first bracket is found with one
+    vectorised comparison and the interpolation is then evaluated with the reference's own scalar expressions on that bracket, so
+    the result is the same float (tests/test_host_logic.py compares with the loop on every table of the reference)."""
+    last = len(alpha) - 1
+    if alpha_infer < alpha[last]:
+        return last
+    if alpha_infer > alpha[0]:
+        return 0
+    inside = (alpha[1:] <= alpha_infer) & (alpha_infer <= alpha[:-1])
+    hit = torch.nonzero(inside)
+    if hit.numel() == 0:
+        return -1
+    t = int(hit[0])
+    hi, lo = alpha[t], alpha[t + 1]
+    frac = hi - alpha_infer
+    frac /= hi - lo            # fp32 quotient, then a Python-float sum, as the reference
+    return t + frac.item()
+
+
+def _map_noise_scale_to_time_step_loop(alpha_infer, alpha):
+    """The reference's loop form of the function above (kept for the equality test)."""
     last = len(alpha) - 1
     if alpha_infer < alpha[last]:
         return last
@@ -47,7 +68,7 @@ def map_noise_scale_to_time_step(alpha_infer, alpha):
         hi, lo = alpha[t], alpha[t + 1]
         if lo <= alpha_infer <= hi:
             frac = hi - alpha_infer
-            frac /= hi - lo            # fp32 quotient, then a Python-float sum, as the reference
+            frac /= hi - lo
             return t + frac.item()
     return -1
 

@@ -62,6 +62,25 @@ def test_schedule_selection_errors():
     assert torch.equal(schedules.noise_schedule_for(7, [0.1, 0.2]), torch.FloatTensor([0.1, 0.2]))
 
 
+def test_map_noise_scale_vectorised_search_equals_the_references_loop():
+    """map_noise_scale_to_time_step finds the bracket with one vectorised comparison; the reference walks the table (util.py:
+    394-404).  Same float on every schedule of the reference, on values exactly at table entries (ties take the FIRST bracket in
+    both), outside the table, and on random levels."""
+    dh = schedules.training_hyperparams()
+    alpha = dh["alpha"]
+    levels = []
+    for N in (3, 4, 6, 8, 200, 1000):
+        levels += list(sampler.InferenceSchedule(dh, schedules.noise_schedule_for(N), verbose=False).alpha_hat)
+    levels += [alpha[0], alpha[5], alpha[998], alpha[999], alpha[0] + 1e-3, alpha[999] - 1e-3]
+    g = torch.Generator().manual_seed(5)
+    levels += list(torch.rand(200, generator=g) * (alpha[0] - alpha[999]) + alpha[999])
+    for a in levels:
+        assert sampler.map_noise_scale_to_time_step(a, alpha) == sampler._map_noise_scale_to_time_step_loop(a, alpha), float(a)
+    # a table with a gap (no bracket): -1 in both forms
+    gap = torch.tensor([0.9, 0.7, 0.8, 0.2])
+    assert sampler.map_noise_scale_to_time_step(torch.tensor(0.75), gap) == sampler._map_noise_scale_to_time_step_loop(torch.tensor(0.75), gap)
+
+
 def test_map_noise_scale_edges():
     alpha = torch.tensor([0.9, 0.8, 0.5, 0.1])
     assert sampler.map_noise_scale_to_time_step(torch.tensor(0.95), alpha) == 0
