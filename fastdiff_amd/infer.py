@@ -119,32 +119,44 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
     rows = InferenceSchedule(diffusion_hyperparams, noise_schedule, verbose=False).rows()
     lengths = [it["len"] for it in items]
     out: Dict[str, np.ndarray] = {}
-    pending = None                 # (event, pinned PCM, names, lens) of the micro-batch still on its way to the host
+    if not items:
+        return out
+    # pinned staging, allocated once per job (a pinned allocation per micro-batch costs more than vocoding it): two mel and two PCM
+    # buffers, used alternately -- buffer k & 1 is free again once micro-batch k - 2 has been collected, which happens in iteration k - 1
+    hop = model.hop_length
+    t_max, b_max = max(lengths), min(max_batch, len(items))
+    mel_pin = [torch.empty(b_max * 80 * t_max, dtype=torch.float32).pin_memory() for _ in range(2)]
+    pcm_pin = [torch.empty(b_max * t_max * hop, dtype=torch.int16).pin_memory() for _ in range(2)]
+    pending = None                 # (event, pinned PCM view, names, lens) of the micro-batch still on its way to the host
 
     def collect(p):
         done, host, names, lens = p
         done.synchronize()
         for b, (name, t) in enumerate(zip(names, lens)):
-            out[name] = host[b, : t * model.hop_length].numpy().copy()
+            out[name] = host[b, : t * hop].numpy().copy()
 
-    for k, batch_idx in enumerate(shard.micro_batches(range(len(items)), lengths, max_batch)):
+    k = 0
+    for batch_idx in shard.micro_batches(range(len(items)), lengths, max_batch):
         mels, lens, names = collate_test_batch([items[i] for i in batch_idx], drop_last_frame)
         if mels is None:
             continue
         uid_of = {items[i]["item_name"]: int(items[i].get("uid", i)) for i in batch_idx}
-        mels = mels.pin_memory().cuda(non_blocking=True)
         B, _, T = mels.shape
+        mel_h = mel_pin[k & 1][: B * 80 * T].view(B, 80, T)
+        mel_h.copy_(mels)
+        mels = mel_h.cuda(non_blocking=True)
         with torch.no_grad():
             wav = model.sample(mels, rows, ddim=False, seed=seed, lens=lens, stream_ids=[uid_of[n] for n in names])
         # one epilogue call and one asynchronous copy per micro-batch; the previous batch is unpacked on the host while this one runs
-        pcm = model.peak_normalize_int16(wav, valid=[t * model.hop_length for t in lens])
-        host = torch.empty(pcm.shape, dtype=torch.int16).pin_memory()
+        pcm = model.peak_normalize_int16(wav, valid=[t * hop for t in lens])
+        host = pcm_pin[k & 1][: B * T * hop].view(B, T * hop)
         host.copy_(pcm, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
         if pending is not None:
             collect(pending)
         pending = (done, host, names, lens)
+        k += 1
     if pending is not None:
         collect(pending)
     return out

@@ -309,7 +309,10 @@ class FastDiff(nn.Module):
         return ct.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
     def _state_signature(self):
-        return tuple((k, v.data_ptr(), v._version) for k, v in self.state_dict(keep_vars=True).items())
+        # (name, storage, version) of every parameter: changes when a tensor is replaced (load_state_dict, .cuda(), remove_weight_norm)
+        # or written in place.  named_parameters() instead of state_dict(): the latter walks every module's hooks (1-5 ms per call,
+        # more than a B=1 sample call takes on the GPU)
+        return tuple((k, v.data_ptr(), v._version) for k, v in self.named_parameters())
 
     def _ready(self, device):
         """Create the context on `device` if needed and (re)upload weights when any parameter changed."""

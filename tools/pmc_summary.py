@@ -26,8 +26,10 @@ def fam(name):
     m = re.search(r"k_lvc_h2<(\d+)", name)            # the fp16-pipe LVC layer (hop 64, 256)
     if m:
         return "lvc_layer_h" + m.group(1)
-    if "k_lvc_h8<" in name:                           # the hop-8 layer: all VALU, one frame per wave
+    if "k_lvc_h8m<" in name:                          # the hop-8 layer on 16x16x32 fp16 matrix tiles
         return "lvc_layer_h8"
+    if "k_lvc_h8<" in name:                           # its all-VALU fp32 twin: an early-exit fallback launch in the default build
+        return "lvc_h8_fp32_fallback"
     if "k_lvc_layer<" in name:                        # fp32 kernel for hop 64 / 256: an early-exit fallback launch
         return "lvc_fp32_fallback"
     m = re.search(r"::(k_\w+)", name)
@@ -63,5 +65,6 @@ for k in sorted(acc, key=lambda k: -dur[k][0]):
             line += f" {n[3:]}={c[n]:.3g}"
     print(line)
 if "--json" in sys.argv:
+    traffic["_source"] = os.environ.get("PMC_SOURCE", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --no-graph, HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch")
     with open(sys.argv[sys.argv.index("--json") + 1], "w") as fh:
         json.dump(traffic, fh, indent=1, sort_keys=True)
