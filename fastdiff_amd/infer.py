@@ -76,21 +76,30 @@ def load_wav_inputs(model, test_input_dir: str, sample_rate: int = 22050, mel_va
     return items
 
 
-def collate_test_batch(items: Sequence[dict], drop_last_frame: bool = True):
-    """mels [B, 80, T'] zero-padded, lens [B] (frames kept per item), item_names -- the test-time collater."""
-    mels, lens, names = [], [], []
+def collate_test_batch(items: Sequence[dict], drop_last_frame: bool = True, out: "np.ndarray" = None):
+    """mels [B, 80, T'] zero-padded, lens [B] (frames kept per item), item_names -- the test-time collater.
+    The padding and the [T, 80] -> [80, T] transposition are plain numpy slice copies (torch's CPU kernels wake a whole OpenMP team
+    for these few hundred KB, which on a 256-core host now and then costs tens of milliseconds).  `out`: optional flat float32
+    buffer (e.g. pinned memory) that receives the batch; the returned tensor is then a view of it."""
+    kept, lens, names = [], [], []
     for it in items:
         c = it["mel"]
-        if drop_last_frame:
-            if c.shape[0] < 2:
-                continue                      # the reference prints "Removed short sample from batch" and skips it
-            c = c[: c.shape[0] - 1]
-        mels.append(c.transpose(0, 1).contiguous())       # [80, T']
-        lens.append(c.shape[0])
+        t = c.shape[0] - 1 if drop_last_frame else c.shape[0]
+        if drop_last_frame and c.shape[0] < 2:
+            continue                          # the reference cannot collate a one-frame item (dataset_utils.py:110 squeezes it away)
+        kept.append(c)
+        lens.append(t)
         names.append(it["item_name"])
-    if not mels:
+    if not kept:
         return None, [], []
-    return shard.pad_mels(mels), lens, names
+    B, C, T = len(kept), kept[0].shape[1], max(lens)
+    buf = np.empty(B * C * T, np.float32) if out is None else out[: B * C * T]
+    batch = buf.reshape(B, C, T)
+    for b, (c, t) in enumerate(zip(kept, lens)):
+        a = c.numpy() if isinstance(c, torch.Tensor) else np.asarray(c)
+        batch[b, :, :t] = a[:t].T
+        batch[b, :, t:] = 0.0
+    return torch.from_numpy(batch), lens, names
 
 
 def distributed_sampler_indices(n_items: int, rank: int, world_size: int) -> List[int]:
@@ -127,6 +136,7 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
     t_max, b_max = max(lengths), min(max_batch, len(items))
     mel_pin = [torch.empty(b_max * 80 * t_max, dtype=torch.float32).pin_memory() for _ in range(2)]
     pcm_pin = [torch.empty(b_max * t_max * hop, dtype=torch.int16).pin_memory() for _ in range(2)]
+    mel_np = [m.numpy() for m in mel_pin]      # the collater writes the batch straight into the pinned buffer
     pending = None                 # (event, pinned PCM view, names, lens) of the micro-batch still on its way to the host
 
     def collect(p):
@@ -137,14 +147,12 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
 
     k = 0
     for batch_idx in shard.micro_batches(range(len(items)), lengths, max_batch):
-        mels, lens, names = collate_test_batch([items[i] for i in batch_idx], drop_last_frame)
+        mels, lens, names = collate_test_batch([items[i] for i in batch_idx], drop_last_frame, out=mel_np[k & 1])
         if mels is None:
             continue
         uid_of = {items[i]["item_name"]: int(items[i].get("uid", i)) for i in batch_idx}
         B, _, T = mels.shape
-        mel_h = mel_pin[k & 1][: B * 80 * T].view(B, 80, T)
-        mel_h.copy_(mels)
-        mels = mel_h.cuda(non_blocking=True)
+        mels = mel_pin[k & 1][: B * 80 * T].view(B, 80, T).cuda(non_blocking=True)
         with torch.no_grad():
             wav = model.sample(mels, rows, ddim=False, seed=seed, lens=lens, stream_ids=[uid_of[n] for n in names])
         # one epilogue call and one asynchronous copy per micro-batch; the previous batch is unpacked on the host while this one runs
@@ -176,7 +184,7 @@ def synthesize_sharded(model, items, n_steps: int = 4, max_batch: int = 8, seed:
     meta = [None]
     if rank == src:      # the collater's view of every item: [80, T'] with the last frame dropped, too-short items left out
         kept = [(i, it) for i, it in enumerate(items) if not drop_last_frame or it["mel"].shape[0] >= 2]
-        mels = [(it["mel"][: it["mel"].shape[0] - 1] if drop_last_frame else it["mel"]).transpose(0, 1).contiguous() for _, it in kept]
+        mels = [torch.from_numpy(np.ascontiguousarray(it["mel"].numpy()[: it["mel"].shape[0] - (1 if drop_last_frame else 0)].T)) for _, it in kept]
         meta = [([it["item_name"] for _, it in kept], [int(it.get("uid", i)) for i, it in kept])]
     dist.broadcast_object_list(meta, src=src)
     names, uids = meta[0]
