@@ -2,9 +2,10 @@
 
 Drop-in names of the reference:
     fastdiff_amd.FastDiff                          <- modules.FastDiff.module.FastDiff_model.FastDiff
-    fastdiff_amd.sampler (alias fastdiff_amd.util): sampling_given_noise_schedule, compute_hyperparams_given_schedule, noise_scheduling, theta_timestep_loss (forward only), ...
+    fastdiff_amd.sampler (alias fastdiff_amd.util): sampling_given_noise_schedule, compute_hyperparams_given_schedule, noise_scheduling, theta_timestep_loss (under no_grad and under autograd), ...
                                                    <- modules.FastDiff.module.util
     fastdiff_amd.location_variable_convolution     <- TimeAware_LVCBlock.location_variable_convolution (modules.py:220-253), forward AND backward
+FastDiff.forward in train() mode records an autograd graph (fastdiff_amd/train.py) whose LVC nodes are that operator.
 """
 from .model import FastDiff  # noqa: F401
 from . import sampler, schedules  # noqa: F401

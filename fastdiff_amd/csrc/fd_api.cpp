@@ -229,6 +229,7 @@ int fd_destroy(fd_handle h)
     free_workspace(h);
     for (void *p : h->dev_allocs) hipFree(p);
     if (h->scratch) hipFree(h->scratch);
+    if (h->lvc_scratch) hipFree(h->lvc_scratch);
     for (auto &sl : h->stage) {
         if (sl.host) hipHostFree(sl.host);
         if (sl.done) hipEventDestroy(sl.done);
@@ -1156,6 +1157,24 @@ static int check_lvc_op(fd_handle h, int B, int Cin, int Cout, int ks, int T, in
     return FD_OK;
 }
 
+// The matrix-pipe kernels of the operator read the predicted kernels frame-major: room for one copy (B*T*Cin*Cout*ks floats), kept on
+// the handle and grown when a call needs more (hipFree waits for the device, so work in flight on the old buffer is safe).  Calls on
+// one handle share it: they must be ordered on one stream, as torch.autograd orders a forward and its backward.
+static int lvc_scratch(fd_handle h, int B, int Cin, int Cout, int ks, int T, int hop, float **out)
+{
+    *out = nullptr;
+    if (!fdk::lvc_op_needs_scratch(Cin, Cout, ks, hop)) return FD_OK;
+    const size_t bytes = sizeof(float) * (size_t)B * T * Cin * Cout * ks;
+    if (h->lvc_scratch_bytes < bytes) {
+        if (h->lvc_scratch) FD_HIP(h, hipFree(h->lvc_scratch));
+        h->lvc_scratch = nullptr; h->lvc_scratch_bytes = 0;
+        FD_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->lvc_scratch), bytes));
+        h->lvc_scratch_bytes = bytes;
+    }
+    *out = h->lvc_scratch;
+    return FD_OK;
+}
+
 int fd_lvc_forward(fd_handle h, const float *x, const float *kernel, const float *bias, int B, int Cin, int Cout, int ks, int T, int hop,
                    float *out, void *stream)
 {
@@ -1164,8 +1183,10 @@ int fd_lvc_forward(fd_handle h, const float *x, const float *kernel, const float
     int rc = check_lvc_op(h, B, Cin, Cout, ks, T, hop, "fd_lvc_forward");
     if (rc != FD_OK) return rc;
     FD_HIP(h, hipSetDevice(h->device));
+    float *scratch = nullptr;
+    if ((rc = lvc_scratch(h, B, Cin, Cout, ks, T, hop, &scratch)) != FD_OK) return rc;
     fdk::Launch L = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::lvc_op_forward(L, x, kernel, bias, out, B, Cin, Cout, ks, T, hop);
+    hipError_t e = fdk::lvc_op_forward(L, x, kernel, bias, out, B, Cin, Cout, ks, T, hop, scratch);
     if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_lvc_forward: %s", hipGetErrorString(e));
     return FD_OK;
 }
@@ -1178,8 +1199,11 @@ int fd_lvc_backward(fd_handle h, const float *x, const float *kernel, const floa
     int rc = check_lvc_op(h, B, Cin, Cout, ks, T, hop, "fd_lvc_backward");
     if (rc != FD_OK) return rc;
     FD_HIP(h, hipSetDevice(h->device));
+    float *scratch = nullptr;
+    if ((rc = lvc_scratch(h, B, Cin, Cout, ks, T, hop, &scratch)) != FD_OK) return rc;
+    if (scratch && dx && !kernel) FD_FAIL(h, FD_ERR_INVALID, "fd_lvc_backward: null pointer");
     fdk::Launch L = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::lvc_op_backward(L, x, kernel, dout, dx, dkernel, dbias, B, Cin, Cout, ks, T, hop);
+    hipError_t e = fdk::lvc_op_backward(L, x, kernel, dout, dx, dkernel, dbias, B, Cin, Cout, ks, T, hop, scratch);
     if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_lvc_backward: %s", hipGetErrorString(e));
     return FD_OK;
 }

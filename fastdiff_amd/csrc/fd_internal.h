@@ -204,6 +204,8 @@ struct fd_context {
     int *flags_host = nullptr;               // pinned, 32 words: the sticky flags of the pending call
     hipEvent_t flags_done = nullptr;
     void *scratch = nullptr;                 // 64 KB device scratch (abs-max words, ...)
+    float *lvc_scratch = nullptr;            // the LVC operator's frame-major kernel copy (fd_lvc_forward / fd_lvc_backward), grown on demand
+    size_t lvc_scratch_bytes = 0;
     std::vector<ProfEntry> prof_pending;
     std::vector<hipEvent_t> event_pool;
     std::map<std::string, std::pair<int64_t, double>> prof_acc;

@@ -21,8 +21,10 @@ hipError_t fast_convt(const Launch &L, int n, const float *x_in, float *x_out, i
 hipError_t fast_lvc_layer(const Launch &L, int n, int layer, const float *x_in, const float *skip, float *x_out, int B, int T);
 hipError_t fast_final(const Launch &L, const StepIO &io, const float *x32, int B, int T);
 // the LVC operator with its gradients (fd_kernels_train.hip)
+// scratch: B*T*Cin*Cout*ks floats when lvc_op_needs_scratch (the model's shape: matrix-pipe kernels), else unused
+bool lvc_op_needs_scratch(int Cin, int Cout, int ks, int hop);
 hipError_t lvc_op_forward(const Launch &L, const float *x, const float *K, const float *bias, float *out, int B, int Cin, int Cout, int ks,
-                          int T, int hop);
+                          int T, int hop, float *scratch);
 hipError_t lvc_op_backward(const Launch &L, const float *x, const float *K, const float *dout, float *dx, float *dK, float *dbias, int B,
-                           int Cin, int Cout, int ks, int T, int hop);
+                           int Cin, int Cout, int ks, int T, int hop, float *scratch);
 }  // namespace fdk

@@ -3,11 +3,347 @@
 // (modules/FastDiff/module/modules.py:220-253 with dilation = 1, the only value the model passes, modules.py:216), in the REFERENCE's
 // own tensor layouts: x [B,Cin,L], K [B,Cin,Cout,ks,T] (T innermost), bias [B,Cout,T], out [B,Cout,L], L = T * hop.  This is what the
 // reference's training step (theta_timestep_loss, util.py:291-325) differentiates through twelve times per forward; everything else
-// of that step can stay on PyTorch autograd around it.  Plain fp32 VALU kernels: correctness first, the training side is not the
-// measured hot path.
+// of that step stays on PyTorch autograd around it (fastdiff_amd/train.py).
+//
+// Two kernel sets.  The model's own shape (Cin 32, Cout 64, ks 3, hop 8 / 64 / 256) runs on the exact-fp32 matrix instruction
+// (v_mfma_f32_32x32x2_f32: training keeps fp32 products, no operand range to watch): per frame the operator is a small GEMM,
+//   forward   Out_l [64 x hop] = K_l [64 x 96] Xwin_l [96 x hop]            dx   dX_l [32 x hop] = K_l' [32 x 192] dOutwin_l [192 x hop]
+//   dK_l [64 x 96] = dOut_l [64 x hop] Xwin_l' [hop x 96]
+// and the only awkward part is the reference's kernel layout, T innermost: a frame's 6144 coefficients lie T floats apart.  They are
+// brought into frame-major order by a tiled transpose whose row order is the matrix instruction's A-operand order (one coalesced
+// float4 per lane and four k-steps), the main kernels then stream them once; dK leaves its kernel frame-major in the accumulator
+// layout and a second transpose puts it back.  The scratch buffer of B*T*6144 floats comes from the caller (fd_api.cpp).
+// Any other shape takes the plain one-thread-per-output VALU kernels at the end of the file.
 #include "fd_kernels.h"
 
 namespace fdk_train {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float f4c(const float4 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+// D layout of the 32x32 tile: register r of lane (col = lane & 31, hi = lane >> 5) is row (r & 3) + 8 (r >> 2) + 4 hi
+__device__ __forceinline__ int drow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+constexpr int MI = 32, MO = 64, MK = 3, ME = MI * MO * MK;      // the model's operator: 6144 coefficients per frame
+
+// Frame-major orders: position e of a frame's 6144 floats -> row (i*64 + o)*3 + k of the reference layout [B, Cin, Cout, ks, T].
+// e = (group*64 + lane)*4 + j: the float4 a lane loads covers four consecutive k-steps (j) of one 32x32x2 operand column.
+enum { ORDER_FWD = 0, ORDER_DX = 1, ORDER_DK = 2 };
+template <int ORDER>
+__device__ __forceinline__ int row_of(int e)
+{
+    const int j = e & 3, lane = (e >> 2) & 63, grp = e >> 8, l31 = lane & 31, hi = lane >> 5;
+    int i, o, k;
+    if (ORDER == ORDER_FWD) {          // A[o][tap*32 + i]: grp = mt*12 + sq, k index = 2 (4 sq + j) + hi
+        const int mt = grp / 12, sq = grp - 12 * mt, kidx = 2 * (4 * sq + j) + hi;
+        o = 32 * mt + l31; k = kidx >> 5; i = kidx & 31;
+    } else if (ORDER == ORDER_DX) {    // A[i][tap*64 + o]: grp = sq (24), k index = 2 (4 sq + j) + hi
+        const int kidx = 2 * (4 * grp + j) + hi;
+        i = l31; k = kidx >> 6; o = kidx & 63;
+    } else {                           // the dK accumulators: grp = ((mt*3 + tap)*4 + g), rows 32 mt + 8 g + 4 hi + j, column i
+        const int g = grp & 3, t6 = grp >> 2, mt = t6 / 3;
+        k = t6 - 3 * mt; o = 32 * mt + 8 * g + 4 * hi + j; i = l31;
+    }
+    return (i * MO + o) * MK + k;
+}
+
+// K [B][6144 rows][T] -> frame-major [B][T][6144] in ORDER (64 x 64 tiles through LDS, both sides coalesced)
+template <int ORDER>
+__global__ void __launch_bounds__(256) k_lvc_pack(const float *__restrict__ K, float *__restrict__ Kf, int T)
+{
+    __shared__ float tile[64][65];
+    const int l0 = blockIdx.x * 64, e0 = blockIdx.y * 64, b = blockIdx.z, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int el = w * 16 + r, l = l0 + lane;
+        tile[el][lane] = l < T ? K[((int64_t)b * ME + row_of<ORDER>(e0 + el)) * T + l] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int ll = w * 16 + r, l = l0 + ll;
+        if (l < T) Kf[((int64_t)b * T + l) * ME + e0 + lane] = tile[lane][ll];
+    }
+}
+
+// frame-major dK (ORDER_DK) -> dK [B][6144 rows][T]
+__global__ void __launch_bounds__(256) k_lvc_unpack(const float *__restrict__ Kf, float *__restrict__ K, int T)
+{
+    __shared__ float tile[64][65];
+    const int l0 = blockIdx.x * 64, e0 = blockIdx.y * 64, b = blockIdx.z, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int ll = w * 16 + r, l = l0 + ll;
+        tile[ll][lane] = l < T ? Kf[((int64_t)b * T + l) * ME + e0 + lane] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int el = w * 16 + r, l = l0 + lane;
+        if (l < T) K[((int64_t)b * ME + row_of<ORDER_DK>(e0 + el)) * T + l] = tile[lane][el];
+    }
+}
+
+// Work split of the forward and dx kernels.  Workgroup = 256 threads = W columns: hop 256: one frame, hop 64: four frames, hop 8: four
+// frames (32 columns).  Forward: hop 256: wave = (row tile, column half), 4 column tiles; hop 64 / 8: wave = frame, both row tiles.
+// LDS rows: [3 pad][halo][W columns][halo][3 pad], so that the W columns are 16 B aligned (column c of the tile at index c + 4).
+template <int HOP>
+struct LvcGeo {
+    static constexpr int W = HOP == 8 ? 32 : 256, FPW = W / HOP, LD = W + 8, C0 = 4;
+};
+
+// rows x (W + 2 halo) of a [rows][L] tensor into LDS, zero outside the signal: float4 for the aligned centre, scalars for the halo;
+// every load is issued before the first LDS write
+template <int ROWS, int W, int LD>
+__device__ __forceinline__ void stage_rows(float *__restrict__ lds, const float *__restrict__ src, int L, int q0, int tid)
+{
+    constexpr int NF4 = ROWS * (W / 4), NV = (NF4 + 255) / 256, NH = (2 * ROWS + 255) / 256;
+    float4 v[NV];
+    float hv[NH];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int idx = k * 256 + tid, r = idx / (W / 4), c4 = idx - r * (W / 4), q = q0 + 4 * c4;
+        v[k] = (idx < NF4 && q < L) ? *reinterpret_cast<const float4 *>(src + (int64_t)r * L + q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+        const int idx = k * 256 + tid, r = idx >> 1, q = (idx & 1) ? q0 + W : q0 - 1;
+        hv[k] = (idx < 2 * ROWS && q >= 0 && q < L) ? src[(int64_t)r * L + q] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int idx = k * 256 + tid, r = idx / (W / 4), c4 = idx - r * (W / 4);
+        if (idx < NF4) *reinterpret_cast<float4 *>(lds + r * LD + 4 + 4 * c4) = v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+        const int idx = k * 256 + tid, r = idx >> 1;
+        if (idx < 2 * ROWS) lds[r * LD + ((idx & 1) ? 4 + W : 3)] = hv[k];
+    }
+}
+
+template <int HOP>
+__global__ void __launch_bounds__(256, HOP == 256 ? 3 : 2) k_lvc_fwd_mfma(const float *__restrict__ x, const float *__restrict__ Kf,
+                                                                        const float *__restrict__ bias, float *__restrict__ out, int T)
+{
+    using G = LvcGeo<HOP>;
+    constexpr int W = G::W, LD = G::LD, NMT = HOP == 256 ? 1 : 2, NCT = HOP == 256 ? 4 : (HOP == 64 ? 2 : 1);
+    __shared__ __attribute__((aligned(16))) float xs[MI * LD];
+    const int L = T * HOP, b = blockIdx.y, q0 = blockIdx.x * W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, hi = lane >> 5;
+    const int f = HOP == 256 ? blockIdx.x : blockIdx.x * G::FPW + wave;          // this wave's frame
+    const int mt0 = HOP == 256 ? (wave & 1) : 0;
+    const int cbase = HOP == 256 ? 128 * (wave >> 1) : HOP * wave;               // first column of the wave inside the tile
+    const bool wave_valid = f < T;
+    float4 a[NMT][12];
+    if (wave_valid) {
+        const float4 *ap = reinterpret_cast<const float4 *>(Kf + ((int64_t)b * T + f) * ME);
+#pragma unroll
+        for (int m = 0; m < NMT; ++m)
+#pragma unroll
+            for (int sq = 0; sq < 12; ++sq) a[m][sq] = ap[((mt0 + m) * 12 + sq) * 64 + lane];
+    }
+    stage_rows<MI, W, LD>(xs, x + (int64_t)b * MI * L, L, q0, tid);
+    __syncthreads();
+    if (!wave_valid) return;
+    const int colc = HOP == 8 ? min(col, HOP - 1) : col;      // hop 8: a tile is one frame, 8 of its 32 columns exist
+    float bz[NMT][16];
+    {
+        const float *bp = bias + ((int64_t)b * MO + 32 * mt0 + 4 * hi) * T + f;
+#pragma unroll
+        for (int m = 0; m < NMT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bz[m][r] = bp[(32 * m + (r & 3) + 8 * (r >> 2)) * T];
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        f32x16 acc[NMT];
+#pragma unroll
+        for (int m = 0; m < NMT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = bz[m][r];
+        const int cl = G::C0 - 1 + cbase + 32 * ct + colc;    // x[q + tap - 1] = xs[.][C0 + (q - q0) + tap - 1]
+#pragma unroll
+        for (int s = 0; s < 48; ++s) {
+            const float v = xs[(2 * (s & 15) + hi) * LD + cl + (s >> 4)];
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) acc[m] = mfma32(f4c(a[m][s >> 2], s & 3), v, acc[m]);
+        }
+        if (HOP != 8 || col < HOP) {
+            const int q = q0 + cbase + 32 * ct + col;
+#pragma unroll
+            for (int m = 0; m < NMT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) out[((int64_t)b * MO + 32 * (mt0 + m) + drow(r, hi)) * L + q] = acc[m][r];
+        }
+    }
+}
+
+// dx.  Wave = 64 columns (hop 8: one frame), one 32-row tile, k = (tap, o).  The matrix part covers the taps that stay inside the
+// column's own frame; a frame's first and last column also see the neighbour frames' kernels,
+//   dx[i, l hop] += sum_o dout[o, l hop - 1] K[i, o, 2, l-1]          dx[i, (l+1) hop - 1] += sum_o dout[o, (l+1) hop] K[i, o, 0, l+1],
+// 2 x 32 sums of 64 products per frame: the wave that owns the column computes them on VALU (lane = (i, parity of o): its eight
+// float4 of the neighbour frame's operand copy are exactly those coefficients) and adds them before the store.
+template <int HOP>
+__global__ void __launch_bounds__(256, 2) k_lvc_dx_mfma(const float *__restrict__ dout, const float *__restrict__ Kx, float *__restrict__ dx,
+                                                        int T)
+{
+    using G = LvcGeo<HOP>;
+    constexpr int W = G::W, LD = G::LD, NCT = HOP == 8 ? 1 : 2;
+    __shared__ __attribute__((aligned(16))) float ds[MO * LD];
+    const int L = T * HOP, b = blockIdx.y, q0 = blockIdx.x * W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, hi = lane >> 5;
+    const int f = HOP == 256 ? blockIdx.x : blockIdx.x * G::FPW + wave;
+    const int cbase = HOP == 8 ? HOP * wave : 64 * wave;
+    const int fbase = HOP == 256 ? 0 : HOP * wave;            // the frame's first column inside the tile
+    const bool wave_valid = f < T;
+    const bool own_first = HOP == 256 ? wave == 0 : true, own_last = HOP == 256 ? wave == 3 : true;
+    float4 a[24], ef[8], el[8];
+    const bool edge_f = wave_valid && own_first && f > 0, edge_l = wave_valid && own_last && f + 1 < T;
+    if (wave_valid) {
+        const float4 *ap = reinterpret_cast<const float4 *>(Kx + ((int64_t)b * T + f) * ME);
+#pragma unroll
+        for (int sq = 0; sq < 24; ++sq) a[sq] = ap[sq * 64 + lane];
+#pragma unroll
+        for (int sq = 0; sq < 8; ++sq) {
+            ef[sq] = edge_f ? (ap - ME / 4)[(16 + sq) * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);      // frame f-1, tap 2
+            el[sq] = edge_l ? (ap + ME / 4)[sq * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);             // frame f+1, tap 0
+        }
+    }
+    stage_rows<MO, W, LD>(ds, dout + (int64_t)b * MO * L, L, q0, tid);
+    __syncthreads();
+    if (!wave_valid) return;
+    // lane (i = col, parity hi): o = 2 (4 sq + j) + hi
+    float e0 = 0.0f, e1 = 0.0f;
+    {
+        const float *d0 = ds + G::C0 + fbase - 1, *d1 = ds + G::C0 + fbase + HOP;
+#pragma unroll
+        for (int sq = 0; sq < 8; ++sq)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int o = 2 * (4 * sq + j) + hi;
+                e0 = fmaf(f4c(ef[sq], j), d0[o * LD], e0);
+                e1 = fmaf(f4c(el[sq], j), d1[o * LD], e1);
+            }
+        e0 += __shfl_xor(e0, 32, 64);
+        e1 += __shfl_xor(e1, 32, 64);
+    }
+    const int colc = HOP == 8 ? min(col, HOP - 1) : col;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const int pl = cbase + 32 * ct + colc, pf = pl % HOP;       // column inside the tile / inside its frame
+        const bool first = pf == 0, last = pf == HOP - 1;
+        // dx[p] += dout[q] K[., ., tap], q = p - tap + 1 = ds[.][C0 + p - q0 + 1 - tap]; q must lie in p's own frame
+#pragma unroll
+        for (int s = 0; s < 96; ++s) {
+            const int tap = s >> 5;
+            float v = ds[(2 * (s & 31) + hi) * LD + G::C0 + pl + 1 - tap];
+            if (tap == 0) v = last ? 0.0f : v;
+            if (tap == 2) v = first ? 0.0f : v;
+            acc = mfma32(f4c(a[s >> 2], s & 3), v, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {      // (every lane takes part in the shuffles)
+            const float g0 = __shfl(e0, drow(r, hi), 64), g1 = __shfl(e1, drow(r, hi), 64);
+            acc[r] += (first ? g0 : 0.0f) + (last ? g1 : 0.0f);
+        }
+        if (HOP != 8 || col < HOP) {
+            const int p = q0 + cbase + 32 * ct + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dx[((int64_t)b * MI + drow(r, hi)) * L + p] = acc[r];
+        }
+    }
+}
+
+// dK and dbias of one frame: 3 waves, wave = tap, both row tiles; the frame goes through LDS CH columns at a time (A: lanes along
+// the rows of dout, B: lanes along the channels of x -- both row strides odd, so conflict-free), the next chunk's loads in flight
+// under the current chunk's matrix work.  dK stays frame-major (ORDER_DK).
+template <int CH>
+__global__ void __launch_bounds__(192) k_lvc_dk_mfma(const float *__restrict__ x, const float *__restrict__ dout, float *__restrict__ dKf,
+                                                     float *__restrict__ dbias, int T, int hop)
+{
+    constexpr int DLD = CH + 1, XLD = CH + 3, C4 = CH / 4;
+    constexpr int ND = (MO * C4 + 191) / 192, NX = (MI * C4 + 191) / 192;
+    __shared__ float ds[MO * DLD];
+    __shared__ float xs[MI * XLD];
+    __shared__ float red[3][MO];
+    const int L = T * hop, l = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const float *dp = dout + (int64_t)b * MO * L, *xp = x + (int64_t)b * MI * L;
+    float4 dv[ND], xv[NX];
+    float hv = 0.0f;
+    auto load_chunk = [&](int qc) {
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            const int idx = k * 192 + tid, o = idx / C4, c4 = idx - o * C4;
+            dv[k] = idx < MO * C4 ? *reinterpret_cast<const float4 *>(dp + (int64_t)o * L + qc + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int idx = k * 192 + tid, i = idx / C4, c4 = idx - i * C4;
+            xv[k] = idx < MI * C4 ? *reinterpret_cast<const float4 *>(xp + (int64_t)i * L + qc + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (tid < 2 * MI) {
+            const int q = (tid & 1) ? qc + CH : qc - 1;
+            hv = (q >= 0 && q < L) ? xp[(int64_t)(tid >> 1) * L + q] : 0.0f;
+        }
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+    float accb = 0.0f;
+    load_chunk(l * hop);
+    for (int s0 = 0; s0 < hop; s0 += CH) {
+        __syncthreads();                     // the previous chunk's reads are done
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            const int idx = k * 192 + tid, o = idx / C4, c4 = idx - o * C4;
+            if (idx < MO * C4) {
+                float *w = ds + o * DLD + 4 * c4;
+                w[0] = dv[k].x; w[1] = dv[k].y; w[2] = dv[k].z; w[3] = dv[k].w;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int idx = k * 192 + tid, i = idx / C4, c4 = idx - i * C4;
+            if (idx < MI * C4) {
+                float *w = xs + i * XLD + 1 + 4 * c4;
+                w[0] = xv[k].x; w[1] = xv[k].y; w[2] = xv[k].z; w[3] = xv[k].w;
+            }
+        }
+        if (tid < 2 * MI) xs[(tid >> 1) * XLD + ((tid & 1) ? CH + 1 : 0)] = hv;
+        __syncthreads();
+        if (s0 + CH < hop) load_chunk(l * hop + s0 + CH);
+#pragma unroll 8
+        for (int st = 0; st < CH / 2; ++st) {
+            const int sc = 2 * st + hi;
+            const float bv = xs[l31 * XLD + sc + tap];                 // x[q + tap - 1]
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[m] = mfma32(ds[(32 * m + l31) * DLD + sc], bv, acc[m]);
+        }
+        for (int c = tap; c < CH; c += 3) accb += ds[lane * DLD + c];   // thread = (row lane, every third column)
+    }
+    if (dKf) {
+        float4 *dst = reinterpret_cast<float4 *>(dKf + ((int64_t)b * T + l) * ME);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                dst[(((m * 3 + tap) * 4 + g) * 64) + lane] = make_float4(acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]);
+    }
+    if (dbias) {
+        red[tap][lane] = accb;
+        __syncthreads();
+        if (tid < MO) dbias[((int64_t)b * MO + tid) * T + l] = red[0][tid] + red[1][tid] + red[2][tid];
+    }
+}
+
+// ---- any other shape: one thread per output ------------------------------------------------------------------------------------
 
 // thread = one output (b, o, q); lanes run along q: x reads are coalesced, the K element is the same for every lane of a frame
 __global__ void __launch_bounds__(256) k_lvc_fwd(const float *__restrict__ x, const float *__restrict__ K, const float *__restrict__ bias,
@@ -103,22 +439,47 @@ __global__ void __launch_bounds__(256) k_lvc_bwd_k(const float *__restrict__ x, 
 namespace fdk {
 using namespace fdk_train;
 
+static bool model_shape(int Cin, int Cout, int ks, int hop) { return Cin == MI && Cout == MO && ks == MK && (hop == 8 || hop == 64 || hop == 256); }
+bool lvc_op_needs_scratch(int Cin, int Cout, int ks, int hop) { return model_shape(Cin, Cout, ks, hop); }
+
 hipError_t lvc_op_forward(const Launch &L, const float *x, const float *K, const float *bias, float *out, int B, int Cin, int Cout, int ks,
-                          int T, int hop)
+                          int T, int hop, float *scratch)
 {
     const int Ln = T * hop;
-    FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd, dim3((Ln + 255) / 256, Cout, B), dim3(256), 0, x, K, bias, out, Cin, Cout, ks, T, hop);
+    if (!scratch || !model_shape(Cin, Cout, ks, hop)) {
+        FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd, dim3((Ln + 255) / 256, Cout, B), dim3(256), 0, x, K, bias, out, Cin, Cout, ks, T, hop);
+        return hipSuccess;
+    }
+    FD_LAUNCH(L, "lvc_op_pack", k_lvc_pack<ORDER_FWD>, dim3((T + 63) / 64, ME / 64, B), dim3(256), 0, K, scratch, T);
+    if (hop == 256) FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd_mfma<256>, dim3(T, B), dim3(256), 0, x, scratch, bias, out, T);
+    else if (hop == 64) FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd_mfma<64>, dim3((T + 3) / 4, B), dim3(256), 0, x, scratch, bias, out, T);
+    else FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd_mfma<8>, dim3((T + 3) / 4, B), dim3(256), 0, x, scratch, bias, out, T);
     return hipSuccess;
 }
 
 hipError_t lvc_op_backward(const Launch &L, const float *x, const float *K, const float *dout, float *dx, float *dK, float *dbias, int B,
-                           int Cin, int Cout, int ks, int T, int hop)
+                           int Cin, int Cout, int ks, int T, int hop, float *scratch)
 {
     const int Ln = T * hop;
-    if (dx) FD_LAUNCH(L, "lvc_op_backward_x", k_lvc_bwd_x, dim3((Ln + 255) / 256, Cin, B), dim3(256), 0, dout, K, dx, Cin, Cout, ks, T, hop);
+    if (!scratch || !model_shape(Cin, Cout, ks, hop)) {
+        if (dx) FD_LAUNCH(L, "lvc_op_backward_x", k_lvc_bwd_x, dim3((Ln + 255) / 256, Cin, B), dim3(256), 0, dout, K, dx, Cin, Cout, ks, T, hop);
+        if (dK || dbias) {
+            const size_t shmem = sizeof(float) * ((size_t)Cout * DK_CHUNK + (size_t)Cin * (DK_CHUNK + ks - 1));
+            FD_LAUNCH(L, "lvc_op_backward_k", k_lvc_bwd_k, dim3(T, B), dim3(256), shmem, x, dout, dK, dbias, Cin, Cout, ks, T, hop);
+        }
+        return hipSuccess;
+    }
+    if (dx) {
+        FD_LAUNCH(L, "lvc_op_pack", k_lvc_pack<ORDER_DX>, dim3((T + 63) / 64, ME / 64, B), dim3(256), 0, K, scratch, T);
+        if (hop == 256) FD_LAUNCH(L, "lvc_op_backward_x", k_lvc_dx_mfma<256>, dim3(T, B), dim3(256), 0, dout, scratch, dx, T);
+        else if (hop == 64) FD_LAUNCH(L, "lvc_op_backward_x", k_lvc_dx_mfma<64>, dim3((T + 3) / 4, B), dim3(256), 0, dout, scratch, dx, T);
+        else FD_LAUNCH(L, "lvc_op_backward_x", k_lvc_dx_mfma<8>, dim3((T + 3) / 4, B), dim3(256), 0, dout, scratch, dx, T);
+    }
     if (dK || dbias) {
-        const size_t shmem = sizeof(float) * ((size_t)Cout * DK_CHUNK + (size_t)Cin * (DK_CHUNK + ks - 1));
-        FD_LAUNCH(L, "lvc_op_backward_k", k_lvc_bwd_k, dim3(T, B), dim3(256), shmem, x, dout, dK, dbias, Cin, Cout, ks, T, hop);
+        float *dKf = dK ? scratch : nullptr;      // (the dx kernels are done with the scratch: same stream)
+        if (hop == 8) FD_LAUNCH(L, "lvc_op_backward_k", k_lvc_dk_mfma<8>, dim3(T, B), dim3(192), 0, x, dout, dKf, dbias, T, hop);
+        else FD_LAUNCH(L, "lvc_op_backward_k", k_lvc_dk_mfma<64>, dim3(T, B), dim3(192), 0, x, dout, dKf, dbias, T, hop);
+        if (dK) FD_LAUNCH(L, "lvc_op_unpack", k_lvc_unpack, dim3((T + 63) / 64, ME / 64, B), dim3(256), 0, scratch, dK, T);
     }
     return hipSuccess;
 }

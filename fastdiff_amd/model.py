@@ -3,9 +3,11 @@
 `FastDiff` keeps the reference's constructor signature, parameter names / shapes / registration order
 (so `state_dict()`, `load_state_dict(ckpt['state_dict']['model'])`, `.cuda()`, `.eval()` behave as for
 modules/FastDiff/module/FastDiff_model.py:10-122) and the `forward(data)` contract
-(FastDiff_model.py:74-102).  The torch.nn sub-modules below are parameter holders only: no
-PyTorch op runs on the compute path -- forward() hands raw device pointers to the C ABI
-(include/fastdiff_hip.h).  There is no CPU fallback: without the HIP library or a HIP device it raises.
+(FastDiff_model.py:74-102).  On the inference path the torch.nn sub-modules below are parameter holders only: no
+PyTorch op runs there -- forward() hands raw device pointers to the C ABI (include/fastdiff_hip.h).  Under autograd
+(train() mode, or an input that requires a gradient) forward() records the same network as autograd nodes with the
+location-variable convolutions on the HIP operator, forward and backward (fastdiff_amd/train.py).
+There is no CPU fallback: without the HIP library or a HIP device it raises.
 """
 import ctypes as ct
 
@@ -138,6 +140,14 @@ class FastDiff(nn.Module):
         """eps = net((audio [B,1,L], c [B,80,T] or [80,T], diffusion_steps [B,1])) -- FastDiff_model.py:74-102.
         lens (extension, optional): valid frames per utterance of a zero-padded batch, see sample()."""
         audio, c, diffusion_steps = data
+        if torch.is_grad_enabled() and (self.training or audio.requires_grad or c.requires_grad):
+            # training (FastDiff.py:44-49): the same network as autograd nodes, the location-variable convolutions forward and
+            # backward on the HIP operator (fastdiff_amd/train.py)
+            if lens is not None:
+                raise NotImplementedError("lens is an extension of the inference path; under autograd pass whole utterances")
+            self._require_device(audio, c)
+            from .train import differentiable_forward
+            return differentiable_forward(self, (audio.float(), self._prep_condition(c, audio.shape[0], audio.device), diffusion_steps))
         self._require_inference(audio, c)
         audio = audio.contiguous().float()
         B, ch, L = audio.shape
@@ -286,14 +296,18 @@ class FastDiff(nn.Module):
         return _capi.load().fd_bias_index(layer, out_ch)
 
     # ---- internals ----------------------------------------------------------------------------------------
-    def _require_inference(self, *tensors):
+    @staticmethod
+    def _require_device(*tensors):
         for t in tensors:
             if not t.is_cuda:
                 raise RuntimeError("fastdiff_amd.FastDiff runs only on a HIP device (no CPU fallback): move the module "
                                    "and its inputs to cuda")
+
+    def _require_inference(self, *tensors):
+        self._require_device(*tensors)
         if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
-            raise NotImplementedError("fastdiff_amd implements the inference path only; training "
-                                      "(theta_timestep_loss, util.py:291-325) stays on the PyTorch module")
+            raise NotImplementedError("this entry point is the inference pipeline (no saved activations): only FastDiff.forward "
+                                      "records an autograd graph (fastdiff_amd/train.py)")
 
     def _prep_condition(self, c, B, device):
         c = c.to(device=device, dtype=torch.float32)

@@ -187,9 +187,10 @@ def sampling_given_noise_schedule(net, size, diffusion_hyperparams, inference_no
 def theta_timestep_loss(net, X, diffusion_hyperparams, reverse=False):
     """MSE(eps_theta(x_t, mel, t), z) at a random training step per item; same signature as util.py:291-325.
 
-    This is the quantity FastDiffTask.validation_step reports (FastDiff.py:52-57): one denoiser evaluation, no autograd, so it runs
-    on the HIP module as is.  _training_step (FastDiff.py:44-49) calls the same function with gradients enabled: the HIP module
-    has no backward and says so (NotImplementedError from FastDiff.forward) -- training stays on the PyTorch module.
+    FastDiffTask.validation_step reports this quantity under no_grad (FastDiff.py:52-57): one denoiser evaluation on the inference
+    kernels.  _training_step (FastDiff.py:44-49) calls the same function with the module in train() mode and autograd recording:
+    FastDiff.forward then builds the graph of fastdiff_amd/train.py (location-variable convolutions forward and backward on the HIP
+    operator), and loss.backward() fills the gradients of the module's weight_g / weight_v / bias parameters.
     Random draws follow the reference order: torch.randint for the steps, then std_normal for z (both on the CPU generator)."""
     assert type(X) == tuple and len(X) == 2
     mel_spectrogram, audio = X

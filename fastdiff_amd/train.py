@@ -1,0 +1,87 @@
+"""The denoiser under autograd: what `FastDiffTask._training_step` (FastDiff.py:44-49) differentiates through
+`theta_timestep_loss` (util.py:291-325).
+
+The inference path (fd_forward / fd_sample) is one hand-written pipeline with no saved activations; training needs them, and needs
+gradients with respect to 175 parameter tensors.  Split used here: the location-variable convolution -- twelve calls per forward,
+each reading a predicted kernel 6144 x T floats large, the operator the reference implements with unfold + einsum over a
+[B, C, T, hop + 2, 3] view (modules.py:220-253) -- runs forward AND backward on the HIP operator
+(fastdiff_amd.location_variable_convolution: fd_lvc_forward / fd_lvc_backward); the plain convolutions, linear layers and
+activations around it are torch.autograd nodes on the module's own parameters (weight-norm included: the sub-modules of
+fastdiff_amd.FastDiff are real nn.Conv1d / nn.Linear holders with the reference's weight_g / weight_v parametrisation), so the
+reference's optimizer, checkpointing and DDP wrapper see the module they expect.  FastDiff.forward takes this path when autograd is
+recording and the module is in train() mode or an input requires a gradient; everything else stays on the inference kernels.
+
+`lvc` (tests only): a replacement for the HIP operator with the same signature, so that the structure around it can be pinned on
+the reference's gradients on a machine without a GPU; the product never passes it.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def step_embedding(diffusion_steps, dim_in):
+    """calc_diffusion_step_embedding (util.py:407-432): [sin(t w_j), cos(t w_j)], w_j = 10000^(-j / (dim_in/2 - 1))."""
+    assert dim_in % 2 == 0
+    half = dim_in // 2
+    w = torch.exp(torch.arange(half, device=diffusion_steps.device) * -(math.log(10000) / (half - 1)))
+    e = diffusion_steps * w
+    return torch.cat((torch.sin(e), torch.cos(e)), 1)
+
+
+def _swish(x):
+    return x * torch.sigmoid(x)
+
+
+def _dblock(p, x):
+    """DiffusionDBlock.forward (modules.py:127-138); F.interpolate(size = L // factor) in its default nearest mode picks every
+    factor-th sample."""
+    size = x.shape[-1] // p.factor
+    residual = F.interpolate(p.residual_dense(x), size=size)
+    x = F.interpolate(x, size=size)
+    for layer in p.conv:
+        x = layer(F.leaky_relu(x, 0.2))
+    return x + residual
+
+
+def _kernel_predictor(p, c, layers, cin, cout, ks):
+    """KernelPredictor.forward (modules.py:320-343)."""
+    B, _, T = c.shape
+    c = p.input_conv(c)
+    c = c + p.residual_conv(c)
+    return (p.kernel_conv(c).contiguous().view(B, layers, cin, cout, ks, T),
+            p.bias_conv(c).contiguous().view(B, layers, cout, T))
+
+
+def _lvc_block(p, x, audio_down, c, emb, cfg, lvc):
+    """TimeAware_LVCBlock.forward (modules.py:189-218); the in-place `x += audio_down` of the reference written out of place."""
+    C = cfg["inner_channels"]
+    cond = c + p.fc_t(emb).unsqueeze(-1)
+    kernels, bias = _kernel_predictor(p.kernel_predictor, cond, cfg["lvc_layers_each_block"], C, 2 * C, cfg["lvc_kernel_size"])
+    x = p.upsample(F.leaky_relu(x, 0.2))
+    for i, conv in enumerate(p.convs):
+        x = x + audio_down
+        y = F.leaky_relu(conv(F.leaky_relu(x, 0.2)), 0.2)
+        y = lvc(y, kernels[:, i], bias[:, i], 1, p.cond_hop_length)
+        x = x + torch.sigmoid(y[:, :C]) * torch.tanh(y[:, C:])
+    return x
+
+
+def differentiable_forward(module, data, lvc=None):
+    """eps = net((audio, c, diffusion_steps)) as FastDiff.forward (FastDiff_model.py:74-102), recorded by autograd."""
+    if lvc is None:
+        from .lvc_op import location_variable_convolution as lvc
+    audio, c, diffusion_steps = data
+    cfg = module._cfg
+    if c.dim() == 2:
+        c = c.unsqueeze(0)
+    emb = step_embedding(diffusion_steps.to(audio.dtype).view(audio.shape[0], 1), cfg["diffusion_step_embed_dim_in"])
+    emb = _swish(module.fc_t2(_swish(module.fc_t1(emb))))
+    x = module.first_audio_conv(audio)
+    skips = []
+    for down in module.downsample:
+        skips.append(x)
+        x = _dblock(down, x)
+    for n, audio_down in enumerate(reversed(skips)):
+        x = _lvc_block(module.lvc_blocks[n], x, audio_down, c, emb, cfg, lvc)
+    return module.final_conv(x)

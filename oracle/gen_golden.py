@@ -321,6 +321,49 @@ def gen_theta_loss(dh):
     np.savez_compressed(os.path.join(GOLD, "theta_loss.npz"), **out)
 
 
+def grad_sample(t, n=64):
+    """What the theta_grad fixture keeps of a gradient tensor: its L2 norm and n evenly spaced elements of the flattened tensor."""
+    flat = t.detach().double().reshape(-1)
+    step = max(1, flat.numel() // n)
+    return float(flat.norm()), flat[::step][:n].numpy().copy()
+
+
+def gen_theta_grad(dh):
+    """The training step's backward (FastDiff.py:44-49): util.py:291-325 on the reference module in train() mode with autograd
+    recording, loss.backward(), for float64 and float32.  Kept: the loss, d loss / d audio in full, and of every parameter's
+    gradient (175 tensors, the reference's weight_g / weight_v parametrisation) the L2 norm and 64 evenly spaced elements."""
+    B, T = 2, 6
+    mel = synth.synth_mel(SEED + 500, B, T)
+    audio = (0.3 * synth.hash_normal(SEED + 500, 1, B * T * 256)).reshape(B, 1, T * 256).astype(np.float32)
+    z = synth.hash_normal(SEED + 500, 2, B * T * 256).reshape(B, 1, T * 256)
+    ts = np.array([437, 12], np.int64).reshape(B, 1, 1)
+    out = {"mel": mel, "audio": audio, "z": z, "ts": ts}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        model = make_model(dt).train()
+        net = model if dt == torch.float32 else (lambda data: model((data[0], data[1], data[2].double())))
+        orig_n, orig_r = ref_util.std_normal, torch.randint
+        ref_util.std_normal = lambda size: torch.from_numpy(z.copy()).to(dt).view(*size)
+        torch.randint = lambda *a, **k: torch.from_numpy(ts.copy())
+        a = torch.from_numpy(audio).to(dt).requires_grad_(True)
+        try:
+            loss = ref_util.theta_timestep_loss(net, (torch.from_numpy(mel).to(dt), a), {"T": dh["T"], "alpha": dh["alpha"].to(dt)})
+        finally:
+            ref_util.std_normal, torch.randint = orig_n, orig_r
+        loss.backward()
+        out[f"loss_{tag}"] = np.float64(loss.item())
+        out[f"daudio_{tag}"] = a.grad.double().numpy()
+        names = []
+        for name, p in model.named_parameters():
+            assert p.grad is not None, name
+            nrm, smp = grad_sample(p.grad)
+            out[f"{tag}_norm/{name}"] = np.float64(nrm)
+            out[f"{tag}_sample/{name}"] = smp
+            names.append(name)
+        out["names"] = np.array(names)
+        print("theta_grad", tag, loss.item(), len(names), "parameters; |d audio| max", float(a.grad.abs().max()))
+    np.savez_compressed(os.path.join(GOLD, "theta_grad.npz"), **out)
+
+
 def gen_collate():
     """collate_2d (utils/__init__.py:136-150) cannot be imported (the package needs chardet): its definition is cut out of the
     reference file with ast and executed as is."""
@@ -525,7 +568,7 @@ def gen_statedict_manifest():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["schedule", "embed", "ops", "forward", "sample", "manifest", "collate", "collater", "frontend", "frontend_tacotron",
-                             "frontend_pwg", "noise_scheduling", "theta_loss", "lvc_grad"]
+                             "frontend_pwg", "noise_scheduling", "theta_loss", "theta_grad", "lvc_grad"]
     dh = gen_schedule()
     if "embed" in which:
         gen_embed()
@@ -549,6 +592,8 @@ if __name__ == "__main__":
         gen_frontend()
     if "theta_loss" in which:
         gen_theta_loss(dh)
+    if "theta_grad" in which:
+        gen_theta_grad(dh)
     if "noise_scheduling" in which:
         gen_noise_scheduling(dh)
     if "frontend_tacotron" in which:

@@ -599,7 +599,7 @@ def test_noise_scheduling_on_the_hip_denoiser(model, gc, sched, monkeypatch):
 def test_validation_loss_on_the_hip_denoiser(model, gc, sched, monkeypatch):
     """FastDiffTask.validation_step = theta_timestep_loss(model, (mels, wavs), dh) (FastDiff.py:52-57), forward only: with the HIP
     module as `net` the loss and the x_0 estimate must be the reference's (golden: gen_theta_loss, steps and z replayed).  With
-    gradients enabled (_training_step) the HIP module refuses instead of silently returning a constant."""
+    autograd recording the same call builds the graph of fastdiff_amd/train.py; the sampling entry point refuses such inputs."""
     import fastdiff_amd
     from fastdiff_amd import sampler
     g = load_golden("theta_loss")
@@ -614,9 +614,12 @@ def test_validation_loss_on_the_hip_denoiser(model, gc, sched, monkeypatch):
     assert abs(loss.item() - float(g["loss_f64"])) < 1e-6 * float(g["loss_f64"])
     # x_0 = (x_t - delta eps) / alpha_t: at t = 999 alpha_t is 0.08, so eps errors are amplified 12x
     assert gc.maxdiff(x0.cpu().numpy(), g["x0_f64"]) < 12.5 * FWD_TOL
+    # an input that requires a gradient: the autograd path (fastdiff_amd/train.py, tests/test_training_path.py) -- same loss
     audio = X[1].clone().requires_grad_(True)
-    with pytest.raises(NotImplementedError, match="inference path only"):
-        fastdiff_amd.theta_timestep_loss(model, (X[0], audio), dh)
+    loss_g = fastdiff_amd.theta_timestep_loss(model, (X[0], audio), dh)
+    assert loss_g.grad_fn is not None and abs(loss_g.item() - loss.item()) < 1e-5 * loss.item()
+    with pytest.raises(NotImplementedError, match="inference pipeline"):
+        model.sample(X[0].clone().requires_grad_(True), [{"t": 0.0, "c_eps": 0.0, "c_div": 1.0, "sigma": 0.0, "c1": 1.0, "c2": 0.0, "c3": 0.0, "add_noise": 0}])
 
 
 def test_philox_noise_statistics(model):

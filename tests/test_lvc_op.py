@@ -99,3 +99,39 @@ def test_hip_operator_in_place_of_the_reference_method_under_autograd():
         fastdiff_amd.location_variable_convolution(y, K, bias, 2, hop)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         fastdiff_amd.location_variable_convolution(y.cpu(), K.cpu(), bias.cpu(), 1, hop)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hop,T,B", [(8, 70, 2), (64, 70, 2), (256, 5, 3), (8, 1, 1), (256, 1, 1)])
+def test_matrix_pipe_kernels_against_the_numpy_oracle_at_ragged_sizes(hop, T, B):
+    """The model's shape (Cin 32, Cout 64, ks 3) runs on the fp32 matrix instruction behind two tiled transposes: T beyond one
+    64-frame transpose tile, T not a multiple of the four frames a workgroup owns, and the single-frame case (no frame boundary)."""
+    import fastdiff_amd
+    rng = np.random.default_rng(hop * 1000 + T)
+    x, K = rng.standard_normal((B, 32, T * hop)), 0.2 * rng.standard_normal((B, 32, 64, 3, T))
+    b, d = rng.standard_normal((B, 64, T)), rng.standard_normal((B, 64, T * hop))
+    ref = lg.lvc_forward(x, K, b, hop)
+    rdx, rdK, rdb = lg.lvc_backward(x, K, d, hop)
+    xt, Kt, bt = (torch.from_numpy(a.astype(np.float32)).cuda().requires_grad_(True) for a in (x, K, b))
+    y = fastdiff_amd.location_variable_convolution(xt, Kt, bt, 1, hop)
+    y.backward(torch.from_numpy(d.astype(np.float32)).cuda())
+    for name, got, want in (("out", y.detach(), ref), ("dx", xt.grad, rdx), ("dK", Kt.grad, rdK), ("dbias", bt.grad, rdb)):
+        err = np.abs(got.cpu().numpy().astype(np.float64) - want).max()
+        assert got.shape == want.shape and err <= 3e-6 * max(1.0, np.abs(want).max()), (name, err)
+
+
+@pytest.mark.gpu
+def test_other_shapes_take_the_generic_kernels():
+    import fastdiff_amd
+    rng = np.random.default_rng(5)
+    B, Cin, Cout, ks, T, hop = 2, 6, 10, 5, 7, 12
+    x, K = rng.standard_normal((B, Cin, T * hop)), rng.standard_normal((B, Cin, Cout, ks, T))
+    b, d = rng.standard_normal((B, Cout, T)), rng.standard_normal((B, Cout, T * hop))
+    ref = lg.lvc_forward(x, K, b, hop)
+    rdx, rdK, rdb = lg.lvc_backward(x, K, d, hop)
+    xt, Kt, bt = (torch.from_numpy(a.astype(np.float32)).cuda().requires_grad_(True) for a in (x, K, b))
+    y = fastdiff_amd.location_variable_convolution(xt, Kt, bt, 1, hop)
+    y.backward(torch.from_numpy(d.astype(np.float32)).cuda())
+    for name, got, want in (("out", y.detach(), ref), ("dx", xt.grad, rdx), ("dK", Kt.grad, rdK), ("dbias", bt.grad, rdb)):
+        err = np.abs(got.cpu().numpy().astype(np.float64) - want).max()
+        assert got.shape == want.shape and err <= 3e-6 * max(1.0, np.abs(want).max()), (name, err)

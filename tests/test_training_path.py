@@ -1,0 +1,114 @@
+"""The denoiser under autograd (fastdiff_amd/train.py) against tests/golden/theta_grad.npz: the reference's
+training step -- theta_timestep_loss (util.py:291-325) on the reference module in train() mode, loss.backward() -- executed by
+oracle/gen_golden.py in float64 and float32: the loss, d loss / d audio, and norm + 64 elements of every parameter's gradient.
+
+CPU: the autograd graph around the LVC operator (float64, the operator replaced by the unfold + einsum restatement of
+oracle/torch_eager.py) reproduces the float64 reference to rounding.  GPU: the product path -- FastDiff.forward in train() mode, the
+twelve location-variable convolutions forward and backward on the HIP operator -- inside fastdiff_amd.theta_timestep_loss."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+
+def _module(dtype=torch.float32):
+    import fastdiff_amd
+    import synth
+    m = fastdiff_amd.FastDiff()
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.synth_state_dict(1234).items()}, strict=True)
+    return m.to(dtype)
+
+
+def _compare(model, daudio, g, tol, tag="f64"):
+    worst = (0.0, "")
+    for name, p in model.named_parameters():
+        assert p.grad is not None, name
+        flat = p.grad.detach().double().reshape(-1).cpu()
+        step = max(1, flat.numel() // 64)
+        got, ref = flat[::step][:64].numpy(), g[f"{tag}_sample/{name}"]
+        scale = max(float(np.abs(ref).max()), 1e-12)
+        err = float(np.abs(got - ref).max()) / scale
+        nerr = abs(float(flat.norm()) - float(g[f"{tag}_norm/{name}"])) / max(float(g[f"{tag}_norm/{name}"]), 1e-12)
+        worst = max(worst, (max(err, nerr), name))
+        assert err <= tol and nerr <= tol, (name, err, nerr)
+    da = float(np.abs(daudio.detach().double().cpu().numpy() - g[f"daudio_{tag}"]).max()) / float(np.abs(g[f"daudio_{tag}"]).max())
+    assert da <= tol, da
+    return worst, da
+
+
+def test_gradient_fixture_lists_every_parameter_of_the_module():
+    g = load_golden("theta_grad")
+    m = _module()
+    assert [n for n, _ in m.named_parameters()] == list(g["names"]) and len(g["names"]) == 175
+
+
+def test_autograd_graph_around_the_operator_matches_the_reference_backward_in_float64():
+    """Everything of fastdiff_amd/train.py except the HIP operator, on the CPU in float64."""
+    from fastdiff_amd import train
+    from torch_eager import EagerFastDiff
+    g = load_golden("theta_grad")
+    sched = load_golden("schedule")
+    m = _module(torch.float64).train()
+    alpha = torch.from_numpy(sched["train_alpha"]).double()
+    ts = torch.from_numpy(g["ts"])
+    z = torch.from_numpy(g["z"]).double()
+    audio = torch.from_numpy(g["audio"]).double().requires_grad_(True)
+    a_t = alpha[ts]
+    x_t = a_t * audio + (1 - a_t ** 2.).sqrt() * z
+    eps = train.differentiable_forward(m, (x_t, torch.from_numpy(g["mel"]).double(), ts.view(-1, 1)),
+                                       lvc=lambda y, k, b, dil, hop: EagerFastDiff.lvc(y, k, b, hop))
+    loss = torch.nn.functional.mse_loss(eps, z)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss_f64"])) <= 1e-12 * float(g["loss_f64"])
+    worst, da = _compare(m, audio.grad, g, 1e-9)
+    print("float64 graph vs float64 reference: worst parameter", worst, "d audio", da)
+
+
+def test_inference_entry_points_still_refuse_autograd_inputs_on_cpu():
+    m = _module()
+    x = torch.zeros(1, 1, 512, requires_grad=True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m((x, torch.zeros(1, 80, 2), torch.zeros(1, 1)))
+
+
+@pytest.mark.gpu
+def test_training_step_on_the_hip_operator_matches_the_reference_backward(monkeypatch):
+    import fastdiff_amd
+    from fastdiff_amd import sampler
+    g = load_golden("theta_grad")
+    sched = load_golden("schedule")
+    m = _module().cuda().train()
+    monkeypatch.setattr(sampler, "std_normal", lambda size: torch.from_numpy(g["z"].copy()).view(*size).cuda())
+    monkeypatch.setattr(torch, "randint", lambda *a, **k: torch.from_numpy(g["ts"].copy()))
+    dh = {"T": 1000, "alpha": torch.from_numpy(sched["train_alpha"]).cuda()}
+    audio = torch.from_numpy(g["audio"]).cuda().requires_grad_(True)
+    calls = []
+    real = fastdiff_amd.lvc_op.location_variable_convolution
+    monkeypatch.setattr(fastdiff_amd.lvc_op, "location_variable_convolution", lambda x, k, b, d, h: (calls.append(h), real(x, k, b, d, h))[1])
+    loss = fastdiff_amd.theta_timestep_loss(m, (torch.from_numpy(g["mel"]).cuda(), audio), dh)
+    loss.backward()
+    assert calls == [8] * 4 + [64] * 4 + [256] * 4                       # the twelve LVC calls went through the HIP operator
+    gap = abs(float(g["loss_f32"]) - float(g["loss_f64"]))
+    print("loss %.9f: |d| vs float64 reference %.2e (the float32 reference: %.2e)" % (loss.item(), abs(loss.item() - float(g["loss_f64"])), gap))
+    assert abs(loss.item() - float(g["loss_f64"])) <= 2e-6 * float(g["loss_f64"])
+    # the float32 reference itself sits up to 8e-6 (relative to the largest element of a tensor) from the float64 one
+    worst, da = _compare(m, audio.grad, g, 1e-4)
+    print("HIP training step vs float64 reference: worst parameter", worst, "d audio", da)
+
+
+@pytest.mark.gpu
+def test_eval_mode_keeps_the_inference_kernels_and_train_mode_agrees_with_them():
+    m = _module().cuda()
+    g = load_golden("theta_grad")
+    x, mel = torch.from_numpy(g["audio"]).cuda(), torch.from_numpy(g["mel"]).cuda()
+    steps = torch.tensor([[437.0], [12.0]]).cuda()
+    m.eval()
+    y_inf = m((x, mel, steps))
+    assert y_inf.grad_fn is None                                         # no graph: the fused pipeline
+    m.train()
+    y_tr = m((x, mel, steps))
+    assert y_tr.grad_fn is not None
+    assert float((y_tr.detach() - y_inf).abs().max()) <= 2e-5            # the forward tolerance of the parity tests
+    with torch.no_grad():
+        assert m((x, mel, steps)).grad_fn is None

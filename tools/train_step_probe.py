@@ -1,0 +1,83 @@
+"""Training-side timing: the reference's training shape -- max_sentences 20 x max_samples 25600 (base.yaml:50-51),
+i.e. B = 20 utterance crops of T = 100 frames -- through FastDiff.forward in train() mode + loss.backward(), with the location-variable
+convolution (a) on the HIP operator (fd_lvc_forward / fd_lvc_backward) and (b) as the reference states it, pad + unfold + einsum on
+PyTorch-ROCm (modules.py:220-253 with dilation 1), on the same GPU; then the operator alone, forward and backward, per hop size.
+Usage: python tools/train_step_probe.py [B] [T]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch
+import torch.nn.functional as F
+
+import fastdiff_amd
+from fastdiff_amd import train
+
+
+def lvc_unfold_einsum(x, kernel, bias, dilation, hop):
+    """out[b,o,l*hop+s] = bias[b,o,l] + sum_{i,k} xpad[b,i,l*hop+s+k] kernel[b,i,o,k,l] the way eager PyTorch runs it."""
+    B, _, L = x.shape
+    win = F.pad(x, (1, 1)).unfold(2, hop + 2, hop).unfold(3, 3, 1)           # [B, in, T, hop, 3]
+    out = torch.einsum("bithk,biokt->both", win, kernel) + bias.unsqueeze(-1)
+    return out.reshape(B, -1, L)
+
+
+def timed(fn, warm=2, reps=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    T = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    torch.manual_seed(0)
+    m = fastdiff_amd.FastDiff().cuda().train()
+    mel = (torch.rand(B, 80, T) * 7.5 - 6.0).cuda()
+    x = (0.3 * torch.randn(B, 1, T * 256)).cuda()
+    z = torch.randn(B, 1, T * 256).cuda()
+    steps = torch.randint(1000, (B, 1)).float().cuda()
+
+    def step(lvc):
+        m.zero_grad(set_to_none=True)
+        eps = train.differentiable_forward(m, (x, mel, steps), lvc=lvc)
+        F.mse_loss(eps, z).backward()
+
+    def fwd(lvc):
+        with torch.no_grad():
+            train.differentiable_forward(m, (x, mel, steps), lvc=lvc)
+
+    print(f"training shape B={B} T={T} ({B * T * 256} samples)")
+    for name, lvc in (("HIP operator", None), ("unfold+einsum (PyTorch-ROCm eager)", lvc_unfold_einsum)):
+        try:
+            print(f"  forward + backward, LVC = {name}: {timed(lambda: step(lvc)):8.2f} ms   forward only (no_grad): {timed(lambda: fwd(lvc)):8.2f} ms")
+        except Exception as e:      # noqa: BLE001 -- e.g. out of memory in the unfold view's backward
+            print(f"  LVC = {name}: failed: {e!r}")
+    for hop in (8, 64, 256):
+        L = T * hop
+        y = torch.randn(B, 32, L, device="cuda", requires_grad=True)
+        k = (0.1 * torch.randn(B, 32, 64, 3, T, device="cuda")).requires_grad_(True)
+        b = torch.randn(B, 64, T, device="cuda", requires_grad=True)
+        d = torch.randn(B, 64, L, device="cuda")
+        for name, op in (("HIP", fastdiff_amd.location_variable_convolution), ("unfold+einsum", lvc_unfold_einsum)):
+            def f():
+                with torch.no_grad():
+                    op(y, k, b, 1, hop)
+
+            def fb():
+                y.grad = k.grad = b.grad = None
+                op(y, k, b, 1, hop).backward(d)
+            tf, tfb = timed(f), timed(fb)
+            flops = 2.0 * B * L * 64 * 96
+            print(f"  hop {hop:3d} {name:14s}: forward {tf:7.3f} ms ({flops / tf / 1e9:6.1f} TFLOP/s)   forward+backward {tfb:7.3f} ms ({3 * flops / tfb / 1e9:6.1f} TFLOP/s)")
+
+
+if __name__ == "__main__":
+    main()
