@@ -146,7 +146,10 @@ FD_API int fd_peak_normalize_int16_ragged(fd_handle h, const float *wav, int B, 
  *   out[b,o,q] = bias[b,o,q/hop] + sum_{i,k} xpad[b,i,q+k-(ks-1)/2] * kernel[b,i,o,k,q/hop]
  *   x [B,Cin,T*hop]   kernel [B,Cin,Cout,ks,T]   bias [B,Cout,T]   out, dout [B,Cout,T*hop]      (all device, float32, contiguous)
  * fd_lvc_backward writes the gradients whose pointer is not NULL: dx (needs kernel), dkernel and dbias (need x).
- * Any handle of the device will do (it supplies the device and the error text); Cin*Cout*ks <= 8192, ks odd. */
+ * Any handle of the device will do (it supplies the device, the error text and, for the model's own shape -- Cin 32, Cout 64, ks 3,
+ * hop 8 / 64 / 256, which runs on the fp32 matrix instruction -- a scratch buffer of B*T*Cin*Cout*ks floats for the frame-major copy of
+ * the kernels: calls on one handle must therefore be ordered on one stream, as autograd orders a forward and its backward);
+ * Cin*Cout*ks <= 8192, ks odd. */
 FD_API int fd_lvc_forward(fd_handle h, const float *x, const float *kernel, const float *bias, int B, int Cin, int Cout, int ks, int T,
                           int hop, float *out, void *stream);
 FD_API int fd_lvc_backward(fd_handle h, const float *x, const float *kernel, const float *dout, int B, int Cin, int Cout, int ks, int T,
