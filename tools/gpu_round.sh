@@ -16,6 +16,7 @@ echo "== bench config4 (64 ragged utterances, N=6, host to host) on this one GPU
 echo "== the multi-rank path, 2 ranks sharing this GPU over gloo (FD_BENCH_OVERSUBSCRIBE: a code-path check, not a scaling number)"
 FD_BENCH_OVERSUBSCRIBE=1 timeout 900 python bench.py --gpus 2 --workload config4 --steps 3 --warmup 1 > gpurun_out/bench_config4_2ranks_1gpu.log 2>&1 ; grep '^{' gpurun_out/bench_config4_2ranks_1gpu.log | cut -c1-300
 echo "== bench --gpus 2 without the override must refuse" ; python bench.py --gpus 2 > gpurun_out/bench_gpus2_refused.log 2>&1 ; echo "rc=$?" ; tail -1 gpurun_out/bench_gpus2_refused.log
+echo "== training side: denoiser forward + backward, LVC operator vs unfold+einsum" ; timeout 600 python tools/train_step_probe.py 2>&1 | grep -v "Warning\|WeightNorm\|amdgpu.ids" | tee gpurun_out/train_step_probe.txt
 echo "== rocprof kernel-trace"
 cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o kt -- python $R/bench.py --steps 5 --warmup 1 --no-roofline --no-cpu-baseline --no-fp32-pipe --no-host-io > $R/gpurun_out/rocprof.log 2>&1 ; echo "rocprof rc=$?"
 cd $R; find gpurun_out/prof -name '*kernel_trace.csv' -size +20M -delete 2>/dev/null
