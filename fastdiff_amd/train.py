@@ -59,10 +59,13 @@ def _lvc_block(p, x, audio_down, c, emb, cfg, lvc):
     cond = c + p.fc_t(emb).unsqueeze(-1)
     kernels, bias = _kernel_predictor(p.kernel_predictor, cond, cfg["lvc_layers_each_block"], C, 2 * C, cfg["lvc_kernel_size"])
     x = p.upsample(F.leaky_relu(x, 0.2))
+    # the reference slices kernels[:, i] (modules.py:213-214), whose backward builds a zero tensor of all four layers per slice and
+    # adds the four up; unbind hands autograd the same views and gets one stack back
+    kernels, bias = kernels.unbind(1), bias.unbind(1)
     for i, conv in enumerate(p.convs):
         x = x + audio_down
         y = F.leaky_relu(conv(F.leaky_relu(x, 0.2)), 0.2)
-        y = lvc(y, kernels[:, i], bias[:, i], 1, p.cond_hop_length)
+        y = lvc(y, kernels[i], bias[i], 1, p.cond_hop_length)
         x = x + torch.sigmoid(y[:, :C]) * torch.tanh(y[:, C:])
     return x
 

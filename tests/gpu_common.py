@@ -1,4 +1,6 @@
 """Helpers shared by the GPU parity tests (imported only under -m gpu)."""
+import os
+
 import numpy as np
 import torch
 
@@ -44,7 +46,10 @@ def make_model(seed=1234, device="cuda"):
     m = fastdiff_amd.FastDiff()
     sd = {k: torch.from_numpy(v.copy()) for k, v in synth.synth_state_dict(seed).items()}
     m.load_state_dict(sd, strict=True)
-    return m.to(device).eval()
+    m = m.to(device).eval()
+    for kv in filter(None, os.environ.get("FD_TEST_OPTS", "").split(",")):      # bisecting aid: library options for every test model
+        m.set_option(*kv.split("=", 1))
+    return m
 
 
 def run_forward(m, audio, mel, steps):
