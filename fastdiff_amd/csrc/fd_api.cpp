@@ -819,6 +819,10 @@ static int set_lens(fd_handle h, const int *lens, int B, int T, hipStream_t stre
         ragged = ragged || lens[b] < T;
     }
     if (!ragged) return FD_OK;                       // every utterance fills the batch: same launches as without lens
+    for (int i = ST_FIRST; i < ST_COUNT; ++i)      // (the step embedding has no time axis)
+        if (!h->fast[i])
+            FD_FAIL(h, FD_ERR_UNSUPPORTED, "%s: a ragged batch (lens) needs the fast kernel set; the naive kernels (option kernels.<stage> = naive) "
+                                           "compute the padded tensor and would silently ignore the lengths", who);
     memcpy(staged, lens, sizeof(int) * B);
     FD_HIP(h, hipMemcpyAsync(h->ws.lens_dev, staged, sizeof(int) * B, hipMemcpyHostToDevice, stream));
     h->step_lens = h->ws.lens_dev;

@@ -862,3 +862,21 @@ def test_peak_normalize_int16_ragged_equals_each_utterance_alone(model, oracle64
         assert not pcm[b, n:].any(), b
     with pytest.raises(Exception, match="valid"):
         model.peak_normalize_int16(torch.from_numpy(wav).cuda(), valid=[5000, 0, 1, 1])
+
+
+def test_ragged_batch_is_refused_on_the_naive_kernels(gc):
+    """The straightforward kernels compute the padded tensor: with `lens` they would silently ignore the lengths (results then depend on
+    what the padding region of the workspace holds).  The library refuses instead; full-length `lens` are no ragged batch."""
+    import synth
+    m = gc.make_model()
+    B, T = 2, 20
+    mel = torch.from_numpy(synth.synth_mel(3, B, T)).cuda()
+    rows = [{"t": 5.0, "c_eps": 0.1, "c_div": 1.0, "sigma": 0.0, "c1": 1.0, "c2": 0.0, "c3": 0.0, "add_noise": 0}]
+    m.set_option("kernels.lvc", "naive")
+    with torch.no_grad():
+        m.sample(mel, rows, seed=1, lens=[T, T])
+        with pytest.raises(NotImplementedError, match="ragged batch"):
+            m.sample(mel, rows, seed=1, lens=[T, T - 3])
+    m.set_option("kernels.lvc", "fast")
+    with torch.no_grad():
+        assert torch.isfinite(m.sample(mel, rows, seed=1, lens=[T, T - 3])[1, 0, : (T - 3) * 256]).all()
