@@ -142,7 +142,7 @@ def test_synthesize_sharded_world2_hip_vocoder_equals_single_process():
     to the single-process one.  The ranks take turns on the GPU: with both processes vocoding AT THE SAME TIME on the one device, about
     3 % of runs showed one utterance off in a few hundred samples (the last 64 columns of one 256-column tile of a hop-256 layer read
     stale; also with graph=0 and fuse_final=0; never in one process, never with the ranks taking turns: 0 of 110 runs against 5 of 171 --
-    profiles/r02/s12_s18_two_processes_one_gpu.txt).  One process per GPU, which is what the sharded path is for, has no second
+    profiles/r02/s12_s19_two_processes_one_gpu.txt).  One process per GPU, which is what the sharded path is for, has no second
     process on its device; FD_TEST_SERIALIZE=0 restores the concurrent arrangement for hunting (tools/gpu_r2_s14.sh)."""
     ctx = mp.get_context("spawn")
     ret = ctx.SimpleQueue()
