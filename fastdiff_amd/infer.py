@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from . import schedules, shard
-from .sampler import InferenceSchedule, compute_hyperparams_given_schedule, sampling_given_noise_schedule
+from .sampler import InferenceSchedule
 
 
 def load_mel_inputs(test_input_dir: str) -> List[dict]:

@@ -13,7 +13,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from fastdiff_amd import infer, shard
+from fastdiff_amd import infer
 
 
 def _free_port():
