@@ -14,19 +14,10 @@ recording and the module is in train() mode or an input requires a gradient; eve
 `lvc` (tests only): a replacement for the HIP operator with the same signature, so that the structure around it can be pinned on
 the reference's gradients on a machine without a GPU; the product never passes it.
 """
-import math
-
 import torch
 import torch.nn.functional as F
 
-
-def step_embedding(diffusion_steps, dim_in):
-    """calc_diffusion_step_embedding (util.py:407-432): [sin(t w_j), cos(t w_j)], w_j = 10000^(-j / (dim_in/2 - 1))."""
-    assert dim_in % 2 == 0
-    half = dim_in // 2
-    w = torch.exp(torch.arange(half, device=diffusion_steps.device) * -(math.log(10000) / (half - 1)))
-    e = diffusion_steps * w
-    return torch.cat((torch.sin(e), torch.cos(e)), 1)
+from .sampler import calc_diffusion_step_embedding
 
 
 def _swish(x):
@@ -78,7 +69,7 @@ def differentiable_forward(module, data, lvc=None):
     cfg = module._cfg
     if c.dim() == 2:
         c = c.unsqueeze(0)
-    emb = step_embedding(diffusion_steps.to(audio.dtype).view(audio.shape[0], 1), cfg["diffusion_step_embed_dim_in"])
+    emb = calc_diffusion_step_embedding(diffusion_steps.to(audio.dtype).view(audio.shape[0], 1), cfg["diffusion_step_embed_dim_in"])
     emb = _swish(module.fc_t2(_swish(module.fc_t1(emb))))
     x = module.first_audio_conv(audio)
     skips = []
