@@ -832,6 +832,7 @@ static int set_lens(fd_handle h, const int *lens, int B, int T, hipStream_t stre
 int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps, int B, int T, const int *lens,
                float *eps_out, void *stream)
 {
+    if (h) h->noise_ids.clear();                 // stream ids are for the next fd_sample only: a forward in between drops them
     int rc = check_common(h, B, T, "fd_forward");
     if (rc != FD_OK) return rc;
     if ((rc = settle(h)) != FD_OK) return rc;
@@ -979,6 +980,8 @@ static int resolve_pending(fd_handle h, unsigned *mask)
 int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, const fd_step *table, int N, int ddim,
               const float *x_T, const float *z, uint64_t seed, float *out, float *seq_out, void *stream_)
 {
+    std::vector<unsigned long long> ids;
+    if (h) ids.swap(h->noise_ids);               // one-shot: fd_set_noise_streams applies to this call only, also when it fails below
     int rc = check_common(h, B, T, "fd_sample");
     if (rc != FD_OK) return rc;
     if ((rc = settle(h)) != FD_OK) return rc;
@@ -988,8 +991,6 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
     hipStream_t stream = (hipStream_t)stream_;
     Workspace &ws = h->ws;
     const size_t n_el = (size_t)B * T * fd::HOPT;
-    std::vector<unsigned long long> ids;
-    ids.swap(h->noise_ids);                      // one-shot: fd_set_noise_streams applies to this call only
     if (!ids.empty() && (int)ids.size() != B)
         FD_FAIL(h, FD_ERR_INVALID, "fd_sample: fd_set_noise_streams gave %d stream ids but B=%d", (int)ids.size(), B);
 

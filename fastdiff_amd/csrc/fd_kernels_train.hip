@@ -465,6 +465,10 @@ hipError_t lvc_op_backward(const Launch &L, const float *x, const float *K, cons
         if (dx) FD_LAUNCH(L, "lvc_op_backward_x", k_lvc_bwd_x, dim3((Ln + 255) / 256, Cin, B), dim3(256), 0, dout, K, dx, Cin, Cout, ks, T, hop);
         if (dK || dbias) {
             const size_t shmem = sizeof(float) * ((size_t)Cout * DK_CHUNK + (size_t)Cin * (DK_CHUNK + ks - 1));
+            if (shmem > 48 * 1024) {      // wide outputs (Cout up to 256 is admitted) ask for more dynamic LDS than a launch gets by default
+                const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(k_lvc_bwd_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+                if (ea != hipSuccess) return ea;
+            }
             FD_LAUNCH(L, "lvc_op_backward_k", k_lvc_bwd_k, dim3(T, B), dim3(256), shmem, x, dout, dK, dbias, Cin, Cout, ks, T, hop);
         }
         return hipSuccess;

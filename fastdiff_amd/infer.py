@@ -113,30 +113,92 @@ def distributed_sampler_indices(n_items: int, rank: int, world_size: int) -> Lis
     return idx[rank:total:world_size]
 
 
+def _job_cache(model) -> dict:
+    """Per-model cache of what a synthesis job needs besides the weights: the step table of each schedule (host arithmetic that
+    depends on the schedule only: ~6 ms for N = 6) and the pinned staging buffers (a pinned allocation costs more than vocoding a
+    micro-batch).  Lives on the module, so it is released with it."""
+    cache = getattr(model, "_infer_cache", None)
+    if cache is None:
+        cache = {"rows": {}, "pin": None}
+        try:
+            model._infer_cache = cache
+        except AttributeError:          # a stand-in without attributes (tests): no caching
+            pass
+    return cache
+
+
+def _step_rows(model, n_steps, noise_schedule, diffusion_hyperparams):
+    if diffusion_hyperparams is not None:          # caller-owned tables: derived as given, not cached
+        if noise_schedule is None:
+            noise_schedule = schedules.noise_schedule_for(n_steps)
+        return InferenceSchedule(diffusion_hyperparams, noise_schedule, verbose=False).rows()
+    if noise_schedule is None:
+        noise_schedule = schedules.noise_schedule_for(n_steps)
+    key = tuple(float(v) for v in torch.as_tensor(noise_schedule).reshape(-1).tolist())
+    rows_of = _job_cache(model)["rows"]
+    if key not in rows_of:
+        rows_of[key] = InferenceSchedule(schedules.training_hyperparams(), noise_schedule, verbose=False).rows()
+    return rows_of[key]
+
+
+def _pinned_staging(model, n_mel: int, n_pcm: int):
+    """Two mel and two PCM pinned buffers of at least the given element counts, kept on the model between jobs."""
+    cache = _job_cache(model)
+    pin = cache["pin"]
+    if pin is None or pin[0][0].numel() < n_mel or pin[1][0].numel() < n_pcm:
+        n_mel = max(n_mel, pin[0][0].numel() if pin else 0)
+        n_pcm = max(n_pcm, pin[1][0].numel() if pin else 0)
+        pin = ([torch.empty(n_mel, dtype=torch.float32).pin_memory() for _ in range(2)],
+               [torch.empty(n_pcm, dtype=torch.int16).pin_memory() for _ in range(2)])
+        cache["pin"] = pin
+    return pin
+
+
+def _collate_on_device(items: Sequence[dict], drop_last_frame: bool):
+    """collate_test_batch for mels that already live on the GPU (the RCCL scatter of synthesize_sharded delivers them there):
+    the same padded [B, 80, T'] batch, built with device copies -- no round trip over PCIe."""
+    kept, lens, names = [], [], []
+    for it in items:
+        c = it["mel"]
+        t = c.shape[0] - 1 if drop_last_frame else c.shape[0]
+        if drop_last_frame and c.shape[0] < 2:
+            continue
+        kept.append(c)
+        lens.append(t)
+        names.append(it["item_name"])
+    if not kept:
+        return None, [], []
+    batch = torch.zeros(len(kept), kept[0].shape[1], max(lens), dtype=torch.float32, device=kept[0].device)
+    for b, (c, t) in enumerate(zip(kept, lens)):
+        batch[b, :, :t] = c[:t].transpose(0, 1)
+    return batch, lens, names
+
+
 def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 8, seed: int = 0, drop_last_frame: bool = True,
-               noise_schedule=None, diffusion_hyperparams=None) -> Dict[str, np.ndarray]:
+               noise_schedule=None, diffusion_hyperparams=None, return_device: bool = False) -> Dict[str, np.ndarray]:
     """item_name -> int16 PCM of its own length (hop 256 x frames), through length-sorted padded micro-batches.
     Noise: utterance `it` draws x_T and z from Philox stream (seed, it["uid"]) over its own samples (fd_set_noise_streams); "uid"
     defaults to the item's position in `items`, callers that shard a job put the utterance's index in the WHOLE job there, so a
-    waveform does not depend on the micro-batch, rank or world size that produced it."""
-    if diffusion_hyperparams is None:
-        diffusion_hyperparams = schedules.training_hyperparams()
-    if noise_schedule is None:
-        noise_schedule = schedules.noise_schedule_for(n_steps)
-    # the step table depends on the schedule only: derived once (sampling_given_noise_schedule derives it on every call, as the
-    # reference does -- 6 ms of host arithmetic per call for N = 6), the same rows then drive every micro-batch
-    rows = InferenceSchedule(diffusion_hyperparams, noise_schedule, verbose=False).rows()
+    waveform does not depend on the micro-batch, rank or world size that produced it.
+    Mels may live on the host ([T, 80] tensors or arrays: collated in numpy straight into pinned memory) or on the GPU (collated
+    there).  return_device: the values are int16 device tensors instead of host arrays (no device-to-host copy at all: what
+    synthesize_sharded hands to the RCCL gather)."""
+    # the step table depends on the schedule only: derived once per schedule and model (sampling_given_noise_schedule derives it on
+    # every call, as the reference does), the same rows then drive every micro-batch
+    rows = _step_rows(model, n_steps, noise_schedule, diffusion_hyperparams)
     lengths = [it["len"] for it in items]
     out: Dict[str, np.ndarray] = {}
     if not items:
         return out
-    # pinned staging, allocated once per job (a pinned allocation per micro-batch costs more than vocoding it): two mel and two PCM
-    # buffers, used alternately -- buffer k & 1 is free again once micro-batch k - 2 has been collected, which happens in iteration k - 1
     hop = model.hop_length
+    on_device = isinstance(items[0]["mel"], torch.Tensor) and items[0]["mel"].is_cuda
     t_max, b_max = max(lengths), min(max_batch, len(items))
-    mel_pin = [torch.empty(b_max * 80 * t_max, dtype=torch.float32).pin_memory() for _ in range(2)]
-    pcm_pin = [torch.empty(b_max * t_max * hop, dtype=torch.int16).pin_memory() for _ in range(2)]
-    mel_np = [m.numpy() for m in mel_pin]      # the collater writes the batch straight into the pinned buffer
+    # pinned staging, two mel and two PCM buffers used alternately -- buffer k & 1 is free again once micro-batch k - 2 has been
+    # collected, which happens in iteration k - 1.  Only the legs that cross PCIe need it.
+    mel_pin = pcm_pin = mel_np = None
+    if not (on_device and return_device):
+        mel_pin, pcm_pin = _pinned_staging(model, 0 if on_device else b_max * 80 * t_max, 0 if return_device else b_max * t_max * hop)
+        mel_np = [m.numpy() for m in mel_pin]      # the collater writes the batch straight into the pinned buffer
     pending = None                 # (event, pinned PCM view, names, lens) of the micro-batch still on its way to the host
 
     def collect(p):
@@ -147,16 +209,26 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
 
     k = 0
     for batch_idx in shard.micro_batches(range(len(items)), lengths, max_batch):
-        mels, lens, names = collate_test_batch([items[i] for i in batch_idx], drop_last_frame, out=mel_np[k & 1])
+        batch_items = [items[i] for i in batch_idx]
+        if on_device:
+            mels, lens, names = _collate_on_device(batch_items, drop_last_frame)
+        else:
+            mels, lens, names = collate_test_batch(batch_items, drop_last_frame, out=mel_np[k & 1])
         if mels is None:
             continue
         uid_of = {items[i]["item_name"]: int(items[i].get("uid", i)) for i in batch_idx}
         B, _, T = mels.shape
-        mels = mel_pin[k & 1][: B * 80 * T].view(B, 80, T).cuda(non_blocking=True)
+        if not on_device:
+            mels = mel_pin[k & 1][: B * 80 * T].view(B, 80, T).cuda(non_blocking=True)
         with torch.no_grad():
             wav = model.sample(mels, rows, ddim=False, seed=seed, lens=lens, stream_ids=[uid_of[n] for n in names])
         # one epilogue call and one asynchronous copy per micro-batch; the previous batch is unpacked on the host while this one runs
         pcm = model.peak_normalize_int16(wav, valid=[t * hop for t in lens])
+        if return_device:
+            for b, (name, t) in enumerate(zip(names, lens)):
+                out[name] = pcm[b, : t * hop]
+            k += 1
+            continue
         host = pcm_pin[k & 1][: B * T * hop].view(B, T * hop)
         host.copy_(pcm, non_blocking=True)
         done = torch.cuda.Event()
@@ -176,7 +248,10 @@ def synthesize_sharded(model, items, n_steps: int = 4, max_batch: int = 8, seed:
     partition (shard.partition_utterances) -> scatter of the mels -> every rank vocodes its share in padded micro-batches on its
     own GPU -> gather of the int16 PCM on `src`, which returns item_name -> PCM (the other ranks return {}).  The process group
     must be initialised; `device` is where the messages are staged (the GPU for RCCL, None = host for gloo).  Without a process
-    group (one process) this is synthesize()."""
+    group (one process) this is synthesize().
+    With `device` set the data crosses PCIe exactly twice: the mels go up once on `src` (inside the scatter), the scattered mels are
+    collated on the GPU they arrive on, the PCM stays on the device through the gather, and `src` brings the whole job back with ONE
+    device-to-host copy."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return synthesize(model, items, n_steps, max_batch, seed, drop_last_frame)
@@ -185,21 +260,24 @@ def synthesize_sharded(model, items, n_steps: int = 4, max_batch: int = 8, seed:
     if rank == src:      # the collater's view of every item: [80, T'] with the last frame dropped, too-short items left out
         kept = [(i, it) for i, it in enumerate(items) if not drop_last_frame or it["mel"].shape[0] >= 2]
         mels = [torch.from_numpy(np.ascontiguousarray(it["mel"].numpy()[: it["mel"].shape[0] - (1 if drop_last_frame else 0)].T)) for _, it in kept]
-        meta = [([it["item_name"] for _, it in kept], [int(it.get("uid", i)) for i, it in kept])]
-    dist.broadcast_object_list(meta, src=src)
-    names, uids = meta[0]
-    lens_src = [m.shape[-1] for m in mels] if rank == src else [0] * len(names)
-    lens_t = torch.tensor(lens_src, dtype=torch.int64, device=device)
-    dist.broadcast(lens_t, src=src)
-    parts = shard.partition_utterances(lens_t.tolist(), world)
-    mine, lens = shard.scatter_utterances(mels if rank == src else None, parts, src=src, device=device)
+        meta = [([it["item_name"] for _, it in kept], [int(it.get("uid", i)) for i, it in kept], [int(m.shape[-1]) for m in mels])]
+    dist.broadcast_object_list(meta, src=src)          # names, noise-stream ids and lengths in one message
+    names, uids, lens = meta[0]
+    parts = shard.partition_utterances(lens, world)
+    mine, _ = shard.scatter_utterances(mels if rank == src else None, parts, src=src, device=device, lens=lens)
+    on_gpu = device is not None and torch.device(device).type == "cuda"
     local = [{"item_name": str(i), "mel": m.transpose(0, 1), "len": m.shape[-1], "uid": uids[i]} for i, m in mine]
-    pcm = synthesize(model, local, n_steps, max_batch, seed, drop_last_frame=False)
-    wavs = [(i, torch.from_numpy(pcm[str(i)]).to(device) if device is not None else torch.from_numpy(pcm[str(i)])) for i, _ in mine]
+    pcm = synthesize(model, local, n_steps, max_batch, seed, drop_last_frame=False, return_device=on_gpu)
+    wavs = [(i, pcm[str(i)] if on_gpu else torch.from_numpy(pcm[str(i)])) for i, _ in mine]
     out = shard.gather_waveforms(wavs, lens, parts, hop=model.hop_length, dst=src, device=device, dtype=torch.int16)
     if rank != src:
         return {}
-    return {names[i]: out[i].cpu().numpy() for i in range(len(names))}
+    if not on_gpu:
+        return {names[i]: out[i].numpy() for i in range(len(names))}
+    sizes = [int(o.numel()) for o in out]
+    flat = torch.cat([o.reshape(-1) for o in out]).cpu().numpy()          # one device-to-host copy for the whole job
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    return {names[i]: flat[offs[i]: offs[i + 1]] for i in range(len(names))}
 
 
 def save_wavs(pcm: Dict[str, np.ndarray], out_dir: str, sample_rate: int = 22050) -> List[str]:

@@ -41,6 +41,9 @@ class _LVC(torch.autograd.Function):
     def forward(ctx, x, kernel, bias, hop_size):
         if not (x.is_cuda and kernel.is_cuda and bias.is_cuda):
             raise RuntimeError("fastdiff_amd.location_variable_convolution runs only on a HIP device (no CPU fallback)")
+        # the kernels compute in float32 (the reference trains in float32); other floating types are converted on the way in and
+        # the gradients go back in each input's own type, as autograd requires
+        ctx.in_dtypes = (x.dtype, kernel.dtype, bias.dtype)
         x, kernel, bias = x.contiguous().float(), kernel.contiguous().float(), bias.contiguous().float()
         B, Cin, L = x.shape
         _, _, Cout, ks, T = kernel.shape
@@ -50,7 +53,7 @@ class _LVC(torch.autograd.Function):
                                                out.data_ptr(), _stream(x.device)), "fd_lvc_forward")
         ctx.save_for_backward(x, kernel)
         ctx.hop = int(hop_size)
-        return out
+        return out.to(ctx.in_dtypes[0])
 
     @staticmethod
     def backward(ctx, dout):
@@ -66,7 +69,8 @@ class _LVC(torch.autograd.Function):
         _capi.check(lib, h, lib.fd_lvc_backward(h, x.data_ptr(), kernel.data_ptr(), dout.data_ptr(), B, Cin, Cout, ks, T, ctx.hop,
                                                 None if dx is None else dx.data_ptr(), None if dk is None else dk.data_ptr(),
                                                 None if db is None else db.data_ptr(), _stream(x.device)), "fd_lvc_backward")
-        return dx, dk, db, None
+        tx, tk, tb = ctx.in_dtypes
+        return (None if dx is None else dx.to(tx), None if dk is None else dk.to(tk), None if db is None else db.to(tb), None)
 
 
 def location_variable_convolution(x, kernel, bias, dilation=1, hop_size=256):

@@ -146,6 +146,12 @@ class FastDiff(nn.Module):
             if lens is not None:
                 raise NotImplementedError("lens is an extension of the inference path; under autograd pass whole utterances")
             self._require_device(audio, c)
+            if not getattr(self, "_warned_autograd_path", False) and not (audio.requires_grad or c.requires_grad):
+                # nn.Module starts in train() mode: a freshly built model called outside no_grad lands here, not on the fused kernels
+                import warnings
+                warnings.warn("fastdiff_amd.FastDiff.forward is recording an autograd graph (module in train() mode with gradients "
+                              "enabled): the fused inference kernels run under torch.no_grad() or after .eval()", stacklevel=2)
+                self._warned_autograd_path = True
             from .train import differentiable_forward
             return differentiable_forward(self, (audio.float(), self._prep_condition(c, audio.shape[0], audio.device), diffusion_steps))
         self._require_inference(audio, c)

@@ -53,23 +53,37 @@ def _as_bytes(t: torch.Tensor) -> torch.Tensor:
 
 def _exchange(ops):
     """Post all point-to-point operations of this rank as ONE group (ncclGroupStart/End on RCCL, plain isend/irecv on gloo)
-    and wait for them.  Messages between a pair of ranks are matched in posting order; no tags (RCCL ignores them)."""
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
+    and wait for them.  Messages between a pair of ranks are matched in posting order; no tags (RCCL ignores them).
+    gloo moves host memory only: device buffers handed to it (the device-staged path exercised on a box without RCCL peers, e.g.
+    two ranks sharing one GPU in the tests) go through host copies here, so the callers stay the same for both backends."""
+    if not ops:
+        return
+    if dist.get_backend(ops[0].group) == "gloo" and any(op.tensor.is_cuda for op in ops):
+        host = [op.tensor.cpu() if op.op is dist.isend else torch.empty(op.tensor.shape, dtype=op.tensor.dtype) for op in ops]
+        for req in dist.batch_isend_irecv([dist.P2POp(op.op, h, op.peer, op.group, op.tag) for op, h in zip(ops, host)]):
             req.wait()
+        for op, h in zip(ops, host):
+            if op.op is dist.irecv:
+                op.tensor.copy_(h)
+        return
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
 
 
-def scatter_utterances(mels: Sequence[torch.Tensor], parts: List[List[int]], src: int = 0, device=None):
+def scatter_utterances(mels: Sequence[torch.Tensor], parts: List[List[int]], src: int = 0, device=None, lens: Sequence[int] = None):
     """Rank `src` holds all mels ([80,T_i] each); afterwards every rank holds its own (index, mel) list.
-    Lengths travel first as one small broadcast; then ONE packed message per peer (its utterances back to back, in the order of
-    parts[r]) in a single grouped send/recv -- at most world-1 messages leave `src`, whatever the number of utterances."""
+    Lengths travel first as one small broadcast (skipped when the caller already distributed them: `lens`); then ONE packed
+    message per peer (its utterances back to back, in the order of parts[r]) in a single grouped send/recv -- at most world-1
+    messages leave `src`, whatever the number of utterances.  Returns (own (index, mel) list, all lengths)."""
     rank, world = dist.get_rank(), dist.get_world_size()
     n = sum(len(p) for p in parts)
-    lens = torch.zeros(n, dtype=torch.int64, device=device)
-    if rank == src:
-        lens = torch.tensor([m.shape[-1] for m in mels], dtype=torch.int64, device=device)
-    dist.broadcast(lens, src=src)
-    lens_l = [int(v) for v in lens.tolist()]
+    if lens is None:
+        lens_t = torch.zeros(n, dtype=torch.int64, device=device)
+        if rank == src:
+            lens_t = torch.tensor([m.shape[-1] for m in mels], dtype=torch.int64, device=device)
+        dist.broadcast(lens_t, src=src)
+        lens = lens_t.tolist()
+    lens_l = [int(v) for v in lens]
     mine = []
     if rank == src:
         ops, keep = [], []

@@ -108,6 +108,15 @@ def test_synthesize_directory_end_to_end(tmp_path):
         own = wav[b, 0, : t * 256]
         ref = (own / own.abs().max() * 32767).cpu().numpy().astype(np.int16)
         assert np.array_equal(pcm[name], ref), name
+    # mels already on the GPU (what the RCCL scatter of synthesize_sharded delivers) are collated there; return_device keeps the PCM
+    # in HBM (what its gather sends): same bits either way, and a second job on the model reuses the cached table and staging
+    dev_items = [dict(it, mel=it["mel"].cuda()) for it in items]
+    on_dev = infer.synthesize(model, dev_items, n_steps=4, max_batch=2, seed=11, return_device=True)
+    assert all(v.is_cuda and v.dtype == torch.int16 for v in on_dev.values())
+    assert all(np.array_equal(on_dev[k].cpu().numpy(), pcm[k]) for k in pcm)
+    mixed = infer.synthesize(model, dev_items, n_steps=4, max_batch=3, seed=11)
+    assert all(np.array_equal(mixed[k], pcm[k]) for k in pcm)
+    assert len(model._infer_cache["rows"]) == 1 and model._infer_cache["pin"] is not None
     paths = infer.save_wavs(pcm, str(tmp_path / "out"))
     assert sorted(os.path.basename(p) for p in paths) == ["x.npy_pred.wav", "y.npy_pred.wav", "z.npy_pred.wav"]
     sr, data = wavfile.read(paths[0])

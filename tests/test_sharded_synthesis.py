@@ -83,7 +83,7 @@ def test_synthesize_sharded_world2_gloo_stub_vocoder():
     assert ret.get() == "ok"
 
 
-def _gpu_worker(rank, world, port, ret, gpu_lock):
+def _gpu_worker(rank, world, port, ret, gpu_lock, stage="host"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import sys
@@ -108,7 +108,10 @@ def _gpu_worker(rank, world, port, ret, gpu_lock):
                     torch.cuda.synchronize()
                     return r
             infer.synthesize = one_rank_at_a_time
-        out = infer.synthesize_sharded(model, items, n_steps=4, max_batch=2, seed=77, drop_last_frame=True, src=0, device=None)
+        # stage = "device": the messages are staged on the GPU as on an RCCL node (mels collated on the device they arrive on, PCM
+        # gathered from device memory, one device-to-host copy on rank 0); gloo itself moves them through host copies (shard._exchange)
+        out = infer.synthesize_sharded(model, items, n_steps=4, max_batch=2, seed=77, drop_last_frame=True, src=0,
+                                       device=torch.device("cuda", 0) if stage == "device" else None)
         if rank == 0:
             single = infer.synthesize(model, items, n_steps=4, max_batch=4, seed=77, drop_last_frame=True)
             assert sorted(out) == sorted(single)
@@ -136,25 +139,85 @@ def _gpu_worker(rank, world, port, ret, gpu_lock):
         dist.destroy_process_group()
 
 
-@pytest.mark.gpu
-def test_synthesize_sharded_world2_hip_vocoder_equals_single_process():
-    """Both ranks drive the real HIP vocoder on cuda:0 (the test box has one GPU); every waveform of the sharded job must be bit-equal
-    to the single-process one.  The ranks take turns on the GPU: with both processes vocoding AT THE SAME TIME on the one device, about
-    3 % of runs showed one utterance off in a few hundred samples (the last 64 columns of one 256-column tile of a hop-256 layer read
-    stale; also with graph=0 and fuse_final=0; never in one process, never with the ranks taking turns: 0 of 110 runs against 5 of 171 --
-    profiles/r02/s12_s19_two_processes_one_gpu.txt).  One process per GPU, which is what the sharded path is for, has no second
-    process on its device; FD_TEST_SERIALIZE=0 restores the concurrent arrangement for hunting (tools/gpu_r2_s14.sh)."""
+def _run_two_gpu_ranks(stage):
     ctx = mp.get_context("spawn")
     ret = ctx.SimpleQueue()
     port = _free_port()
     gpu_lock = ctx.Lock()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, ret, gpu_lock)) for r in range(2)]
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, ret, gpu_lock, stage)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(600)
         assert p.exitcode == 0
     assert ret.get() == "ok"
+
+
+@pytest.mark.gpu
+def test_synthesize_sharded_world2_hip_vocoder_equals_single_process():
+    """Both ranks drive the real HIP vocoder on cuda:0 (the test box has one GPU); every waveform of the sharded job must be bit-equal
+    to the single-process one.  The ranks take turns on the GPU: with both processes vocoding AT THE SAME TIME on the one device, about
+    3 % of runs showed one utterance off in a few hundred samples (profiles/r02/s12_s19_two_processes_one_gpu.txt and the round-3
+    follow-up in DESIGN.md section 4).  One process per GPU, which is what the sharded path is for, has no second process on its
+    device; FD_TEST_SERIALIZE=0 restores the concurrent arrangement for hunting (tools/xproc_hunt.py, tools/history/gpu_r2_s14.sh)."""
+    _run_two_gpu_ranks("host")
+
+
+@pytest.mark.gpu
+def test_synthesize_sharded_world2_device_staged_messages():
+    """The same job with the messages staged on the GPU (`device=cuda`), the arrangement of an RCCL node: scattered mels arrive as
+    device tensors and are collated there, the PCM never visits the host before the gather, rank 0 brings the job back with one
+    copy.  (Round 2 crashed here: the numpy collater met a device tensor.)"""
+    _run_two_gpu_ranks("device")
+
+
+def _nccl_self_worker(ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from fastdiff_amd import shard
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                      # what bench.py prints as n_gpus
+        dist.barrier(device_ids=[0])
+        g = torch.Generator().manual_seed(5)
+        mels = [torch.rand(80, t, generator=g) for t in (7, 3, 5)]
+        packed = torch.cat([m.reshape(-1) for m in mels]).to(dev)
+        got = torch.empty_like(packed)
+        # one packed message through the grouped send/recv of the scatter, to this rank itself (isend allows src == dst)
+        shard._exchange([dist.P2POp(dist.isend, packed, 0), dist.P2POp(dist.irecv, got, 0)])
+        torch.cuda.synchronize()
+        assert torch.equal(got, packed)
+        pcm = (torch.arange(5 * 256, device=dev) % 251).to(torch.int16)      # the gather's int16 payload as bytes
+        back = torch.empty_like(pcm)
+        shard._exchange([dist.P2POp(dist.isend, shard._as_bytes(pcm), 0), dist.P2POp(dist.irecv, shard._as_bytes(back), 0)])
+        torch.cuda.synchronize()
+        assert torch.equal(back, pcm)
+        # and the whole-job helpers at world size 1 (no peers: every utterance stays on rank 0)
+        mine, lens = shard.scatter_utterances([m.to(dev) for m in mels], [[0, 1, 2]], src=0, device=dev)
+        assert lens == [7, 3, 5] and [i for i, _ in mine] == [0, 1, 2] and all(m.is_cuda for _, m in mine)
+        wavs = [(i, torch.full((lens[i] * 256,), i, dtype=torch.int16, device=dev)) for i, _ in mine]
+        out = shard.gather_waveforms(wavs, lens, [[0, 1, 2]], hop=256, dst=0, device=dev, dtype=torch.int16)
+        assert all(int(o[0]) == i and o.numel() == lens[i] * 256 for i, o in enumerate(out))
+        ret.put((float(ones.item()), dist.get_backend()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_backend_carries_the_packed_messages_world1():
+    """The `nccl` (= RCCL) branch of the sharded path on the one GPU a test box has: process group of size 1 on cuda:0, device
+    barrier, all-reduce, and the scatter's / gather's packed messages pushed through shard._exchange as a grouped self send/recv."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.SimpleQueue()
+    os.environ["MASTER_PORT"] = str(_free_port())
+    p = ctx.Process(target=_nccl_self_worker, args=(ret,))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    ones, backend = ret.get()
+    assert ones == 1.0 and backend == "nccl"
 
 
 def test_pcm_to_float_scales_every_integer_width():
