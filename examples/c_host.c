@@ -4,7 +4,9 @@
  *
  *   cc -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/c_host.c -o examples/c_host \
  *      -Lfastdiff_amd/lib -lfastdiff_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/fastdiff_amd/lib -Wl,-rpath,/opt/rocm/lib
- *   examples/c_host job.bin out.f32
+ *   examples/c_host job.bin out.f32 [pad_MiB]
+ *   (pad_MiB, optional: reserve that much device memory before anything else -- a testing aid that moves the addresses of everything
+ *   the library allocates afterwards; tools/xproc_hunt.py uses it)
  *
  * job.bin (little endian, written by tests/test_c_host.py):
  *   int32 n_tensors; per tensor: int32 name_len, name bytes, int32 ndim, int64 dims[ndim], float data[]      -- the state_dict
@@ -26,9 +28,13 @@ static void rd(FILE *f, void *dst, size_t n) { if (fread(dst, 1, n, f) != n) DIE
 
 int main(int argc, char **argv)
 {
-    if (argc != 3) DIE("usage: %s job.bin out.f32", argv[0]);
+    if (argc != 3 && argc != 4) DIE("usage: %s job.bin out.f32 [pad_MiB]", argv[0]);
     FILE *f = fopen(argv[1], "rb");
     if (!f) DIE("cannot open %s", argv[1]);
+    if (argc == 4 && atol(argv[3]) > 0) {
+        void *pad;
+        HIP(hipMalloc(&pad, (size_t)atol(argv[3]) << 20));      /* kept until exit */
+    }
 
     fd_config cfg;
     fd_handle h = NULL;

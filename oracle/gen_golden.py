@@ -227,7 +227,7 @@ def run_sampler(model, dtype, B, T, N, dh, noises, ddim, return_sequence):
     return res
 
 
-def gen_sample(dh):
+def gen_sample(dh, only=None):
     m32 = make_model(torch.float32)
     m64 = make_model(torch.float64)
     cases = {
@@ -237,8 +237,13 @@ def gen_sample(dh):
         "s3": (1, 5, 6, False, False, True),
         "s4": (1, 4, 1000, False, False, True),
         "s5": (1, 4, 8, False, False, True),
+        # BASELINE configs[2] at a length with tile edges (four 256-column tiles per frame row at hop 256, 64 frames): the full
+        # N = 1000 schedule; stored: x_0 and the state after every 125 steps (the whole sequence is 65 MB)
+        "s6": (1, 64, 1000, False, "every125", True),
     }
     for ci, (name, (B, T, N, ddim, seq, run64)) in enumerate(cases.items()):
+        if only and name not in only:
+            continue
         mel = synth.synth_mel(SEED + 100 + ci, B, T)
         n_el = B * T * 256
         x_T = synth.hash_normal(SEED + 100 + ci, 1, n_el).reshape(B, 1, T * 256)
@@ -254,13 +259,17 @@ def gen_sample(dh):
             model._mel = torch.from_numpy(mel).to(dt)
             dh_t = {"T": dh["T"], "alpha": dh["alpha"], "beta": dh["beta"], "sigma": dh["sigma"]}
             res = run_sampler(model, dt, B, T, N, dh_t, noises, ddim, seq)
-            if seq:
+            if seq == "every125":
+                out["ckpt_idx"] = np.arange(0, N + 1, 125)
+                out[f"ckpt_{tag}"] = np.stack([res[k].numpy() for k in range(0, N + 1, 125)])
+                out[f"y_{tag}"] = res[N].numpy()
+            elif seq:
                 out[f"seq_{tag}"] = np.stack([r.numpy() for r in res])
             else:
                 out[f"y_{tag}"] = res.numpy()
         np.savez_compressed(os.path.join(GOLD, f"sample_{name}.npz"), **out)
-        key = "seq_f32" if seq else "y_f32"
-        k64 = "seq_f64" if seq else "y_f64"
+        key = "seq_f32" if seq is True else "y_f32"
+        k64 = "seq_f64" if seq is True else "y_f64"
         print(name, "max|y|", float(np.abs(out[key]).max()), "f32-vs-f64", float(np.abs(out[key] - out[k64]).max()) if k64 in out else None)
 
 
@@ -578,6 +587,9 @@ if __name__ == "__main__":
         gen_forward()
     if "sample" in which:
         gen_sample(dh)
+    for w in which:                       # "sample:s6" regenerates one sampler case
+        if w.startswith("sample:"):
+            gen_sample(dh, only=w.split(":", 1)[1].split(","))
     if "manifest" in which:
         gen_statedict_manifest()
     if "collate" in which:

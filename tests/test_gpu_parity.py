@@ -297,6 +297,40 @@ def test_everything_out_of_fp16_range_falls_back_on_device(gc, oracle64):
     assert gc.maxdiff(y, y_ref) < 3e-6 * float(np.abs(y_ref).max())
 
 
+def test_sampler_hands_over_to_fp32_at_64_frames(gc, sched):
+    """The hand-over inside the sampler at a length with tile edges (64 frames, a ragged batch of two): with the first conv scaled by
+    1e7 every DBlock / ConvTranspose / LVC launch of step 0 raises its flag and is redone by the fp32 kernel behind it; from step 1
+    on those launches skip their fp16 attempt (skip_after_previous_overflow).  The result must agree with the same call on the
+    fp32 kernels selected outright (options lvc = conv = fp32), relative to its own scale, and the call's flags must say so."""
+    import synth
+    sd = dict(synth.synth_state_dict(1234))
+    sd["first_audio_conv.weight_g"] = (sd["first_audio_conv.weight_g"] * 1.0e7).astype(np.float32)
+    B, T, N = 2, 64, 8
+    lens = [64, 40]
+    rows, _ = gc.table_rows(sched, N)
+    mel = torch.from_numpy(synth.synth_mel(9, B, T)).cuda()
+    mel[1, :, lens[1]:] = 0.0
+    out = {}
+    for tag, opts in (("handover", {}), ("fp32", {"lvc": "fp32", "conv": "fp32"})):
+        m = gc.fastdiff_amd.FastDiff()
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+        m = m.cuda().eval()
+        for k, v in opts.items():
+            m.set_option(k, v)
+        with torch.no_grad():
+            y = m.sample(mel, rows, seed=5, lens=lens, stream_ids=[0, 1])
+        out[tag] = [y[b, 0, : lens[b] * 256].cpu().numpy() for b in range(B)]
+        flags = m.read_tap("range_flags_call").view(np.int32)
+        if tag == "handover":
+            assert flags[0] == 0 and flags[13:19].all() and flags[1:13].reshape(3, 4)[1:].all(), flags[:20]
+        else:
+            assert not flags[1:19].any()
+    for b in range(B):
+        scale = float(np.abs(out["fp32"][b]).max())
+        assert np.isfinite(out["handover"][b]).all() and scale > 32768.0
+        assert gc.maxdiff(out["handover"][b], out["fp32"][b]) < 1e-5 * scale, (b, scale)
+
+
 def test_ragged_batch_with_lens_equals_each_utterance_alone(gc, sched):
     """BASELINE config 4 in small: utterances of different length in one zero-padded batch.  With `lens` every utterance must
     come out bit-identical to running it alone at its own length (forward, and the N-step sampler through the cached graph),
@@ -534,6 +568,41 @@ def test_n1000_full_schedule_drift(model, gc, sched):
     ref_drift = gc.maxdiff(g["y_f32"], g["y_f64"])
     assert np.isfinite(y).all()
     assert gc.maxdiff(y, g["y_f64"]) < 10 * ref_drift, (gc.maxdiff(y, g["y_f64"]), ref_drift)
+
+
+def test_n1000_at_64_frames_against_the_reference_trajectory(gc, sched):
+    """BASELINE configs[2] with tile edges: 64 frames (16 tiles per row at hop 256, partial workgroups at hop 8), the full N = 1000
+    schedule, against the reference's own float64 trajectory every 125 steps (tests/golden/sample_s6.npz).  Bar: 10x the float32
+    reference's own distance from its float64 run at the same checkpoint (floor 2e-5).  The same call with every contraction on
+    the exact-fp32 pipe must meet the same bar; the range flags say which launches, if any, handed over to their fp32 kernels."""
+    g = load_golden("sample_s6")
+    N = int(g["N"])
+    B, _, T = g["mel"].shape
+    rows, _ = gc.table_rows(sched, N)
+    noise = torch.from_numpy(gc.exec_order_noise(gc.noise_from_seed(int(g["seed"]), B, T, N))).cuda()
+    mel, x_T = torch.from_numpy(g["mel"]).cuda(), torch.from_numpy(g["x_T"]).cuda()
+    idx = [int(k) for k in g["ckpt_idx"]]
+    worst = {}
+    for pipe in ("f16x2", "fp32"):
+        m = gc.make_model()
+        for k in ("gemm", "lvc", "conv"):
+            m.set_option(k, pipe)
+        with torch.no_grad():
+            seq = m.sample(mel, rows, x_T=x_T, noise=noise, return_sequence=True)
+        flags = m.read_tap("range_flags_call").view(np.int32)
+        for i, k in enumerate(idx):
+            got = seq[k].cpu().numpy()
+            assert np.isfinite(got).all()
+            ref_drift = gc.maxdiff(g["ckpt_f32"][i], g["ckpt_f64"][i])
+            d = gc.maxdiff(got, g["ckpt_f64"][i])
+            assert d <= max(10 * ref_drift, 2e-5), (pipe, k, d, ref_drift)
+            worst[(pipe, k)] = (d, ref_drift)
+        if pipe == "fp32":
+            assert not flags.any()            # the fp32 kernels have no operand range to watch
+        else:
+            # this trajectory stays small (|x| <= 631 at x_0): no launch may have left the fp16 pipe
+            assert not flags.any(), np.nonzero(flags)[0]
+    print("n1000 T=64 worst (ours vs f64, reference f32 vs f64):", {k: (f"{v[0]:.2e}", f"{v[1]:.2e}") for k, v in worst.items() if k[1] in (125, 1000)})
 
 
 def test_drop_in_sampling_function(model, gc, sched, oracle64):

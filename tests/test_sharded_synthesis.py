@@ -83,7 +83,7 @@ def test_synthesize_sharded_world2_gloo_stub_vocoder():
     assert ret.get() == "ok"
 
 
-def _gpu_worker(rank, world, port, ret, gpu_lock, stage="host"):
+def _gpu_worker(rank, world, port, ret, gpu_lock, stage="host", sharing="turns"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import sys
@@ -98,7 +98,7 @@ def _gpu_worker(rank, world, port, ret, gpu_lock, stage="host"):
         model = gpu_common.make_model()
         lens = [40, 12, 33, 7, 25, 18, 40, 3, 29]
         items = _items(11, lens) if rank == 0 else None
-        if os.environ.get("FD_TEST_SERIALIZE", "1") == "1":
+        if sharing == "turns" and os.environ.get("FD_TEST_SERIALIZE", "1") == "1":
             # the two ranks take turns on the one GPU of the test box (see the note at the test below)
             real = infer.synthesize
 
@@ -129,6 +129,9 @@ def _gpu_worker(rank, world, port, ret, gpu_lock, stage="host"):
                           f"least-squares scale sharded/single {scale:.6f}, residual after scaling {np.abs(a - scale * b).max():.1f}; "
                           f"a second single-process run equals: sharded {np.array_equal(a, c)}, single {np.array_equal(b, c)}", flush=True)
                     np.savez_compressed(os.path.join(dump, f"sharded_mismatch_{name}.npz"), sharded=out[name], single=single[name], again=again[name])
+            if bad and sharing == "masks":
+                ret.put("mismatch " + ",".join(bad))
+                return
             assert not bad, bad
             assert all(v.dtype == np.int16 for v in out.values())
             other = infer.synthesize(model, items, n_steps=4, max_batch=4, seed=78, drop_last_frame=True)
@@ -139,28 +142,49 @@ def _gpu_worker(rank, world, port, ret, gpu_lock, stage="host"):
         dist.destroy_process_group()
 
 
-def _run_two_gpu_ranks(stage):
+def _run_two_gpu_ranks(stage, sharing="turns"):
     ctx = mp.get_context("spawn")
     ret = ctx.SimpleQueue()
     port = _free_port()
     gpu_lock = ctx.Lock()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, ret, gpu_lock, stage)) for r in range(2)]
-    for p in procs:
-        p.start()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, ret, gpu_lock, stage, sharing)) for r in range(2)]
+    saved = os.environ.get("HSA_CU_MASK")
+    try:
+        for r, p in enumerate(procs):
+            if sharing == "masks":      # each rank gets its own half of the CUs (read by the ROCm runtime when the child initialises it)
+                os.environ["HSA_CU_MASK"] = "0:0-127" if r == 0 else "0:128-255"
+            p.start()
+    finally:
+        if saved is None:
+            os.environ.pop("HSA_CU_MASK", None)
+        else:
+            os.environ["HSA_CU_MASK"] = saved
     for p in procs:
         p.join(600)
         assert p.exitcode == 0
-    assert ret.get() == "ok"
+    return ret.get()
 
 
 @pytest.mark.gpu
 def test_synthesize_sharded_world2_hip_vocoder_equals_single_process():
     """Both ranks drive the real HIP vocoder on cuda:0 (the test box has one GPU); every waveform of the sharded job must be bit-equal
-    to the single-process one.  The ranks take turns on the GPU: with both processes vocoding AT THE SAME TIME on the one device, about
-    3 % of runs showed one utterance off in a few hundred samples (profiles/r02/s12_s19_two_processes_one_gpu.txt and the round-3
-    follow-up in DESIGN.md section 4).  One process per GPU, which is what the sharded path is for, has no second process on its
-    device; FD_TEST_SERIALIZE=0 restores the concurrent arrangement for hunting (tools/xproc_hunt.py, tools/history/gpu_r2_s14.sh)."""
-    _run_two_gpu_ranks("host")
+    to the single-process one.  The ranks take turns on the GPU here.  Why: two processes vocoding on the SAME compute units can
+    disturb each other -- round 2 saw ~3 % of concurrent runs with one utterance off in a few hundred samples; round 3 narrowed it
+    down (profiles/r03/two_processes_one_gpu.txt, tools/xproc_hunt.py): it takes a second process that starts,
+    runs this library's sampler and exits while sharing CUs with the victim; long-lived neighbours, allocation churn, code-object
+    loads and foreign kernels do nothing, and with the two processes on disjoint CU masks it does not happen (next test).
+    One process per GPU, which is what the sharded path is for, has no second process on its device."""
+    assert _run_two_gpu_ranks("host") == "ok"
+
+
+@pytest.mark.gpu
+def test_synthesize_sharded_world2_concurrent_on_disjoint_compute_units():
+    """The same job with both ranks vocoding AT THE SAME TIME, each on its own half of the GPU's compute units (HSA_CU_MASK): the
+    arrangement measured clean in round 3 (0 mismatches where ~15 were expected without the masks).  A mismatch here is reported as
+    an expected failure of the platform arrangement, not of the kernels -- visible in the summary, not silently retried."""
+    res = _run_two_gpu_ranks("host", sharing="masks")
+    if res != "ok":
+        pytest.xfail("two processes on one GPU disturbed each other despite disjoint CU masks: " + res)
 
 
 @pytest.mark.gpu
@@ -168,7 +192,7 @@ def test_synthesize_sharded_world2_device_staged_messages():
     """The same job with the messages staged on the GPU (`device=cuda`), the arrangement of an RCCL node: scattered mels arrive as
     device tensors and are collated there, the PCM never visits the host before the gather, rank 0 brings the job back with one
     copy.  (Round 2 crashed here: the numpy collater met a device tensor.)"""
-    _run_two_gpu_ranks("device")
+    assert _run_two_gpu_ranks("device") == "ok"
 
 
 def _nccl_self_worker(ret):

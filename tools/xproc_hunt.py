@@ -41,7 +41,15 @@ def aggressor(mode):
         "model": [sys.executable, "-c", f"import sys; sys.path[:0] = [{ROOT!r}, {os.path.join(ROOT, 'oracle')!r}, {os.path.join(ROOT, 'tests')!r}]; "
                   "import torch, gpu_common; m = gpu_common.make_model(); m._ready(torch.device('cuda', 0)); torch.cuda.synchronize()  # %d"],
         "chost": [os.path.join(ROOT, "examples", "c_host"), "/tmp/xproc_job.bin", "/tmp/xproc_chost_%d.f32"],      # the library without Python or torch
+        "chost_pad": [os.path.join(ROOT, "examples", "c_host"), "/tmp/xproc_job.bin", "/tmp/xproc_chost_%d.f32", "1536"],      # the same, every address moved by 1.5 GiB
+        # the library's code object loaded and ONE small kernel of it launched (the int16 epilogue on 1 MB): no workspace, no sampler
+        "modload": [sys.executable, os.path.abspath(__file__), "--aggressor", "modload_once"],
+        # a different code object (a stand-alone HIP binary of tools/ubench), fresh process each time
+        "othermod": [os.path.join(ROOT, "tools", "ubench", "copy_mix_probe")],
     }
+    if mode in ("fdloop", "fdloop_pad"):      # a second long-lived sampler loop of the same shapes (its first call is ~8 s after its start)
+        env = dict(os.environ, FD_HUNT_PAD_MB="1536") if mode == "fdloop_pad" else dict(os.environ)
+        os.execve(sys.executable, [sys.executable, os.path.abspath(__file__), "100000", "idle", "fd"], env)
     if mode in fresh:
         while True:
             ps = [subprocess.Popen([a.replace("%d", str(i)) for a in fresh[mode]], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for i in range(2)]
@@ -49,6 +57,19 @@ def aggressor(mode):
                 p.wait()
     hip = ct.CDLL("libamdhip64.so")
     hip.hipSetDevice(0)
+    if mode == "modload_once":
+        lib = ct.CDLL(os.path.join(ROOT, "fastdiff_amd", "lib", "libfastdiff_hip.so"))
+        cfg = (ct.c_int * 64)()
+        lib.fd_default_config(cfg)
+        h, d, p = ct.c_void_p(), ct.c_void_p(), ct.c_void_p()
+        assert lib.fd_create(cfg, 0, ct.byref(h)) == 0
+        hip.hipMalloc(ct.byref(d), ct.c_size_t(1 << 20))
+        hip.hipMemset(d, 0x3c, ct.c_size_t(1 << 20))
+        hip.hipMalloc(ct.byref(p), ct.c_size_t(1 << 19))
+        lib.fd_peak_normalize_int16.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int64, ct.c_void_p, ct.c_void_p]
+        assert lib.fd_peak_normalize_int16(h, d, 1, 1 << 18, p, None) == 0
+        hip.hipDeviceSynchronize()
+        return
     if mode == "oneshot":
         d = ct.c_void_p()
         if hip.hipMalloc(ct.byref(d), ct.c_size_t(64 << 20)) == 0:
@@ -111,6 +132,8 @@ def main():
         for b, i in enumerate(pick):
             mel[b, :, : lens[b]] = mels_all[i][: lens[b]].T
         rows = InferenceSchedule(schedules.training_hyperparams(), schedules.noise_schedule_for(4), verbose=False).rows()
+        if os.environ.get("FD_HUNT_PAD_MB"):      # moves the addresses of everything allocated afterwards
+            pad = torch.empty(int(os.environ["FD_HUNT_PAD_MB"]) << 20, dtype=torch.uint8, device="cuda")
         model = gpu_common.make_model()
         for kv in filter(None, os.environ.get("FD_HUNT_OPTS", "").split(",")):
             model.set_option(*kv.split("=", 1))
@@ -150,8 +173,12 @@ def main():
     for mode in modes:
         ag = None
         if mode != "idle":
+            env = dict(os.environ)
+            for kv in filter(None, os.environ.get("XPROC_AGG_ENV", "").split(";")):      # e.g. a CU mask for the aggressor only
+                env[kv.split("=", 1)[0]] = kv.split("=", 1)[1]
+            env.pop("HSA_CU_MASK", None) if "HSA_CU_MASK" not in os.environ.get("XPROC_AGG_ENV", "") else None
             ag = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--aggressor", mode], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                                  start_new_session=True)
+                                  start_new_session=True, env=env)
             time.sleep(1.0)
         t0, it, bad = time.time(), 0, 0
         while time.time() - t0 < secs:
@@ -161,13 +188,14 @@ def main():
                 bad += 1
                 d = np.abs(r.astype(np.float64) - ref).reshape(-1)
                 nz = np.nonzero(d)[0]
-                print(f"  {mode}: iteration {it}: {nz.size} values differ, max {d.max():.3e}, first {nz[0]}, last {nz[-1]}", flush=True)
+                print(f"  {mode}: t = {time.time() - t0:.1f} s, iteration {it}: {nz.size} values differ, max {d.max():.3e}, first {nz[0]}, last {nz[-1]}", flush=True)
                 if bad <= 4:
                     np.savez_compressed(os.path.join(ROOT, "gpurun_out", f"xproc_{victim}_{mode}_{it}.npz"), got=r, ref=ref)
         if ag is not None:
             os.killpg(ag.pid, 9)          # the aggressor's own process group (start_new_session): exactly what this script started
             ag.wait()
-        line = f"victim {victim}, aggressor {mode}: {it} iterations in {time.time() - t0:.1f} s, {bad} mismatches"
+        line = (f"victim {victim} [{os.environ.get('FD_HUNT_OPTS', '')}] [victim mask {os.environ.get('HSA_CU_MASK', '-')}; aggressor env "
+                f"{os.environ.get('XPROC_AGG_ENV', '-')}], aggressor {mode}: {it} iterations in {time.time() - t0:.1f} s, {bad} mismatches")
         print(line, flush=True)
         summary.append(line)
     with open(os.path.join(ROOT, "gpurun_out", f"xproc_hunt_{victim}.txt"), "a") as f:
