@@ -494,6 +494,12 @@ def main():
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
 
+    if os.environ.get("FD_BENCH_OVERSUBSCRIBE") == "1" and "LOCAL_RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # ranks sharing one GPU get disjoint compute units (must be set before the ROCm runtime initialises): two vocoding processes on
+        # the same CUs can disturb each other around process start / exit (profiles/r03/two_processes_one_gpu.txt)
+        w_, r_ = int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+        per = 256 // w_
+        os.environ.setdefault("HSA_CU_MASK", "0:%d-%d" % (r_ * per, (r_ + 1) * per - 1))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: fastdiff_amd has no CPU path")
     n_dev = torch.cuda.device_count()

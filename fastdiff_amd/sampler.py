@@ -208,6 +208,32 @@ def theta_timestep_loss(net, X, diffusion_hyperparams, reverse=False):
     return loss
 
 
+def phi_loss(net, X, diffusion_hyperparams):
+    """The BDDM loss of the scheduling network (util.py:328-362); same signature.  Needs `net.noise_pred(x_t [B, L], (beta_next
+    [B, 1], delta^2 [B, 1]))` -- the network the reference calls but never defines, so with the stock module it
+    ends, there as here, in AttributeError after the denoiser evaluation.  The denoiser evaluation itself is FastDiff.forward:
+    the inference kernels under no_grad, the autograd graph of fastdiff_amd/train.py otherwise.
+    Random draws in the reference's order: torch.randint for the steps, then std_normal for z."""
+    assert type(X) == tuple and len(X) == 2
+    dh = diffusion_hyperparams
+    T_train, alpha, tau = dh["T"], dh["alpha"], dh["tau"]
+    mel_spectrogram, audio = X
+    n_items = audio.shape[0]
+    ts = torch.randint(tau, T_train - tau, size=(n_items,)).cuda()
+    alpha = alpha.to(ts.device)
+    alpha_cur = alpha.index_select(0, ts).view(n_items, 1, 1)
+    alpha_nxt = alpha.index_select(0, ts + tau).view(n_items, 1, 1)
+    beta_nxt = 1 - (alpha_nxt / alpha_cur) ** 2.
+    delta = (1 - alpha_cur ** 2.).sqrt()
+    z = std_normal(audio.shape)
+    x_t = alpha_cur * audio + delta * z                     # a draw of q(x_t | x_0)
+    eps = net((x_t, mel_spectrogram, ts.view(n_items, 1)))
+    beta_est = net.noise_pred(x_t.squeeze(1), (beta_nxt.view(n_items, 1), delta.view(n_items, 1) ** 2.))
+    loss = 1 / (2. * (delta ** 2. - beta_est)) * (delta * z - beta_est / delta * eps) ** 2.
+    loss = loss + torch.log(1e-8 + delta ** 2. / (beta_est + 1e-8)) / 4.
+    return (torch.mean(loss, -1, keepdim=True) + beta_est / delta ** 2 / 2.).mean()
+
+
 def noise_scheduling(net, size, diffusion_hyperparams, condition=None, ddim=False):
     """Greedy search of an inference schedule with a learned noise predictor; same signature as util.py:237.
 

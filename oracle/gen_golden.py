@@ -330,6 +330,35 @@ def gen_theta_loss(dh):
     np.savez_compressed(os.path.join(GOLD, "theta_loss.npz"), **out)
 
 
+def gen_phi_loss(dh):
+    """util.py:328-362 on the reference module with synth.stub_noise_pred_batch attached as `noise_pred` (the reference ships no such
+    network); random steps and z replayed; the loss for float32 and float64."""
+    B, T, tau = 3, 6, 50
+    mel = synth.synth_mel(SEED + 600, B, T)
+    audio = (0.3 * synth.hash_normal(SEED + 600, 1, B * T * 256)).reshape(B, 1, T * 256).astype(np.float32)
+    z = synth.hash_normal(SEED + 600, 2, B * T * 256).reshape(B, 1, T * 256)
+    ts = np.array([50, 437, 949], np.int64)
+    out = {"mel": mel, "audio": audio, "z": z, "ts": ts, "tau": np.int64(tau)}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        model = make_model(dt)
+        model.noise_pred = synth.stub_noise_pred_batch
+        fwd = model.forward
+        if dt == torch.float64:
+            model.forward = lambda data: fwd((data[0], data[1], data[2].double()))
+        orig_n, orig_r = ref_util.std_normal, torch.randint
+        ref_util.std_normal = lambda size: torch.from_numpy(z.copy()).to(dt).view(*size)
+        torch.randint = lambda *a, **k: torch.from_numpy(ts.copy())
+        try:
+            with torch.no_grad():
+                loss = ref_util.phi_loss(model, (torch.from_numpy(mel).to(dt), torch.from_numpy(audio).to(dt)),
+                                         {"T": dh["T"], "alpha": dh["alpha"].to(dt), "tau": tau})
+        finally:
+            ref_util.std_normal, torch.randint = orig_n, orig_r
+        out[f"loss_{tag}"] = np.float64(loss.item())
+        print("phi_loss", tag, loss.item())
+    np.savez_compressed(os.path.join(GOLD, "phi_loss.npz"), **out)
+
+
 def grad_sample(t, n=64):
     """What the theta_grad fixture keeps of a gradient tensor: its L2 norm and n evenly spaced elements of the flattened tensor."""
     flat = t.detach().double().reshape(-1)
@@ -577,7 +606,7 @@ def gen_statedict_manifest():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["schedule", "embed", "ops", "forward", "sample", "manifest", "collate", "collater", "frontend", "frontend_tacotron",
-                             "frontend_pwg", "noise_scheduling", "theta_loss", "theta_grad", "lvc_grad"]
+                             "frontend_pwg", "noise_scheduling", "theta_loss", "phi_loss", "theta_grad", "lvc_grad"]
     dh = gen_schedule()
     if "embed" in which:
         gen_embed()
@@ -604,6 +633,8 @@ if __name__ == "__main__":
         gen_frontend()
     if "theta_loss" in which:
         gen_theta_loss(dh)
+    if "phi_loss" in which:
+        gen_phi_loss(dh)
     if "theta_grad" in which:
         gen_theta_grad(dh)
     if "noise_scheduling" in which:

@@ -105,6 +105,15 @@ def synth_audio(seed: int, B: int, T: int, stream: int = 900002) -> np.ndarray:
     return hash_normal(seed, stream, B * T * 256).reshape(B, 1, T * 256)
 
 
+def stub_noise_pred_batch(x, cond):
+    """The same stand-in for a batch (phi_loss, util.py:356): x [B, L]; cond = (beta_next [B,1], delta^2 [B,1]) -> beta [B,1,1] in
+    (0, min(beta_next, delta^2)), a smooth function of each item's own x."""
+    import torch
+    beta_next, delta2 = cond
+    ratio = 0.3 + 0.2 * torch.tanh(x.abs().mean(-1, keepdim=True))
+    return torch.minimum(beta_next * ratio, delta2 * 0.9).view(-1, 1, 1)
+
+
 def stub_noise_pred(x, cond):
     """A stand-in for the BDDM scheduling network the reference calls but does not ship (`net.noise_pred`, util.py:284-285;
     SURVEY.md 3.5): any deterministic, smooth function of (x, beta_next, 1 - alpha^2) exercises noise_scheduling's arithmetic.

@@ -691,6 +691,28 @@ def test_validation_loss_on_the_hip_denoiser(model, gc, sched, monkeypatch):
         model.sample(X[0].clone().requires_grad_(True), [{"t": 0.0, "c_eps": 0.0, "c_div": 1.0, "sigma": 0.0, "c1": 1.0, "c2": 0.0, "c3": 0.0, "add_noise": 0}])
 
 
+def test_phi_loss_on_the_hip_denoiser(gc, sched, monkeypatch):
+    """phi_loss (util.py:328-362) with the HIP module as `net` and the stand-in noise_pred of the fixture attached to it: the
+    reference's value (golden: gen_phi_loss, steps and z replayed); the stock module (no noise_pred) ends in AttributeError."""
+    import fastdiff_amd
+    import synth
+    from fastdiff_amd import sampler
+    g = load_golden("phi_loss")
+    monkeypatch.setattr(sampler, "std_normal", lambda size: torch.from_numpy(g["z"].copy()).view(*size).cuda())
+    monkeypatch.setattr(torch, "randint", lambda *a, **k: torch.from_numpy(g["ts"].copy()))
+    dh = {"T": 1000, "alpha": torch.from_numpy(sched["train_alpha"]).cuda(), "tau": int(g["tau"])}
+    X = (torch.from_numpy(g["mel"]).cuda(), torch.from_numpy(g["audio"]).cuda())
+    m = gc.make_model()
+    with torch.no_grad():
+        with pytest.raises(AttributeError):
+            fastdiff_amd.phi_loss(m, X, dh)
+        m.noise_pred = synth.stub_noise_pred_batch
+        loss = fastdiff_amd.phi_loss(m, X, dh)
+    ref = float(g["loss_f64"])
+    print("phi loss %.9f, |d| vs f64 reference %.2e (fp32 reference: %.2e)" % (loss.item(), abs(loss.item() - ref), abs(float(g["loss_f32"]) - ref)))
+    assert abs(loss.item() - ref) < 2e-6 * abs(ref)
+
+
 def test_philox_noise_statistics(model):
     import fastdiff_amd
     B, T = 4, 16

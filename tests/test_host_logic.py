@@ -238,6 +238,32 @@ def test_theta_timestep_loss_host_arithmetic_matches_the_reference(monkeypatch, 
         sampler.theta_timestep_loss(net, [X[0], X[1]], dh)                # util.py:306: X must be a 2-tuple
 
 
+def test_phi_loss_host_arithmetic_matches_the_reference(monkeypatch, oracle64):
+    """phi_loss (util.py:328-362) with a stand-in noise_pred: golden = the reference function on the reference module with the
+    random steps and z replayed (oracle/gen_golden.py gen_phi_loss).  Denoiser = float64 oracle, so the step pairs (t, t + tau),
+    beta_next, the q(x_t|x_0) mix and the loss expression are what is under test; without a noise_pred: AttributeError."""
+    import synth
+    from fastdiff_amd import sampler
+    g, sch = load_golden("phi_loss"), load_golden("schedule")
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    monkeypatch.setattr(sampler, "std_normal", lambda size: torch.from_numpy(g["z"].copy()).double().view(*size))
+    monkeypatch.setattr(torch, "randint", lambda *a, **k: torch.from_numpy(g["ts"].copy()))
+
+    class Net:
+        noise_pred = staticmethod(synth.stub_noise_pred_batch)
+
+        def __call__(self, data):
+            return torch.from_numpy(oracle64.forward(data[0].numpy(), data[1].numpy(), data[2].numpy().reshape(-1).astype(np.float64)))
+
+    dh = {"T": 1000, "alpha": torch.from_numpy(sch["train_alpha"]).double(), "tau": int(g["tau"])}
+    X = (torch.from_numpy(g["mel"]).double(), torch.from_numpy(g["audio"]).double())
+    loss = sampler.phi_loss(Net(), X, dh)
+    assert abs(loss.item() - float(g["loss_f64"])) < 1e-9 * abs(float(g["loss_f64"]))
+    assert abs(float(g["loss_f32"]) - float(g["loss_f64"])) < 1e-4 * abs(float(g["loss_f64"]))
+    with pytest.raises(AttributeError):
+        sampler.phi_loss(lambda data: Net()(data), X, dh)                 # the stock module has no noise_pred (SURVEY.md 3.5)
+
+
 def test_product_never_touches_the_oracle_or_the_reference():
     """The shipped package (fastdiff_amd/, bench.py's measured path aside from its baseline legs) must not import, link or open
     anything under oracle/ or /root/reference: the checker is not the product."""
