@@ -443,20 +443,20 @@ def project_sharded(args, model, items, t_full, dev):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps, r
 
-    def prep():      # rank 0: [80, T] views of every mel, one packed device buffer per peer
-        mels = [torch.from_numpy(np.ascontiguousarray(it["mel"].numpy().T)) for it in items]
-        return [torch.cat([mels[i].reshape(-1) for i in p]).to(dev, non_blocking=True) for p in parts]
+    def prep():      # rank 0 (infer.synthesize_sharded -> shard.scatter_utterances): every mel as stored, packed once, one upload
+        return shard.pack_messages([it["mel"] for it in items], parts, dev)
     t_prep, packed = timed(prep)
     shares = []
     for r, p in enumerate(parts):
         off, local = 0, []
         for i in p:
-            local.append({"item_name": str(i), "mel": packed[r][off: off + 80 * lens[i]].view(80, lens[i]).transpose(0, 1), "len": lens[i], "uid": i})
+            local.append({"item_name": str(i), "mel": packed[r][off: off + 80 * lens[i]].view(lens[i], 80), "len": lens[i], "uid": i})
             off += 80 * lens[i]
         t_r, pcm = timed(lambda: infer.synthesize(model, local, N, args.batch, 1234, drop_last_frame=False, return_device=True))
         shares.append(t_r)
     whole = torch.empty(sum(lens) * HOP, dtype=torch.int16, device=dev)
-    t_back, _ = timed(lambda: whole.cpu())
+    pin = shard._pinned_buffer("job_pcm", whole.numel(), torch.int16)[: whole.numel()]
+    t_back, _ = timed(lambda: (pin.copy_(whole, non_blocking=True), torch.cuda.current_stream().synchronize(), pin.numpy().copy()))
     t_share, t_fixed = max(shares), t_prep + t_back
     return {"projected_ranks": R, "is_a_projection": True, "t_full_1gpu_ms": round(t_full * 1e3, 3),
             "t_share_ms": {"max": round(t_share * 1e3, 3), "min": round(min(shares) * 1e3, 3)},

@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stddef.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -162,6 +163,10 @@ int fd_create(const fd_config *cfg, int device, fd_handle *out)
     }
     for (int i = 0; i < ST_COUNT; ++i) c->fast[i] = true;
     if ((e = hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_join[0], hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_join[1], hipEventDisableTiming)) != hipSuccess ||
         (e = hipMalloc(&c->scratch, 65536)) != hipSuccess) {
         g_create_error = std::string("fd_create: ") + hipGetErrorString(e);
         delete c;
@@ -236,6 +241,9 @@ int fd_destroy(fd_handle h)
     }
     for (void *p : h->mel_allocs) hipFree(p);
     if (h->cap_stream) hipStreamDestroy(h->cap_stream);
+    if (h->side_stream) hipStreamDestroy(h->side_stream);
+    for (hipEvent_t ev : {h->ev_fork, h->ev_join[0], h->ev_join[1]})
+        if (ev) hipEventDestroy(ev);
     delete h;
     return FD_OK;
 }
@@ -750,10 +758,25 @@ static hipError_t run_step(const Launch &L, const StepIO &io, int B, int T)
     for (int d = 0; d < fd::NBLK; ++d)
         if ((e = dblock(L, io, d, B, T)) != hipSuccess) return e;
     if ((e = kp_front(L, io, B, T)) != hipSuccess) return e;
-    if ((e = kp_gemm(L, B, T)) != hipSuccess) return e;
+    // option overlap = gemm: block 0's predicted kernels first, then [LVC block 0 || GEMM block 1] and [LVC block 1 || GEMM block 2]:
+    // the matrix-bound GEMM next to the memory-bound layers instead of in front of them, and block 0's records read while fresh
+    const bool overlap = c->overlap_gemm && c->fast[ST_KP_GEMM] && c->side_stream && fd_pipe(c, c->gemm_f16 && c->w.gemm_f16_ok, 0) != PIPE_F32_ONLY;
+    if (!overlap) {
+        if ((e = kp_gemm(L, B, T)) != hipSuccess) return e;
+    } else {
+        if ((e = fast_kp_gemm(L, B, T, 0, 1, 2)) != hipSuccess) return e;        // + the fp32 fallback of all three blocks behind it
+        if ((e = hipEventRecord(c->ev_fork, L.stream)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(c->side_stream, c->ev_fork, 0)) != hipSuccess) return e;
+        const Launch Ls = {c, c->side_stream, L.capturing};
+        for (int n = 1; n < fd::NBLK; ++n) {
+            if ((e = fast_kp_gemm(Ls, B, T, n, 1, c->overlap_wg)) != hipSuccess) return e;
+            if ((e = hipEventRecord(c->ev_join[n - 1], c->side_stream)) != hipSuccess) return e;
+        }
+    }
     float *x = ws.a[3];
     for (int n = 0; n < fd::NBLK; ++n) {
         float *xo = nullptr;
+        if (overlap && n > 0 && (e = hipStreamWaitEvent(L.stream, c->ev_join[n - 1], 0)) != hipSuccess) return e;
         if ((e = lvc_block_run(L, n, x, B, T, &xo)) != hipSuccess) return e;
         x = xo;
     }
@@ -861,7 +884,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
 static unsigned mode_signature(const fd_context *h)
 {
     unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_f16 ? 2u : 0u) | (h->lvc_f16 ? 4u : 0u) | (h->conv_f16 ? 8u : 0u) | (h->step_lens ? 16u : 0u) |
-                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u);
+                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u) | (h->overlap_gemm ? 128u : 0u) | ((unsigned)h->overlap_wg << 8);
     for (int i = 0; i < ST_COUNT; ++i) s = (s << 1) | (h->fast[i] ? 1u : 0u);
     return s ^ (h->fp32_mask * 2654435761u);
 }
@@ -1314,6 +1337,20 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
         return FD_OK;
     }
     if (k == "fuse_final") { h->fuse_final = on; drop_graph(h); return FD_OK; }
+    if (k == "overlap") {
+        if (v == "gemm") h->overlap_gemm = true;
+        else if (v == "off") h->overlap_gemm = false;
+        else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: overlap expects gemm|off, got '%s'", value);
+        drop_graph(h);
+        return FD_OK;
+    }
+    if (k == "overlap_wg") {
+        const int n = atoi(value);
+        if (n < 1 || n > 2) FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: overlap_wg expects 1 or 2, got '%s'", value);
+        h->overlap_wg = n;
+        drop_graph(h);
+        return FD_OK;
+    }
     if (k == "graph") { h->use_graph = on; return FD_OK; }
     if (k == "profile") { h->profile = on; return FD_OK; }
     if (k == "taps") { h->keep_taps = on; return FD_OK; }

@@ -183,6 +183,12 @@ struct fd_context {
     std::vector<void *> mel_allocs;           // device memory behind `mel` (built on first use, freed at fd_destroy)
     int last_B = 0, last_T = 0;
     hipStream_t cap_stream = nullptr;
+    // option overlap = gemm: the predictor GEMM of blocks 1 and 2 runs on `side_stream` next to the LVC layers of blocks 0 and 1
+    // (fork / join through events; inside a captured step the side stream joins the capture).  overlap_wg: its workgroups per CU.
+    bool overlap_gemm = false;
+    int overlap_wg = 1;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     // captured denoiser steps, one per (B, T, mode): micro-batches of different padded length alternate without re-capturing
     struct StepGraph { int B, T, steps; unsigned sig; hipGraph_t graph; hipGraphExec_t exec; unsigned long long last_use; };   // `steps` denoiser steps per launch
     std::vector<StepGraph> graphs;           // at most FD_MAX_GRAPHS, least recently used evicted

@@ -16,7 +16,7 @@ hipError_t naive_update(const Launch &L, float *x, const float *eps, int64_t n);
 hipError_t fast_first_conv(const Launch &L, const StepIO &io, int B, int T);
 hipError_t fast_dblock(const Launch &L, int d, int B, int T, const float *audio);
 hipError_t fast_kp_front(const Launch &L, const StepIO &io, int B, int T);
-hipError_t fast_kp_gemm(const Launch &L, int B, int T);
+hipError_t fast_kp_gemm(const Launch &L, int B, int T, int blk0 = 0, int nblk = fd::NBLK, int wg_per_cu = 2);
 hipError_t fast_convt(const Launch &L, int n, const float *x_in, float *x_out, int B, int Lin);
 hipError_t fast_lvc_layer(const Launch &L, int n, int layer, const float *x_in, const float *skip, float *x_out, int B, int T);
 hipError_t fast_final(const Launch &L, const StepIO &io, const float *x32, int B, int T);

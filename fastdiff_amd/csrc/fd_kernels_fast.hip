@@ -966,8 +966,11 @@ __device__ __forceinline__ void gx_item(char *lds, const GxItem &cur, bool more,
 __global__ void __launch_bounds__(256, 2) k_kp_gemm_h2(const char *__restrict__ hx /*[3][B][R][2][64] fp16*/, float *__restrict__ kpack,
                                                        const float4 *g0, const float4 *g1, const float4 *g2, const float *gb0,
                                                        const float *gb1, const float *gb2, const int *__restrict__ range_flag, int B,
-                                                       int T, int R, int chunks_per_utt, int n_items, const int *__restrict__ lens)
+                                                       int T, int R, int chunks_per_utt, int n_items, const int *__restrict__ lens,
+                                                       int blk0, int nblk)
 {
+    // blk0, nblk: the LVC blocks this launch computes (0, 3: all of them; option overlap = gemm launches block 0 alone and the other
+    // two next to the LVC layers of the block before them); n_items counts the items of those blocks only
     __shared__ __attribute__((aligned(16))) char lds[2 * GX_BUFB];     // 2 x 36 KB
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -980,7 +983,7 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm_h2(const char *__restrict__ 
     // is fetched from HBM once per XCD instead of once per workgroup (the 2 GB output stream turns L2 over every few
     // microseconds).  The groups that do not divide evenly are cut into equal contiguous id ranges at the end.
     const int ny = B * chunks_per_utt, n_wg = gridDim.x, w = blockIdx.x;
-    const int q = (3 * XG) / n_wg, base = q * n_wg * ny, rest = n_items - base;
+    const int q = (nblk * XG) / n_wg, base = q * n_wg * ny, rest = n_items - base;
     const int r0 = (int)((int64_t)w * rest / n_wg), r1 = (int)((int64_t)(w + 1) * rest / n_wg);
     const int n_mine = q * ny + (r1 - r0);
     if (n_mine <= 0) return;
@@ -988,6 +991,7 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm_h2(const char *__restrict__ 
         GxItem it;
         it.blk = id / (XG * ny);
         const int rem = id - it.blk * (XG * ny);
+        it.blk += blk0;
         it.xg = rem / ny;
         const int yy = rem - it.xg * ny;
         it.b = yy / chunks_per_utt;
@@ -2320,8 +2324,10 @@ hipError_t fast_kp_front(const Launch &L, const StepIO &io, int B, int T)
     return hipSuccess;
 }
 
-hipError_t fast_kp_gemm(const Launch &L, int B, int T)
+hipError_t fast_kp_gemm(const Launch &L, int B, int T, int blk0, int nblk, int wg_per_cu)
 {
+    // blk0, nblk: the blocks to compute (the fp16x2 kernel only: the fp32 kernel, whole job or early-exit fallback, always covers all
+    // three and is launched with the range that starts at block 0); wg_per_cu: persistent workgroups per CU (2 alone on the chip)
     fd_context *c = L.ctx;
     const DevWeights &w = c->w;
     const int tiles_per_utt = (T + 31) / 32;
@@ -2333,17 +2339,18 @@ hipError_t fast_kp_gemm(const Launch &L, int B, int T)
     const bool f16 = pipe != PIPE_F32_ONLY;
     if (f16) {
         const int R = gx_rows(T);
-        const int chunks = (T + GX_CT * 32 - 1) / (GX_CT * 32), items = fd::NBLK * (fd::KREC / 128) * B * chunks;
-        const int grid2 = items < 2 * c->num_cus ? items : 2 * c->num_cus;
-        if (!c->h_image_ready)      // the fp16-pipe predictor front writes the image itself
+        const int chunks = (T + GX_CT * 32 - 1) / (GX_CT * 32), items = nblk * (fd::KREC / 128) * B * chunks;
+        const int grid2 = items < wg_per_cu * c->num_cus ? items : wg_per_cu * c->num_cus;
+        if (!c->h_image_ready && blk0 == 0)      // the fp16-pipe predictor front writes the image itself
             FD_LAUNCH(L, "h_split", k_h_split, dim3((32 * R + 255) / 256, fd::NBLK * B), dim3(256), 0, (const float *)c->ws.kp_hB,
                       reinterpret_cast<unsigned *>(c->ws.h_f16), c->ws.range_flag, B, T, R, c->step_lens);
         FD_LAUNCH(L, "kp_gemm_f16x2", k_kp_gemm_h2, dim3(grid2), dim3(256), 0, reinterpret_cast<const char *>(c->ws.h_f16), c->ws.kpack,
                   reinterpret_cast<const float4 *>(w.gemm_h2_pack[0]), reinterpret_cast<const float4 *>(w.gemm_h2_pack[1]),
                   reinterpret_cast<const float4 *>(w.gemm_h2_pack[2]), w.gemm_bias[0], w.gemm_bias[1], w.gemm_bias[2],
-                  (const int *)c->ws.range_flag, B, T, R, chunks, items, c->step_lens);
-        if (pipe == PIPE_F16_ONLY) return hipSuccess;
+                  (const int *)c->ws.range_flag, B, T, R, chunks, items, c->step_lens, blk0, nblk);
+        if (pipe == PIPE_F16_ONLY || blk0 != 0) return hipSuccess;
     }
+    if (blk0 != 0) return hipSuccess;
     // fp32 matrix pipe: the whole job when the fp16 form is off, otherwise an early-exit launch that only works when
     // k_h_split found operands outside the fp16 range
     FD_LAUNCH(L, f16 ? "kp_gemm_fp32_fallback" : "kp_gemm", k_kp_gemm, dim3(grid), dim3(256), 0, (const float *)c->ws.kp_hB, c->ws.kpack,

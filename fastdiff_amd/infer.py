@@ -257,16 +257,16 @@ def synthesize_sharded(model, items, n_steps: int = 4, max_batch: int = 8, seed:
         return synthesize(model, items, n_steps, max_batch, seed, drop_last_frame)
     rank, world = dist.get_rank(), dist.get_world_size()
     meta = [None]
-    if rank == src:      # the collater's view of every item: [80, T'] with the last frame dropped, too-short items left out
-        kept = [(i, it) for i, it in enumerate(items) if not drop_last_frame or it["mel"].shape[0] >= 2]
-        mels = [torch.from_numpy(np.ascontiguousarray(it["mel"].numpy()[: it["mel"].shape[0] - (1 if drop_last_frame else 0)].T)) for _, it in kept]
-        meta = [([it["item_name"] for _, it in kept], [int(it.get("uid", i)) for i, it in kept], [int(m.shape[-1]) for m in mels])]
+    if rank == src:      # the collater's view of every item: the on-disk [T', 80] rows with the last frame dropped (a view: no copy, no
+        kept = [(i, it) for i, it in enumerate(items) if not drop_last_frame or it["mel"].shape[0] >= 2]      # transposition on the host)
+        mels = [it["mel"][: it["mel"].shape[0] - (1 if drop_last_frame else 0)] for _, it in kept]
+        meta = [([it["item_name"] for _, it in kept], [int(it.get("uid", i)) for i, it in kept], [int(m.shape[0]) for m in mels])]
     dist.broadcast_object_list(meta, src=src)          # names, noise-stream ids and lengths in one message
     names, uids, lens = meta[0]
     parts = shard.partition_utterances(lens, world)
-    mine, _ = shard.scatter_utterances(mels if rank == src else None, parts, src=src, device=device, lens=lens)
+    mine, _ = shard.scatter_utterances(mels if rank == src else None, parts, src=src, device=device, lens=lens, frames_first=True)
     on_gpu = device is not None and torch.device(device).type == "cuda"
-    local = [{"item_name": str(i), "mel": m.transpose(0, 1), "len": m.shape[-1], "uid": uids[i]} for i, m in mine]
+    local = [{"item_name": str(i), "mel": m, "len": m.shape[0], "uid": uids[i]} for i, m in mine]
     pcm = synthesize(model, local, n_steps, max_batch, seed, drop_last_frame=False, return_device=on_gpu)
     wavs = [(i, pcm[str(i)] if on_gpu else torch.from_numpy(pcm[str(i)])) for i, _ in mine]
     out = shard.gather_waveforms(wavs, lens, parts, hop=model.hop_length, dst=src, device=device, dtype=torch.int16)
@@ -275,7 +275,10 @@ def synthesize_sharded(model, items, n_steps: int = 4, max_batch: int = 8, seed:
     if not on_gpu:
         return {names[i]: out[i].numpy() for i in range(len(names))}
     sizes = [int(o.numel()) for o in out]
-    flat = torch.cat([o.reshape(-1) for o in out]).cpu().numpy()          # one device-to-host copy for the whole job
+    host = shard._pinned_buffer("job_pcm", sum(sizes), torch.int16)[: sum(sizes)]
+    host.copy_(torch.cat([o.reshape(-1) for o in out]), non_blocking=True)          # one device-to-host copy for the whole job
+    torch.cuda.current_stream().synchronize()
+    flat = host.numpy().copy()
     offs = np.concatenate([[0], np.cumsum(sizes)])
     return {names[i]: flat[offs[i]: offs[i + 1]] for i in range(len(names))}
 

@@ -70,40 +70,79 @@ def _exchange(ops):
         req.wait()
 
 
-def scatter_utterances(mels: Sequence[torch.Tensor], parts: List[List[int]], src: int = 0, device=None, lens: Sequence[int] = None):
-    """Rank `src` holds all mels ([80,T_i] each); afterwards every rank holds its own (index, mel) list.
+_pinned = {}
+
+
+def _pinned_buffer(key: str, n: int, dtype: torch.dtype) -> torch.Tensor:
+    """A pinned host buffer of at least n elements, kept between jobs (a pinned allocation costs milliseconds)."""
+    buf = _pinned.get(key)
+    if buf is None or buf.numel() < n or buf.dtype != dtype:
+        buf = torch.empty(n, dtype=dtype).pin_memory()
+        _pinned[key] = buf
+    return buf
+
+
+def pack_messages(mels: Sequence[torch.Tensor], parts: List[List[int]], device=None) -> List[torch.Tensor]:
+    """All utterances (2-D float32 host tensors, any layout: each travels as its own flat bytes) back to back in the order of
+    parts[0], parts[1], ...: ONE buffer, one flat slice per rank.  With `device` a GPU the buffer is pinned host memory, filled by
+    numpy slice copies (torch's CPU kernels wake an OpenMP team per call: tens of milliseconds on a 256-core host) and uploaded
+    with ONE asynchronous copy; the slices are then device memory, ready for RCCL."""
+    import numpy as np
+    order = [i for p in parts for i in p]
+    sizes = [int(mels[i].numel()) for i in order]
+    total = sum(sizes)
+    on_gpu = device is not None and torch.device(device).type == "cuda"
+    host = _pinned_buffer("scatter", total, torch.float32)[:total] if on_gpu else torch.empty(total, dtype=torch.float32)
+    host_np = host.numpy()
+    off = 0
+    for i, n in zip(order, sizes):
+        host_np[off: off + n] = np.asarray(mels[i].detach().numpy(), np.float32).reshape(-1)
+        off += n
+    buf = host.to(device, non_blocking=True) if on_gpu else host
+    out, off = [], 0
+    for p in parts:
+        n = sum(int(mels[i].numel()) for i in p)
+        out.append(buf[off: off + n])
+        off += n
+    return out
+
+
+def scatter_utterances(mels: Sequence[torch.Tensor], parts: List[List[int]], src: int = 0, device=None, lens: Sequence[int] = None,
+                       frames_first: bool = False):
+    """Rank `src` holds all mels; afterwards every rank holds its own (index, mel) list.
     Lengths travel first as one small broadcast (skipped when the caller already distributed them: `lens`); then ONE packed
     message per peer (its utterances back to back, in the order of parts[r]) in a single grouped send/recv -- at most world-1
-    messages leave `src`, whatever the number of utterances.  Returns (own (index, mel) list, all lengths)."""
+    messages leave `src`, whatever the number of utterances.  Layout: [80, T_i] tensors by default; frames_first = the on-disk
+    layout [T_i, 80] (dataset_utils.py:186-204), which saves the host transposition -- the receiver's collater transposes on the
+    device.  Returns (own (index, mel) list, all lengths)."""
     rank, world = dist.get_rank(), dist.get_world_size()
     n = sum(len(p) for p in parts)
+    t_axis = 0 if frames_first else -1
     if lens is None:
         lens_t = torch.zeros(n, dtype=torch.int64, device=device)
         if rank == src:
-            lens_t = torch.tensor([m.shape[-1] for m in mels], dtype=torch.int64, device=device)
+            lens_t = torch.tensor([m.shape[t_axis] for m in mels], dtype=torch.int64, device=device)
         dist.broadcast(lens_t, src=src)
         lens = lens_t.tolist()
     lens_l = [int(v) for v in lens]
-    mine = []
-    if rank == src:
-        ops, keep = [], []
-        for r in range(world):
-            if r == src:
-                mine = [(i, mels[i].to(device) if device is not None else mels[i]) for i in parts[r]]
-            elif parts[r]:
-                buf = torch.cat([mels[i].reshape(-1).float() for i in parts[r]])
-                buf = buf.to(device) if device is not None else buf.contiguous()
-                keep.append(buf)
-                ops.append(dist.P2POp(dist.isend, buf, r))
-        _exchange(ops)
-    elif parts[rank]:
-        buf = torch.empty(80 * sum(lens_l[i] for i in parts[rank]), dtype=torch.float32, device=device)
-        _exchange([dist.P2POp(dist.irecv, buf, src)])
-        off = 0
-        for i in parts[rank]:
-            mine.append((i, buf[off: off + 80 * lens_l[i]].view(80, lens_l[i])))
+
+    def unpack(buf, idx):
+        mine, off = [], 0
+        for i in idx:
+            m = buf[off: off + 80 * lens_l[i]]
+            mine.append((i, m.view(lens_l[i], 80) if frames_first else m.view(80, lens_l[i])))
             off += 80 * lens_l[i]
-    return mine, lens_l
+        return mine
+
+    if rank == src:
+        msgs = pack_messages(mels, parts, device)
+        _exchange([dist.P2POp(dist.isend, msgs[r], r) for r in range(world) if r != src and parts[r]])
+        return unpack(msgs[src], parts[src]), lens_l
+    if not parts[rank]:
+        return [], lens_l
+    buf = torch.empty(80 * sum(lens_l[i] for i in parts[rank]), dtype=torch.float32, device=device)
+    _exchange([dist.P2POp(dist.irecv, buf, src)])
+    return unpack(buf, parts[rank]), lens_l
 
 
 def gather_waveforms(mine, lens: Sequence[int], parts: List[List[int]], hop: int = 256, dst: int = 0, device=None,

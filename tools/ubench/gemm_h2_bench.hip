@@ -31,7 +31,7 @@ int main(int argc, char **argv)
     auto run = [&]() {
         hipLaunchKernelGGL(fdk_fast::k_h_split, dim3((32 * R + 255) / 256, 3 * B), dim3(256), 0, 0, h, (unsigned *)hx, flag, B, T, R, (const int *)nullptr);
         hipLaunchKernelGGL(fdk_fast::k_kp_gemm_h2, dim3(G), dim3(256), 0, 0, (const char *)hx, kp, (const float4 *)g, (const float4 *)g,
-                           (const float4 *)g, gb, gb, gb, (const int *)flag, B, T, R, chunks, n_items, (const int *)nullptr);
+                           (const float4 *)g, gb, gb, gb, (const int *)flag, B, T, R, chunks, n_items, (const int *)nullptr, 0, 3);
     };
     for (int i = 0; i < 2; ++i) run();
     CK(hipDeviceSynchronize());
