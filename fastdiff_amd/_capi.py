@@ -26,7 +26,7 @@ class FdKernelStat(ct.Structure):
 
 
 EXPORTS = ["fd_default_config", "fd_create", "fd_destroy", "fd_last_error", "fd_set_weight", "fd_commit_weights",
-           "fd_forward", "fd_sample", "fd_sample_check", "fd_set_noise_streams", "fd_peak_normalize_int16", "fd_peak_normalize_int16_ragged", "fd_mel_spectrogram", "fd_lvc_forward", "fd_lvc_backward", "fd_set_option", "fd_read_tap", "fd_kernel_index", "fd_bias_index",
+           "fd_forward", "fd_sample", "fd_sample_check", "fd_sample_ticket", "fd_sample_settle", "fd_set_noise_streams", "fd_peak_normalize_int16", "fd_peak_normalize_int16_ragged", "fd_mel_spectrogram", "fd_lvc_forward", "fd_lvc_backward", "fd_set_option", "fd_read_tap", "fd_kernel_index", "fd_bias_index",
            "fd_get_profile", "fd_reset_profile", "fd_version"]
 
 _lib = None
@@ -59,6 +59,9 @@ def load():
     lib.fd_sample.argtypes = [vp, vp, ci, ci, vp, ct.POINTER(FdStep), ci, ci, vp, vp, ct.c_uint64, vp, vp, vp]
     lib.fd_set_noise_streams.argtypes = [vp, vp, ci]
     lib.fd_sample_check.argtypes = [vp]
+    lib.fd_sample_ticket.argtypes = [vp]
+    lib.fd_sample_ticket.restype = ct.c_int64
+    lib.fd_sample_settle.argtypes = [vp, ct.c_int64]
     lib.fd_peak_normalize_int16.argtypes = [vp, vp, ci, ct.c_int64, vp, vp]
     lib.fd_peak_normalize_int16_ragged.argtypes = [vp, vp, ci, ct.c_int64, vp, vp, vp]
     lib.fd_mel_spectrogram.argtypes = [vp, vp, ci, ct.c_int64, vp, ci, vp]

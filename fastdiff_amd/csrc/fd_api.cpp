@@ -173,7 +173,8 @@ int fd_create(const fd_config *cfg, int device, fd_handle *out)
         return FD_ERR_HIP;
     }
     if ((e = hipHostMalloc(reinterpret_cast<void **>(&c->flags_host), 256, hipHostMallocDefault)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&c->flags_done, hipEventDisableTiming)) != hipSuccess) {
+        (e = hipEventCreateWithFlags(&c->flags_done, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->flags_done2, hipEventDisableTiming)) != hipSuccess) {
         if (c->flags_host) hipHostFree(c->flags_host);
         hipFree(c->scratch);
         hipStreamDestroy(c->cap_stream);
@@ -229,6 +230,7 @@ int fd_destroy(fd_handle h)
     prof_drain(h);
     if (h->flags_host) hipHostFree(h->flags_host);
     if (h->flags_done) hipEventDestroy(h->flags_done);
+    if (h->flags_done2) hipEventDestroy(h->flags_done2);
     for (auto ev : h->event_pool) hipEventDestroy(ev);
     drop_graph(h);
     free_workspace(h);
@@ -413,6 +415,10 @@ int fd_commit_weights(fd_handle h)
 {
     if (!h) return FD_ERR_INVALID;
     FD_HIP(h, hipSetDevice(h->device));
+    {
+        const int rcs = settle(h);      // a pending host check would otherwise run its call again on the NEW weights
+        if (rcs != FD_OK) return rcs;
+    }
     FD_HIP(h, hipDeviceSynchronize());
     for (void *p : h->dev_allocs) hipFree(p);
     h->dev_allocs.clear();
@@ -974,20 +980,27 @@ static int enqueue_steps(fd_handle h, int B, int T, int count, unsigned fp32_mas
     return FD_OK;
 }
 
-// fallback = host: waits for the pending piece of work, looks at its range flags and, if one was raised, runs that piece again from
-// the saved x with the flagged stages on their fp32 kernels (and every other stage with its fallback inline: the second pass is
-// always right).  Returns 1 if it redid the work, 0 if not; *mask receives the flagged stages (sticky for the rest of a long call).
-static int resolve_pending(fd_handle h, unsigned *mask)
+static int sample_core(fd_handle h, const fd_context::SampleArgs &a, unsigned force_mask, long long ticket);
+
+// fallback = host: waits for the pending piece of work, looks at its range flags and, if one was raised, runs that piece again with
+// the flagged stages on their fp32 kernels (and every other stage with its fallback inline: the second pass is always right) -- a
+// lazily checked call (<= 8 steps) as a whole from its arguments, a piece of a long schedule from the saved x.
+// Returns 1 if it redid the work, 0 if not; *mask receives the flagged stages (sticky for the rest of a long call).
+static int resolve_call(fd_handle h, const fd_context::PendingCall &p, unsigned *mask)
 {
-    fd_context::PendingCall p = h->pending;
-    h->pending.active = false;
-    FD_HIP(h, hipEventSynchronize(h->flags_done));
+    FD_HIP(h, hipEventSynchronize(p.slot ? h->flags_done2 : h->flags_done));
+    const int *fl = h->flags_host + 32 * p.slot;
     unsigned m = 0;
     for (int i = 0; i < 32; ++i)
-        if (h->flags_host[i]) m |= 1u << i;
+        if (fl[i]) m |= 1u << i;
     if (m & (1u << 19)) m |= 1u;                 // the predictor front feeds the GEMM: both go
     *mask |= m;
     if (m == 0) return 0;
+    h->redone_ring[h->redone_next++ % 16] = p.ticket;
+    if (p.lazy) {
+        const int rc = sample_core(h, p.args, *mask, p.ticket);
+        return rc < 0 ? rc : 1;
+    }
     Workspace &ws = h->ws;
     const size_t n_el = (size_t)p.B * p.T * fd::HOPT;
     FD_HIP(h, hipMemcpyAsync(ws.x, ws.xsave, sizeof(float) * n_el, hipMemcpyDeviceToDevice, p.stream));
@@ -1000,37 +1013,37 @@ static int resolve_pending(fd_handle h, unsigned *mask)
     return 1;
 }
 
-int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, const fd_step *table, int N, int ddim,
-              const float *x_T, const float *z, uint64_t seed, float *out, float *seq_out, void *stream_)
+static int resolve_pending(fd_handle h, unsigned *mask)
 {
-    std::vector<unsigned long long> ids;
-    if (h) ids.swap(h->noise_ids);               // one-shot: fd_set_noise_streams applies to this call only, also when it fails below
-    int rc = check_common(h, B, T, "fd_sample");
-    if (rc != FD_OK) return rc;
-    if ((rc = settle(h)) != FD_OK) return rc;
-    if (!mel || !table || !out) FD_FAIL(h, FD_ERR_INVALID, "fd_sample: null pointer");
-    if (N <= 0 || N > 1024) FD_FAIL(h, FD_ERR_INVALID, "fd_sample: N=%d outside 1..1024", N);
-    if ((rc = ensure_workspace(h, B, T)) != FD_OK) return rc;
-    hipStream_t stream = (hipStream_t)stream_;
+    fd_context::PendingCall p = h->pending;
+    h->pending.active = false;
+    return resolve_call(h, p, mask);
+}
+
+// One whole sample call on a.stream.  force_mask != 0: a redo (the flagged stages on fp32, every other fallback inline, nothing left
+// pending); otherwise the handle's mode: in-graph fallbacks, or fallback = host (lazy for N <= 8, checked every 8 steps beyond).
+static int sample_core(fd_handle h, const fd_context::SampleArgs &a, unsigned force_mask, long long ticket)
+{
+    int rc;
+    const int B = a.B, T = a.T, N = a.N;
+    hipStream_t stream = a.stream;
     Workspace &ws = h->ws;
     const size_t n_el = (size_t)B * T * fd::HOPT;
-    if (!ids.empty() && (int)ids.size() != B)
-        FD_FAIL(h, FD_ERR_INVALID, "fd_sample: fd_set_noise_streams gave %d stream ids but B=%d", (int)ids.size(), B);
-
+    const std::vector<unsigned long long> &ids = a.ids;
     // per-call parameters -> device block the captured kernels read.  Staged through the pinned ring: the call returns
     // without waiting for the stream, so the host prepares the next call while this one runs.
     {
         fd_context::StageSlot *sl = nullptr;
         const size_t off_lens = sizeof(StepParams), off_ids = off_lens + ((sizeof(int) * B + 7) & ~(size_t)7);
         if ((rc = stage_acquire(h, off_ids + sizeof(unsigned long long) * B, &sl)) != FD_OK) return rc;
-        if ((rc = set_lens(h, lens, B, T, stream, "fd_sample", reinterpret_cast<int *>(sl->host + off_lens))) != FD_OK) return rc;
+        if ((rc = set_lens(h, a.has_lens ? a.lens.data() : nullptr, B, T, stream, "fd_sample", reinterpret_cast<int *>(sl->host + off_lens))) != FD_OK) return rc;
         if (!ids.empty()) {
             memcpy(sl->host + off_ids, ids.data(), sizeof(unsigned long long) * B);
             FD_HIP(h, hipMemcpyAsync(ws.uid_dev, sl->host + off_ids, sizeof(unsigned long long) * B, hipMemcpyHostToDevice, stream));
         }
         StepParams *p = reinterpret_cast<StepParams *>(sl->host);
-        memcpy(p->table, table, sizeof(fd_step) * N);
-        p->z = z; p->seq = seq_out; p->seed = seed; p->n_steps = N; p->ddim = ddim ? 1 : 0; p->step_idx = 0; p->l4 = T * (fd::HOPT / 4);
+        memcpy(p->table, a.table.data(), sizeof(fd_step) * N);
+        p->z = a.z; p->seq = a.seq_out; p->seed = a.seed; p->n_steps = N; p->ddim = a.ddim ? 1 : 0; p->step_idx = 0; p->l4 = T * (fd::HOPT / 4);
         p->uids = ids.empty() ? nullptr : ws.uid_dev;
         // only the used prefix of the table plus the trailer needs to travel
         const size_t head = sizeof(fd_step) * N;
@@ -1040,23 +1053,38 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
                                  hipMemcpyHostToDevice, stream));
         if ((rc = stage_commit(h, sl, stream)) != FD_OK) return rc;
     }
-    FD_HIP(h, hipMemcpyAsync(ws.mel, mel, sizeof(float) * (size_t)B * fd::COND * T, hipMemcpyDeviceToDevice, stream));
+    FD_HIP(h, hipMemcpyAsync(ws.mel, a.mel, sizeof(float) * (size_t)B * fd::COND * T, hipMemcpyDeviceToDevice, stream));
     fdk::Launch L = {h, stream, false};
     hipError_t e = hipSuccess;
-    if (x_T) FD_HIP(h, hipMemcpyAsync(ws.x, x_T, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
-    else if ((e = fdk::init_noise(L, ws.x, (int64_t)n_el, seed, ids.empty() ? nullptr : ws.uid_dev, T * (fd::HOPT / 4))) != hipSuccess)
+    if (a.x_T) FD_HIP(h, hipMemcpyAsync(ws.x, a.x_T, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
+    else if ((e = fdk::init_noise(L, ws.x, (int64_t)n_el, a.seed, ids.empty() ? nullptr : ws.uid_dev, T * (fd::HOPT / 4))) != hipSuccess)
         FD_FAIL(h, FD_ERR_HIP, "fd_sample: init_noise failed: %s", hipGetErrorString(e));
-    if (seq_out) FD_HIP(h, hipMemcpyAsync(seq_out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
+    if (a.seq_out) FD_HIP(h, hipMemcpyAsync(a.seq_out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
 
     StepIO io = {ws.x, ws.mel, nullptr, nullptr, 1};
     if ((e = fdk::embed(L, io, B, N)) != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample: embed failed: %s", hipGetErrorString(e));
     if ((e = fdk::clear_range_flags(L)) != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample: %s", hipGetErrorString(e));
 
-    if (h->host_fallback) {
-        // fallback = host: no fp32 launch trails the fp16x2 kernels; their flags accumulate on the device, and the call (or, for a
-        // long schedule, each 8-step piece of it) is redone with the flagged stages on their fp32 kernels once the host has seen them
+    constexpr int CHUNK = 8;
+    if (force_mask != 0) {
+        if ((rc = enqueue_steps(h, B, T, N, force_mask, true, stream)) != FD_OK) return rc;
+        FD_HIP(h, hipMemcpyAsync(a.out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
+    } else if (h->host_fallback && N <= CHUNK) {
+        // fallback = host, one graph launch: no fp32 launch trails the fp16x2 kernels; their flags accumulate on the device and travel
+        // to the host behind the work.  Looked at lazily: by the next fd_sample after it has enqueued itself, or by fd_sample_check /
+        // fd_sample_settle; a flagged call is then run again as a whole.
+        if ((rc = enqueue_steps(h, B, T, N, 0u, /*inline_fallback=*/false, stream)) != FD_OK) return rc;
+        const int slot = (int)(ticket & 1);
+        FD_HIP(h, hipMemcpyAsync(h->flags_host + 32 * slot, ws.range_flag + 64, sizeof(int) * 32, hipMemcpyDeviceToHost, stream));
+        FD_HIP(h, hipEventRecord(slot ? h->flags_done2 : h->flags_done, stream));
+        FD_HIP(h, hipMemcpyAsync(a.out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));      // provisional until checked
+        h->pending.active = true; h->pending.lazy = true; h->pending.slot = slot; h->pending.ticket = ticket;
+        h->pending.B = B; h->pending.T = T; h->pending.N = N; h->pending.first = 0; h->pending.count = N; h->pending.out = a.out;
+        h->pending.stream = stream; h->pending.args = a;
+    } else if (h->host_fallback) {
+        // a long schedule: each 8-step piece is checked (one stream synchronisation) before the next is enqueued, and redone from the
+        // saved x with the flagged stages on their fp32 kernels once the host has seen them
         FD_HIP(h, hipMemcpyAsync(ws.xsave, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
-        constexpr int CHUNK = 8;
         unsigned mask = 0;
         for (int first = 0; first < N; first += CHUNK) {
             const int count = std::min(CHUNK, N - first);
@@ -1066,18 +1094,90 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
             if (mask != 0) continue;              // already on the safe path: nothing to look at
             FD_HIP(h, hipMemcpyAsync(h->flags_host, ws.range_flag + 64, sizeof(int) * 32, hipMemcpyDeviceToHost, stream));
             FD_HIP(h, hipEventRecord(h->flags_done, stream));
-            h->pending = {true, B, T, N, first, count, out, stream};
+            h->pending.active = true; h->pending.lazy = false; h->pending.slot = 0; h->pending.ticket = ticket;
+            h->pending.B = B; h->pending.T = T; h->pending.N = N; h->pending.first = first; h->pending.count = count; h->pending.out = a.out;
+            h->pending.stream = stream;
             if (last) break;                      // the caller's fd_sample_check (or the next call on this handle) looks at it
             int redone = resolve_pending(h, &mask);
             if (redone < 0) return redone;
         }
-        FD_HIP(h, hipMemcpyAsync(out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));      // (provisional while a check is pending)
+        FD_HIP(h, hipMemcpyAsync(a.out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));      // (provisional while a check is pending)
     } else {
         if ((rc = enqueue_steps(h, B, T, N, 0u, true, stream)) != FD_OK) return rc;
-        FD_HIP(h, hipMemcpyAsync(out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
+        FD_HIP(h, hipMemcpyAsync(a.out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
     }
     h->last_B = B; h->last_T = T;
     return FD_OK;
+}
+
+int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, const fd_step *table, int N, int ddim,
+              const float *x_T, const float *z, uint64_t seed, float *out, float *seq_out, void *stream_)
+{
+    std::vector<unsigned long long> ids;
+    if (h) ids.swap(h->noise_ids);               // one-shot: fd_set_noise_streams applies to this call only, also when it fails below
+    int rc = check_common(h, B, T, "fd_sample");
+    if (rc != FD_OK) return rc;
+    // A lazily checked previous call (fallback = host, <= 8 steps) is looked at AFTER this call has enqueued its own work -- unless
+    // this call cannot be lazy itself, or the workspace must grow first (that waits for the device anyway).
+    const bool lazy = h->host_fallback && N >= 1 && N <= 8;
+    const int64_t frames = (int64_t)B * T, rows_ = (int64_t)B * gx_rows_host(T);
+    const bool ws_ok = h->ws.B >= B && h->ws.frames >= frames && h->ws.rows >= rows_ && h->ws.params;
+    fd_context::PendingCall prev;
+    if (lazy && ws_ok && h->pending.active && h->pending.lazy) {
+        prev = h->pending;
+        h->pending.active = false;
+    } else if ((rc = settle(h)) != FD_OK) return rc;
+    auto finish_prev = [&]() -> int {
+        if (!prev.active) return FD_OK;
+        unsigned mask = 0;
+        const fd_context::PendingCall cur = h->pending;      // a redo of the previous call must not disturb this call's record
+        h->pending.active = false;
+        const int r = resolve_call(h, prev, &mask);
+        h->pending = cur;
+        prev.active = false;
+        return r < 0 ? r : FD_OK;
+    };
+    if (!mel || !table || !out) { finish_prev(); FD_FAIL(h, FD_ERR_INVALID, "fd_sample: null pointer"); }
+    if (N <= 0 || N > 1024) { finish_prev(); FD_FAIL(h, FD_ERR_INVALID, "fd_sample: N=%d outside 1..1024", N); }
+    if (!ids.empty() && (int)ids.size() != B) {
+        finish_prev();
+        FD_FAIL(h, FD_ERR_INVALID, "fd_sample: fd_set_noise_streams gave %d stream ids but B=%d", (int)ids.size(), B);
+    }
+    if ((rc = ensure_workspace(h, B, T)) != FD_OK) { finish_prev(); return rc; }
+    fd_context::SampleArgs a;
+    a.mel = mel; a.B = B; a.T = T; a.N = N; a.ddim = ddim;
+    a.has_lens = lens != nullptr;
+    if (lens) a.lens.assign(lens, lens + B);
+    a.table.assign(table, table + N);
+    a.x_T = x_T; a.z = z; a.seed = seed; a.out = out; a.seq_out = seq_out; a.stream = (hipStream_t)stream_;
+    a.ids.swap(ids);
+    const long long ticket = ++h->ticket_counter;
+    rc = sample_core(h, a, 0u, ticket);
+    const int rc_prev = finish_prev();
+    return rc != FD_OK ? rc : rc_prev;
+}
+
+int64_t fd_sample_ticket(fd_handle h) { return h ? (int64_t)h->ticket_counter : FD_ERR_INVALID; }
+
+// 1 if call `ticket` had to be redone on the fp32 kernels (now, or when a later fd_sample looked at it), 0 if not.
+static int ticket_redone(fd_handle h, long long ticket)
+{
+    for (long long t : h->redone_ring)
+        if (t == ticket && t != 0) return 1;
+    return 0;
+}
+
+int fd_sample_settle(fd_handle h, int64_t ticket)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (ticket <= 0 || ticket > h->ticket_counter) FD_FAIL(h, FD_ERR_INVALID, "fd_sample_settle: unknown ticket %lld", (long long)ticket);
+    if (h->pending.active && h->pending.ticket <= ticket) {
+        FD_HIP(h, hipSetDevice(h->device));
+        unsigned mask = 0;
+        const int r = resolve_pending(h, &mask);
+        if (r < 0) return r;
+    }
+    return ticket_redone(h, ticket);
 }
 
 int fd_sample_check(fd_handle h)
@@ -1163,7 +1263,7 @@ int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_samples, 
     if (h->mel_variant == MEL_TACOTRON && n_samples <= 512)      // F.pad(mode='reflect') needs pad < length (tacotron/stft.py:84-88)
         FD_FAIL(h, FD_ERR_INVALID, "fd_mel_spectrogram: reflect padding of 512 needs more than 512 samples, got %lld", (long long)n_samples);
     FD_HIP(h, hipSetDevice(h->device));
-    int rc = settle(h);
+    int rc = (h->pending.active && h->pending.lazy) ? FD_OK : settle(h);      // the front-end touches no sampler state
     if (rc != FD_OK) return rc;
     rc = ensure_mel_tables(h);
     if (rc != FD_OK) return rc;
@@ -1240,7 +1340,7 @@ int fd_peak_normalize_int16_ragged(fd_handle h, const float *wav, int B, int64_t
 {
     if (!h || !wav || !pcm || B <= 0 || len <= 0 || B > 4096) return FD_ERR_INVALID;
     FD_HIP(h, hipSetDevice(h->device));
-    {
+    if (!(h->pending.active && h->pending.lazy)) {      // a lazily checked call stays pending: the epilogue's result is provisional with it
         const int rcs = settle(h);
         if (rcs != FD_OK) return rcs;
     }

@@ -200,15 +200,38 @@ struct fd_context {
     struct StageSlot { char *host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; };
     StageSlot stage[STAGE_SLOTS];
     unsigned stage_next = 0;
-    // option fallback = host: the fd_sample call whose range flags have not been looked at yet (fd_sample_check)
+    // Everything fd_sample was called with (host arrays copied): what a redo of a call of up to 8 steps starts from again
+    struct SampleArgs {
+        const float *mel = nullptr;
+        int B = 0, T = 0, N = 0, ddim = 0;
+        bool has_lens = false;
+        std::vector<int> lens;
+        std::vector<fd_step> table;
+        const float *x_T = nullptr, *z = nullptr;
+        unsigned long long seed = 0;
+        float *out = nullptr, *seq_out = nullptr;
+        hipStream_t stream = nullptr;
+        std::vector<unsigned long long> ids;
+    };
+    // option fallback = host: the fd_sample call whose range flags have not been looked at yet (fd_sample_check / fd_sample_settle).
+    //   lazy (schedules of up to 8 steps = one graph launch): the NEXT fd_sample enqueues its own work first and looks at this call's
+    //   flags afterwards, so the host's wait falls on a busy GPU; a flagged call is then run again as a whole from `args`;
+    //   otherwise (longer schedules, checked every 8 steps): redone from `xsave`, steps [first, first + count).
     struct PendingCall {
         bool active = false;
+        bool lazy = false;
+        int slot = 0;                                       // which of the two flag buffers / events
+        long long ticket = 0;
         int B = 0, T = 0, N = 0, first = 0, count = 0;      // steps [first, first + count) were enqueued without fallbacks
         float *out = nullptr;
         hipStream_t stream = nullptr;
+        SampleArgs args;
     } pending;
-    int *flags_host = nullptr;               // pinned, 32 words: the sticky flags of the pending call
-    hipEvent_t flags_done = nullptr;
+    long long ticket_counter = 0;            // one per fd_sample
+    long long redone_ring[16] = {};          // tickets of the calls that had to be redone (0 = none), newest overwrite oldest
+    unsigned redone_next = 0;
+    int *flags_host = nullptr;               // pinned, 2 x 32 words: the sticky flags of the pending call(s)
+    hipEvent_t flags_done = nullptr, flags_done2 = nullptr;
     void *scratch = nullptr;                 // 64 KB device scratch (abs-max words, ...)
     float *lvc_scratch = nullptr;            // the LVC operator's frame-major kernel copy (fd_lvc_forward / fd_lvc_backward), grown on demand
     size_t lvc_scratch_bytes = 0;

@@ -199,11 +199,18 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
     if not (on_device and return_device):
         mel_pin, pcm_pin = _pinned_staging(model, 0 if on_device else b_max * 80 * t_max, 0 if return_device else b_max * t_max * hop)
         mel_np = [m.numpy() for m in mel_pin]      # the collater writes the batch straight into the pinned buffer
-    pending = None                 # (event, pinned PCM view, names, lens) of the micro-batch still on its way to the host
+    pending = None                 # (event, pinned PCM view, names, lens, ticket, wav) of the micro-batch still on its way to the host
+    # library option fallback = "host": the range check of a sample call is looked at by the NEXT call, after that one has enqueued
+    # itself (FastDiff.settle); until then the waveform and everything computed from it is provisional
+    host_check = getattr(model, "_options", {}).get("fallback") == "host"
+    on_device_results = []         # return_device: (ticket, wav, names, lens) of every micro-batch
 
     def collect(p):
-        done, host, names, lens = p
+        done, host, names, lens, ticket, wav = p
         done.synchronize()
+        if host_check and model.settle(ticket):      # an operand left the fp16 range: the call was run again on fp32 -- so is its epilogue
+            host.copy_(model.peak_normalize_int16(wav, valid=[t * hop for t in lens]), non_blocking=True)
+            torch.cuda.current_stream().synchronize()
         for b, (name, t) in enumerate(zip(names, lens)):
             out[name] = host[b, : t * hop].numpy().copy()
 
@@ -221,12 +228,14 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
         if not on_device:
             mels = mel_pin[k & 1][: B * 80 * T].view(B, 80, T).cuda(non_blocking=True)
         with torch.no_grad():
-            wav = model.sample(mels, rows, ddim=False, seed=seed, lens=lens, stream_ids=[uid_of[n] for n in names])
+            wav = model.sample(mels, rows, ddim=False, seed=seed, lens=lens, stream_ids=[uid_of[n] for n in names], defer_check=host_check)
+        ticket = getattr(model, "last_ticket", 0)
         # one epilogue call and one asynchronous copy per micro-batch; the previous batch is unpacked on the host while this one runs
         pcm = model.peak_normalize_int16(wav, valid=[t * hop for t in lens])
         if return_device:
             for b, (name, t) in enumerate(zip(names, lens)):
                 out[name] = pcm[b, : t * hop]
+            on_device_results.append((ticket, wav, names, lens))
             k += 1
             continue
         host = pcm_pin[k & 1][: B * T * hop].view(B, T * hop)
@@ -235,10 +244,16 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
         done.record()
         if pending is not None:
             collect(pending)
-        pending = (done, host, names, lens)
+        pending = (done, host, names, lens, ticket, wav)
         k += 1
     if pending is not None:
         collect(pending)
+    if host_check:
+        for ticket, wav, names, lens in on_device_results:
+            if model.settle(ticket):
+                pcm = model.peak_normalize_int16(wav, valid=[t * hop for t in lens])
+                for b, (name, t) in enumerate(zip(names, lens)):
+                    out[name] = pcm[b, : t * hop]
     return out
 
 

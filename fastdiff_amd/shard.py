@@ -92,6 +92,14 @@ def pack_messages(mels: Sequence[torch.Tensor], parts: List[List[int]], device=N
     sizes = [int(mels[i].numel()) for i in order]
     total = sum(sizes)
     on_gpu = device is not None and torch.device(device).type == "cuda"
+    if any(m.is_cuda for m in mels):            # utterances that already live on a GPU (e.g. fresh from the device mel front-end)
+        buf = torch.cat([mels[i].reshape(-1).float() for i in order]).to(device if on_gpu else "cpu")
+        out, off = [], 0
+        for p in parts:
+            n = sum(int(mels[i].numel()) for i in p)
+            out.append(buf[off: off + n])
+            off += n
+        return out
     host = _pinned_buffer("scatter", total, torch.float32)[:total] if on_gpu else torch.empty(total, dtype=torch.float32)
     host_np = host.numpy()
     off = 0

@@ -121,8 +121,20 @@ FD_API int fd_sample(fd_handle h, const float *mel, int B, int T, const int *len
  * Until it has returned, `out` / `seq_out` of that fd_sample are provisional and its `z` must stay valid.  Every later call on the
  * handle settles a pending check first, so nothing is ever lost -- but a caller that reads `out` itself must call fd_sample_check
  * before.  Schedules longer than 8 steps are checked (with a stream synchronisation) every 8 steps inside fd_sample.
- * With the default ("graph") fd_sample_check is a no-op returning 0. */
+ * With the default ("graph") fd_sample_check is a no-op returning 0.
+ *
+ * Pipelined form (round 3; schedules of up to 8 steps, i.e. one graph launch per call): the next fd_sample on the handle does NOT
+ * wait for the pending call -- it enqueues its own work first and looks at the previous call's flags afterwards, when the host's
+ * wait falls on a busy GPU; a flagged call is then run again as a whole (its mel / x_T / z buffers must therefore stay valid until
+ * it has been looked at, and its `out` is rewritten behind everything enqueued so far).  The waveform epilogue and the mel
+ * front-end do not wait either.  A caller that enqueues work on a provisional `out` (epilogue, copies) asks afterwards:
+ *   fd_sample_ticket(h)          the ticket of the last fd_sample on this handle (1, 2, ...);
+ *   fd_sample_settle(h, ticket)  makes call `ticket` final (waits for it if nobody has looked at it yet) and returns 1 if it had to be
+ *                                redone -- then whatever was computed from its `out` must be computed again -- 0 if not, < 0 on error.
+ * Tickets older than the last 16 redone calls are reported as 0. */
 FD_API int fd_sample_check(fd_handle h);
+FD_API int64_t fd_sample_ticket(fd_handle h);
+FD_API int fd_sample_settle(fd_handle h, int64_t ticket);
 
 /* Per-utterance noise streams for the NEXT fd_sample call (one-shot; the reference draws std_normal per batch on the CPU,
  * util.py:63-68, so it has no counterpart there).  stream_ids [B] host: utterance b's x_T and z are then drawn from Philox stream

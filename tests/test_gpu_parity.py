@@ -312,7 +312,7 @@ def test_sampler_hands_over_to_fp32_at_64_frames(gc, sched):
     mel = torch.from_numpy(synth.synth_mel(9, B, T)).cuda()
     mel[1, :, lens[1]:] = 0.0
     out = {}
-    for tag, opts in (("handover", {}), ("fp32", {"lvc": "fp32", "conv": "fp32"})):
+    for tag, opts in (("handover", {"fallback": "graph"}), ("hostcheck", {"fallback": "host"}), ("fp32", {"lvc": "fp32", "conv": "fp32"})):
         m = gc.fastdiff_amd.FastDiff()
         m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
         m = m.cuda().eval()
@@ -324,12 +324,13 @@ def test_sampler_hands_over_to_fp32_at_64_frames(gc, sched):
         flags = m.read_tap("range_flags_call").view(np.int32)
         if tag == "handover":
             assert flags[0] == 0 and flags[13:19].all() and flags[1:13].reshape(3, 4)[1:].all(), flags[:20]
-        else:
+        else:      # fp32 selected outright, or (host check) the call run again with the flagged stages on fp32: nothing left to flag
             assert not flags[1:19].any()
     for b in range(B):
         scale = float(np.abs(out["fp32"][b]).max())
-        assert np.isfinite(out["handover"][b]).all() and scale > 32768.0
-        assert gc.maxdiff(out["handover"][b], out["fp32"][b]) < 1e-5 * scale, (b, scale)
+        assert scale > 32768.0
+        for tag in ("handover", "hostcheck"):
+            assert np.isfinite(out[tag][b]).all() and gc.maxdiff(out[tag][b], out["fp32"][b]) < 1e-5 * scale, (tag, b, scale)
 
 
 def test_ragged_batch_with_lens_equals_each_utterance_alone(gc, sched):
@@ -503,11 +504,55 @@ def test_host_checked_fallback_equals_inline_fallback(gc, sched, oracle64):
     scale = float(np.abs(ref).max())
     assert np.isfinite(h1.cpu().numpy()).all() and torch.equal(h1, h2)
     assert gc.maxdiff(h1.cpu().numpy(), ref) < 1e-5 * scale and gc.maxdiff(g.cpu().numpy(), ref) < 1e-5 * scale
-    # a later call on the handle settles a deferred check by itself
+    # the pipelined form: the epilogue does not wait for the check (its result is provisional with the waveform); settle(ticket) says
+    # whether the call was run again -- here it was -- and the epilogue is then computed again from the final waveform
     with torch.no_grad():
         h3 = m2.sample(melc, rows, defer_check=True, **args)
-        pcm = m2.peak_normalize_int16(h3)                              # settles, then reads the final h3
+        ticket = m2.last_ticket
+        m2.peak_normalize_int16(h3)
+        assert m2.settle(ticket) is True and m2.settle(ticket) is True          # asking twice does no harm
+        pcm = m2.peak_normalize_int16(h3)
     assert torch.equal(h3, h1) and pcm.shape == (B, T * 256)
+    assert torch.equal(pcm, m2.peak_normalize_int16(h1))
+
+
+def test_pipelined_host_check_looks_at_a_call_after_the_next_one_is_enqueued(gc, sched):
+    """Option fallback = "host" with deferred checks, the way a serving loop drives it: call k is looked at by call k + 1 after that
+    one has enqueued itself.  A run of calls that alternate between an ordinary start and one scaled by 1e6 (every DBlock /
+    ConvTranspose / LVC launch of that call leaves the fp16 range) must give, call for call, the result of the in-graph fallbacks (the
+    same bits where nothing was flagged); settle(ticket) must name exactly the scaled calls, whenever it is asked."""
+    import synth
+    rows, _ = gc.table_rows(sched, 4)
+    B, T, N = 2, 37, 4
+    mel = torch.from_numpy(synth.synth_mel(41, B, T)).cuda()
+    starts = []
+    for k in range(6):
+        x = synth.hash_normal(50 + k, 1, B * T * 256).reshape(B, 1, T * 256)
+        starts.append(torch.from_numpy(x * (1.0e6 if k % 2 else 1.0)).float().cuda())
+    zeros = torch.zeros(N, B, 1, T * 256, device="cuda")
+    ref_model = gc.make_model()
+    ref_model.set_option("fallback", "graph")
+    with torch.no_grad():
+        want = [ref_model.sample(mel, rows, x_T=x, noise=zeros) for x in starts]
+        flags = ref_model.read_tap("range_flags_call").view(np.int32)
+    assert flags[13:19].all()                                   # the last (scaled) call did leave the range
+    m = gc.make_model()
+    m.set_option("fallback", "host")
+    got, tickets = [], []
+    with torch.no_grad():
+        for x in starts:
+            got.append(m.sample(mel, rows, x_T=x, noise=zeros, defer_check=True))
+            tickets.append(m.last_ticket)
+        redone = [m.settle(t) for t in tickets]                 # the last call is looked at here, the others already were
+    assert redone == [False, True, False, True, False, True]
+    torch.cuda.synchronize()
+    for k, (a, b) in enumerate(zip(got, want)):
+        if k % 2 == 0:
+            assert torch.equal(a, b), k                          # nothing flagged: the same kernels ran
+        else:                                                    # redone with the flagged stages on fp32 in EVERY step (in-graph: per step)
+            scale = float(b.abs().max())
+            assert torch.isfinite(a).all() and float((a - b).abs().max()) < 1e-5 * scale, (k, scale)
+    assert tickets == list(range(tickets[0], tickets[0] + 6)) and m.settle(tickets[1]) is True
 
 
 def test_host_checked_fallback_long_schedule(gc, sched):

@@ -1,4 +1,4 @@
-"""The LVC operator's kernels one by one: run under `rocprofv3 --kernel-trace --stats` (tools/gpu_r2_s10.sh).  B = 20, T = 100."""
+"""The LVC operator's kernels one by one: run under `rocprofv3 --kernel-trace --stats` (tools/history/gpu_r2_s10.sh).  B = 20, T = 100."""
 import os
 import sys
 
