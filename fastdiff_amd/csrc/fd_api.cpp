@@ -1336,6 +1336,30 @@ int fd_lvc_backward(fd_handle h, const float *x, const float *kernel, const floa
     return FD_OK;
 }
 
+int fd_gate_forward(fd_handle h, const float *x, const float *y, int B, int C, int64_t L, float *out, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!x || !y || !out) FD_FAIL(h, FD_ERR_INVALID, "fd_gate_forward: null pointer");
+    if (B <= 0 || C <= 0 || L <= 0 || B > 65535 || C > 65535) FD_FAIL(h, FD_ERR_INVALID, "fd_gate_forward: B=%d C=%d L=%lld", B, C, (long long)L);
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::gate_forward(La, x, y, out, B, C, L);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_gate_forward: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+int fd_gate_backward(fd_handle h, const float *y, const float *dout, int B, int C, int64_t L, float *dy, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!y || !dout || !dy) FD_FAIL(h, FD_ERR_INVALID, "fd_gate_backward: null pointer");
+    if (B <= 0 || C <= 0 || L <= 0 || B > 65535 || C > 65535) FD_FAIL(h, FD_ERR_INVALID, "fd_gate_backward: B=%d C=%d L=%lld", B, C, (long long)L);
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::gate_backward(La, y, dout, dy, B, C, L);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_gate_backward: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
 int fd_peak_normalize_int16_ragged(fd_handle h, const float *wav, int B, int64_t len, const int64_t *valid, int16_t *pcm, void *stream)
 {
     if (!h || !wav || !pcm || B <= 0 || len <= 0 || B > 4096) return FD_ERR_INVALID;

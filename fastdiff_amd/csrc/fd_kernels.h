@@ -27,4 +27,7 @@ hipError_t lvc_op_forward(const Launch &L, const float *x, const float *K, const
                           int T, int hop, float *scratch);
 hipError_t lvc_op_backward(const Launch &L, const float *x, const float *K, const float *dout, float *dx, float *dK, float *dbias, int B,
                            int Cin, int Cout, int ks, int T, int hop, float *scratch);
+// the gate + residual of an LVC layer, one pass forward and one backward (modules.py:217)
+hipError_t gate_forward(const Launch &L, const float *x, const float *y, float *out, int B, int C, int64_t len);
+hipError_t gate_backward(const Launch &L, const float *y, const float *dout, float *dy, int B, int C, int64_t len);
 }  // namespace fdk

@@ -434,10 +434,69 @@ __global__ void __launch_bounds__(256) k_lvc_bwd_k(const float *__restrict__ x, 
     if (dbias && tid < Cout) dbias[((int64_t)b * Cout + tid) * T + l] = accb;
 }
 
+// ---- the gate of an LVC layer with its residual (modules.py:217): out = x + sigmoid(y[:, :C]) * tanh(y[:, C:]) --------------------
+// Under autograd the reference spends four elementwise kernels on it forward (sigmoid, tanh, mul, add) and eight backward, each
+// moving the layer's whole [B, 32, L] tensor through HBM; here it is one pass each way: forward reads x and both halves of y,
+// backward reads y and dout and writes both halves of dy (d out / d x is the identity: autograd hands dout on).
+__device__ __forceinline__ float sigm(float a) { return 1.0f / (1.0f + expf(-a)); }
+__device__ __forceinline__ float tanh_e(float b) { return 1.0f - 2.0f / (expf(2.0f * b) + 1.0f); }      // exact limits at +-inf
+
+template <int VEC>
+__global__ void __launch_bounds__(256) k_gate_fwd(const float *__restrict__ x, const float *__restrict__ y, float *__restrict__ out, int C,
+                                                  int64_t L)
+{
+    const int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (q >= L) return;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float *ya = y + ((int64_t)b * 2 * C + c) * L + q, *yb = ya + (int64_t)C * L;
+    const int64_t xo = ((int64_t)b * C + c) * L + q;
+    if (VEC == 4) {
+        const float4 a = *reinterpret_cast<const float4 *>(ya), t = *reinterpret_cast<const float4 *>(yb), xv = *reinterpret_cast<const float4 *>(x + xo);
+        *reinterpret_cast<float4 *>(out + xo) = make_float4(xv.x + sigm(a.x) * tanh_e(t.x), xv.y + sigm(a.y) * tanh_e(t.y),
+                                                            xv.z + sigm(a.z) * tanh_e(t.z), xv.w + sigm(a.w) * tanh_e(t.w));
+    } else {
+        out[xo] = x[xo] + sigm(ya[0]) * tanh_e(yb[0]);
+    }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) k_gate_bwd(const float *__restrict__ y, const float *__restrict__ dout, float *__restrict__ dy, int C,
+                                                  int64_t L)
+{
+    const int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (q >= L) return;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int64_t ao = ((int64_t)b * 2 * C + c) * L + q, bo = ao + (int64_t)C * L, xo = ((int64_t)b * C + c) * L + q;
+    auto da = [](float g, float a, float t) { const float s = sigm(a), th = tanh_e(t); return g * th * s * (1.0f - s); };
+    auto db = [](float g, float a, float t) { const float s = sigm(a), th = tanh_e(t); return g * s * (1.0f - th * th); };
+    if (VEC == 4) {
+        const float4 a = *reinterpret_cast<const float4 *>(y + ao), t = *reinterpret_cast<const float4 *>(y + bo), g = *reinterpret_cast<const float4 *>(dout + xo);
+        *reinterpret_cast<float4 *>(dy + ao) = make_float4(da(g.x, a.x, t.x), da(g.y, a.y, t.y), da(g.z, a.z, t.z), da(g.w, a.w, t.w));
+        *reinterpret_cast<float4 *>(dy + bo) = make_float4(db(g.x, a.x, t.x), db(g.y, a.y, t.y), db(g.z, a.z, t.z), db(g.w, a.w, t.w));
+    } else {
+        dy[ao] = da(dout[xo], y[ao], y[bo]);
+        dy[bo] = db(dout[xo], y[ao], y[bo]);
+    }
+}
+
 }  // namespace fdk_train
 
 namespace fdk {
 using namespace fdk_train;
+
+hipError_t gate_forward(const Launch &L, const float *x, const float *y, float *out, int B, int C, int64_t len)
+{
+    if (len % 4 == 0) FD_LAUNCH(L, "gate_forward", k_gate_fwd<4>, dim3((unsigned)((len / 4 + 255) / 256), C, B), dim3(256), 0, x, y, out, C, len);
+    else FD_LAUNCH(L, "gate_forward", k_gate_fwd<1>, dim3((unsigned)((len + 255) / 256), C, B), dim3(256), 0, x, y, out, C, len);
+    return hipSuccess;
+}
+
+hipError_t gate_backward(const Launch &L, const float *y, const float *dout, float *dy, int B, int C, int64_t len)
+{
+    if (len % 4 == 0) FD_LAUNCH(L, "gate_backward", k_gate_bwd<4>, dim3((unsigned)((len / 4 + 255) / 256), C, B), dim3(256), 0, y, dout, dy, C, len);
+    else FD_LAUNCH(L, "gate_backward", k_gate_bwd<1>, dim3((unsigned)((len + 255) / 256), C, B), dim3(256), 0, y, dout, dy, C, len);
+    return hipSuccess;
+}
 
 static bool model_shape(int Cin, int Cout, int ks, int hop) { return Cin == MI && Cout == MO && ks == MK && (hop == 8 || hop == 64 || hop == 256); }
 bool lvc_op_needs_scratch(int Cin, int Cout, int ks, int hop) { return model_shape(Cin, Cout, ks, hop); }

@@ -290,10 +290,9 @@ def synthesize_sharded(model, items, n_steps: int = 4, max_batch: int = 8, seed:
     if not on_gpu:
         return {names[i]: out[i].numpy() for i in range(len(names))}
     sizes = [int(o.numel()) for o in out]
-    host = shard._pinned_buffer("job_pcm", sum(sizes), torch.int16)[: sum(sizes)]
-    host.copy_(torch.cat([o.reshape(-1) for o in out]), non_blocking=True)          # one device-to-host copy for the whole job
-    torch.cuda.current_stream().synchronize()
-    flat = host.numpy().copy()
+    # one device-to-host copy for the whole job, into pageable memory the caller owns (through a pinned buffer it measured 9 ms for
+    # the 27 MB of BASELINE config 4 against 1 ms: reading pinned memory back on the host is slow)
+    flat = torch.cat([o.reshape(-1) for o in out]).cpu().numpy()
     offs = np.concatenate([[0], np.cumsum(sizes)])
     return {names[i]: flat[offs[i]: offs[i + 1]] for i in range(len(names))}
 

@@ -73,6 +73,43 @@ class _LVC(torch.autograd.Function):
         return (None if dx is None else dx.to(tx), None if dk is None else dk.to(tk), None if db is None else db.to(tb), None)
 
 
+class _Gate(torch.autograd.Function):
+    """out = x + sigmoid(y[:, :C]) * tanh(y[:, C:]) (modules.py:217), one HIP pass forward (fd_gate_forward) and one backward."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        if not (x.is_cuda and y.is_cuda):
+            raise RuntimeError("fastdiff_amd.gated_residual runs only on a HIP device (no CPU fallback)")
+        ctx.in_dtypes = (x.dtype, y.dtype)
+        x, y = x.contiguous().float(), y.contiguous().float()
+        B, C, L = x.shape
+        assert tuple(y.shape) == (B, 2 * C, L), "gate: y must hold the sigmoid half and the tanh half of every channel of x"
+        out = torch.empty_like(x)
+        lib, h = _handle(x.device)
+        _capi.check(lib, h, lib.fd_gate_forward(h, x.data_ptr(), y.data_ptr(), B, C, L, out.data_ptr(), _stream(x.device)), "fd_gate_forward")
+        ctx.save_for_backward(y)
+        return out.to(ctx.in_dtypes[0])
+
+    @staticmethod
+    def backward(ctx, dout):
+        (y,) = ctx.saved_tensors
+        dy = None
+        if ctx.needs_input_grad[1]:
+            g = dout.contiguous().float()
+            B, C2, L = y.shape
+            dy = torch.empty_like(y)
+            lib, h = _handle(y.device)
+            _capi.check(lib, h, lib.fd_gate_backward(h, y.data_ptr(), g.data_ptr(), B, C2 // 2, L, dy.data_ptr(), _stream(y.device)), "fd_gate_backward")
+            dy = dy.to(ctx.in_dtypes[1])
+        return (dout if ctx.needs_input_grad[0] else None), dy
+
+
+def gated_residual(x, y):
+    """x + sigmoid(y[:, :C]) * tanh(y[:, C:]) for x [B, C, L], y [B, 2C, L]: the last line of an LVC layer (modules.py:217) as one
+    differentiable operator."""
+    return _Gate.apply(x, y)
+
+
 def location_variable_convolution(x, kernel, bias, dilation=1, hop_size=256):
     """(batch, in_channels, in_length), (batch, in_channels, out_channels, kernel_size, kernel_length), (batch, out_channels,
     kernel_length) -> (batch, out_channels, in_length); same assert as the reference (modules.py:236).  dilation must be 1: it is

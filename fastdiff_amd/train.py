@@ -44,7 +44,12 @@ def _kernel_predictor(p, c, layers, cin, cout, ks):
             p.bias_conv(c).contiguous().view(B, layers, cout, T))
 
 
-def _lvc_block(p, x, audio_down, c, emb, cfg, lvc):
+def _torch_gate(x, y):
+    C = x.shape[1]
+    return x + torch.sigmoid(y[:, :C]) * torch.tanh(y[:, C:])
+
+
+def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate):
     """TimeAware_LVCBlock.forward (modules.py:189-218); the in-place `x += audio_down` of the reference written out of place."""
     C = cfg["inner_channels"]
     cond = c + p.fc_t(emb).unsqueeze(-1)
@@ -57,14 +62,15 @@ def _lvc_block(p, x, audio_down, c, emb, cfg, lvc):
         x = x + audio_down
         y = F.leaky_relu(conv(F.leaky_relu(x, 0.2)), 0.2)
         y = lvc(y, kernels[i], bias[i], 1, p.cond_hop_length)
-        x = x + torch.sigmoid(y[:, :C]) * torch.tanh(y[:, C:])
+        x = gate(x, y)                                   # x + sigmoid(y[:, :C]) * tanh(y[:, C:])  (modules.py:217)
     return x
 
 
 def differentiable_forward(module, data, lvc=None):
     """eps = net((audio, c, diffusion_steps)) as FastDiff.forward (FastDiff_model.py:74-102), recorded by autograd."""
-    if lvc is None:
-        from .lvc_op import location_variable_convolution as lvc
+    gate = _torch_gate
+    if lvc is None:                    # the product path: both operators of the layer on HIP kernels, forward and backward
+        from .lvc_op import location_variable_convolution as lvc, gated_residual as gate
     audio, c, diffusion_steps = data
     cfg = module._cfg
     if c.dim() == 2:
@@ -77,5 +83,5 @@ def differentiable_forward(module, data, lvc=None):
         skips.append(x)
         x = _dblock(down, x)
     for n, audio_down in enumerate(reversed(skips)):
-        x = _lvc_block(module.lvc_blocks[n], x, audio_down, c, emb, cfg, lvc)
+        x = _lvc_block(module.lvc_blocks[n], x, audio_down, c, emb, cfg, lvc, gate)
     return module.final_conv(x)

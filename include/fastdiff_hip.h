@@ -167,6 +167,13 @@ FD_API int fd_lvc_forward(fd_handle h, const float *x, const float *kernel, cons
 FD_API int fd_lvc_backward(fd_handle h, const float *x, const float *kernel, const float *dout, int B, int Cin, int Cout, int ks, int T,
                            int hop, float *dx, float *dkernel, float *dbias, void *stream);
 
+/* The gate of an LVC layer with its residual (modules.py:217) for the training path: out = x + sigmoid(y[:, :C]) * tanh(y[:, C:]),
+ * x, out, dout [B,C,L], y, dy [B,2C,L] (device, float32, contiguous).  Under autograd the reference runs twelve elementwise kernels
+ * for this line (four forward, eight backward), each moving the layer's whole tensor through HBM; these are one pass each way.
+ * d out / d x is the identity, so fd_gate_backward only produces dy. */
+FD_API int fd_gate_forward(fd_handle h, const float *x, const float *y, int B, int C, int64_t L, float *out, void *stream);
+FD_API int fd_gate_backward(fd_handle h, const float *y, const float *dout, int B, int C, int64_t L, float *dy, void *stream);
+
 /* Mel front-end in front of the vocoder: process_utterance(..., vocoder='pwg') of
  * data_gen/tts/data_gen_utils.py:93-147 = librosa.stft(n_fft 1024, hop 256, win 1024, "hann", center, pad_mode "constant") ->
  * magnitude -> librosa.filters.mel(22050, 1024, 80, fmin 80, fmax 7600) -> log10(max(1e-6, .)).

@@ -324,8 +324,10 @@ def test_sampler_hands_over_to_fp32_at_64_frames(gc, sched):
         flags = m.read_tap("range_flags_call").view(np.int32)
         if tag == "handover":
             assert flags[0] == 0 and flags[13:19].all() and flags[1:13].reshape(3, 4)[1:].all(), flags[:20]
-        else:      # fp32 selected outright, or (host check) the call run again with the flagged stages on fp32: nothing left to flag
+        elif tag == "fp32":
             assert not flags[1:19].any()
+        # (host check: the flags left behind are those of the second pass -- stages that met garbage, not large values, in the first
+        # pass and so were flagged only now, with their fp32 twin inline -- nothing to assert on them but the result below)
     for b in range(B):
         scale = float(np.abs(out["fp32"][b]).max())
         assert scale > 32768.0

@@ -135,3 +135,30 @@ def test_other_shapes_take_the_generic_kernels():
     for name, got, want in (("out", y.detach(), ref), ("dx", xt.grad, rdx), ("dK", Kt.grad, rdK), ("dbias", bt.grad, rdb)):
         err = np.abs(got.cpu().numpy().astype(np.float64) - want).max()
         assert got.shape == want.shape and err <= 3e-6 * max(1.0, np.abs(want).max()), (name, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 32, 100 * 256), (3, 5, 37), (1, 32, 8 * 7)])
+def test_gate_operator_forward_and_backward_match_torch_autograd(shape):
+    """fastdiff_amd.gated_residual = x + sigmoid(y[:, :C]) * tanh(y[:, C:]) (modules.py:217) as one HIP pass each way, against the same
+    line on torch autograd in float64 (values include saturated arguments, where tanh' and sigmoid' vanish)."""
+    import fastdiff_amd
+    B, C, L = shape
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    x = torch.randn(B, C, L, generator=g)
+    y = torch.randn(B, 2 * C, L, generator=g) * 4.0
+    y[0, 0, :8] = torch.tensor([-120.0, 120.0, -30.0, 30.0, 0.0, 1e-4, -88.0, 88.0])
+    y[0, C, :8] = torch.tensor([60.0, -60.0, 0.0, 20.0, -20.0, 1e-4, 50.0, -50.0])
+    dout = torch.randn(B, C, L, generator=g)
+    x64, y64 = x.double().requires_grad_(True), y.double().requires_grad_(True)
+    ref = x64 + torch.sigmoid(y64[:, :C]) * torch.tanh(y64[:, C:])
+    ref.backward(dout.double())
+    xg, yg = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+    out = fastdiff_amd.gated_residual(xg, yg)
+    out.backward(dout.cuda())
+    assert out.dtype == torch.float32 and torch.isfinite(out).all() and torch.isfinite(yg.grad).all()
+    assert float((out.double().cpu() - ref.detach()).abs().max()) < 2e-6
+    assert torch.equal(xg.grad.cpu(), dout)                                  # d out / d x is the identity
+    assert float((yg.grad.double().cpu() - y64.grad).abs().max()) < 2e-6 * max(1.0, float(y64.grad.abs().max()))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        fastdiff_amd.gated_residual(x, y)
