@@ -237,6 +237,7 @@ int fd_destroy(fd_handle h)
     for (void *p : h->dev_allocs) hipFree(p);
     if (h->scratch) hipFree(h->scratch);
     if (h->lvc_scratch) hipFree(h->lvc_scratch);
+    if (h->kconv_scratch) hipFree(h->kconv_scratch);
     for (auto &sl : h->stage) {
         if (sl.host) hipHostFree(sl.host);
         if (sl.done) hipEventDestroy(sl.done);
@@ -1333,6 +1334,44 @@ int fd_lvc_backward(fd_handle h, const float *x, const float *kernel, const floa
     fdk::Launch L = {h, (hipStream_t)stream, false};
     hipError_t e = fdk::lvc_op_backward(L, x, kernel, dout, dx, dkernel, dbias, B, Cin, Cout, ks, T, hop, scratch);
     if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_lvc_backward: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+// kernel_conv of the KernelPredictor (training path).  The backward's dh pass adds up 16 row slices through a scratch buffer kept on
+// the handle next to the LVC operator's (same rule: calls on one handle are ordered on one stream).
+int fd_kconv_forward(fd_handle h, const float *x, const float *weight, const float *bias, int B, int M, int T, float *out, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!x || !weight || !bias || !out) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_forward: null pointer");
+    if (B <= 0 || B > 65535) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_forward: B=%d", B);
+    if (!fdk::kconv_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_forward: M=%d (a multiple of 128) and T=%d (1..128) only", M, T);
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::kconv_forward(La, x, weight, bias, out, B, M, T);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_kconv_forward: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+int fd_kconv_backward(fd_handle h, const float *x, const float *weight, const float *dout, int B, int M, int T, float *dx, float *dweight,
+                      float *dbias, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!dout || ((dweight || dbias) && !x) || (dx && !weight)) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward: null pointer");
+    if (B <= 0 || B > 65535) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward: B=%d", B);
+    if (!fdk::kconv_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_backward: M=%d (a multiple of 128) and T=%d (1..128) only", M, T);
+    FD_HIP(h, hipSetDevice(h->device));
+    if (dx) {
+        const size_t bytes = sizeof(float) * fdk::kconv_scratch_floats(B, T);
+        if (h->kconv_scratch_bytes < bytes) {
+            if (h->kconv_scratch) FD_HIP(h, hipFree(h->kconv_scratch));
+            h->kconv_scratch = nullptr; h->kconv_scratch_bytes = 0;
+            FD_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->kconv_scratch), bytes));
+            h->kconv_scratch_bytes = bytes;
+        }
+    }
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::kconv_backward(La, x, weight, dout, dx, dweight, dbias, B, M, T, h->kconv_scratch);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_kconv_backward: %s", hipGetErrorString(e));
     return FD_OK;
 }
 

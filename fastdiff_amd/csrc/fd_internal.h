@@ -235,6 +235,8 @@ struct fd_context {
     void *scratch = nullptr;                 // 64 KB device scratch (abs-max words, ...)
     float *lvc_scratch = nullptr;            // the LVC operator's frame-major kernel copy (fd_lvc_forward / fd_lvc_backward), grown on demand
     size_t lvc_scratch_bytes = 0;
+    float *kconv_scratch = nullptr;          // the row-slice partial sums of fd_kconv_backward's dh pass, grown on demand
+    size_t kconv_scratch_bytes = 0;
     std::vector<ProfEntry> prof_pending;
     std::vector<hipEvent_t> event_pool;
     std::map<std::string, std::pair<int64_t, double>> prof_acc;

@@ -110,6 +110,54 @@ def gated_residual(x, y):
     return _Gate.apply(x, y)
 
 
+class _KConv(torch.autograd.Function):
+    """KernelPredictor.kernel_conv (modules.py:315-318,330-331: Conv1d(64 -> M, k3, pad 1)) forward and backward on fp32-MFMA HIP
+    kernels (fd_kconv_forward / fd_kconv_backward), the reference's layouts."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.in_dtypes = (x.dtype, weight.dtype, bias.dtype)
+        x, weight, bias = x.contiguous().float(), weight.contiguous().float(), bias.contiguous().float()
+        B, _, T = x.shape
+        M = weight.shape[0]
+        out = torch.empty((B, M, T), device=x.device, dtype=torch.float32)
+        lib, h = _handle(x.device)
+        _capi.check(lib, h, lib.fd_kconv_forward(h, x.data_ptr(), weight.data_ptr(), bias.data_ptr(), B, M, T, out.data_ptr(), _stream(x.device)),
+                    "fd_kconv_forward")
+        ctx.save_for_backward(x, weight)
+        return out.to(ctx.in_dtypes[0])
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight = ctx.saved_tensors
+        dout = dout.contiguous().float()
+        B, _, T = x.shape
+        M = weight.shape[0]
+        need_x, need_w, need_b = ctx.needs_input_grad
+        dx = torch.empty_like(x) if need_x else None
+        dw = torch.empty_like(weight) if need_w else None
+        db = torch.empty((M,), device=x.device, dtype=torch.float32) if need_b else None
+        lib, h = _handle(x.device)
+        _capi.check(lib, h, lib.fd_kconv_backward(h, x.data_ptr(), weight.data_ptr(), dout.data_ptr(), B, M, T,
+                                                  None if dx is None else dx.data_ptr(), None if dw is None else dw.data_ptr(),
+                                                  None if db is None else db.data_ptr(), _stream(x.device)), "fd_kconv_backward")
+        tx, tw, tb = ctx.in_dtypes
+        return (None if dx is None else dx.to(tx), None if dw is None else dw.to(tw), None if db is None else db.to(tb))
+
+
+def kernel_conv_supported(x, weight):
+    """The shapes the HIP kernels cover: 64 input channels, kernel 3, a multiple of 128 output channels, at most 128 frames (the
+    reference trains on crops of 100: base.yaml:50-51)."""
+    return (x.is_cuda and x.dim() == 3 and weight.dim() == 3 and x.shape[1] == 64 and tuple(weight.shape[1:]) == (64, 3)
+            and weight.shape[0] % 128 == 0 and 1 <= x.shape[2] <= 128)
+
+
+def kernel_conv1d(x, weight, bias):
+    """conv1d(x [B,64,T], weight [M,64,3], bias [M], padding=1) -> [B,M,T] as a differentiable HIP operator (the predictor's
+    kernel_conv); shapes outside kernel_conv_supported() are refused by the library (FD_ERR_UNSUPPORTED)."""
+    return _KConv.apply(x, weight, bias)
+
+
 def location_variable_convolution(x, kernel, bias, dilation=1, hop_size=256):
     """(batch, in_channels, in_length), (batch, in_channels, out_channels, kernel_size, kernel_length), (batch, out_channels,
     kernel_length) -> (batch, out_channels, in_length); same assert as the reference (modules.py:236).  dilation must be 1: it is

@@ -35,12 +35,26 @@ def _dblock(p, x):
     return x + residual
 
 
-def _kernel_predictor(p, c, layers, cin, cout, ks):
-    """KernelPredictor.forward (modules.py:320-343)."""
+def _conv_weight(m):
+    """The effective weight of a conv module: g * v / ||v|| while weight-norm is attached (what its forward hook computes), the plain
+    weight after remove_weight_norm()."""
+    if hasattr(m, "weight_g"):
+        return torch._weight_norm(m.weight_v, m.weight_g, 0)
+    return m.weight
+
+
+def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None):
+    """KernelPredictor.forward (modules.py:320-343).  kconv: the HIP operator for kernel_conv (64 -> 24576 channels: the largest
+    matrix product of the step) where its shapes fit, else the module's own convolution."""
     B, _, T = c.shape
     c = p.input_conv(c)
     c = c + p.residual_conv(c)
-    return (p.kernel_conv(c).contiguous().view(B, layers, cin, cout, ks, T),
+    kc = p.kernel_conv
+    if kconv is not None and kconv[1](c, kc.weight_v if hasattr(kc, "weight_v") else kc.weight):
+        k = kconv[0](c, _conv_weight(kc), kc.bias)
+    else:
+        k = kc(c)
+    return (k.contiguous().view(B, layers, cin, cout, ks, T),
             p.bias_conv(c).contiguous().view(B, layers, cout, T))
 
 
@@ -49,11 +63,11 @@ def _torch_gate(x, y):
     return x + torch.sigmoid(y[:, :C]) * torch.tanh(y[:, C:])
 
 
-def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate):
+def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate, kconv=None):
     """TimeAware_LVCBlock.forward (modules.py:189-218); the in-place `x += audio_down` of the reference written out of place."""
     C = cfg["inner_channels"]
     cond = c + p.fc_t(emb).unsqueeze(-1)
-    kernels, bias = _kernel_predictor(p.kernel_predictor, cond, cfg["lvc_layers_each_block"], C, 2 * C, cfg["lvc_kernel_size"])
+    kernels, bias = _kernel_predictor(p.kernel_predictor, cond, cfg["lvc_layers_each_block"], C, 2 * C, cfg["lvc_kernel_size"], kconv)
     x = p.upsample(F.leaky_relu(x, 0.2))
     # the reference slices kernels[:, i] (modules.py:213-214), whose backward builds a zero tensor of all four layers per slice and
     # adds the four up; unbind hands autograd the same views and gets one stack back
@@ -68,9 +82,10 @@ def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate):
 
 def differentiable_forward(module, data, lvc=None):
     """eps = net((audio, c, diffusion_steps)) as FastDiff.forward (FastDiff_model.py:74-102), recorded by autograd."""
-    gate = _torch_gate
-    if lvc is None:                    # the product path: both operators of the layer on HIP kernels, forward and backward
-        from .lvc_op import location_variable_convolution as lvc, gated_residual as gate
+    gate, kconv = _torch_gate, None
+    if lvc is None:                    # the product path: the layer's two operators and the predictor's kernel_conv on HIP kernels
+        from .lvc_op import location_variable_convolution as lvc, gated_residual as gate, kernel_conv1d, kernel_conv_supported
+        kconv = (kernel_conv1d, kernel_conv_supported)
     audio, c, diffusion_steps = data
     cfg = module._cfg
     if c.dim() == 2:
@@ -83,5 +98,5 @@ def differentiable_forward(module, data, lvc=None):
         skips.append(x)
         x = _dblock(down, x)
     for n, audio_down in enumerate(reversed(skips)):
-        x = _lvc_block(module.lvc_blocks[n], x, audio_down, c, emb, cfg, lvc, gate)
+        x = _lvc_block(module.lvc_blocks[n], x, audio_down, c, emb, cfg, lvc, gate, kconv)
     return module.final_conv(x)

@@ -167,6 +167,16 @@ FD_API int fd_lvc_forward(fd_handle h, const float *x, const float *kernel, cons
 FD_API int fd_lvc_backward(fd_handle h, const float *x, const float *kernel, const float *dout, int B, int Cin, int Cout, int ks, int T,
                            int hop, float *dx, float *dkernel, float *dbias, void *stream);
 
+/* KernelPredictor.kernel_conv (modules/FastDiff/module/modules.py:315-318,330-331: Conv1d(64 -> M, kernel 3, padding 1) with
+ * M = lvc_layers * in * 2 in * 3 = 24576) for the training path, in the reference's layouts: x [B,64,T], weight [M,64,3] (after
+ * weight-norm), bias [M], out / dout [B,M,T] (device, float32, contiguous); the three gradients whose pointer is not NULL are written
+ * (dx needs weight; dweight and dbias need x).  fp32 matrix instruction throughout.  M a multiple of 128, 1 <= T <= 128 (the
+ * reference trains on crops of 100 frames: base.yaml:50-51) -- anything else returns FD_ERR_UNSUPPORTED and the caller keeps its own
+ * convolution. */
+FD_API int fd_kconv_forward(fd_handle h, const float *x, const float *weight, const float *bias, int B, int M, int T, float *out, void *stream);
+FD_API int fd_kconv_backward(fd_handle h, const float *x, const float *weight, const float *dout, int B, int M, int T, float *dx,
+                             float *dweight, float *dbias, void *stream);
+
 /* The gate of an LVC layer with its residual (modules.py:217) for the training path: out = x + sigmoid(y[:, :C]) * tanh(y[:, C:]),
  * x, out, dout [B,C,L], y, dy [B,2C,L] (device, float32, contiguous).  Under autograd the reference runs twelve elementwise kernels
  * for this line (four forward, eight backward), each moving the layer's whole tensor through HBM; these are one pass each way.

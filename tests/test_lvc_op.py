@@ -162,3 +162,34 @@ def test_gate_operator_forward_and_backward_match_torch_autograd(shape):
     assert float((yg.grad.double().cpu() - y64.grad).abs().max()) < 2e-6 * max(1.0, float(y64.grad.abs().max()))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         fastdiff_amd.gated_residual(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 256, 100), (2, 128, 37), (1, 384, 128), (2, 128, 1)])
+def test_kernel_conv_operator_forward_and_backward_match_torch_autograd(shape):
+    """fastdiff_amd.kernel_conv1d = the predictor's kernel_conv, Conv1d(64 -> M, k3, pad 1) (modules.py:315-318,330-331), forward and
+    its three gradients on fp32-MFMA HIP kernels, against torch's conv1d and autograd in float64 (T a multiple of 4 and not, one
+    frame, a last column tile of every fill)."""
+    import fastdiff_amd
+    import torch.nn.functional as F
+    B, M, T = shape
+    g = torch.Generator().manual_seed(M + T)
+    x = torch.randn(B, 64, T, generator=g)
+    w = torch.randn(M, 64, 3, generator=g) / 14.0
+    bias = torch.randn(M, generator=g)
+    dout = torch.randn(B, M, T, generator=g)
+    x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, bias))
+    ref = F.conv1d(x64, w64, b64, padding=1)
+    ref.backward(dout.double())
+    xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, bias))
+    out = fastdiff_amd.kernel_conv1d(xg, wg, bg)
+    out.backward(dout.cuda())
+    rel = lambda got, want: float((got.double().cpu() - want).abs().max()) / max(1.0, float(want.abs().max()))      # noqa: E731
+    assert rel(out, ref.detach()) < 2e-6
+    assert rel(xg.grad, x64.grad) < 3e-6 and rel(wg.grad, w64.grad) < 3e-6 and rel(bg.grad, b64.grad) < 3e-6
+    # only one gradient asked for: the others' kernels are not run
+    x2 = x.cuda().requires_grad_(True)
+    fastdiff_amd.kernel_conv1d(x2, w.cuda(), bias.cuda()).backward(dout.cuda())
+    assert rel(x2.grad, x64.grad) < 3e-6
+    with pytest.raises(NotImplementedError, match="128"):          # more than 128 frames: refused, never silently computed elsewhere
+        fastdiff_amd.kernel_conv1d(torch.zeros(1, 64, 200).cuda(), w.cuda(), bias.cuda())
