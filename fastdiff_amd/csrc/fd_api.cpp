@@ -1337,8 +1337,9 @@ int fd_lvc_backward(fd_handle h, const float *x, const float *kernel, const floa
     return FD_OK;
 }
 
-// kernel_conv of the KernelPredictor (training path).  The backward's dh pass adds up 16 row slices through a scratch buffer kept on
-// the handle next to the LVC operator's (same rule: calls on one handle are ordered on one stream).
+// kernel_conv of the KernelPredictor (training path).  The backward adds up partial sums (row slices for dx, utterance ranges for
+// dweight / dbias, each in a fixed order) through a scratch buffer kept on the handle next to the LVC operator's (same rule: calls on
+// one handle are ordered on one stream).
 int fd_kconv_forward(fd_handle h, const float *x, const float *weight, const float *bias, int B, int M, int T, float *out, void *stream)
 {
     if (!h) return FD_ERR_INVALID;
@@ -1360,8 +1361,8 @@ int fd_kconv_backward(fd_handle h, const float *x, const float *weight, const fl
     if (B <= 0 || B > 65535) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward: B=%d", B);
     if (!fdk::kconv_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_backward: M=%d (a multiple of 128) and T=%d (1..128) only", M, T);
     FD_HIP(h, hipSetDevice(h->device));
-    if (dx) {
-        const size_t bytes = sizeof(float) * fdk::kconv_scratch_floats(B, T);
+    {
+        const size_t bytes = sizeof(float) * fdk::kconv_scratch_floats(B, M, T);
         if (h->kconv_scratch_bytes < bytes) {
             if (h->kconv_scratch) FD_HIP(h, hipFree(h->kconv_scratch));
             h->kconv_scratch = nullptr; h->kconv_scratch_bytes = 0;

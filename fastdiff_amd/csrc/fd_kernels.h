@@ -31,9 +31,9 @@ hipError_t lvc_op_backward(const Launch &L, const float *x, const float *K, cons
 hipError_t gate_forward(const Launch &L, const float *x, const float *y, float *out, int B, int C, int64_t len);
 hipError_t gate_backward(const Launch &L, const float *y, const float *dout, float *dy, int B, int C, int64_t len);
 // the KernelPredictor's kernel_conv (Conv1d 64 -> M, k3) forward and backward for the training path (fd_kernels_kconv.hip);
-// scratch: kconv_scratch_floats(B, T) floats for the backward's dh pass
+// scratch: kconv_scratch_floats(B, M, T) floats for the backward's partial sums
 bool kconv_supported(int M, int T);
-size_t kconv_scratch_floats(int B, int T);
+size_t kconv_scratch_floats(int B, int M, int T);
 hipError_t kconv_forward(const Launch &L, const float *h, const float *W, const float *bias, float *out, int B, int M, int T);
 hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const float *dout, float *dh, float *dW, float *dbias, int B, int M,
                           int T, float *scratch);

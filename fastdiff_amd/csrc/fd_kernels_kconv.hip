@@ -12,6 +12,8 @@
 // MFMA operand layout (32x32x2): A lane l = A[row l&31][k l>>5], B lane l = B[k l>>5][col l&31], D lane l reg r = D[(r&3) + 8(r>>2) + 4(l>>5)][l&31].
 // One k-step s of lane half hi stands for the reduction index 8 (s>>2) + 4 hi + (s&3): a lane then owns 4 consecutive indices per 4
 // steps, i.e. one aligned float4 of a row-major operand.
+#include <stdint.h>
+
 #include <algorithm>
 
 #include "fd_kernels.h"
@@ -24,9 +26,13 @@ __device__ __forceinline__ float f4c(const float4 &v, int i) { return i == 0 ? v
 __device__ __forceinline__ int drow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
 constexpr int CI = 64, KS = 3, KK = CI * KS;      // 192 = the reduction length of the forward product
+// LDS row strides are compile-time constants (T <= 128), so that every per-step offset is an immediate of the ds_read and costs neither
+// a register nor an address instruction: the h window [64][LD], x = t + 1 in [0, LD): LD = 131 = 3 (mod 32) makes the dW kernel's B
+// reads -- lane = column (c, tap), address c * LD + tap + t -- fall into 32 different banks; columns behind T + 1 are zero.
+constexpr int LD = 131, LDD = 129;
 
 // h[b] (64 x T) into LDS with one zero column each side: hs[c * LD + x] = h[b, c, x - 1], x in [0, T + 1]
-__device__ __forceinline__ void stage_h(float *__restrict__ hs, const float *__restrict__ h, int b, int T, int LD, int tid)
+__device__ __forceinline__ void stage_h(float *__restrict__ hs, const float *__restrict__ h, int b, int T, int tid)
 {
     const int n = CI * (T + 2);
     for (int idx = tid; idx < n; idx += 256) {
@@ -34,44 +40,56 @@ __device__ __forceinline__ void stage_h(float *__restrict__ hs, const float *__r
         hs[c * LD + x] = (t >= 0 && t < T) ? h[((int64_t)b * CI + c) * T + t] : 0.0f;
     }
 }
+__device__ __forceinline__ void zero_h(float *__restrict__ hs, int tid)      // once per workgroup: the columns no staging writes
+{
+    for (int idx = tid; idx < CI * LD; idx += 256) hs[idx] = 0.0f;
+}
 
 // ---- forward: workgroup = 128 output rows (wave = 32 rows, weights in 96 registers) x a range of utterances ------------------------
 __global__ void __launch_bounds__(256, 2) k_kc_fwd(const float *__restrict__ h, const float *__restrict__ W, const float *__restrict__ bias,
-                                                   float *__restrict__ out, int B, int M, int T, int LD, int bchunk)
+                                                   float *__restrict__ out, int B, int M, int T, int bchunk)
 {
-    extern __shared__ float hs[];
+    __shared__ float hs[CI * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int p0 = (blockIdx.x * 4 + wave) * 32;
     const int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
+    // reduction index of step s in lane half hi: 96 hi + s = c * 3 + tap, i.e. the halves split the input channels (32 each):
+    // A = 24 aligned float4 of the lane's weight row, B = hs[(32 hi + s / 3) * LD + s % 3 + t]: one base register + an immediate
     float4 a[24];
     {
-        const float4 *wp = reinterpret_cast<const float4 *>(W + (int64_t)(p0 + l31) * KK);
+        const float4 *wp = reinterpret_cast<const float4 *>(W + (int64_t)(p0 + l31) * KK) + 24 * hi;
 #pragma unroll
-        for (int q = 0; q < 24; ++q) a[q] = wp[2 * q + hi];
+        for (int q = 0; q < 24; ++q) a[q] = wp[q];
     }
     float bz[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) bz[r] = bias[p0 + drow(r, hi)];
-    const int nct = (T + 31) / 32;
+    const int nct = (T + 31) / 32;                      // <= 4 (T <= 128)
+    const float *hb = hs + hi * 32 * LD + l31;
+    zero_h(hs, tid);
     for (int b = b0; b < b1; ++b) {
         __syncthreads();
-        stage_h(hs, h, b, T, LD, tid);
+        stage_h(hs, h, b, T, tid);
         __syncthreads();
-        for (int ct = 0; ct < nct; ++ct) {
-            const int tcol = ct * 32 + l31, tc = min(tcol, T - 1);
-            f32x16 acc;
+        // all column tiles of the utterance first, their stores together at the end: the pieces of an output row (T floats, not a
+        // multiple of a cache line) then reach L2 back to back and leave it as whole lines
+        f32x16 acc[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = bz[r];
+        for (int ct = 0; ct < 4; ++ct) {
+            if (ct < nct) {
 #pragma unroll
-            for (int s = 0; s < 96; ++s) {
-                const int k0 = 8 * (s >> 2) + (s & 3), k1 = k0 + 4;                   // reduction index (c, tap) of the two lane halves
-                const int o0 = (k0 / 3) * LD + (k0 % 3), o1 = (k1 / 3) * LD + (k1 % 3);
-                acc = mfma32(f4c(a[s >> 2], s & 3), hs[(hi ? o1 : o0) + tc], acc);     // h[c, t + tap - 1] = hs[c][t + tap]
+                for (int r = 0; r < 16; ++r) acc[ct][r] = bz[r];
+#pragma unroll
+                for (int s = 0; s < 96; ++s)      // h[c, t + tap - 1] = hs[c][t + tap]; columns behind the utterance read zeros
+                    acc[ct] = mfma32(f4c(a[s >> 2], s & 3), hb[(s / 3) * LD + (s % 3) + ct * 32], acc[ct]);
             }
-            if (tcol < T) {
+        }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) out[((int64_t)b * M + p0 + drow(r, hi)) * T + tcol] = acc[r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            float *orow = out + ((int64_t)b * M + p0 + drow(r, hi)) * T;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+                if (ct < nct && ct * 32 + l31 < T) orow[ct * 32 + l31] = acc[ct][r];
         }
     }
 }
@@ -79,87 +97,135 @@ __global__ void __launch_bounds__(256, 2) k_kc_fwd(const float *__restrict__ h, 
 // ---- dW and dbias: workgroup = 128 rows p (wave = 32 rows), all 192 columns (c, k) in six accumulator tiles, reduction over every
 //      (b, t); the A operand (dout) comes straight from global memory, one float4 = four reduction steps per lane -------------------
 template <bool ALIGNED>
-__global__ void __launch_bounds__(256, 2) k_kc_dw(const float *__restrict__ h, const float *__restrict__ dout, float *__restrict__ dW,
-                                                  float *__restrict__ dbias, int B, int M, int T, int LD)
+__global__ void __launch_bounds__(256, 2) k_kc_dw(const float *__restrict__ h, const float *__restrict__ dout, float *__restrict__ part,
+                                                  int B, int M, int T, int bchunk)
 {
-    extern __shared__ float hs[];
+    // blockIdx.y = a range of utterances: the partial sums of the ranges are added by k_kc_dw_sum in a fixed order (bit-reproducible,
+    // unlike atomics); the ranges give the CUs equal loads and let one workgroup load while its neighbour multiplies
+    __shared__ float hs[CI * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int p0 = (blockIdx.x * 4 + wave) * 32;
+    const int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
     f32x16 acc[6];
 #pragma unroll
     for (int ct = 0; ct < 6; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
-    int offb[6];                                   // this lane's column (c, tap) of every column tile: hs offset c * LD + tap
+    // reduction index of step (q, j) in lane half hi: t = 8 q + 4 hi + j.  B = h[c, t + tap - 1] = hs[c * LD + tap + t] for the lane's
+    // column (c, tap) = 32 ct + l31 of column tile ct: one base register per tile + the immediate 8 q + j
+    const float *hb[6];
 #pragma unroll
     for (int ct = 0; ct < 6; ++ct) {
         const int kk = ct * 32 + l31;
-        offb[ct] = (kk / 3) * LD + (kk % 3);
+        hb[ct] = hs + (kk / 3) * LD + (kk % 3) + 4 * hi;
     }
     float accb = 0.0f;
-    const int nq = (T + 7) / 8;
-    for (int b = 0; b < B; ++b) {
-        __syncthreads();
-        stage_h(hs, h, b, T, LD, tid);
-        __syncthreads();
+    const int nq = (T + 7) / 8;                    // <= 16
+    zero_h(hs, tid);
+    for (int b = b0; b < b1; ++b) {
+        // this lane's row of dout: all of it is requested before h is staged, so the loads fly during the staging and the barriers
         const float *dr = dout + ((int64_t)b * M + p0 + l31) * T;
-        for (int q = 0; q < nq; ++q) {
+        float4 dv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
             const int t0 = 8 * q + 4 * hi;
-            float4 dv;
-            if (ALIGNED && t0 + 3 < T) dv = *reinterpret_cast<const float4 *>(dr + t0);
-            else dv = make_float4(t0 < T ? dr[t0] : 0.0f, t0 + 1 < T ? dr[t0 + 1] : 0.0f, t0 + 2 < T ? dr[t0 + 2] : 0.0f, t0 + 3 < T ? dr[t0 + 3] : 0.0f);
-            accb += (dv.x + dv.y) + (dv.z + dv.w);
+            if (q < nq) {
+                if (ALIGNED && t0 + 3 < T) dv[q] = *reinterpret_cast<const float4 *>(dr + t0);
+                else dv[q] = make_float4(t0 < T ? dr[t0] : 0.0f, t0 + 1 < T ? dr[t0 + 1] : 0.0f, t0 + 2 < T ? dr[t0 + 2] : 0.0f, t0 + 3 < T ? dr[t0 + 3] : 0.0f);
+            }
+        }
+        __syncthreads();
+        stage_h(hs, h, b, T, tid);
+        __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int tt = min(t0 + j, T - 1);                      // beyond T the A value is 0: any finite B value will do
-                const float av = f4c(dv, j);
+        for (int q = 0; q < 16; ++q) {
+            if (q < nq) {
+                accb += (dv[q].x + dv[q].y) + (dv[q].z + dv[q].w);
 #pragma unroll
-                for (int ct = 0; ct < 6; ++ct) acc[ct] = mfma32(av, hs[offb[ct] + tt], acc[ct]);      // h[c, tt + tap - 1]
+                for (int j = 0; j < 4; ++j) {
+                    const float av = f4c(dv[q], j);                     // 0 beyond T; the window reads zeros there
+#pragma unroll
+                    for (int ct = 0; ct < 6; ++ct) acc[ct] = mfma32(av, hb[ct][8 * q + j], acc[ct]);
+                }
             }
         }
     }
-    if (dW) {
+    // partial sums of this utterance range: [range][M][192] and, behind them, [range][M] for the bias
+    float *pw = part + (int64_t)blockIdx.y * M * KK;
 #pragma unroll
-        for (int ct = 0; ct < 6; ++ct)
+    for (int ct = 0; ct < 6; ++ct)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dW[(int64_t)(p0 + drow(r, hi)) * KK + ct * 32 + l31] = acc[ct][r];
-    }
+        for (int r = 0; r < 16; ++r) pw[(int64_t)(p0 + drow(r, hi)) * KK + ct * 32 + l31] = acc[ct][r];
     accb += __shfl_xor(accb, 32, 64);
-    if (dbias && hi == 0) dbias[p0 + l31] = accb;
+    if (hi == 0) part[(int64_t)gridDim.y * M * KK + (int64_t)blockIdx.y * M + p0 + l31] = accb;
+}
+
+// the utterance ranges added up in a fixed order: dW [M][192] and dbias [M] (either may be null)
+__global__ void __launch_bounds__(256) k_kc_dw_sum(const float *__restrict__ part, float *__restrict__ dW, float *__restrict__ dbias, int M, int ny)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, nW = (int64_t)M * KK;
+    if (idx < nW) {
+        if (!dW) return;
+        float v = 0.0f;
+        for (int y = 0; y < ny; ++y) v += part[y * nW + idx];
+        dW[idx] = v;
+    } else if (idx < nW + M) {
+        if (!dbias) return;
+        float v = 0.0f;
+        for (int y = 0; y < ny; ++y) v += part[ny * nW + (int64_t)y * M + (idx - nW)];
+        dbias[idx - nW] = v;
+    }
 }
 
 // ---- dh, first pass: workgroup = (slice of the rows p, utterance b): G_part[(c,k), t] = sum over the slice of W[p,(c,k)] dout[b,p,t];
 //      wave = one 32-column tile of t (T <= 128), all six 32-row tiles of (c,k); W and dout go through LDS 32 rows at a time ----------
 __global__ void __launch_bounds__(256, 2) k_kc_dh(const float *__restrict__ W, const float *__restrict__ dout, float *__restrict__ part,
-                                                  int B, int M, int T, int LDD, int prows)
+                                                  int B, int M, int T, int prows)
 {
-    extern __shared__ float sm[];
-    float *ws = sm, *dsm = sm + 32 * KK;
+    __shared__ __attribute__((aligned(16))) float ws[32 * KK];
+    __shared__ float dsm[32 * LDD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int ks = blockIdx.x, b = blockIdx.y, pbeg = ks * prows;
     const int tcol = wave * 32 + l31, tc = min(tcol, T - 1);
     const bool wave_live = wave * 32 < T;
+    const float *wb = ws + hi * KK + l31, *db = dsm + hi * LDD + tc;      // lane bases: every per-step offset below is an immediate
     f32x16 acc[6];
 #pragma unroll
     for (int rt = 0; rt < 6; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[rt][r] = 0.0f;
+    // 32 rows of W (6 float4 per thread) and of dout (<= 16 floats per thread) per chunk; the next chunk's loads are in flight under
+    // the current chunk's matrix work
+    float4 wv[6];
+    float dvv[16];
+    const int nd = (32 * T + 255) / 256;          // <= 16
+    auto load_chunk = [&](int pc) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) wv[k] = reinterpret_cast<const float4 *>(W + (int64_t)pc * KK)[k * 256 + tid];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int idx = k * 256 + tid;
+            if (k < nd) dvv[k] = idx < 32 * T ? dout[((int64_t)b * M + pc + idx / T) * T + idx % T] : 0.0f;
+        }
+    };
+    load_chunk(pbeg);
     for (int pc = pbeg; pc < pbeg + prows; pc += 32) {
-        __syncthreads();
-        for (int idx = tid; idx < 32 * (KK / 4); idx += 256)
-            reinterpret_cast<float4 *>(ws)[idx] = reinterpret_cast<const float4 *>(W + (int64_t)pc * KK)[idx];
-        for (int idx = tid; idx < 32 * T; idx += 256) {
-            const int row = idx / T, t = idx - row * T;
-            dsm[row * LDD + t] = dout[((int64_t)b * M + pc + row) * T + t];
+        __syncthreads();                          // the previous chunk's reads are done
+#pragma unroll
+        for (int k = 0; k < 6; ++k) reinterpret_cast<float4 *>(ws)[k * 256 + tid] = wv[k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int idx = k * 256 + tid;
+            if (k < nd && idx < 32 * T) dsm[(idx / T) * LDD + idx % T] = dvv[k];
         }
         __syncthreads();
+        if (pc + 32 < pbeg + prows) load_chunk(pc + 32);
         if (wave_live) {
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const int kp = 2 * s + hi;                               // row p of the chunk = the reduction index
-                const float bv = dsm[kp * LDD + tc];
+                const float bv = db[2 * s * LDD];                        // row p = 2 s + hi of the chunk = the reduction index
 #pragma unroll
-                for (int rt = 0; rt < 6; ++rt) acc[rt] = mfma32(ws[kp * KK + rt * 32 + l31], bv, acc[rt]);
+                for (int rt = 0; rt < 6; ++rt) acc[rt] = mfma32(wb[2 * s * KK + rt * 32], bv, acc[rt]);
             }
         }
     }
@@ -195,36 +261,54 @@ __global__ void __launch_bounds__(256) k_kc_dh_fold(const float *__restrict__ pa
 namespace fdk {
 using namespace fdk_kconv;
 
-// LDS row stride of the h window: >= T + 2 and == 3 (mod 32), so that the dW kernel's B reads -- lane = column (c, tap), address
-// c * LD + tap + t -- fall into 32 different banks (c * 3 + tap = the lane's column index)
-static int kconv_ld(int T) { return ((T + 2 + 28) / 32) * 32 + 3; }
 bool kconv_supported(int M, int T) { return M > 0 && M % 128 == 0 && T >= 1 && T <= 128; }
-size_t kconv_scratch_floats(int B, int T) { return (size_t)16 * B * KK * T; }      // the 16 row slices of the dh pass
+
+// How many ranges to cut `units` (utterances / row chunks) into when `per_range` workgroups work on each range: the CUs take the
+// workgroups in turn, so the launch lasts (workgroups per CU) x (units per range); the smallest product wins, then the fewest ranges.
+static int pick_ranges(int per_range, int units, int max_ranges, int num_cus)
+{
+    int best = 1;
+    int64_t best_cost = INT64_MAX;
+    for (int n = 1; n <= std::min(units, max_ranges); ++n) {
+        const int64_t cost = (int64_t)(((int64_t)per_range * n + num_cus - 1) / num_cus) * ((units + n - 1) / n);
+        if (cost < best_cost) { best_cost = cost; best = n; }
+    }
+    return best;
+}
+constexpr int KC_DW_RANGES = 8, KC_DH_SLICES = 64;
+// scratch: the dh pass's row slices [slices][B][192][T], then the dW pass's utterance ranges [ranges][M][192] + [ranges][M]
+size_t kconv_scratch_floats(int B, int M, int T) { return (size_t)KC_DH_SLICES * B * KK * T + (size_t)KC_DW_RANGES * M * (KK + 1); }
 
 hipError_t kconv_forward(const Launch &L, const float *h, const float *W, const float *bias, float *out, int B, int M, int T)
 {
-    const int LD = kconv_ld(T), gx = M / 128;
-    int ny = std::max(1, std::min(B, (2 * L.ctx->num_cus + gx - 1) / gx));
-    const int bchunk = (B + ny - 1) / ny;
-    ny = (B + bchunk - 1) / bchunk;
-    FD_LAUNCH(L, "kconv_forward", k_kc_fwd, dim3(gx, ny), dim3(256), sizeof(float) * CI * LD, h, W, bias, out, B, M, T, LD, bchunk);
+    const int gx = M / 128;
+    const int ny0 = pick_ranges(gx, B, 16, L.ctx->num_cus), bchunk = (B + ny0 - 1) / ny0, ny = (B + bchunk - 1) / bchunk;
+    FD_LAUNCH(L, "kconv_forward", k_kc_fwd, dim3(gx, ny), dim3(256), 0, h, W, bias, out, B, M, T, bchunk);
     return hipSuccess;
 }
 
 hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const float *dout, float *dh, float *dW, float *dbias, int B, int M,
                           int T, float *scratch)
 {
-    const int LD = kconv_ld(T);
+    float *part_h = scratch, *part_w = scratch + (size_t)KC_DH_SLICES * B * KK * T;
     if (dW || dbias) {
-        if (T % 4 == 0) FD_LAUNCH(L, "kconv_backward_w", k_kc_dw<true>, dim3(M / 128), dim3(256), sizeof(float) * CI * LD, h, dout, dW, dbias, B, M, T, LD);
-        else FD_LAUNCH(L, "kconv_backward_w", k_kc_dw<false>, dim3(M / 128), dim3(256), sizeof(float) * CI * LD, h, dout, dW, dbias, B, M, T, LD);
+        const int gx = M / 128;
+        const int ny0 = pick_ranges(gx, B, KC_DW_RANGES, L.ctx->num_cus), bchunk = (B + ny0 - 1) / ny0, ny = (B + bchunk - 1) / bchunk;
+        if (T % 4 == 0) FD_LAUNCH(L, "kconv_backward_w", k_kc_dw<true>, dim3(gx, ny), dim3(256), 0, h, dout, part_w, B, M, T, bchunk);
+        else FD_LAUNCH(L, "kconv_backward_w", k_kc_dw<false>, dim3(gx, ny), dim3(256), 0, h, dout, part_w, B, M, T, bchunk);
+        FD_LAUNCH(L, "kconv_backward_w_sum", k_kc_dw_sum, dim3((unsigned)(((int64_t)M * (KK + 1) + 255) / 256)), dim3(256), 0, (const float *)part_w, dW,
+                  dbias, M, ny);
     }
     if (dh) {
-        int nks = 16;
-        while (nks > 1 && (M % (nks * 32) != 0)) nks >>= 1;              // slices of whole 32-row chunks
-        const int LDD = T | 1;                                            // odd row stride: the staging writes spread over the banks
-        FD_LAUNCH(L, "kconv_backward_h", k_kc_dh, dim3(nks, B), dim3(256), sizeof(float) * (32 * KK + 32 * LDD), W, dout, scratch, B, M, T, LDD, M / nks);
-        FD_LAUNCH(L, "kconv_backward_h_fold", k_kc_dh_fold, dim3((B * CI * T + 255) / 256), dim3(256), 0, (const float *)scratch, dh, B, T, nks);
+        const int chunks = M / 32;                                        // slices of whole 32-row chunks, a power of two of them
+        int nks = 1;
+        int64_t best = INT64_MAX;
+        for (int n = 1; n <= KC_DH_SLICES && chunks % n == 0; n *= 2) {
+            const int64_t cost = (int64_t)(((int64_t)n * B + L.ctx->num_cus - 1) / L.ctx->num_cus) * (chunks / n);
+            if (cost < best) { best = cost; nks = n; }
+        }
+        FD_LAUNCH(L, "kconv_backward_h", k_kc_dh, dim3(nks, B), dim3(256), 0, W, dout, part_h, B, M, T, M / nks);
+        FD_LAUNCH(L, "kconv_backward_h_fold", k_kc_dh_fold, dim3((B * CI * T + 255) / 256), dim3(256), 0, (const float *)part_h, dh, B, T, nks);
     }
     return hipSuccess;
 }
