@@ -1155,6 +1155,7 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
     const long long ticket = ++h->ticket_counter;
     rc = sample_core(h, a, 0u, ticket);
     const int rc_prev = finish_prev();
+    h->last_B = B; h->last_T = T;                // (a redo of the previous call has just run with that call's shape)
     return rc != FD_OK ? rc : rc_prev;
 }
 
