@@ -73,12 +73,19 @@ def _map_noise_scale_to_time_step_loop(alpha_infer, alpha):
     return -1
 
 
+_EMBED_FREQ = {}
+
+
 def calc_diffusion_step_embedding(diffusion_steps, diffusion_step_embed_dim_in):
     """[B,1] -> [B,dim] = cat(sin(t*f), cos(t*f)), f_j = exp(-j ln(1e4)/(dim/2-1)) (util.py:407-432).
     API parity only: on the device path the embed kernel evaluates this expression itself."""
     assert diffusion_step_embed_dim_in % 2 == 0
     half = diffusion_step_embed_dim_in // 2
-    freq = torch.exp(torch.arange(half) * -(np.log(10000) / (half - 1))).to(diffusion_steps.device)
+    key = (half, diffusion_steps.device)
+    freq = _EMBED_FREQ.get(key)
+    if freq is None:      # evaluated on the CPU, as the reference does (util.py:425-427), once per device: no host-to-device copy
+        freq = torch.exp(torch.arange(half) * -(np.log(10000) / (half - 1))).to(diffusion_steps.device)      # per call, so the step can be captured in a hipGraph
+        _EMBED_FREQ[key] = freq
     arg = diffusion_steps * freq
     return torch.cat((torch.sin(arg), torch.cos(arg)), 1)
 

@@ -60,6 +60,31 @@ def main():
             print(f"  forward + backward, LVC = {name}: {timed(lambda: step(lvc)):8.2f} ms   forward only (no_grad): {timed(lambda: fwd(lvc)):8.2f} ms")
         except Exception as e:      # noqa: BLE001 -- e.g. out of memory in the unfold view's backward
             print(f"  LVC = {name}: failed: {e!r}")
+    # the same step captured once in a hipGraph (torch.cuda.graph) and replayed: what is left when the ~1500 kernel launches of a step
+    # cost no host time
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step(None)
+        torch.cuda.current_stream().wait_stream(side)
+        m.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            eps = train.differentiable_forward(m, (x, mel, steps), lvc=None)
+            loss = F.mse_loss(eps, z)
+            loss.backward()
+        graph.replay()
+        torch.cuda.synchronize()
+        g_graph = {n: p.grad.clone() for n, p in m.named_parameters()}
+        loss_graph = float(loss)
+        step(None)
+        torch.cuda.synchronize()
+        worst = max(float((g_graph[n] - p.grad).abs().max()) / max(float(p.grad.abs().max()), 1e-20) for n, p in m.named_parameters())
+        print(f"  forward + backward, LVC = HIP operator, replayed from a hipGraph: {timed(graph.replay):8.2f} ms   (loss {loss_graph:.6f}; gradients vs the eager step: max relative difference {worst:.1e})")
+    except Exception as e:      # noqa: BLE001
+        print(f"  hipGraph capture of the training step failed: {e!r}")
     for hop in (8, 64, 256):
         L = T * hop
         y = torch.randn(B, 32, L, device="cuda", requires_grad=True)
