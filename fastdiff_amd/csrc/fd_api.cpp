@@ -761,9 +761,22 @@ static hipError_t run_step(const Launch &L, const StepIO &io, int B, int T)
     fd_context *c = L.ctx;
     Workspace &ws = c->ws;
     hipError_t e;
-    if ((e = first_conv(L, io, B, T)) != hipSuccess) return e;
-    for (int d = 0; d < fd::NBLK; ++d)
-        if ((e = dblock(L, io, d, B, T)) != hipSuccess) return e;
+    // option overlap = paths: the down path (first conv, DBlocks: reads x only) on the side stream next to the predictor (front + GEMM:
+    // reads the mel only); joined before the first LVC block, which needs both
+    const bool paths = c->overlap_paths && c->side_stream && !c->overlap_gemm;
+    if (paths) {
+        if ((e = hipEventRecord(c->ev_fork, L.stream)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(c->side_stream, c->ev_fork, 0)) != hipSuccess) return e;
+        const Launch Ls = {c, c->side_stream, L.capturing};
+        if ((e = first_conv(Ls, io, B, T)) != hipSuccess) return e;
+        for (int d = 0; d < fd::NBLK; ++d)
+            if ((e = dblock(Ls, io, d, B, T)) != hipSuccess) return e;
+        if ((e = hipEventRecord(c->ev_join[0], c->side_stream)) != hipSuccess) return e;
+    } else {
+        if ((e = first_conv(L, io, B, T)) != hipSuccess) return e;
+        for (int d = 0; d < fd::NBLK; ++d)
+            if ((e = dblock(L, io, d, B, T)) != hipSuccess) return e;
+    }
     if ((e = kp_front(L, io, B, T)) != hipSuccess) return e;
     // option overlap = gemm: block 0's predicted kernels first, then [LVC block 0 || GEMM block 1] and [LVC block 1 || GEMM block 2]:
     // the matrix-bound GEMM next to the memory-bound layers instead of in front of them, and block 0's records read while fresh
@@ -780,6 +793,7 @@ static hipError_t run_step(const Launch &L, const StepIO &io, int B, int T)
             if ((e = hipEventRecord(c->ev_join[n - 1], c->side_stream)) != hipSuccess) return e;
         }
     }
+    if (paths && (e = hipStreamWaitEvent(L.stream, c->ev_join[0], 0)) != hipSuccess) return e;
     float *x = ws.a[3];
     for (int n = 0; n < fd::NBLK; ++n) {
         float *xo = nullptr;
@@ -891,7 +905,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
 static unsigned mode_signature(const fd_context *h)
 {
     unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_f16 ? 2u : 0u) | (h->lvc_f16 ? 4u : 0u) | (h->conv_f16 ? 8u : 0u) | (h->step_lens ? 16u : 0u) |
-                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u) | (h->overlap_gemm ? 128u : 0u) | ((unsigned)h->overlap_wg << 8);
+                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u) | (h->overlap_gemm ? 128u : 0u) | ((unsigned)h->overlap_wg << 8) | (h->overlap_paths ? 1024u : 0u);
     for (int i = 0; i < ST_COUNT; ++i) s = (s << 1) | (h->fast[i] ? 1u : 0u);
     return s ^ (h->fp32_mask * 2654435761u);
 }
@@ -1503,9 +1517,10 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
     }
     if (k == "fuse_final") { h->fuse_final = on; drop_graph(h); return FD_OK; }
     if (k == "overlap") {
-        if (v == "gemm") h->overlap_gemm = true;
-        else if (v == "off") h->overlap_gemm = false;
-        else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: overlap expects gemm|off, got '%s'", value);
+        if (v == "gemm") { h->overlap_gemm = true; h->overlap_paths = false; }
+        else if (v == "paths") { h->overlap_paths = true; h->overlap_gemm = false; }
+        else if (v == "off") { h->overlap_gemm = false; h->overlap_paths = false; }
+        else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: overlap expects gemm|paths|off, got '%s'", value);
         drop_graph(h);
         return FD_OK;
     }

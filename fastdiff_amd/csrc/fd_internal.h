@@ -186,6 +186,7 @@ struct fd_context {
     // option overlap = gemm: the predictor GEMM of blocks 1 and 2 runs on `side_stream` next to the LVC layers of blocks 0 and 1
     // (fork / join through events; inside a captured step the side stream joins the capture).  overlap_wg: its workgroups per CU.
     bool overlap_gemm = false;
+    bool overlap_paths = false;               // option overlap = paths: the down path next to the predictor (see run_step)
     int overlap_wg = 1;
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
