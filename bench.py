@@ -281,8 +281,27 @@ def torch_eager_baseline(mel, rows, audio_s, reps=3):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / reps * 1e3
     assert torch.isfinite(out).all()
-    return {"ms_per_step": round(ms, 3), "value": round(audio_s / (ms / 1e3), 2), "unit": "x real-time", "kind": "port",
-            "sample": "oracle/torch_eager.py, torch %s eager fp32 on this GPU, B=%d T=%d N=%d, %d repetitions" % (torch.__version__, B, T, len(rows), reps)}
+    res = {"ms_per_step": round(ms, 3), "value": round(audio_s / (ms / 1e3), 2), "unit": "x real-time", "kind": "port",
+           "sample": "oracle/torch_eager.py, torch %s eager fp32 on this GPU, B=%d T=%d N=%d, %d repetitions" % (torch.__version__, B, T, len(rows), reps)}
+    # ... and with what the reference's own code adds around the same kernels on every call: weight-norm evaluated inside every
+    # convolution, the schedule recursion and the 1000-iteration step-mapping loop per level on the host, CPU random numbers copied
+    # to the device per step (still a restatement: /root/reference cannot travel to this box)
+    from fastdiff_amd import sampler, schedules
+    m2 = EagerFastDiff(synth.synth_state_dict(1234), device=mel.device, weight_norm_each_forward=True)
+    dh = schedules.training_hyperparams()
+    sched = schedules.noise_schedule_for(len(rows))
+    with torch.no_grad():
+        m2.sample_like_the_reference(mel, dh, sched, sampler._map_noise_scale_to_time_step_loop)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out2 = m2.sample_like_the_reference(mel, dh, sched, sampler._map_noise_scale_to_time_step_loop)
+        torch.cuda.synchronize()
+        ms2 = (time.perf_counter() - t0) / reps * 1e3
+    assert torch.isfinite(out2).all()
+    res["like_the_reference"] = {"ms_per_step": round(ms2, 3), "value": round(audio_s / (ms2 / 1e3), 2), "kind": "port",
+                                 "adds": "weight-norm in every conv call, per-call schedule recursion + step-mapping loops on the host, CPU std_normal + H2D per step"}
+    return res
 
 
 def host_inclusive(model, mel, rows, lens, audio_s, reps=20):

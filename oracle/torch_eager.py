@@ -27,16 +27,24 @@ def fold(sd, name):
 
 
 class EagerFastDiff:
-    def __init__(self, state_dict, device="cpu", dtype=torch.float32):
+    def __init__(self, state_dict, device="cpu", dtype=torch.float32, weight_norm_each_forward=False):
+        """weight_norm_each_forward: keep (v, g) and evaluate w = g v / ||v|| inside every convolution call, as the reference's
+        weight-norm hooks do on every forward (FastDiff_model.py:115-122; nobody calls remove_weight_norm() at inference) -- part of
+        what running the reference's own code costs, left out of the lean restatement."""
         sd = {k: torch.as_tensor(v).to(device=device, dtype=dtype) for k, v in state_dict.items()}
         self.w = {}
+        self.vg = {}
         names = sorted({k.rsplit(".", 1)[0] for k in sd})
         for n in names:
             self.w[n] = (fold(sd, n), sd.get(n + ".bias"))
+            if weight_norm_each_forward and n + ".weight_v" in sd:
+                self.vg[n] = (sd[n + ".weight_v"], sd[n + ".weight_g"])
         self.freq = torch.exp(torch.arange(64, dtype=torch.float32) * -(math.log(10000.0) / 63)).to(device=device, dtype=dtype)
 
     def conv(self, name, x, dilation=1):
         w, b = self.w[name]
+        if name in self.vg:
+            w = torch._weight_norm(self.vg[name][0], self.vg[name][1], 0)
         return F.conv1d(x, w, b, padding=dilation * (w.shape[-1] - 1) // 2, dilation=dilation)
 
     def lin(self, name, x):
@@ -99,4 +107,30 @@ class EagerFastDiff:
             x = (x - row["c_eps"] * eps) / row["c_div"]
             if row["add_noise"]:
                 x = x + row["sigma"] * (torch.randn_like(x) if noise is None else noise[k])
+        return x
+
+    def sample_like_the_reference(self, mel, diffusion_hyperparams, inference_noise_schedule, map_step):
+        """sampling_given_noise_schedule with the host work the reference does on EVERY call and step (util.py:158-235): the
+        alpha / sigma recursion and the step mapping (map_step: its 1000-iteration Python loop per level, util.py:394-404), x_T and
+        every z drawn on the CPU and copied to the device (std_normal, util.py:63-68), the step tensor built on the CPU per step
+        (util.py:217), in-place updates.  A restatement for timing only (bench.py --torch-eager-baseline)."""
+        dev = mel.device
+        alpha = diffusion_hyperparams["alpha"]
+        beta = inference_noise_schedule.clone()
+        a2, s2 = 1 - beta, beta + 0
+        for t in range(1, len(beta)):
+            a2[t] *= a2[t - 1]
+            s2[t] *= (1 - a2[t - 1]) / (1 - a2[t])
+        alpha_hat, sigma_hat = torch.sqrt(a2), torch.sqrt(s2)
+        steps = [s for s in (map_step(a, alpha) for a in alpha_hat) if s >= 0]
+        B, L = mel.shape[0], mel.shape[-1] * 256
+        x = torch.normal(0, 1, size=(B, 1, L)).to(dev)
+        beta_d, ah_d, sh_d = beta.to(dev), alpha_hat.to(dev), sigma_hat.to(dev)
+        for n in range(len(steps) - 1, -1, -1):
+            t = (steps[n] * torch.ones((B, 1))).to(dev)
+            eps = self.forward(x, mel, t.view(-1))
+            x -= beta_d[n] / torch.sqrt(1 - ah_d[n] ** 2.) * eps
+            x /= torch.sqrt(1 - beta_d[n])
+            if n > 0:
+                x = x + sh_d[n] * torch.normal(0, 1, size=(B, 1, L)).to(dev)
         return x
