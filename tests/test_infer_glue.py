@@ -139,3 +139,33 @@ def test_copy_synthesis_from_a_recording(tmp_path):
     assert np.abs(items[0]["mel"].numpy().T - g["mel_f64"])[g["mel_f64"] > -4.0].max() < 2e-4
     pcm = infer.synthesize(model, items, n_steps=4, max_batch=4, seed=3)
     assert pcm["LJ001-0002.wav"].shape == (163 * 256,) and pcm["LJ001-0002.wav"].dtype == np.int16      # last frame dropped by the collater
+
+
+@pytest.mark.gpu
+def test_synthesize_runs_the_epilogue_again_for_a_call_that_left_the_fp16_range():
+    """infer.synthesize drives the pipelined host check (library option fallback = "host", the module's default): a micro-batch whose
+    sample call is flagged is run again on the fp32 kernels one batch later, and its int16 epilogue and copy with it.  Forced with a
+    first conv scaled by 3e4 (every DBlock / ConvTranspose / LVC launch leaves the fp16 range): the PCM must be what the in-graph
+    fallbacks give (option "graph"), host arrays and device tensors alike."""
+    import fastdiff_amd
+    import synth
+    sd = dict(synth.synth_state_dict(1234))
+    sd["first_audio_conv.weight_g"] = (sd["first_audio_conv.weight_g"] * 3.0e4).astype(np.float32)
+    rng = np.random.default_rng(5)
+    items = [{"item_name": f"u{i}", "mel": torch.from_numpy((rng.random((t, 80)) * 7.5 - 6.0).astype(np.float32)), "len": t}
+             for i, t in enumerate((9, 14, 6, 11, 7))]
+    out = {}
+    for mode in ("graph", "host"):
+        m = fastdiff_amd.FastDiff()
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+        m = m.cuda().eval()
+        m.set_option("fallback", mode)
+        out[mode] = infer.synthesize(m, items, n_steps=4, max_batch=2, seed=3)
+        if mode == "host":
+            dev = infer.synthesize(m, [dict(it, mel=it["mel"].cuda()) for it in items], n_steps=4, max_batch=2, seed=3, return_device=True)
+    for name, pcm in out["graph"].items():
+        assert pcm.dtype == np.int16 and np.abs(pcm).max() == 32767
+        # the second pass runs the flagged stages on fp32 in every step, the in-graph form per step: a last-bit difference of the
+        # waveform can move a sample by one LSB
+        assert np.abs(out["host"][name].astype(np.int32) - pcm.astype(np.int32)).max() <= 1, name
+        assert np.array_equal(dev[name].cpu().numpy(), out["host"][name]), name

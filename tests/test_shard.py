@@ -64,10 +64,18 @@ def _worker(rank, world, port, ret):
         assert sorted(i for i, _ in mine) == parts[rank]
         wavs = [(i, _stub_vocoder(m)) for i, m in mine]
         out = shard.gather_waveforms(wavs, lens, parts, hop=256, dst=0)
+        # the on-disk layout [T, 80] travels as it is (no host transposition); lengths already known to every rank
+        rows = [m.t().contiguous() for m in mels] if rank == 0 else None
+        mine2, _ = shard.scatter_utterances(rows, parts, src=0, lens=lens, frames_first=True)
+        assert [i for i, _ in mine2] == [i for i, _ in mine] and all(m.shape == (lens[i], 80) for i, m in mine2)
+        assert all(torch.equal(a.t(), b) for (_, a), (_, b) in zip(mine2, mine))
         if rank == 0:
             for i, t in enumerate(lens):
                 assert out[i].shape == (t * 256,)
                 assert torch.equal(out[i], _stub_vocoder(mels[i]))
+            msgs = shard.pack_messages(rows, parts)            # one flat buffer, one slice per rank, utterances back to back
+            assert [m.numel() for m in msgs] == [80 * sum(lens[i] for i in p) for p in parts]
+            assert torch.equal(msgs[1][: 80 * lens[parts[1][0]]].view(lens[parts[1][0]], 80), rows[parts[1][0]])
             ret.put("ok")
     finally:
         dist.destroy_process_group()
