@@ -206,7 +206,7 @@ static void free_workspace(fd_context *c)
 {
     Workspace &w = c->ws;
     void *ptrs[] = {w.noise, w.embed_h2, w.a[0], w.a[1], w.a[2], w.a[3], w.kp_h0, w.kp_hA, w.kp_hB, w.kpack, w.h_f16, w.range_flag, w.lens_dev, w.uid_dev, w.xsave, w.xA, w.xB,
-                    w.xtap[0], w.xtap[1], w.xtap[2], w.mel, w.x, w.eps_acc, w.steps, w.params};
+                    w.xtap[0], w.xtap[1], w.xtap[2], w.mel, w.mel_rep, w.x, w.eps_acc, w.steps, w.params};
     for (void *p : ptrs)
         if (p) hipFree(p);
     w = Workspace();
@@ -645,7 +645,8 @@ int fd_commit_weights(fd_handle h)
 // Buffers scale with three quantities of a call: B (per-utterance arrays), B*T (every activation, the predicted kernels) and
 // B*gx_rows(T) (the GEMM's fp16 image, padded per utterance).  Capacity is tracked in exactly those terms, so a handle that served
 // (B=64, T=864) and then meets (B=1, T=20000) needs room for max(64*864, 20000) frames -- not for 64 x 20000.
-static hipError_t allocate_workspace(fd_context *h, int64_t capB, int64_t frames, int64_t rows, size_t *total_out)
+static hipError_t allocate_workspace(fd_context *h, int64_t capB, int64_t frames, int64_t rows, int64_t pframes, int64_t prows, int64_t plens,
+                                     size_t *total_out)
 {
     Workspace &w = h->ws;
     const size_t f = sizeof(float), FL = (size_t)frames * fd::HOPT;      // FL: samples of all utterances together
@@ -662,11 +663,13 @@ static hipError_t allocate_workspace(fd_context *h, int64_t capB, int64_t frames
     WS(w.noise, (size_t)1024 * capB * fd::NBLK * fd::COND);
     WS(w.embed_h2, (size_t)std::max<int64_t>(1024, capB) * fd::E_OUT);
     WS(w.a[0], fd::C * FL); WS(w.a[1], fd::C * FL / 4); WS(w.a[2], fd::C * FL / 32); WS(w.a[3], (size_t)fd::C * frames);
-    WS(w.kp_h0, (size_t)fd::NBLK * fd::HID * frames); WS(w.kp_hA, (size_t)fd::NBLK * fd::HID * frames);
-    WS(w.kp_hB, (size_t)fd::NBLK * fd::HID * frames);
-    WS(w.kpack, (size_t)fd::NBLK * frames * fd::KREC);
-    WS(w.h_f16, (size_t)fd::NBLK * rows * 64 + 1024);      // + slack for the rounded-up last DMA
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w.lens_dev), sizeof(int) * (size_t)std::max<int64_t>(capB, 64));
+    // the predictor's buffers: their own capacities (a hoisted predictor holds N reverse steps: fd_internal.h)
+    WS(w.kp_h0, (size_t)fd::NBLK * fd::HID * pframes); WS(w.kp_hA, (size_t)fd::NBLK * fd::HID * pframes);
+    WS(w.kp_hB, (size_t)fd::NBLK * fd::HID * pframes);
+    WS(w.kpack, (size_t)fd::NBLK * pframes * fd::KREC);
+    WS(w.h_f16, (size_t)fd::NBLK * prows * 64 + 1024);      // + slack for the rounded-up last DMA
+    WS(w.mel_rep, (size_t)fd::COND * pframes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w.lens_dev), sizeof(int) * (size_t)std::max<int64_t>(plens, 64));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w.uid_dev), sizeof(unsigned long long) * (size_t)std::max<int64_t>(capB, 64));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&w.range_flag), 512);
     if (e == hipSuccess) e = hipMemset(w.range_flag, 0, 512);
@@ -680,27 +683,44 @@ static hipError_t allocate_workspace(fd_context *h, int64_t capB, int64_t frames
     return e;
 }
 
-static int ensure_workspace(fd_context *h, int B, int T)
+static bool workspace_fits(const fd_context *h, int B, int T, int pmult)
+{
+    const Workspace &w = h->ws;
+    const int64_t frames = (int64_t)B * T, rows = (int64_t)B * gx_rows_host(T);
+    return w.B >= B && w.frames >= frames && w.rows >= rows && w.params && w.pframes >= frames * pmult && w.prows >= rows * pmult &&
+           w.plens >= (int64_t)B * pmult;
+}
+
+static int ensure_workspace(fd_context *h, int B, int T, int pmult = 1)
 {
     Workspace &w = h->ws;
     const int64_t frames = (int64_t)B * T, rows = (int64_t)B * gx_rows_host(T);
-    if (w.B >= B && w.frames >= frames && w.rows >= rows && w.params) return FD_OK;
+    if (workspace_fits(h, B, T, pmult)) return FD_OK;
     FD_HIP(h, hipDeviceSynchronize());
     drop_graph(h);
     // grow to the largest of each quantity seen so far, so that alternating shapes settle; if that does not fit, this call's own
     // needs alone are tried before giving up
-    const int64_t want[2][3] = {{std::max<int64_t>(B, w.B), std::max(frames, w.frames), std::max(rows, w.rows)}, {B, frames, rows}};
+    const int64_t own[6] = {B, frames, rows, frames * pmult, rows * pmult, (int64_t)B * pmult};
+    const int64_t seen[6] = {w.B, w.frames, w.rows, w.pframes, w.prows, w.plens};
+    int64_t want[2][6];
+    bool same = true;
+    for (int i = 0; i < 6; ++i) {
+        want[0][i] = std::max(own[i], seen[i]);
+        want[1][i] = own[i];
+        same = same && want[0][i] == want[1][i];
+    }
     size_t total = 0;
     hipError_t e = hipSuccess;
     for (int attempt = 0; attempt < 2; ++attempt) {
         free_workspace(h);
-        e = allocate_workspace(h, want[attempt][0], want[attempt][1], want[attempt][2], &total);
+        e = allocate_workspace(h, want[attempt][0], want[attempt][1], want[attempt][2], want[attempt][3], want[attempt][4], want[attempt][5], &total);
         if (e == hipSuccess) {
-            w.B = (int)want[attempt][0]; w.frames = want[attempt][1]; w.rows = want[attempt][2]; w.bytes = total;
+            w.B = (int)want[attempt][0]; w.frames = want[attempt][1]; w.rows = want[attempt][2];
+            w.pframes = want[attempt][3]; w.prows = want[attempt][4]; w.plens = want[attempt][5]; w.bytes = total;
             return FD_OK;
         }
         (void)hipGetLastError();
-        if (want[0][0] == want[1][0] && want[0][1] == want[1][1] && want[0][2] == want[1][2]) break;
+        if (same) break;
     }
     free_workspace(h);
     FD_FAIL(h, FD_ERR_HIP, "workspace allocation for B=%d T=%d (%.1f MB) failed: %s", B, T, total / 1e6, hipGetErrorString(e));
@@ -777,11 +797,13 @@ static hipError_t run_step(const Launch &L, const StepIO &io, int B, int T)
         for (int d = 0; d < fd::NBLK; ++d)
             if ((e = dblock(L, io, d, B, T)) != hipSuccess) return e;
     }
-    if ((e = kp_front(L, io, B, T)) != hipSuccess) return e;
+    const bool hoisted = c->hoist_np > 1;      // the predictor of all N steps ran in front of the loop (sample_core)
+    if (!hoisted && (e = kp_front(L, io, B, T)) != hipSuccess) return e;
     // option overlap = gemm: block 0's predicted kernels first, then [LVC block 0 || GEMM block 1] and [LVC block 1 || GEMM block 2]:
     // the matrix-bound GEMM next to the memory-bound layers instead of in front of them, and block 0's records read while fresh
-    const bool overlap = c->overlap_gemm && c->fast[ST_KP_GEMM] && c->side_stream && fd_pipe(c, c->gemm_f16 && c->w.gemm_f16_ok, 0) != PIPE_F32_ONLY;
-    if (!overlap) {
+    const bool overlap = !hoisted && c->overlap_gemm && c->fast[ST_KP_GEMM] && c->side_stream && fd_pipe(c, c->gemm_f16 && c->w.gemm_f16_ok, 0) != PIPE_F32_ONLY;
+    if (hoisted) {
+    } else if (!overlap) {
         if ((e = kp_gemm(L, B, T)) != hipSuccess) return e;
     } else {
         if ((e = fast_kp_gemm(L, B, T, 0, 1, 2)) != hipSuccess) return e;        // + the fp32 fallback of all three blocks behind it
@@ -881,6 +903,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
     if (rc != FD_OK) return rc;
     if ((rc = settle(h)) != FD_OK) return rc;
     h->inline_fallback = true; h->fp32_mask = 0;      // a single forward always carries its fallbacks inline
+    h->hoist_np = 1; h->hoist_step = 0;
     if (!x || !mel || !steps || !eps_out) FD_FAIL(h, FD_ERR_INVALID, "fd_forward: null pointer");
     if (x == eps_out) FD_FAIL(h, FD_ERR_INVALID, "fd_forward: eps_out must not alias x");
     if ((rc = ensure_workspace(h, B, T)) != FD_OK) return rc;
@@ -905,7 +928,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
 static unsigned mode_signature(const fd_context *h)
 {
     unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_f16 ? 2u : 0u) | (h->lvc_f16 ? 4u : 0u) | (h->conv_f16 ? 8u : 0u) | (h->step_lens ? 16u : 0u) |
-                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u) | (h->overlap_gemm ? 128u : 0u) | ((unsigned)h->overlap_wg << 8) | (h->overlap_paths ? 1024u : 0u);
+                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u) | (h->overlap_gemm ? 128u : 0u) | ((unsigned)h->overlap_wg << 8) | (h->overlap_paths ? 1024u : 0u) | ((unsigned)h->hoist_np << 11);
     for (int i = 0; i < ST_COUNT; ++i) s = (s << 1) | (h->fast[i] ? 1u : 0u);
     return s ^ (h->fp32_mask * 2654435761u);
 }
@@ -930,10 +953,11 @@ static int enqueue_steps(fd_handle h, int B, int T, int count, unsigned fp32_mas
     h->fp32_mask = fp32_mask;
     h->inline_fallback = inline_fallback;
     StepIO io = {ws.x, ws.mel, nullptr, nullptr, 1};
-    struct Restore { fd_handle h; ~Restore() { h->fp32_mask = 0; h->inline_fallback = true; } } restore{h};
+    struct Restore { fd_handle h; ~Restore() { h->fp32_mask = 0; h->inline_fallback = true; h->hoist_step = 0; } } restore{h};
     if (!(h->use_graph && !h->profile)) {
         fdk::Launch L = {h, stream, false};
         for (int k = 0; k < count; ++k) {
+            h->hoist_step = h->hoist_np > 1 ? k : 0;
             hipError_t e = fdk::run_step(L, io, B, T);
             if (e == hipSuccess) e = fdk::advance_step(L);
             if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample: step %d failed: %s", k, hipGetErrorString(e));
@@ -962,6 +986,7 @@ static int enqueue_steps(fd_handle h, int B, int T, int count, unsigned fp32_mas
         fdk::Launch Lc = {h, h->cap_stream, true};
         hipError_t ec = hipSuccess;
         for (int k = 0; k < steps && ec == hipSuccess; ++k) {
+            h->hoist_step = h->hoist_np > 1 ? k : 0;      // (hoisted: the graph holds the whole call, so k is the call's step)
             ec = fdk::run_step(Lc, io, B, T);
             if (ec == hipSuccess) ec = fdk::advance_step(Lc);
         }
@@ -996,6 +1021,15 @@ static int enqueue_steps(fd_handle h, int B, int T, int count, unsigned fp32_mas
 }
 
 static int sample_core(fd_handle h, const fd_context::SampleArgs &a, unsigned force_mask, long long ticket);
+
+// How many reverse steps' kernels one predictor launch pair computes for this call: N (hoisted) or 1 (the predictor stays in the step)
+static int hoist_mult(const fd_context *h, int B, int T, int N)
+{
+    if (h->hoist_mode == 0 || N < 2 || N > 8) return 1;
+    if (!(h->fast[ST_KP_FRONT] && h->fast[ST_KP_GEMM] && h->fast[ST_LVC]) || h->keep_taps || h->overlap_gemm) return 1;
+    if (h->hoist_mode == 2) return N;
+    return (int64_t)B * T <= 4096 ? N : 1;        // measured at T = 864: B = 1 -7.8 %, 2 -6.2 %, 3 -4.1 %, 4 -1.9 %, 8 and 16 +-0 (profiles/r03/s20_*)
+}
 
 // fallback = host: waits for the pending piece of work, looks at its range flags and, if one was raised, runs that piece again with
 // the flagged stages on their fp32 kernels (and every other stage with its fallback inline: the second pass is always right) -- a
@@ -1081,6 +1115,24 @@ static int sample_core(fd_handle h, const fd_context::SampleArgs &a, unsigned fo
     if ((e = fdk::clear_range_flags(L)) != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample: %s", hipGetErrorString(e));
 
     constexpr int CHUNK = 8;
+    // Hoisted predictor (fd_internal.h: hoist_np): one front + GEMM launch pair over the batch of N * B (step, utterance) entries
+    h->hoist_np = hoist_mult(h, B, T, N);
+    h->hoist_step = 0;
+    if (h->hoist_np > 1) {
+        const size_t mel_n = (size_t)B * fd::COND * T;
+        for (int n = 0; n < N; ++n)
+            FD_HIP(h, hipMemcpyAsync(ws.mel_rep + n * mel_n, ws.mel, sizeof(float) * mel_n, hipMemcpyDeviceToDevice, stream));
+        if (h->step_lens)
+            for (int n = 1; n < N; ++n)
+                FD_HIP(h, hipMemcpyAsync(ws.lens_dev + n * B, ws.lens_dev, sizeof(int) * B, hipMemcpyDeviceToDevice, stream));
+        h->fp32_mask = force_mask;
+        h->inline_fallback = force_mask != 0 || !h->host_fallback;
+        StepIO iop = {ws.x, ws.mel_rep, nullptr, nullptr, 0};      // "forward" addressing: batch entry n * B + b reads noise row n * B + b
+        e = fdk::kp_front(L, iop, B * N, T);
+        if (e == hipSuccess) e = fdk::kp_gemm(L, B * N, T);
+        h->fp32_mask = 0; h->inline_fallback = true;
+        if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample: predictor launch failed: %s", hipGetErrorString(e));
+    }
     if (force_mask != 0) {
         if ((rc = enqueue_steps(h, B, T, N, force_mask, true, stream)) != FD_OK) return rc;
         FD_HIP(h, hipMemcpyAsync(a.out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
@@ -1135,8 +1187,8 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
     // A lazily checked previous call (fallback = host, <= 8 steps) is looked at AFTER this call has enqueued its own work -- unless
     // this call cannot be lazy itself, or the workspace must grow first (that waits for the device anyway).
     const bool lazy = h->host_fallback && N >= 1 && N <= 8;
-    const int64_t frames = (int64_t)B * T, rows_ = (int64_t)B * gx_rows_host(T);
-    const bool ws_ok = h->ws.B >= B && h->ws.frames >= frames && h->ws.rows >= rows_ && h->ws.params;
+    const int np = (N >= 1 && N <= 1024) ? hoist_mult(h, B, T, N) : 1;
+    const bool ws_ok = workspace_fits(h, B, T, np);
     fd_context::PendingCall prev;
     if (lazy && ws_ok && h->pending.active && h->pending.lazy) {
         prev = h->pending;
@@ -1158,7 +1210,7 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
         finish_prev();
         FD_FAIL(h, FD_ERR_INVALID, "fd_sample: fd_set_noise_streams gave %d stream ids but B=%d", (int)ids.size(), B);
     }
-    if ((rc = ensure_workspace(h, B, T)) != FD_OK) { finish_prev(); return rc; }
+    if ((rc = ensure_workspace(h, B, T, np)) != FD_OK) { finish_prev(); return rc; }
     fd_context::SampleArgs a;
     a.mel = mel; a.B = B; a.T = T; a.N = N; a.ddim = ddim;
     a.has_lens = lens != nullptr;
@@ -1516,6 +1568,13 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
         return FD_OK;
     }
     if (k == "fuse_final") { h->fuse_final = on; drop_graph(h); return FD_OK; }
+    if (k == "hoist") {
+        if (v == "auto") h->hoist_mode = 1;
+        else if (v == "on") h->hoist_mode = 2;
+        else if (v == "off") h->hoist_mode = 0;
+        else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: hoist expects auto|on|off, got '%s'", value);
+        return FD_OK;
+    }
     if (k == "overlap") {
         if (v == "gemm") { h->overlap_gemm = true; h->overlap_paths = false; }
         else if (v == "paths") { h->overlap_paths = true; h->overlap_gemm = false; }

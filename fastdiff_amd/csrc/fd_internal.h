@@ -128,6 +128,10 @@ struct Workspace {
                                 // words 64..95: OR over all steps since the last clear (what option fallback = host reads back)
     float *xA = nullptr, *xB = nullptr;                           // [B][32][L] ping-pong
     float *xtap[fd::NBLK] = {}; // block outputs kept for fd_read_tap
+    int64_t pframes = 0, prows = 0, plens = 0;   // capacity of the predictor's buffers (kp_h*, kpack, mel_rep / h_f16 / lens_dev): frames, image
+                                                 // rows and utterances x the reverse steps predicted at once (fd_context::hoist_np), tracked on
+                                                 // their own so that a large batch and a hoisted small one do not multiply
+    float *mel_rep = nullptr;   // [N][B][80][T] the mel once per reverse step: the hoisted predictor's batch
     float *mel = nullptr;       // [B][80][T] library-owned copy used by the sampler graph
     float *x = nullptr;         // [B][L] running x_t of the sampler
     float *eps_acc = nullptr;   // [B][L] final_conv sums written by the last LVC layer (k_lvc_h2 FINAL); all zero between steps
@@ -185,6 +189,13 @@ struct fd_context {
     hipStream_t cap_stream = nullptr;
     // option overlap = gemm: the predictor GEMM of blocks 1 and 2 runs on `side_stream` next to the LVC layers of blocks 0 and 1
     // (fork / join through events; inside a captured step the side stream joins the capture).  overlap_wg: its workgroups per CU.
+    // The predictor (front + GEMM) sees the mel and the step embedding only -- never x -- so for a short schedule on a small batch all N
+    // steps' kernels are predicted by ONE pair of launches in front of the loop (batch entry n * B + b = step n of utterance b): at
+    // B = 1 the front's seven-layer latency chain and the GEMM's fill are paid once per call instead of once per step.  hoist_np = N
+    // while such a call is enqueued (1 otherwise), hoist_step = the step being enqueued: the LVC layers read kpack at that offset.
+    // option "hoist" = auto (B * T <= 4096 frames, 2 <= N <= 8) | on | off
+    int hoist_mode = 1;                       // 0 off, 1 auto, 2 on
+    int hoist_np = 1, hoist_step = 0;
     bool overlap_gemm = false;
     bool overlap_paths = false;               // option overlap = paths: the down path next to the predictor (see run_step)
     int overlap_wg = 1;

@@ -2392,7 +2392,9 @@ static hipError_t launch_lvc(const Launch &L, const char *name, int n, int layer
     const DevWeights &w = c->w;
     constexpr int W = LvcCfg<HOP, DIL>::W;
     const int Ln = T * HOP;
-    const float *kp = c->ws.kpack + (int64_t)n * B * T * fd::KREC;
+    // block n's records; with a hoisted predictor (fd_internal.h) the batch behind kpack is hoist_np * B entries and this step's are
+    // the hoist_step-th B of them
+    const float *kp = c->ws.kpack + ((int64_t)n * c->hoist_np + c->hoist_step) * B * T * fd::KREC;
     const int *run_if = nullptr;
     if constexpr (HOP == 256 && DIL == 27) c->final_fused = false;
     if constexpr (HOP >= 64) {
@@ -2435,7 +2437,7 @@ hipError_t fast_lvc_layer(const Launch &L, int n, int layer, const float *x_in, 
         fd_context *c = L.ctx;
         const DevWeights &w = c->w;
         const int Ln = T * 8;
-        const float *kp = c->ws.kpack;
+        const float *kp = c->ws.kpack + (int64_t)c->hoist_step * B * T * fd::KREC;      // (block 0; hoisted predictor: this step's entries)
         const dim3 grid((Ln + 31) / 32, B);
         const Pipe pipe = fd_pipe(c, c->lvc_f16 && w.lvc_f16_ok && c->lvc_h8_mfma, 1 + layer);
         int *flag = c->ws.range_flag + 1 + layer;

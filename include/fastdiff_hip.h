@@ -207,6 +207,11 @@ FD_API int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_sa
  *          (the all-VALU fp32 kernel, which is also the fallback);
  * "fallback" = "graph" (default: every fp16x2 kernel is followed by its fp32 twin, which exits at once unless the first raised its
  *          range flag -- no host round trip, fully asynchronous) | "host" (see fd_sample_check);
+ * "hoist" = "auto" (default) | "on" | "off": the predictor (front + GEMM) sees the mel and the step embedding only, never x, so fd_sample can
+ *          predict the kernels of ALL N reverse steps with one launch pair in front of the loop (batch entry = (step, utterance)) -- at a
+ *          small batch its latency chain and fill are then paid once per call, not once per step (B = 1: -8 %); costs N x the
+ *          predicted-kernel memory.  auto: 2 <= N <= 8 and B * T <= 4096 frames;
+ * "overlap" = "off" (default) | "gemm" | "paths", "overlap_wg": measured variants of the step on two streams;
  * "taps" = "1" | "0" (keep block outputs for fd_read_tap). */
 FD_API int fd_set_option(fd_handle h, const char *key, const char *value);
 
