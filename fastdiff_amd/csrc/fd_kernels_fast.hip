@@ -92,6 +92,22 @@ __device__ __forceinline__ void split8(const float (&v)[8], float4 &hi, float4 &
 __device__ __forceinline__ float amax4(float m, const float4 &v) { return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w))); }
 // byte offset of 16 B slot `slot` (piece*4 + channel/8) of row `row` in a [row][128 B] piece image
 __device__ __forceinline__ int h2_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+// 8 channels (image slot `slot`, 0..3) of one conv tap at image row `row`: the products the matrix pipe forms for the other
+// columns -- a1 += w1.x1, a2 += w1.x2 + w2.x1, fp32 accumulation -- on v_dot2_f32_f16.  w1/w2 = the weight pieces of those channels.
+__device__ __forceinline__ void halo_dot(const char *xs, int row, int slot, const float4 &w1f, const float4 &w2f, float &a1, float &a2)
+{
+    union { float4 f; h2_t h[4]; } x1, x2, w1, w2;
+    x1.f = *reinterpret_cast<const float4 *>(xs + h2_off(row, slot));
+    x2.f = *reinterpret_cast<const float4 *>(xs + h2_off(row, 4 + slot));
+    w1.f = w1f;
+    w2.f = w2f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        a1 = __builtin_amdgcn_fdot2(w1.h[q], x1.h[q], a1, false);
+        a2 = __builtin_amdgcn_fdot2(w1.h[q], x2.h[q], a2, false);
+        a2 = __builtin_amdgcn_fdot2(w2.h[q], x1.h[q], a2, false);
+    }
+}
 
 
 // =================================================================================================
@@ -1273,6 +1289,12 @@ struct LvcCfg {
 __device__ long long fd_dbg[64 * 4 * 8];
 #define FD_STAMP(i) do { if (lane == 0 && blockIdx.y == FD_LVC_TIMING && blockIdx.x >= 100 && blockIdx.x < 164) \
         fd_dbg[((blockIdx.x - 100) * 4 + wave) * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#elif defined(FD_LVC_TIMELINE)
+// every workgroup's wave 0: s_memrealtime at each phase boundary + where it ran (tools/ubench/lvc_h2_timeline.hip)
+__device__ long long *fd_tl;
+#define FD_STAMP(i) do { if (threadIdx.x == 0) { long long *q_ = fd_tl + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 10; \
+        q_[i] = (long long)__builtin_amdgcn_s_memrealtime(); \
+        if ((i) == 0) { q_[8] = __builtin_amdgcn_s_getreg(63492); q_[9] = __builtin_amdgcn_s_getreg(63508); } } } while (0)
 #else
 #define FD_STAMP(i)
 #endif
@@ -1582,6 +1604,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
     float4 cb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) cb[j] = reinterpret_cast<const float4 *>(cbias)[2 * j + hi];
+    const float hbias = cbias[l31];          // for the halo outputs
 
     // ---- stage x + skip.  Centre: wave = channel group of 8, lane = 4 columns, so that one column of a thread is one 16 B
     //      slot per piece.  Halo (2H columns): wave = channel group, lane = one column.  Every wave does the same work. --------
@@ -1637,7 +1660,6 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
         }
     }
     if constexpr (HOP != 256) load_kernel(0);
-    const int hside = tid >> 7, ho = (tid & 127) >> 2, hq = tid & 3;
     __syncthreads();
     FD_STAMP(1);
     // residual values of this lane's outputs: registers, so that ys can take the conv output
@@ -1655,11 +1677,6 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
     }
     FD_STAMP(2);
 
-    // conv weights of the halo outputs (L2), requested ahead of the conv that hides their latency
-    float4 hwt[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) hwt[j] = reinterpret_cast<const float4 *>(wref + (ho * fd::C + 8 * hq) * 3)[j];
-    const float hbias = cbias[ho];
     // ---- dilated conv on the fp16 pipe; y = lrelu(conv) is split again and written as the B image of the LVC -------------
     if (wave_valid) {
         int xo_[3][2][2];
@@ -1708,34 +1725,28 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
     }
     if constexpr (HOP != 256) load_kernel(1);
     FD_STAMP(3);
-    // ---- the two halo columns (-1 and W) the LVC taps reach: VALU on the reassembled x, 4 threads per output ----------------
-    {
-        const int c = hside ? W : -1, g = w0 + c;
+    // ---- the two halo columns (-1 and W) the LVC taps reach, on VALU: waves 0 and 1, one column each.  The weights are the conv's
+    //      A operand registers: lane (row l31, half hi) holds, per k group, channels 16 (kg & 1) + 8 hi .. + 7 of tap kg / 2 of
+    //      output l31.  Three forms were timed in one session (hop 256 / hop 64, us, B=8, T=864): 24 fp32 FMAs per thread on
+    //      weights loaded for the purpose 254.1 / 78.3, this one 250.4 / 74.1, two more conv tiles on the matrix pipe 250.9 / 76.9
+    //      (profiles/r03_halo_ab.txt) ---------------------------------------------------------------------------------------
+    if (wave < 2) {
+        const int c = wave ? W : -1, g = w0 + c;
         const bool ok = g >= 0 && g < Lnb;
-        float accv = 0.0f;
+        float a1 = 0.0f, a2 = 0.0f;
         if (ok) {
-            const float wv[24] = {hwt[0].x, hwt[0].y, hwt[0].z, hwt[0].w, hwt[1].x, hwt[1].y, hwt[1].z, hwt[1].w,
-                                  hwt[2].x, hwt[2].y, hwt[2].z, hwt[2].w, hwt[3].x, hwt[3].y, hwt[3].z, hwt[3].w,
-                                  hwt[4].x, hwt[4].y, hwt[4].z, hwt[4].w, hwt[5].x, hwt[5].y, hwt[5].z, hwt[5].w};
 #pragma unroll
-            for (int tap = 0; tap < 3; ++tap) {
-                const int row = H + c + (tap - 1) * DIL;
-                union { float4 f; _Float16 h[8]; } p1, p2;
-                p1.f = *reinterpret_cast<const float4 *>(xs + h2_off(row, hq));
-                p2.f = *reinterpret_cast<const float4 *>(xs + h2_off(row, 4 + hq));
-#pragma unroll
-                for (int j = 0; j < 8; ++j) accv += wv[j * 3 + tap] * fmaf((float)p2.h[j], GX_INV_SCALE, (float)p1.h[j]);
-            }
+            for (int kg = 0; kg < 6; ++kg) halo_dot(xs, H + c + ((kg >> 1) - 1) * DIL, (kg & 1) * 2 + hi, wa[0][kg], wa[1][kg], a1, a2);
         }
-        accv += __shfl_xor(accv, 1, 64);
-        accv += __shfl_xor(accv, 2, 64);
-        if (hq == 0) {
+        float accv = fmaf(a2, GX_INV_SCALE, a1);
+        accv += __shfl_xor(accv, 32, 64);
+        if (hi == 0) {
             const float v = ok ? lrelu(accv + hbias, 0.2f) : 0.0f;
             mx = fmaxf(mx, fabsf(v));
             const _Float16 v1 = (_Float16)v, v2 = (_Float16)((v - (float)v1) * GX_SCALE);
             const int yrow = c + 1;
-            *reinterpret_cast<_Float16 *>(ys + h2_off(yrow, ho >> 3) + (ho & 7) * 2) = v1;
-            *reinterpret_cast<_Float16 *>(ys + h2_off(yrow, 4 + (ho >> 3)) + (ho & 7) * 2) = v2;
+            *reinterpret_cast<_Float16 *>(ys + h2_off(yrow, l31 >> 3) + (l31 & 7) * 2) = v1;
+            *reinterpret_cast<_Float16 *>(ys + h2_off(yrow, 4 + (l31 >> 3)) + (l31 & 7) * 2) = v2;
         }
     }
     FD_STAMP(4);
