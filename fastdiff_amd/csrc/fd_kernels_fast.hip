@@ -1583,7 +1583,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
     float4 ka[LT][12];
     float4 bz[LT][4];
     auto load_kernel = [&](int m) {
-        if (wave_valid) {
+        if (HOP == 256 || wave_valid) {      // hop 256: utterance lengths are whole tiles, every wave of a live workgroup is valid
             const int f = (w0 + lcw) / HOP;
             const float *rec = kpack + ((int64_t)b * T + f) * fd::KREC;
             const float4 *kp4 = reinterpret_cast<const float4 *>(rec + layer * fd::KLAYER) + 2 * lane;
@@ -1594,7 +1594,9 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
             for (int j = 0; j < 4; ++j) bz[m][j] = kb4[(mt0 + m) * 8 + 2 * j + hi];
         }
     };
+#ifndef FD_LVC_LATE_KERNEL
     if constexpr (HOP == 256) load_kernel(0);
+#endif
     // conv weights: A operand pieces [piece][kg][lane] x 8 fp16, k = 16*kg + 8*hi + e = tap*32 + in
     float4 wa[2][6];
 #pragma unroll
@@ -1605,6 +1607,15 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
 #pragma unroll
     for (int j = 0; j < 4; ++j) cb[j] = reinterpret_cast<const float4 *>(cbias)[2 * j + hi];
     const float hbias = cbias[l31];          // for the halo outputs
+#ifdef FD_LVC_PAD_LOADS     // probe (tools/ubench): is the layer bound by the CU's memory pipe?  N extra 16 B loads per lane (L2 hits)
+    {
+        float4 pad_[FD_LVC_PAD_LOADS];
+#pragma unroll
+        for (int i_ = 0; i_ < FD_LVC_PAD_LOADS; ++i_) pad_[i_] = wpack16[(i_ % 12) * 64 + lane];
+#pragma unroll
+        for (int i_ = 0; i_ < FD_LVC_PAD_LOADS; ++i_) mx = fmaxf(mx, fminf(pad_[i_].x, 0.0f) * 1e-30f);
+    }
+#endif
 
     // ---- stage x + skip.  Centre: wave = channel group of 8, lane = 4 columns, so that one column of a thread is one 16 B
     //      slot per piece.  Halo (2H columns): wave = channel group, lane = one column.  Every wave does the same work. --------
@@ -1626,6 +1637,10 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
             hx[c] = hok ? xr[(int64_t)c * Ln + hg] : 0.0f;
             hs[c] = hok ? sr[(int64_t)c * Ln + hg] : 0.0f;
         }
+#ifdef FD_LVC_LATE_KERNEL
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (HOP == 256) load_kernel(0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -1777,6 +1792,14 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
         const int64_t ooff = (int64_t)b * fd::C * Ln + (int64_t)(4 * hi) * Ln + w0 + lcw + l31;    // + channel*Ln + nt*32
         float *xo = xout + ooff;
         FD_STAMP(6);
+#ifdef FD_LVC_PAD_VALU     // probe (tools/ubench): is the layer bound by instruction issue?  N extra independent VALU instructions here
+        {
+            float pad_ = mx;
+#pragma unroll
+            for (int i_ = 0; i_ < FD_LVC_PAD_VALU; ++i_) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(pad_));
+            mx = fminf(mx, pad_ * 0.0f + mx);
+        }
+#endif
         const unsigned Lnu = (unsigned)Ln;
 #pragma unroll
         for (int nt = 0; nt < LN; ++nt) {
