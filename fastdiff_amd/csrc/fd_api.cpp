@@ -784,6 +784,14 @@ static hipError_t run_step(const Launch &L, const StepIO &io, int B, int T)
     // option overlap = paths: the down path (first conv, DBlocks: reads x only) on the side stream next to the predictor (front + GEMM:
     // reads the mel only); joined before the first LVC block, which needs both
     const bool paths = c->overlap_paths && c->side_stream && !c->overlap_gemm;
+    const bool hoisted = c->hoist_np > 1;      // the predictor of all N steps ran in front of the loop (sample_core)
+    // option order = predictor: the predictor first, so that the GEMM's 2 GB of dirty lines drain under the down path and not under
+    // the first LVC layers
+    const bool pfirst = c->predictor_first && !hoisted && !c->overlap_gemm && !c->overlap_paths;
+    if (pfirst) {
+        if ((e = kp_front(L, io, B, T)) != hipSuccess) return e;
+        if ((e = kp_gemm(L, B, T)) != hipSuccess) return e;
+    }
     if (paths) {
         if ((e = hipEventRecord(c->ev_fork, L.stream)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(c->side_stream, c->ev_fork, 0)) != hipSuccess) return e;
@@ -797,12 +805,11 @@ static hipError_t run_step(const Launch &L, const StepIO &io, int B, int T)
         for (int d = 0; d < fd::NBLK; ++d)
             if ((e = dblock(L, io, d, B, T)) != hipSuccess) return e;
     }
-    const bool hoisted = c->hoist_np > 1;      // the predictor of all N steps ran in front of the loop (sample_core)
-    if (!hoisted && (e = kp_front(L, io, B, T)) != hipSuccess) return e;
+    if (!hoisted && !pfirst && (e = kp_front(L, io, B, T)) != hipSuccess) return e;
     // option overlap = gemm: block 0's predicted kernels first, then [LVC block 0 || GEMM block 1] and [LVC block 1 || GEMM block 2]:
     // the matrix-bound GEMM next to the memory-bound layers instead of in front of them, and block 0's records read while fresh
     const bool overlap = !hoisted && c->overlap_gemm && c->fast[ST_KP_GEMM] && c->side_stream && fd_pipe(c, c->gemm_f16 && c->w.gemm_f16_ok, 0) != PIPE_F32_ONLY;
-    if (hoisted) {
+    if (hoisted || pfirst) {
     } else if (!overlap) {
         if ((e = kp_gemm(L, B, T)) != hipSuccess) return e;
     } else {
@@ -928,7 +935,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
 static unsigned mode_signature(const fd_context *h)
 {
     unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_f16 ? 2u : 0u) | (h->lvc_f16 ? 4u : 0u) | (h->conv_f16 ? 8u : 0u) | (h->step_lens ? 16u : 0u) |
-                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u) | (h->overlap_gemm ? 128u : 0u) | ((unsigned)h->overlap_wg << 8) | (h->overlap_paths ? 1024u : 0u) | ((unsigned)h->hoist_np << 11);
+                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u) | (h->overlap_gemm ? 128u : 0u) | ((unsigned)h->overlap_wg << 8) | (h->overlap_paths ? 1024u : 0u) | ((unsigned)h->hoist_np << 11) | (h->predictor_first ? (1u << 20) : 0u);
     for (int i = 0; i < ST_COUNT; ++i) s = (s << 1) | (h->fast[i] ? 1u : 0u);
     return s ^ (h->fp32_mask * 2654435761u);
 }
@@ -1580,6 +1587,13 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
         else if (v == "paths") { h->overlap_paths = true; h->overlap_gemm = false; }
         else if (v == "off") { h->overlap_gemm = false; h->overlap_paths = false; }
         else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: overlap expects gemm|paths|off, got '%s'", value);
+        drop_graph(h);
+        return FD_OK;
+    }
+    if (k == "order") {
+        if (v == "predictor") h->predictor_first = true;
+        else if (v == "down") h->predictor_first = false;
+        else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: order expects predictor|down, got '%s'", value);
         drop_graph(h);
         return FD_OK;
     }

@@ -199,6 +199,7 @@ struct fd_context {
     bool overlap_gemm = false;
     bool overlap_paths = false;               // option overlap = paths: the down path next to the predictor (see run_step)
     int overlap_wg = 1;
+    bool predictor_first = false;             // option order = down (default) | predictor: front + GEMM behind the down path or in front of it
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     // captured denoiser steps, one per (B, T, mode): micro-batches of different padded length alternate without re-capturing

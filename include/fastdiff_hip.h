@@ -212,6 +212,8 @@ FD_API int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_sa
  *          small batch its latency chain and fill are then paid once per call, not once per step (B = 1: -8 %); costs N x the
  *          predicted-kernel memory.  auto: 2 <= N <= 8 and B * T <= 4096 frames;
  * "overlap" = "off" (default) | "gemm" | "paths", "overlap_wg": measured variants of the step on two streams;
+ * "order" = "down" (default: the reference's order of statements) | "predictor" (front + GEMM first, so that the GEMM's 2 GB of
+ *          stores drain under the DBlocks and not under the first LVC layers; same bits, measured +-0: INTEGRATION.md);
  * "taps" = "1" | "0" (keep block outputs for fd_read_tap). */
 FD_API int fd_set_option(fd_handle h, const char *key, const char *value);
 
