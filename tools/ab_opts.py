@@ -1,7 +1,10 @@
 """A/B of library options inside ONE process and ONE GPU session (box-to-box variation is +-4 %, in-session +-0.3 %):
     python tools/ab_opts.py [--batch 8] [--frames 864] [--nsteps 4] [--reps 3] [--steps 20] "" "overlap=gemm" "overlap=gemm,overlap_wg=2" ...
 Every argument is one configuration ("k=v,k=v"; "" = defaults).  The configurations are timed in turn, `reps` times round-robin, on the
-same model and the same mel (HBM-resident in and out, like bench.py's `value`); printed: ms per sample call, per round and the mean."""
+same model and the same mel (HBM-resident in and out, like bench.py's `value`); printed: ms per sample call, per round and the mean.
+Every configuration is its own model instance with its own workspace, and two instances of the SAME configuration can differ by ~1.4 %
+(where their buffers landed): list a configuration twice, alternating with the other, before believing a difference of that size
+(profiles/r03/s31_order.txt)."""
 import argparse
 import os
 import sys
