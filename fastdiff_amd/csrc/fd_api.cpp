@@ -910,7 +910,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
     if (rc != FD_OK) return rc;
     if ((rc = settle(h)) != FD_OK) return rc;
     h->inline_fallback = true; h->fp32_mask = 0;      // a single forward always carries its fallbacks inline
-    h->hoist_np = 1; h->hoist_step = 0;
+    h->hoist_np = 1; h->hoist_step = 0; h->hoist_chunk = false;
     if (!x || !mel || !steps || !eps_out) FD_FAIL(h, FD_ERR_INVALID, "fd_forward: null pointer");
     if (x == eps_out) FD_FAIL(h, FD_ERR_INVALID, "fd_forward: eps_out must not alias x");
     if ((rc = ensure_workspace(h, B, T)) != FD_OK) return rc;
@@ -935,7 +935,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
 static unsigned mode_signature(const fd_context *h)
 {
     unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_f16 ? 2u : 0u) | (h->lvc_f16 ? 4u : 0u) | (h->conv_f16 ? 8u : 0u) | (h->step_lens ? 16u : 0u) |
-                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u) | (h->overlap_gemm ? 128u : 0u) | ((unsigned)h->overlap_wg << 8) | (h->overlap_paths ? 1024u : 0u) | ((unsigned)h->hoist_np << 11) | (h->predictor_first ? (1u << 20) : 0u);
+                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u) | (h->overlap_gemm ? 128u : 0u) | ((unsigned)h->overlap_wg << 8) | (h->overlap_paths ? 1024u : 0u) | ((unsigned)h->hoist_np << 11) | (h->predictor_first ? (1u << 20) : 0u) | (h->hoist_chunk ? (1u << 21) : 0u);
     for (int i = 0; i < ST_COUNT; ++i) s = (s << 1) | (h->fast[i] ? 1u : 0u);
     return s ^ (h->fp32_mask * 2654435761u);
 }
@@ -960,11 +960,25 @@ static int enqueue_steps(fd_handle h, int B, int T, int count, unsigned fp32_mas
     h->fp32_mask = fp32_mask;
     h->inline_fallback = inline_fallback;
     StepIO io = {ws.x, ws.mel, nullptr, nullptr, 1};
-    struct Restore { fd_handle h; ~Restore() { h->fp32_mask = 0; h->inline_fallback = true; h->hoist_step = 0; } } restore{h};
+    struct Restore { fd_handle h; ~Restore() { h->fp32_mask = 0; h->inline_fallback = true; h->hoist_step = 0; if (h->hoist_chunk) h->hoist_np = 1; } } restore{h};
+    constexpr int CHUNK = 8;
+    // hoist_chunk: the predictor of an np-step piece in front of it, over np * B (step, utterance) entries; the steps then skip theirs
+    auto piece_predictor = [&](const fdk::Launch &L, int np) -> hipError_t {
+        h->hoist_np = np;
+        if (np < 2) return hipSuccess;
+        StepIO iop = {ws.x, ws.mel_rep, nullptr, nullptr, np};
+        hipError_t e = fdk::kp_front(L, iop, B * np, T);
+        return e == hipSuccess ? fdk::kp_gemm(L, B * np, T) : e;
+    };
+    if (h->hoist_chunk) h->hoist_np = 1;          // (the signature below must not depend on the piece that ran last)
     if (!(h->use_graph && !h->profile)) {
         fdk::Launch L = {h, stream, false};
         for (int k = 0; k < count; ++k) {
-            h->hoist_step = h->hoist_np > 1 ? k : 0;
+            if (h->hoist_chunk && k % CHUNK == 0) {
+                hipError_t e = piece_predictor(L, std::min(CHUNK, count - k));
+                if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample: predictor launch failed: %s", hipGetErrorString(e));
+            }
+            h->hoist_step = h->hoist_np > 1 ? (h->hoist_chunk ? k % CHUNK : k) : 0;
             hipError_t e = fdk::run_step(L, io, B, T);
             if (e == hipSuccess) e = fdk::advance_step(L);
             if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample: step %d failed: %s", k, hipGetErrorString(e));
@@ -991,9 +1005,9 @@ static int enqueue_steps(fd_handle h, int B, int T, int count, unsigned fp32_mas
         }
         FD_HIP(h, hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
         fdk::Launch Lc = {h, h->cap_stream, true};
-        hipError_t ec = hipSuccess;
+        hipError_t ec = h->hoist_chunk ? piece_predictor(Lc, steps) : hipSuccess;
         for (int k = 0; k < steps && ec == hipSuccess; ++k) {
-            h->hoist_step = h->hoist_np > 1 ? k : 0;      // (hoisted: the graph holds the whole call, so k is the call's step)
+            h->hoist_step = h->hoist_np > 1 ? k : 0;      // (hoisted: the graph holds the whole call or piece, so k is its step)
             ec = fdk::run_step(Lc, io, B, T);
             if (ec == hipSuccess) ec = fdk::advance_step(Lc);
         }
@@ -1013,7 +1027,6 @@ static int enqueue_steps(fd_handle h, int B, int T, int count, unsigned fp32_mas
         *out = ex;
         return FD_OK;
     };
-    constexpr int CHUNK = 8;
     int rc;
     hipGraphExec_t g_chunk = nullptr, g_rest = nullptr;
     if (count >= CHUNK && (rc = graph_of(CHUNK, &g_chunk)) != FD_OK) return rc;
@@ -1032,10 +1045,11 @@ static int sample_core(fd_handle h, const fd_context::SampleArgs &a, unsigned fo
 // How many reverse steps' kernels one predictor launch pair computes for this call: N (hoisted) or 1 (the predictor stays in the step)
 static int hoist_mult(const fd_context *h, int B, int T, int N)
 {
-    if (h->hoist_mode == 0 || N < 2 || N > 8) return 1;
+    if (h->hoist_mode == 0 || N < 2) return 1;
     if (!(h->fast[ST_KP_FRONT] && h->fast[ST_KP_GEMM] && h->fast[ST_LVC]) || h->keep_taps || h->overlap_gemm) return 1;
-    if (h->hoist_mode == 2) return N;
-    return (int64_t)B * T <= 4096 ? N : 1;        // measured at T = 864: B = 1 -7.8 %, 2 -6.2 %, 3 -4.1 %, 4 -1.9 %, 8 and 16 +-0 (profiles/r03/s20_*)
+    const int np = std::min(N, 8);             // a longer schedule hoists per 8-step graph piece (fd_context::hoist_chunk)
+    if (h->hoist_mode == 2) return np;
+    return (int64_t)B * T <= 4096 ? np : 1;        // measured at T = 864: B = 1 -7.8 %, 2 -6.2 %, 3 -4.1 %, 4 -1.9 %, 8 and 16 +-0 (profiles/r03/s20_*)
 }
 
 // fallback = host: waits for the pending piece of work, looks at its range flags and, if one was raised, runs that piece again with
@@ -1125,13 +1139,17 @@ static int sample_core(fd_handle h, const fd_context::SampleArgs &a, unsigned fo
     // Hoisted predictor (fd_internal.h: hoist_np): one front + GEMM launch pair over the batch of N * B (step, utterance) entries
     h->hoist_np = hoist_mult(h, B, T, N);
     h->hoist_step = 0;
+    h->hoist_chunk = h->hoist_np > 1 && N > CHUNK;
     if (h->hoist_np > 1) {
         const size_t mel_n = (size_t)B * fd::COND * T;
-        for (int n = 0; n < N; ++n)
+        for (int n = 0; n < h->hoist_np; ++n)
             FD_HIP(h, hipMemcpyAsync(ws.mel_rep + n * mel_n, ws.mel, sizeof(float) * mel_n, hipMemcpyDeviceToDevice, stream));
         if (h->step_lens)
-            for (int n = 1; n < N; ++n)
+            for (int n = 1; n < h->hoist_np; ++n)
                 FD_HIP(h, hipMemcpyAsync(ws.lens_dev + n * B, ws.lens_dev, sizeof(int) * B, hipMemcpyDeviceToDevice, stream));
+    }
+    if (h->hoist_chunk) h->hoist_np = 1;          // enqueue_steps sets it piece by piece
+    else if (h->hoist_np > 1) {
         h->fp32_mask = force_mask;
         h->inline_fallback = force_mask != 0 || !h->host_fallback;
         StepIO iop = {ws.x, ws.mel_rep, nullptr, nullptr, 0};      // "forward" addressing: batch entry n * B + b reads noise row n * B + b

@@ -193,9 +193,12 @@ struct fd_context {
     // steps' kernels are predicted by ONE pair of launches in front of the loop (batch entry n * B + b = step n of utterance b): at
     // B = 1 the front's seven-layer latency chain and the GEMM's fill are paid once per call instead of once per step.  hoist_np = N
     // while such a call is enqueued (1 otherwise), hoist_step = the step being enqueued: the LVC layers read kpack at that offset.
-    // option "hoist" = auto (B * T <= 4096 frames, 2 <= N <= 8) | on | off
+    // A longer schedule does the same per captured piece of 8 steps (hoist_chunk): the piece's graph starts with the predictor of its
+    // own steps (rows step_idx .. step_idx + 7 of the embedding table, read through the device step counter).
+    // option "hoist" = auto (B * T <= 4096 frames, N >= 2) | on | off
     int hoist_mode = 1;                       // 0 off, 1 auto, 2 on
     int hoist_np = 1, hoist_step = 0;
+    bool hoist_chunk = false;                 // a long schedule (N > 8): the predictor of each 8-step graph piece is hoisted to the piece's front
     bool overlap_gemm = false;
     bool overlap_paths = false;               // option overlap = paths: the down path next to the predictor (see run_step)
     int overlap_wg = 1;

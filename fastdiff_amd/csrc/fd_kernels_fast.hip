@@ -440,8 +440,10 @@ __global__ void __launch_bounds__(256, 2) k_kp_front(const float *__restrict__ m
     if (t0 >= Tb) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int mt = wave & 1, nt = wave >> 1;
+    // sampler = 0: batch entry b reads row b (fd_forward; a hoisted whole call: row = step * B' + utterance already);  1: row
+    // step_idx * B + b;  np >= 2 (the predictor of an np-step piece of a long schedule, B = np * B' entries): step_idx * B' + b
     const int step = sampler ? params->step_idx : 0;
-    const float *nz = noise + (((int64_t)step * B + b) * fd::NBLK + blk) * fd::COND;
+    const float *nz = noise + (((int64_t)step * (sampler > 1 ? B / sampler : B) + b) * fd::NBLK + blk) * fd::COND;
     {   // stage mel + noise (loads batched), zero the guard columns of the activation buffers
         constexpr int TOTAL = fd::COND * KPF_LDI, NK = (TOTAL + 255) / 256;
         float v[NK];
@@ -548,8 +550,10 @@ __global__ void __launch_bounds__(256, 2) k_kp_front_h2(const float *__restrict_
     if (t0 > Tb) return;      // the tile holding frame Tb still runs: it writes the zero row the GEMM reads behind the utterance
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int mt = wave & 1, nt = wave >> 1;
+    // sampler = 0: batch entry b reads row b (fd_forward; a hoisted whole call: row = step * B' + utterance already);  1: row
+    // step_idx * B + b;  np >= 2 (the predictor of an np-step piece of a long schedule, B = np * B' entries): step_idx * B' + b
     const int step = sampler ? params->step_idx : 0;
-    const float *nz = noise + (((int64_t)step * B + b) * fd::NBLK + blk) * fd::COND;
+    const float *nz = noise + (((int64_t)step * (sampler > 1 ? B / sampler : B) + b) * fd::NBLK + blk) * fd::COND;
     float mx = 0.0f;
     {   // stage mel + noise: thread = (8-channel group of 10, column of 68) = 680 units; padding stays zero (modules.py:203)
         const float *src = mel + (int64_t)b * fd::COND * T;

@@ -210,7 +210,8 @@ FD_API int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_sa
  * "hoist" = "auto" (default) | "on" | "off": the predictor (front + GEMM) sees the mel and the step embedding only, never x, so fd_sample can
  *          predict the kernels of ALL N reverse steps with one launch pair in front of the loop (batch entry = (step, utterance)) -- at a
  *          small batch its latency chain and fill are then paid once per call, not once per step (B = 1: -8 %); costs N x the
- *          predicted-kernel memory.  auto: 2 <= N <= 8 and B * T <= 4096 frames;
+ *          predicted-kernel memory.  A schedule of more than 8 steps does it per captured 8-step piece (N = 1000 at B = 1: -8 %).
+ *          auto: N >= 2 and B * T <= 4096 frames;
  * "overlap" = "off" (default) | "gemm" | "paths", "overlap_wg": measured variants of the step on two streams;
  * "order" = "down" (default: the reference's order of statements) | "predictor" (front + GEMM first, so that the GEMM's 2 GB of
  *          stores drain under the DBlocks and not under the first LVC layers; same bits, measured +-0: INTEGRATION.md);

@@ -583,6 +583,37 @@ def test_host_checked_fallback_long_schedule(gc, sched):
     assert torch.equal(a[1], b[1])                                     # before anything overflows the two modes run the same kernels
 
 
+@pytest.mark.parametrize("N", [4, 19])
+def test_hoisted_predictor_equals_the_per_step_one(gc, sched, N):
+    """The predictor never sees x, so fd_sample runs it for all reverse steps of a short schedule at once (N <= 8), and for a longer
+    one at the front of every captured 8-step piece (N = 19: pieces of 8, 8 and 3 steps, rows step_idx .. of the embedding table read
+    through the device step counter).  Same kernels on the same operands as the per-step predictor (option hoist = off): the
+    same bits, on a ragged batch, from the graph and launched one by one."""
+    import synth
+    B, T = 3, 37
+    lens = [37, 12, 25]
+    mel = torch.from_numpy(synth.synth_mel(77, B, T)).cuda()
+    for b, t in enumerate(lens):
+        mel[b, :, t:] = 0.0
+    rows = [{"t": 190.0 - 9.5 * k, "c_eps": 0.02, "c_div": 0.99, "sigma": 0.05, "c1": 1.0, "c2": 0.0, "c3": 0.0, "add_noise": int(k < N - 1)}
+            for k in range(N)]
+    out = {}
+    with torch.no_grad():
+        for hoist in ("on", "off"):
+            for graph in ("1", "0"):
+                m = gc.make_model()
+                m.set_option("hoist", hoist)
+                m.set_option("graph", graph)
+                y = m.sample(mel, rows, seed=5, lens=lens)
+                y2 = m.sample(mel, rows, seed=5, lens=lens)          # (second call: cached graphs, workspace already sized)
+                assert torch.equal(y, y2), (hoist, graph)
+                out[(hoist, graph)] = y
+    ref = out[("off", "0")]
+    assert torch.isfinite(ref).all() and float(ref.abs().max()) > 0.1
+    for k, y in out.items():
+        assert torch.equal(y, ref), k
+
+
 def test_graph_cache_alternating_shapes(gc, sched):
     """One captured step per (B, T, mode) is kept (micro-batches of different padded length alternate in infer.py): results with
     the cache warm, after other shapes ran in between, and after more shapes than the cache holds (eviction) must equal the
