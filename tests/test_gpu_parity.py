@@ -402,6 +402,44 @@ def test_forward_ragged_sizes_against_oracle(model, gc, oracle64, B, T):
     assert gc.maxdiff(y, y_ref) < FWD_TOL
 
 
+def test_random_shapes_default_pipe_against_fp32_pipe(gc):
+    """A sweep over shapes nobody picked by hand: 64 seeded draws of (B, T, lens, N) -- one frame, tile edges (T * hop around 64,
+    128, 256 columns), ragged batches, schedules that are one graph, whole 8-step pieces and pieces with a remainder, with and
+    without the hoisted predictor -- each sampled on the default pipe (2-piece fp16 operands, hoisting, host-checked range) and on
+    the exact-fp32 kernels (themselves held against the float64 oracle above), same seed and noise.  Bar: the N-step loop tolerance."""
+    import synth
+    rng = np.random.RandomState(20240917)
+    fast, exact = gc.make_model(), gc.make_model()
+    for k in ("gemm", "lvc", "conv"):
+        exact.set_option(k, "fp32")
+    exact.set_option("hoist", "off")
+    worst = 0.0
+    with torch.no_grad():
+        for draw in range(64):
+            B = int(rng.choice([1, 1, 2, 3, 5, 8, 9]))
+            T = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 33, 48, 65, 100, 130, 257]))
+            N = int(rng.choice([1, 2, 3, 4, 6, 8, 9, 11, 16, 17]))
+            lens = [int(v) for v in rng.randint(1, T + 1, size=B)]
+            lens[int(rng.randint(B))] = T
+            use_lens = lens if (B > 1 and draw % 3) else None
+            mel = torch.from_numpy(synth.synth_mel(900 + draw, B, T)).cuda()
+            if use_lens:
+                for b, t in enumerate(use_lens):
+                    mel[b, :, t:] = 0.0
+            rows = [{"t": float(rng.uniform(0, 999)), "c_eps": 0.03, "c_div": 0.995, "sigma": 0.1, "c1": 1.0, "c2": 0.0, "c3": 0.0,
+                     "add_noise": int(k < N - 1)} for k in range(N)]
+            fast.set_option("hoist", "off" if draw % 4 == 3 else "auto")
+            a = fast.sample(mel, rows, seed=draw, lens=use_lens)
+            b = exact.sample(mel, rows, seed=draw, lens=use_lens)
+            assert torch.isfinite(a).all() and torch.isfinite(b).all(), (draw, B, T, N, use_lens)
+            for i in range(B):
+                n = (use_lens[i] if use_lens else T) * 256
+                d = float((a[i, :, :n] - b[i, :, :n]).abs().max())
+                assert d <= LOOP_TOL * max(1.0, float(b[i, :, :n].abs().max())), (draw, B, T, N, use_lens, i, d)
+                worst = max(worst, d)
+    assert worst > 0.0          # (two different arithmetic pipes: identical bits would mean the option did not take)
+
+
 def test_forward_accepts_unbatched_mel_and_long_steps(model, gc):
     """egs/demo.ipynb passes a [80,T] mel; training passes integer steps (util.py:311-319)."""
     g = load_golden("forward_f1")

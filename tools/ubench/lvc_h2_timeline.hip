@@ -11,8 +11,8 @@ void fd_prof_end(const fdk::Launch &) {}
 
 int main(int argc, char **argv)
 {
-    const int B = 8, T = 864, HOP = 256, Ln = T * HOP;
     const char *outp = argc > 1 ? argv[1] : "timeline.bin";
+    const int B = argc > 2 ? atoi(argv[2]) : 8, T = argc > 3 ? atoi(argv[3]) : 864, HOP = 256, Ln = T * HOP;
     const size_t nx = (size_t)B * 32 * Ln, nk = (size_t)B * T * fd::KREC;
     float *x, *skip, *out, *kp, *wpack, *wref, *cb;
     int *flag;
