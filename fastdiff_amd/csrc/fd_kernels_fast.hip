@@ -1552,6 +1552,8 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
 // thread per column adds them in a fixed order and stores the sum to eps_acc; the 3 + 3 columns at each tile edge get the missing
 // taps from the neighbour tile, both sides with one atomic add onto a zeroed word (two addends: the order cannot change the bits).
 // k_final_acc turns eps_acc (+ bias) into eps / the sampler update and leaves it zeroed.
+// (wref, the fp32 conv weights, is no longer read here -- the halo columns use the A operand registers -- and stays in the signature
+// for the fp32 twin launched with the same argument list.)
 template <int HOP, int DIL, bool FINAL>
 __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin, const float *__restrict__ skip, float *__restrict__ xout,
                                                    const float *__restrict__ kpack, int layer, const float4 *__restrict__ wpack16,
