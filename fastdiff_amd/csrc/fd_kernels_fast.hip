@@ -110,6 +110,31 @@ __device__ __forceinline__ void halo_dot(const char *xs, int row, int slot, cons
 }
 
 
+// Cache policy of the big streams.  FD_LVC_NT bits: which accesses carry the nt (non-temporal) bit -- hop-64/256 LVC layers: 1 = x
+// loads, 2 = out stores, 4 = the frame's record, 8 = skip loads; 16 = hop-8 LVC out stores, 32 = ConvTranspose out stores, 64 =
+// first_conv out stores.  Measured (profiles/r03/s40_s41_nt_policy.txt): 2 pays (layer -3 % alone, call -0.75 % at B=8, -1.9 % at B=1),
+// 4 costs 6 % (both waves of a row tile read the record: it has to stay in L1/L2), the rest +-0.
+#ifndef FD_LVC_NT
+#define FD_LVC_NT 2
+#endif
+typedef float lvc_f4 __attribute__((ext_vector_type(4)));
+template <int BIT>
+__device__ __forceinline__ float4 lvc_ld(const float4 *p)
+{
+    if constexpr ((FD_LVC_NT & BIT) != 0) {
+        const lvc_f4 v = __builtin_nontemporal_load(reinterpret_cast<const lvc_f4 *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else return *p;
+}
+template <int BIT>
+__device__ __forceinline__ void lvc_st(float *p, float v) { if constexpr ((FD_LVC_NT & BIT) != 0) __builtin_nontemporal_store(v, p); else *p = v; }
+template <int BIT>
+__device__ __forceinline__ void lvc_st(float4 *p, const float4 &v)
+{
+    if constexpr ((FD_LVC_NT & BIT) != 0) __builtin_nontemporal_store(lvc_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<lvc_f4 *>(p));
+    else *p = v;
+}
+
 // =================================================================================================
 // a3: first_audio_conv  Conv1d(1,32,k7,pad3)  (FastDiff_model.py:34-36,89)   -- VALU, HBM-write bound
 // =================================================================================================
@@ -139,7 +164,7 @@ __global__ void __launch_bounds__(256) k_first_conv(const float *__restrict__ x,
         for (int k = 0; k < 7; ++k) {
             r.x += wv[k] * xv[k]; r.y += wv[k] * xv[k + 1]; r.z += wv[k] * xv[k + 2]; r.w += wv[k] * xv[k + 3];
         }
-        *reinterpret_cast<float4 *>(a0 + ((int64_t)b * fd::C + o) * L + t0) = r;
+        lvc_st<64>(reinterpret_cast<float4 *>(a0 + ((int64_t)b * fd::C + o) * L + t0), r);
     }
 }
 
@@ -1266,7 +1291,7 @@ __global__ void __launch_bounds__(256, 2) k_convt_h2(const float *__restrict__ x
         if (q < Lb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                *reinterpret_cast<float4 *>(ob + (unsigned)((r & 3) + 8 * (r >> 2)) * Lu + pg) = make_float4(res[0][r], res[1][r], res[2][r], res[3][r]);
+                lvc_st<32>(reinterpret_cast<float4 *>(ob + (unsigned)((r & 3) + 8 * (r >> 2)) * Lu + pg), make_float4(res[0][r], res[1][r], res[2][r], res[3][r]));
         }
     }
 }
@@ -1595,7 +1620,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
             const float4 *kp4 = reinterpret_cast<const float4 *>(rec + layer * fd::KLAYER) + 2 * lane;
             const float4 *kb4 = reinterpret_cast<const float4 *>(rec + fd::KW + layer * 64);
 #pragma unroll
-            for (int i = 0; i < 12; ++i) ka[m][i] = kp4[((mt0 + m) * 6 + (i >> 1)) * 128 + (i & 1)];
+            for (int i = 0; i < 12; ++i) ka[m][i] = lvc_ld<4>(kp4 + ((mt0 + m) * 6 + (i >> 1)) * 128 + (i & 1));
 #pragma unroll
             for (int j = 0; j < 4; ++j) bz[m][j] = kb4[(mt0 + m) * 8 + 2 * j + hi];
         }
@@ -1635,8 +1660,8 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
         float hx[8], hs[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            xa[c] = ok ? *reinterpret_cast<const float4 *>(xr + (int64_t)c * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
-            sa[c] = ok ? *reinterpret_cast<const float4 *>(sr + (int64_t)c * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xa[c] = ok ? lvc_ld<1>(reinterpret_cast<const float4 *>(xr + (int64_t)c * Ln + g)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            sa[c] = ok ? lvc_ld<8>(reinterpret_cast<const float4 *>(sr + (int64_t)c * Ln + g)) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -1827,7 +1852,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
                     const int chl = 16 * (mt0 + m) + (r & 3) + 8 * (r >> 2);     // channel minus 4*hi
                     const float zs = fmaf(al[r], GX_INV_SCALE, ah[r]), zt = fmaf(al[r + 8], GX_INV_SCALE, ah[r + 8]);
                     if constexpr (FINAL) resid[nt][m * 8 + r] += gate(zs, zt);
-                    else xo[(unsigned)chl * Lnu + (unsigned)(nt * 32)] = resid[nt][m * 8 + r] + gate(zs, zt);
+                    else lvc_st<2>(xo + ((unsigned)chl * Lnu + (unsigned)(nt * 32)), resid[nt][m * 8 + r] + gate(zs, zt));
                 }
             }
         }
@@ -2225,7 +2250,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h8m(const float *__restrict__ xi
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {      // channel 16 mt + 4 g4 + r: sigmoid input in tile (mt, 0), tanh input in tile (mt, 1)
                     const float zs = fmaf(zl[0][r], GX_INV_SCALE, zh[0][r]), zt = fmaf(zl[1][r], GX_INV_SCALE, zh[1][r]);
-                    xo[(int64_t)(16 * mt + r) * Ln] = rr[(16 * mt + r) * W] + gate(zs, zt);
+                    lvc_st<16>(xo + (int64_t)(16 * mt + r) * Ln, rr[(16 * mt + r) * W] + gate(zs, zt));
                 }
             }
         }
