@@ -1205,8 +1205,12 @@ __global__ void __launch_bounds__(256, 2) k_convt(const float *__restrict__ xin,
 
 // The same ConvTranspose on the fp16 matrix pipe with 2-piece operands: 12 MFMAs of 32 cycles per
 // output phase instead of 32 of 64.  leaky_relu(x) is split once into a [position][piece][32 ch] fp16 image (row = q - q0 + 1).
+#ifndef FD_CONVT_OCC
+#define FD_CONVT_OCC(R) 2      // workgroups per CU the register budget is cut for.  r = 4 fits three (168 VGPRs, no spills) and is
+                               // slower with them: 73 -> 80 us in the step (profiles/r03/s44_convt_occupancy.txt)
+#endif
 template <int R>
-__global__ void __launch_bounds__(256, 2) k_convt_h2(const float *__restrict__ xin, const float4 *__restrict__ pack16,
+__global__ void __launch_bounds__(256, FD_CONVT_OCC(R)) k_convt_h2(const float *__restrict__ xin, const float4 *__restrict__ pack16,
                                                   const float *__restrict__ bias, float *__restrict__ out, int Lin,
                                                   int *__restrict__ range_flag, const int *__restrict__ lens, int per_frame)
 {
