@@ -756,10 +756,20 @@ static hipError_t lvc_block_run(const Launch &L, int n, const float *x_in, int B
     const int Lin = T * (fd::hop(n) / fd::ratio(n));
     float *cur = (x_in == ws.xA) ? ws.xB : ws.xA;
     float *other = (cur == ws.xA) ? ws.xB : ws.xA;
-    hipError_t e = c->fast[ST_CONVT] ? fast_convt(L, n, x_in, cur, B, Lin) : naive_convt(L, n, x_in, cur, B, Lin);
-    if (e != hipSuccess) return e;
     const float *skip = ws.a[2 - n];
-    for (int i = 0; i < fd::LAYERS; ++i) {
+    // blocks 1 and 2 (hop 64, 256) on the fp16x2 pipe with the range check on the host: the up-sampler runs inside the first layer
+    // (k_lvc_h2<.., UP>), its output never goes to HBM and back; x_in is read by that layer, which writes the other buffer
+    const bool fuse_up = c->fuse_up && n >= 1 && c->fast[ST_CONVT] && c->fast[ST_LVC] &&
+                         fd_pipe(c, c->conv_f16 && c->w.convt_f16_ok, 16 + n) == PIPE_F16_ONLY &&
+                         fd_pipe(c, c->lvc_f16 && c->w.lvc_f16_ok, 1 + n * fd::LAYERS) == PIPE_F16_ONLY;
+    hipError_t e = hipSuccess;
+    if (fuse_up) {
+        if ((e = fast_lvc_layer(L, n, 0, x_in, skip, cur, B, T, true)) != hipSuccess) return e;
+    } else {
+        e = c->fast[ST_CONVT] ? fast_convt(L, n, x_in, cur, B, Lin) : naive_convt(L, n, x_in, cur, B, Lin);
+        if (e != hipSuccess) return e;
+    }
+    for (int i = fuse_up ? 1 : 0; i < fd::LAYERS; ++i) {
         if (c->fast[ST_LVC]) {
             e = fast_lvc_layer(L, n, i, cur, skip, other, B, T);
             std::swap(cur, other);
@@ -935,7 +945,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
 static unsigned mode_signature(const fd_context *h)
 {
     unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_f16 ? 2u : 0u) | (h->lvc_f16 ? 4u : 0u) | (h->conv_f16 ? 8u : 0u) | (h->step_lens ? 16u : 0u) |
-                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u) | (h->overlap_gemm ? 128u : 0u) | ((unsigned)h->overlap_wg << 8) | (h->overlap_paths ? 1024u : 0u) | ((unsigned)h->hoist_np << 11) | (h->predictor_first ? (1u << 20) : 0u) | (h->hoist_chunk ? (1u << 21) : 0u);
+                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u) | (h->overlap_gemm ? 128u : 0u) | ((unsigned)h->overlap_wg << 8) | (h->overlap_paths ? 1024u : 0u) | ((unsigned)h->hoist_np << 11) | (h->predictor_first ? (1u << 20) : 0u) | (h->hoist_chunk ? (1u << 21) : 0u) | (h->fuse_up ? (1u << 22) : 0u);
     for (int i = 0; i < ST_COUNT; ++i) s = (s << 1) | (h->fast[i] ? 1u : 0u);
     return s ^ (h->fp32_mask * 2654435761u);
 }
@@ -1593,6 +1603,7 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
         return FD_OK;
     }
     if (k == "fuse_final") { h->fuse_final = on; drop_graph(h); return FD_OK; }
+    if (k == "fuse_up") { h->fuse_up = on; drop_graph(h); return FD_OK; }
     if (k == "hoist") {
         if (v == "auto") h->hoist_mode = 1;
         else if (v == "on") h->hoist_mode = 2;

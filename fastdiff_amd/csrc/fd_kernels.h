@@ -18,7 +18,8 @@ hipError_t fast_dblock(const Launch &L, int d, int B, int T, const float *audio)
 hipError_t fast_kp_front(const Launch &L, const StepIO &io, int B, int T);
 hipError_t fast_kp_gemm(const Launch &L, int B, int T, int blk0 = 0, int nblk = fd::NBLK, int wg_per_cu = 2);
 hipError_t fast_convt(const Launch &L, int n, const float *x_in, float *x_out, int B, int Lin);
-hipError_t fast_lvc_layer(const Launch &L, int n, int layer, const float *x_in, const float *skip, float *x_out, int B, int T);
+// up: layer 0 of block n >= 1 with the block's ConvTranspose inside it -- x_in is then the block's input (fp16x2-only launches)
+hipError_t fast_lvc_layer(const Launch &L, int n, int layer, const float *x_in, const float *skip, float *x_out, int B, int T, bool up = false);
 hipError_t fast_final(const Launch &L, const StepIO &io, const float *x32, int B, int T);
 // the LVC operator with its gradients (fd_kernels_train.hip)
 // scratch: B*T*Cin*Cout*ks floats when lvc_op_needs_scratch (the model's shape: matrix-pipe kernels), else unused

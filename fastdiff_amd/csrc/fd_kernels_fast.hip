@@ -1583,15 +1583,30 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
 // k_final_acc turns eps_acc (+ bias) into eps / the sampler update and leaves it zeroed.
 // (wref, the fp32 conv weights, is no longer read here -- the halo columns use the A operand registers -- and stays in the signature
 // for the fp32 twin launched with the same argument list.)
-template <int HOP, int DIL, bool FINAL>
+// UP = r > 0 (the first layer of a block, DIL = 1): the block's ConvTranspose1d (k_convt_h2<r>) runs inside the staging -- xin is then
+// the block's INPUT [B][32][L / r], the up-sampled x never goes to HBM and back (hop 256: 226 MB each way and a 73 us launch).
+// Wave w takes output phases w * r/4 ..: the same MFMA sequence on the same operands as k_convt_h2 (bias in the accumulator, per k
+// group h.h, h.l, l.h), so x -- and with it everything behind -- keeps its bits.  x + skip then meets in the parking area: skip is
+// loaded the coalesced way (wave = channel group, lane = 4 columns) and parked, each lane of the conv's result layout (16 channels of
+// one column) reads its 16 skip values back from there, writes x' over them and the leaky-relu pieces into the x image.
+// up_flag: the ConvTranspose's own range flag (raised together with the layer's: the host then redoes both on fp32 kernels).
+template <int HOP, int DIL, bool FINAL, int UP = 0>
 __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin, const float *__restrict__ skip, float *__restrict__ xout,
                                                    const float *__restrict__ kpack, int layer, const float4 *__restrict__ wpack16,
                                                    const float *__restrict__ wref, const float *__restrict__ cbias,
                                                    int *__restrict__ range_flag, int T, const int *__restrict__ lens,
-                                                   float *__restrict__ eps_acc, const float4 *__restrict__ ffuse)
+                                                   float *__restrict__ eps_acc, const float4 *__restrict__ ffuse,
+                                                   const float4 *__restrict__ up_pack16, const float *__restrict__ up_bias,
+                                                   int *__restrict__ up_flag)
 {
     static_assert(!FINAL || HOP == 256, "the fused final conv relies on whole-tile utterance lengths");
+    static_assert(UP == 0 || (DIL == 1 && (UP == 4 || UP == 8)), "the fused up-sampler belongs to the first layer of a block");
     constexpr int W = 256, WC = 64, H = (DIL + 1 + 3) & ~3, XC = W + 2 * H, YC = W + 2;
+    // fused up-sampler: tile columns -H .. W+H-1 = positions q0 - 1 .. of the block input, UPPAD columns in front of the tile make the
+    // first one whole; UPN positions, UPROWS image rows (one more position on either side for the second tap)
+    constexpr int UPPAD = UP ? UP : 1, UPN = UP ? (W + 2 * UPPAD) / UPPAD : 0, UPROWS = UPN + 2;
+    __shared__ __attribute__((aligned(16))) char xp_img[UP ? UPROWS * 128 : 16];      // leaky_relu(block input) pieces, row = position - (q0 - 2)
+    __shared__ float hsk[UP ? fd::C * 2 * H : 1];                                       // skip at the 2H halo columns
     constexpr int LT = (HOP == 256) ? 1 : 2;           // row tiles per wave   (hop 256: wave = (row tile, column half))
     constexpr int LN = (HOP == 256) ? 4 : 2;           // column tiles per wave
     // the predicted kernel (HBM, the longest latency) is requested as early as the registers allow: hop 256 (one row tile per
@@ -1630,7 +1645,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
         }
     };
 #ifndef FD_LVC_LATE_KERNEL
-    if constexpr (HOP == 256) load_kernel(0);
+    if constexpr (HOP == 256 && UP == 0) load_kernel(0);
 #endif
     // conv weights: A operand pieces [piece][kg][lane] x 8 fp16, k = 16*kg + 8*hi + e = tap*32 + in
     float4 wa[2][6];
@@ -1652,6 +1667,120 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
     }
 #endif
 
+    if constexpr (UP > 0) {
+        // ---- fused up-sampler (see the head of the kernel) ---------------------------------------------------------------------
+        constexpr int R = UP, NT = (UPN + 31) / 32, PHW = R / 4;
+        const int Lq = Ln / R, Lqb = Lnb / R, q0 = w0 / R;
+        {   // (a) skip: centre parked as fp32 [32][256] in the y area, the 2H halo columns in hsk; block input: leaky-relu pieces
+            const float *sr = skip + ((int64_t)b * fd::C + wave * 8) * Ln;
+            const int g = w0 + 4 * lane;
+            const bool ok = g < Lnb;
+            const int hc = lane, hg = (hc < H) ? w0 - H + hc : w0 + W + hc - H;
+            const bool hok = hc < 2 * H && hg >= 0 && hg < Lnb;
+            float4 sa[8];
+            float hs[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) sa[c] = ok ? lvc_ld<8>(reinterpret_cast<const float4 *>(sr + (int64_t)c * Ln + g)) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) hs[c] = hok ? sr[(int64_t)c * Ln + hg] : 0.0f;
+            constexpr int NU = 4 * UPROWS, NK = (NU + 255) / 256;       // thread = (8-channel group, image row)
+            float v[NK][8];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int u = k * 256 + tid, cg = u / UPROWS, jj = u - cg * UPROWS, j = q0 - 2 + jj;
+                const bool okp = u < NU && j >= 0 && j < Lqb;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[k][c] = okp ? xin[((int64_t)b * fd::C + cg * 8 + c) * Lq + j] : 0.0f;
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) *reinterpret_cast<float4 *>(ys + ((wave * 8 + c) * W + 4 * lane) * 4) = sa[c];
+            if (hc < 2 * H) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) hsk[(wave * 8 + c) * (2 * H) + hc] = hs[c];
+            }
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int u = k * 256 + tid, cg = u / UPROWS, jj = u - cg * UPROWS;
+                if (u < NU) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) { mx = fmaxf(mx, fabsf(v[k][c])); v[k][c] = lrelu(v[k][c], 0.2f); }
+                    float4 ph, pl;
+                    split8(v[k], ph, pl);
+                    *reinterpret_cast<float4 *>(xp_img + h2_off(jj, cg)) = ph;
+                    *reinterpret_cast<float4 *>(xp_img + h2_off(jj, 4 + cg)) = pl;
+                }
+            }
+        }
+        if constexpr (HOP == 256) load_kernel(0);
+        float4 ub[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ub[j] = reinterpret_cast<const float4 *>(up_bias)[2 * j + hi];
+        // the first phase's weights are requested in front of the barrier (L2 latency under the wait), the next phase's under the MFMAs
+        float4 wun[2][4];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) wun[p][kg] = up_pack16[(((wave * PHW) * 2 + p) * 4 + kg) * 64 + lane];
+        __syncthreads();
+        // (b) wave = PHW output phases; per phase and 32-position tile the ConvTranspose's 12 MFMAs, then x' = x + skip in place
+        float *park = reinterpret_cast<float *>(ys);
+#pragma unroll
+        for (int pw = 0; pw < PHW; ++pw) {
+            const int ph = wave * PHW + pw;
+            float4 wu[2][4];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) wu[p][kg] = wun[p][kg];
+            if (pw + 1 < PHW) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int kg = 0; kg < 4; ++kg) wun[p][kg] = up_pack16[(((ph + 1) * 2 + p) * 4 + kg) * 64 + lane];
+            }
+            const int offA = (ph < R / 2) ? 0 : 1, offB = offA - 1;      // sel 0 reads position q + offA, sel 1 position q + offB
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int ql = 32 * t + l31, qc = min(ql, UPN - 1);        // position index in the tile (row qc + 1 of the image)
+                f32x16 ah, al;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { ah[r] = f4c(ub[r >> 2], r & 3); al[r] = 0.0f; }
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) {          // k = 16*kg + 8*hi + e = sel*32 + i
+                    const int row = qc + 1 + ((kg >> 1) ? offB : offA), c2 = kg & 1;
+                    const float4 b1 = *reinterpret_cast<const float4 *>(xp_img + h2_off(row, c2 * 2 + hi));
+                    const float4 b2 = *reinterpret_cast<const float4 *>(xp_img + h2_off(row, 4 + c2 * 2 + hi));
+                    ah = mfma_f16(wu[0][kg], b1, ah);
+                    al = mfma_f16(wu[0][kg], b2, al);
+                    al = mfma_f16(wu[1][kg], b1, al);
+                }
+                const int row = R * ql + ph - (UPPAD - H);                  // image row of this lane's column; column = row - H
+                if (ql < UPN && row >= 0 && row < XC) {
+                    const int col = row - H, g = w0 + col;
+                    const bool inb = g >= 0 && g < Lnb, centre = col >= 0 && col < W;
+                    const int hcol = col < 0 ? col + H : col - W + H;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {                         // D rows 8j + 4hi + {0..3}: half a slot
+                        float v[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int ch = 8 * j + 4 * hi + i;
+                            const float sk = centre ? park[ch * W + col] : hsk[ch * (2 * H) + hcol];
+                            const float xv = inb ? fmaf(al[4 * j + i], GX_INV_SCALE, ah[4 * j + i]) + sk : 0.0f;
+                            mx = fmaxf(mx, fabsf(xv));
+                            if (centre) park[ch * W + col] = xv;
+                            v[i] = lrelu(xv, 0.2f);
+                        }
+                        uint2 p1, p2;
+                        split2(v[0], v[1], p1.x, p2.x);
+                        split2(v[2], v[3], p1.y, p2.y);
+                        *reinterpret_cast<uint2 *>(xs + h2_off(row, j) + 8 * hi) = p1;
+                        *reinterpret_cast<uint2 *>(xs + h2_off(row, 4 + j) + 8 * hi) = p2;
+                    }
+                }
+            }
+        }
+    } else
     // ---- stage x + skip.  Centre: wave = channel group of 8, lane = 4 columns, so that one column of a thread is one 16 B
     //      slot per piece.  Halo (2H columns): wave = channel group, lane = one column.  Every wave does the same work. --------
     {
@@ -1904,7 +2033,10 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
             if (w0 + t >= 0 && w0 + t < Lnb) atomicAdd(ea + t, column_sum(t));
         }
     }
-    if (!(mx < GX_LIMIT)) atomicOr(range_flag, 1);      // also inf; a NaN operand gives a NaN result on either path
+    if (!(mx < GX_LIMIT)) {      // also inf; a NaN operand gives a NaN result on either path
+        atomicOr(range_flag, 1);
+        if constexpr (UP > 0) atomicOr(up_flag, 1);
+    }
     FD_STAMP(7);
 }
 
@@ -2455,7 +2587,7 @@ hipError_t fast_convt(const Launch &L, int n, const float *x_in, float *x_out, i
 
 template <int HOP, int DIL>
 static hipError_t launch_lvc(const Launch &L, const char *name, int n, int layer, const float *x_in, const float *skip, float *x_out,
-                             int B, int T)
+                             int B, int T, bool up)
 {
     fd_context *c = L.ctx;
     const DevWeights &w = c->w;
@@ -2466,6 +2598,16 @@ static hipError_t launch_lvc(const Launch &L, const char *name, int n, int layer
     const float *kp = c->ws.kpack + ((int64_t)n * c->hoist_np + c->hoist_step) * B * T * fd::KREC;
     const int *run_if = nullptr;
     if constexpr (HOP == 256 && DIL == 27) c->final_fused = false;
+    if constexpr (HOP >= 64 && DIL == 1) {
+        if (up) {      // x_in = the block's input: the ConvTranspose runs inside the layer (the caller made sure both stages are fp16x2-only)
+            constexpr int R = (HOP == 256) ? 4 : 8;
+            FD_LAUNCH(L, name, (k_lvc_h2<HOP, 1, false, R>), dim3(((Ln + 255) / 256 + 7) / 8 * 8, B), dim3(256), 0, x_in, skip, x_out, kp, layer,
+                      reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]), w.blk[n].convs[layer].w, w.blk[n].convs[layer].b,
+                      c->ws.range_flag + 1 + n * fd::LAYERS + layer, T, c->step_lens, (float *)nullptr, (const float4 *)nullptr,
+                      reinterpret_cast<const float4 *>(w.up_h2[n]), w.blk[n].up.b, c->ws.range_flag + 16 + n);
+            return hipSuccess;
+        }
+    }
     if constexpr (HOP >= 64) {
         const Pipe pipe = fd_pipe(c, c->lvc_f16 && w.lvc_f16_ok, 1 + n * fd::LAYERS + layer);
         if (pipe != PIPE_F32_ONLY) {
@@ -2477,12 +2619,14 @@ static hipError_t launch_lvc(const Launch &L, const char *name, int n, int layer
                 if (c->final_fused)
                     FD_LAUNCH(L, name, (k_lvc_h2<HOP, DIL, true>), dim3(((Ln + 255) / 256 + 7) / 8 * 8, B), dim3(256), 0, x_in, skip, x_out, kp,
                               layer, reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]), w.blk[n].convs[layer].w,
-                              w.blk[n].convs[layer].b, flag, T, c->step_lens, c->ws.eps_acc, reinterpret_cast<const float4 *>(w.final_fuse));
+                              w.blk[n].convs[layer].b, flag, T, c->step_lens, c->ws.eps_acc, reinterpret_cast<const float4 *>(w.final_fuse),
+                              (const float4 *)nullptr, (const float *)nullptr, (int *)nullptr);
             }
             if (!c->final_fused)
                 FD_LAUNCH(L, name, (k_lvc_h2<HOP, DIL, false>), dim3(((Ln + 255) / 256 + 7) / 8 * 8, B), dim3(256), 0, x_in, skip, x_out, kp,
                           layer, reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]), w.blk[n].convs[layer].w,
-                          w.blk[n].convs[layer].b, flag, T, c->step_lens, (float *)nullptr, (const float4 *)nullptr);
+                          w.blk[n].convs[layer].b, flag, T, c->step_lens, (float *)nullptr, (const float4 *)nullptr,
+                          (const float4 *)nullptr, (const float *)nullptr, (int *)nullptr);
             run_if = flag;
             name = "lvc_fp32_fallback";
             if (pipe == PIPE_F16_ONLY) return hipSuccess;
@@ -2493,14 +2637,14 @@ static hipError_t launch_lvc(const Launch &L, const char *name, int n, int layer
     return hipSuccess;
 }
 
-hipError_t fast_lvc_layer(const Launch &L, int n, int layer, const float *x_in, const float *skip, float *x_out, int B, int T)
+hipError_t fast_lvc_layer(const Launch &L, int n, int layer, const float *x_in, const float *skip, float *x_out, int B, int T, bool up)
 {
 #define FD_LVC_CASE(HOP_, NAME_)                                                                                    \
     switch (layer) {                                                                                                \
-    case 0: return launch_lvc<HOP_, 1>(L, NAME_ "_d1", n, layer, x_in, skip, x_out, B, T);                           \
-    case 1: return launch_lvc<HOP_, 3>(L, NAME_ "_d3", n, layer, x_in, skip, x_out, B, T);                           \
-    case 2: return launch_lvc<HOP_, 9>(L, NAME_ "_d9", n, layer, x_in, skip, x_out, B, T);                           \
-    default: return launch_lvc<HOP_, 27>(L, NAME_ "_d27", n, layer, x_in, skip, x_out, B, T);                        \
+    case 0: return launch_lvc<HOP_, 1>(L, NAME_ "_d1", n, layer, x_in, skip, x_out, B, T, up);                           \
+    case 1: return launch_lvc<HOP_, 3>(L, NAME_ "_d3", n, layer, x_in, skip, x_out, B, T, up);                           \
+    case 2: return launch_lvc<HOP_, 9>(L, NAME_ "_d9", n, layer, x_in, skip, x_out, B, T, up);                           \
+    default: return launch_lvc<HOP_, 27>(L, NAME_ "_d27", n, layer, x_in, skip, x_out, B, T, up);                        \
     }
     if (n == 0) {
         fd_context *c = L.ctx;

@@ -652,6 +652,29 @@ def test_hoisted_predictor_equals_the_per_step_one(gc, sched, N):
         assert torch.equal(y, ref), k
 
 
+@pytest.mark.parametrize("B,T,lens", [(3, 37, [37, 12, 25]), (2, 130, None), (1, 5, None), (4, 64, [64, 1, 33, 64])])
+def test_up_sampler_inside_the_first_lvc_layer(gc, sched, B, T, lens):
+    """Under the host-checked range (every stage fp16x2-only) blocks 1 and 2 run their ConvTranspose inside the first LVC layer
+    (k_lvc_h2<.., UP>): the same matrix instructions on the same operands as k_convt_h2, so option fuse_up = 0 must give the same
+    bits -- tile edges, ragged lengths and one-frame utterances included."""
+    import synth
+    mel = torch.from_numpy(synth.synth_mel(500 + T, B, T)).cuda()
+    if lens:
+        for b, t in enumerate(lens):
+            mel[b, :, t:] = 0.0
+    rows, _ = gc.table_rows(sched, 4)
+    out = {}
+    with torch.no_grad():
+        for fuse in ("1", "0"):
+            m = gc.make_model()
+            assert m._options.get("fallback") == "host"
+            m.set_option("fuse_up", fuse)
+            out[fuse] = [m.sample(mel, rows, seed=11, lens=lens), m.sample(mel, rows, seed=12, lens=lens)]
+    for a, b in zip(out["1"], out["0"]):
+        assert torch.isfinite(a).all() and float(a.abs().max()) > 0.1
+        assert torch.equal(a, b)
+
+
 def test_graph_cache_alternating_shapes(gc, sched):
     """One captured step per (B, T, mode) is kept (micro-batches of different padded length alternate in infer.py): results with
     the cache warm, after other shapes ran in between, and after more shapes than the cache holds (eviction) must equal the

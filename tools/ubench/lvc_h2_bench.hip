@@ -31,10 +31,10 @@ int run(int B, int T, int reps)
     dim3 grid(((Ln + 255) / 256 + 7) / 8 * 8, B);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((fdk_fast::k_lvc_h2<HOP, DIL, false>), grid, dim3(256), 0, 0, x, skip, out, kp, 1, (const float4 *)wpack, wref, cb, flag, T, (const int *)nullptr, (float *)nullptr, (const float4 *)nullptr);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((fdk_fast::k_lvc_h2<HOP, DIL, false>), grid, dim3(256), 0, 0, x, skip, out, kp, 1, (const float4 *)wpack, wref, cb, flag, T, (const int *)nullptr, (float *)nullptr, (const float4 *)nullptr, (const float4 *)nullptr, (const float *)nullptr, (int *)nullptr);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((fdk_fast::k_lvc_h2<HOP, DIL, false>), grid, dim3(256), 0, 0, x, skip, out, kp, 1, (const float4 *)wpack, wref, cb, flag, T, (const int *)nullptr, (float *)nullptr, (const float4 *)nullptr);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((fdk_fast::k_lvc_h2<HOP, DIL, false>), grid, dim3(256), 0, 0, x, skip, out, kp, 1, (const float4 *)wpack, wref, cb, flag, T, (const int *)nullptr, (float *)nullptr, (const float4 *)nullptr, (const float4 *)nullptr, (const float *)nullptr, (int *)nullptr);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms = 0;

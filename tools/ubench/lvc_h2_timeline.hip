@@ -39,7 +39,7 @@ int main(int argc, char **argv)
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL((fdk_fast::k_lvc_h2<256, 27, false>), grid, dim3(256), 0, 0, x, skip, out, kp, 1, (const float4 *)wpack, wref, cb, flag, T, (const int *)nullptr, (float *)nullptr, (const float4 *)nullptr);
+        hipLaunchKernelGGL((fdk_fast::k_lvc_h2<256, 27, false>), grid, dim3(256), 0, 0, x, skip, out, kp, 1, (const float4 *)wpack, wref, cb, flag, T, (const int *)nullptr, (float *)nullptr, (const float4 *)nullptr, (const float4 *)nullptr, (const float *)nullptr, (int *)nullptr);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms = 0;
