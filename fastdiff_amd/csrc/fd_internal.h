@@ -185,6 +185,12 @@ struct fd_context {
                                              // stages run fp16x2-only, i.e. under fallback = host or a forced mask without them).  Same
                                              // bits, one launch and one round trip of x less per block: B=1 -4.4 %, B=2 -3 %, B=8 -1.6 %
     bool final_fused = false;                // set by the last LVC layer's launch, consumed by fast_final
+    // the step embedding and the three fc_t rows of every reverse step depend on the schedule's t values and the weights only: kept from
+    // the previous fd_sample when those are unchanged (two launches per call)
+    std::vector<float> embed_t;
+    int embed_B = 0;
+    bool embed_valid = false;
+    bool embed_cache = true;                 // option "embed_cache"
     MelTables mel[MEL_VARIANTS];             // [MEL_PWG]: fmin 80, fmax 7600; [MEL_TACOTRON]: fmin 0, fmax 8000 (twiddles/window shared)
     int mel_variant = MEL_PWG;               // option "mel"
     std::vector<void *> mel_allocs;           // device memory behind `mel` (built on first use, freed at fd_destroy)

@@ -675,6 +675,28 @@ def test_up_sampler_inside_the_first_lvc_layer(gc, sched, B, T, lens):
         assert torch.equal(a, b)
 
 
+def test_embedding_table_kept_between_calls(gc, sched):
+    """The step-embedding rows of a schedule (two launches per call) stay in the workspace while the next call uses the same t values
+    and batch size; a different schedule, another batch size or an fd_forward in between must bring the table up to date."""
+    import synth
+    B, T = 2, 21
+    mel = torch.from_numpy(synth.synth_mel(61, B, T)).cuda()
+    rows4, _ = gc.table_rows(sched, 4)
+    rows6, _ = gc.table_rows(sched, 6)
+    rows19 = [{"t": 190.0 - 9.5 * k, "c_eps": 0.02, "c_div": 0.99, "sigma": 0.05, "c1": 1.0, "c2": 0.0, "c3": 0.0, "add_noise": int(k < 18)}
+              for k in range(19)]
+    with torch.no_grad():
+        want = {n: gc.make_model().sample(mel, r, seed=3) for n, r in (("4", rows4), ("6", rows6), ("19", rows19))}      # fresh handles
+        want1 = gc.make_model().sample(mel[:1], rows4, seed=3)
+        m = gc.make_model()
+        for n, r in (("4", rows4), ("4", rows4), ("6", rows6), ("4", rows4), ("19", rows19), ("19", rows19), ("6", rows6)):
+            assert torch.equal(m.sample(mel, r, seed=3), want[n]), n
+        assert torch.equal(m.sample(mel[:1], rows4, seed=3), want1)              # another batch size
+        audio = torch.from_numpy(synth.synth_audio(61, B, T)).cuda()
+        m((audio, mel, torch.full((B, 1), 7.0).cuda()))                           # fd_forward writes its own rows into the table
+        assert torch.equal(m.sample(mel, rows4, seed=3), want["4"])
+
+
 def test_graph_cache_alternating_shapes(gc, sched):
     """One captured step per (B, T, mode) is kept (micro-batches of different padded length alternate in infer.py): results with
     the cache warm, after other shapes ran in between, and after more shapes than the cache holds (eviction) must equal the
