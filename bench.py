@@ -55,6 +55,12 @@ def kernel_model(name, B, T):
     if name.startswith("lvc_block_h8"):
         # the four hop-8 layers of block 0 in one launch: per layer read x+skip, the frame's record; write x
         return "hbm", 4 * 4.0 * B * T * (96 * 8 + 6208), 4 * 2.0 * B * T * 8 * (32 * 96 + 64 * 96)
+    if name.startswith("lvc_up_h"):
+        # the first layer of blocks 1 / 2 with the block's ConvTranspose inside: reads the block input (32 ch at rate hop/r, r = 8 / 4)
+        # instead of x, skip and the frame record as every layer, writes x
+        hop = int(name.split("_h")[1].split("_")[0])
+        r = 4 if hop == 256 else 8
+        return "hbm", 4.0 * B * T * (64 * hop + 32 * hop // r + 6208), 2.0 * B * T * hop * (32 * 96 + 64 * 96 + 32 * 64)
     if name.startswith("lvc_layer_h"):
         hop = int(name.split("_h")[1].split("_")[0])
         # read x, skip (32 ch each), write x (32 ch) at rate hop*T; read the frame's 64x96 kernel + 64 biases
@@ -147,12 +153,21 @@ def measure_roofline(model, mel, rows, B, T, nsteps, lens=None):
         except Exception:
             pass
     # the LVC layers time-weighted (north_star's ">= 50 % of HBM roofline in the LVC kernel" spans all twelve launches)
-    lvc = [(k, v) for k, v in fam.items() if k.startswith("lvc_layer_h") or k.startswith("lvc_block_h")]
+    def weighted(keys):
+        by = sum(kernel_model(k, B, T)[1] * fam[k][0] for k in keys)
+        ms = sum(fam[k][1] for k in keys)
+        return {"GBps": round(by / (ms * 1e-3) / 1e9, 1), "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "ms_per_sample_call": round(ms / 2, 4), "launches_per_step": sum(fam[k][0] for k in keys) // (2 * nsteps)}
+    lvc = [k for k in fam if k.startswith("lvc_layer_h") or k.startswith("lvc_block_h")]
+    up = [k for k in fam if k.startswith("lvc_up_h")]
     if lvc:
-        by = sum(kernel_model(k, B, T)[1] * v[0] for k, v in lvc)
-        ms = sum(v[1] for _, v in lvc)
-        roof["lvc_all_layers"] = {"GBps": round(by / (ms * 1e-3) / 1e9, 1), "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                  "ms_per_sample_call": round(ms / 2, 4)}
+        roof["lvc_all_layers"] = weighted(lvc)
+    if up:      # the first layers of blocks 1 and 2 carry the block's ConvTranspose (option fuse_up): fewer bytes by construction (the
+        # up-sampled x never reaches HBM) and the up-sampler's arithmetic inside -- their own rows, not part of the figure above
+        roof["lvc_first_layers_with_upsampler"] = weighted(up)
+        roof["lvc_all_layers"]["note"] = ("the LVC layer kernel alone (%d launches per step); the first layers of blocks 1 and 2 run the block's "
+                                          "ConvTranspose inside (lvc_first_layers_with_upsampler): the pair (ConvTranspose + layer) used to move more "
+                                          "bytes in more time" % roof["lvc_all_layers"]["launches_per_step"])
     return roof, table
 
 

@@ -183,7 +183,7 @@ struct fd_context {
     bool fuse_final = true;                  // option "fuse_final": final_conv inside the last LVC layer
     bool fuse_up = true;                     // option "fuse_up": the ConvTranspose of blocks 1 and 2 inside their first LVC layer (when both
                                              // stages run fp16x2-only, i.e. under fallback = host or a forced mask without them).  Same
-                                             // bits, one launch and one round trip of x less per block: B=1 -4.4 %, B=2 -3 %, B=8 -1.6 %
+                                             // bits, one launch and one round trip of x less per block: B=1 -5.2 %, B=8 -2.6 %
     bool final_fused = false;                // set by the last LVC layer's launch, consumed by fast_final
     // the step embedding and the three fc_t rows of every reverse step depend on the schedule's t values and the weights only: kept from
     // the previous fd_sample when those are unchanged (two launches per call)

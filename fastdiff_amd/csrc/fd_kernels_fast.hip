@@ -1606,7 +1606,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
     // first one whole; UPN positions, UPROWS image rows (one more position on either side for the second tap)
     constexpr int UPPAD = UP ? UP : 1, UPN = UP ? (W + 2 * UPPAD) / UPPAD : 0, UPROWS = UPN + 2;
     __shared__ __attribute__((aligned(16))) char xp_img[UP ? UPROWS * 128 : 16];      // leaky_relu(block input) pieces, row = position - (q0 - 2)
-    __shared__ float hsk[UP ? fd::C * 2 * H : 1];                                       // skip at the 2H halo columns
+    __shared__ float hsk[UP ? fd::C * 2 * H : 1];                                       // the up-sampled x at the 2H halo columns
     constexpr int LT = (HOP == 256) ? 1 : 2;           // row tiles per wave   (hop 256: wave = (row tile, column half))
     constexpr int LN = (HOP == 256) ? 4 : 2;           // column tiles per wave
     // the predicted kernel (HBM, the longest latency) is requested as early as the registers allow: hop 256 (one row tile per
@@ -1667,122 +1667,9 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
     }
 #endif
 
-    if constexpr (UP > 0) {
-        // ---- fused up-sampler (see the head of the kernel) ---------------------------------------------------------------------
-        constexpr int R = UP, NT = (UPN + 31) / 32, PHW = R / 4;
-        const int Lq = Ln / R, Lqb = Lnb / R, q0 = w0 / R;
-        {   // (a) skip: centre parked as fp32 [32][256] in the y area, the 2H halo columns in hsk; block input: leaky-relu pieces
-            const float *sr = skip + ((int64_t)b * fd::C + wave * 8) * Ln;
-            const int g = w0 + 4 * lane;
-            const bool ok = g < Lnb;
-            const int hc = lane, hg = (hc < H) ? w0 - H + hc : w0 + W + hc - H;
-            const bool hok = hc < 2 * H && hg >= 0 && hg < Lnb;
-            float4 sa[8];
-            float hs[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) sa[c] = ok ? lvc_ld<8>(reinterpret_cast<const float4 *>(sr + (int64_t)c * Ln + g)) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) hs[c] = hok ? sr[(int64_t)c * Ln + hg] : 0.0f;
-            constexpr int NU = 4 * UPROWS, NK = (NU + 255) / 256;       // thread = (8-channel group, image row)
-            float v[NK][8];
-#pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                const int u = k * 256 + tid, cg = u / UPROWS, jj = u - cg * UPROWS, j = q0 - 2 + jj;
-                const bool okp = u < NU && j >= 0 && j < Lqb;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v[k][c] = okp ? xin[((int64_t)b * fd::C + cg * 8 + c) * Lq + j] : 0.0f;
-            }
-#pragma unroll
-            for (int c = 0; c < 8; ++c) *reinterpret_cast<float4 *>(ys + ((wave * 8 + c) * W + 4 * lane) * 4) = sa[c];
-            if (hc < 2 * H) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) hsk[(wave * 8 + c) * (2 * H) + hc] = hs[c];
-            }
-#pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                const int u = k * 256 + tid, cg = u / UPROWS, jj = u - cg * UPROWS;
-                if (u < NU) {
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) { mx = fmaxf(mx, fabsf(v[k][c])); v[k][c] = lrelu(v[k][c], 0.2f); }
-                    float4 ph, pl;
-                    split8(v[k], ph, pl);
-                    *reinterpret_cast<float4 *>(xp_img + h2_off(jj, cg)) = ph;
-                    *reinterpret_cast<float4 *>(xp_img + h2_off(jj, 4 + cg)) = pl;
-                }
-            }
-        }
-        if constexpr (HOP == 256) load_kernel(0);
-        float4 ub[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ub[j] = reinterpret_cast<const float4 *>(up_bias)[2 * j + hi];
-        // the first phase's weights are requested in front of the barrier (L2 latency under the wait), the next phase's under the MFMAs
-        float4 wun[2][4];
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int kg = 0; kg < 4; ++kg) wun[p][kg] = up_pack16[(((wave * PHW) * 2 + p) * 4 + kg) * 64 + lane];
-        __syncthreads();
-        // (b) wave = PHW output phases; per phase and 32-position tile the ConvTranspose's 12 MFMAs, then x' = x + skip in place
-        float *park = reinterpret_cast<float *>(ys);
-#pragma unroll
-        for (int pw = 0; pw < PHW; ++pw) {
-            const int ph = wave * PHW + pw;
-            float4 wu[2][4];
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int kg = 0; kg < 4; ++kg) wu[p][kg] = wun[p][kg];
-            if (pw + 1 < PHW) {
-#pragma unroll
-                for (int p = 0; p < 2; ++p)
-#pragma unroll
-                    for (int kg = 0; kg < 4; ++kg) wun[p][kg] = up_pack16[(((ph + 1) * 2 + p) * 4 + kg) * 64 + lane];
-            }
-            const int offA = (ph < R / 2) ? 0 : 1, offB = offA - 1;      // sel 0 reads position q + offA, sel 1 position q + offB
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int ql = 32 * t + l31, qc = min(ql, UPN - 1);        // position index in the tile (row qc + 1 of the image)
-                f32x16 ah, al;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { ah[r] = f4c(ub[r >> 2], r & 3); al[r] = 0.0f; }
-#pragma unroll
-                for (int kg = 0; kg < 4; ++kg) {          // k = 16*kg + 8*hi + e = sel*32 + i
-                    const int row = qc + 1 + ((kg >> 1) ? offB : offA), c2 = kg & 1;
-                    const float4 b1 = *reinterpret_cast<const float4 *>(xp_img + h2_off(row, c2 * 2 + hi));
-                    const float4 b2 = *reinterpret_cast<const float4 *>(xp_img + h2_off(row, 4 + c2 * 2 + hi));
-                    ah = mfma_f16(wu[0][kg], b1, ah);
-                    al = mfma_f16(wu[0][kg], b2, al);
-                    al = mfma_f16(wu[1][kg], b1, al);
-                }
-                const int row = R * ql + ph - (UPPAD - H);                  // image row of this lane's column; column = row - H
-                if (ql < UPN && row >= 0 && row < XC) {
-                    const int col = row - H, g = w0 + col;
-                    const bool inb = g >= 0 && g < Lnb, centre = col >= 0 && col < W;
-                    const int hcol = col < 0 ? col + H : col - W + H;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {                         // D rows 8j + 4hi + {0..3}: half a slot
-                        float v[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int ch = 8 * j + 4 * hi + i;
-                            const float sk = centre ? park[ch * W + col] : hsk[ch * (2 * H) + hcol];
-                            const float xv = inb ? fmaf(al[4 * j + i], GX_INV_SCALE, ah[4 * j + i]) + sk : 0.0f;
-                            mx = fmaxf(mx, fabsf(xv));
-                            if (centre) park[ch * W + col] = xv;
-                            v[i] = lrelu(xv, 0.2f);
-                        }
-                        uint2 p1, p2;
-                        split2(v[0], v[1], p1.x, p2.x);
-                        split2(v[2], v[3], p1.y, p2.y);
-                        *reinterpret_cast<uint2 *>(xs + h2_off(row, j) + 8 * hi) = p1;
-                        *reinterpret_cast<uint2 *>(xs + h2_off(row, 4 + j) + 8 * hi) = p2;
-                    }
-                }
-            }
-        }
-    } else
     // ---- stage x + skip.  Centre: wave = channel group of 8, lane = 4 columns, so that one column of a thread is one 16 B
-    //      slot per piece.  Halo (2H columns): wave = channel group, lane = one column.  Every wave does the same work. --------
+    //      slot per piece.  Halo (2H columns): wave = channel group, lane = one column.  Every wave does the same work.
+    //      UP: x is not read but computed -- the block's ConvTranspose lands in the parking area first (below). -----------------
     {
         const float *xr = xin + ((int64_t)b * fd::C + wave * 8) * Ln, *sr = skip + ((int64_t)b * fd::C + wave * 8) * Ln;
         const int g = w0 + 4 * lane;
@@ -1793,17 +1680,106 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
         float hx[8], hs[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            xa[c] = ok ? lvc_ld<1>(reinterpret_cast<const float4 *>(xr + (int64_t)c * Ln + g)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (UP == 0) xa[c] = ok ? lvc_ld<1>(reinterpret_cast<const float4 *>(xr + (int64_t)c * Ln + g)) : make_float4(0.f, 0.f, 0.f, 0.f);
             sa[c] = ok ? lvc_ld<8>(reinterpret_cast<const float4 *>(sr + (int64_t)c * Ln + g)) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            hx[c] = hok ? xr[(int64_t)c * Ln + hg] : 0.0f;
+            if constexpr (UP == 0) hx[c] = hok ? xr[(int64_t)c * Ln + hg] : 0.0f;
             hs[c] = hok ? sr[(int64_t)c * Ln + hg] : 0.0f;
+        }
+        if constexpr (UP > 0) {
+            // ---- the block's ConvTranspose (see the head of the kernel); skip is on its way from HBM meanwhile -----------------
+            constexpr int R = UP, NT = (UPN + 31) / 32, PHW = R / 4;
+            const int Lq = Ln / R, Lqb = Lnb / R, q0 = w0 / R;
+            {   // (a) the block input as leaky-relu pieces: thread = (8-channel group, image row)
+                constexpr int NU = 4 * UPROWS, NK = (NU + 255) / 256;
+                float v[NK][8];
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const int u = k * 256 + tid, cg = u / UPROWS, jj = u - cg * UPROWS, j = q0 - 2 + jj;
+                    const bool okp = u < NU && j >= 0 && j < Lqb;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[k][c] = okp ? xin[((int64_t)b * fd::C + cg * 8 + c) * Lq + j] : 0.0f;
+                }
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const int u = k * 256 + tid, cg = u / UPROWS, jj = u - cg * UPROWS;
+                    if (u < NU) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) { mx = fmaxf(mx, fabsf(v[k][c])); v[k][c] = lrelu(v[k][c], 0.2f); }
+                        float4 ph, pl;
+                        split8(v[k], ph, pl);
+                        *reinterpret_cast<float4 *>(xp_img + h2_off(jj, cg)) = ph;
+                        *reinterpret_cast<float4 *>(xp_img + h2_off(jj, 4 + cg)) = pl;
+                    }
+                }
+            }
+            float4 ub[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ub[j] = reinterpret_cast<const float4 *>(up_bias)[2 * j + hi];
+            // the first phase's weights are requested in front of the barrier (L2 latency under the wait), the next phase's under the MFMAs
+            float4 wun[2][4];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) wun[p][kg] = up_pack16[(((wave * PHW) * 2 + p) * 4 + kg) * 64 + lane];
+            __syncthreads();
+            // (b) wave = PHW output phases; per phase and 32-position tile the ConvTranspose's 12 MFMAs; x goes to the parking area
+            //     ([32][256] fp32 in the y area; the 2H halo columns to hsk), zero outside the utterance like the loads of the other path
+            float *park = reinterpret_cast<float *>(ys);
+#pragma unroll
+            for (int pw = 0; pw < PHW; ++pw) {
+                const int ph = wave * PHW + pw;
+                float4 wu[2][4];
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int kg = 0; kg < 4; ++kg) wu[p][kg] = wun[p][kg];
+                if (pw + 1 < PHW) {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int kg = 0; kg < 4; ++kg) wun[p][kg] = up_pack16[(((ph + 1) * 2 + p) * 4 + kg) * 64 + lane];
+                }
+                const int offA = (ph < R / 2) ? 0 : 1, offB = offA - 1;      // sel 0 reads position q + offA, sel 1 position q + offB
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int ql = 32 * t + l31, qc = min(ql, UPN - 1);        // position index in the tile (row qc + 1 of the image)
+                    f32x16 ah, al;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { ah[r] = f4c(ub[r >> 2], r & 3); al[r] = 0.0f; }
+#pragma unroll
+                    for (int kg = 0; kg < 4; ++kg) {          // k = 16*kg + 8*hi + e = sel*32 + i
+                        const int row = qc + 1 + ((kg >> 1) ? offB : offA), c2 = kg & 1;
+                        const float4 b1 = *reinterpret_cast<const float4 *>(xp_img + h2_off(row, c2 * 2 + hi));
+                        const float4 b2 = *reinterpret_cast<const float4 *>(xp_img + h2_off(row, 4 + c2 * 2 + hi));
+                        ah = mfma_f16(wu[0][kg], b1, ah);
+                        al = mfma_f16(wu[0][kg], b2, al);
+                        al = mfma_f16(wu[1][kg], b1, al);
+                    }
+                    const int col = R * ql + ph - UPPAD;                        // this lane's column of the tile
+                    if (ql < UPN && col >= -H && col < W + H) {
+                        const int gc = w0 + col;
+                        const bool inb = gc >= 0 && gc < Lnb;
+                        float *dst = (col >= 0 && col < W) ? park + col : hsk + (col < 0 ? col + H : col - W + H);
+                        const int cs = (col >= 0 && col < W) ? W : 2 * H;          // channel stride of the destination
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)                              // D rows 8j + 4hi + i = register 4j + i
+                            dst[(8 * (r >> 2) + 4 * hi + (r & 3)) * cs] = inb ? fmaf(al[r], GX_INV_SCALE, ah[r]) : 0.0f;
+                    }
+                }
+            }
+            __syncthreads();
+            if constexpr (HOP == 256) load_kernel(0);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) xa[c] = *reinterpret_cast<const float4 *>(ys + ((wave * 8 + c) * W + 4 * lane) * 4);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) hx[c] = hc < 2 * H ? hsk[(wave * 8 + c) * (2 * H) + hc] : 0.0f;
         }
 #ifdef FD_LVC_LATE_KERNEL
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (HOP == 256) load_kernel(0);
+        if constexpr (HOP == 256 && UP == 0) load_kernel(0);
 #endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -2601,7 +2577,7 @@ static hipError_t launch_lvc(const Launch &L, const char *name, int n, int layer
     if constexpr (HOP >= 64 && DIL == 1) {
         if (up) {      // x_in = the block's input: the ConvTranspose runs inside the layer (the caller made sure both stages are fp16x2-only)
             constexpr int R = (HOP == 256) ? 4 : 8;
-            FD_LAUNCH(L, name, (k_lvc_h2<HOP, 1, false, R>), dim3(((Ln + 255) / 256 + 7) / 8 * 8, B), dim3(256), 0, x_in, skip, x_out, kp, layer,
+            FD_LAUNCH(L, HOP == 256 ? "lvc_up_h256" : "lvc_up_h64", (k_lvc_h2<HOP, 1, false, R>), dim3(((Ln + 255) / 256 + 7) / 8 * 8, B), dim3(256), 0, x_in, skip, x_out, kp, layer,
                       reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]), w.blk[n].convs[layer].w, w.blk[n].convs[layer].b,
                       c->ws.range_flag + 1 + n * fd::LAYERS + layer, T, c->step_lens, (float *)nullptr, (const float4 *)nullptr,
                       reinterpret_cast<const float4 *>(w.up_h2[n]), w.blk[n].up.b, c->ws.range_flag + 16 + n);

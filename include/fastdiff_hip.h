@@ -214,7 +214,7 @@ FD_API int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_sa
  *          auto: N >= 2 and B * T <= 4096 frames;
  * "overlap" = "off" (default) | "gemm" | "paths", "overlap_wg": measured variants of the step on two streams;
  * "fuse_up" = "1" (default) | "0": under "fallback" = "host" the ConvTranspose of blocks 1 and 2 runs inside the block's first LVC
- *          layer (same bits; one launch and one round trip of x less per block: B = 1 -4 %, B = 8 -1.6 %);
+ *          layer (same bits; one launch and one round trip of x less per block: B = 1 -5 %, B = 8 -2.6 %);
  * "embed_cache" = "1" (default) | "0": keep the step-embedding rows of the last schedule between fd_sample calls (same t values and B);
  * "order" = "down" (default: the reference's order of statements) | "predictor" (front + GEMM first, so that the GEMM's 2 GB of
  *          stores drain under the DBlocks and not under the first LVC layers; same bits, measured +-0: INTEGRATION.md);

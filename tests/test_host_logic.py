@@ -303,4 +303,8 @@ def test_roofline_numerators_are_the_surveys_algorithmic_figures():
         assert bound == "hbm" and nbytes == 4.0 * 864 * (96 * hop + 6208) and abs(nbytes / 1e6 / mb - 1.0) < 0.01, (name, nbytes)
         assert flops >= gflop * 1e9                               # the fused layer also counts its dilated conv
         assert bench.kernel_model(name, 8, 864)[1] == 8 * nbytes
+    # the first layer of blocks 1 / 2 with the block's ConvTranspose inside: the block input (1/r of the x bytes) instead of x
+    for name, hop, r in (("lvc_up_h64", 64, 8), ("lvc_up_h256", 256, 4)):
+        nb = bench.kernel_model(name, 1, 864)[1]
+        assert nb == 4.0 * 864 * (64 * hop + 32 * hop // r + 6208) and nb < bench.kernel_model("lvc_layer_h%d" % hop, 1, 864)[1]
     assert bench.HBM_PEAK_GBS == 8000.0
