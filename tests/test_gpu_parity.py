@@ -652,7 +652,7 @@ def test_hoisted_predictor_equals_the_per_step_one(gc, sched, N):
         assert torch.equal(y, ref), k
 
 
-@pytest.mark.parametrize("B,T,lens", [(3, 37, [37, 12, 25]), (2, 130, None), (1, 5, None), (4, 64, [64, 1, 33, 64])])
+@pytest.mark.parametrize("B,T,lens", [(3, 37, [37, 12, 25]), (2, 130, None), (1, 5, None), (4, 64, [64, 1, 33, 64]), (3, 230, [112, 230, 113])])
 def test_up_sampler_inside_the_first_lvc_layer(gc, sched, B, T, lens):
     """Under the host-checked range (every stage fp16x2-only) blocks 1 and 2 run their ConvTranspose inside the first LVC layer
     (k_lvc_h2<.., UP>): the same matrix instructions on the same operands as k_convt_h2, so option fuse_up = 0 must give the same
