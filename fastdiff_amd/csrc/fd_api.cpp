@@ -948,7 +948,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
 static unsigned mode_signature(const fd_context *h)
 {
     unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_f16 ? 2u : 0u) | (h->lvc_f16 ? 4u : 0u) | (h->conv_f16 ? 8u : 0u) | (h->step_lens ? 16u : 0u) |
-                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u) | (h->overlap_gemm ? 128u : 0u) | ((unsigned)h->overlap_wg << 8) | (h->overlap_paths ? 1024u : 0u) | ((unsigned)h->hoist_np << 11) | (h->predictor_first ? (1u << 20) : 0u) | (h->hoist_chunk ? (1u << 21) : 0u) | (h->fuse_up ? (1u << 22) : 0u);
+                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u) | (h->overlap_gemm ? 128u : 0u) | ((unsigned)h->overlap_wg << 8) | (h->overlap_paths ? 1024u : 0u) | ((unsigned)h->hoist_np << 11) | (h->predictor_first ? (1u << 20) : 0u) | (h->hoist_chunk ? (1u << 21) : 0u) | (h->fuse_up ? (1u << 22) : 0u) | (h->fuse_advance ? (1u << 23) : 0u);
     for (int i = 0; i < ST_COUNT; ++i) s = (s << 1) | (h->fast[i] ? 1u : 0u);
     return s ^ (h->fp32_mask * 2654435761u);
 }
@@ -984,6 +984,10 @@ static int enqueue_steps(fd_handle h, int B, int T, int count, unsigned fp32_mas
         return e == hipSuccess ? fdk::kp_gemm(L, B * np, T) : e;
     };
     if (h->hoist_chunk) h->hoist_np = 1;          // (the signature below must not depend on the piece that ran last)
+    // between two steps of one sequence the bookkeeping can ride in the next step's first kernel -- when that kernel is the fast one,
+    // on the main stream (not option overlap = paths) and the first of the step (not option order = predictor with an in-step predictor)
+    const bool defer_advance = h->fuse_advance && h->fast[ST_FIRST] && !h->overlap_paths && !(h->predictor_first && h->hoist_np <= 1 && !h->hoist_chunk);
+    h->advance_pending = false;
     if (!(h->use_graph && !h->profile)) {
         fdk::Launch L = {h, stream, false};
         for (int k = 0; k < count; ++k) {
@@ -993,7 +997,10 @@ static int enqueue_steps(fd_handle h, int B, int T, int count, unsigned fp32_mas
             }
             h->hoist_step = h->hoist_np > 1 ? (h->hoist_chunk ? k % CHUNK : k) : 0;
             hipError_t e = fdk::run_step(L, io, B, T);
-            if (e == hipSuccess) e = fdk::advance_step(L);
+            if (e == hipSuccess) {
+                if (k + 1 < count && defer_advance) h->advance_pending = true;      // the next step's first kernel does it
+                else e = fdk::advance_step(L);
+            }
             if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample: step %d failed: %s", k, hipGetErrorString(e));
         }
         return FD_OK;
@@ -1022,7 +1029,10 @@ static int enqueue_steps(fd_handle h, int B, int T, int count, unsigned fp32_mas
         for (int k = 0; k < steps && ec == hipSuccess; ++k) {
             h->hoist_step = h->hoist_np > 1 ? k : 0;      // (hoisted: the graph holds the whole call or piece, so k is its step)
             ec = fdk::run_step(Lc, io, B, T);
-            if (ec == hipSuccess) ec = fdk::advance_step(Lc);
+            if (ec == hipSuccess) {
+                if (k + 1 < steps && defer_advance) h->advance_pending = true;
+                else ec = fdk::advance_step(Lc);
+            }
         }
         hipGraph_t g = nullptr;
         hipError_t e2 = hipStreamEndCapture(h->cap_stream, &g);
@@ -1616,6 +1626,7 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
     }
     if (k == "fuse_final") { h->fuse_final = on; drop_graph(h); return FD_OK; }
     if (k == "fuse_up") { h->fuse_up = on; drop_graph(h); return FD_OK; }
+    if (k == "fuse_advance") { h->fuse_advance = on; drop_graph(h); return FD_OK; }
     if (k == "embed_cache") { h->embed_cache = on; return FD_OK; }
     if (k == "hoist") {
         if (v == "auto") h->hoist_mode = 1;

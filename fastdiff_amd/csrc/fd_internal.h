@@ -185,6 +185,9 @@ struct fd_context {
                                              // stages run fp16x2-only, i.e. under fallback = host or a forced mask without them).  Same
                                              // bits, one launch and one round trip of x less per block: B=1 -5.2 %, B=8 -2.6 %
     bool final_fused = false;                // set by the last LVC layer's launch, consumed by fast_final
+    bool fuse_advance = true;                // option "fuse_advance": between two steps of one graph / launch sequence the end-of-step
+                                             // bookkeeping (k_advance) rides in the next step's first kernel instead of a launch of its own
+    bool advance_pending = false;            // set by enqueue_steps after a step whose bookkeeping the next first_conv will do
     // the step embedding and the three fc_t rows of every reverse step depend on the schedule's t values and the weights only: kept from
     // the previous fd_sample when those are unchanged (two launches per call)
     std::vector<float> embed_t;

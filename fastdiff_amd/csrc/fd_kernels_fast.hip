@@ -138,10 +138,23 @@ __device__ __forceinline__ void lvc_st(float4 *p, const float4 &v)
 // =================================================================================================
 // a3: first_audio_conv  Conv1d(1,32,k7,pad3)  (FastDiff_model.py:34-36,89)   -- VALU, HBM-write bound
 // =================================================================================================
+// advance != null (a sampler step that is not the first of its graph / launch sequence): the first workgroup does the previous step's
+// end-of-step bookkeeping on the way -- next row of the step table, that step's range flags become "previous step" and join the call's
+// sticky set -- what k_advance does in a launch of its own.  Nothing else in this kernel reads either; the kernels behind it start
+// after the whole grid.
 __global__ void __launch_bounds__(256) k_first_conv(const float *__restrict__ x, const float *__restrict__ w,
                                                     const float *__restrict__ bias, float *__restrict__ a0, int L,
-                                                    const int *__restrict__ lens)
+                                                    const int *__restrict__ lens, StepParams *advance, int *__restrict__ range_flags)
 {
+    if (advance && blockIdx.x == 0 && blockIdx.y == 0) {
+        if (threadIdx.x == 0) advance->step_idx += 1;
+        if (threadIdx.x < 32) {
+            const int f = range_flags[threadIdx.x];
+            range_flags[32 + threadIdx.x] = f;
+            range_flags[64 + threadIdx.x] |= f;
+            range_flags[threadIdx.x] = 0;
+        }
+    }
     const int b = blockIdx.y;
     const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
     const int Lb = lens ? lens[b] * fd::HOPT : L;          // this utterance's own length (ragged batch)
@@ -2423,8 +2436,11 @@ hipError_t fast_first_conv(const Launch &L, const StepIO &io, int B, int T)
 {
     const DevWeights &w = L.ctx->w;
     const int Lf = T * fd::HOPT;
+    fd_context *c = L.ctx;
+    const bool adv = io.sampler && c->advance_pending;      // the previous step of this sequence left its bookkeeping to us
     FD_LAUNCH(L, "first_conv", k_first_conv, dim3((Lf + 1023) / 1024, B), dim3(256), 0, io.x_in, w.first.w, w.first.b,
-              L.ctx->ws.a[0], Lf, L.ctx->step_lens);
+              c->ws.a[0], Lf, c->step_lens, adv ? c->ws.params : (StepParams *)nullptr, c->ws.range_flag);
+    if (adv) c->advance_pending = false;
     return hipSuccess;
 }
 

@@ -675,6 +675,30 @@ def test_up_sampler_inside_the_first_lvc_layer(gc, sched, B, T, lens):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("N", [4, 19])
+def test_step_bookkeeping_in_the_next_steps_first_kernel(gc, N):
+    """Between two steps of one graph (or launch sequence) the end-of-step bookkeeping -- next row of the step table, rotate the range
+    flags -- rides in the next step's first kernel; only the last step of a sequence keeps the k_advance launch.  Option
+    fuse_advance = 0 (a launch after every step) must give the same trajectory, from the graph and launched one by one."""
+    import synth
+    B, T = 2, 9
+    mel = torch.from_numpy(synth.synth_mel(88, B, T)).cuda()
+    rows = [{"t": 190.0 - 9.5 * k, "c_eps": 0.02, "c_div": 0.99, "sigma": 0.05, "c1": 1.0, "c2": 0.0, "c3": 0.0, "add_noise": int(k < N - 1)}
+            for k in range(N)]
+    out = {}
+    with torch.no_grad():
+        for adv in ("1", "0"):
+            for graph in ("1", "0"):
+                m = gc.make_model()
+                m.set_option("fuse_advance", adv)
+                m.set_option("graph", graph)
+                out[(adv, graph)] = torch.stack(list(m.sample(mel, rows, seed=9, return_sequence=True)))
+    ref = out[("0", "0")]
+    assert torch.isfinite(ref).all() and float((ref[-1] - ref[0]).abs().max()) > 0.1
+    for k, y in out.items():
+        assert torch.equal(y, ref), k
+
+
 def test_embedding_table_kept_between_calls(gc, sched):
     """The step-embedding rows of a schedule (two launches per call) stay in the workspace while the next call uses the same t values
     and batch size; a different schedule, another batch size or an fd_forward in between must bring the table up to date."""
