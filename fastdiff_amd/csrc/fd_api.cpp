@@ -1159,6 +1159,7 @@ static int sample_core(fd_handle h, const fd_context::SampleArgs &a, unsigned fo
         std::vector<float> ts(N);
         for (int k = 0; k < N; ++k) ts[k] = a.table[k].t;
         if (!(h->embed_cache && h->embed_valid && h->embed_B == B && h->embed_t == ts)) {
+            h->embed_valid = false;
             if ((e = fdk::embed(L, io, B, N)) != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample: embed failed: %s", hipGetErrorString(e));
             h->embed_t.swap(ts);
             h->embed_B = B;
