@@ -196,12 +196,13 @@ __global__ void __launch_bounds__(256, 2) k_kc_dh(const float *__restrict__ W, c
         for (int r = 0; r < 16; ++r) acc[rt][r] = 0.0f;
     // 32 rows of W (6 float4 per thread) and of dout (<= 16 floats per thread) per chunk; the next chunk's loads are in flight under
     // the current chunk's matrix work
-    float4 wv[6];
+    typedef float f4n __attribute__((ext_vector_type(4)));
+    f4n wv[6];      // (a native vector type: the HIP float4 struct kept this prefetch buffer in scratch)
     float dvv[16];
     const int nd = (32 * T + 255) / 256;          // <= 16
     auto load_chunk = [&](int pc) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) wv[k] = reinterpret_cast<const float4 *>(W + (int64_t)pc * KK)[k * 256 + tid];
+        for (int k = 0; k < 6; ++k) wv[k] = reinterpret_cast<const f4n *>(W + (int64_t)pc * KK)[k * 256 + tid];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int idx = k * 256 + tid;
@@ -212,7 +213,7 @@ __global__ void __launch_bounds__(256, 2) k_kc_dh(const float *__restrict__ W, c
     for (int pc = pbeg; pc < pbeg + prows; pc += 32) {
         __syncthreads();                          // the previous chunk's reads are done
 #pragma unroll
-        for (int k = 0; k < 6; ++k) reinterpret_cast<float4 *>(ws)[k * 256 + tid] = wv[k];
+        for (int k = 0; k < 6; ++k) reinterpret_cast<f4n *>(ws)[k * 256 + tid] = wv[k];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int idx = k * 256 + tid;
