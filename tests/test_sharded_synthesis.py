@@ -48,13 +48,13 @@ class _Hop:
     hop_length = 256
 
 
-def _cpu_worker(rank, world, port, ret):
+def _cpu_worker(rank, world, port, ret, lens=(9, 4, 13, 2, 7, 7, 1, 5)):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         infer.synthesize = _stub_synthesize
-        lens = [9, 4, 13, 2, 7, 7, 1, 5]          # item 6 has one frame: the collater drops it (dataset_utils.py:116-125)
+        lens = list(lens)                         # (default: item 6 has one frame: the collater drops it, dataset_utils.py:116-125)
         items = _items(3, lens) if rank == 0 else None
         out = infer.synthesize_sharded(_Hop(), items, n_steps=4, max_batch=3, seed=5, drop_last_frame=True, src=0, device=None)
         if rank == 0:
@@ -70,17 +70,30 @@ def _cpu_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_synthesize_sharded_world2_gloo_stub_vocoder():
+def _run_cpu_group(world, lens=None):
     ctx = mp.get_context("spawn")
     ret = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_cpu_worker, args=(r, 2, port, ret)) for r in range(2)]
+    args = (lambda r: (r, world, port, ret)) if lens is None else (lambda r: (r, world, port, ret, tuple(lens)))
+    procs = [ctx.Process(target=_cpu_worker, args=args(r)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(180)
         assert p.exitcode == 0
     assert ret.get() == "ok"
+
+
+def test_synthesize_sharded_world2_gloo_stub_vocoder():
+    _run_cpu_group(2)
+
+
+@pytest.mark.parametrize("world,lens", [(3, (9, 4, 13, 2, 7, 7, 1, 5)),      # an odd world: three shares of a job of seven
+                                        (3, (5, 3)),                          # fewer utterances than ranks: rank 2 gets nothing
+                                        (2, (1,)),                            # the only utterance is dropped by the collater: an empty job
+                                        (2, ())])                             # no utterance at all
+def test_synthesize_sharded_uneven_and_empty_jobs(world, lens):
+    _run_cpu_group(world, lens)
 
 
 def _gpu_worker(rank, world, port, ret, gpu_lock, stage="host", sharing="turns"):
