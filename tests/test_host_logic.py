@@ -337,4 +337,11 @@ def test_no_kernel_spills_to_scratch():
             bad = [(n, int(s)) for n, s in zip(names, scratch) if int(s) != 0]
             assert not bad, (src, bad)
             seen += len(names)
+            # the kernels whose design rests on two workgroups per CU: registers for two waves per SIMD and half the 160 KB of LDS each
+            occ = [int(v) for v in re.findall(r"Occupancy \[waves/SIMD\]: (\d+)", r.stderr)]
+            lds = [int(v) for v in re.findall(r"LDS Size \[bytes/block\]: (\d+)", r.stderr)]
+            assert len(occ) == len(names) == len(lds)
+            for n, o, l in zip(names, occ, lds):
+                if any(k in n for k in ("k_lvc_h2I", "k_kp_gemm_h2", "k_kp_front_h2", "k_convt_h2I", "k_lvc_h8mI")):
+                    assert o >= 2 and l <= 80 * 1024, (n, o, l)
     assert seen >= 70
