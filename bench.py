@@ -50,28 +50,31 @@ DTYPE = "f32 (results fp32; contractions as 2-piece fp16 operands, 22 significan
 
 
 def kernel_model(name, B, T):
-    """Algorithmic work of ONE launch of a kernel family: (bound, bytes, flops)."""
+    """Algorithmic work of ONE launch of a kernel family: (bound, bytes, flops).  `bytes` is what THIS launch has to
+    move at least (SURVEY.md 8(d)'s figure for the plain LVC layer; a fused launch is charged only what it really needs)."""
     L = T * HOP
-    if name.startswith("lvc_block_h8"):
-        # the four hop-8 layers of block 0 in one launch: per layer read x+skip, the frame's record; write x
-        return "hbm", 4 * 4.0 * B * T * (96 * 8 + 6208), 4 * 2.0 * B * T * 8 * (32 * 96 + 64 * 96)
     if name.startswith("lvc_up_h"):
         # the first layer of blocks 1 / 2 with the block's ConvTranspose inside: reads the block input (32 ch at rate hop/r, r = 8 / 4)
         # instead of x, skip and the frame record as every layer, writes x
         hop = int(name.split("_h")[1].split("_")[0])
         r = 4 if hop == 256 else 8
         return "hbm", 4.0 * B * T * (64 * hop + 32 * hop // r + 6208), 2.0 * B * T * hop * (32 * 96 + 64 * 96 + 32 * 64)
+    if name.startswith("lvc_final_h"):
+        # the last layer of the last block with final_conv inside: reads x, skip and the record, writes ONE channel of per-sample sums
+        # (eps_acc, 4 B per sample) instead of its 32 output channels
+        hop = int(name.split("_h")[1].split("_")[0])
+        return "hbm", 4.0 * B * T * (64 * hop + 6208) + 4.0 * B * L, 2.0 * B * T * hop * (32 * 96 + 64 * 96) + 2.0 * 7 * 32 * B * L
     if name.startswith("lvc_layer_h"):
         hop = int(name.split("_h")[1].split("_")[0])
-        # read x, skip (32 ch each), write x (32 ch) at rate hop*T; read the frame's 64x96 kernel + 64 biases
+        # read x, skip (32 ch each), write x (32 ch) at rate hop*T; read the frame's 64x96 kernel + 64 biases: SURVEY.md 8(d)
         return "hbm", 4.0 * B * T * (96 * hop + 6208), 2.0 * B * T * hop * (32 * 96 + 64 * 96)
     if name == "kp_gemm":
         # all 3 LVC blocks in one launch: [24832 x 192] x [192 x B*T] each, output written once (fp32 matrix pipe)
         return "mfma", 3 * 4.0 * (B * T * 24832 + 24832 * 192 + B * T * 64), 3 * 2.0 * 24832 * 192 * B * T
     if name == "kp_gemm_f16x2":
-        # the same product as three fp16 MFMA passes (2-piece operands): 3x the flops on a 16x faster pipe -- the
-        # 2.06 GB of predicted kernels it writes is what bounds it (DESIGN.md 3.2)
-        return "hbm", 3 * 4.0 * (B * T * 24832 + 24832 * 192 + B * T * 64), 3 * 3 * 2.0 * 24832 * 192 * B * T
+        # the same product on the fp16 pipe with 2-piece operands (three MFMA passes: 3x these flops are EXECUTED, see
+        # executed_flops); the 2.06 GB of predicted kernels it writes is what bounds it (DESIGN.md 3.2)
+        return "hbm", 3 * 4.0 * (B * T * 24832 + 24832 * 192 + B * T * 64), 3 * 2.0 * 24832 * 192 * B * T
     if name == "kp_front":
         # input conv (K=400) + six 64->64 k3 convs (K=192) for the three predictors, fused through LDS
         return "mfma", 3 * 4.0 * B * T * (80 + 64), 3 * 2.0 * 64 * (400 + 6 * 192) * B * T
@@ -88,6 +91,26 @@ def kernel_model(name, B, T):
     return "hbm", None, None
 
 
+def executed_flops(name, B, T):
+    """Matrix-pipe flops a launch really issues when that differs from the algorithmic count: the fp16x2 GEMM forms h.h, h.l and l.h."""
+    if name == "kp_gemm_f16x2":
+        return 3 * kernel_model(name, B, T)[2]
+    return None
+
+
+def unfused_bytes(name, B, T):
+    """What the ops a fused launch replaces would move as separate launches (for the 'credited with the un-fused ops' bytes' figure):
+    lvc_up = the ConvTranspose (read 32 ch at hop/r, write 32 ch at hop) + a plain layer; lvc_final = a plain layer."""
+    if name.startswith("lvc_up_h"):
+        hop = int(name.split("_h")[1].split("_")[0])
+        r = 4 if hop == 256 else 8
+        return 4.0 * B * T * (96 * hop + 6208) + 4.0 * B * T * (32 * hop // r + 32 * hop)
+    if name.startswith("lvc_final_h"):
+        hop = int(name.split("_h")[1].split("_")[0])
+        return 4.0 * B * T * (96 * hop + 6208)
+    return kernel_model(name, B, T)[1]
+
+
 def family(name):
     if os.environ.get("FD_BENCH_SPLIT"):
         return name
@@ -97,15 +120,29 @@ def family(name):
     return name
 
 
+def template_group(fam_name):
+    """Rows that are instantiations of one kernel template: k_lvc_h2<HOP, DIL, FINAL, UP> runs as lvc_layer_h<HOP> (plain), lvc_final_h256
+    (final_conv inside, no output channels written) and lvc_up_h<HOP> (the block's ConvTranspose inside)."""
+    for p in ("lvc_layer_h", "lvc_final_h", "lvc_up_h"):
+        if fam_name.startswith(p):
+            return "lvc_h" + fam_name[len(p):]
+    return fam_name
+
+
 def measure_roofline(model, mel, rows, B, T, nsteps, lens=None):
-    """Eager (graph off) profiled pass: per-kernel HIP-event timing on the launch stream."""
-    model.set_option("profile", "1")
+    """Profiled pass with the graph off: every launch goes through hipExtLaunchKernelGGL with start / stop events that receive the
+    dispatch's own begin / end timestamps (library option profile = 1; what rocprofv3 --kernel-trace reads), the launches back to
+    back on the launch stream as in the replayed graph.  FD_BENCH_PROFILE=events selects the older form (hipEventRecord around each
+    launch: the gaps it opens let the previous kernel's stores drain, 3-5 % shorter readings)."""
+    reps = 3
+    mode = os.environ.get("FD_BENCH_PROFILE", "1")
+    model.set_option("profile", mode)
     try:
         with torch.no_grad():
             model.sample(mel, rows, seed=1, lens=lens)
             torch.cuda.synchronize()
             model.profile(reset=True)
-            for _ in range(2):
+            for _ in range(reps):
                 model.sample(mel, rows, seed=1, lens=lens)
             torch.cuda.synchronize()
         stats = model.profile(reset=True)
@@ -121,14 +158,25 @@ def measure_roofline(model, mel, rows, B, T, nsteps, lens=None):
     for name, (launches, ms) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
         bound, nbytes, flops = kernel_model(name, B, T)
         avg_ms = ms / launches
-        e = {"launches": launches, "avg_us": round(avg_ms * 1e3, 2), "share": round(ms / total_ms, 4)}
+        e = {"launches": launches, "launches_per_step": round(launches / (reps * nsteps), 3), "avg_us": round(avg_ms * 1e3, 2), "share": round(ms / total_ms, 4)}
         if nbytes:
+            e["MB"] = round(nbytes / 1e6, 1)
             e["GBps"] = round(nbytes / (avg_ms * 1e-3) / 1e9, 1)
             e["hbm_frac"] = round(nbytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         if flops:
-            e["TFLOPs"] = round(flops / (avg_ms * 1e-3) / 1e12, 2)
+            e["TFLOPs_algorithmic"] = round(flops / (avg_ms * 1e-3) / 1e12, 2)
+            ex = executed_flops(name, B, T)
+            if ex:
+                e["TFLOPs_executed"] = round(ex / (avg_ms * 1e-3) / 1e12, 2)
         table[name] = e
-    dom = next(iter(table))
+    # the dominant kernel = the kernel TEMPLATE with the largest share of the step; its roofline is quoted on the plain instantiation
+    groups = {}
+    for name, (launches, ms) in fam.items():
+        groups[template_group(name)] = groups.get(template_group(name), 0.0) + ms
+    dom_group = max(groups, key=groups.get)
+    members = [k for k in fam if template_group(k) == dom_group]
+    plain = [k for k in members if k.startswith("lvc_layer_h")]
+    dom = plain[0] if plain else max(members, key=lambda k: fam[k][1])
     bound, nbytes, flops = kernel_model(dom, B, T)
     avg_s = fam[dom][1] / fam[dom][0] * 1e-3
     if bound == "mfma" and flops:
@@ -139,6 +187,14 @@ def measure_roofline(model, mel, rows, B, T, nsteps, lens=None):
                 "unit": "GB/s"}
     roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
     roof["avg_launch_us"] = round(avg_s * 1e6, 2)
+    roof["algorithmic_MB_per_launch"] = round((nbytes or 0.0) / 1e6, 1)
+    roof["timing"] = ("kernel begin/end timestamps through hipExtLaunchKernelGGL start/stop events, launches back to back, graph off" if mode == "1"
+                      else "hipEventRecord around each launch, graph off")
+    roof["template_share_of_step"] = round(groups[dom_group] / total_ms, 4)
+    if len(members) > 1:
+        roof["kernel_is"] = ("the plain instantiation of the step's dominant kernel template (%s: %s); each instantiation with its own byte "
+                             "model under `variants`" % (dom_group, ", ".join(sorted(members))))
+        roof["variants"] = {k: {kk: table[k][kk] for kk in ("launches_per_step", "avg_us", "MB", "GBps", "hbm_frac", "share") if kk in table[k]} for k in sorted(members)}
     # HBM bytes per launch come from rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, each its own run: tools/gpu_round.sh), which
     # cannot run inside this process: the committed summary of the same command is quoted, with its source, or null
     roof["traffic"] = None
@@ -150,24 +206,33 @@ def measure_roofline(model, mel, rows, B, T, nsteps, lens=None):
                 roof["traffic"] = d.get(dom)
                 roof["traffic_source"] = "profiles/pmc_traffic.json (%s)" % d.get("_source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command")
                 roof["traffic_measured_here"] = False      # a committed figure of an earlier session, not of this run
+                if "variants" in roof:
+                    for k in roof["variants"]:
+                        if d.get(k) is not None:
+                            roof["variants"][k]["traffic"] = d[k]
         except Exception:
             pass
-    # the LVC layers time-weighted (north_star's ">= 50 % of HBM roofline in the LVC kernel" spans all twelve launches)
-    def weighted(keys):
-        by = sum(kernel_model(k, B, T)[1] * fam[k][0] for k in keys)
+    # the LVC layers time-weighted (north_star's ">= 50 % of HBM roofline in the LVC kernel" spans all twelve launches per step)
+    def weighted(keys, byte_fn=lambda k: kernel_model(k, B, T)[1]):
+        by = sum(byte_fn(k) * fam[k][0] for k in keys)
         ms = sum(fam[k][1] for k in keys)
         return {"GBps": round(by / (ms * 1e-3) / 1e9, 1), "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "ms_per_sample_call": round(ms / 2, 4), "launches_per_step": sum(fam[k][0] for k in keys) // (2 * nsteps)}
-    lvc = [k for k in fam if k.startswith("lvc_layer_h") or k.startswith("lvc_block_h")]
-    up = [k for k in fam if k.startswith("lvc_up_h")]
+                "ms_per_sample_call": round(ms / reps, 4), "launches_per_step": sum(fam[k][0] for k in keys) // (reps * nsteps)}
+    lvc = [k for k in fam if k.startswith("lvc_layer_h")]
+    fused = [k for k in fam if k.startswith("lvc_up_h") or k.startswith("lvc_final_h")]
     if lvc:
-        roof["lvc_all_layers"] = weighted(lvc)
-    if up:      # the first layers of blocks 1 and 2 carry the block's ConvTranspose (option fuse_up): fewer bytes by construction (the
-        # up-sampled x never reaches HBM) and the up-sampler's arithmetic inside -- their own rows, not part of the figure above
-        roof["lvc_first_layers_with_upsampler"] = weighted(up)
-        roof["lvc_all_layers"]["note"] = ("the LVC layer kernel alone (%d launches per step); the first layers of blocks 1 and 2 run the block's "
-                                          "ConvTranspose inside (lvc_first_layers_with_upsampler): the pair (ConvTranspose + layer) used to move more "
-                                          "bytes in more time" % roof["lvc_all_layers"]["launches_per_step"])
+        roof["lvc_plain_layers"] = weighted(lvc)
+    if lvc and fused:
+        allk = lvc + fused
+        a = weighted(allk)
+        a["frac_minimal_bytes"] = a.pop("frac")
+        a["GBps_minimal_bytes"] = a.pop("GBps")
+        u = weighted(allk, lambda k: unfused_bytes(k, B, T))
+        a["frac_unfused_ops_bytes"] = u["frac"]
+        a["note"] = ("all LVC launches of a step, time-weighted: plain layers + lvc_final_h256 (final_conv inside) + lvc_up_h64/h256 (the block's "
+                     "ConvTranspose inside).  minimal = each launch charged what it must move itself; unfused = the fused launches credited "
+                     "with the bytes of the separate ops they replace")
+        roof["lvc_all_12_launches"] = a
     return roof, table
 
 
@@ -380,10 +445,10 @@ def b1_object(model, mel, rows, steps):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
     roof, table = measure_roofline(model, m1, rows, 1, T, len(rows))
-    top = {k: {"avg_us": v["avg_us"], "share": v["share"], **({"hbm_frac": v["hbm_frac"]} if "hbm_frac" in v else {})} for k, v in list(table.items())[:6]}
+    top = {k: {"avg_us": v["avg_us"], "share": v["share"], **({"hbm_frac": v["hbm_frac"]} if "hbm_frac" in v else {})} for k, v in list(table.items())[:8]}
     return {"ms_per_step": round(ms, 4), "value": round(T * HOP / SR / (ms / 1e3), 2), "unit": "x real-time", "batch": 1, "frames": T,
             "roofline": {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us") if k in roof},
-            "lvc_all_layers_frac": roof.get("lvc_all_layers", {}).get("frac"), "kernels_top": top}
+            "lvc_all_12_launches_frac_minimal_bytes": roof.get("lvc_all_12_launches", {}).get("frac_minimal_bytes"), "kernels_top": top}
 
 
 def box_state():

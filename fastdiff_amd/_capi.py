@@ -27,7 +27,7 @@ class FdKernelStat(ct.Structure):
 
 EXPORTS = ["fd_default_config", "fd_create", "fd_destroy", "fd_last_error", "fd_set_weight", "fd_commit_weights",
            "fd_forward", "fd_sample", "fd_sample_check", "fd_sample_ticket", "fd_sample_settle", "fd_set_noise_streams", "fd_peak_normalize_int16", "fd_peak_normalize_int16_ragged", "fd_mel_spectrogram", "fd_lvc_forward", "fd_lvc_backward", "fd_gate_forward", "fd_gate_backward", "fd_kconv_forward", "fd_kconv_backward", "fd_set_option", "fd_read_tap", "fd_kernel_index", "fd_bias_index",
-           "fd_get_profile", "fd_reset_profile", "fd_version"]
+           "fd_get_profile", "fd_reset_profile", "fd_get_counter", "fd_version"]
 
 _lib = None
 
@@ -78,6 +78,8 @@ def load():
     lib.fd_bias_index.argtypes = [ci, ci]
     lib.fd_get_profile.argtypes = [vp, ct.POINTER(FdKernelStat), ci]
     lib.fd_reset_profile.argtypes = [vp]
+    lib.fd_get_counter.argtypes = [vp, ct.c_char_p]
+    lib.fd_get_counter.restype = ct.c_int64
     _lib = lib
     return lib
 

@@ -33,10 +33,26 @@ static inline int gx_rows_host(int T) { return ((T + 127) / 128) * 128 + 2; }
 // ------------------------------------------------------------------------------------------------
 // profiling helpers (declared in fd_internal.h)
 // ------------------------------------------------------------------------------------------------
+bool fd_prof_stamps(const fdk::Launch &L, const char *name, hipEvent_t *e0, hipEvent_t *e1)
+{
+    fd_context *c = L.ctx;
+    if (c->profile != 1 || L.capturing) return false;
+    hipEvent_t ev[2];
+    for (int i = 0; i < 2; ++i) {
+        if (!c->event_pool.empty()) { ev[i] = c->event_pool.back(); c->event_pool.pop_back(); }
+        else if (hipEventCreate(&ev[i]) != hipSuccess) return false;
+    }
+    ProfEntry pe;
+    pe.name = name;
+    pe.e0 = *e0 = ev[0]; pe.e1 = *e1 = ev[1];
+    c->prof_pending.push_back(pe);
+    return true;
+}
+
 void fd_prof_begin(const fdk::Launch &L, const char *name)
 {
     fd_context *c = L.ctx;
-    if (!c->profile || L.capturing) return;
+    if (c->profile != 2 || L.capturing) return;
     ProfEntry pe;
     pe.name = name;
     hipEvent_t ev[2];
@@ -52,7 +68,7 @@ void fd_prof_begin(const fdk::Launch &L, const char *name)
 void fd_prof_end(const fdk::Launch &L)
 {
     fd_context *c = L.ctx;
-    if (!c->profile || L.capturing || c->prof_pending.empty()) return;
+    if (c->profile != 2 || L.capturing || c->prof_pending.empty()) return;
     hipEventRecord(c->prof_pending.back().e1, L.stream);
 }
 
@@ -243,6 +259,7 @@ int fd_destroy(fd_handle h)
         if (sl.done) hipEventDestroy(sl.done);
     }
     for (void *p : h->mel_allocs) hipFree(p);
+    if (h->ev_switch) hipEventDestroy(h->ev_switch);
     if (h->cap_stream) hipStreamDestroy(h->cap_stream);
     if (h->side_stream) hipStreamDestroy(h->side_stream);
     for (hipEvent_t ev : {h->ev_fork, h->ev_join[0], h->ev_join[1]})
@@ -893,6 +910,22 @@ static int stage_commit(fd_handle h, fd_context::StageSlot *sl, hipStream_t stre
     return FD_OK;
 }
 
+// One stream at a time per handle: a call on another stream than the previous one first settles what is pending there and then makes
+// the new stream wait for the old one (workspace, embedding rows and step parameters are reused from call to call).
+static int follow_stream(fd_handle h, hipStream_t s)
+{
+    if (h->have_last_stream && h->last_stream != s) {
+        const int rc = settle(h);
+        if (rc != FD_OK) return rc;
+        if (!h->ev_switch) FD_HIP(h, hipEventCreateWithFlags(&h->ev_switch, hipEventDisableTiming));
+        FD_HIP(h, hipEventRecord(h->ev_switch, h->last_stream));
+        FD_HIP(h, hipStreamWaitEvent(s, h->ev_switch, 0));
+    }
+    h->last_stream = s;
+    h->have_last_stream = true;
+    return FD_OK;
+}
+
 // `lens` (host, nullable): valid frames per utterance of a zero-padded batch, uploaded for the kernels from the pinned area `staged`.
 static int set_lens(fd_handle h, const int *lens, int B, int T, hipStream_t stream, const char *who, int *staged)
 {
@@ -921,6 +954,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
     int rc = check_common(h, B, T, "fd_forward");
     if (rc != FD_OK) return rc;
     if ((rc = settle(h)) != FD_OK) return rc;
+    if ((rc = follow_stream(h, (hipStream_t)stream)) != FD_OK) return rc;
     h->inline_fallback = true; h->fp32_mask = 0;      // a single forward always carries its fallbacks inline
     h->hoist_np = 1; h->hoist_step = 0; h->hoist_chunk = false;
     h->embed_valid = false;                      // fd_forward writes its own rows into the same table
@@ -998,7 +1032,9 @@ static int enqueue_steps(fd_handle h, int B, int T, int count, unsigned fp32_mas
             h->hoist_step = h->hoist_np > 1 ? (h->hoist_chunk ? k % CHUNK : k) : 0;
             hipError_t e = fdk::run_step(L, io, B, T);
             if (e == hipSuccess) {
-                if (k + 1 < count && defer_advance) h->advance_pending = true;      // the next step's first kernel does it
+                // the next step's first kernel does it -- unless a piece predictor runs in between: its front reads the embedding rows
+                // through the device step counter, which must already stand at the piece's first step
+                if (k + 1 < count && defer_advance && !(h->hoist_chunk && (k + 1) % CHUNK == 0)) h->advance_pending = true;
                 else e = fdk::advance_step(L);
             }
             if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample: step %d failed: %s", k, hipGetErrorString(e));
@@ -1090,6 +1126,8 @@ static int resolve_call(fd_handle h, const fd_context::PendingCall &p, unsigned 
     *mask |= m;
     if (m == 0) return 0;
     h->redone_ring[h->redone_next++ % 16] = p.ticket;
+    if (p.lazy) ++h->n_calls_redone;
+    else { ++h->n_pieces_redone; h->call_fp32_mask |= *mask; }
     if (p.lazy) {
         const int rc = sample_core(h, p.args, *mask, p.ticket);
         return rc < 0 ? rc : 1;
@@ -1214,6 +1252,8 @@ static int sample_core(fd_handle h, const fd_context::SampleArgs &a, unsigned fo
         for (int first = 0; first < N; first += CHUNK) {
             const int count = std::min(CHUNK, N - first);
             const bool last = first + count == N;
+            ++h->n_pieces;
+            if (mask != 0) ++h->n_pieces_fp32;
             if (first > 0 && mask == 0) FD_HIP(h, hipMemcpyAsync(ws.xsave, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
             if ((rc = enqueue_steps(h, B, T, count, mask, /*inline_fallback=*/mask != 0, stream)) != FD_OK) return rc;
             if (mask != 0) continue;              // already on the safe path: nothing to look at
@@ -1242,6 +1282,7 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
     if (h) ids.swap(h->noise_ids);               // one-shot: fd_set_noise_streams applies to this call only, also when it fails below
     int rc = check_common(h, B, T, "fd_sample");
     if (rc != FD_OK) return rc;
+    if ((rc = follow_stream(h, (hipStream_t)stream_)) != FD_OK) return rc;
     // A lazily checked previous call (fallback = host, <= 8 steps) is looked at AFTER this call has enqueued its own work -- unless
     // this call cannot be lazy itself, or the workspace must grow first (that waits for the device anyway).
     const bool lazy = h->host_fallback && N >= 1 && N <= 8;
@@ -1277,6 +1318,8 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
     a.x_T = x_T; a.z = z; a.seed = seed; a.out = out; a.seq_out = seq_out; a.stream = (hipStream_t)stream_;
     a.ids.swap(ids);
     const long long ticket = ++h->ticket_counter;
+    h->n_pieces = h->n_pieces_redone = h->n_pieces_fp32 = 0;
+    h->call_fp32_mask = 0;
     rc = sample_core(h, a, 0u, ticket);
     const int rc_prev = finish_prev();
     h->last_B = B; h->last_T = T;                // (a redo of the previous call has just run with that call's shape)
@@ -1659,7 +1702,7 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
         return FD_OK;
     }
     if (k == "graph") { h->use_graph = on; return FD_OK; }
-    if (k == "profile") { h->profile = on; return FD_OK; }
+    if (k == "profile") { h->profile = (v == "events") ? 2 : (on ? 1 : 0); return FD_OK; }
     if (k == "taps") { h->keep_taps = on; return FD_OK; }
     FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: unknown option '%s'", key);
 }
@@ -1715,6 +1758,22 @@ int fd_bias_index(int layer, int out_ch)
 {
     if (layer < 0 || layer >= fd::LAYERS || out_ch < 0 || out_ch >= 2 * fd::C) return FD_ERR_INVALID;
     return fd::bias_index(layer, out_ch);
+}
+
+int64_t fd_get_counter(fd_handle h, const char *name)
+{
+    if (!h || !name) return FD_ERR_INVALID;
+    const std::string k(name);
+    if (k == "pieces_redone" || k == "fp32_mask") {      // the last piece of a long call may still be waiting for its check
+        const int rcs = settle(h);
+        if (rcs != FD_OK) return rcs;
+    }
+    if (k == "pieces") return h->n_pieces;
+    if (k == "pieces_redone") return h->n_pieces_redone;
+    if (k == "pieces_fp32") return h->n_pieces_fp32;
+    if (k == "fp32_mask") return (int64_t)h->call_fp32_mask;
+    if (k == "calls_redone") return h->n_calls_redone;
+    FD_FAIL(h, FD_ERR_INVALID, "fd_get_counter: unknown counter '%s'", name);
 }
 
 int fd_get_profile(fd_handle h, fd_kernel_stat *stats, int capacity)

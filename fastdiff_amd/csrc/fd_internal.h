@@ -1,6 +1,7 @@
 // fd_internal.h -- shared between the host side (fd_api.cpp, fd_weights.cpp) and the kernel files.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <map>
 #include <string>
@@ -158,7 +159,7 @@ struct fd_context {
     bool committed = false;
     bool fast[ST_COUNT];
     bool use_graph = true;
-    bool profile = false;
+    int profile = 0;                          // option "profile": 0 off | 1 the kernels' own begin / end timestamps | 2 ("events") stream events around each launch
     bool keep_taps = false;
     bool gemm_f16 = true;                     // kp_gemm on the fp16 matrix pipe with the 2-piece operand split
     bool lvc_f16 = true;                      // LVC layers (hop 64, 256) likewise
@@ -199,6 +200,12 @@ struct fd_context {
     std::vector<void *> mel_allocs;           // device memory behind `mel` (built on first use, freed at fd_destroy)
     int last_B = 0, last_T = 0;
     hipStream_t cap_stream = nullptr;
+    // Calls on one handle share the workspace, the embedding rows and the pending range check: they are ordered by the stream they run
+    // on.  When a caller moves to another stream (fd_forward / fd_sample), a pending check is settled on the old stream and the new
+    // stream waits for everything the old one still holds (follow_stream in fd_api.cpp).
+    hipStream_t last_stream = nullptr;
+    bool have_last_stream = false;
+    hipEvent_t ev_switch = nullptr;
     // option overlap = gemm: the predictor GEMM of blocks 1 and 2 runs on `side_stream` next to the LVC layers of blocks 0 and 1
     // (fork / join through events; inside a captured step the side stream joins the capture).  overlap_wg: its workgroups per CU.
     // The predictor (front + GEMM) sees the mel and the step embedding only -- never x -- so for a short schedule on a small batch all N
@@ -256,6 +263,10 @@ struct fd_context {
         SampleArgs args;
     } pending;
     long long ticket_counter = 0;            // one per fd_sample
+    // fd_get_counter: the last long call's 8-step pieces (enqueued / run again after a flag / enqueued with stages already on fp32 and
+    // with which), and the short calls run again as a whole since fd_create
+    long long n_pieces = 0, n_pieces_redone = 0, n_pieces_fp32 = 0, n_calls_redone = 0;
+    unsigned call_fp32_mask = 0;
     long long redone_ring[16] = {};          // tickets of the calls that had to be redone (0 = none), newest overwrite oldest
     unsigned redone_next = 0;
     int *flags_host = nullptr;               // pinned, 2 x 32 words: the sticky flags of the pending call(s)
@@ -305,15 +316,24 @@ hipError_t init_noise(const Launch &L, float *x, int64_t n, unsigned long long s
 hipError_t peak_normalize_int16(const Launch &L, const float *wav, int B, int64_t len, int16_t *pcm, const long long *valid_dev);
 }  // namespace fdk
 
-// profiling-aware launch helper
+// profiling-aware launch helper.  Option profile = 1: the launch goes through hipExtLaunchKernelGGL with a start and a stop event, which
+// receive the dispatch's own begin / end timestamps (what rocprofv3 --kernel-trace reports) -- nothing is put between two launches, so
+// the kernels run back to back as in the replayed graph.  profile = events: hipEventRecord in front of and behind each launch (two
+// barrier packets per kernel: the gaps let the previous kernel's dirty lines drain, the numbers come out 3-5 % shorter).
+bool fd_prof_stamps(const fdk::Launch &L, const char *name, hipEvent_t *e0, hipEvent_t *e1);
 void fd_prof_begin(const fdk::Launch &L, const char *name);
 void fd_prof_end(const fdk::Launch &L);
 
 #define FD_LAUNCH(L, name, kernel, grid, block, shmem, ...)                                  \
     do {                                                                                     \
-        fd_prof_begin(L, name);                                                              \
-        hipLaunchKernelGGL(kernel, grid, block, shmem, (L).stream, __VA_ARGS__);             \
-        fd_prof_end(L);                                                                      \
+        hipEvent_t ev0__ = nullptr, ev1__ = nullptr;                                         \
+        if (fd_prof_stamps(L, name, &ev0__, &ev1__)) {                                       \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, (L).stream, ev0__, ev1__, 0, __VA_ARGS__); \
+        } else {                                                                             \
+            fd_prof_begin(L, name);                                                          \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, (L).stream, __VA_ARGS__);         \
+            fd_prof_end(L);                                                                  \
+        }                                                                                    \
         hipError_t e__ = hipGetLastError();                                                  \
         if (e__ != hipSuccess) return e__;                                                   \
     } while (0)

@@ -2608,8 +2608,8 @@ static hipError_t launch_lvc(const Launch &L, const char *name, int n, int layer
             c->final_fused = false;
             if constexpr (HOP == 256 && DIL == 27) c->final_fused = c->fast[ST_FINAL] && !c->keep_taps && c->fuse_final;
             if constexpr (HOP == 256 && DIL == 27) {
-                if (c->final_fused)
-                    FD_LAUNCH(L, name, (k_lvc_h2<HOP, DIL, true>), dim3(((Ln + 255) / 256 + 7) / 8 * 8, B), dim3(256), 0, x_in, skip, x_out, kp,
+                if (c->final_fused)      // its own profile row: this variant never writes its 32 output channels
+                    FD_LAUNCH(L, "lvc_final_h256", (k_lvc_h2<HOP, DIL, true>), dim3(((Ln + 255) / 256 + 7) / 8 * 8, B), dim3(256), 0, x_in, skip, x_out, kp,
                               layer, reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]), w.blk[n].convs[layer].w,
                               w.blk[n].convs[layer].b, flag, T, c->step_lens, c->ws.eps_acc, reinterpret_cast<const float4 *>(w.final_fuse),
                               (const float4 *)nullptr, (const float *)nullptr, (int *)nullptr);

@@ -199,11 +199,21 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
     if not (on_device and return_device):
         mel_pin, pcm_pin = _pinned_staging(model, 0 if on_device else b_max * 80 * t_max, 0 if return_device else b_max * t_max * hop)
         mel_np = [m.numpy() for m in mel_pin]      # the collater writes the batch straight into the pinned buffer
+    mel_up = [None, None]          # event behind the upload that last read mel_pin[i]: the collater waits for it before writing there again
     pending = None                 # (event, pinned PCM view, names, lens, ticket, wav) of the micro-batch still on its way to the host
     # library option fallback = "host": the range check of a sample call is looked at by the NEXT call, after that one has enqueued
     # itself (FastDiff.settle); until then the waveform and everything computed from it is provisional
     host_check = getattr(model, "_options", {}).get("fallback") == "host"
-    on_device_results = []         # return_device: (ticket, wav, names, lens) of every micro-batch
+    prev_dev = None                # return_device: (ticket, wav, names, lens) of the micro-batch nobody has settled yet
+
+    def settle_on_device(p):
+        # the library remembers a bounded number of redone tickets (fd_sample_settle), so a micro-batch is settled as soon as the
+        # next sample() has looked at it (no wait by then) and not at the end of the job
+        ticket, wav, names, lens = p
+        if model.settle(ticket):                     # run again on fp32: so is its epilogue
+            pcm = model.peak_normalize_int16(wav, valid=[t * hop for t in lens])
+            for b, (name, t) in enumerate(zip(names, lens)):
+                out[name] = pcm[b, : t * hop]
 
     def collect(p):
         done, host, names, lens, ticket, wav = p
@@ -220,6 +230,8 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
         if on_device:
             mels, lens, names = _collate_on_device(batch_items, drop_last_frame)
         else:
+            if mel_up[k & 1] is not None:            # the upload of micro-batch k - 2 read this pinned buffer
+                mel_up[k & 1].synchronize()
             mels, lens, names = collate_test_batch(batch_items, drop_last_frame, out=mel_np[k & 1])
         if mels is None:
             continue
@@ -227,6 +239,8 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
         B, _, T = mels.shape
         if not on_device:
             mels = mel_pin[k & 1][: B * 80 * T].view(B, 80, T).cuda(non_blocking=True)
+            mel_up[k & 1] = torch.cuda.Event()
+            mel_up[k & 1].record()
         with torch.no_grad():
             wav = model.sample(mels, rows, ddim=False, seed=seed, lens=lens, stream_ids=[uid_of[n] for n in names], defer_check=host_check)
         ticket = getattr(model, "last_ticket", 0)
@@ -235,7 +249,9 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
         if return_device:
             for b, (name, t) in enumerate(zip(names, lens)):
                 out[name] = pcm[b, : t * hop]
-            on_device_results.append((ticket, wav, names, lens))
+            if host_check and prev_dev is not None:
+                settle_on_device(prev_dev)
+            prev_dev = (ticket, wav, names, lens)
             k += 1
             continue
         host = pcm_pin[k & 1][: B * T * hop].view(B, T * hop)
@@ -248,12 +264,8 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
         k += 1
     if pending is not None:
         collect(pending)
-    if host_check:
-        for ticket, wav, names, lens in on_device_results:
-            if model.settle(ticket):
-                pcm = model.peak_normalize_int16(wav, valid=[t * hop for t in lens])
-                for b, (name, t) in enumerate(zip(names, lens)):
-                    out[name] = pcm[b, : t * hop]
+    if host_check and prev_dev is not None:
+        settle_on_device(prev_dev)
     return out
 
 

@@ -187,9 +187,12 @@ class FastDiff(nn.Module):
         and lens[b] frames long (its first lens[b]*256 samples are exactly that result; the rest of its row is unspecified).
         stream_ids: optional [B] integers (fd_set_noise_streams): utterance b draws its noise from Philox stream (seed, stream_ids[b])
         over its own samples, i.e. independently of its place in the batch.
-        defer_check: with the library option fallback = "host" (set_option; the default is "graph") the result is final only after
-        check() (fd_sample_check: one stream synchronisation and, rarely, a second pass on the fp32 kernels); sample() runs it
-        before returning unless told to defer -- then call check(), or any other method of the module, before reading the tensor."""
+        defer_check: this class runs the library with option fallback = "host" (self._options; the C ABI's own default is "graph"): a
+        result is final only after its range check has been looked at (fd_sample_check: one stream synchronisation and, rarely, a
+        second pass on the fp32 kernels).  sample() does that before returning unless told to defer.  A deferred call is settled ONLY by
+        check(), settle(ticket), forward(), the next sample() (which looks at it after enqueuing itself), set_option and a weight
+        upload -- NOT by peak_normalize_int16 / mel_spectrogram, which run on a provisional waveform without waiting: read their output
+        only after check() / settle(last_ticket) returned False, and compute it again when they returned True."""
         B = condition.shape[0]
         self._require_inference(condition, condition)
         condition = condition.contiguous().float()
@@ -303,6 +306,11 @@ class FastDiff(nn.Module):
         buf = np.empty(n, np.float32)
         _capi.check(lib, self._handle, lib.fd_read_tap(self._handle, name.encode(), buf.ctypes.data, n), "fd_read_tap")
         return buf
+
+    def counter(self, name):
+        """fd_get_counter: "pieces" / "pieces_redone" / "pieces_fp32" / "fp32_mask" of the last long sample() call, "calls_redone"."""
+        lib = _capi.load()
+        return int(_capi.check(lib, self._handle, lib.fd_get_counter(self._handle, name.encode()), "fd_get_counter"))
 
     def profile(self, reset=False):
         lib = _capi.load()

@@ -9,7 +9,10 @@
  * Conventions
  *   - every function returns 0 on success, a negative fd_status on failure; fd_last_error() gives text.
  *   - a handle is bound to one device and is NOT thread safe (one handle per GPU/stream, like one
- *     reference process per GPU under mp.spawn, utils/trainer.py:94-107).
+ *     reference process per GPU under mp.spawn, utils/trainer.py:94-107).  Its calls share one workspace and are ordered by the
+ *     stream they run on: when fd_forward / fd_sample arrive on another stream than the previous call, a pending range check is
+ *     settled first and the new stream is made to wait for the old one (an event), so consecutive calls may change streams but
+ *     never overlap.
  *   - device pointers are caller-owned; all work is enqueued asynchronously on `stream`
  *     (a hipStream_t passed as void*; NULL = the default stream).  No hidden synchronisation except
  *     in fd_create / fd_destroy / fd_commit_weights / fd_read_tap / workspace growth.
@@ -118,9 +121,10 @@ FD_API int fd_sample(fd_handle h, const float *mel, int B, int T, const int *len
  * per reverse step less); whether an operand left the fp16 range is then known on the HOST, after the work has run:
  *   fd_sample_check waits for the last fd_sample of this handle and, if one of its kernels raised a range flag, runs it again from
  *   the saved start with the flagged stages on their fp32 kernels.  Returns 1 if the call was redone, 0 if not, < 0 on error.
- * Until it has returned, `out` / `seq_out` of that fd_sample are provisional and its `z` must stay valid.  Every later call on the
- * handle settles a pending check first, so nothing is ever lost -- but a caller that reads `out` itself must call fd_sample_check
- * before.  Schedules longer than 8 steps are checked (with a stream synchronisation) every 8 steps inside fd_sample.
+ * Until it has returned, `out` / `seq_out` of that fd_sample are provisional and its `z` must stay valid.  fd_forward, fd_sample (see
+ * the pipelined form below), fd_commit_weights, fd_set_option, fd_read_tap and fd_destroy settle a pending check first, so nothing
+ * is ever lost; fd_peak_normalize_int16[_ragged] and fd_mel_spectrogram do NOT (since round 3: they run on the provisional result
+ * without waiting) -- a caller that reads `out`, or anything computed from it, must call fd_sample_check / fd_sample_settle before.  Schedules longer than 8 steps are checked (with a stream synchronisation) every 8 steps inside fd_sample.
  * With the default ("graph") fd_sample_check is a no-op returning 0.
  *
  * Pipelined form (round 3; schedules of up to 8 steps, i.e. one graph launch per call): the next fd_sample on the handle does NOT
@@ -247,6 +251,15 @@ typedef struct fd_kernel_stat {
 } fd_kernel_stat;
 FD_API int fd_get_profile(fd_handle h, fd_kernel_stat *stats, int capacity);
 FD_API int fd_reset_profile(fd_handle h);
+
+/* Bookkeeping of the host-checked range fallback (option "fallback" = "host").  Names:
+ *   "pieces"         8-step pieces the last fd_sample of more than 8 steps was enqueued as (0 for a shorter call);
+ *   "pieces_redone"  of those, the pieces that raised a range flag and were run again from the saved x (settles a pending last piece);
+ *   "pieces_fp32"    of those, the pieces enqueued with stages already on their fp32 kernels (after an earlier piece had flagged them);
+ *   "fp32_mask"      the flag words (bit i = word i of "range_flags") those later pieces ran on fp32 -- sticky over the call;
+ *   "calls_redone"   fd_sample calls of up to 8 steps run again as a whole since fd_create.
+ * Returns the value (>= 0) or a negative status. */
+FD_API int64_t fd_get_counter(fd_handle h, const char *name);
 
 FD_API const char *fd_version(void);
 

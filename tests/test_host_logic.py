@@ -307,6 +307,16 @@ def test_roofline_numerators_are_the_surveys_algorithmic_figures():
     for name, hop, r in (("lvc_up_h64", 64, 8), ("lvc_up_h256", 256, 4)):
         nb = bench.kernel_model(name, 1, 864)[1]
         assert nb == 4.0 * 864 * (64 * hop + 32 * hop // r + 6208) and nb < bench.kernel_model("lvc_layer_h%d" % hop, 1, 864)[1]
+    # the last layer of the last block with final_conv inside never writes its 32 output channels: x + skip + record in, one channel of
+    # sums out (round-3 VERDICT: 632 MB at B=8, not the plain layer's 851 MB)
+    nb = bench.kernel_model("lvc_final_h256", 8, 864)[1]
+    assert nb == 4.0 * 8 * 864 * (64 * 256 + 6208) + 4.0 * 8 * 864 * 256 and abs(nb / 1e6 - 631.7) < 0.5
+    assert bench.unfused_bytes("lvc_final_h256", 8, 864) == bench.kernel_model("lvc_layer_h256", 8, 864)[1]
+    assert bench.unfused_bytes("lvc_up_h256", 1, 864) == bench.kernel_model("lvc_layer_h256", 1, 864)[1] + 4.0 * 864 * (32 * 64 + 32 * 256)
+    # the f16x2 GEMM: algorithmic flops in the model, the three passes it executes under their own name
+    assert bench.executed_flops("kp_gemm_f16x2", 8, 864) == 3 * bench.kernel_model("kp_gemm_f16x2", 8, 864)[2] == 3 * 3 * 2.0 * 24832 * 192 * 8 * 864
+    assert bench.kernel_model("kp_gemm_f16x2", 8, 864)[2] == bench.kernel_model("kp_gemm", 8, 864)[2]
+    assert [bench.template_group(k) for k in ("lvc_layer_h256", "lvc_final_h256", "lvc_up_h256", "lvc_up_h64", "kp_gemm_f16x2")] == ["lvc_h256"] * 3 + ["lvc_h64", "kp_gemm_f16x2"]
     assert bench.HBM_PEAK_GBS == 8000.0
 
 

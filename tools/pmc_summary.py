@@ -23,9 +23,11 @@ BENCH_NAME = {"k_kp_gemm": "kp_gemm_fp32_fallback", "k_kp_gemm_h2": "kp_gemm_f16
 
 
 def fam(name):
-    m = re.search(r"k_lvc_h2<(\d+), *\d+, *\w+, *(\d+)", name)   # the fp16-pipe LVC layer (hop 64, 256); last argument: the fused up-sampler's ratio
-    if m:
-        return ("lvc_up_h" if int(m.group(2)) > 0 else "lvc_layer_h") + m.group(1)
+    m = re.search(r"k_lvc_h2<(\d+), *\d+, *(\w+), *(\d+)", name)   # the fp16-pipe LVC layer (hop 64, 256): <HOP, DIL, FINAL, UP = the fused up-sampler's ratio>
+    if m:                                                            # one row per instantiation kind, as in bench.py's `kernels` table
+        if int(m.group(3)) > 0:
+            return "lvc_up_h" + m.group(1)
+        return ("lvc_final_h" if m.group(2) in ("true", "1") else "lvc_layer_h") + m.group(1)
     m = re.search(r"k_lvc_h2<(\d+)", name)
     if m:
         return "lvc_layer_h" + m.group(1)
