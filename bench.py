@@ -129,11 +129,81 @@ def template_group(fam_name):
     return fam_name
 
 
-def measure_roofline(model, mel, rows, B, T, nsteps, lens=None):
-    """Profiled pass with the graph off: every launch goes through hipExtLaunchKernelGGL with start / stop events that receive the
-    dispatch's own begin / end timestamps (library option profile = 1; what rocprofv3 --kernel-trace reads), the launches back to
-    back on the launch stream as in the replayed graph.  FD_BENCH_PROFILE=events selects the older form (hipEventRecord around each
-    launch: the gaps it opens let the previous kernel's stores drain, 3-5 % shorter readings)."""
+ROCPROF_NAME = {"k_kp_gemm_h2": "kp_gemm_f16x2", "k_final_acc": "final_update", "k_first_conv": "first_conv", "k_kp_front_h2": "kp_front",
+                "k_advance": "advance_step", "k_init_noise": "init_noise", "k_embed_mlp": "embed", "k_embed_fct": "embed_fct", "k_kp_gemm": "kp_gemm",
+                "k_final": "final_conv_update", "k_h_split": "h_split"}
+
+
+def rocprof_row(name):
+    """Kernel name of a rocprofv3 trace -> the row it has in this file's `kernels` table (None: not one of this library's kernels)."""
+    import re
+    m = re.search(r"k_lvc_h2<(\d+), *\d+, *(\w+), *(\d+)", name)      # <HOP, DIL, FINAL, UP>
+    if m:
+        if int(m.group(3)) > 0:
+            return "lvc_up_h" + m.group(1)
+        return ("lvc_final_h" if m.group(2) in ("true", "1") else "lvc_layer_h") + m.group(1)
+    if "k_lvc_h8m<" in name:
+        return "lvc_layer_h8"
+    m = re.search(r"k_dblock_h2<(\d+)", name)
+    if m:
+        return "dblock_f" + m.group(1)
+    m = re.search(r"k_convt_h2<(\d+)", name)
+    if m:
+        return "convt_r" + m.group(1)
+    m = re.search(r"fdk\w*::(k_\w+)", name)
+    return ROCPROF_NAME.get(m.group(1), m.group(1)) if m else None
+
+
+def rocprof_graph_replay(args, calls=5):
+    """The timed loop of this very command (same batch, frames, schedule, options; graph replays, nothing else) run once more in a
+    child process under `rocprofv3 --kernel-trace --stats`: {row: [launches, total ms]} + the number of sample calls, or None when
+    rocprofv3 is not there / failed.  These are the durations a committed kernel_stats.csv of the command holds."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="fd_bench_prof_", dir="/tmp")
+    warm = 2
+    cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "-o", "kt", "--", sys.executable, os.path.abspath(__file__),
+           "--steps", str(calls), "--warmup", str(warm), "--batch", str(args.batch), "--frames", str(args.frames), "--nsteps", str(args.nsteps)]
+    for kv in args.opt:
+        cmd += ["--opt", kv]
+    env = dict(os.environ, FD_BENCH_CHILD="1", TMPDIR="/tmp")
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
+        files = glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return {"error": "rocprofv3 child rc=%d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
+        fam = {}
+        for row in csv.DictReader(open(files[0])):
+            k = rocprof_row(row["Name"])
+            if k is None:
+                continue
+            f = fam.setdefault(k, [0, 0.0])
+            f[0] += int(row["Calls"])
+            f[1] += float(row["TotalDurationNs"]) * 1e-6
+        keep = os.environ.get("FD_BENCH_KEEP_STATS")
+        if keep:
+            shutil.copy(files[0], keep)
+        return {"fam": fam, "calls": warm + calls}
+    except Exception as e:      # noqa: BLE001
+        return {"error": repr(e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def measure_roofline(model, mel, rows, B, T, nsteps, lens=None, replay=None):
+    """Per-kernel durations of the step, two ways:
+    * `replay` (rocprof_graph_replay): the kernels inside the REPLAYED hipGraph of the timed loop, from a rocprofv3 kernel trace of
+      a child run -- the step as it is timed, and what a committed rocprofv3 summary of this command shows.  `roofline` and the
+      `kernels` table are computed from these when they are there;
+    * in this process, graph off: every launch through hipExtLaunchKernelGGL with start / stop events that receive the dispatch's
+      own begin / end timestamps (library option profile = 1), launches back to back on the launch stream.  Reported beside the
+      first as `avg_us_eager` (3-7 % shorter: each timestamped dispatch completes -- caches written back -- before the next starts).
+      FD_BENCH_PROFILE=events selects hipEventRecord around each launch instead."""
     reps = 3
     mode = os.environ.get("FD_BENCH_PROFILE", "1")
     model.set_option("profile", mode)
@@ -148,11 +218,18 @@ def measure_roofline(model, mel, rows, B, T, nsteps, lens=None):
         stats = model.profile(reset=True)
     finally:
         model.set_option("profile", "0")
-    fam = {}
+    eager = {}
     for name, (launches, ms) in stats.items():
-        f = fam.setdefault(family(name), [0, 0.0])
+        f = eager.setdefault(family(name), [0, 0.0])
         f[0] += launches
         f[1] += ms
+    timing_eager = ("kernel begin/end timestamps through hipExtLaunchKernelGGL start/stop events, launches back to back, graph off" if mode == "1"
+                    else "hipEventRecord around each launch, graph off")
+    if replay and replay.get("fam"):
+        fam, reps = replay["fam"], replay["calls"]
+        timing = "rocprofv3 --kernel-trace of the timed loop re-run in a child process: the kernels inside the replayed hipGraph (%d sample calls)" % reps
+    else:
+        fam, timing = eager, timing_eager
     total_ms = sum(v[1] for v in fam.values())
     table = {}
     for name, (launches, ms) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
@@ -168,6 +245,8 @@ def measure_roofline(model, mel, rows, B, T, nsteps, lens=None):
             ex = executed_flops(name, B, T)
             if ex:
                 e["TFLOPs_executed"] = round(ex / (avg_ms * 1e-3) / 1e12, 2)
+        if fam is not eager and name in eager:
+            e["avg_us_eager"] = round(eager[name][1] / eager[name][0] * 1e3, 2)
         table[name] = e
     # the dominant kernel = the kernel TEMPLATE with the largest share of the step; its roofline is quoted on the plain instantiation
     groups = {}
@@ -188,8 +267,12 @@ def measure_roofline(model, mel, rows, B, T, nsteps, lens=None):
     roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
     roof["avg_launch_us"] = round(avg_s * 1e6, 2)
     roof["algorithmic_MB_per_launch"] = round((nbytes or 0.0) / 1e6, 1)
-    roof["timing"] = ("kernel begin/end timestamps through hipExtLaunchKernelGGL start/stop events, launches back to back, graph off" if mode == "1"
-                      else "hipEventRecord around each launch, graph off")
+    roof["timing"] = timing
+    if fam is not eager and dom in eager:
+        avg_e = eager[dom][1] / eager[dom][0] * 1e-3
+        roof["eager"] = {"avg_launch_us": round(avg_e * 1e6, 2), "frac": round((nbytes or 0.0) / avg_e / 1e9 / HBM_PEAK_GBS, 4), "timing": timing_eager}
+    if replay and replay.get("error"):
+        roof["replay_error"] = replay["error"]
     roof["template_share_of_step"] = round(groups[dom_group] / total_ms, 4)
     if len(members) > 1:
         roof["kernel_is"] = ("the plain instantiation of the step's dominant kernel template (%s: %s); each instantiation with its own byte "
@@ -447,7 +530,7 @@ def b1_object(model, mel, rows, steps):
     roof, table = measure_roofline(model, m1, rows, 1, T, len(rows))
     top = {k: {"avg_us": v["avg_us"], "share": v["share"], **({"hbm_frac": v["hbm_frac"]} if "hbm_frac" in v else {})} for k, v in list(table.items())[:8]}
     return {"ms_per_step": round(ms, 4), "value": round(T * HOP / SR / (ms / 1e3), 2), "unit": "x real-time", "batch": 1, "frames": T,
-            "roofline": {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us") if k in roof},
+            "roofline": {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "timing") if k in roof},
             "lvc_all_12_launches_frac_minimal_bytes": roof.get("lvc_all_12_launches", {}).get("frac_minimal_bytes"), "kernels_top": top}
 
 
@@ -566,13 +649,25 @@ def project_sharded(args, model, items, t_full, dev):
         shares.append(t_r)
     whole = torch.empty(sum(lens) * HOP, dtype=torch.int16, device=dev)
     t_back, _ = timed(lambda: whole.cpu())
-    t_share, t_fixed = max(shares), t_prep + t_back
+    # the job's start-up message (names, noise-stream ids, lengths: pickle + two broadcasts + unpickle), timed on a gloo group of R
+    # processes on this host -- a term of its own: against a per-rank share of ~10 ms it is not negligible
+    bcast = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import broadcast_cost
+        bcast = broadcast_cost.measure(world=R, n_items=len(items), reps=100)
+    except Exception as e:      # noqa: BLE001
+        bcast = {"error": repr(e)}
+    t_bcast = (bcast.get("median_ms") or 0.0) * 1e-3
+    t_share, t_fixed = max(shares), t_prep + t_back + t_bcast
     return {"projected_ranks": R, "is_a_projection": True, "t_full_1gpu_ms": round(t_full * 1e3, 3),
             "t_share_ms": {"max": round(t_share * 1e3, 3), "min": round(min(shares) * 1e3, 3)},
-            "t_fixed_rank0_ms": {"pack_and_upload": round(t_prep * 1e3, 3), "job_pcm_to_host": round(t_back * 1e3, 3)},
+            "t_fixed_rank0_ms": {"pack_and_upload": round(t_prep * 1e3, 3), "job_pcm_to_host": round(t_back * 1e3, 3),
+                                 "startup_broadcast_object_list": round(t_bcast * 1e3, 3)},
+            "startup_broadcast": bcast,
             "projected_ms_per_job": round((t_fixed + t_share) * 1e3, 3),
             "projected_efficiency": round(t_full / (R * (t_fixed + t_share)), 4),
-            "not_included": "RCCL transport of <= 2.2 MB out / 3.5 MB back per peer, broadcast of names/lengths"}
+            "not_included": "RCCL transport of <= 2.2 MB out / 3.5 MB back per peer over xGMI (the broadcast of names / ids / lengths is in, as timed on gloo)"}
 
 
 def main():
@@ -585,6 +680,7 @@ def main():
     ap.add_argument("--frames", type=int, default=864)
     ap.add_argument("--nsteps", type=int, default=None, help="reverse steps N (3,4,6,8,200,1000); default 4 (config4: 6)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-replay-profile", action="store_true", help="roofline from the in-process timestamped launches only (no rocprofv3 child run of the timed loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (cpu_baseline and parity)")
     ap.add_argument("--no-fp32-pipe", action="store_true")
     ap.add_argument("--no-b1", action="store_true", help="skip the one-utterance-per-call (reference CLI mode) object")
@@ -691,6 +787,8 @@ def main():
             barrier()
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
+        if os.environ.get("FD_BENCH_CHILD") == "1":      # rocprof_graph_replay's child: the timed loop only
+            return
         assert torch.isfinite(out if lens is None else torch.stack([out[b, :, : lens[b] * HOP].abs().max() for b in range(B)])).all()
         total_frames = world * valid_frames        # (ragged: rank 0's draw stands for every rank)
         padded_frames = world * B * T
@@ -698,9 +796,11 @@ def main():
         workload = ("BASELINE configs[1]: LJSpeech FastDiff.yaml shape, batch=%d utterances of 80x%d mel per GPU, "
                     "N=%d, HIP LVC/dilated-conv kernels + hipGraph sampler" % (B, T, N))
     t = torch.tensor([elapsed], dtype=torch.float64, device=None if oversub else dev)
+    t_min = t.clone()
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        dist.all_reduce(t_min, op=dist.ReduceOp.MIN)      # a straggler shows as a gap between the two
+    elapsed, elapsed_min = float(t.item()), float(t_min.item())
     ms_per_step = elapsed / args.steps * 1e3
     audio_s = total_frames * HOP / SR
     line = {
@@ -709,6 +809,7 @@ def main():
         "unit": "x real-time",
         "samples_per_s": round(padded_frames * HOP / (ms_per_step / 1e3), 1),
         "n_gpus": (min(rccl_ranks, n_dev) if oversub else rccl_ranks) if world > 1 else 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "ms_per_step_ranks": {"max": round(ms_per_step, 4), "min": round(elapsed_min / args.steps * 1e3, 4), "ranks": world},
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": workload,
                    "batch_per_gpu": B, "frames": T, "reverse_steps": N,
@@ -734,7 +835,8 @@ def main():
             line["value_host_to_host"] = line["host_inclusive"]["value"]
             line["ms_per_step_host_to_host"] = line["host_inclusive"]["ms_per_step"]
         if not args.no_roofline:
-            roof, table = measure_roofline(model, mel, rows, B, T, N, use_lens)
+            replay = None if (args.no_replay_profile or args.no_graph or args.ragged) else rocprof_graph_replay(args)
+            roof, table = measure_roofline(model, mel, rows, B, T, N, use_lens, replay)
             line["roofline"] = roof
             line["kernels"] = table
         if B > 1 and not args.ragged and not args.no_b1:

@@ -13,7 +13,8 @@ Reference behaviour restated (none of this is on the GPU path, so plain torch/nu
     The reference CLI runs B = 1 (config `max_sentences`); batching is this path's extension: the batch goes down with its
     `lens`, so every item is computed exactly as if it ran alone (and the padding costs nothing), then cropped to its length.
 
-Entry points: load_mel_inputs, load_wav_inputs (device mel front-end), collate_test_batch, distributed_sampler_indices, synthesize, save_wavs and a small CLI
+Entry points: load_mel_inputs, load_wav_inputs (device mel front-end), collate_test_batch, distributed_sampler_indices, synthesize, test_step
+(the mirror of FastDiffTask.test_step itself), save_wavs and a small CLI
 (`python -m fastdiff_amd.infer --test_input_dir D --out_dir O [--N 4] [--ckpt model.ckpt]`).
 """
 import argparse
@@ -270,7 +271,7 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
 
 
 def synthesize_sharded(model, items, n_steps: int = 4, max_batch: int = 8, seed: int = 0, drop_last_frame: bool = True, src: int = 0,
-                       device=None) -> Dict[str, np.ndarray]:
+                       device=None, force_collectives: int = 0) -> Dict[str, np.ndarray]:
     """BASELINE config 4 as north_star words it: rank `src` holds all utterances (items; None elsewhere) -> length-balanced
     partition (shard.partition_utterances) -> scatter of the mels -> every rank vocodes its share in padded micro-batches on its
     own GPU -> gather of the int16 PCM on `src`, which returns item_name -> PCM (the other ranks return {}).  The process group
@@ -278,9 +279,13 @@ def synthesize_sharded(model, items, n_steps: int = 4, max_batch: int = 8, seed:
     group (one process) this is synthesize().
     With `device` set the data crosses PCIe exactly twice: the mels go up once on `src` (inside the scatter), the scattered mels are
     collated on the GPU they arrive on, the PCM stays on the device through the gather, and `src` brings the whole job back with ONE
-    device-to-host copy."""
+    device-to-host copy.
+    force_collectives = R > 1 in a process group of ONE rank (a box with a single GPU): the job still takes the multi-rank route --
+    the broadcast of names / ids / lengths, a partition into R parts, and parts 1 .. R-1 scattered and gathered as packed messages
+    from this rank to itself through the backend (shard loopback) -- so every line a real peer would execute runs on RCCL too."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    loop = int(force_collectives) if (dist.is_available() and dist.is_initialized() and dist.get_world_size() == 1) else 0
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and loop < 2):
         return synthesize(model, items, n_steps, max_batch, seed, drop_last_frame)
     rank, world = dist.get_rank(), dist.get_world_size()
     meta = [None]
@@ -290,13 +295,13 @@ def synthesize_sharded(model, items, n_steps: int = 4, max_batch: int = 8, seed:
         meta = [([it["item_name"] for _, it in kept], [int(it.get("uid", i)) for i, it in kept], [int(m.shape[0]) for m in mels])]
     dist.broadcast_object_list(meta, src=src)          # names, noise-stream ids and lengths in one message
     names, uids, lens = meta[0]
-    parts = shard.partition_utterances(lens, world)
-    mine, _ = shard.scatter_utterances(mels if rank == src else None, parts, src=src, device=device, lens=lens, frames_first=True)
+    parts = shard.partition_utterances(lens, loop or world)
+    mine, _ = shard.scatter_utterances(mels if rank == src else None, parts, src=src, device=device, lens=lens, frames_first=True, loopback=bool(loop))
     on_gpu = device is not None and torch.device(device).type == "cuda"
     local = [{"item_name": str(i), "mel": m, "len": m.shape[0], "uid": uids[i]} for i, m in mine]
     pcm = synthesize(model, local, n_steps, max_batch, seed, drop_last_frame=False, return_device=on_gpu)
     wavs = [(i, pcm[str(i)] if on_gpu else torch.from_numpy(pcm[str(i)])) for i, _ in mine]
-    out = shard.gather_waveforms(wavs, lens, parts, hop=model.hop_length, dst=src, device=device, dtype=torch.int16)
+    out = shard.gather_waveforms(wavs, lens, parts, hop=model.hop_length, dst=src, device=device, dtype=torch.int16, loopback=bool(loop))
     if rank != src:
         return {}
     if not on_gpu:
@@ -307,6 +312,47 @@ def synthesize_sharded(model, items, n_steps: int = 4, max_batch: int = 8, seed:
     flat = torch.cat([o.reshape(-1) for o in out]).cpu().numpy()
     offs = np.concatenate([[0], np.cumsum(sizes)])
     return {names[i]: flat[offs[i]: offs[i + 1]] for i in range(len(names))}
+
+
+def test_step(model, sample: dict, hparams: dict, diffusion_hyperparams=None, gen_dir: str = None, noise_source: str = "device",
+              seed=None) -> Dict[str, np.ndarray]:
+    """`FastDiffTask.test_step(sample, batch_idx)` (modules/FastDiff/task/FastDiff.py:60-119) around the HIP sampler, statement for
+    statement: the schedule is hparams['noise_schedule'] when set (a list becomes a FloatTensor, :65-68), else picked by
+    hparams['N'] (:70-93: 1000 / 200 linspaces, the literal lists for 8 / 6 / 4 / 3, a missing N -> 4 with the reference's message,
+    anything else NotImplementedError); ONE sampling_given_noise_schedule call of size (1, 1, T * hop_size) on sample['mels'] (:98-103);
+    every predicted waveform divided by its own peak (:110,115) and written through save_wav = * 32767 -> int16 (utils/audio.py:11-16)
+    as `<gen_dir>/<item_name>_pred.wav`; with ground-truth waveforms in sample['wavs'] also `<item_name>_gt.wav`, normalised the same
+    way (:113-117).  Returns item_name -> int16 PCM of the prediction.
+    sample: {"mels": [1, 80, T] tensor, "wavs": [] or [1, 1, L] tensor, "item_name": [name]}, as the test-time collater builds it
+    (collate_test_batch; the reference CLI runs max_sentences = 1, base.yaml:53, and the size above is only valid for one item).
+    gen_dir: where the files go (the reference derives it from work_dir / global_step / gen_dir_name, :104; None = write nothing).
+    noise_source "device" (Philox on the GPU, `seed`) or "reference" (std_normal on the CPU generator in the reference's order: a
+    seeded run then draws the reference's random stream)."""
+    from . import sampler
+    mels, y = sample["mels"], sample["wavs"]
+    schedule = schedules.noise_schedule_for(hparams.get("N"), hparams.get("noise_schedule", ""))
+    if isinstance(schedule, list):
+        schedule = torch.FloatTensor(schedule)
+    if diffusion_hyperparams is None:
+        diffusion_hyperparams = schedules.training_hyperparams()
+    audio_length = mels.shape[-1] * hparams["hop_size"]
+    y_ = sampler.sampling_given_noise_schedule(model, (1, 1, audio_length), diffusion_hyperparams, schedule, condition=mels.cuda(), ddim=False,
+                                               return_sequence=False, noise_source=noise_source, seed=seed)
+    if gen_dir is not None:
+        os.makedirs(gen_dir, exist_ok=True)
+    out: Dict[str, np.ndarray] = {}
+    pcm = model.peak_normalize_int16(y_).cpu().numpy()            # wav_pred / wav_pred.abs().max(), then save_wav's * 32767 -> int16
+    gts = y if len(y) else [None] * len(sample["item_name"])
+    for idx, (wav_gt, item_name) in enumerate(zip(gts, sample["item_name"])):
+        out[item_name] = pcm[idx].reshape(-1)
+        if gen_dir is None:
+            continue
+        from scipy.io import wavfile
+        if wav_gt is not None:
+            gt = model.peak_normalize_int16(wav_gt.reshape(1, 1, -1).cuda().float()).cpu().numpy().reshape(-1)
+            wavfile.write(f"{gen_dir}/{item_name}_gt.wav", hparams["audio_sample_rate"], gt)
+        wavfile.write(f"{gen_dir}/{item_name}_pred.wav", hparams["audio_sample_rate"], out[item_name])
+    return out
 
 
 def save_wavs(pcm: Dict[str, np.ndarray], out_dir: str, sample_rate: int = 22050) -> List[str]:

@@ -58,6 +58,18 @@ def _exchange(ops):
     two ranks sharing one GPU in the tests) go through host copies here, so the callers stay the same for both backends."""
     if not ops:
         return
+    if dist.get_backend(ops[0].group) == "gloo":
+        # gloo has no pair from a rank to itself (RCCL does): messages to self are matched in posting order and copied
+        me = dist.get_rank()
+        mine = [op for op in ops if op.peer == me]
+        if mine:
+            sends, recvs = [op for op in mine if op.op is dist.isend], [op for op in mine if op.op is dist.irecv]
+            assert len(sends) == len(recvs)
+            for a, b in zip(sends, recvs):
+                b.tensor.copy_(a.tensor)
+            ops = [op for op in ops if op.peer != me]
+            if not ops:
+                return
     if dist.get_backend(ops[0].group) == "gloo" and any(op.tensor.is_cuda for op in ops):
         host = [op.tensor.cpu() if op.op is dist.isend else torch.empty(op.tensor.shape, dtype=op.tensor.dtype) for op in ops]
         for req in dist.batch_isend_irecv([dist.P2POp(op.op, h, op.peer, op.group, op.tag) for op, h in zip(ops, host)]):
@@ -116,14 +128,18 @@ def pack_messages(mels: Sequence[torch.Tensor], parts: List[List[int]], device=N
 
 
 def scatter_utterances(mels: Sequence[torch.Tensor], parts: List[List[int]], src: int = 0, device=None, lens: Sequence[int] = None,
-                       frames_first: bool = False):
+                       frames_first: bool = False, loopback: bool = False):
     """Rank `src` holds all mels; afterwards every rank holds its own (index, mel) list.
     Lengths travel first as one small broadcast (skipped when the caller already distributed them: `lens`); then ONE packed
     message per peer (its utterances back to back, in the order of parts[r]) in a single grouped send/recv -- at most world-1
     messages leave `src`, whatever the number of utterances.  Layout: [80, T_i] tensors by default; frames_first = the on-disk
     layout [T_i, 80] (dataset_utils.py:186-204), which saves the host transposition -- the receiver's collater transposes on the
-    device.  Returns (own (index, mel) list, all lengths)."""
+    device.  Returns (own (index, mel) list, all lengths).
+    loopback (a world of ONE rank, `parts` of any length): parts[1:] are "virtual peers" -- their packed messages go through the
+    backend's grouped send/recv from this rank to itself and are unpacked from the receive buffers, so the transport and the
+    packing / unpacking of a multi-rank job run on a box with a single GPU; the rank ends up with every utterance."""
     rank, world = dist.get_rank(), dist.get_world_size()
+    assert not loopback or world == 1, "loopback is the single-rank stand-in for peers"
     n = sum(len(p) for p in parts)
     t_axis = 0 if frames_first else -1
     if lens is None:
@@ -144,6 +160,10 @@ def scatter_utterances(mels: Sequence[torch.Tensor], parts: List[List[int]], src
 
     if rank == src:
         msgs = pack_messages(mels, parts, device)
+        if loopback:
+            back = {r: torch.empty_like(msgs[r]) for r in range(1, len(parts)) if parts[r]}
+            _exchange([op for r, b in back.items() for op in (dist.P2POp(dist.isend, msgs[r], src), dist.P2POp(dist.irecv, b, src))])
+            return unpack(msgs[0], parts[0]) + [m for r, b in back.items() for m in unpack(b, parts[r])], lens_l
         _exchange([dist.P2POp(dist.isend, msgs[r], r) for r in range(world) if r != src and parts[r]])
         return unpack(msgs[src], parts[src]), lens_l
     if not parts[rank]:
@@ -154,10 +174,28 @@ def scatter_utterances(mels: Sequence[torch.Tensor], parts: List[List[int]], src
 
 
 def gather_waveforms(mine, lens: Sequence[int], parts: List[List[int]], hop: int = 256, dst: int = 0, device=None,
-                     dtype: torch.dtype = torch.float32):
+                     dtype: torch.dtype = torch.float32, loopback: bool = False):
     """Inverse of scatter_utterances: rank `dst` ends up with the list of waveforms ([T_i*hop] each, float32 or the int16 PCM of
-    the device epilogue) in index order.  One packed message per peer, all receives of `dst` posted as one group."""
+    the device epilogue) in index order.  One packed message per peer, all receives of `dst` posted as one group.
+    loopback: see scatter_utterances -- the waveforms of parts[1:] come back as packed byte messages from this rank to itself."""
     rank, world = dist.get_rank(), dist.get_world_size()
+    if loopback:
+        assert world == 1 and rank == dst
+        by_idx = dict(mine)
+        out = [None] * len(lens)
+        for i in parts[0]:
+            out[i] = by_idx[i]
+        sends = {r: torch.cat([by_idx[i].reshape(-1).to(dtype) for i in parts[r]]) for r in range(1, len(parts)) if parts[r]}
+        if device is not None:
+            sends = {r: b.to(device) for r, b in sends.items()}
+        recvs = {r: torch.empty_like(b) for r, b in sends.items()}
+        _exchange([op for r in sends for op in (dist.P2POp(dist.isend, _as_bytes(sends[r]), dst), dist.P2POp(dist.irecv, _as_bytes(recvs[r]), dst))])
+        for r, buf in recvs.items():
+            off = 0
+            for i in parts[r]:
+                out[i] = buf[off: off + int(lens[i]) * hop]
+                off += int(lens[i]) * hop
+        return out
     if rank != dst:
         if mine:
             by_idx = dict(mine)

@@ -590,6 +590,67 @@ def gen_lvc_grad():
     np.savez_compressed(os.path.join(GOLD, "lvc_grad.npz"), **out)
 
 
+def gen_test_step(dh):
+    """The reference's OWN caller of the hot path, executed here: FastDiffTask.test_step (modules/FastDiff/task/FastDiff.py:60-119)
+    cut out with ast (the file's imports -- utils, tasks.vocoder.vocoder_base, utils.audio -- need chardet, tensorboard, resemblyzer,
+    librosa, all absent) and run unmodified against stand-ins for what it reaches: `hparams` (N, noise_schedule '', hop_size,
+    work_dir, gen_dir_name, audio_sample_rate), `audio.save_wav` = the reference's own save_wav, also cut out of utils/audio.py:11-16,
+    `sampling_given_noise_schedule` = the reference's (util.py:158-235) with std_normal replaying recorded noise, `self` = an object
+    with the reference model, the build_model hyper-parameters and trainer.global_step.  Stored: what save_wav wrote (read back from
+    the RIFF file) for N = 4, N = 6 and an explicit hparams['noise_schedule'] list, plus the NotImplementedError of an unknown N."""
+    import tempfile, types
+    from scipy.io import wavfile
+    ns_a = {"np": np, "wavfile": wavfile}
+    exec(compile(_ast_pick(os.path.join(REF, "utils", "audio.py"), functions=("save_wav",)), "audio", "exec"), ns_a)
+    hp = {}
+    ns = {"os": os, "torch": torch, "hparams": hp, "audio": types.SimpleNamespace(save_wav=ns_a["save_wav"]),
+          "sampling_given_noise_schedule": ref_util.sampling_given_noise_schedule}
+    exec(compile(_ast_pick(os.path.join(REF, "modules", "FastDiff", "task", "FastDiff.py"), klass="FastDiffTask", methods=("test_step",)),
+                 "FastDiffTask", "exec"), ns)
+    task = ns["FastDiffTask"].__new__(ns["FastDiffTask"])
+    task.model = make_model(torch.float32)
+    task.diffusion_hyperparams = {"T": dh["T"], "alpha": dh["alpha"], "beta": dh["beta"], "sigma": dh["sigma"]}
+    task.trainer = types.SimpleNamespace(global_step=160000)
+    T, seed = 12, SEED + 300
+    mel = synth.synth_mel(seed, 1, T)
+    L = T * 256
+    out = {"mel": mel, "seed": np.int64(seed), "item_name": np.array(["utt_a.npy"])}
+    cases = {"N4": {"N": 4, "noise_schedule": ""}, "N6": {"N": 6, "noise_schedule": ""},
+             "list3": {"N": 4, "noise_schedule": [9.0000e-05, 9.0000e-03, 6.0000e-01]}}      # a list overrides N (FastDiff.py:65-68)
+    with tempfile.TemporaryDirectory() as d:
+        for name, c in cases.items():
+            hp.clear()
+            hp.update({"N": c["N"], "noise_schedule": c["noise_schedule"], "hop_size": 256, "work_dir": d, "gen_dir_name": name,
+                       "audio_sample_rate": 22050})
+            n_draws = len(c["noise_schedule"]) if c["noise_schedule"] != "" else c["N"]
+            noises = [synth.hash_normal(seed, 1, L).reshape(1, 1, L)] + [synth.hash_normal(seed, 2 + n, L).reshape(1, 1, L) for n in range(n_draws - 1, 0, -1)]
+            it = iter(noises)
+            orig = ref_util.std_normal
+            ref_util.std_normal = lambda size: torch.from_numpy(next(it).copy()).view(*size).clone()
+            try:
+                devnull = open(os.devnull, "w")
+                stdout, sys.stdout = sys.stdout, devnull
+                ret = task.test_step({"mels": torch.from_numpy(mel), "wavs": [], "item_name": ["utt_a.npy"]}, 0)
+            finally:
+                sys.stdout = stdout
+                ref_util.std_normal = orig
+            assert ret == {}
+            path = os.path.join(d, f"generated_160000_{name}", "utt_a.npy_pred.wav")
+            sr, pcm = wavfile.read(path)
+            assert sr == 22050 and pcm.dtype == np.int16 and pcm.shape == (L,)
+            out["pcm_" + name] = pcm
+            out["n_draws_" + name] = np.int64(n_draws)
+            print("test_step", name, "peak", int(np.abs(pcm.astype(np.int32)).max()), "first", pcm[:4])
+        hp.update({"N": 5, "noise_schedule": ""})
+        try:
+            task.test_step({"mels": torch.from_numpy(mel), "wavs": [], "item_name": ["utt_a.npy"]}, 0)
+            raised = ""
+        except NotImplementedError as e:
+            raised = type(e).__name__
+        out["unknown_N_raises"] = np.array([raised])
+    np.savez_compressed(os.path.join(GOLD, "test_step.npz"), **out)
+
+
 def gen_statedict_manifest():
     """Key set + shapes of the reference module's state_dict, and a default-init digest, for the drop-in shim test."""
     torch.manual_seed(SEED)
@@ -606,7 +667,7 @@ def gen_statedict_manifest():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["schedule", "embed", "ops", "forward", "sample", "manifest", "collate", "collater", "frontend", "frontend_tacotron",
-                             "frontend_pwg", "noise_scheduling", "theta_loss", "phi_loss", "theta_grad", "lvc_grad"]
+                             "frontend_pwg", "noise_scheduling", "theta_loss", "phi_loss", "theta_grad", "lvc_grad", "test_step"]
     dh = gen_schedule()
     if "embed" in which:
         gen_embed()
@@ -639,6 +700,8 @@ if __name__ == "__main__":
         gen_theta_grad(dh)
     if "noise_scheduling" in which:
         gen_noise_scheduling(dh)
+    if "test_step" in which:
+        gen_test_step(dh)
     if "frontend_tacotron" in which:
         gen_frontend_tacotron()
     print("golden fixtures written to", GOLD)

@@ -886,6 +886,36 @@ def test_drop_in_sampling_function(model, gc, sched, oracle64):
     assert torch.equal(r1, r2)
 
 
+@pytest.mark.parametrize("case,hp", [("N4", {"N": 4, "noise_schedule": ""}), ("N6", {"N": 6, "noise_schedule": ""}),
+                                     ("list3", {"N": 4, "noise_schedule": [9.0000e-05, 9.0000e-03, 6.0000e-01]})])
+def test_caller_test_step_against_the_references_own(model, gc, monkeypatch, tmp_path, case, hp):
+    """The caller of the hot path, pinned on the reference's own function: tests/golden/test_step.npz holds what
+    FastDiffTask.test_step (modules/FastDiff/task/FastDiff.py:60-119, cut out with ast and executed on the reference model) wrote
+    through save_wav -- schedule by hparams['N'] or the hparams['noise_schedule'] list, size (1, 1, T * hop_size), peak-normalised
+    int16.  infer.test_step mirrors it around the HIP sampler; with std_normal replaying the same draws in the reference's order
+    (noise_source = "reference") the file it writes must hold the same samples within 1 LSB."""
+    import synth
+    from scipy.io import wavfile
+    from fastdiff_amd import infer, sampler
+    g = load_golden("test_step")
+    mel, seed = g["mel"], int(g["seed"])
+    L = mel.shape[-1] * 256
+    n_draws = int(g["n_draws_" + case])
+    draws = iter([synth.hash_normal(seed, 1, L)] + [synth.hash_normal(seed, 2 + n, L) for n in range(n_draws - 1, 0, -1)])
+    monkeypatch.setattr(sampler, "std_normal", lambda size: torch.from_numpy(next(draws).copy()).view(*size).cuda())
+    hparams = dict(hp, hop_size=256, audio_sample_rate=22050)
+    name = str(g["item_name"][0])
+    out = infer.test_step(model, {"mels": torch.from_numpy(mel), "wavs": [], "item_name": [name]}, hparams, gen_dir=str(tmp_path), noise_source="reference")
+    assert next(draws, None) is None                              # exactly the reference's number of draws
+    sr, pcm = wavfile.read(str(tmp_path / f"{name}_pred.wav"))
+    assert sr == 22050 and np.array_equal(pcm, out[name])
+    d = np.abs(pcm.astype(np.int32) - g["pcm_" + case].astype(np.int32))
+    print(f"test_step {case}: int16 max|d| = {int(d.max())}, differing samples {int((d > 0).sum())} of {d.size}")
+    assert d.max() <= 1
+    with pytest.raises(NotImplementedError):                      # FastDiff.py:92-93
+        infer.test_step(model, {"mels": torch.from_numpy(mel), "wavs": [], "item_name": [name]}, dict(hparams, N=5, noise_schedule=""))
+
+
 def test_noise_scheduling_on_the_hip_denoiser(model, gc, sched, monkeypatch):
     """noise_scheduling (util.py:237-288) with the HIP module as `net` and a stand-in `noise_pred` attached to it: the schedule
     found must be the one the reference function finds on the reference module (golden: gen_noise_scheduling)."""

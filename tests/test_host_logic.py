@@ -317,6 +317,14 @@ def test_roofline_numerators_are_the_surveys_algorithmic_figures():
     assert bench.executed_flops("kp_gemm_f16x2", 8, 864) == 3 * bench.kernel_model("kp_gemm_f16x2", 8, 864)[2] == 3 * 3 * 2.0 * 24832 * 192 * 8 * 864
     assert bench.kernel_model("kp_gemm_f16x2", 8, 864)[2] == bench.kernel_model("kp_gemm", 8, 864)[2]
     assert [bench.template_group(k) for k in ("lvc_layer_h256", "lvc_final_h256", "lvc_up_h256", "lvc_up_h64", "kp_gemm_f16x2")] == ["lvc_h256"] * 3 + ["lvc_h64", "kp_gemm_f16x2"]
+    # rocprofv3 kernel names -> rows: one per instantiation kind of the LVC layer template <HOP, DIL, FINAL, UP>
+    rows = {"void fdk_fast::k_lvc_h2<256, 27, true, 0>(float const*, float const*)": "lvc_final_h256", "void fdk_fast::k_lvc_h2<256, 3, false, 0>(float const*)": "lvc_layer_h256",
+            "void fdk_fast::k_lvc_h2<256, 1, false, 4>(float const*)": "lvc_up_h256", "void fdk_fast::k_lvc_h2<64, 1, false, 8>(float const*)": "lvc_up_h64",
+            "void fdk_fast::k_lvc_h8m<9>(float const*)": "lvc_layer_h8", "fdk_fast::k_kp_gemm_h2(char const*, float*)": "kp_gemm_f16x2",
+            "void fdk_fast::k_dblock_h2<4, true>(float const*)": "dblock_f4", "fdk::k_advance(StepParams*, int*, int, int)": "advance_step",
+            "void at::native::vectorized_elementwise_kernel<4, at::native::AbsFunctor<float> >(int)": None, "__amd_rocclr_copyBuffer": None}
+    for name, want in rows.items():
+        assert bench.rocprof_row(name) == want, name
     assert bench.HBM_PEAK_GBS == 8000.0
 
 

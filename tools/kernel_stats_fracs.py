@@ -11,7 +11,6 @@ import csv
 import importlib.util
 import json
 import os
-import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,26 +20,7 @@ sys.argv_saved, sys.argv = sys.argv, [sys.argv[0]]
 spec.loader.exec_module(bench)
 sys.argv = sys.argv_saved
 
-BENCH_NAME = {"k_kp_gemm_h2": "kp_gemm_f16x2", "k_final_acc": "final_update", "k_first_conv": "first_conv", "k_kp_front_h2": "kp_front",
-              "k_advance": "advance_step", "k_init_noise": "init_noise", "k_embed_mlp": "embed", "k_embed_fct": "embed_fct"}
-
-
-def fam(name):
-    m = re.search(r"k_lvc_h2<(\d+), *\d+, *(\w+), *(\d+)", name)
-    if m:
-        if int(m.group(3)) > 0:
-            return "lvc_up_h" + m.group(1)
-        return ("lvc_final_h" if m.group(2) in ("true", "1") else "lvc_layer_h") + m.group(1)
-    if "k_lvc_h8m<" in name:
-        return "lvc_layer_h8"
-    m = re.search(r"k_dblock_h2<(\d+)", name)
-    if m:
-        return "dblock_f" + m.group(1)
-    m = re.search(r"k_convt_h2<(\d+)", name)
-    if m:
-        return "convt_r" + m.group(1)
-    m = re.search(r"::(k_\w+)", name)
-    return BENCH_NAME.get(m.group(1), m.group(1)) if m else None
+fam = bench.rocprof_row      # kernel name -> bench.py row (one per instantiation kind of k_lvc_h2: plain, FINAL, UP)
 
 
 def main():
