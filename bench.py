@@ -822,6 +822,11 @@ def main():
                    "world_size": world, "gpus_visible": n_dev, "oversubscribed": bool(oversub),
                    "ragged": (None if not args.ragged else {"lens": lens, "told_to_library": not args.no_lens})},
     }
+    if rank == 0 and args.workload == "configs1" and N > 8:
+        # a schedule of more than 8 steps runs as 8-step pieces, each checked on the host; which pipe did the LAST timed call run on?
+        line["long_schedule"] = {"pieces": model.counter("pieces"), "pieces_redone_on_fp32": model.counter("pieces_redone"),
+                                 "pieces_enqueued_with_stages_on_fp32": model.counter("pieces_fp32"), "fp32_stage_mask": hex(model.counter("fp32_mask")),
+                                 "of": "the last timed sample call (fd_get_counter); 0 / 0 = every piece ran on the default fp16x2 pipe"}
     if rank == 0:
         line["box"] = box_state()
         if args.workload == "config4" and projection is not None:

@@ -1603,7 +1603,15 @@ __global__ void __launch_bounds__(256, 2) k_lvc_layer(const float *__restrict__ 
 // loaded the coalesced way (wave = channel group, lane = 4 columns) and parked, each lane of the conv's result layout (16 channels of
 // one column) reads its 16 skip values back from there, writes x' over them and the leaky-relu pieces into the x image.
 // up_flag: the ConvTranspose's own range flag (raised together with the layer's: the host then redoes both on fp32 kernels).
-template <int HOP, int DIL, bool FINAL, int UP = 0>
+// VAR (option "lvc_variant"; the fused instantiations only).  UP > 0: 1 = the parking area holds the ConvTranspose's x phase-major -- [channel][phase][position], for
+// r = 8 with the position XOR-ed by 16 in phases 4..7 -- so that the 32 lanes of a matrix tile (32 positions of ONE phase: columns r
+// apart) store to 32 different banks instead of 4-/8-way into 8 / 4 of them, and a lane reads its four columns back as four
+// conflict-free dwords; the frame's record is requested in front of the ConvTranspose (as the plain layer does: first of all) and
+// the conv weights, which come from L2, behind it.  0 = round 3's form (column-major parking, record requested behind the up-sampler).
+// FINAL: 1 = the final_conv weights (4 parts x 8 channels x 8 taps = 1 KB) are copied to LDS by the first wave on its way in and
+// read from there in the epilogue; 0 = round 3's form: 16 float4 per lane from L2 behind the LVC's last matrix instruction, where
+// every wave of the workgroup waited for them at the end of its life (more registers for them earlier would spill).
+template <int HOP, int DIL, bool FINAL, int UP = 0, int VAR = 1>
 __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin, const float *__restrict__ skip, float *__restrict__ xout,
                                                    const float *__restrict__ kpack, int layer, const float4 *__restrict__ wpack16,
                                                    const float *__restrict__ wref, const float *__restrict__ cbias,
@@ -1657,19 +1665,28 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
             for (int j = 0; j < 4; ++j) bz[m][j] = kb4[(mt0 + m) * 8 + 2 * j + hi];
         }
     };
+    constexpr bool UPNEW = UP > 0 && VAR == 1;
+    __shared__ float4 ffs[(FINAL && VAR == 1) ? 64 : 1];
+    if constexpr (FINAL && VAR == 1) {
+        if (tid < 64) ffs[tid] = ffuse[tid];      // visible to everyone behind the staging barrier
+    }
 #ifndef FD_LVC_LATE_KERNEL
-    if constexpr (HOP == 256 && UP == 0) load_kernel(0);
+    if constexpr (HOP == 256 && (UP == 0 || UPNEW)) load_kernel(0);
 #endif
     // conv weights: A operand pieces [piece][kg][lane] x 8 fp16, k = 16*kg + 8*hi + e = tap*32 + in
     float4 wa[2][6];
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int kg = 0; kg < 6; ++kg) wa[p][kg] = wpack16[(p * 6 + kg) * 64 + lane];
     float4 cb[4];
+    float hbias;                             // for the halo outputs
+    auto load_conv_weights = [&]() {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) cb[j] = reinterpret_cast<const float4 *>(cbias)[2 * j + hi];
-    const float hbias = cbias[l31];          // for the halo outputs
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int kg = 0; kg < 6; ++kg) wa[p][kg] = wpack16[(p * 6 + kg) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cb[j] = reinterpret_cast<const float4 *>(cbias)[2 * j + hi];
+        hbias = cbias[l31];
+    };
+    if constexpr (!UPNEW) load_conv_weights();
 #ifdef FD_LVC_PAD_LOADS     // probe (tools/ubench): is the layer bound by the CU's memory pipe?  N extra 16 B loads per lane (L2 hits)
     {
         float4 pad_[FD_LVC_PAD_LOADS];
@@ -1775,7 +1792,9 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
                     if (ql < UPN && col >= -H && col < W + H) {
                         const int gc = w0 + col;
                         const bool inb = gc >= 0 && gc < Lnb;
-                        float *dst = (col >= 0 && col < W) ? park + col : hsk + (col < 0 ? col + H : col - W + H);
+                        // centre columns: UPV = 1 phase-major (col = R (ql - 1) + ph: position ql - 1 of phase ph), UPV = 0 as they lie
+                        const int pcol = UPNEW ? ph * (W / R) + ((ql - 1) ^ ((R == 8) ? 16 * (ph >> 2) : 0)) : col;
+                        float *dst = (col >= 0 && col < W) ? park + pcol : hsk + (col < 0 ? col + H : col - W + H);
                         const int cs = (col >= 0 && col < W) ? W : 2 * H;          // channel stride of the destination
 #pragma unroll
                         for (int r = 0; r < 16; ++r)                              // D rows 8j + 4hi + i = register 4j + i
@@ -1784,9 +1803,19 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
                 }
             }
             __syncthreads();
-            if constexpr (HOP == 256) load_kernel(0);
+            if constexpr (HOP == 256 && !UPNEW) load_kernel(0);
+            if constexpr (UPNEW) {
+                load_conv_weights();
+                // columns 4 lane + j: r = 4 -> position lane of phase j; r = 8 -> position lane / 2 of phase 4 (lane & 1) + j
+                const float *pk = reinterpret_cast<const float *>(ys) + wave * 8 * W +
+                                  (R == 4 ? lane : (4 * (lane & 1)) * (W / R) + ((lane >> 1) ^ (16 * (lane & 1))));
 #pragma unroll
-            for (int c = 0; c < 8; ++c) xa[c] = *reinterpret_cast<const float4 *>(ys + ((wave * 8 + c) * W + 4 * lane) * 4);
+                for (int c = 0; c < 8; ++c)
+                    xa[c] = make_float4(pk[c * W], pk[c * W + (W / R)], pk[c * W + 2 * (W / R)], pk[c * W + 3 * (W / R)]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) xa[c] = *reinterpret_cast<const float4 *>(ys + ((wave * 8 + c) * W + 4 * lane) * 4);
+            }
 #pragma unroll
             for (int c = 0; c < 8; ++c) hx[c] = hc < 2 * H ? hsk[(wave * 8 + c) * (2 * H) + hc] : 0.0f;
         }
@@ -1987,7 +2016,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
             float fw[8][8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const float4 lo4 = ffuse[(part * 8 + r) * 2], hi4 = ffuse[(part * 8 + r) * 2 + 1];
+                const float4 lo4 = (VAR == 1) ? ffs[(part * 8 + r) * 2] : ffuse[(part * 8 + r) * 2], hi4 = (VAR == 1) ? ffs[(part * 8 + r) * 2 + 1] : ffuse[(part * 8 + r) * 2 + 1];
                 fw[r][0] = lo4.x; fw[r][1] = lo4.y; fw[r][2] = lo4.z; fw[r][3] = lo4.w; fw[r][4] = hi4.x; fw[r][5] = hi4.y; fw[r][6] = hi4.z;
             }
 #pragma unroll
@@ -2593,10 +2622,16 @@ static hipError_t launch_lvc(const Launch &L, const char *name, int n, int layer
     if constexpr (HOP >= 64 && DIL == 1) {
         if (up) {      // x_in = the block's input: the ConvTranspose runs inside the layer (the caller made sure both stages are fp16x2-only)
             constexpr int R = (HOP == 256) ? 4 : 8;
-            FD_LAUNCH(L, HOP == 256 ? "lvc_up_h256" : "lvc_up_h64", (k_lvc_h2<HOP, 1, false, R>), dim3(((Ln + 255) / 256 + 7) / 8 * 8, B), dim3(256), 0, x_in, skip, x_out, kp, layer,
-                      reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]), w.blk[n].convs[layer].w, w.blk[n].convs[layer].b,
-                      c->ws.range_flag + 1 + n * fd::LAYERS + layer, T, c->step_lens, (float *)nullptr, (const float4 *)nullptr,
-                      reinterpret_cast<const float4 *>(w.up_h2[n]), w.blk[n].up.b, c->ws.range_flag + 16 + n);
+            if (c->lvc_variant == 1)
+                FD_LAUNCH(L, HOP == 256 ? "lvc_up_h256" : "lvc_up_h64", (k_lvc_h2<HOP, 1, false, R, 1>), dim3(((Ln + 255) / 256 + 7) / 8 * 8, B), dim3(256), 0, x_in, skip, x_out, kp, layer,
+                          reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]), w.blk[n].convs[layer].w, w.blk[n].convs[layer].b,
+                          c->ws.range_flag + 1 + n * fd::LAYERS + layer, T, c->step_lens, (float *)nullptr, (const float4 *)nullptr,
+                          reinterpret_cast<const float4 *>(w.up_h2[n]), w.blk[n].up.b, c->ws.range_flag + 16 + n);
+            else
+                FD_LAUNCH(L, HOP == 256 ? "lvc_up_h256" : "lvc_up_h64", (k_lvc_h2<HOP, 1, false, R, 0>), dim3(((Ln + 255) / 256 + 7) / 8 * 8, B), dim3(256), 0, x_in, skip, x_out, kp, layer,
+                          reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]), w.blk[n].convs[layer].w, w.blk[n].convs[layer].b,
+                          c->ws.range_flag + 1 + n * fd::LAYERS + layer, T, c->step_lens, (float *)nullptr, (const float4 *)nullptr,
+                          reinterpret_cast<const float4 *>(w.up_h2[n]), w.blk[n].up.b, c->ws.range_flag + 16 + n);
             return hipSuccess;
         }
     }
@@ -2608,8 +2643,13 @@ static hipError_t launch_lvc(const Launch &L, const char *name, int n, int layer
             c->final_fused = false;
             if constexpr (HOP == 256 && DIL == 27) c->final_fused = c->fast[ST_FINAL] && !c->keep_taps && c->fuse_final;
             if constexpr (HOP == 256 && DIL == 27) {
-                if (c->final_fused)      // its own profile row: this variant never writes its 32 output channels
-                    FD_LAUNCH(L, "lvc_final_h256", (k_lvc_h2<HOP, DIL, true>), dim3(((Ln + 255) / 256 + 7) / 8 * 8, B), dim3(256), 0, x_in, skip, x_out, kp,
+                if (c->final_fused && c->lvc_variant == 1)      // its own profile row: this variant never writes its 32 output channels
+                    FD_LAUNCH(L, "lvc_final_h256", (k_lvc_h2<HOP, DIL, true, 0, 1>), dim3(((Ln + 255) / 256 + 7) / 8 * 8, B), dim3(256), 0, x_in, skip, x_out, kp,
+                              layer, reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]), w.blk[n].convs[layer].w,
+                              w.blk[n].convs[layer].b, flag, T, c->step_lens, c->ws.eps_acc, reinterpret_cast<const float4 *>(w.final_fuse),
+                              (const float4 *)nullptr, (const float *)nullptr, (int *)nullptr);
+                else if (c->final_fused)
+                    FD_LAUNCH(L, "lvc_final_h256", (k_lvc_h2<HOP, DIL, true, 0, 0>), dim3(((Ln + 255) / 256 + 7) / 8 * 8, B), dim3(256), 0, x_in, skip, x_out, kp,
                               layer, reinterpret_cast<const float4 *>(w.lvc_conv_h2[n][layer]), w.blk[n].convs[layer].w,
                               w.blk[n].convs[layer].b, flag, T, c->step_lens, c->ws.eps_acc, reinterpret_cast<const float4 *>(w.final_fuse),
                               (const float4 *)nullptr, (const float *)nullptr, (int *)nullptr);
