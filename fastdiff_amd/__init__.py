@@ -10,9 +10,9 @@ FastDiff.forward in train() mode records an autograd graph (fastdiff_amd/train.p
 from .model import FastDiff  # noqa: F401
 from . import sampler, schedules  # noqa: F401
 from . import sampler as util  # noqa: F401  (the reference module is called util)
-from .lvc_op import location_variable_convolution, gated_residual, kernel_conv1d  # noqa: F401
+from .lvc_op import location_variable_convolution, gated_residual, kernel_conv1d, conv32  # noqa: F401
 from .sampler import (compute_hyperparams_given_schedule, sampling_given_noise_schedule, noise_scheduling,  # noqa: F401
                    map_noise_scale_to_time_step, calc_diffusion_step_embedding, std_normal, theta_timestep_loss, phi_loss)
 
-__all__ = ["FastDiff", "location_variable_convolution", "gated_residual", "kernel_conv1d", "util", "schedules", "compute_hyperparams_given_schedule", "sampling_given_noise_schedule",
+__all__ = ["FastDiff", "location_variable_convolution", "gated_residual", "kernel_conv1d", "conv32", "util", "schedules", "compute_hyperparams_given_schedule", "sampling_given_noise_schedule",
            "noise_scheduling", "map_noise_scale_to_time_step", "calc_diffusion_step_embedding", "std_normal", "theta_timestep_loss", "phi_loss"]

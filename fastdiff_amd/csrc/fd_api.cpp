@@ -254,6 +254,7 @@ int fd_destroy(fd_handle h)
     if (h->scratch) hipFree(h->scratch);
     if (h->lvc_scratch) hipFree(h->lvc_scratch);
     if (h->kconv_scratch) hipFree(h->kconv_scratch);
+    if (h->cconv_scratch) hipFree(h->cconv_scratch);
     for (auto &sl : h->stage) {
         if (sl.host) hipHostFree(sl.host);
         if (sl.done) hipEventDestroy(sl.done);
@@ -1541,6 +1542,56 @@ int fd_kconv_backward(fd_handle h, const float *x, const float *weight, const fl
     fdk::Launch La = {h, (hipStream_t)stream, false};
     hipError_t e = fdk::kconv_backward(La, x, weight, dout, dx, dweight, dbias, B, M, T, h->kconv_scratch);
     if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_kconv_backward: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+// The small convolutions of the training path (fd_kernels_cconv.hip).  The backward's per-workgroup partial sums live in a scratch
+// buffer on the handle (calls on one handle are ordered on one stream, as for the operators above).
+static int check_conv32(fd_handle h, int B, int64_t L, int dil, float pre, float post, const char *who)
+{
+    if (B <= 0 || B > 65535 || L <= 0) FD_FAIL(h, FD_ERR_INVALID, "%s: B=%d L=%lld", who, B, (long long)L);
+    if (!(pre > 0.0f && pre <= 1.0f) || !(post > 0.0f && post <= 1.0f))
+        FD_FAIL(h, FD_ERR_INVALID, "%s: leaky-relu slopes must lie in (0, 1] (1 = no activation), got %g / %g", who, pre, post);
+    if (!fdk::cconv_supported(dil, L))
+        FD_FAIL(h, FD_ERR_UNSUPPORTED, "%s: dilation %d (1, 2, 3, 4, 9, 27) and a length that is a multiple of 4 only, got L=%lld", who, dil, (long long)L);
+    if ((int64_t)B * 32 * L >= (int64_t)1 << 40) FD_FAIL(h, FD_ERR_INVALID, "%s: tensor too large", who);
+    return FD_OK;
+}
+
+int fd_conv32_forward(fd_handle h, const float *x, const float *skip, const float *weight, const float *bias, int B, int64_t L, int dilation,
+                      float pre_slope, float post_slope, float *xs_out, float *y, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!x || !weight || !bias || !y || (skip && !xs_out)) FD_FAIL(h, FD_ERR_INVALID, "fd_conv32_forward: null pointer (xs_out is needed with a skip)");
+    int rc = check_conv32(h, B, L, dilation, pre_slope, post_slope, "fd_conv32_forward");
+    if (rc != FD_OK) return rc;
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::cconv_forward(La, x, skip, weight, bias, xs_out, y, B, L, dilation, pre_slope, post_slope);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_conv32_forward: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+int fd_conv32_backward(fd_handle h, const float *xs, const float *y, const float *weight, const float *dy, const float *gxs, int B, int64_t L,
+                       int dilation, float pre_slope, float post_slope, float *dxs, float *dweight, float *dbias, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!xs || !y || !weight || !dy) FD_FAIL(h, FD_ERR_INVALID, "fd_conv32_backward: null pointer");
+    int rc = check_conv32(h, B, L, dilation, pre_slope, post_slope, "fd_conv32_backward");
+    if (rc != FD_OK) return rc;
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    {
+        const size_t bytes = sizeof(float) * fdk::cconv_scratch_floats(La, dilation, B, L);
+        if (h->cconv_scratch_bytes < bytes) {
+            if (h->cconv_scratch) FD_HIP(h, hipFree(h->cconv_scratch));
+            h->cconv_scratch = nullptr; h->cconv_scratch_bytes = 0;
+            FD_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->cconv_scratch), bytes));
+            h->cconv_scratch_bytes = bytes;
+        }
+    }
+    hipError_t e = fdk::cconv_backward(La, xs, y, weight, dy, gxs, dxs, dweight, dbias, B, L, dilation, pre_slope, post_slope, h->cconv_scratch);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_conv32_backward: %s", hipGetErrorString(e));
     return FD_OK;
 }
 

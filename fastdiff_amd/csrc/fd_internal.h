@@ -277,6 +277,8 @@ struct fd_context {
     size_t lvc_scratch_bytes = 0;
     float *kconv_scratch = nullptr;          // the row-slice partial sums of fd_kconv_backward's dh pass, grown on demand
     size_t kconv_scratch_bytes = 0;
+    float *cconv_scratch = nullptr;          // per-workgroup partial sums of fd_conv32_backward's dW / db, grown on demand
+    size_t cconv_scratch_bytes = 0;
     std::vector<ProfEntry> prof_pending;
     std::vector<hipEvent_t> event_pool;
     std::map<std::string, std::pair<int64_t, double>> prof_acc;

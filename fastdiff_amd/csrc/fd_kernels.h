@@ -38,4 +38,12 @@ size_t kconv_scratch_floats(int B, int M, int T);
 hipError_t kconv_forward(const Launch &L, const float *h, const float *W, const float *bias, float *out, int B, int M, int T);
 hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const float *dout, float *dh, float *dW, float *dbias, int B, int M,
                           int T, float *scratch);
+// one layer's "x (+ skip) -> leaky_relu -> dilated Conv1d(32 -> 32, k3) -> bias -> (leaky_relu)" forward and backward for the training
+// path (fd_kernels_cconv.hip); scratch: cconv_scratch_floats() floats for the per-workgroup partial sums of dW / db
+bool cconv_supported(int dil, int64_t len);
+size_t cconv_scratch_floats(const Launch &L, int dil, int B, int64_t len);
+hipError_t cconv_forward(const Launch &L, const float *x, const float *skip, const float *w, const float *bias, float *xs_out, float *y, int B,
+                         int64_t len, int dil, float pre, float post);
+hipError_t cconv_backward(const Launch &L, const float *xs, const float *y, const float *w, const float *dy, const float *gxs, float *dxs,
+                          float *dw, float *db, int B, int64_t len, int dil, float pre, float post, float *scratch);
 }  // namespace fdk

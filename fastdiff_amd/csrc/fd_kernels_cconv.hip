@@ -1,0 +1,311 @@
+// fd_kernels_cconv.hip -- the 21 small convolutions of the denoiser as ONE differentiable operator for the training path (SURVEY.md 8f
+// row 4): the three `Conv1d(32, 32, 3, dilation = 1 / 2 / 4)` of every DiffusionDBlock (modules/FastDiff/module/modules.py:120-125,
+// applied as `layer(leaky_relu(x, 0.2))`, :136-137) and the four `Conv1d(32, 32, 3, dilation = 3^i)` of every TimeAware_LVCBlock
+// (modules.py:183-187, applied as `x += audio_down; y = leaky_relu(conv(leaky_relu(x, 0.2)), 0.2)`, :209-212):
+//
+//     xs = x (+ skip)                         (the layer's input; written out when there is a skip: the gate behind the LVC reads it)
+//     y  = post(bias + W * pre(xs)),          pre(v) = leaky_relu(v, pre_slope),  post(v) = leaky_relu(v, post_slope) or the identity
+//
+// forward in one pass (read x, skip; write xs, y), and backward in one pass as well: from dy, y (the sign of the pre-activation), xs and
+// the gradient that reached xs from its other readers it produces  dxs = gxs + mask_pre * (W^T * du),  du = dy * mask_post,  the weight
+// gradient dW[o][i][k] = sum du[o][t] a[i][t + (k - 1) d]  and the bias gradient db[o] = sum du[o][t]  -- the two sums as per-workgroup
+// partials (every workgroup walks its tiles in a fixed order and keeps the 32 x 96 tile of dW in matrix accumulators), added up in a
+// fixed order by a second small kernel: same bits every run.  Under torch autograd the same layer is an add, two leaky-relus, a
+// MIOpen convolution with NHWC transposes around it, and in the backward two more convolutions, two leaky-relu gradients, an add and
+// a reduction launch for the bias: profiles/r03_train_step_families.txt.
+// All products on the exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32): training keeps fp32 products, nothing to range-check.
+// Weight layout as the reference's parameter: [out 32][in 32][tap 3] (already folded: g * v / ||v|| is the caller's, torch._weight_norm).
+#include <algorithm>
+
+#include "fd_kernels.h"
+
+namespace fdk_cconv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+// D layout of the 32x32 tile: register r of lane (col = lane & 31, hi = lane >> 5) is row (r & 3) + 8 (r >> 2) + 4 hi
+__device__ __forceinline__ int drow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+__device__ __forceinline__ float lrelu(float v, float s) { return v > 0.0f ? v : v * s; }
+__device__ __forceinline__ float dlrelu(float v, float s) { return v > 0.0f ? 1.0f : s; }      // torch: grad * (x > 0 ? 1 : slope)
+
+constexpr int C = 32, KS = 3, NW = C * C * KS;      // 3072 weights
+constexpr int PSTRIDE = NW + C;                     // one workgroup's partial: dW [32][32][3] then db [32]
+
+template <int DIL> struct Cfg {
+    static constexpr int H = (DIL + 3) & ~3;                    // halo columns per side (a multiple of 4: float4 staging)
+    static constexpr int WF = 256;                              // forward tile
+    static constexpr int WB = 128;                              // backward tile (256 columns: the staging registers next to the two
+                                                                // resident operand sets spill)
+};
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// forward: workgroup = 256 columns of one utterance, wave = 64 of them (two 32 x 32 tiles), K = 96 = (tap, in) in 48 steps
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int DIL>
+__global__ void __launch_bounds__(256) k_cconv_fwd(const float *__restrict__ x, const float *__restrict__ skip, const float *__restrict__ w,
+                                                   const float *__restrict__ bias, float *__restrict__ xs_out, float *__restrict__ y, int L,
+                                                   int tiles_per_row, float pre, float post)
+{
+    constexpr int W = Cfg<DIL>::WF, H = Cfg<DIL>::H, XLD = W + 2 * H, NF4 = XLD / 4, TOTAL = C * NF4, NK = (TOTAL + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float as[C * XLD];      // pre(x + skip), column c at index c + H
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.x / tiles_per_row, w0 = (blockIdx.x - b * tiles_per_row) * W;
+    // A operand: lane (row = out channel l31, half hi) holds k = 2 s + hi = tap * 32 + in for s = 0 .. 47
+    float wa[48];
+#pragma unroll
+    for (int s = 0; s < 48; ++s) {
+        const int kk = 2 * s + hi;
+        wa[s] = w[(l31 * C + (kk & 31)) * KS + (kk >> 5)];
+    }
+    float cb[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cb[r] = bias[drow(r, hi)];
+    {
+        const float *xr = x + (int64_t)b * C * L, *sr = skip ? skip + (int64_t)b * C * L : nullptr;
+        float *xo = xs_out ? xs_out + (int64_t)b * C * L : nullptr;
+        float4 xa[NK], sa[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int idx = k * 256 + tid, ci = idx / NF4, c4 = idx - ci * NF4, g = w0 - H + 4 * c4;
+            const bool ok = idx < TOTAL && g >= 0 && g < L;      // L is a multiple of 4: a quad is all in or all out
+            xa[k] = ok ? *reinterpret_cast<const float4 *>(xr + (int64_t)ci * L + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            sa[k] = (ok && sr) ? *reinterpret_cast<const float4 *>(sr + (int64_t)ci * L + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int idx = k * 256 + tid, ci = idx / NF4, c4 = idx - ci * NF4, g = w0 - H + 4 * c4;
+            if (idx < TOTAL) {
+                const float4 r = make_float4(xa[k].x + sa[k].x, xa[k].y + sa[k].y, xa[k].z + sa[k].z, xa[k].w + sa[k].w);
+                if (xo && c4 >= H / 4 && c4 < H / 4 + W / 4 && g < L) *reinterpret_cast<float4 *>(xo + (int64_t)ci * L + g) = r;
+                *reinterpret_cast<float4 *>(as + ci * XLD + 4 * c4) = make_float4(lrelu(r.x, pre), lrelu(r.y, pre), lrelu(r.z, pre), lrelu(r.w, pre));
+            }
+        }
+    }
+    __syncthreads();
+    const int cw = wave * 64;
+    if (w0 + cw >= L) return;
+    float *yo = y + (int64_t)b * C * L + w0;
+    const unsigned Lu = (unsigned)L;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int col = cw + ct * 32 + l31;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = cb[r];
+#pragma unroll
+        for (int s = 0; s < 48; ++s) {
+            const int kk = 2 * s, tap = kk >> 5, in0 = kk & 31;      // this lane's k = kk + hi: same tap, channel in0 + hi
+            acc = mfma32(wa[s], as[(in0 + hi) * XLD + H + col + (tap - 1) * DIL], acc);
+        }
+        if (w0 + col < L) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yo[(unsigned)drow(r, hi) * Lu + (unsigned)col] = lrelu(acc[r], post);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// backward: persistent workgroups over tiles (utterance, WB columns).  Per tile: du and a = pre(xs) with halo in LDS (odd row stride:
+// the dW products read them with lane = channel); dxs for the tile's columns as 32 (in) x 96 (tap, out) x columns; this wave's share of
+// dW as 32 (out) x 32 (in) per tap with k = its columns, kept in accumulators over all tiles of the workgroup.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int DIL>
+__global__ void __launch_bounds__(256, 2) k_cconv_bwd(const float *__restrict__ xs, const float *__restrict__ y, const float *__restrict__ w,
+                                                      const float *__restrict__ dy, const float *__restrict__ gxs, float *__restrict__ dxs,
+                                                      float *__restrict__ partial, int L, int tiles_per_row, int ntiles, float pre, float post)
+{
+    constexpr int W = Cfg<DIL>::WB, H = Cfg<DIL>::H, XW = W + 2 * H, XLD = XW + 1 - (XW & 1) + 0, NF4 = XW / 4, TOTAL = C * NF4, NK = (TOTAL + 255) / 256;
+    static_assert(XLD % 2 == 1, "odd row stride: lanes that index rows hit different banks");
+    constexpr int WC = W / 4, NCT = WC / 32;           // columns per wave, 32-column tiles per wave
+    constexpr int SMEM = (2 * C * XLD > 4 * NW + 4 * C) ? 2 * C * XLD : 4 * NW + 4 * C;      // the two images; at the end the reduction buffer
+    __shared__ float smem[SMEM];
+    float *du = smem;                                  // dy * post'(y), column c at index c + H, zero outside the signal
+    float *aa = smem + C * XLD;                        // pre(xs), likewise
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    // A operand of the dxs product: lane (row = in channel l31, half hi) holds k' = 2 s + hi = tap * 32 + out: W[out][l31][tap]
+    float wt[48];
+#pragma unroll
+    for (int s = 0; s < 48; ++s) {
+        const int kk = 2 * s + hi;
+        wt[s] = w[((kk & 31) * C + l31) * KS + (kk >> 5)];
+    }
+    f32x16 dw[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dw[k][r] = 0.0f;
+    float db = 0.0f;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_row, w0 = (tile - b * tiles_per_row) * W;
+        {
+            const float *yr = y + (int64_t)b * C * L, *gr = dy + (int64_t)b * C * L, *xr = xs + (int64_t)b * C * L;
+            // two batches (dy and y, then xs): all three at once would not fit the registers next to the two operand sets
+            {
+                float4 ya[NK], ga[NK];
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const int idx = k * 256 + tid, ci = idx / NF4, c4 = idx - ci * NF4, g = w0 - H + 4 * c4;
+                    const bool ok = idx < TOTAL && g >= 0 && g < L;
+                    const int64_t off = (int64_t)ci * L + g;
+                    ya[k] = ok ? *reinterpret_cast<const float4 *>(yr + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    ga[k] = ok ? *reinterpret_cast<const float4 *>(gr + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const int idx = k * 256 + tid, ci = idx / NF4, c4 = idx - ci * NF4;
+                    if (idx < TOTAL) {
+                        float *d = du + ci * XLD + 4 * c4;
+                        d[0] = ga[k].x * dlrelu(ya[k].x, post); d[1] = ga[k].y * dlrelu(ya[k].y, post);
+                        d[2] = ga[k].z * dlrelu(ya[k].z, post); d[3] = ga[k].w * dlrelu(ya[k].w, post);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the second batch's loads behind the first batch's LDS writes
+            {
+                float4 xa[NK];
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const int idx = k * 256 + tid, ci = idx / NF4, c4 = idx - ci * NF4, g = w0 - H + 4 * c4;
+                    const bool ok = idx < TOTAL && g >= 0 && g < L;
+                    xa[k] = ok ? *reinterpret_cast<const float4 *>(xr + (int64_t)ci * L + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const int idx = k * 256 + tid, ci = idx / NF4, c4 = idx - ci * NF4;
+                    if (idx < TOTAL) {
+                        float *a = aa + ci * XLD + 4 * c4;
+                        a[0] = lrelu(xa[k].x, pre); a[1] = lrelu(xa[k].y, pre); a[2] = lrelu(xa[k].z, pre); a[3] = lrelu(xa[k].w, pre);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int cw = wave * WC;
+        if (w0 + cw < L) {
+            // ---- dxs[i][t] = gxs[i][t] + pre'(xs[i][t]) * sum_{tap, o} W[o][i][tap] du[o][t - (tap - 1) d]
+            if (dxs) {
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const int col = cw + ct * 32 + l31;
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+                    for (int s = 0; s < 48; ++s) {
+                        const int kk = 2 * s, tap = kk >> 5, o0 = kk & 31;
+                        acc = mfma32(wt[s], du[(o0 + hi) * XLD + H + col - (tap - 1) * DIL], acc);
+                    }
+                    if (w0 + col < L) {
+                        // uniform 64-bit bases, 32-bit per-lane offsets (32 L < 2^31): sixteen rows of addresses would otherwise cost 64 registers
+                        const float *gb = gxs ? gxs + (int64_t)b * C * L + w0 : nullptr;
+                        float *ob = dxs + (int64_t)b * C * L + w0;
+                        const unsigned Lu = (unsigned)L, o0 = (unsigned)(4 * hi) * Lu + (unsigned)col;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int i = drow(r, hi);
+                            const unsigned off = o0 + (unsigned)((r & 3) + 8 * (r >> 2)) * Lu;
+                            // a > 0 <=> xs > 0 (leaky-relu keeps the sign; a = 0 <=> xs = 0, where torch's gradient is the slope)
+                            const float m = aa[i * XLD + H + col] > 0.0f ? 1.0f : pre;
+                            const float g0 = gb ? gb[off] : 0.0f;
+                            ob[off] = fmaf(acc[r], m, g0);
+                        }
+                    }
+                }
+            }
+            // ---- dW[o][i][tap] += sum_t du[o][t] a[i][t + (tap - 1) d] over this wave's columns; db[o] += sum_t du[o][t]
+#pragma unroll 4
+            for (int s = 0; s < WC / 2; ++s) {
+                const int t = H + cw + 2 * s + hi;
+                const float av = du[l31 * XLD + t];
+                db += av;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dw[k] = mfma32(av, aa[l31 * XLD + t + (k - 1) * DIL], dw[k]);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- the workgroup's partial: the four waves' accumulators added in a fixed order through LDS ---------------------------------
+    float *red = smem;                                  // [wave][tap][out][in] = 4 x 3072 floats over the (dead) images
+    float *redb = smem + 4 * NW;                        // [wave][32]
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave * 3 + k) * C + drow(r, hi)) * C + l31] = dw[k][r];
+    db += __shfl_xor(db, 32, 64);
+    if (hi == 0) redb[wave * C + l31] = db;
+    __syncthreads();
+    float *pout = partial + (int64_t)blockIdx.x * PSTRIDE;
+    for (int e = tid; e < NW; e += 256) {              // e = (tap * 32 + out) * 32 + in  ->  weight layout [out][in][tap]
+        const int k = e / (C * C), o = (e / C) % C, i = e % C;
+        pout[(o * C + i) * KS + k] = (red[e] + red[NW + e]) + (red[2 * NW + e] + red[3 * NW + e]);
+    }
+    if (tid < C) pout[NW + tid] = (redb[tid] + redb[C + tid]) + (redb[2 * C + tid] + redb[3 * C + tid]);
+}
+
+// partial [nparts][PSTRIDE] -> dW [3072], db [32]: workgroup = 32 elements x 8 slices of the partials, each slice summed in order, the
+// eight slice sums added in order
+__global__ void __launch_bounds__(256) k_cconv_reduce(const float *__restrict__ partial, int nparts, float *__restrict__ dw, float *__restrict__ db)
+{
+    __shared__ float sl[8][32];
+    const int e = blockIdx.x * 32 + (threadIdx.x & 31), q = threadIdx.x >> 5;
+    const int per = (nparts + 7) / 8, p0 = q * per, p1 = min(nparts, p0 + per);
+    float acc = 0.0f;
+    if (e < PSTRIDE)
+        for (int p = p0; p < p1; ++p) acc += partial[(int64_t)p * PSTRIDE + e];
+    sl[q][threadIdx.x & 31] = acc;
+    __syncthreads();
+    if (q == 0 && e < PSTRIDE) {
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += sl[j][threadIdx.x];
+        if (e < NW) { if (dw) dw[e] = s; }
+        else if (db) db[e - NW] = s;
+    }
+}
+
+}  // namespace fdk_cconv
+
+namespace fdk {
+
+using namespace fdk_cconv;
+
+bool cconv_supported(int dil, int64_t L) { return (dil == 1 || dil == 2 || dil == 3 || dil == 4 || dil == 9 || dil == 27) && L >= 4 && L % 4 == 0 && L < ((int64_t)1 << 25); }
+
+int cconv_bwd_grid(const Launch &L_, int dil, int B, int64_t L)
+{
+    const int W = 128;
+    const int64_t ntiles = (int64_t)B * ((L + W - 1) / W);
+    return (int)std::min<int64_t>(ntiles, 2 * (int64_t)L_.ctx->num_cus);
+}
+size_t cconv_scratch_floats(const Launch &L_, int dil, int B, int64_t L) { return (size_t)cconv_bwd_grid(L_, dil, B, L) * PSTRIDE; }
+
+hipError_t cconv_forward(const Launch &L_, const float *x, const float *skip, const float *w, const float *bias, float *xs_out, float *y, int B,
+                         int64_t L, int dil, float pre, float post)
+{
+    const int tiles = (int)((L + 255) / 256);
+#define FD_CC_FWD(D)                                                                                                                  \
+    case D: FD_LAUNCH(L_, "cconv_fwd", k_cconv_fwd<D>, dim3(B * tiles), dim3(256), 0, x, skip, w, bias, xs_out, y, (int)L, tiles, pre, post); break
+    switch (dil) {
+        FD_CC_FWD(1); FD_CC_FWD(2); FD_CC_FWD(3); FD_CC_FWD(4); FD_CC_FWD(9); FD_CC_FWD(27);
+    default: return hipErrorInvalidValue;
+    }
+#undef FD_CC_FWD
+    return hipSuccess;
+}
+
+hipError_t cconv_backward(const Launch &L_, const float *xs, const float *y, const float *w, const float *dy, const float *gxs, float *dxs,
+                          float *dw, float *db, int B, int64_t L, int dil, float pre, float post, float *scratch)
+{
+    const int W = 128, tiles = (int)((L + W - 1) / W), ntiles = B * tiles, grid = cconv_bwd_grid(L_, dil, B, L);
+#define FD_CC_BWD(D)                                                                                                                  \
+    case D: FD_LAUNCH(L_, "cconv_bwd", k_cconv_bwd<D>, dim3(grid), dim3(256), 0, xs, y, w, dy, gxs, dxs, scratch, (int)L, tiles, ntiles, pre, post); break
+    switch (dil) {
+        FD_CC_BWD(1); FD_CC_BWD(2); FD_CC_BWD(3); FD_CC_BWD(4); FD_CC_BWD(9); FD_CC_BWD(27);
+    default: return hipErrorInvalidValue;
+    }
+#undef FD_CC_BWD
+    if (dw || db) FD_LAUNCH(L_, "cconv_reduce", k_cconv_reduce, dim3((PSTRIDE + 31) / 32), dim3(256), 0, (const float *)scratch, grid, dw, db);
+    return hipSuccess;
+}
+
+}  // namespace fdk

@@ -145,6 +145,77 @@ class _KConv(torch.autograd.Function):
         return (None if dx is None else dx.to(tx), None if dw is None else dw.to(tw), None if db is None else db.to(tb))
 
 
+class _Conv32(torch.autograd.Function):
+    """xs = x (+ skip); y = post(bias + conv1d(pre(xs), weight, dilation, padding = dilation)) -- one of the denoiser's 21 small
+    convolutions with everything the reference wraps around it (modules.py:136-137 and 209-212), forward in one HIP pass
+    (fd_conv32_forward) and backward in one pass plus a fixed-order reduction of the weight / bias gradients (fd_conv32_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, skip, weight, bias, dilation, pre_slope, post_slope):
+        ctx.in_dtypes = (x.dtype, None if skip is None else skip.dtype, weight.dtype, bias.dtype)
+        x, weight, bias = x.contiguous().float(), weight.contiguous().float(), bias.contiguous().float()
+        B, _, L = x.shape
+        y = torch.empty_like(x)
+        xs = x
+        if skip is not None:
+            skip = skip.contiguous().float()
+            xs = torch.empty_like(x)
+        lib, h = _handle(x.device)
+        _capi.check(lib, h, lib.fd_conv32_forward(h, x.data_ptr(), None if skip is None else skip.data_ptr(), weight.data_ptr(), bias.data_ptr(), B, L,
+                                                  int(dilation), float(pre_slope), float(post_slope), None if skip is None else xs.data_ptr(),
+                                                  y.data_ptr(), _stream(x.device)), "fd_conv32_forward")
+        ctx.save_for_backward(xs, y, weight)
+        ctx.cfg = (int(dilation), float(pre_slope), float(post_slope), skip is not None)
+        ctx.set_materialize_grads(False)                 # an output nobody differentiates arrives as None, not as a tensor of zeros
+        if skip is None:
+            return y.to(ctx.in_dtypes[0])
+        return xs.to(ctx.in_dtypes[0]), y.to(ctx.in_dtypes[0])
+
+    @staticmethod
+    def backward(ctx, *grads):
+        xs, y, weight = ctx.saved_tensors
+        dilation, pre, post, has_skip = ctx.cfg
+        gxs, gy = (grads if has_skip else (None, grads[0]))
+        B, _, L = xs.shape
+        need_x = ctx.needs_input_grad[0] or (has_skip and ctx.needs_input_grad[1])
+        need_w, need_b = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        lib, h = _handle(xs.device)
+        if gy is None:                                   # y had no reader: only the pass-through of xs is left
+            d = gxs
+            dw = torch.zeros_like(weight) if need_w else None
+            db = torch.zeros(32, device=xs.device) if need_b else None
+        else:
+            gy = gy.contiguous().float()
+            gxs = None if gxs is None else gxs.contiguous().float()
+            d = torch.empty_like(xs) if need_x else None
+            dw = torch.empty_like(weight) if need_w else None
+            db = torch.empty(32, device=xs.device, dtype=torch.float32) if need_b else None
+            _capi.check(lib, h, lib.fd_conv32_backward(h, xs.data_ptr(), y.data_ptr(), weight.data_ptr(), gy.data_ptr(),
+                                                       None if gxs is None else gxs.data_ptr(), B, L, dilation, pre, post,
+                                                       None if d is None else d.data_ptr(), None if dw is None else dw.data_ptr(),
+                                                       None if db is None else db.data_ptr(), _stream(xs.device)), "fd_conv32_backward")
+        tx, ts, tw, tb = ctx.in_dtypes
+        dx = d.to(tx) if (d is not None and ctx.needs_input_grad[0]) else None
+        ds = d.to(ts) if (d is not None and has_skip and ctx.needs_input_grad[1]) else None
+        return dx, ds, (None if dw is None else dw.to(tw)), (None if db is None else db.to(tb)), None, None, None
+
+
+def conv32_supported(x, weight, dilation):
+    """The shapes the HIP operator covers: 32 -> 32 channels, kernel 3, dilation 1 / 2 / 3 / 4 / 9 / 27 (every small convolution of
+    the model), a length that is a multiple of 4."""
+    return (x.is_cuda and x.dim() == 3 and x.shape[1] == 32 and tuple(weight.shape) == (32, 32, 3) and int(dilation) in (1, 2, 3, 4, 9, 27)
+            and x.shape[2] % 4 == 0 and 4 <= x.shape[2] < (1 << 25))
+
+
+def conv32(x, weight, bias, dilation, skip=None, pre_slope=0.2, post_slope=1.0):
+    """One small convolution of the denoiser as the reference applies it, as a differentiable HIP operator:
+        xs = x + skip (when a skip is given);   y = leaky_relu_post(bias + conv1d(leaky_relu_pre(xs), weight, dilation=d, padding=d))
+    with slope 1.0 = no activation.  DiffusionDBlock: conv32(x, w, b, d) (modules.py:136-137); TimeAware_LVCBlock layer i:
+    xs, y = conv32(x, w, b, 3 ** i, skip=audio_down, post_slope=0.2) (modules.py:209-212).  Returns y, or (xs, y) with a skip.
+    weight is the folded weight (torch._weight_norm of the module's weight_v / weight_g under weight-norm)."""
+    return _Conv32.apply(x, skip, weight, bias, dilation, pre_slope, post_slope)
+
+
 def kernel_conv_supported(x, weight):
     """The shapes the HIP kernels cover: 64 input channels, kernel 3, a multiple of 128 output channels, at most 128 frames (the
     reference trains on crops of 100: base.yaml:50-51)."""

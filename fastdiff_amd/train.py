@@ -6,7 +6,10 @@ gradients with respect to 175 parameter tensors.  Split used here: the location-
 each reading a predicted kernel 6144 x T floats large, the operator the reference implements with unfold + einsum over a
 [B, C, T, hop + 2, 3] view (modules.py:220-253) -- runs forward AND backward on the HIP operator
 (fastdiff_amd.location_variable_convolution: fd_lvc_forward / fd_lvc_backward); the plain convolutions, linear layers and
-activations around it are torch.autograd nodes on the module's own parameters (weight-norm included: the sub-modules of
+activations around it are torch.autograd nodes on the module's own parameters -- except the 21 small 32-channel convolutions (three per
+DiffusionDBlock, four per LVC block), each of which runs with its pre-activation, skip add, bias and post-activation as one HIP
+operator forward and backward (fastdiff_amd.conv32: fd_conv32_forward / fd_conv32_backward), the gate, and the predictor's
+kernel_conv; the rest stays on torch (weight-norm included: the sub-modules of
 fastdiff_amd.FastDiff are real nn.Conv1d / nn.Linear holders with the reference's weight_g / weight_v parametrisation), so the
 reference's optimizer, checkpointing and DDP wrapper see the module they expect.  FastDiff.forward takes this path when autograd is
 recording and the module is in train() mode or an input requires a gradient; everything else stays on the inference kernels.
@@ -24,23 +27,28 @@ def _swish(x):
     return x * torch.sigmoid(x)
 
 
-def _dblock(p, x):
-    """DiffusionDBlock.forward (modules.py:127-138); F.interpolate(size = L // factor) in its default nearest mode picks every
-    factor-th sample."""
-    size = x.shape[-1] // p.factor
-    residual = F.interpolate(p.residual_dense(x), size=size)
-    x = F.interpolate(x, size=size)
-    for layer in p.conv:
-        x = layer(F.leaky_relu(x, 0.2))
-    return x + residual
-
-
 def _conv_weight(m):
     """The effective weight of a conv module: g * v / ||v|| while weight-norm is attached (what its forward hook computes), the plain
     weight after remove_weight_norm()."""
     if hasattr(m, "weight_g"):
         return torch._weight_norm(m.weight_v, m.weight_g, 0)
     return m.weight
+
+
+def _dblock(p, x, cconv=None):
+    """DiffusionDBlock.forward (modules.py:127-138); F.interpolate(size = L // factor) in its default nearest mode picks every
+    factor-th sample.  The reference runs the 1 x 1 residual convolution at the full rate and then picks (modules.py:129-130); a
+    1 x 1 convolution commutes with picking columns, so here it runs on the picked columns: 1 / factor of the work, the same values
+    and the same gradients (only the picked columns ever receive one).  cconv: the HIP operator for `layer(leaky_relu(x, 0.2))`."""
+    size = x.shape[-1] // p.factor
+    x = F.interpolate(x, size=size)
+    residual = p.residual_dense(x)
+    for layer in p.conv:
+        if cconv is not None and cconv[1](x, layer.weight_v if hasattr(layer, "weight_v") else layer.weight, layer.dilation[0]):
+            x = cconv[0](x, _conv_weight(layer), layer.bias, layer.dilation[0])
+        else:
+            x = layer(F.leaky_relu(x, 0.2))
+    return x + residual
 
 
 def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None):
@@ -67,15 +75,19 @@ def _torch_gate(x, y):
     return x + torch.sigmoid(y[:, :C]) * torch.tanh(y[:, C:])
 
 
-def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate, kconv=None):
+def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate, kconv=None, cconv=None):
     """TimeAware_LVCBlock.forward (modules.py:189-218); the in-place `x += audio_down` of the reference written out of place."""
     C = cfg["inner_channels"]
     cond = c + p.fc_t(emb).unsqueeze(-1)
     kernels, bias = _kernel_predictor(p.kernel_predictor, cond, cfg["lvc_layers_each_block"], C, 2 * C, cfg["lvc_kernel_size"], kconv)
     x = p.upsample(F.leaky_relu(x, 0.2))
     for i, conv in enumerate(p.convs):
-        x = x + audio_down
-        y = F.leaky_relu(conv(F.leaky_relu(x, 0.2)), 0.2)
+        if cconv is not None and cconv[1](x, conv.weight_v if hasattr(conv, "weight_v") else conv.weight, conv.dilation[0]):
+            # x += audio_down; leaky_relu; conv; leaky_relu (modules.py:209-212) in one HIP pass each way
+            x, y = cconv[0](x, _conv_weight(conv), conv.bias, conv.dilation[0], skip=audio_down, post_slope=0.2)
+        else:
+            x = x + audio_down
+            y = F.leaky_relu(conv(F.leaky_relu(x, 0.2)), 0.2)
         y = lvc(y, kernels[i], bias[i], 1, p.cond_hop_length)
         x = gate(x, y)                                   # x + sigmoid(y[:, :C]) * tanh(y[:, C:])  (modules.py:217)
     return x
@@ -83,10 +95,11 @@ def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate, kconv=None)
 
 def differentiable_forward(module, data, lvc=None):
     """eps = net((audio, c, diffusion_steps)) as FastDiff.forward (FastDiff_model.py:74-102), recorded by autograd."""
-    gate, kconv = _torch_gate, None
-    if lvc is None:                    # the product path: the layer's two operators and the predictor's kernel_conv on HIP kernels
-        from .lvc_op import location_variable_convolution as lvc, gated_residual as gate, kernel_conv1d, kernel_conv_supported
+    gate, kconv, cconv = _torch_gate, None, None
+    if lvc is None:                    # the product path: the layer's operators, its convolution and the predictor's kernel_conv on HIP kernels
+        from .lvc_op import location_variable_convolution as lvc, gated_residual as gate, kernel_conv1d, kernel_conv_supported, conv32, conv32_supported
         kconv = (kernel_conv1d, kernel_conv_supported)
+        cconv = (conv32, conv32_supported)
     audio, c, diffusion_steps = data
     cfg = module._cfg
     if c.dim() == 2:
@@ -97,7 +110,7 @@ def differentiable_forward(module, data, lvc=None):
     skips = []
     for down in module.downsample:
         skips.append(x)
-        x = _dblock(down, x)
+        x = _dblock(down, x, cconv)
     for n, audio_down in enumerate(reversed(skips)):
-        x = _lvc_block(module.lvc_blocks[n], x, audio_down, c, emb, cfg, lvc, gate, kconv)
+        x = _lvc_block(module.lvc_blocks[n], x, audio_down, c, emb, cfg, lvc, gate, kconv, cconv)
     return module.final_conv(x)

@@ -188,6 +188,22 @@ FD_API int fd_kconv_backward(fd_handle h, const float *x, const float *weight, c
 FD_API int fd_gate_forward(fd_handle h, const float *x, const float *y, int B, int C, int64_t L, float *out, void *stream);
 FD_API int fd_gate_backward(fd_handle h, const float *y, const float *dout, int B, int C, int64_t L, float *dy, void *stream);
 
+/* The denoiser's 21 small convolutions on the training path -- DiffusionDBlock.conv[0..2] applied as `layer(F.leaky_relu(x, 0.2))`
+ * (modules/FastDiff/module/modules.py:120-125,136-137) and TimeAware_LVCBlock.convs[0..3] applied as `x += audio_down;
+ * y = F.leaky_relu(conv(F.leaky_relu(x, 0.2)), 0.2)` (modules.py:183-187,209-212) -- as one differentiable operator:
+ *   xs = x (+ skip);   y = post(bias + conv1d(pre(xs), weight, dilation, padding = dilation)),   pre / post = leaky_relu with the given
+ *   slope, slope 1 = no activation.   x, skip, xs, y, dy, gxs, dxs [B,32,L];  weight [32,32,3] (folded: the caller applies weight-norm),
+ *   bias [32];  L a multiple of 4, dilation one of 1, 2, 3, 4, 9, 27.
+ * forward: skip may be NULL (then xs = x and xs_out may be NULL); with a skip xs_out receives x + skip (the layer's gate reads it).
+ * backward: xs = the convolution's un-activated input (x + skip, or x), y = the forward's output (its sign is the post-activation's
+ * mask), gxs (nullable) = the gradient that reached xs from its other readers; writes dxs = gxs + pre'(xs) * (W^T * (dy * post'(y)))
+ * (the gradient of x and of skip alike), dweight [32,32,3], dbias [32] (each nullable).  Sums are formed in a fixed order. */
+FD_API int fd_conv32_forward(fd_handle h, const float *x, const float *skip, const float *weight, const float *bias, int B, int64_t L,
+                             int dilation, float pre_slope, float post_slope, float *xs_out, float *y, void *stream);
+FD_API int fd_conv32_backward(fd_handle h, const float *xs, const float *y, const float *weight, const float *dy, const float *gxs, int B,
+                              int64_t L, int dilation, float pre_slope, float post_slope, float *dxs, float *dweight, float *dbias,
+                              void *stream);
+
 /* Mel front-end in front of the vocoder: process_utterance(..., vocoder='pwg') of
  * data_gen/tts/data_gen_utils.py:93-147 = librosa.stft(n_fft 1024, hop 256, win 1024, "hann", center, pad_mode "constant") ->
  * magnitude -> librosa.filters.mel(22050, 1024, 80, fmin 80, fmax 7600) -> log10(max(1e-6, .)).

@@ -193,3 +193,72 @@ def test_kernel_conv_operator_forward_and_backward_match_torch_autograd(shape):
     assert rel(x2.grad, x64.grad) < 3e-6
     with pytest.raises(NotImplementedError, match="128"):          # more than 128 frames: refused, never silently computed elsewhere
         fastdiff_amd.kernel_conv1d(torch.zeros(1, 64, 200).cuda(), w.cuda(), bias.cuda())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,L,dil,skip,post", [(2, 1024, 1, True, 0.2), (3, 388, 3, True, 0.2), (1, 2560, 9, True, 0.2), (2, 904, 27, True, 0.2),
+                                                (2, 640, 1, False, 1.0), (1, 132, 2, False, 1.0), (3, 260, 4, False, 1.0), (1, 4, 27, True, 0.2),
+                                                (20, 25600, 27, True, 0.2)])
+def test_conv32_operator_forward_and_backward_match_torch_autograd(B, L, dil, skip, post):
+    """fastdiff_amd.conv32 = one small convolution of the denoiser as the reference applies it -- `x += audio_down; y =
+    leaky_relu(conv(leaky_relu(x, 0.2)), 0.2)` (modules.py:209-212) or `layer(leaky_relu(x, 0.2))` (modules.py:136-137) -- one HIP pass
+    forward and one backward, against the same lines on torch autograd in float64: y, xs, and the gradients of x, skip, weight and
+    bias, with a gradient arriving at xs from another reader as in the LVC layer (the gate).  Tile edges (lengths that are not
+    multiples of the 256 / 128-column tiles), every dilation of the model, one quad of columns, and the training shape itself."""
+    import fastdiff_amd
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(L + 7 * dil)
+    x = torch.randn(B, 32, L, generator=g)
+    sk = torch.randn(B, 32, L, generator=g) if skip else None
+    x[0, 0, :4] = torch.tensor([0.0, -0.0, 1e-30, -1e-30])                       # the activation's kink
+    if skip:
+        sk[0, 0, :4] = 0.0
+    w = torch.randn(32, 32, 3, generator=g) / 9.8
+    bias = torch.randn(32, generator=g)
+    gy, gxs = torch.randn(B, 32, L, generator=g), torch.randn(B, 32, L, generator=g)
+    big = B * L > 100000
+    dt = torch.float32 if big else torch.float64                                  # (the training shape: float32 on the GPU as the yardstick)
+    dev = "cuda" if big else "cpu"
+    x64, w64, b64 = (t.to(dev, dt).requires_grad_(True) for t in (x, w, bias))
+    s64 = sk.to(dev, dt).requires_grad_(True) if skip else None
+    xs64 = x64 + s64 if skip else x64
+    y64 = F.conv1d(F.leaky_relu(xs64, 0.2), w64, b64, padding=dil, dilation=dil)
+    if post != 1.0:
+        y64 = F.leaky_relu(y64, post)
+    ((y64 * gy.to(dev, dt)).sum() + ((xs64 * gxs.to(dev, dt)).sum() if skip else 0.0)).backward()
+    xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, bias))
+    sg = sk.cuda().requires_grad_(True) if skip else None
+    out = fastdiff_amd.conv32(xg, wg, bg, dil, skip=sg, post_slope=post)
+    if skip:
+        xs, y = out
+        ((y * gy.cuda()).sum() + (xs * gxs.cuda()).sum()).backward()
+        assert torch.equal(xs.detach(), (xg + sg).detach())
+        assert torch.equal(xg.grad, sg.grad)                                      # x and skip receive the same gradient
+    else:
+        y = out
+        (y * gy.cuda()).sum().backward()
+    rel = lambda got, want: float((got.double().cpu() - want.double().cpu()).abs().max()) / max(1.0, float(want.abs().max()))      # noqa: E731
+    tol = 2e-5 if big else 3e-6
+    assert rel(y.detach(), y64.detach()) < tol
+    assert rel(xg.grad, x64.grad) < tol and rel(wg.grad, w64.grad) < tol and rel(bg.grad, b64.grad) < tol
+    # the weight and bias gradients are summed in a fixed order: the same bits on a second run
+    xg2, wg2, bg2 = (t.cuda().requires_grad_(True) for t in (x, w, bias))
+    out2 = fastdiff_amd.conv32(xg2, wg2, bg2, dil, skip=None if not skip else sk.cuda().requires_grad_(True), post_slope=post)
+    if skip:
+        ((out2[1] * gy.cuda()).sum() + (out2[0] * gxs.cuda()).sum()).backward()
+    else:
+        (out2 * gy.cuda()).sum().backward()
+    assert torch.equal(wg2.grad, wg.grad) and torch.equal(bg2.grad, bg.grad) and torch.equal(xg2.grad, xg.grad)
+
+
+@pytest.mark.gpu
+def test_conv32_refuses_what_it_has_no_kernel_for():
+    import fastdiff_amd
+    w, b = torch.zeros(32, 32, 3).cuda(), torch.zeros(32).cuda()
+    with pytest.raises(NotImplementedError, match="multiple of 4"):
+        fastdiff_amd.conv32(torch.zeros(1, 32, 6).cuda(), w, b, 1)
+    with pytest.raises(NotImplementedError, match="dilation"):
+        fastdiff_amd.conv32(torch.zeros(1, 32, 64).cuda(), w, b, 5)
+    from fastdiff_amd.lvc_op import conv32_supported
+    assert conv32_supported(torch.zeros(1, 32, 64).cuda(), w, 27) and not conv32_supported(torch.zeros(1, 32, 6).cuda(), w, 1)
+    assert not conv32_supported(torch.zeros(1, 16, 64).cuda(), w, 1) and not conv32_supported(torch.zeros(1, 32, 64), w, 1)
