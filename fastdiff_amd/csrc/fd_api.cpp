@@ -1514,7 +1514,7 @@ int fd_kconv_forward(fd_handle h, const float *x, const float *weight, const flo
     if (!h) return FD_ERR_INVALID;
     if (!x || !weight || !bias || !out) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_forward: null pointer");
     if (B <= 0 || B > 65535) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_forward: B=%d", B);
-    if (!fdk::kconv_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_forward: M=%d (a multiple of 128) and T=%d (1..128) only", M, T);
+    if (!fdk::kconv_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_forward: M=%d (a multiple of 32) and T=%d (1..128) only", M, T);
     FD_HIP(h, hipSetDevice(h->device));
     fdk::Launch La = {h, (hipStream_t)stream, false};
     hipError_t e = fdk::kconv_forward(La, x, weight, bias, out, B, M, T);
@@ -1528,7 +1528,7 @@ int fd_kconv_backward(fd_handle h, const float *x, const float *weight, const fl
     if (!h) return FD_ERR_INVALID;
     if (!dout || ((dweight || dbias) && !x) || (dx && !weight)) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward: null pointer");
     if (B <= 0 || B > 65535) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward: B=%d", B);
-    if (!fdk::kconv_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_backward: M=%d (a multiple of 128) and T=%d (1..128) only", M, T);
+    if (!fdk::kconv_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_backward: M=%d (a multiple of 32) and T=%d (1..128) only", M, T);
     FD_HIP(h, hipSetDevice(h->device));
     {
         const size_t bytes = sizeof(float) * fdk::kconv_scratch_floats(B, M, T);
@@ -1592,6 +1592,31 @@ int fd_conv32_backward(fd_handle h, const float *xs, const float *y, const float
     }
     hipError_t e = fdk::cconv_backward(La, xs, y, weight, dy, gxs, dxs, dweight, dbias, B, L, dilation, pre_slope, post_slope, h->cconv_scratch);
     if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_conv32_backward: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+int fd_weight_norm_forward(fd_handle h, const float *v, const float *g, int64_t rows, int cols, float *w, float *norm, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!v || !g || !w || !norm) FD_FAIL(h, FD_ERR_INVALID, "fd_weight_norm_forward: null pointer");
+    if (rows <= 0 || cols <= 0 || rows > ((int64_t)1 << 31)) FD_FAIL(h, FD_ERR_INVALID, "fd_weight_norm_forward: rows=%lld cols=%d", (long long)rows, cols);
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::weight_norm_forward(La, v, g, w, norm, rows, cols);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_weight_norm_forward: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+int fd_weight_norm_backward(fd_handle h, const float *v, const float *g, const float *norm, const float *dw, int64_t rows, int cols, float *dv,
+                            float *dg, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!v || !g || !norm || !dw || !dv || !dg) FD_FAIL(h, FD_ERR_INVALID, "fd_weight_norm_backward: null pointer");
+    if (rows <= 0 || cols <= 0 || rows > ((int64_t)1 << 31)) FD_FAIL(h, FD_ERR_INVALID, "fd_weight_norm_backward: rows=%lld cols=%d", (long long)rows, cols);
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::weight_norm_backward(La, v, g, norm, dw, dv, dg, rows, cols);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_weight_norm_backward: %s", hipGetErrorString(e));
     return FD_OK;
 }
 

@@ -46,4 +46,8 @@ hipError_t cconv_forward(const Launch &L, const float *x, const float *skip, con
                          int64_t len, int dil, float pre, float post);
 hipError_t cconv_backward(const Launch &L, const float *xs, const float *y, const float *w, const float *dy, const float *gxs, float *dxs,
                           float *dw, float *db, int B, int64_t len, int dil, float pre, float post, float *scratch);
+// torch._weight_norm(v, g, 0) on a [rows, cols] view and its backward (fd_kernels_cconv.hip)
+hipError_t weight_norm_forward(const Launch &L, const float *v, const float *g, float *w, float *norm, int64_t rows, int cols);
+hipError_t weight_norm_backward(const Launch &L, const float *v, const float *g, const float *norm, const float *dw, float *dv, float *dg,
+                                int64_t rows, int cols);
 }  // namespace fdk

@@ -263,11 +263,64 @@ __global__ void __launch_bounds__(256) k_cconv_reduce(const float *__restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// weight-norm (FastDiff_model.py:115-122: torch.nn.utils.weight_norm on every Conv1d = torch._weight_norm(v, g, 0)):
+//   w[r, :] = v[r, :] * g[r] / ||v[r, :]||,   and from dw:   dg[r] = <dw[r], v[r]> / ||v[r]||,   dv[r] = (g / ||v||) (dw[r] - v[r] <dw[r], v[r]> / ||v||^2)
+// one wave per row (row = output channel, cols = in * k: 7 .. 400), sums by a butterfly: the same order every run
+// ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_wn_fwd(const float *__restrict__ v, const float *__restrict__ g, float *__restrict__ w,
+                                                float *__restrict__ norm, int64_t rows, int cols)
+{
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const float *vr = v + r * cols;
+    float ss = 0.0f;
+    for (int c = lane; c < cols; c += 64) ss = fmaf(vr[c], vr[c], ss);
+    const float nrm = sqrtf(wave_sum(ss)), sc = g[r] / nrm;
+    for (int c = lane; c < cols; c += 64) w[r * cols + c] = vr[c] * sc;
+    if (lane == 0) norm[r] = nrm;
+}
+
+__global__ void __launch_bounds__(256) k_wn_bwd(const float *__restrict__ v, const float *__restrict__ g, const float *__restrict__ norm,
+                                                const float *__restrict__ dw, float *__restrict__ dv, float *__restrict__ dg, int64_t rows, int cols)
+{
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const float *vr = v + r * cols, *dr = dw + r * cols;
+    float dot = 0.0f;
+    for (int c = lane; c < cols; c += 64) dot = fmaf(dr[c], vr[c], dot);
+    dot = wave_sum(dot);
+    const float nrm = norm[r], gn = g[r] / nrm, k2 = dot / (nrm * nrm);
+    for (int c = lane; c < cols; c += 64) dv[r * cols + c] = gn * (dr[c] - vr[c] * k2);
+    if (lane == 0) dg[r] = dot / nrm;
+}
+
 }  // namespace fdk_cconv
 
 namespace fdk {
 
 using namespace fdk_cconv;
+
+hipError_t weight_norm_forward(const Launch &L_, const float *v, const float *g, float *w, float *norm, int64_t rows, int cols)
+{
+    FD_LAUNCH(L_, "weight_norm_fwd", k_wn_fwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, v, g, w, norm, rows, cols);
+    return hipSuccess;
+}
+hipError_t weight_norm_backward(const Launch &L_, const float *v, const float *g, const float *norm, const float *dw, float *dv, float *dg,
+                                int64_t rows, int cols)
+{
+    FD_LAUNCH(L_, "weight_norm_bwd", k_wn_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, v, g, norm, dw, dv, dg, rows, cols);
+    return hipSuccess;
+}
 
 bool cconv_supported(int dil, int64_t L) { return (dil == 1 || dil == 2 || dil == 3 || dil == 4 || dil == 9 || dil == 27) && L >= 4 && L % 4 == 0 && L < ((int64_t)1 << 25); }
 

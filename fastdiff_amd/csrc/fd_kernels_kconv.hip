@@ -1,5 +1,6 @@
 // fd_kernels_kconv.hip -- the KernelPredictor's `kernel_conv` for the TRAINING path: Conv1d(64 -> M, k = 3, pad 1)
-// with M = 24576 (modules/FastDiff/module/modules.py:315-318,330-331), forward and the three gradients, in the reference's own tensor
+// with M = 24576 (modules/FastDiff/module/modules.py:315-318,330-331) -- and, since round 4, its `bias_conv` (M = 256, :316-318) and the
+// six 64 -> 64 convolutions of its residual stack (:303-314): any M that is a multiple of 32 --, forward and the three gradients, in the reference's own tensor
 // layouts (h [B,64,T], weight [M,64,3], bias [M], out [B,M,T]) on the exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32: training
 // keeps fp32 products).  Per block of the network this is the largest matrix product of the training step
 // (2 * 24576 * 192 * B*T flops each way: 18.9 GFLOP at the reference's batch of 20 x 100 frames), which eager PyTorch runs as MIOpen
@@ -55,15 +56,16 @@ __global__ void __launch_bounds__(256, 2) k_kc_fwd(const float *__restrict__ h, 
     const int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
     // reduction index of step s in lane half hi: 96 hi + s = c * 3 + tap, i.e. the halves split the input channels (32 each):
     // A = 24 aligned float4 of the lane's weight row, B = hs[(32 hi + s / 3) * LD + s % 3 + t]: one base register + an immediate
+    const bool live = p0 < M;      // M a multiple of 32, not necessarily of 128: the last workgroup's waves beyond M only stage and wait
     float4 a[24];
     {
-        const float4 *wp = reinterpret_cast<const float4 *>(W + (int64_t)(p0 + l31) * KK) + 24 * hi;
+        const float4 *wp = reinterpret_cast<const float4 *>(W + (int64_t)(live ? p0 + l31 : 0) * KK) + 24 * hi;
 #pragma unroll
         for (int q = 0; q < 24; ++q) a[q] = wp[q];
     }
     float bz[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bz[r] = bias[p0 + drow(r, hi)];
+    for (int r = 0; r < 16; ++r) bz[r] = bias[live ? p0 + drow(r, hi) : 0];
     const int nct = (T + 31) / 32;                      // <= 4 (T <= 128)
     const float *hb = hs + hi * 32 * LD + l31;
     zero_h(hs, tid);
@@ -71,6 +73,7 @@ __global__ void __launch_bounds__(256, 2) k_kc_fwd(const float *__restrict__ h, 
         __syncthreads();
         stage_h(hs, h, b, T, tid);
         __syncthreads();
+        if (!live) continue;
         // all column tiles of the utterance first, their stores together at the end: the pieces of an output row (T floats, not a
         // multiple of a cache line) then reach L2 back to back and leave it as whole lines
         f32x16 acc[4];
@@ -121,10 +124,11 @@ __global__ void __launch_bounds__(256, 2) k_kc_dw(const float *__restrict__ h, c
     }
     float accb = 0.0f;
     const int nq = (T + 7) / 8;                    // <= 16
+    const bool live = p0 < M;                      // (M a multiple of 32: see k_kc_fwd)
     zero_h(hs, tid);
     for (int b = b0; b < b1; ++b) {
         // this lane's row of dout: all of it is requested before h is staged, so the loads fly during the staging and the barriers
-        const float *dr = dout + ((int64_t)b * M + p0 + l31) * T;
+        const float *dr = dout + ((int64_t)b * M + (live ? p0 + l31 : 0)) * T;
         float4 dv[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -137,6 +141,7 @@ __global__ void __launch_bounds__(256, 2) k_kc_dw(const float *__restrict__ h, c
         __syncthreads();
         stage_h(hs, h, b, T, tid);
         __syncthreads();
+        if (!live) continue;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             if (q < nq) {
@@ -150,6 +155,7 @@ __global__ void __launch_bounds__(256, 2) k_kc_dw(const float *__restrict__ h, c
             }
         }
     }
+    if (!live) return;
     // partial sums of this utterance range: [range][M][192] and, behind them, [range][M] for the bias
     float *pw = part + (int64_t)blockIdx.y * M * KK;
 #pragma unroll
@@ -262,7 +268,7 @@ __global__ void __launch_bounds__(256) k_kc_dh_fold(const float *__restrict__ pa
 namespace fdk {
 using namespace fdk_kconv;
 
-bool kconv_supported(int M, int T) { return M > 0 && M % 128 == 0 && T >= 1 && T <= 128; }
+bool kconv_supported(int M, int T) { return M > 0 && M % 32 == 0 && T >= 1 && T <= 128; }
 
 // How many ranges to cut `units` (utterances / row chunks) into when `per_range` workgroups work on each range: the CUs take the
 // workgroups in turn, so the launch lasts (workgroups per CU) x (units per range); the smallest product wins, then the fewest ranges.
@@ -282,7 +288,7 @@ size_t kconv_scratch_floats(int B, int M, int T) { return (size_t)KC_DH_SLICES *
 
 hipError_t kconv_forward(const Launch &L, const float *h, const float *W, const float *bias, float *out, int B, int M, int T)
 {
-    const int gx = M / 128;
+    const int gx = (M + 127) / 128;
     const int ny0 = pick_ranges(gx, B, 16, L.ctx->num_cus), bchunk = (B + ny0 - 1) / ny0, ny = (B + bchunk - 1) / bchunk;
     FD_LAUNCH(L, "kconv_forward", k_kc_fwd, dim3(gx, ny), dim3(256), 0, h, W, bias, out, B, M, T, bchunk);
     return hipSuccess;
@@ -293,7 +299,7 @@ hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const
 {
     float *part_h = scratch, *part_w = scratch + (size_t)KC_DH_SLICES * B * KK * T;
     if (dW || dbias) {
-        const int gx = M / 128;
+        const int gx = (M + 127) / 128;
         const int ny0 = pick_ranges(gx, B, KC_DW_RANGES, L.ctx->num_cus), bchunk = (B + ny0 - 1) / ny0, ny = (B + bchunk - 1) / bchunk;
         if (T % 4 == 0) FD_LAUNCH(L, "kconv_backward_w", k_kc_dw<true>, dim3(gx, ny), dim3(256), 0, h, dout, part_w, B, M, T, bchunk);
         else FD_LAUNCH(L, "kconv_backward_w", k_kc_dw<false>, dim3(gx, ny), dim3(256), 0, h, dout, part_w, B, M, T, bchunk);

@@ -145,6 +145,42 @@ class _KConv(torch.autograd.Function):
         return (None if dx is None else dx.to(tx), None if dw is None else dw.to(tw), None if db is None else db.to(tb))
 
 
+class _WeightNorm(torch.autograd.Function):
+    """w = torch._weight_norm(v, g, 0) (what torch.nn.utils.weight_norm's hook evaluates on every forward, FastDiff_model.py:115-122)
+    as one HIP launch forward (fd_weight_norm_forward) and one backward (fd_weight_norm_backward)."""
+
+    @staticmethod
+    def forward(ctx, v, g):
+        v, g = v.contiguous(), g.contiguous()
+        rows, cols = v.shape[0], v.numel() // v.shape[0]
+        w = torch.empty_like(v)
+        norm = torch.empty(rows, device=v.device, dtype=torch.float32)
+        lib, h = _handle(v.device)
+        _capi.check(lib, h, lib.fd_weight_norm_forward(h, v.data_ptr(), g.data_ptr(), rows, cols, w.data_ptr(), norm.data_ptr(), _stream(v.device)),
+                    "fd_weight_norm_forward")
+        ctx.save_for_backward(v, g, norm)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        v, g, norm = ctx.saved_tensors
+        dw = dw.contiguous().float()
+        rows, cols = v.shape[0], v.numel() // v.shape[0]
+        dv, dg = torch.empty_like(v), torch.empty_like(g)
+        lib, h = _handle(v.device)
+        _capi.check(lib, h, lib.fd_weight_norm_backward(h, v.data_ptr(), g.data_ptr(), norm.data_ptr(), dw.data_ptr(), rows, cols, dv.data_ptr(),
+                                                        dg.data_ptr(), _stream(v.device)), "fd_weight_norm_backward")
+        return dv, dg
+
+
+def weight_norm(v, g):
+    """torch._weight_norm(v, g, 0) for float32 HIP tensors (g of shape [out, 1, ...]) as a differentiable HIP operator; anything else
+    goes to torch."""
+    if v.is_cuda and v.dtype == torch.float32 and g.dtype == torch.float32 and g.numel() == v.shape[0]:
+        return _WeightNorm.apply(v, g)
+    return torch._weight_norm(v, g, 0)
+
+
 class _Conv32(torch.autograd.Function):
     """xs = x (+ skip); y = post(bias + conv1d(pre(xs), weight, dilation, padding = dilation)) -- one of the denoiser's 21 small
     convolutions with everything the reference wraps around it (modules.py:136-137 and 209-212), forward in one HIP pass
@@ -217,10 +253,10 @@ def conv32(x, weight, bias, dilation, skip=None, pre_slope=0.2, post_slope=1.0):
 
 
 def kernel_conv_supported(x, weight):
-    """The shapes the HIP kernels cover: 64 input channels, kernel 3, a multiple of 128 output channels, at most 128 frames (the
-    reference trains on crops of 100: base.yaml:50-51)."""
+    """The shapes the HIP kernels cover: 64 input channels, kernel 3, a multiple of 32 output channels (kernel_conv 24576, bias_conv
+    256, the predictor's residual convolutions 64), at most 128 frames (the reference trains on crops of 100: base.yaml:50-51)."""
     return (x.is_cuda and x.dim() == 3 and weight.dim() == 3 and x.shape[1] == 64 and tuple(weight.shape[1:]) == (64, 3)
-            and weight.shape[0] % 128 == 0 and 1 <= x.shape[2] <= 128)
+            and weight.shape[0] % 32 == 0 and 1 <= x.shape[2] <= 128)
 
 
 def kernel_conv1d(x, weight, bias):

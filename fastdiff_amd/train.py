@@ -28,11 +28,21 @@ def _swish(x):
 
 
 def _conv_weight(m):
-    """The effective weight of a conv module: g * v / ||v|| while weight-norm is attached (what its forward hook computes), the plain
-    weight after remove_weight_norm()."""
+    """The effective weight of a conv module: g * v / ||v|| while weight-norm is attached (what its forward hook computes: on HIP
+    tensors one launch of fastdiff_amd.lvc_op.weight_norm each way), the plain weight after remove_weight_norm()."""
     if hasattr(m, "weight_g"):
+        if m.weight_v.is_cuda:
+            from .lvc_op import weight_norm
+            return weight_norm(m.weight_v, m.weight_g)
         return torch._weight_norm(m.weight_v, m.weight_g, 0)
     return m.weight
+
+
+def _conv(m, x):
+    """m(x) for a Conv1d holder: on HIP tensors the weight-norm runs on this repo's operator (the module's own hook would run torch's)."""
+    if x.is_cuda and hasattr(m, "weight_g"):
+        return F.conv1d(x, _conv_weight(m), m.bias, stride=m.stride, padding=m.padding, dilation=m.dilation)
+    return m(x)
 
 
 def _dblock(p, x, cconv=None):
@@ -42,12 +52,12 @@ def _dblock(p, x, cconv=None):
     and the same gradients (only the picked columns ever receive one).  cconv: the HIP operator for `layer(leaky_relu(x, 0.2))`."""
     size = x.shape[-1] // p.factor
     x = F.interpolate(x, size=size)
-    residual = p.residual_dense(x)
+    residual = _conv(p.residual_dense, x)
     for layer in p.conv:
         if cconv is not None and cconv[1](x, layer.weight_v if hasattr(layer, "weight_v") else layer.weight, layer.dilation[0]):
             x = cconv[0](x, _conv_weight(layer), layer.bias, layer.dilation[0])
         else:
-            x = layer(F.leaky_relu(x, 0.2))
+            x = _conv(layer, F.leaky_relu(x, 0.2))
     return x + residual
 
 
@@ -55,19 +65,26 @@ def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None):
     """KernelPredictor.forward (modules.py:320-343).  kconv: the HIP operator for kernel_conv (64 -> 24576 channels: the largest
     matrix product of the step) where its shapes fit, else the module's own convolution."""
     B, _, T = c.shape
-    c = p.input_conv(c)
-    c = c + p.residual_conv(c)
-    kc = p.kernel_conv
-    if kconv is not None and kconv[1](c, kc.weight_v if hasattr(kc, "weight_v") else kc.weight):
-        k = kconv[0](c, _conv_weight(kc), kc.bias)
-    else:
-        k = kc(c)
+
+    def conv(m, h):      # a 64 -> M, k3 convolution of the predictor: the HIP operator where its shapes fit, else the module itself
+        if kconv is not None and isinstance(m, torch.nn.Conv1d) and m.padding == (1,) and m.dilation == (1,) and \
+                kconv[1](h, m.weight_v if hasattr(m, "weight_v") else m.weight):
+            return kconv[0](h, _conv_weight(m), m.bias)
+        return _conv(m, h) if isinstance(m, torch.nn.Conv1d) else m(h)
+
+    for m in p.input_conv:                       # Conv1d 80 -> 64 k5, LeakyReLU(0.1)
+        c = conv(m, c)
+    r = c
+    for m in p.residual_conv:                    # Dropout(p = 0), Conv1d 64 -> 64 k3, LeakyReLU(0.1), Conv1d, LeakyReLU, three times
+        r = conv(m, r) if isinstance(m, torch.nn.Conv1d) else m(r)
+    c = c + r
+    k = conv(p.kernel_conv, c)
     # the reference slices kernels[:, i] (modules.py:213-214), whose backward builds a zero tensor of all four layers per slice and
     # adds the four up; unbind hands autograd the same views and gets one stack back.  (One kernel_conv call per layer on that
     # layer's weight rows -- contiguous kernels, no stack -- measured slower: 18.3 vs 17.1 ms per step; the slices of the WEIGHT then
     # pay the same zero-fill-and-add in their backward.)
     return (k.contiguous().view(B, layers, cin, cout, ks, T).unbind(1),
-            p.bias_conv(c).contiguous().view(B, layers, cout, T).unbind(1))
+            conv(p.bias_conv, c).contiguous().view(B, layers, cout, T).unbind(1))
 
 
 def _torch_gate(x, y):
@@ -87,7 +104,7 @@ def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate, kconv=None,
             x, y = cconv[0](x, _conv_weight(conv), conv.bias, conv.dilation[0], skip=audio_down, post_slope=0.2)
         else:
             x = x + audio_down
-            y = F.leaky_relu(conv(F.leaky_relu(x, 0.2)), 0.2)
+            y = F.leaky_relu(_conv(conv, F.leaky_relu(x, 0.2)), 0.2)
         y = lvc(y, kernels[i], bias[i], 1, p.cond_hop_length)
         x = gate(x, y)                                   # x + sigmoid(y[:, :C]) * tanh(y[:, C:])  (modules.py:217)
     return x
@@ -106,11 +123,11 @@ def differentiable_forward(module, data, lvc=None):
         c = c.unsqueeze(0)
     emb = calc_diffusion_step_embedding(diffusion_steps.to(audio.dtype).view(audio.shape[0], 1), cfg["diffusion_step_embed_dim_in"])
     emb = _swish(module.fc_t2(_swish(module.fc_t1(emb))))
-    x = module.first_audio_conv(audio)
+    x = _conv(module.first_audio_conv, audio)
     skips = []
     for down in module.downsample:
         skips.append(x)
         x = _dblock(down, x, cconv)
     for n, audio_down in enumerate(reversed(skips)):
         x = _lvc_block(module.lvc_blocks[n], x, audio_down, c, emb, cfg, lvc, gate, kconv, cconv)
-    return module.final_conv(x)
+    return _conv(module.final_conv[0], x)

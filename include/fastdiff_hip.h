@@ -188,6 +188,13 @@ FD_API int fd_kconv_backward(fd_handle h, const float *x, const float *weight, c
 FD_API int fd_gate_forward(fd_handle h, const float *x, const float *y, int B, int C, int64_t L, float *out, void *stream);
 FD_API int fd_gate_backward(fd_handle h, const float *y, const float *dout, int B, int C, int64_t L, float *dy, void *stream);
 
+/* Weight-norm of the training path: every Conv1d of the model carries torch.nn.utils.weight_norm (FastDiff_model.py:71-72,115-122), i.e.
+ * its forward evaluates w = torch._weight_norm(v, g, 0): w[r, :] = v[r, :] * g[r] / ||v[r, :]|| on the [rows = out channels, cols = in * k]
+ * view.  forward also leaves ||v[r]|| in norm [rows] for the backward, which turns dw into dv [rows, cols] and dg [rows]. */
+FD_API int fd_weight_norm_forward(fd_handle h, const float *v, const float *g, int64_t rows, int cols, float *w, float *norm, void *stream);
+FD_API int fd_weight_norm_backward(fd_handle h, const float *v, const float *g, const float *norm, const float *dw, int64_t rows, int cols,
+                                   float *dv, float *dg, void *stream);
+
 /* The denoiser's 21 small convolutions on the training path -- DiffusionDBlock.conv[0..2] applied as `layer(F.leaky_relu(x, 0.2))`
  * (modules/FastDiff/module/modules.py:120-125,136-137) and TimeAware_LVCBlock.convs[0..3] applied as `x += audio_down;
  * y = F.leaky_relu(conv(F.leaky_relu(x, 0.2)), 0.2)` (modules.py:183-187,209-212) -- as one differentiable operator:

@@ -165,11 +165,12 @@ def test_gate_operator_forward_and_backward_match_torch_autograd(shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(3, 256, 100), (2, 128, 37), (1, 384, 128), (2, 128, 1)])
+@pytest.mark.parametrize("shape", [(3, 256, 100), (2, 128, 37), (1, 384, 128), (2, 128, 1), (20, 64, 100), (2, 96, 50), (3, 32, 7)])
 def test_kernel_conv_operator_forward_and_backward_match_torch_autograd(shape):
     """fastdiff_amd.kernel_conv1d = the predictor's kernel_conv, Conv1d(64 -> M, k3, pad 1) (modules.py:315-318,330-331), forward and
     its three gradients on fp32-MFMA HIP kernels, against torch's conv1d and autograd in float64 (T a multiple of 4 and not, one
-    frame, a last column tile of every fill)."""
+    frame, a last column tile of every fill; M = 64 / 96 / 32: the predictor's residual convolutions and other row counts that leave
+    waves of the last 128-row workgroup without rows)."""
     import fastdiff_amd
     import torch.nn.functional as F
     B, M, T = shape
@@ -262,3 +263,23 @@ def test_conv32_refuses_what_it_has_no_kernel_for():
     from fastdiff_amd.lvc_op import conv32_supported
     assert conv32_supported(torch.zeros(1, 32, 64).cuda(), w, 27) and not conv32_supported(torch.zeros(1, 32, 6).cuda(), w, 1)
     assert not conv32_supported(torch.zeros(1, 16, 64).cuda(), w, 1) and not conv32_supported(torch.zeros(1, 32, 64), w, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(24576, 64, 3), (32, 32, 3), (64, 80, 5), (32, 1, 7), (1, 32, 7), (32, 32, 1), (256, 64, 3)])
+def test_weight_norm_operator_matches_torch(shape):
+    """fastdiff_amd.lvc_op.weight_norm = torch._weight_norm(v, g, 0), the fold every Conv1d of the model evaluates on each training
+    forward (FastDiff_model.py:115-122), and its backward, against torch in float64 on every weight shape of the model."""
+    from fastdiff_amd.lvc_op import weight_norm
+    g0 = torch.Generator().manual_seed(shape[0] + shape[1])
+    v = torch.randn(*shape, generator=g0)
+    g = torch.rand(shape[0], 1, 1, generator=g0) + 0.5
+    dw = torch.randn(*shape, generator=g0)
+    v64, g64 = v.double().requires_grad_(True), g.double().requires_grad_(True)
+    torch._weight_norm(v64, g64, 0).backward(dw.double())
+    vg, gg = v.cuda().requires_grad_(True), g.cuda().requires_grad_(True)
+    w = weight_norm(vg, gg)
+    w.backward(dw.cuda())
+    rel = lambda got, want: float((got.double().cpu() - want).abs().max()) / max(1e-30, float(want.abs().max()))      # noqa: E731
+    assert rel(w.detach(), torch._weight_norm(v64, g64, 0).detach()) < 1e-6
+    assert rel(vg.grad, v64.grad) < 2e-6 and rel(gg.grad, g64.grad) < 2e-6 and gg.grad.shape == g.shape

@@ -1,0 +1,156 @@
+// xproc_repro.hip -- standalone attempt to reproduce the two-processes-on-one-GPU disturbance (DESIGN.md section 4,
+// profiles/r03/two_processes_one_gpu.txt) WITHOUT this library and without torch: plain HIP, one file.
+//
+//   hipcc --offload-arch=gfx950 -O3 -o tools/ubench/xproc_repro tools/ubench/xproc_repro.hip
+//   ./xproc_repro victim  SECONDS      a long-lived process: one kernel shaped like the hop-256 LVC layer's skeleton (256 threads, two
+//                                      workgroups per CU, 72 KB of static LDS: global -> registers -> LDS image -> barrier -> matrix
+//                                      instructions on LDS operands -> barrier -> second LDS image -> barrier -> stores) launched in a
+//                                      loop on fixed inputs; every launch's output is compared on the device with the first launch's,
+//                                      bit for bit; prints launches and mismatching launches
+//   ./xproc_repro aggressor [REPS]     a short-lived process: context + allocations + the same kernel REPS times + exit (run it in a
+//                                      shell loop next to the victim: `while true; do ./xproc_repro aggressor; done`)
+//
+// What round 3 established with the library's own sampler as victim: nothing happens next to resident neighbours, allocation churn,
+// fresh processes that do not run the sampler; 10-14 mismatching calls per 25 s next to fresh processes that start, run the sampler
+// and exit; 0 with the two processes on disjoint CU masks.  This file asks whether a generic kernel of the same resource shape is
+// disturbed the same way.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <chrono>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int W = 256, C = 32, H = 28, XC = W + 2 * H;      // a 256-column tile with a 28-column halo, 32 channels
+
+// one tile: x + skip -> fp16 image in LDS ([column][32 ch] 64 B rows) -> 3-tap "conv" on the matrix pipe with operands from LDS ->
+// second image -> second matrix pass -> gate-like epilogue -> store.  Deterministic: same input, same bits.
+__global__ void __launch_bounds__(256, 2) k_tile(const float *__restrict__ x, const float *__restrict__ skip, const _Float16 *__restrict__ wgt,
+                                                 float *__restrict__ out, int L)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 xs[XC * 64];      // 39.9 KB (row = 64 halves = 128 B: two 32-channel pieces)
+    __shared__ __attribute__((aligned(16))) _Float16 ys[(W + 2) * 64]; // 33.0 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.y, w0 = blockIdx.x * W;
+    const float *xr = x + (size_t)b * C * L, *sr = skip + (size_t)b * C * L;
+    // stage: wave = 8-channel group, lane = 4 columns (+ halo: one column per lane)
+    for (int c = 0; c < 8; ++c) {
+        const int ch = wave * 8 + c, g = w0 + 4 * lane;
+        float4 a = *reinterpret_cast<const float4 *>(xr + (size_t)ch * L + g), s = *reinterpret_cast<const float4 *>(sr + (size_t)ch * L + g);
+        const float v[4] = {a.x + s.x, a.y + s.y, a.z + s.z, a.w + s.w};
+        for (int j = 0; j < 4; ++j) {
+            const float t = v[j] > 0.f ? v[j] : 0.2f * v[j];
+            const _Float16 h1 = (_Float16)t, h2 = (_Float16)((t - (float)h1) * 2048.0f);
+            xs[(H + 4 * lane + j) * 64 + ch] = h1;
+            xs[(H + 4 * lane + j) * 64 + 32 + ch] = h2;
+        }
+        if (lane < 2 * H) {
+            const int hc = lane < H ? lane : W + lane, hg = w0 - H + hc;
+            const float t0 = (hg >= 0 && hg < L) ? xr[(size_t)ch * L + hg] + sr[(size_t)ch * L + hg] : 0.0f;
+            const float t = t0 > 0.f ? t0 : 0.2f * t0;
+            const _Float16 h1 = (_Float16)t, h2 = (_Float16)((t - (float)h1) * 2048.0f);
+            xs[hc * 64 + ch] = h1;
+            xs[hc * 64 + 32 + ch] = h2;
+        }
+    }
+    f16x8 wa[6];
+    for (int kg = 0; kg < 6; ++kg) wa[kg] = *reinterpret_cast<const f16x8 *>(wgt + (kg * 64 + lane) * 8);
+    __syncthreads();
+    // conv: wave = 64 columns, two 32-column tiles, k = (tap, channel) = 96 in 6 steps of 16; dilation 27
+    for (int ct = 0; ct < 2; ++ct) {
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, lo = acc;
+        const int col = wave * 64 + ct * 32 + l31;
+        for (int kg = 0; kg < 6; ++kg) {
+            const int tap = kg >> 1, row = H + col + (tap - 1) * 27, c8 = ((kg & 1) * 2 + hi) * 8;
+            const f16x8 b1 = *reinterpret_cast<const f16x8 *>(xs + row * 64 + c8), b2 = *reinterpret_cast<const f16x8 *>(xs + row * 64 + 32 + c8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[kg], b1, acc, 0, 0, 0);
+            lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[kg], b2, lo, 0, 0, 0);
+        }
+        for (int r = 0; r < 16; ++r) {
+            const int ch = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float t = acc[r] + lo[r] * (1.0f / 2048.0f);
+            const _Float16 h1 = (_Float16)t, h2 = (_Float16)((t - (float)h1) * 2048.0f);
+            ys[(col + 1) * 64 + ch] = h1;
+            ys[(col + 1) * 64 + 32 + ch] = h2;
+        }
+    }
+    if (tid < 64) { ys[(tid < 32 ? 0 : W + 1) * 64 + (tid & 31)] = (_Float16)0.0f; ys[(tid < 32 ? 0 : W + 1) * 64 + 32 + (tid & 31)] = (_Float16)0.0f; }
+    __syncthreads();
+    // second pass on the y image (taps -1, 0, +1), then a gate-like epilogue and the store
+    float *ob = out + (size_t)b * C * L + w0;
+    for (int ct = 0; ct < 2; ++ct) {
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, lo = acc;
+        const int col = wave * 64 + ct * 32 + l31;
+        for (int kg = 0; kg < 6; ++kg) {
+            const int tap = kg >> 1, row = col + tap, c8 = ((kg & 1) * 2 + hi) * 8;
+            const f16x8 b1 = *reinterpret_cast<const f16x8 *>(ys + row * 64 + c8), b2 = *reinterpret_cast<const f16x8 *>(ys + row * 64 + 32 + c8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[5 - kg], b1, acc, 0, 0, 0);
+            lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[5 - kg], b2, lo, 0, 0, 0);
+        }
+        for (int r = 0; r < 16; ++r) {
+            const int ch = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float z = acc[r] + lo[r] * (1.0f / 2048.0f);
+            ob[(size_t)ch * L + col] = z / (1.0f + __expf(-z));
+        }
+    }
+}
+
+__global__ void k_compare(const unsigned *a, const unsigned *b, size_t n, unsigned *diff)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned d = 0;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) d += a[i] != b[i];
+    if (d) atomicAdd(diff, d);
+}
+
+int main(int argc, char **argv)
+{
+    const bool victim = argc > 1 && !strcmp(argv[1], "victim");
+    const double seconds = victim && argc > 2 ? atof(argv[2]) : 0.0;
+    const int reps = !victim && argc > 2 ? atoi(argv[2]) : 40;
+    const int B = 1, T = 864, L = T * 256;                     // B = 1: 864 tiles on 512 slots, the latency-bound shape of the failing test
+    const size_t n = (size_t)B * C * L;
+    float *x, *skip, *out, *ref;
+    _Float16 *w;
+    unsigned *diff;
+    CK(hipMalloc(&x, n * 4)); CK(hipMalloc(&skip, n * 4)); CK(hipMalloc(&out, n * 4)); CK(hipMalloc(&ref, n * 4)); CK(hipMalloc(&w, 6 * 64 * 8 * 2));
+    CK(hipMalloc(&diff, 4));
+    {
+        std::vector<float> h(n);
+        for (size_t i = 0; i < n; ++i) h[i] = (float)((i * 2654435761u) % 2001) * 1e-3f - 1.0f;
+        CK(hipMemcpy(x, h.data(), n * 4, hipMemcpyHostToDevice));
+        for (size_t i = 0; i < n; ++i) h[i] = (float)((i * 40503u + 7u) % 1999) * 1e-3f - 1.0f;
+        CK(hipMemcpy(skip, h.data(), n * 4, hipMemcpyHostToDevice));
+        std::vector<_Float16> hw(6 * 64 * 8);
+        for (size_t i = 0; i < hw.size(); ++i) hw[i] = (_Float16)(((float)((i * 97u) % 61) - 30.0f) / 300.0f);
+        CK(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    }
+    dim3 grid(L / W, B);
+    hipLaunchKernelGGL(k_tile, grid, dim3(256), 0, 0, x, skip, w, ref, L);
+    CK(hipDeviceSynchronize());
+    if (!victim) {
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_tile, grid, dim3(256), 0, 0, x, skip, w, out, L);
+        CK(hipDeviceSynchronize());
+        return 0;
+    }
+    long long launches = 0, bad = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+        for (int i = 0; i < 20; ++i) {
+            CK(hipMemsetAsync(diff, 0, 4, 0));
+            hipLaunchKernelGGL(k_tile, grid, dim3(256), 0, 0, x, skip, w, out, L);
+            hipLaunchKernelGGL(k_compare, dim3(512), dim3(256), 0, 0, (const unsigned *)out, (const unsigned *)ref, n, diff);
+            unsigned d = 0;
+            CK(hipMemcpy(&d, diff, 4, hipMemcpyDeviceToHost));
+            ++launches;
+            if (d) { ++bad; if (bad <= 5) printf("  launch %lld: %u of %zu words differ\n", launches, d, n); }
+        }
+    }
+    printf("victim: %lld launches in %.0f s, %lld with a result different from the first launch's\n", launches, seconds, bad);
+    return bad ? 1 : 0;
+}
