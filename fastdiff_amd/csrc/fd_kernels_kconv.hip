@@ -183,6 +183,104 @@ __global__ void __launch_bounds__(256) k_kc_dw_sum(const float *__restrict__ par
     }
 }
 
+// ---- small M (the predictor's 64 -> 64 convolutions and bias_conv, M = 64 / 256): the kernels above put 128 rows on a workgroup and
+//      walk the utterances one after the other -- with one or two row groups in all that leaves the chip empty (48 / 78 us per launch
+//      at M = 64).  Here a workgroup is (utterance, 64 rows): wave = (32-row tile, half of the column tiles), B * M / 64 workgroups.
+__global__ void __launch_bounds__(256, 2) k_kcs_fwd(const float *__restrict__ h, const float *__restrict__ W, const float *__restrict__ bias,
+                                                    float *__restrict__ out, int B, int M, int T)
+{
+    __shared__ float hs[CI * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.x, p0 = (blockIdx.y * 2 + (wave & 1)) * 32, ch = wave >> 1;      // ch: column tiles 2 ch, 2 ch + 1
+    const bool live = p0 < M;
+    float4 a[24];
+    {
+        const float4 *wp = reinterpret_cast<const float4 *>(W + (int64_t)(live ? p0 + l31 : 0) * KK) + 24 * hi;
+#pragma unroll
+        for (int q = 0; q < 24; ++q) a[q] = wp[q];
+    }
+    float bz[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bz[r] = bias[live ? p0 + drow(r, hi) : 0];
+    zero_h(hs, tid);
+    __syncthreads();
+    stage_h(hs, h, b, T, tid);
+    __syncthreads();
+    if (!live) return;
+    const float *hb = hs + hi * 32 * LD + l31;
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+        const int ct = 2 * ch + c2;
+        if (ct * 32 >= T) break;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bz[r];
+#pragma unroll
+        for (int s = 0; s < 96; ++s) acc = mfma32(f4c(a[s >> 2], s & 3), hb[(s / 3) * LD + (s % 3) + ct * 32], acc);
+        if (ct * 32 + l31 < T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[((int64_t)b * M + p0 + drow(r, hi)) * T + ct * 32 + l31] = acc[r];
+        }
+    }
+}
+
+// dW / dbias partial of ONE utterance: part [B][M][192] and, behind it, [B][M]; k_kc_dw_sum adds the utterances in order.
+// wave = (32-row tile, three of the six column tiles (c, k))
+template <bool ALIGNED>
+__global__ void __launch_bounds__(256, 2) k_kcs_dw(const float *__restrict__ h, const float *__restrict__ dout, float *__restrict__ part,
+                                                   int B, int M, int T)
+{
+    __shared__ float hs[CI * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.x, p0 = (blockIdx.y * 2 + (wave & 1)) * 32, ch = wave >> 1;      // ch: column tiles 3 ch .. 3 ch + 2
+    const bool live = p0 < M;
+    const float *dr = dout + ((int64_t)b * M + (live ? p0 + l31 : 0)) * T;
+    const int nq = (T + 7) / 8;
+    float4 dv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int t0 = 8 * q + 4 * hi;
+        if (q < nq) {
+            if (ALIGNED && t0 + 3 < T) dv[q] = *reinterpret_cast<const float4 *>(dr + t0);
+            else dv[q] = make_float4(t0 < T ? dr[t0] : 0.0f, t0 + 1 < T ? dr[t0 + 1] : 0.0f, t0 + 2 < T ? dr[t0 + 2] : 0.0f, t0 + 3 < T ? dr[t0 + 3] : 0.0f);
+        }
+    }
+    zero_h(hs, tid);
+    __syncthreads();
+    stage_h(hs, h, b, T, tid);
+    __syncthreads();
+    if (!live) return;
+    f32x16 acc[3];
+    const float *hb[3];
+#pragma unroll
+    for (int c3 = 0; c3 < 3; ++c3) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c3][r] = 0.0f;
+        const int kk = (3 * ch + c3) * 32 + l31;
+        hb[c3] = hs + (kk / 3) * LD + (kk % 3) + 4 * hi;
+    }
+    float accb = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        if (q < nq) {
+            accb += (dv[q].x + dv[q].y) + (dv[q].z + dv[q].w);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float av = f4c(dv[q], j);
+#pragma unroll
+                for (int c3 = 0; c3 < 3; ++c3) acc[c3] = mfma32(av, hb[c3][8 * q + j], acc[c3]);
+            }
+        }
+    }
+    float *pw = part + (int64_t)b * M * KK;
+#pragma unroll
+    for (int c3 = 0; c3 < 3; ++c3)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pw[(int64_t)(p0 + drow(r, hi)) * KK + (3 * ch + c3) * 32 + l31] = acc[c3][r];
+    accb += __shfl_xor(accb, 32, 64);
+    if (hi == 0 && ch == 0) part[(int64_t)B * M * KK + (int64_t)b * M + p0 + l31] = accb;
+}
+
 // ---- dh, first pass: workgroup = (slice of the rows p, utterance b): G_part[(c,k), t] = sum over the slice of W[p,(c,k)] dout[b,p,t];
 //      wave = one 32-column tile of t (T <= 128), all six 32-row tiles of (c,k); W and dout go through LDS 32 rows at a time ----------
 __global__ void __launch_bounds__(256, 2) k_kc_dh(const float *__restrict__ W, const float *__restrict__ dout, float *__restrict__ part,
@@ -284,10 +382,18 @@ static int pick_ranges(int per_range, int units, int max_ranges, int num_cus)
 }
 constexpr int KC_DW_RANGES = 8, KC_DH_SLICES = 64;
 // scratch: the dh pass's row slices [slices][B][192][T], then the dW pass's utterance ranges [ranges][M][192] + [ranges][M]
-size_t kconv_scratch_floats(int B, int M, int T) { return (size_t)KC_DH_SLICES * B * KK * T + (size_t)KC_DW_RANGES * M * (KK + 1); }
+constexpr int KC_SMALL_M = 512;      // up to here a workgroup is (utterance, 64 rows): k_kcs_fwd / k_kcs_dw
+size_t kconv_scratch_floats(int B, int M, int T)
+{
+    return (size_t)KC_DH_SLICES * B * KK * T + (size_t)(M <= KC_SMALL_M ? std::max(B, KC_DW_RANGES) : KC_DW_RANGES) * M * (KK + 1);
+}
 
 hipError_t kconv_forward(const Launch &L, const float *h, const float *W, const float *bias, float *out, int B, int M, int T)
 {
+    if (M <= KC_SMALL_M) {
+        FD_LAUNCH(L, "kconv_forward_small", k_kcs_fwd, dim3(B, (M + 63) / 64), dim3(256), 0, h, W, bias, out, B, M, T);
+        return hipSuccess;
+    }
     const int gx = (M + 127) / 128;
     const int ny0 = pick_ranges(gx, B, 16, L.ctx->num_cus), bchunk = (B + ny0 - 1) / ny0, ny = (B + bchunk - 1) / bchunk;
     FD_LAUNCH(L, "kconv_forward", k_kc_fwd, dim3(gx, ny), dim3(256), 0, h, W, bias, out, B, M, T, bchunk);
@@ -298,7 +404,12 @@ hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const
                           int T, float *scratch)
 {
     float *part_h = scratch, *part_w = scratch + (size_t)KC_DH_SLICES * B * KK * T;
-    if (dW || dbias) {
+    if ((dW || dbias) && M <= KC_SMALL_M) {
+        if (T % 4 == 0) FD_LAUNCH(L, "kconv_backward_w_small", k_kcs_dw<true>, dim3(B, (M + 63) / 64), dim3(256), 0, h, dout, part_w, B, M, T);
+        else FD_LAUNCH(L, "kconv_backward_w_small", k_kcs_dw<false>, dim3(B, (M + 63) / 64), dim3(256), 0, h, dout, part_w, B, M, T);
+        FD_LAUNCH(L, "kconv_backward_w_sum", k_kc_dw_sum, dim3((unsigned)(((int64_t)M * (KK + 1) + 255) / 256)), dim3(256), 0, (const float *)part_w, dW,
+                  dbias, M, B);
+    } else if (dW || dbias) {
         const int gx = (M + 127) / 128;
         const int ny0 = pick_ranges(gx, B, KC_DW_RANGES, L.ctx->num_cus), bchunk = (B + ny0 - 1) / ny0, ny = (B + bchunk - 1) / bchunk;
         if (T % 4 == 0) FD_LAUNCH(L, "kconv_backward_w", k_kc_dw<true>, dim3(gx, ny), dim3(256), 0, h, dout, part_w, B, M, T, bchunk);
