@@ -228,11 +228,13 @@ def test_synthesize_sharded_world2_hip_vocoder_equals_single_process():
 @pytest.mark.gpu
 def test_synthesize_sharded_world2_concurrent_on_disjoint_compute_units():
     """The same job with both ranks vocoding AT THE SAME TIME, each on its own half of the GPU's compute units (HSA_CU_MASK): the
-    arrangement measured clean in round 3 (0 mismatches where ~15 were expected without the masks).  A mismatch here is reported as
-    an expected failure of the platform arrangement, not of the kernels -- visible in the summary, not silently retried."""
+    arrangement measured clean in round 3 (0 mismatches where ~15 were expected without the masks).  A mismatch here FAILS the test;
+    FD_TEST_ALLOW_PLATFORM_XFAIL=1 turns it into an expected failure of the platform arrangement (visible in the summary, never
+    silently retried) for whoever has to run the suite on a box where the masks do not hold."""
     res = _run_two_gpu_ranks("host", sharing="masks")
-    if res != "ok":
+    if res != "ok" and os.environ.get("FD_TEST_ALLOW_PLATFORM_XFAIL") == "1":
         pytest.xfail("two processes on one GPU disturbed each other despite disjoint CU masks: " + res)
+    assert res == "ok", "two processes on one GPU disturbed each other despite disjoint CU masks: " + res
 
 
 @pytest.mark.gpu

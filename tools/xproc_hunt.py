@@ -46,6 +46,9 @@ def aggressor(mode):
         "modload": [sys.executable, os.path.abspath(__file__), "--aggressor", "modload_once"],
         # a different code object (a stand-alone HIP binary of tools/ubench), fresh process each time
         "othermod": [os.path.join(ROOT, "tools", "ubench", "copy_mix_probe")],
+        # round 4: a generic kernel of the hop-256 layer's resource shape (72 KB LDS, 2 workgroups per CU, matrix instructions on LDS
+        # operands), none of this library's code: tools/ubench/xproc_repro.hip, 40 launches per process
+        "generic": [os.path.join(ROOT, "tools", "ubench", "xproc_repro"), "aggressor", "40", "%d"],
     }
     if mode in ("fdloop", "fdloop_pad"):      # a second long-lived sampler loop of the same shapes (its first call is ~8 s after its start)
         env = dict(os.environ, FD_HUNT_PAD_MB="1536") if mode == "fdloop_pad" else dict(os.environ)
