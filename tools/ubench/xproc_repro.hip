@@ -38,6 +38,16 @@ __global__ void __launch_bounds__(256, 2) k_tile(const float *__restrict__ x, co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int b = blockIdx.y, w0 = blockIdx.x * W;
     const float *xr = x + (size_t)b * C * L, *sr = skip + (size_t)b * C * L;
+#ifdef FAT_REGS
+    // -DFAT_REGS=N: N more registers per lane live from here to the last store (the library's LVC kernels hold 235-256 VGPRs, this
+    // kernel 118 without them): is a wave with (nearly) the full two-waves-per-SIMD register budget what the disturbance needs?
+    float keep[FAT_REGS];
+#pragma unroll
+    for (int i = 0; i < FAT_REGS; ++i) {
+        keep[i] = xr[(size_t)(i & 31) * L + w0 + ((tid + 7 * i) & 255)];
+        asm volatile("" : "+v"(keep[i]));
+    }
+#endif
     // stage: wave = 8-channel group, lane = 4 columns (+ halo: one column per lane)
     for (int c = 0; c < 8; ++c) {
         const int ch = wave * 8 + c, g = w0 + 4 * lane;
@@ -94,7 +104,15 @@ __global__ void __launch_bounds__(256, 2) k_tile(const float *__restrict__ x, co
         }
         for (int r = 0; r < 16; ++r) {
             const int ch = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float z = acc[r] + lo[r] * (1.0f / 2048.0f);
+            float z = acc[r] + lo[r] * (1.0f / 2048.0f);
+#ifdef FAT_REGS
+            if (ct == 1 && r == 15) {
+                float ks = 0.0f;
+#pragma unroll
+                for (int i = 0; i < FAT_REGS; ++i) { asm volatile("" : "+v"(keep[i])); ks += keep[i]; }
+                z += ks * 1e-3f;
+            }
+#endif
             ob[(size_t)ch * L + col] = z / (1.0f + __expf(-z));
         }
     }
