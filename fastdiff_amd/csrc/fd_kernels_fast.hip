@@ -142,6 +142,11 @@ __device__ __forceinline__ void lvc_st(float4 *p, const float4 &v)
 // end-of-step bookkeeping on the way -- next row of the step table, that step's range flags become "previous step" and join the call's
 // sticky set -- what k_advance does in a launch of its own.  Nothing else in this kernel reads either; the kernels behind it start
 // after the whole grid.
+// V (option "first_variant"; a probe of round 4's two-process bisect, profiles/r04/s8_*: with this kernel replaced by the naive one the
+// library's sampler is no longer disturbed by short-lived neighbour processes): 0 = as built since round 1 -- the weights arrive by
+// scalar loads (uniform index), x and a0 through the vector L1; 1 = the weights through vector loads + LDS (no scalar data load in the
+// kernel); 2 = x read at system scope (sc0 sc1: past the vector L1); 3 = both.
+template <int V>
 __global__ void __launch_bounds__(256) k_first_conv(const float *__restrict__ x, const float *__restrict__ w,
                                                     const float *__restrict__ bias, float *__restrict__ a0, int L,
                                                     const int *__restrict__ lens, StepParams *advance, int *__restrict__ range_flags)
@@ -155,6 +160,12 @@ __global__ void __launch_bounds__(256) k_first_conv(const float *__restrict__ x,
             range_flags[threadIdx.x] = 0;
         }
     }
+    __shared__ float wl[(V & 1) ? fd::C * 8 : 1];      // [out][7 taps + bias]
+    if constexpr ((V & 1) != 0) {
+        const int o = threadIdx.x >> 3, k = threadIdx.x & 7;
+        wl[threadIdx.x] = k < 7 ? w[o * 7 + k] : bias[o];
+        __syncthreads();
+    }
     const int b = blockIdx.y;
     const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
     const int Lb = lens ? lens[b] * fd::HOPT : L;          // this utterance's own length (ragged batch)
@@ -164,14 +175,15 @@ __global__ void __launch_bounds__(256) k_first_conv(const float *__restrict__ x,
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
         const int p = t0 - 3 + i;
-        xv[i] = (p >= 0 && p < Lb) ? xr[p] : 0.0f;
+        if constexpr ((V & 2) != 0) xv[i] = (p >= 0 && p < Lb) ? __hip_atomic_load(xr + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0f;
+        else xv[i] = (p >= 0 && p < Lb) ? xr[p] : 0.0f;
     }
 #pragma unroll 4
     for (int o = 0; o < fd::C; ++o) {
         float wv[7];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) wv[k] = w[o * 7 + k];
-        const float bv = bias[o];
+        for (int k = 0; k < 7; ++k) wv[k] = (V & 1) ? wl[o * 8 + k] : w[o * 7 + k];
+        const float bv = (V & 1) ? wl[o * 8 + 7] : bias[o];
         float4 r = make_float4(bv, bv, bv, bv);
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
@@ -2467,8 +2479,15 @@ hipError_t fast_first_conv(const Launch &L, const StepIO &io, int B, int T)
     const int Lf = T * fd::HOPT;
     fd_context *c = L.ctx;
     const bool adv = io.sampler && c->advance_pending;      // the previous step of this sequence left its bookkeeping to us
-    FD_LAUNCH(L, "first_conv", k_first_conv, dim3((Lf + 1023) / 1024, B), dim3(256), 0, io.x_in, w.first.w, w.first.b,
-              c->ws.a[0], Lf, c->step_lens, adv ? c->ws.params : (StepParams *)nullptr, c->ws.range_flag);
+#define FD_FIRST(V_) FD_LAUNCH(L, "first_conv", k_first_conv<V_>, dim3((Lf + 1023) / 1024, B), dim3(256), 0, io.x_in, w.first.w, w.first.b, \
+                               c->ws.a[0], Lf, c->step_lens, adv ? c->ws.params : (StepParams *)nullptr, c->ws.range_flag)
+    switch (c->first_variant) {
+    case 1: FD_FIRST(1); break;
+    case 2: FD_FIRST(2); break;
+    case 3: FD_FIRST(3); break;
+    default: FD_FIRST(0); break;
+    }
+#undef FD_FIRST
     if (adv) c->advance_pending = false;
     return hipSuccess;
 }

@@ -6,13 +6,10 @@ mkdir -p gpurun_out/s8
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/s8
 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1
-run() { echo "== victim options: [$1]"; FD_HUNT_OPTS="$1" timeout 300 python $R/tools/xproc_hunt.py 18 generic fd 2>&1 | grep "^victim" ; }
+run() { echo "== victim options: [$1] (padded batch, no lens)"; FD_HUNT_NOLENS=1 FD_HUNT_OPTS="$1" timeout 300 python $R/tools/xproc_hunt.py 18 generic fd 2>&1 | grep "^victim\|Error\|error" | tail -2 ; }
 {
-run ""
-run "kernels=naive"
-run "kernels.lvc=naive"
-run "kernels.kp_gemm=naive,kernels.kp_front=naive"
-run "kernels.dblock=naive,kernels.convt=naive,kernels.first=naive,kernels.final=naive"
-run "fallback=graph,hoist=off,fuse_up=0,fuse_final=0,fuse_advance=0,embed_cache=0"
-run "graph=0"
-} 2>&1 | tee $O/xproc_victim_bisect.txt
+run "first_variant=1"
+run "first_variant=2"
+run "first_variant=3"
+run "first_variant=0"
+} 2>&1 | tee $O/xproc_victim_first_conv_variants.txt

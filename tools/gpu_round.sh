@@ -8,7 +8,7 @@ python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1
 (rocm-smi --showclocks --showpower --showperflevel --showmaxpower --showmemvendor 2>&1 | grep -v "^=\|^$" | head -30) > gpurun_out/box_state.txt
 echo "== pytest gpu" ; timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1 ; echo "pytest rc=$?" ; tail -4 gpurun_out/pytest_gpu.log
 echo "== smoke" ; timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1 ; echo "smoke rc=$?" ; tail -1 gpurun_out/smoke.log
-echo "== bench" ; timeout 900 python bench.py > gpurun_out/bench.log 2>&1 ; echo "bench rc=$?" ; grep '^{' gpurun_out/bench.log | cut -c1-900
+echo "== bench" ; FD_BENCH_KEEP_STATS=$R/gpurun_out/bench_child_kernel_stats.csv timeout 900 python bench.py > gpurun_out/bench.log 2>&1 ; echo "bench rc=$?" ; grep '^{' gpurun_out/bench.log | cut -c1-900
 (rocm-smi --showclocks --showpower 2>&1 | grep -i "sclk\|power (W)" | head -4) >> gpurun_out/box_state.txt
 echo "== bench N=1000 B=1 (config 3)" ; timeout 900 python bench.py --batch 1 --nsteps 1000 --steps 2 --warmup 1 --no-roofline --no-cpu-baseline > gpurun_out/bench_n1000.log 2>&1 ; grep '^{' gpurun_out/bench_n1000.log | cut -c1-400
 echo "== bench config4 (64 ragged utterances, N=6, host to host) on this one GPU" ; timeout 900 python bench.py --workload config4 --steps 5 --warmup 2 > gpurun_out/bench_config4.log 2>&1 ; grep '^{' gpurun_out/bench_config4.log | cut -c1-400
@@ -16,9 +16,14 @@ echo "== the multi-rank path, 2 ranks sharing this GPU over gloo (FD_BENCH_OVERS
 FD_BENCH_OVERSUBSCRIBE=1 timeout 900 python bench.py --gpus 2 --workload config4 --steps 3 --warmup 1 > gpurun_out/bench_config4_2ranks_1gpu.log 2>&1 ; grep '^{' gpurun_out/bench_config4_2ranks_1gpu.log | cut -c1-300
 echo "== bench --gpus 2 without the override must refuse" ; python bench.py --gpus 2 > gpurun_out/bench_gpus2_refused.log 2>&1 ; echo "rc=$?" ; tail -1 gpurun_out/bench_gpus2_refused.log
 echo "== training side: denoiser forward + backward, LVC operator vs unfold+einsum" ; timeout 600 python tools/train_step_probe.py 2>&1 | grep -v "Warning\|WeightNorm\|amdgpu.ids" | tee gpurun_out/train_step_probe.txt
+echo "== training step: kernel families of a steady-state step"
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_train -o train -- python $R/tools/train_step_profile.py 12 > $R/gpurun_out/rocprof_train.log 2>&1; echo "rocprof rc=$?"
+cd $R; KT=$(find gpurun_out/prof_train -name '*kernel_trace.csv' | head -1); python tools/train_step_profile.py --report $KT 12 > gpurun_out/train_step_families.txt 2>&1; head -12 gpurun_out/train_step_families.txt
+find gpurun_out/prof_train -name '*.csv' -size +8M -delete 2>/dev/null
 echo "== rocprof kernel-trace"
 cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o kt -- python $R/bench.py --steps 5 --warmup 1 --no-roofline --no-cpu-baseline --no-fp32-pipe --no-host-io --no-b1 > $R/gpurun_out/rocprof.log 2>&1 ; echo "rocprof rc=$?"
 cd $R; find gpurun_out/prof -name '*kernel_trace.csv' -size +20M -delete 2>/dev/null
+ST=$(find gpurun_out/prof -name '*kernel_stats.csv' | head -1); python tools/kernel_stats_fracs.py $ST --bench-json gpurun_out/bench.log > gpurun_out/fracs_from_kernel_stats.txt 2>&1; head -14 gpurun_out/fracs_from_kernel_stats.txt
 echo "== PMC"
 OUT=$R/gpurun_out/pmc; mkdir -p $OUT; cd /tmp
 CMD="python $R/bench.py --steps 2 --warmup 1 --no-roofline --no-cpu-baseline --no-graph --no-fp32-pipe --no-host-io --no-b1"
@@ -27,5 +32,5 @@ pass p1 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE
 pass p2 FETCH_SIZE
 pass p3 WRITE_SIZE
 pass p4 SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_MFMA
-cd $R; PMC_SOURCE="round 3, rocprofv3 --pmc passes of bench.py --steps 2 --warmup 1 --no-graph (tools/gpu_round.sh); HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch" python tools/pmc_summary.py $OUT --json $OUT/pmc_traffic.json > $OUT/summary.txt 2>&1; cat $OUT/summary.txt | grep -v "at::native\|rocclr"
+cd $R; PMC_SOURCE="round 4, rocprofv3 --pmc passes of bench.py --steps 2 --warmup 1 --no-graph (tools/gpu_round.sh); HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch" python tools/pmc_summary.py $OUT --json $OUT/pmc_traffic.json > $OUT/summary.txt 2>&1; cat $OUT/summary.txt | grep -v "at::native\|rocclr"
 find $OUT -name '*.csv' -size +8M -delete
