@@ -186,7 +186,9 @@ struct fd_context {
                                              // stages run fp16x2-only, i.e. under fallback = host or a forced mask without them).  Same
                                              // bits, one launch and one round trip of x less per block: B=1 -5.2 %, B=8 -2.6 %
     int lvc_variant = 1;                       // option "lvc_variant": 1 = phase-major parking area + early record request in k_lvc_h2<.., UP> (round 4) | 0 = round 3's form
-    int first_variant = 0;                   // option "first_variant": probe forms of k_first_conv (fd_kernels_fast.hip)
+    int first_variant = 1;                   // option "first_variant": 1 (default since round 4) = k_first_conv takes its weights through vector
+                                             // loads + LDS; 0 = through scalar loads (round 1-3: the form a short-lived neighbour process on
+                                             // the same compute units disturbs); 2, 3 = probe forms (fd_kernels_fast.hip)
     bool final_fused = false;                // set by the last LVC layer's launch, consumed by fast_final
     bool fuse_advance = true;                // option "fuse_advance": between two steps of one graph / launch sequence the end-of-step
                                              // bookkeeping (k_advance) rides in the next step's first kernel instead of a launch of its own

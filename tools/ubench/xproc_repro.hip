@@ -31,7 +31,7 @@ constexpr int W = 256, C = 32, H = 28, XC = W + 2 * H;      // a 256-column tile
 // one tile: x + skip -> fp16 image in LDS ([column][32 ch] 64 B rows) -> 3-tap "conv" on the matrix pipe with operands from LDS ->
 // second image -> second matrix pass -> gate-like epilogue -> store.  Deterministic: same input, same bits.
 __global__ void __launch_bounds__(256, 2) k_tile(const float *__restrict__ x, const float *__restrict__ skip, const _Float16 *__restrict__ wgt,
-                                                 float *__restrict__ out, int L)
+                                                 float *__restrict__ out, int L, const float *__restrict__ sw)
 {
     __shared__ __attribute__((aligned(16))) _Float16 xs[XC * 64];      // 39.9 KB (row = 64 halves = 128 B: two 32-channel pieces)
     __shared__ __attribute__((aligned(16))) _Float16 ys[(W + 2) * 64]; // 33.0 KB
@@ -46,6 +46,23 @@ __global__ void __launch_bounds__(256, 2) k_tile(const float *__restrict__ x, co
     for (int i = 0; i < FAT_REGS; ++i) {
         keep[i] = xr[(size_t)(i & 31) * L + w0 + ((tid + 7 * i) & 255)];
         asm volatile("" : "+v"(keep[i]));
+    }
+#endif
+#ifdef SCALAR_W
+    // -DSCALAR_W: 256 weights read with wave-uniform indices, which the compiler turns into SCALAR loads (s_load_dwordxN through the
+    // scalar data cache a group of CUs shares) -- the one thing round 4's bisect found the library's susceptible kernel to do that
+    // this file's kernel did not (its matrix weights arrive by vector loads).  A 7-tap, 32-channel sum as in first_audio_conv.
+    float sacc = 0.0f;
+    {
+        float xv[7];
+        for (int i = 0; i < 7; ++i) xv[i] = xr[w0 + ((tid + i) & 255)];
+#pragma unroll 4
+        for (int o = 0; o < 32; ++o) {
+            float r = sw[224 + o];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) r += sw[o * 7 + k] * xv[k];
+            sacc += r;
+        }
     }
 #endif
     // stage: wave = 8-channel group, lane = 4 columns (+ halo: one column per lane)
@@ -105,6 +122,9 @@ __global__ void __launch_bounds__(256, 2) k_tile(const float *__restrict__ x, co
         for (int r = 0; r < 16; ++r) {
             const int ch = (r & 3) + 8 * (r >> 2) + 4 * hi;
             float z = acc[r] + lo[r] * (1.0f / 2048.0f);
+#ifdef SCALAR_W
+            z += sacc * 1e-2f;
+#endif
 #ifdef FAT_REGS
             if (ct == 1 && r == 15) {
                 float ks = 0.0f;
@@ -133,11 +153,17 @@ int main(int argc, char **argv)
     const int reps = !victim && argc > 2 ? atoi(argv[2]) : 40;
     const int B = 1, T = 864, L = T * 256;                     // B = 1: 864 tiles on 512 slots, the latency-bound shape of the failing test
     const size_t n = (size_t)B * C * L;
-    float *x, *skip, *out, *ref;
+    float *x, *skip, *out, *ref, *sw;
     _Float16 *w;
     unsigned *diff;
     CK(hipMalloc(&x, n * 4)); CK(hipMalloc(&skip, n * 4)); CK(hipMalloc(&out, n * 4)); CK(hipMalloc(&ref, n * 4)); CK(hipMalloc(&w, 6 * 64 * 8 * 2));
     CK(hipMalloc(&diff, 4));
+    CK(hipMalloc(&sw, 256 * 4));
+    {
+        std::vector<float> hs(256);
+        for (int i = 0; i < 256; ++i) hs[i] = (float)((i * 37) % 101 - 50) / 100.0f;
+        CK(hipMemcpy(sw, hs.data(), 256 * 4, hipMemcpyHostToDevice));
+    }
     {
         std::vector<float> h(n);
         for (size_t i = 0; i < n; ++i) h[i] = (float)((i * 2654435761u) % 2001) * 1e-3f - 1.0f;
@@ -149,10 +175,10 @@ int main(int argc, char **argv)
         CK(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
     }
     dim3 grid(L / W, B);
-    hipLaunchKernelGGL(k_tile, grid, dim3(256), 0, 0, x, skip, w, ref, L);
+    hipLaunchKernelGGL(k_tile, grid, dim3(256), 0, 0, x, skip, w, ref, L, (const float *)sw);
     CK(hipDeviceSynchronize());
     if (!victim) {
-        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_tile, grid, dim3(256), 0, 0, x, skip, w, out, L);
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_tile, grid, dim3(256), 0, 0, x, skip, w, out, L, (const float *)sw);
         CK(hipDeviceSynchronize());
         return 0;
     }
@@ -161,7 +187,7 @@ int main(int argc, char **argv)
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
         for (int i = 0; i < 20; ++i) {
             CK(hipMemsetAsync(diff, 0, 4, 0));
-            hipLaunchKernelGGL(k_tile, grid, dim3(256), 0, 0, x, skip, w, out, L);
+            hipLaunchKernelGGL(k_tile, grid, dim3(256), 0, 0, x, skip, w, out, L, (const float *)sw);
             hipLaunchKernelGGL(k_compare, dim3(512), dim3(256), 0, 0, (const unsigned *)out, (const unsigned *)ref, n, diff);
             unsigned d = 0;
             CK(hipMemcpy(&d, diff, 4, hipMemcpyDeviceToHost));
