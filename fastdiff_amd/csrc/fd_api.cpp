@@ -1747,7 +1747,7 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
     if (k == "fuse_final") { h->fuse_final = on; drop_graph(h); return FD_OK; }
     if (k == "fuse_up") { h->fuse_up = on; drop_graph(h); return FD_OK; }
     if (k == "fuse_advance") { h->fuse_advance = on; drop_graph(h); return FD_OK; }
-    if (k == "first_variant") { h->first_variant = atoi(value) & 3; drop_graph(h); return FD_OK; }
+    if (k == "first_variant") { h->first_variant = atoi(value) & 7; drop_graph(h); return FD_OK; }
     if (k == "lvc_variant") { h->lvc_variant = atoi(value) ? 1 : 0; drop_graph(h); return FD_OK; }
     if (k == "embed_cache") { h->embed_cache = on; return FD_OK; }
     if (k == "hoist") {

@@ -145,7 +145,8 @@ __device__ __forceinline__ void lvc_st(float4 *p, const float4 &v)
 // V (option "first_variant"; a probe of round 4's two-process bisect, profiles/r04/s8_*: with this kernel replaced by the naive one the
 // library's sampler is no longer disturbed by short-lived neighbour processes): 0 = as built since round 1 -- the weights arrive by
 // scalar loads (uniform index), x and a0 through the vector L1; 1 = the weights through vector loads + LDS (no scalar data load in the
-// kernel); 2 = x read at system scope (sc0 sc1: past the vector L1); 3 = both.
+// kernel); 2 = x read at system scope (sc0 sc1: past the vector L1); 3 = both; 4 = the scalar-load form behind a dummy LDS write +
+// barrier (the timing of form 1 without its loads); 5 = the weights through vector loads straight from global memory (no LDS, no barrier).
 template <int V>
 __global__ void __launch_bounds__(256) k_first_conv(const float *__restrict__ x, const float *__restrict__ w,
                                                     const float *__restrict__ bias, float *__restrict__ a0, int L,
@@ -160,12 +161,20 @@ __global__ void __launch_bounds__(256) k_first_conv(const float *__restrict__ x,
             range_flags[threadIdx.x] = 0;
         }
     }
-    __shared__ float wl[(V & 1) ? fd::C * 8 : 1];      // [out][7 taps + bias]
-    if constexpr ((V & 1) != 0) {
+    constexpr bool WLDS = (V == 1 || V == 3), WVEC = (V == 5);
+    __shared__ float wl[(WLDS || V == 4) ? fd::C * 8 : 1];      // [out][7 taps + bias]
+    if constexpr (WLDS) {
         const int o = threadIdx.x >> 3, k = threadIdx.x & 7;
         wl[threadIdx.x] = k < 7 ? w[o * 7 + k] : bias[o];
         __syncthreads();
     }
+    if constexpr (V == 4) {      // probe: the scalar-load form with the other form's LDS write + barrier in front (timing only)
+        wl[threadIdx.x] = (float)threadIdx.x;
+        __syncthreads();
+        if (wl[(threadIdx.x + 1) & 255] < 0.0f) return;
+    }
+    int vz = 0;
+    if constexpr (WVEC) asm volatile("v_mov_b32 %0, 0" : "=v"(vz));      // probe: an index the compiler cannot prove uniform -> vector loads, no LDS
     const int b = blockIdx.y;
     const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
     const int Lb = lens ? lens[b] * fd::HOPT : L;          // this utterance's own length (ragged batch)
@@ -175,15 +184,15 @@ __global__ void __launch_bounds__(256) k_first_conv(const float *__restrict__ x,
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
         const int p = t0 - 3 + i;
-        if constexpr ((V & 2) != 0) xv[i] = (p >= 0 && p < Lb) ? __hip_atomic_load(xr + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0f;
+        if constexpr (V == 2 || V == 3) xv[i] = (p >= 0 && p < Lb) ? __hip_atomic_load(xr + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0f;
         else xv[i] = (p >= 0 && p < Lb) ? xr[p] : 0.0f;
     }
 #pragma unroll 4
     for (int o = 0; o < fd::C; ++o) {
         float wv[7];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) wv[k] = (V & 1) ? wl[o * 8 + k] : w[o * 7 + k];
-        const float bv = (V & 1) ? wl[o * 8 + 7] : bias[o];
+        for (int k = 0; k < 7; ++k) wv[k] = WLDS ? wl[o * 8 + k] : w[o * 7 + k + vz];
+        const float bv = WLDS ? wl[o * 8 + 7] : bias[o + vz];
         float4 r = make_float4(bv, bv, bv, bv);
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
@@ -2489,6 +2498,8 @@ hipError_t fast_first_conv(const Launch &L, const StepIO &io, int B, int T)
 #define FD_FIRST(V_) FD_LAUNCH(L, "first_conv", k_first_conv<V_>, dim3((Lf + 1023) / 1024, B), dim3(256), 0, io.x_in, w.first.w, w.first.b, \
                                c->ws.a[0], Lf, c->step_lens, adv ? c->ws.params : (StepParams *)nullptr, c->ws.range_flag)
     switch (c->first_variant) {
+    case 4: FD_FIRST(4); break;
+    case 5: FD_FIRST(5); break;
     case 2: FD_FIRST(2); break;
     case 3: FD_FIRST(3); break;
     case 0: FD_FIRST(0); break;
