@@ -177,7 +177,7 @@ def _gpu_worker(rank, world, port, ret, gpu_lock, stage="host", sharing="turns")
                           f"least-squares scale sharded/single {scale:.6f}, residual after scaling {np.abs(a - scale * b).max():.1f}; "
                           f"a second single-process run equals: sharded {np.array_equal(a, c)}, single {np.array_equal(b, c)}", flush=True)
                     np.savez_compressed(os.path.join(dump, f"sharded_mismatch_{name}.npz"), sharded=out[name], single=single[name], again=again[name])
-            if bad and sharing == "masks":
+            if bad and sharing in ("masks", "none"):
                 ret.put("mismatch " + ",".join(bad))
                 return
             assert not bad, bad
@@ -235,6 +235,17 @@ def test_synthesize_sharded_world2_concurrent_on_disjoint_compute_units():
     if res != "ok" and os.environ.get("FD_TEST_ALLOW_PLATFORM_XFAIL") == "1":
         pytest.xfail("two processes on one GPU disturbed each other despite disjoint CU masks: " + res)
     assert res == "ok", "two processes on one GPU disturbed each other despite disjoint CU masks: " + res
+
+
+@pytest.mark.gpu
+def test_synthesize_sharded_world2_concurrent_on_shared_compute_units():
+    """Both ranks vocoding AT THE SAME TIME on the same compute units, no masks, no turns: the arrangement that gave one utterance with
+    a few hundred wrong samples in ~3 % of the runs of rounds 2 and 3.  Round 4 traced it (tools/xproc_hunt.py: victim-side bisect,
+    profiles/r04/s8_*, s9_*, s10_*) to ONE kernel property -- the first conv reading its weights with scalar loads -- and changed that
+    kernel (weights through vector loads + LDS): 0 mismatching calls in 37030 + 22416 + 16364 next to every aggressor that used to
+    trigger it, against ~90 per 16400 with the old form in the same sessions."""
+    res = _run_two_gpu_ranks("host", sharing="none")
+    assert res == "ok", "two concurrent vocoding processes on shared compute units disturbed each other: " + res
 
 
 @pytest.mark.gpu
