@@ -1545,6 +1545,18 @@ int fd_kconv_backward(fd_handle h, const float *x, const float *weight, const fl
     return FD_OK;
 }
 
+static int cconv_scratch_reserve(fd_handle h, size_t floats)
+{
+    const size_t bytes = sizeof(float) * floats;
+    if (h->cconv_scratch_bytes < bytes) {
+        if (h->cconv_scratch) FD_HIP(h, hipFree(h->cconv_scratch));
+        h->cconv_scratch = nullptr; h->cconv_scratch_bytes = 0;
+        FD_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->cconv_scratch), bytes));
+        h->cconv_scratch_bytes = bytes;
+    }
+    return FD_OK;
+}
+
 // The small convolutions of the training path (fd_kernels_cconv.hip).  The backward's per-workgroup partial sums live in a scratch
 // buffer on the handle (calls on one handle are ordered on one stream, as for the operators above).
 static int check_conv32(fd_handle h, int B, int64_t L, int dil, float pre, float post, const char *who)
@@ -1581,17 +1593,39 @@ int fd_conv32_backward(fd_handle h, const float *xs, const float *y, const float
     if (rc != FD_OK) return rc;
     FD_HIP(h, hipSetDevice(h->device));
     fdk::Launch La = {h, (hipStream_t)stream, false};
-    {
-        const size_t bytes = sizeof(float) * fdk::cconv_scratch_floats(La, dilation, B, L);
-        if (h->cconv_scratch_bytes < bytes) {
-            if (h->cconv_scratch) FD_HIP(h, hipFree(h->cconv_scratch));
-            h->cconv_scratch = nullptr; h->cconv_scratch_bytes = 0;
-            FD_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->cconv_scratch), bytes));
-            h->cconv_scratch_bytes = bytes;
-        }
-    }
+    rc = cconv_scratch_reserve(h, fdk::cconv_scratch_floats(La, dilation, B, L));
+    if (rc != FD_OK) return rc;
     hipError_t e = fdk::cconv_backward(La, xs, y, weight, dy, gxs, dxs, dweight, dbias, B, L, dilation, pre_slope, post_slope, h->cconv_scratch);
     if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_conv32_backward: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+int fd_conv7_forward(fd_handle h, int which, const float *x, const float *weight, const float *bias, int B, int64_t L, float *y, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!x || !weight || !bias || !y) FD_FAIL(h, FD_ERR_INVALID, "fd_conv7_forward: null pointer");
+    if ((which != 0 && which != 1) || B <= 0 || B > 65535 || L < 4 || L % 4 != 0 || L >= ((int64_t)1 << 25))
+        FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_conv7_forward: which=%d (0 first_audio_conv, 1 final_conv), B=%d, L=%lld (a multiple of 4)", which, B, (long long)L);
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::conv7_forward(La, which, x, weight, bias, y, B, L);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_conv7_forward: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+int fd_conv7_backward(fd_handle h, int which, const float *x, const float *weight, const float *dy, int B, int64_t L, float *dx, float *dweight,
+                      float *dbias, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!x || !weight || !dy) FD_FAIL(h, FD_ERR_INVALID, "fd_conv7_backward: null pointer");
+    if ((which != 0 && which != 1) || B <= 0 || B > 65535 || L < 4 || L % 4 != 0 || L >= ((int64_t)1 << 25))
+        FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_conv7_backward: which=%d (0 first_audio_conv, 1 final_conv), B=%d, L=%lld (a multiple of 4)", which, B, (long long)L);
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    int rc = cconv_scratch_reserve(h, fdk::conv7_scratch_floats(La, B, L));
+    if (rc != FD_OK) return rc;
+    hipError_t e = fdk::conv7_backward(La, which, x, weight, dy, dx, dweight, dbias, B, L, h->cconv_scratch);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_conv7_backward: %s", hipGetErrorString(e));
     return FD_OK;
 }
 

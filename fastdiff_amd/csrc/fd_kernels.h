@@ -46,6 +46,11 @@ hipError_t cconv_forward(const Launch &L, const float *x, const float *skip, con
                          int64_t len, int dil, float pre, float post);
 hipError_t cconv_backward(const Launch &L, const float *xs, const float *y, const float *w, const float *dy, const float *gxs, float *dxs,
                           float *dw, float *db, int B, int64_t len, int dil, float pre, float post, float *scratch);
+// first_audio_conv (which = 0: Conv1d 1 -> 32, k7) and final_conv (which = 1: Conv1d 32 -> 1, k7) of the training path
+size_t conv7_scratch_floats(const Launch &L, int B, int64_t len);
+hipError_t conv7_forward(const Launch &L, int which, const float *x, const float *w, const float *bias, float *y, int B, int64_t len);
+hipError_t conv7_backward(const Launch &L, int which, const float *x, const float *w, const float *dy, float *dx, float *dw, float *db, int B,
+                          int64_t len, float *scratch);
 // torch._weight_norm(v, g, 0) on a [rows, cols] view and its backward (fd_kernels_cconv.hip)
 hipError_t weight_norm_forward(const Launch &L, const float *v, const float *g, float *w, float *norm, int64_t rows, int cols);
 hipError_t weight_norm_backward(const Launch &L, const float *v, const float *g, const float *norm, const float *dw, float *dv, float *dg,

@@ -244,24 +244,177 @@ __global__ void __launch_bounds__(256, 2) k_cconv_bwd(const float *__restrict__ 
 
 // partial [nparts][PSTRIDE] -> dW [3072], db [32]: workgroup = 32 elements x 8 slices of the partials, each slice summed in order, the
 // eight slice sums added in order
-__global__ void __launch_bounds__(256) k_cconv_reduce(const float *__restrict__ partial, int nparts, float *__restrict__ dw, float *__restrict__ db)
+// (partials pstride floats apart, `count` of them meaningful: the first nw are the weight gradient, the rest the bias gradient)
+__global__ void __launch_bounds__(256) k_cconv_reduce(const float *__restrict__ partial, int nparts, int pstride, int count, int nw,
+                                                      float *__restrict__ dw, float *__restrict__ db)
 {
     __shared__ float sl[8][32];
     const int e = blockIdx.x * 32 + (threadIdx.x & 31), q = threadIdx.x >> 5;
     const int per = (nparts + 7) / 8, p0 = q * per, p1 = min(nparts, p0 + per);
     float acc = 0.0f;
-    if (e < PSTRIDE)
-        for (int p = p0; p < p1; ++p) acc += partial[(int64_t)p * PSTRIDE + e];
+    if (e < count)
+        for (int p = p0; p < p1; ++p) acc += partial[(int64_t)p * pstride + e];
     sl[q][threadIdx.x & 31] = acc;
     __syncthreads();
-    if (q == 0 && e < PSTRIDE) {
+    if (q == 0 && e < count) {
         float s = 0.0f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) s += sl[j][threadIdx.x];
-        if (e < NW) { if (dw) dw[e] = s; }
-        else if (db) db[e - NW] = s;
+        if (e < nw) { if (dw) dw[e] = s; }
+        else if (db) db[e - nw] = s;
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The two 7-tap convolutions at the ends of the network on the training path: first_audio_conv = Conv1d(1, 32, 7, pad 3)
+// (FastDiff_model.py:34-36,89) and final_conv = Conv1d(32, 1, 7, pad 3) (FastDiff_model.py:67-68,100).  K = 7 is nothing for the matrix
+// pipe: plain VALU, tiles of 256 columns through LDS, the weights through vector loads + LDS (never scalar loads: DESIGN.md section 4).
+// Both weight gradients are the same correlation of a 32-row tile R with ONE row s,  C[r][k] = sum_t R[r][t] s[t + sgn (k - 3)]:
+//   first conv:  R = dy [32 rows], s = x,  sgn = +1;      final conv:  R = x [32 rows], s = dy,  sgn = -1
+// thread = (row r, eighth of the tile's columns, interleaved), 7 running sums kept over all tiles of the persistent workgroup, the
+// eighths added by a butterfly, per-workgroup partials added in a fixed order by k_cconv_reduce.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int C7W = 256, C7LD = 264;      // tile width; LDS row stride (264 = 8 mod 32: lanes (row 0..7, eighth 0..7) hit 64 different banks)
+constexpr int C7P = 32 * 7 + 32;          // one workgroup's partial: dW [32][7], then up to 32 bias sums
+
+__global__ void __launch_bounds__(256) k_c7_first_fwd(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                                                      float *__restrict__ y, int L)
+{
+    __shared__ float wl[256];      // [out][7 taps + bias]
+    wl[threadIdx.x] = (threadIdx.x & 7) < 7 ? w[(threadIdx.x >> 3) * 7 + (threadIdx.x & 7)] : bias[threadIdx.x >> 3];
+    __syncthreads();
+    const int b = blockIdx.y, t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (t0 >= L) return;
+    const float *xr = x + (int64_t)b * L;
+    float xv[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const int p = t0 - 3 + i;
+        xv[i] = (p >= 0 && p < L) ? xr[p] : 0.0f;
+    }
+#pragma unroll 4
+    for (int o = 0; o < C; ++o) {
+        const float bv = wl[o * 8 + 7];
+        float4 r = make_float4(bv, bv, bv, bv);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const float wv = wl[o * 8 + k];
+            r.x += wv * xv[k]; r.y += wv * xv[k + 1]; r.z += wv * xv[k + 2]; r.w += wv * xv[k + 3];
+        }
+        *reinterpret_cast<float4 *>(y + ((int64_t)b * C + o) * L + t0) = r;
+    }
+}
+
+// stage rows [32][C7W + 6] of R (columns w0 - 3 .. w0 + C7W + 2, zero outside [0, L)) and the same window of s
+__device__ __forceinline__ void c7_stage(float *__restrict__ Rs, float *__restrict__ ss, const float *__restrict__ R, const float *__restrict__ s1,
+                                         int b, int w0, int L, int tid)
+{
+    for (int idx = tid; idx < C * (C7W + 6); idx += 256) {
+        const int r = idx / (C7W + 6), c = idx - r * (C7W + 6), g = w0 - 3 + c;
+        Rs[r * C7LD + c] = (g >= 0 && g < L) ? R[((int64_t)b * C + r) * L + g] : 0.0f;
+    }
+    for (int c = tid; c < C7W + 6; c += 256) {
+        const int g = w0 - 3 + c;
+        ss[c] = (g >= 0 && g < L) ? s1[(int64_t)b * L + g] : 0.0f;
+    }
+}
+
+// MODE 0 = first conv backward (R = dy, s = x): dW, db[32] = row sums of dy, and (optionally) dx[t] = sum_{o,k} W[o][k] dy[o][t + 3 - k]
+// MODE 1 = final conv backward (R = x, s = dy): dW, db[1] = sum of dy, and dx[i][t] = sum_k W[i][k] dy[t + 3 - k]
+template <int MODE>
+__global__ void __launch_bounds__(256) k_c7_bwd(const float *__restrict__ R, const float *__restrict__ s1, const float *__restrict__ w,
+                                                float *__restrict__ dx, float *__restrict__ partial, int L, int tiles_per_row, int ntiles)
+{
+    __shared__ float Rs[C * C7LD];
+    __shared__ float ss[C7W + 8];
+    __shared__ float wl[C * 8];
+    const int tid = threadIdx.x, r = tid >> 3, part = tid & 7;
+    wl[tid] = part < 7 ? w[r * 7 + part] : 0.0f;      // weight of row r (first conv: out channel, final conv: in channel), tap `part`
+    float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float rowsum = 0.0f;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_row, w0 = (tile - b * tiles_per_row) * C7W;
+        __syncthreads();
+        c7_stage(Rs, ss, R, s1, b, w0, L, tid);
+        __syncthreads();
+        // ---- the correlation: this thread's columns part, part + 8, ... of the tile (centre columns: LDS index 3 + t)
+#pragma unroll 4
+        for (int j = 0; j < C7W / 8; ++j) {
+            const int t = part + 8 * j;
+            const float rv = Rs[r * C7LD + 3 + t];
+            if (MODE == 0) rowsum += rv;
+            else if (r == 0) rowsum += ss[3 + t];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) acc[k] = fmaf(rv, ss[3 + t + (MODE == 0 ? k - 3 : 3 - k)], acc[k]);
+        }
+        // ---- the input gradient
+        if (dx) {
+            const int t = tid, g = w0 + t;
+            if (MODE == 0) {
+                if (g < L) {
+                    float v = 0.0f;
+#pragma unroll 4
+                    for (int o = 0; o < C; ++o)
+#pragma unroll
+                        for (int k = 0; k < 7; ++k) v = fmaf(wl[o * 8 + k], Rs[o * C7LD + 3 + t + 3 - k], v);
+                    dx[(int64_t)b * L + g] = v;
+                }
+            } else {
+                if (g < L) {
+                    float dv[7];
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) dv[k] = ss[3 + t + 3 - k];
+#pragma unroll 4
+                    for (int i = 0; i < C; ++i) {
+                        float v = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < 7; ++k) v = fmaf(wl[i * 8 + k], dv[k], v);
+                        dx[((int64_t)b * C + i) * L + g] = v;
+                    }
+                }
+            }
+        }
+    }
+    // the eighths of a row sit in eight neighbouring lanes: butterfly, then lane part == 0 writes the workgroup's partial
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        acc[k] += __shfl_xor(acc[k], 1, 64);
+        acc[k] += __shfl_xor(acc[k], 2, 64);
+        acc[k] += __shfl_xor(acc[k], 4, 64);
+    }
+    rowsum += __shfl_xor(rowsum, 1, 64);
+    rowsum += __shfl_xor(rowsum, 2, 64);
+    rowsum += __shfl_xor(rowsum, 4, 64);
+    float *pout = partial + (int64_t)blockIdx.x * C7P;
+    if (part == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) pout[r * 7 + k] = acc[k];
+        if (MODE == 0 || r == 0) pout[C * 7 + r] = rowsum;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_c7_final_fwd(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                                                      float *__restrict__ y, int L, int tiles_per_row)
+{
+    __shared__ float Rs[C * C7LD];
+    __shared__ float wl[C * 8];
+    const int tid = threadIdx.x, b = blockIdx.x / tiles_per_row, w0 = (blockIdx.x - b * tiles_per_row) * C7W;
+    wl[tid] = (tid & 7) < 7 ? w[(tid >> 3) * 7 + (tid & 7)] : (tid == 7 ? bias[0] : 0.0f);      // the bias rides in slot 7 of row 0
+    for (int idx = tid; idx < C * (C7W + 6); idx += 256) {
+        const int r = idx / (C7W + 6), c = idx - r * (C7W + 6), g = w0 - 3 + c;
+        Rs[r * C7LD + c] = (g >= 0 && g < L) ? x[((int64_t)b * C + r) * L + g] : 0.0f;
+    }
+    __syncthreads();
+    const int g = w0 + tid;
+    if (g >= L) return;
+    float v = wl[7];
+#pragma unroll 4
+    for (int i = 0; i < C; ++i)
+#pragma unroll
+        for (int k = 0; k < 7; ++k) v = fmaf(wl[i * 8 + k], Rs[i * C7LD + tid + k], v);
+    y[(int64_t)b * L + g] = v;
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // weight-norm (FastDiff_model.py:115-122: torch.nn.utils.weight_norm on every Conv1d = torch._weight_norm(v, g, 0)):
@@ -357,7 +510,31 @@ hipError_t cconv_backward(const Launch &L_, const float *xs, const float *y, con
     default: return hipErrorInvalidValue;
     }
 #undef FD_CC_BWD
-    if (dw || db) FD_LAUNCH(L_, "cconv_reduce", k_cconv_reduce, dim3((PSTRIDE + 31) / 32), dim3(256), 0, (const float *)scratch, grid, dw, db);
+    if (dw || db) FD_LAUNCH(L_, "cconv_reduce", k_cconv_reduce, dim3((PSTRIDE + 31) / 32), dim3(256), 0, (const float *)scratch, grid, (int)PSTRIDE, (int)PSTRIDE, (int)NW, dw, db);
+    return hipSuccess;
+}
+
+// first_audio_conv / final_conv of the training path.  which: 0 = first (x [B,1,L] -> y [B,32,L]), 1 = final (x [B,32,L] -> y [B,1,L])
+static int c7_grid(const Launch &L_, int B, int64_t L) { return (int)std::min<int64_t>((int64_t)B * ((L + C7W - 1) / C7W), 4 * (int64_t)L_.ctx->num_cus); }
+size_t conv7_scratch_floats(const Launch &L_, int B, int64_t L) { return (size_t)c7_grid(L_, B, L) * C7P; }
+
+hipError_t conv7_forward(const Launch &L_, int which, const float *x, const float *w, const float *bias, float *y, int B, int64_t L)
+{
+    if (which == 0) FD_LAUNCH(L_, "conv7_first_fwd", k_c7_first_fwd, dim3((unsigned)((L + 1023) / 1024), B), dim3(256), 0, x, w, bias, y, (int)L);
+    else {
+        const int tiles = (int)((L + C7W - 1) / C7W);
+        FD_LAUNCH(L_, "conv7_final_fwd", k_c7_final_fwd, dim3(B * tiles), dim3(256), 0, x, w, bias, y, (int)L, tiles);
+    }
+    return hipSuccess;
+}
+
+hipError_t conv7_backward(const Launch &L_, int which, const float *x, const float *w, const float *dy, float *dx, float *dw, float *db, int B,
+                          int64_t L, float *scratch)
+{
+    const int tiles = (int)((L + C7W - 1) / C7W), ntiles = B * tiles, grid = c7_grid(L_, B, L);
+    if (which == 0) FD_LAUNCH(L_, "conv7_first_bwd", k_c7_bwd<0>, dim3(grid), dim3(256), 0, dy, x, w, dx, scratch, (int)L, tiles, ntiles);
+    else FD_LAUNCH(L_, "conv7_final_bwd", k_c7_bwd<1>, dim3(grid), dim3(256), 0, x, dy, w, dx, scratch, (int)L, tiles, ntiles);
+    if (dw || db) FD_LAUNCH(L_, "cconv_reduce", k_cconv_reduce, dim3((C7P + 31) / 32), dim3(256), 0, (const float *)scratch, grid, (int)C7P, which == 0 ? (int)C7P : 32 * 7 + 1, 32 * 7, dw, db);
     return hipSuccess;
 }
 

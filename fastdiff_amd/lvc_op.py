@@ -145,6 +145,51 @@ class _KConv(torch.autograd.Function):
         return (None if dx is None else dx.to(tx), None if dw is None else dw.to(tw), None if db is None else db.to(tb))
 
 
+class _Conv7(torch.autograd.Function):
+    """first_audio_conv (which = 0: Conv1d(1, 32, 7, padding 3)) / final_conv (which = 1: Conv1d(32, 1, 7, padding 3)), FastDiff_model.py:
+    34-36,67-68, forward and backward on HIP kernels (fd_conv7_forward / fd_conv7_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, which):
+        ctx.in_dtypes = (x.dtype, weight.dtype, bias.dtype)
+        x, weight, bias = x.contiguous().float(), weight.contiguous().float(), bias.contiguous().float()
+        B, _, L = x.shape
+        y = torch.empty((B, 32 if which == 0 else 1, L), device=x.device, dtype=torch.float32)
+        lib, h = _handle(x.device)
+        _capi.check(lib, h, lib.fd_conv7_forward(h, int(which), x.data_ptr(), weight.data_ptr(), bias.data_ptr(), B, L, y.data_ptr(), _stream(x.device)),
+                    "fd_conv7_forward")
+        ctx.save_for_backward(x, weight)
+        ctx.which = int(which)
+        return y.to(ctx.in_dtypes[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        B, _, L = x.shape
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
+        dx = torch.empty_like(x) if need_x else None
+        dw = torch.empty_like(weight) if need_w else None
+        db = torch.empty(32 if ctx.which == 0 else 1, device=x.device, dtype=torch.float32) if need_b else None
+        lib, h = _handle(x.device)
+        _capi.check(lib, h, lib.fd_conv7_backward(h, ctx.which, x.data_ptr(), weight.data_ptr(), dy.data_ptr(), B, L, None if dx is None else dx.data_ptr(),
+                                                  None if dw is None else dw.data_ptr(), None if db is None else db.data_ptr(), _stream(x.device)),
+                    "fd_conv7_backward")
+        tx, tw, tb = ctx.in_dtypes
+        return (None if dx is None else dx.to(tx), None if dw is None else dw.to(tw), None if db is None else db.to(tb), None)
+
+
+def conv7_supported(x, weight):
+    """first_audio_conv ([32,1,7] on [B,1,L]) or final_conv ([1,32,7] on [B,32,L]) on a HIP tensor whose length is a multiple of 4."""
+    return (x.is_cuda and x.dim() == 3 and x.shape[2] % 4 == 0 and 4 <= x.shape[2] < (1 << 25) and
+            ((tuple(weight.shape) == (32, 1, 7) and x.shape[1] == 1) or (tuple(weight.shape) == (1, 32, 7) and x.shape[1] == 32)))
+
+
+def conv7(x, weight, bias):
+    """conv1d(x, weight, bias, padding=3) for the model's first_audio_conv / final_conv as a differentiable HIP operator."""
+    return _Conv7.apply(x, weight, bias, 0 if weight.shape[0] == 32 else 1)
+
+
 class _WeightNorm(torch.autograd.Function):
     """w = torch._weight_norm(v, g, 0) (what torch.nn.utils.weight_norm's hook evaluates on every forward, FastDiff_model.py:115-122)
     as one HIP launch forward (fd_weight_norm_forward) and one backward (fd_weight_norm_backward)."""

@@ -39,7 +39,12 @@ def _conv_weight(m):
 
 
 def _conv(m, x):
-    """m(x) for a Conv1d holder: on HIP tensors the weight-norm runs on this repo's operator (the module's own hook would run torch's)."""
+    """m(x) for a Conv1d holder: on HIP tensors the weight-norm runs on this repo's operator (the module's own hook would run torch's), and
+    the two 7-tap convolutions at the ends of the network on theirs (fastdiff_amd.lvc_op.conv7)."""
+    if x.is_cuda and m.kernel_size == (7,):
+        from .lvc_op import conv7, conv7_supported
+        if conv7_supported(x, m.weight_v if hasattr(m, "weight_v") else m.weight):
+            return conv7(x, _conv_weight(m), m.bias)
     if x.is_cuda and hasattr(m, "weight_g"):
         return F.conv1d(x, _conv_weight(m), m.bias, stride=m.stride, padding=m.padding, dilation=m.dilation)
     return m(x)

@@ -188,6 +188,15 @@ FD_API int fd_kconv_backward(fd_handle h, const float *x, const float *weight, c
 FD_API int fd_gate_forward(fd_handle h, const float *x, const float *y, int B, int C, int64_t L, float *out, void *stream);
 FD_API int fd_gate_backward(fd_handle h, const float *y, const float *dout, int B, int C, int64_t L, float *dy, void *stream);
 
+/* The two 7-tap convolutions at the ends of the network on the training path: which = 0 first_audio_conv = Conv1d(1, 32, 7, padding 3)
+ * (FastDiff_model.py:34-36,89): x [B,1,L] -> y [B,32,L], weight [32,1,7]; which = 1 final_conv = Conv1d(32, 1, 7, padding 3)
+ * (FastDiff_model.py:67-68,100): x [B,32,L] -> y [B,1,L], weight [1,32,7].  L a multiple of 4.  backward writes dx (nullable),
+ * dweight and dbias (each nullable) from x, the folded weight and dy; sums in a fixed order. */
+FD_API int fd_conv7_forward(fd_handle h, int which, const float *x, const float *weight, const float *bias, int B, int64_t L, float *y,
+                            void *stream);
+FD_API int fd_conv7_backward(fd_handle h, int which, const float *x, const float *weight, const float *dy, int B, int64_t L, float *dx,
+                             float *dweight, float *dbias, void *stream);
+
 /* Weight-norm of the training path: every Conv1d of the model carries torch.nn.utils.weight_norm (FastDiff_model.py:71-72,115-122), i.e.
  * its forward evaluates w = torch._weight_norm(v, g, 0): w[r, :] = v[r, :] * g[r] / ||v[r, :]|| on the [rows = out channels, cols = in * k]
  * view.  forward also leaves ||v[r]|| in norm [rows] for the backward, which turns dw into dv [rows, cols] and dg [rows]. */

@@ -283,3 +283,36 @@ def test_weight_norm_operator_matches_torch(shape):
     rel = lambda got, want: float((got.double().cpu() - want).abs().max()) / max(1e-30, float(want.abs().max()))      # noqa: E731
     assert rel(w.detach(), torch._weight_norm(v64, g64, 0).detach()) < 1e-6
     assert rel(vg.grad, v64.grad) < 2e-6 and rel(gg.grad, g64.grad) < 2e-6 and gg.grad.shape == g.shape
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,B,L", [(0, 2, 1024), (1, 2, 1024), (0, 3, 260), (1, 3, 260), (0, 1, 4), (1, 1, 4), (0, 20, 25600), (1, 20, 25600)])
+def test_conv7_operators_forward_and_backward_match_torch_autograd(which, B, L):
+    """fastdiff_amd.lvc_op.conv7 = first_audio_conv (Conv1d(1, 32, 7, padding 3), FastDiff_model.py:34-36) and final_conv (Conv1d(32, 1,
+    7, padding 3), FastDiff_model.py:67-68) forward and their three gradients on HIP kernels, against torch's conv1d and autograd in
+    float64 (the training shape: float32 on the GPU as the yardstick); tile edges, one quad of columns."""
+    import torch.nn.functional as F
+    from fastdiff_amd.lvc_op import conv7, conv7_supported
+    g = torch.Generator().manual_seed(10 * L + which)
+    cin, cout = (1, 32) if which == 0 else (32, 1)
+    x = torch.randn(B, cin, L, generator=g)
+    w = torch.randn(cout, cin, 7, generator=g) / 3.0
+    bias = torch.randn(cout, generator=g)
+    dy = torch.randn(B, cout, L, generator=g)
+    big = B * L > 100000
+    dt, dev = (torch.float32, "cuda") if big else (torch.float64, "cpu")
+    x64, w64, b64 = (t.to(dev, dt).requires_grad_(True) for t in (x, w, bias))
+    ref = F.conv1d(x64, w64, b64, padding=3)
+    ref.backward(dy.to(dev, dt))
+    xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, bias))
+    assert conv7_supported(xg, wg)
+    y = conv7(xg, wg, bg)
+    y.backward(dy.cuda())
+    rel = lambda got, want: float((got.double().cpu() - want.double().cpu()).abs().max()) / max(1.0, float(want.abs().max()))      # noqa: E731
+    tol = 2e-5 if big else 3e-6
+    assert y.shape == ref.shape and rel(y.detach(), ref.detach()) < tol
+    assert rel(xg.grad, x64.grad) < tol and rel(wg.grad, w64.grad) < tol and rel(bg.grad, b64.grad) < tol
+    x2 = x.cuda()                                                           # the training case: the audio needs no gradient
+    w2, b2 = w.cuda().requires_grad_(True), bias.cuda().requires_grad_(True)
+    conv7(x2, w2, b2).backward(dy.cuda())
+    assert torch.equal(w2.grad, wg.grad) and torch.equal(b2.grad, bg.grad)  # fixed-order sums: the same bits
