@@ -1473,37 +1473,56 @@ static int lvc_scratch(fd_handle h, int B, int Cin, int Cout, int ks, int T, int
     return FD_OK;
 }
 
-int fd_lvc_forward(fd_handle h, const float *x, const float *kernel, const float *bias, int B, int Cin, int Cout, int ks, int T, int hop,
-                   float *out, void *stream)
+int fd_lvc_forward_strided(fd_handle h, const float *x, const float *kernel, int64_t kernel_bstride, const float *bias, int B, int Cin, int Cout,
+                           int ks, int T, int hop, float *out, void *stream)
 {
     if (!h) return FD_ERR_INVALID;
     if (!x || !kernel || !bias || !out) FD_FAIL(h, FD_ERR_INVALID, "fd_lvc_forward: null pointer");
     int rc = check_lvc_op(h, B, Cin, Cout, ks, T, hop, "fd_lvc_forward");
     if (rc != FD_OK) return rc;
+    const int64_t own = (int64_t)Cin * Cout * ks * T;
+    if (kernel_bstride != 0 && kernel_bstride != own && (kernel_bstride < own || !fdk::lvc_op_needs_scratch(Cin, Cout, ks, hop)))
+        FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_lvc_forward: a batch-strided kernel (stride %lld) needs the model's shape (32 -> 64, k3, hop 8 / 64 / 256)", (long long)kernel_bstride);
     FD_HIP(h, hipSetDevice(h->device));
     float *scratch = nullptr;
     if ((rc = lvc_scratch(h, B, Cin, Cout, ks, T, hop, &scratch)) != FD_OK) return rc;
     fdk::Launch L = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::lvc_op_forward(L, x, kernel, bias, out, B, Cin, Cout, ks, T, hop, scratch);
+    hipError_t e = fdk::lvc_op_forward(L, x, kernel, bias, out, B, Cin, Cout, ks, T, hop, scratch, kernel_bstride);
     if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_lvc_forward: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+int fd_lvc_forward(fd_handle h, const float *x, const float *kernel, const float *bias, int B, int Cin, int Cout, int ks, int T, int hop,
+                   float *out, void *stream)
+{
+    return fd_lvc_forward_strided(h, x, kernel, 0, bias, B, Cin, Cout, ks, T, hop, out, stream);
+}
+
+int fd_lvc_backward_strided(fd_handle h, const float *x, const float *kernel, int64_t kernel_bstride, const float *dout, int B, int Cin, int Cout,
+                            int ks, int T, int hop, float *dx, float *dkernel, int64_t dkernel_bstride, float *dbias, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!dout || ((dkernel || dbias) && !x) || (dx && !kernel)) FD_FAIL(h, FD_ERR_INVALID, "fd_lvc_backward: null pointer");
+    int rc = check_lvc_op(h, B, Cin, Cout, ks, T, hop, "fd_lvc_backward");
+    if (rc != FD_OK) return rc;
+    const int64_t own = (int64_t)Cin * Cout * ks * T;
+    for (int64_t st : {kernel_bstride, dkernel_bstride})
+        if (st != 0 && st != own && (st < own || !fdk::lvc_op_needs_scratch(Cin, Cout, ks, hop)))
+            FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_lvc_backward: a batch-strided kernel / dkernel (stride %lld) needs the model's shape (32 -> 64, k3, hop 8 / 64 / 256)", (long long)st);
+    FD_HIP(h, hipSetDevice(h->device));
+    float *scratch = nullptr;
+    if ((rc = lvc_scratch(h, B, Cin, Cout, ks, T, hop, &scratch)) != FD_OK) return rc;
+    if (scratch && dx && !kernel) FD_FAIL(h, FD_ERR_INVALID, "fd_lvc_backward: null pointer");
+    fdk::Launch L = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::lvc_op_backward(L, x, kernel, dout, dx, dkernel, dbias, B, Cin, Cout, ks, T, hop, scratch, kernel_bstride, dkernel_bstride);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_lvc_backward: %s", hipGetErrorString(e));
     return FD_OK;
 }
 
 int fd_lvc_backward(fd_handle h, const float *x, const float *kernel, const float *dout, int B, int Cin, int Cout, int ks, int T, int hop,
                     float *dx, float *dkernel, float *dbias, void *stream)
 {
-    if (!h) return FD_ERR_INVALID;
-    if (!dout || ((dkernel || dbias) && !x) || (dx && !kernel)) FD_FAIL(h, FD_ERR_INVALID, "fd_lvc_backward: null pointer");
-    int rc = check_lvc_op(h, B, Cin, Cout, ks, T, hop, "fd_lvc_backward");
-    if (rc != FD_OK) return rc;
-    FD_HIP(h, hipSetDevice(h->device));
-    float *scratch = nullptr;
-    if ((rc = lvc_scratch(h, B, Cin, Cout, ks, T, hop, &scratch)) != FD_OK) return rc;
-    if (scratch && dx && !kernel) FD_FAIL(h, FD_ERR_INVALID, "fd_lvc_backward: null pointer");
-    fdk::Launch L = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::lvc_op_backward(L, x, kernel, dout, dx, dkernel, dbias, B, Cin, Cout, ks, T, hop, scratch);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_lvc_backward: %s", hipGetErrorString(e));
-    return FD_OK;
+    return fd_lvc_backward_strided(h, x, kernel, 0, dout, B, Cin, Cout, ks, T, hop, dx, dkernel, 0, dbias, stream);
 }
 
 // kernel_conv of the KernelPredictor (training path).  The backward adds up partial sums (row slices for dx, utterance ranges for

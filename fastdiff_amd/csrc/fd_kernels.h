@@ -24,10 +24,12 @@ hipError_t fast_final(const Launch &L, const StepIO &io, const float *x32, int B
 // the LVC operator with its gradients (fd_kernels_train.hip)
 // scratch: B*T*Cin*Cout*ks floats when lvc_op_needs_scratch (the model's shape: matrix-pipe kernels), else unused
 bool lvc_op_needs_scratch(int Cin, int Cout, int ks, int hop);
+// kbs / dkbs: floats between two utterances of K / dK (0 = a tensor of its own; the model's shape also takes one layer's slice of a
+// [B, layers, Cin, Cout, ks, T] tensor)
 hipError_t lvc_op_forward(const Launch &L, const float *x, const float *K, const float *bias, float *out, int B, int Cin, int Cout, int ks,
-                          int T, int hop, float *scratch);
+                          int T, int hop, float *scratch, int64_t kbs = 0);
 hipError_t lvc_op_backward(const Launch &L, const float *x, const float *K, const float *dout, float *dx, float *dK, float *dbias, int B,
-                           int Cin, int Cout, int ks, int T, int hop, float *scratch);
+                           int Cin, int Cout, int ks, int T, int hop, float *scratch, int64_t kbs = 0, int64_t dkbs = 0);
 // the gate + residual of an LVC layer, one pass forward and one backward (modules.py:217)
 hipError_t gate_forward(const Launch &L, const float *x, const float *y, float *out, int B, int C, int64_t len);
 hipError_t gate_backward(const Launch &L, const float *y, const float *dout, float *dy, int B, int C, int64_t len);

@@ -47,16 +47,17 @@ __device__ __forceinline__ int row_of(int e)
     return (i * MO + o) * MK + k;
 }
 
-// K [B][6144 rows][T] -> frame-major [B][T][6144] in ORDER (64 x 64 tiles through LDS, both sides coalesced)
+// K [B][6144 rows][T] -> frame-major [B][T][6144] in ORDER (64 x 64 tiles through LDS, both sides coalesced).  kbs: floats between two
+// utterances of K (6144 T for a tensor of its own; 4 x that for one layer's slice of the predictor's [B, 4, 32, 64, 3, T] output)
 template <int ORDER>
-__global__ void __launch_bounds__(256) k_lvc_pack(const float *__restrict__ K, float *__restrict__ Kf, int T)
+__global__ void __launch_bounds__(256) k_lvc_pack(const float *__restrict__ K, float *__restrict__ Kf, int T, int64_t kbs)
 {
     __shared__ float tile[64][65];
     const int l0 = blockIdx.x * 64, e0 = blockIdx.y * 64, b = blockIdx.z, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll 4
     for (int r = 0; r < 16; ++r) {
         const int el = w * 16 + r, l = l0 + lane;
-        tile[el][lane] = l < T ? K[((int64_t)b * ME + row_of<ORDER>(e0 + el)) * T + l] : 0.0f;
+        tile[el][lane] = l < T ? K[(int64_t)b * kbs + (int64_t)row_of<ORDER>(e0 + el) * T + l] : 0.0f;
     }
     __syncthreads();
 #pragma unroll 4
@@ -67,7 +68,7 @@ __global__ void __launch_bounds__(256) k_lvc_pack(const float *__restrict__ K, f
 }
 
 // frame-major dK (ORDER_DK) -> dK [B][6144 rows][T]
-__global__ void __launch_bounds__(256) k_lvc_unpack(const float *__restrict__ Kf, float *__restrict__ K, int T)
+__global__ void __launch_bounds__(256) k_lvc_unpack(const float *__restrict__ Kf, float *__restrict__ K, int T, int64_t kbs)
 {
     __shared__ float tile[64][65];
     const int l0 = blockIdx.x * 64, e0 = blockIdx.y * 64, b = blockIdx.z, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -80,7 +81,7 @@ __global__ void __launch_bounds__(256) k_lvc_unpack(const float *__restrict__ Kf
 #pragma unroll 4
     for (int r = 0; r < 16; ++r) {
         const int el = w * 16 + r, l = l0 + lane;
-        if (l < T) K[((int64_t)b * ME + row_of<ORDER_DK>(e0 + el)) * T + l] = tile[lane][el];
+        if (l < T) K[(int64_t)b * kbs + (int64_t)row_of<ORDER_DK>(e0 + el) * T + l] = tile[lane][el];
     }
 }
 
@@ -502,14 +503,16 @@ static bool model_shape(int Cin, int Cout, int ks, int hop) { return Cin == MI &
 bool lvc_op_needs_scratch(int Cin, int Cout, int ks, int hop) { return model_shape(Cin, Cout, ks, hop); }
 
 hipError_t lvc_op_forward(const Launch &L, const float *x, const float *K, const float *bias, float *out, int B, int Cin, int Cout, int ks,
-                          int T, int hop, float *scratch)
+                          int T, int hop, float *scratch, int64_t kbs)
 {
     const int Ln = T * hop;
+    if (kbs == 0) kbs = (int64_t)Cin * Cout * ks * T;
     if (!scratch || !model_shape(Cin, Cout, ks, hop)) {
+        if (kbs != (int64_t)Cin * Cout * ks * T) return hipErrorInvalidValue;      // the generic kernels take a tensor of its own only
         FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd, dim3((Ln + 255) / 256, Cout, B), dim3(256), 0, x, K, bias, out, Cin, Cout, ks, T, hop);
         return hipSuccess;
     }
-    FD_LAUNCH(L, "lvc_op_pack", k_lvc_pack<ORDER_FWD>, dim3((T + 63) / 64, ME / 64, B), dim3(256), 0, K, scratch, T);
+    FD_LAUNCH(L, "lvc_op_pack", k_lvc_pack<ORDER_FWD>, dim3((T + 63) / 64, ME / 64, B), dim3(256), 0, K, scratch, T, kbs);
     if (hop == 256) FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd_mfma<256>, dim3(T, B), dim3(256), 0, x, scratch, bias, out, T);
     else if (hop == 64) FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd_mfma<64>, dim3((T + 3) / 4, B), dim3(256), 0, x, scratch, bias, out, T);
     else FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd_mfma<8>, dim3((T + 3) / 4, B), dim3(256), 0, x, scratch, bias, out, T);
@@ -517,10 +520,14 @@ hipError_t lvc_op_forward(const Launch &L, const float *x, const float *K, const
 }
 
 hipError_t lvc_op_backward(const Launch &L, const float *x, const float *K, const float *dout, float *dx, float *dK, float *dbias, int B,
-                           int Cin, int Cout, int ks, int T, int hop, float *scratch)
+                           int Cin, int Cout, int ks, int T, int hop, float *scratch, int64_t kbs, int64_t dkbs)
 {
     const int Ln = T * hop;
+    const int64_t own = (int64_t)Cin * Cout * ks * T;
+    if (kbs == 0) kbs = own;
+    if (dkbs == 0) dkbs = own;
     if (!scratch || !model_shape(Cin, Cout, ks, hop)) {
+        if (kbs != own || dkbs != own) return hipErrorInvalidValue;
         if (dx) FD_LAUNCH(L, "lvc_op_backward_x", k_lvc_bwd_x, dim3((Ln + 255) / 256, Cin, B), dim3(256), 0, dout, K, dx, Cin, Cout, ks, T, hop);
         if (dK || dbias) {
             const size_t shmem = sizeof(float) * ((size_t)Cout * DK_CHUNK + (size_t)Cin * (DK_CHUNK + ks - 1));
@@ -533,7 +540,7 @@ hipError_t lvc_op_backward(const Launch &L, const float *x, const float *K, cons
         return hipSuccess;
     }
     if (dx) {
-        FD_LAUNCH(L, "lvc_op_pack", k_lvc_pack<ORDER_DX>, dim3((T + 63) / 64, ME / 64, B), dim3(256), 0, K, scratch, T);
+        FD_LAUNCH(L, "lvc_op_pack", k_lvc_pack<ORDER_DX>, dim3((T + 63) / 64, ME / 64, B), dim3(256), 0, K, scratch, T, kbs);
         if (hop == 256) FD_LAUNCH(L, "lvc_op_backward_x", k_lvc_dx_mfma<256>, dim3(T, B), dim3(256), 0, dout, scratch, dx, T);
         else if (hop == 64) FD_LAUNCH(L, "lvc_op_backward_x", k_lvc_dx_mfma<64>, dim3((T + 3) / 4, B), dim3(256), 0, dout, scratch, dx, T);
         else FD_LAUNCH(L, "lvc_op_backward_x", k_lvc_dx_mfma<8>, dim3((T + 3) / 4, B), dim3(256), 0, dout, scratch, dx, T);
@@ -542,7 +549,7 @@ hipError_t lvc_op_backward(const Launch &L, const float *x, const float *K, cons
         float *dKf = dK ? scratch : nullptr;      // (the dx kernels are done with the scratch: same stream)
         if (hop == 8) FD_LAUNCH(L, "lvc_op_backward_k", k_lvc_dk_mfma<8>, dim3(T, B), dim3(192), 0, x, dout, dKf, dbias, T, hop);
         else FD_LAUNCH(L, "lvc_op_backward_k", k_lvc_dk_mfma<64>, dim3(T, B), dim3(192), 0, x, dout, dKf, dbias, T, hop);
-        if (dK) FD_LAUNCH(L, "lvc_op_unpack", k_lvc_unpack, dim3((T + 63) / 64, ME / 64, B), dim3(256), 0, scratch, dK, T);
+        if (dK) FD_LAUNCH(L, "lvc_op_unpack", k_lvc_unpack, dim3((T + 63) / 64, ME / 64, B), dim3(256), 0, scratch, dK, T, dkbs);
     }
     return hipSuccess;
 }

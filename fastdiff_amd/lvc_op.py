@@ -36,21 +36,32 @@ def _stream(device):
     return ct.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def _batch_strided(k):
+    """True if k [B, Cin, Cout, ks, T] is contiguous apart from its batch stride (one layer's slice of a [B, layers, ...] tensor)."""
+    _, ci, co, ks, T = k.shape
+    return k.stride()[1:] == (co * ks * T, ks * T, T, 1) and k.stride(0) >= ci * co * ks * T
+
+
 class _LVC(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, kernel, bias, hop_size):
+    def forward(ctx, x, kernel, bias, hop_size, grad_slot=None):
         if not (x.is_cuda and kernel.is_cuda and bias.is_cuda):
             raise RuntimeError("fastdiff_amd.location_variable_convolution runs only on a HIP device (no CPU fallback)")
         # the kernels compute in float32 (the reference trains in float32); other floating types are converted on the way in and
         # the gradients go back in each input's own type, as autograd requires
         ctx.in_dtypes = (x.dtype, kernel.dtype, bias.dtype)
-        x, kernel, bias = x.contiguous().float(), kernel.contiguous().float(), bias.contiguous().float()
+        # split_layers (below) hands out slices of the predictor's [B, layers, ...] output and a slot for the gradient of each
+        ctx.grad_slot = grad_slot
         B, Cin, L = x.shape
         _, _, Cout, ks, T = kernel.shape
+        model_shape = (Cin, Cout, ks) == (32, 64, 3) and int(hop_size) in (8, 64, 256)
+        x, bias = x.contiguous().float(), bias.contiguous().float()
+        if not (kernel.dtype == torch.float32 and model_shape and _batch_strided(kernel)):      # (a slice stays where it lies)
+            kernel = kernel.contiguous().float()
         out = torch.empty((B, Cout, L), device=x.device, dtype=torch.float32)
         lib, h = _handle(x.device)
-        _capi.check(lib, h, lib.fd_lvc_forward(h, x.data_ptr(), kernel.data_ptr(), bias.data_ptr(), B, Cin, Cout, ks, T, int(hop_size),
-                                               out.data_ptr(), _stream(x.device)), "fd_lvc_forward")
+        _capi.check(lib, h, lib.fd_lvc_forward_strided(h, x.data_ptr(), kernel.data_ptr(), kernel.stride(0), bias.data_ptr(), B, Cin, Cout, ks, T,
+                                                       int(hop_size), out.data_ptr(), _stream(x.device)), "fd_lvc_forward")
         ctx.save_for_backward(x, kernel)
         ctx.hop = int(hop_size)
         return out.to(ctx.in_dtypes[0])
@@ -63,14 +74,54 @@ class _LVC(torch.autograd.Function):
         _, _, Cout, ks, T = kernel.shape
         need_x, need_k, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         dx = torch.empty_like(x) if need_x else None
-        dk = torch.empty_like(kernel) if need_k else None
+        dk = None
+        if need_k:
+            slot = ctx.grad_slot
+            if slot is not None and ctx.in_dtypes[1] == torch.float32:      # this layer's slice of the shared gradient buffer
+                holder, i, shape = slot
+                if holder.get("buf") is None:
+                    holder["buf"] = torch.empty(shape, device=x.device, dtype=torch.float32)
+                dk = holder["buf"][:, i]
+            else:
+                dk = torch.empty(kernel.shape, device=x.device, dtype=torch.float32)
         db = torch.empty((B, Cout, T), device=x.device, dtype=torch.float32) if need_b else None
         lib, h = _handle(x.device)
-        _capi.check(lib, h, lib.fd_lvc_backward(h, x.data_ptr(), kernel.data_ptr(), dout.data_ptr(), B, Cin, Cout, ks, T, ctx.hop,
-                                                None if dx is None else dx.data_ptr(), None if dk is None else dk.data_ptr(),
-                                                None if db is None else db.data_ptr(), _stream(x.device)), "fd_lvc_backward")
+        _capi.check(lib, h, lib.fd_lvc_backward_strided(h, x.data_ptr(), kernel.data_ptr(), kernel.stride(0), dout.data_ptr(), B, Cin, Cout, ks, T,
+                                                        ctx.hop, None if dx is None else dx.data_ptr(), None if dk is None else dk.data_ptr(),
+                                                        0 if dk is None else dk.stride(0), None if db is None else db.data_ptr(), _stream(x.device)),
+                    "fd_lvc_backward")
         tx, tk, tb = ctx.in_dtypes
-        return (None if dx is None else dx.to(tx), None if dk is None else dk.to(tk), None if db is None else db.to(tb), None)
+        return (None if dx is None else dx.to(tx), None if dk is None else dk.to(tk), None if db is None else db.to(tb), None, None)
+
+
+class _SplitLayers(torch.autograd.Function):
+    """kernels [B, layers, Cin, Cout, ks, T] -> the `layers` slices kernels[:, i] (what the reference takes with `kernels[:, i, ...]`,
+    modules.py:213-214), without a copy either way: the location-variable convolution reads a slice where it lies (batch-strided) and
+    writes that layer's gradient into its slice of ONE buffer of the whole shape, which is then this node's gradient as it stands.
+    (torch's own unbind / select give contiguous copies to the operator and stack the four gradients: 0.5 ms per training step.)"""
+
+    @staticmethod
+    def forward(ctx, k, holder):
+        ctx.holder = holder
+        return tuple(k[:, i] for i in range(k.shape[1]))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        buf = ctx.holder.get("buf")
+        ctx.holder["buf"] = None
+        if buf is not None and all(g is not None and g.data_ptr() == buf[:, i].data_ptr() and g.stride() == buf[:, i].stride() and g.dtype == buf.dtype
+                                   for i, g in enumerate(grads)):
+            return buf, None
+        ref = next(g for g in grads if g is not None)
+        return torch.stack([g if g is not None else torch.zeros_like(ref) for g in grads], 1), None
+
+
+def split_layers(kernels):
+    """(slices, slots): the per-layer slices kernels[:, i] of the predictor's kernels [B, layers, Cin, Cout, ks, T] and, for each, the
+    `grad_slot` to hand to location_variable_convolution together with it."""
+    holder = {"buf": None}
+    slices = _SplitLayers.apply(kernels, holder)
+    return slices, tuple((holder, i, tuple(kernels.shape)) for i in range(kernels.shape[1]))
 
 
 class _Gate(torch.autograd.Function):
@@ -310,13 +361,13 @@ def kernel_conv1d(x, weight, bias):
     return _KConv.apply(x, weight, bias)
 
 
-def location_variable_convolution(x, kernel, bias, dilation=1, hop_size=256):
+def location_variable_convolution(x, kernel, bias, dilation=1, hop_size=256, grad_slot=None):
     """(batch, in_channels, in_length), (batch, in_channels, out_channels, kernel_size, kernel_length), (batch, out_channels,
     kernel_length) -> (batch, out_channels, in_length); same assert as the reference (modules.py:236).  dilation must be 1: it is
-    the only value the model ever passes (modules.py:216)."""
+    the only value the model ever passes (modules.py:216).  grad_slot (train.py only): see split_layers."""
     batch, in_channels, in_length = x.shape
     batch, in_channels, out_channels, kernel_size, kernel_length = kernel.shape
     assert in_length == (kernel_length * hop_size), "length of (x, kernel) is not matched"
     if dilation != 1:
         raise NotImplementedError("location_variable_convolution: the HIP operator implements dilation = 1 (modules.py:216)")
-    return _LVC.apply(x, kernel, bias, hop_size)
+    return _LVC.apply(x, kernel, bias, hop_size, grad_slot)

@@ -66,7 +66,7 @@ def _dblock(p, x, cconv=None):
     return x + residual
 
 
-def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None):
+def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None, split=None):
     """KernelPredictor.forward (modules.py:320-343).  kconv: the HIP operator for kernel_conv (64 -> 24576 channels: the largest
     matrix product of the step) where its shapes fit, else the module's own convolution."""
     B, _, T = c.shape
@@ -88,7 +88,9 @@ def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None):
     # adds the four up; unbind hands autograd the same views and gets one stack back.  (One kernel_conv call per layer on that
     # layer's weight rows -- contiguous kernels, no stack -- measured slower: 18.3 vs 17.1 ms per step; the slices of the WEIGHT then
     # pay the same zero-fill-and-add in their backward.)
-    return (k.contiguous().view(B, layers, cin, cout, ks, T).unbind(1),
+    k6 = k.contiguous().view(B, layers, cin, cout, ks, T)
+    # on the product path the slices are used where they lie and their gradients land in one buffer (lvc_op.split_layers)
+    return (split(k6) if split is not None else (k6.unbind(1), None),
             conv(p.bias_conv, c).contiguous().view(B, layers, cout, T).unbind(1))
 
 
@@ -97,11 +99,12 @@ def _torch_gate(x, y):
     return x + torch.sigmoid(y[:, :C]) * torch.tanh(y[:, C:])
 
 
-def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate, kconv=None, cconv=None):
+def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate, kconv=None, cconv=None, split=None):
     """TimeAware_LVCBlock.forward (modules.py:189-218); the in-place `x += audio_down` of the reference written out of place."""
     C = cfg["inner_channels"]
     cond = c + p.fc_t(emb).unsqueeze(-1)
-    kernels, bias = _kernel_predictor(p.kernel_predictor, cond, cfg["lvc_layers_each_block"], C, 2 * C, cfg["lvc_kernel_size"], kconv)
+    (kernels, slots), bias = _kernel_predictor(p.kernel_predictor, cond, cfg["lvc_layers_each_block"], C, 2 * C, cfg["lvc_kernel_size"], kconv,
+                                               split if kconv is not None else None)
     x = p.upsample(F.leaky_relu(x, 0.2))
     for i, conv in enumerate(p.convs):
         if cconv is not None and cconv[1](x, conv.weight_v if hasattr(conv, "weight_v") else conv.weight, conv.dilation[0]):
@@ -110,18 +113,19 @@ def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate, kconv=None,
         else:
             x = x + audio_down
             y = F.leaky_relu(_conv(conv, F.leaky_relu(x, 0.2)), 0.2)
-        y = lvc(y, kernels[i], bias[i], 1, p.cond_hop_length)
+        y = lvc(y, kernels[i], bias[i], 1, p.cond_hop_length) if slots is None else lvc(y, kernels[i], bias[i], 1, p.cond_hop_length, grad_slot=slots[i])
         x = gate(x, y)                                   # x + sigmoid(y[:, :C]) * tanh(y[:, C:])  (modules.py:217)
     return x
 
 
 def differentiable_forward(module, data, lvc=None):
     """eps = net((audio, c, diffusion_steps)) as FastDiff.forward (FastDiff_model.py:74-102), recorded by autograd."""
-    gate, kconv, cconv = _torch_gate, None, None
+    gate, kconv, cconv, split = _torch_gate, None, None, None
     if lvc is None:                    # the product path: the layer's operators, its convolution and the predictor's kernel_conv on HIP kernels
-        from .lvc_op import location_variable_convolution as lvc, gated_residual as gate, kernel_conv1d, kernel_conv_supported, conv32, conv32_supported
+        from .lvc_op import location_variable_convolution as lvc, gated_residual as gate, kernel_conv1d, kernel_conv_supported, conv32, conv32_supported, split_layers
         kconv = (kernel_conv1d, kernel_conv_supported)
         cconv = (conv32, conv32_supported)
+        split = split_layers
     audio, c, diffusion_steps = data
     cfg = module._cfg
     if c.dim() == 2:
@@ -134,5 +138,5 @@ def differentiable_forward(module, data, lvc=None):
         skips.append(x)
         x = _dblock(down, x, cconv)
     for n, audio_down in enumerate(reversed(skips)):
-        x = _lvc_block(module.lvc_blocks[n], x, audio_down, c, emb, cfg, lvc, gate, kconv, cconv)
+        x = _lvc_block(module.lvc_blocks[n], x, audio_down, c, emb, cfg, lvc, gate, kconv, cconv, split)
     return _conv(module.final_conv[0], x)

@@ -170,6 +170,14 @@ FD_API int fd_lvc_forward(fd_handle h, const float *x, const float *kernel, cons
                           int hop, float *out, void *stream);
 FD_API int fd_lvc_backward(fd_handle h, const float *x, const float *kernel, const float *dout, int B, int Cin, int Cout, int ks, int T,
                            int hop, float *dx, float *dkernel, float *dbias, void *stream);
+/* The same with a batch stride on the predicted kernel and on its gradient (floats between two utterances; 0 = Cin*Cout*ks*T, a tensor
+ * of its own): one layer's slice [:, i] of the predictor's [B, layers, Cin, Cout, ks, T] output -- and of the gradient buffer of that
+ * shape -- is used where it lies, without a contiguous copy each way (the model's shape only: 32 -> 64, k3, hop 8 / 64 / 256). */
+FD_API int fd_lvc_forward_strided(fd_handle h, const float *x, const float *kernel, int64_t kernel_bstride, const float *bias, int B, int Cin,
+                                  int Cout, int ks, int T, int hop, float *out, void *stream);
+FD_API int fd_lvc_backward_strided(fd_handle h, const float *x, const float *kernel, int64_t kernel_bstride, const float *dout, int B, int Cin,
+                                   int Cout, int ks, int T, int hop, float *dx, float *dkernel, int64_t dkernel_bstride, float *dbias,
+                                   void *stream);
 
 /* KernelPredictor.kernel_conv (modules/FastDiff/module/modules.py:315-318,330-331: Conv1d(64 -> M, kernel 3, padding 1) with
  * M = lvc_layers * in * 2 in * 3 = 24576) for the training path, in the reference's layouts: x [B,64,T], weight [M,64,3] (after

@@ -316,3 +316,36 @@ def test_conv7_operators_forward_and_backward_match_torch_autograd(which, B, L):
     w2, b2 = w.cuda().requires_grad_(True), bias.cuda().requires_grad_(True)
     conv7(x2, w2, b2).backward(dy.cuda())
     assert torch.equal(w2.grad, wg.grad) and torch.equal(b2.grad, bg.grad)  # fixed-order sums: the same bits
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hop,T", [(8, 37), (64, 100), (256, 12)])
+def test_lvc_operator_on_layer_slices_without_copies(hop, T):
+    """fastdiff_amd.lvc_op.split_layers + location_variable_convolution(..., grad_slot=...): the four layers' kernels are slices
+    kernels[:, i] of the predictor's [B, 4, 32, 64, 3, T] output, read where they lie (batch-strided) and their gradients written into
+    the slices of ONE buffer that becomes the gradient of the whole tensor.  Must equal, bit for bit, the plain route (contiguous copy
+    of every slice in, torch.stack of the four gradients out)."""
+    import fastdiff_amd
+    from fastdiff_amd.lvc_op import split_layers
+    B = 3
+    g = torch.Generator().manual_seed(hop + T)
+    k = (0.1 * torch.randn(B, 4, 32, 64, 3, T, generator=g)).cuda()
+    xs = [torch.randn(B, 32, T * hop, generator=g).cuda() for _ in range(4)]
+    bs = [torch.randn(B, 64, T, generator=g).cuda() for _ in range(4)]
+    ds = [torch.randn(B, 64, T * hop, generator=g).cuda() for _ in range(4)]
+    ka = k.clone().requires_grad_(True)
+    outs_a = [fastdiff_amd.location_variable_convolution(xs[i], ka[:, i], bs[i], 1, hop) for i in range(4)]
+    sum((o * d).sum() for o, d in zip(outs_a, ds)).backward()
+    kb = k.clone().requires_grad_(True)
+    slices, slots = split_layers(kb)
+    assert all(not s_.is_contiguous() and s_.data_ptr() == kb[:, i].data_ptr() for i, s_ in enumerate(slices))
+    outs_b = [fastdiff_amd.location_variable_convolution(xs[i], slices[i], bs[i], 1, hop, grad_slot=slots[i]) for i in range(4)]
+    sum((o * d).sum() for o, d in zip(outs_b, ds)).backward()
+    for a, b in zip(outs_a, outs_b):
+        assert torch.equal(a, b)
+    assert torch.equal(ka.grad, kb.grad) and float(kb.grad.abs().max()) > 0
+    # only three of the four layers used: the fourth's gradient is zero, the others as before (the fallback route of the split node)
+    kc = k.clone().requires_grad_(True)
+    slices, slots = split_layers(kc)
+    sum((fastdiff_amd.location_variable_convolution(xs[i], slices[i], bs[i], 1, hop, grad_slot=slots[i]) * ds[i]).sum() for i in range(3)).backward()
+    assert torch.equal(kc.grad[:, :3], ka.grad[:, :3]) and not kc.grad[:, 3].any()

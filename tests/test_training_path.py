@@ -85,7 +85,7 @@ def test_training_step_on_the_hip_operator_matches_the_reference_backward(monkey
     audio = torch.from_numpy(g["audio"]).cuda().requires_grad_(True)
     calls = []
     real = fastdiff_amd.lvc_op.location_variable_convolution
-    monkeypatch.setattr(fastdiff_amd.lvc_op, "location_variable_convolution", lambda x, k, b, d, h: (calls.append(h), real(x, k, b, d, h))[1])
+    monkeypatch.setattr(fastdiff_amd.lvc_op, "location_variable_convolution", lambda x, k, b, d, h, **kw: (calls.append(h), real(x, k, b, d, h, **kw))[1])
     convs = []
     real_c = fastdiff_amd.lvc_op.conv32
     monkeypatch.setattr(fastdiff_amd.lvc_op, "conv32", lambda x, w, b, d, **k: (convs.append((x.shape[-1], d, "skip" in k)), real_c(x, w, b, d, **k))[1])
