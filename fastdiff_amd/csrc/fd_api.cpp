@@ -1648,6 +1648,35 @@ int fd_conv7_backward(fd_handle h, int which, const float *x, const float *weigh
     return FD_OK;
 }
 
+int fd_upsample_forward(fd_handle h, const float *x, const float *weight, const float *bias, int B, int64_t Lin, int ratio, float *y, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!x || !weight || !bias || !y) FD_FAIL(h, FD_ERR_INVALID, "fd_upsample_forward: null pointer");
+    if ((ratio != 4 && ratio != 8) || B <= 0 || B > 65535 || Lin < 1 || Lin * ratio >= ((int64_t)1 << 25))
+        FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_upsample_forward: ratio %d (4 or 8), B=%d, Lin=%lld", ratio, B, (long long)Lin);
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::convt_forward(La, x, weight, bias, y, B, Lin, ratio);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_upsample_forward: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+int fd_upsample_backward(fd_handle h, const float *x, const float *weight, const float *dy, int B, int64_t Lin, int ratio, float *dx, float *dweight,
+                         float *dbias, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!x || !weight || !dy) FD_FAIL(h, FD_ERR_INVALID, "fd_upsample_backward: null pointer");
+    if ((ratio != 4 && ratio != 8) || B <= 0 || B > 65535 || Lin < 1 || Lin * ratio >= ((int64_t)1 << 25))
+        FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_upsample_backward: ratio %d (4 or 8), B=%d, Lin=%lld", ratio, B, (long long)Lin);
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    int rc = cconv_scratch_reserve(h, fdk::convt_scratch_floats(La, ratio, B, Lin));
+    if (rc != FD_OK) return rc;
+    hipError_t e = fdk::convt_backward(La, x, weight, dy, dx, dweight, dbias, B, Lin, ratio, h->cconv_scratch);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_upsample_backward: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
 int fd_weight_norm_forward(fd_handle h, const float *v, const float *g, int64_t rows, int cols, float *w, float *norm, void *stream)
 {
     if (!h) return FD_ERR_INVALID;

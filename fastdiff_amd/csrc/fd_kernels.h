@@ -53,6 +53,11 @@ size_t conv7_scratch_floats(const Launch &L, int B, int64_t len);
 hipError_t conv7_forward(const Launch &L, int which, const float *x, const float *w, const float *bias, float *y, int B, int64_t len);
 hipError_t conv7_backward(const Launch &L, int which, const float *x, const float *w, const float *dy, float *dx, float *dw, float *db, int B,
                           int64_t len, float *scratch);
+// the block's up-sampler on the training path: leaky_relu(x, 0.2) -> ConvTranspose1d(32, 32, 2 r, stride r, padding r / 2), r = 4 or 8
+size_t convt_scratch_floats(const Launch &L, int r, int B, int64_t len_in);
+hipError_t convt_forward(const Launch &L, const float *x, const float *w, const float *bias, float *y, int B, int64_t len_in, int r);
+hipError_t convt_backward(const Launch &L, const float *x, const float *w, const float *dy, float *dx, float *dw, float *db, int B, int64_t len_in,
+                          int r, float *scratch);
 // torch._weight_norm(v, g, 0) on a [rows, cols] view and its backward (fd_kernels_cconv.hip)
 hipError_t weight_norm_forward(const Launch &L, const float *v, const float *g, float *w, float *norm, int64_t rows, int cols);
 hipError_t weight_norm_backward(const Launch &L, const float *v, const float *g, const float *norm, const float *dw, float *dv, float *dg,

@@ -467,6 +467,161 @@ __global__ void __launch_bounds__(256) k_wn_bwd(const float *__restrict__ v, con
     if (lane == 0) dg[r] = dot / nrm;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The block's up-sampler on the training path: `self.upsample(F.leaky_relu(x, 0.2))` with upsample = ConvTranspose1d(32, 32, 2r, stride r,
+// padding r / 2) (modules.py:163-166,205-206), r = 8, 8, 4:
+//     a = leaky_relu(x, 0.2);   y[o][c] = bias[o] + sum_i sum_j a[i][j] W[i][o][c + r/2 - j r]        (taps 0 <= c + r/2 - j r < 2 r)
+// Output phase ph = c mod r, position q = c / r: two input positions contribute, q + offA with tap kA and q + offA - 1 with tap kA + r,
+//     ph <  r/2:  offA = 0, kA = ph + r/2;        ph >= r/2:  offA = 1, kA = ph - r/2
+// Backward (one kernel): tap k reaches column c = j r + k - r/2 = (j + qoff(k)) r + ph(k),  ph(k) = (k - r/2) mod r,  qoff(k) = floor((k - r/2) / r):
+//     da[i][j] = sum_{k, o} W[i][o][k] dy[o][(j + qoff(k)) r + ph(k)],   dx = da * leaky_relu'(x),
+//     dW[i][o][k] = sum_{b, j} a[i][j] dy[o][(j + qoff(k)) r + ph(k)],   db[o] = sum dy[o][.]
+// Tile = 256 output columns = Q = 256 / r input positions.  LDS: dy phase-major [o][phase][position -1 .. Q] (a matrix tile's 32 lanes
+// then read 32 neighbouring floats whichever operand they feed), a [i][position -1 .. Q] (odd strides where lanes index rows).
+// Wave w owns the taps k in [w r/2, (w + 1) r/2): its share of dW (r/2 accumulator tiles of 32 x 32, kept over all tiles of the
+// persistent workgroup) and its share of the da sum, which the four waves add up through LDS in a fixed order.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int R> struct CtCfg {
+    static constexpr int Q = 256 / R, NT = Q / 32, KW = R / 2;      // positions per tile, 32-position tiles, taps per wave
+    static constexpr int ALD = Q + 3;                                // a row: positions -1 .. Q, odd stride
+    static constexpr int PLD = Q + 2, DLD = R * PLD + 1;             // dy: [phase][position -1 .. Q] per channel, odd channel stride
+    static constexpr int PW = 2 * R * C * C;                         // weights
+};
+
+template <int R>
+__global__ void __launch_bounds__(256) k_ct_fwd(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                                                float *__restrict__ y, int Lin, int tiles_per_row)
+{
+    using G = CtCfg<R>;
+    constexpr int Q = G::Q, NT = G::NT, ALD = G::ALD, OLD = 256 + 4;
+    __shared__ float as[C * ALD];                                     // leaky_relu(x), position j at index j - q0 + 1
+    __shared__ __attribute__((aligned(16))) float os[C * OLD];        // the output tile, written back as whole rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.x / tiles_per_row, q0 = (blockIdx.x - b * tiles_per_row) * Q, Lout = Lin * R;
+    for (int idx = tid; idx < C * (Q + 2); idx += 256) {
+        const int i = idx / (Q + 2), jj = idx - i * (Q + 2), j = q0 - 1 + jj;
+        as[i * ALD + jj] = (j >= 0 && j < Lin) ? lrelu(x[((int64_t)b * C + i) * Lin + j], 0.2f) : 0.0f;
+    }
+    __syncthreads();
+    // units (phase, 32-position tile): R * NT = 8 of them, two per wave
+#pragma unroll
+    for (int u2 = 0; u2 < 2; ++u2) {
+        const int u = wave * 2 + u2, ph = u / NT, pt = u - ph * NT;
+        const int offA = ph < R / 2 ? 0 : 1, kA = ph < R / 2 ? ph + R / 2 : ph - R / 2;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bias[drow(r, hi)];
+#pragma unroll 8
+        for (int s = 0; s < 32; ++s) {      // k' = 2 s + hi = sel * 32 + i: sel 0 -> position q + offA, tap kA; sel 1 -> q + offA - 1, tap kA + r
+            const int kk = 2 * s + hi, sel = kk >> 5, i = kk & 31;
+            const float av = w[((int64_t)i * C + l31) * (2 * R) + kA + sel * R];
+            acc = mfma32(av, as[i * ALD + 1 + pt * 32 + l31 + offA - sel], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) os[drow(r, hi) * OLD + (pt * 32 + l31) * R + ph] = acc[r];
+    }
+    __syncthreads();
+    const int c0 = q0 * R;
+    for (int idx = tid; idx < C * 64; idx += 256) {
+        const int o = idx >> 6, c4 = (idx & 63) * 4;
+        if (c0 + c4 < Lout) *reinterpret_cast<float4 *>(y + ((int64_t)b * C + o) * Lout + c0 + c4) = *reinterpret_cast<const float4 *>(os + o * OLD + c4);
+    }
+}
+
+template <int R>
+__global__ void __launch_bounds__(256) k_ct_bwd(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ dy,
+                                                float *__restrict__ dx, float *__restrict__ partial, int Lin, int tiles_per_row, int ntiles)
+{
+    using G = CtCfg<R>;
+    constexpr int Q = G::Q, NT = G::NT, KW = G::KW, ALD = G::ALD, PLD = G::PLD, DLD = G::DLD, PW = G::PW, P = R / 2;
+    extern __shared__ float smem[];
+    float *ws = smem;                       // [k][o][i]: the A operand of the da product, lane = i
+    float *as = ws + PW;                    // [i][ALD]
+    float *ds = as + C * ALD;               // [o][DLD]; at the end of a tile the four waves' da partials: [wave][NT][32 i][32 j]
+    static_assert(4 * NT * 1024 <= C * DLD, "reduction buffer inside the dy image");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5, Lout = Lin * R;
+    for (int idx = tid; idx < PW; idx += 256) {      // w [i][o][k] -> ws [k][o][i]
+        const int k = idx / (C * C), o = (idx / C) % C, i = idx % C;
+        ws[idx] = w[((int64_t)i * C + o) * (2 * R) + k];
+    }
+    f32x16 dwacc[KW];
+#pragma unroll
+    for (int t = 0; t < KW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dwacc[t][r] = 0.0f;
+    float dbacc = 0.0f;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_row, q0 = (tile - b * tiles_per_row) * Q;
+        __syncthreads();
+        for (int idx = tid; idx < C * (Q + 2); idx += 256) {
+            const int i = idx / (Q + 2), jj = idx - i * (Q + 2), j = q0 - 1 + jj;
+            as[i * ALD + jj] = (j >= 0 && j < Lin) ? x[((int64_t)b * C + i) * Lin + j] : 0.0f;      // RAW x: the mask needs its sign; activated on use
+        }
+        for (int idx = tid; idx < C * R * PLD; idx += 256) {      // columns (q0 - 1) r .. (q0 + Q + 1) r - 1, consecutive threads = consecutive columns
+            const int o = idx / (R * PLD), cc = idx - o * (R * PLD), qq = cc / R, ph = cc - qq * R, c = (q0 - 1 + qq) * R + ph;
+            ds[o * DLD + ph * PLD + qq] = (c >= 0 && c < Lout) ? dy[((int64_t)b * C + o) * Lout + c] : 0.0f;
+        }
+        __syncthreads();
+        // ---- this wave's taps: dW[.][.][k] += a^T-product over the tile's positions; db from the taps with qoff = 0 (each phase once)
+        f32x16 da[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) da[t][r] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < KW; ++t) {
+            const int k = wave * KW + t, m = k - P, qoff = (m >= 0) ? m / R : -1, ph = m - qoff * R;
+            const float *dp = ds + ph * PLD + 1 + qoff;                  // + o * DLD + j
+            // dW tile: rows i (A = a[i][j], lane = i), cols o (B = dy[o][..], lane = o), k-steps = positions j
+#pragma unroll 4
+            for (int s = 0; s < Q / 2; ++s) {
+                const int j = 2 * s + hi;
+                const float bv = dp[l31 * DLD + j];
+                if (qoff == 0) dbacc += bv;
+                dwacc[t] = mfma32(lrelu(as[l31 * ALD + 1 + j], 0.2f), bv, dwacc[t]);
+            }
+            // da partial: rows i (A = W[i][o][k] = ws[k][o][i]), cols j (B = dy[o][..][j + qoff]), k-steps = o
+#pragma unroll
+            for (int pt = 0; pt < NT; ++pt)
+#pragma unroll 4
+                for (int s = 0; s < 16; ++s) {
+                    const int o = 2 * s + hi;
+                    da[pt] = mfma32(ws[(k * C + o) * C + l31], dp[o * DLD + pt * 32 + l31], da[pt]);
+                }
+        }
+        __syncthreads();                                                  // every wave is done with the dy image
+        if (dx) {
+#pragma unroll
+            for (int pt = 0; pt < NT; ++pt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ds[((wave * NT + pt) * 32 + drow(r, hi)) * 32 + l31] = da[pt][r];
+            __syncthreads();
+            for (int idx = tid; idx < C * Q; idx += 256) {
+                const int i = idx / Q, jl = idx - i * Q, j = q0 + jl;
+                if (j < Lin) {
+                    const int e = ((jl >> 5) * 32 + i) * 32 + (jl & 31);
+                    const float v = (ds[e] + ds[NT * 1024 + e]) + (ds[2 * NT * 1024 + e] + ds[3 * NT * 1024 + e]);
+                    dx[((int64_t)b * C + i) * Lin + j] = v * dlrelu(as[i * ALD + 1 + jl], 0.2f);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the workgroup's partial: dW [i][o][k] (the torch layout of a ConvTranspose1d weight), then db [o]
+    float *pout = partial + (int64_t)blockIdx.x * (PW + C);
+#pragma unroll
+    for (int t = 0; t < KW; ++t) {
+        const int k = wave * KW + t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pout[((int64_t)drow(r, hi) * C + l31) * (2 * R) + k] = dwacc[t][r];
+    }
+    dbacc += __shfl_xor(dbacc, 32, 64);
+    float *red = smem;                                                    // (the weights are dead)
+    if (hi == 0) red[wave * C + l31] = dbacc;
+    __syncthreads();
+    if (tid < C) pout[PW + tid] = (red[tid] + red[C + tid]) + (red[2 * C + tid] + red[3 * C + tid]);
+}
+
 }  // namespace fdk_cconv
 
 namespace fdk {
@@ -482,6 +637,45 @@ hipError_t weight_norm_backward(const Launch &L_, const float *v, const float *g
                                 int64_t rows, int cols)
 {
     FD_LAUNCH(L_, "weight_norm_bwd", k_wn_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, v, g, norm, dw, dv, dg, rows, cols);
+    return hipSuccess;
+}
+
+// the block's up-sampler: leaky_relu(x, 0.2) -> ConvTranspose1d(32, 32, 2 r, stride r, padding r / 2), r = 4 or 8
+static int ct_grid(const Launch &L_, int r, int B, int64_t Lin)
+{
+    const int Q = 256 / r;
+    return (int)std::min<int64_t>((int64_t)B * ((Lin + Q - 1) / Q), (int64_t)L_.ctx->num_cus);
+}
+size_t convt_scratch_floats(const Launch &L_, int r, int B, int64_t Lin) { return (size_t)ct_grid(L_, r, B, Lin) * (2 * r * C * C + C); }
+
+hipError_t convt_forward(const Launch &L_, const float *x, const float *w, const float *bias, float *y, int B, int64_t Lin, int r)
+{
+    const int Q = 256 / r, tiles = (int)((Lin + Q - 1) / Q);
+    if (r == 4) FD_LAUNCH(L_, "convt_train_fwd", k_ct_fwd<4>, dim3(B * tiles), dim3(256), 0, x, w, bias, y, (int)Lin, tiles);
+    else if (r == 8) FD_LAUNCH(L_, "convt_train_fwd", k_ct_fwd<8>, dim3(B * tiles), dim3(256), 0, x, w, bias, y, (int)Lin, tiles);
+    else return hipErrorInvalidValue;
+    return hipSuccess;
+}
+
+hipError_t convt_backward(const Launch &L_, const float *x, const float *w, const float *dy, float *dx, float *dw, float *db, int B, int64_t Lin,
+                          int r, float *scratch)
+{
+    const int Q = 256 / r, tiles = (int)((Lin + Q - 1) / Q), ntiles = B * tiles, grid = ct_grid(L_, r, B, Lin);
+    const int pw = 2 * r * C * C;
+    if (r == 4) {
+        using G = CtCfg<4>;
+        const size_t shmem = sizeof(float) * (G::PW + C * G::ALD + C * G::DLD);
+        const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ct_bwd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (ea != hipSuccess) return ea;
+        FD_LAUNCH(L_, "convt_train_bwd", k_ct_bwd<4>, dim3(grid), dim3(256), shmem, x, w, dy, dx, scratch, (int)Lin, tiles, ntiles);
+    } else if (r == 8) {
+        using G = CtCfg<8>;
+        const size_t shmem = sizeof(float) * (G::PW + C * G::ALD + C * G::DLD);
+        const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ct_bwd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (ea != hipSuccess) return ea;
+        FD_LAUNCH(L_, "convt_train_bwd", k_ct_bwd<8>, dim3(grid), dim3(256), shmem, x, w, dy, dx, scratch, (int)Lin, tiles, ntiles);
+    } else return hipErrorInvalidValue;
+    if (dw || db) FD_LAUNCH(L_, "cconv_reduce", k_cconv_reduce, dim3((pw + C + 31) / 32), dim3(256), 0, (const float *)scratch, grid, pw + C, pw + C, pw, dw, db);
     return hipSuccess;
 }
 

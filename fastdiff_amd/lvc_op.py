@@ -241,6 +241,53 @@ def conv7(x, weight, bias):
     return _Conv7.apply(x, weight, bias, 0 if weight.shape[0] == 32 else 1)
 
 
+class _Upsample(torch.autograd.Function):
+    """`upsample(F.leaky_relu(x, 0.2))` of an LVC block (modules.py:163-166,205-206): activation + ConvTranspose1d(32, 32, 2 r, stride r,
+    padding r / 2) forward and backward on HIP kernels (fd_upsample_forward / fd_upsample_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, ratio):
+        ctx.in_dtypes = (x.dtype, weight.dtype, bias.dtype)
+        x, weight, bias = x.contiguous().float(), weight.contiguous().float(), bias.contiguous().float()
+        B, _, Lin = x.shape
+        y = torch.empty((B, 32, Lin * int(ratio)), device=x.device, dtype=torch.float32)
+        lib, h = _handle(x.device)
+        _capi.check(lib, h, lib.fd_upsample_forward(h, x.data_ptr(), weight.data_ptr(), bias.data_ptr(), B, Lin, int(ratio), y.data_ptr(), _stream(x.device)),
+                    "fd_upsample_forward")
+        ctx.save_for_backward(x, weight)
+        ctx.ratio = int(ratio)
+        return y.to(ctx.in_dtypes[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        B, _, Lin = x.shape
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
+        dx = torch.empty_like(x) if need_x else None
+        dw = torch.empty_like(weight) if need_w else None
+        db = torch.empty(32, device=x.device, dtype=torch.float32) if need_b else None
+        lib, h = _handle(x.device)
+        _capi.check(lib, h, lib.fd_upsample_backward(h, x.data_ptr(), weight.data_ptr(), dy.data_ptr(), B, Lin, ctx.ratio, None if dx is None else dx.data_ptr(),
+                                                     None if dw is None else dw.data_ptr(), None if db is None else db.data_ptr(), _stream(x.device)),
+                    "fd_upsample_backward")
+        tx, tw, tb = ctx.in_dtypes
+        return (None if dx is None else dx.to(tx), None if dw is None else dw.to(tw), None if db is None else db.to(tb), None)
+
+
+def upsample_supported(x, m):
+    """An LVC block's up-sampler as the model builds it: ConvTranspose1d(32, 32, 2 r, stride r, padding r / 2), r = 4 or 8, on a HIP tensor."""
+    r = m.stride[0]
+    return (x.is_cuda and x.dim() == 3 and x.shape[1] == 32 and isinstance(m, torch.nn.ConvTranspose1d) and r in (4, 8) and
+            tuple(m.weight.shape) == (32, 32, 2 * r) and m.padding == (r // 2,) and m.output_padding == (0,) and m.dilation == (1,))
+
+
+def upsample(x, weight, bias, ratio):
+    """conv_transpose1d(leaky_relu(x, 0.2), weight, bias, stride=ratio, padding=ratio // 2) for weight [32, 32, 2 * ratio] as a
+    differentiable HIP operator."""
+    return _Upsample.apply(x, weight, bias, ratio)
+
+
 class _WeightNorm(torch.autograd.Function):
     """w = torch._weight_norm(v, g, 0) (what torch.nn.utils.weight_norm's hook evaluates on every forward, FastDiff_model.py:115-122)
     as one HIP launch forward (fd_weight_norm_forward) and one backward (fd_weight_norm_backward)."""

@@ -57,7 +57,12 @@ def _dblock(p, x, cconv=None):
     and the same gradients (only the picked columns ever receive one).  cconv: the HIP operator for `layer(leaky_relu(x, 0.2))`."""
     size = x.shape[-1] // p.factor
     x = F.interpolate(x, size=size)
-    residual = _conv(p.residual_dense, x)
+    rd = p.residual_dense
+    if cconv is not None and rd.kernel_size == (1,) and rd.in_channels == rd.out_channels == 32 and cconv[1](x, torch.empty(32, 32, 3, device="meta"), 1):
+        # the 1 x 1 residual convolution as the centre tap of a 3-tap one (zeros either side) on the same HIP operator, no activations
+        residual = cconv[0](x, F.pad(_conv_weight(rd), (1, 1)), rd.bias, 1, pre_slope=1.0, post_slope=1.0)
+    else:
+        residual = _conv(rd, x)
     for layer in p.conv:
         if cconv is not None and cconv[1](x, layer.weight_v if hasattr(layer, "weight_v") else layer.weight, layer.dilation[0]):
             x = cconv[0](x, _conv_weight(layer), layer.bias, layer.dilation[0])
@@ -105,7 +110,12 @@ def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate, kconv=None,
     cond = c + p.fc_t(emb).unsqueeze(-1)
     (kernels, slots), bias = _kernel_predictor(p.kernel_predictor, cond, cfg["lvc_layers_each_block"], C, 2 * C, cfg["lvc_kernel_size"], kconv,
                                                split if kconv is not None else None)
-    x = p.upsample(F.leaky_relu(x, 0.2))
+    if cconv is not None and x.is_cuda:
+        from .lvc_op import upsample, upsample_supported
+    if cconv is not None and x.is_cuda and upsample_supported(x, p.upsample):
+        x = upsample(x, p.upsample.weight, p.upsample.bias, p.upsample.stride[0])      # leaky_relu + ConvTranspose1d in one HIP pass each way
+    else:
+        x = p.upsample(F.leaky_relu(x, 0.2))
     for i, conv in enumerate(p.convs):
         if cconv is not None and cconv[1](x, conv.weight_v if hasattr(conv, "weight_v") else conv.weight, conv.dilation[0]):
             # x += audio_down; leaky_relu; conv; leaky_relu (modules.py:209-212) in one HIP pass each way

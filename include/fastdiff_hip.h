@@ -205,6 +205,15 @@ FD_API int fd_conv7_forward(fd_handle h, int which, const float *x, const float 
 FD_API int fd_conv7_backward(fd_handle h, int which, const float *x, const float *weight, const float *dy, int B, int64_t L, float *dx,
                              float *dweight, float *dbias, void *stream);
 
+/* The block's up-sampler on the training path: `self.upsample(F.leaky_relu(x, 0.2))`, upsample = ConvTranspose1d(32, 32, 2 r, stride r,
+ * padding r / 2) (modules/FastDiff/module/modules.py:163-166,205-206), ratio r = 4 or 8:  x [B,32,Lin] -> y [B,32,Lin*r]; weight
+ * [32 in, 32 out, 2 r] (torch's ConvTranspose1d layout, no weight-norm), bias [32].  backward: from x, weight, dy it writes dx (the
+ * activation's mask applied), dweight, dbias (each nullable); sums in a fixed order. */
+FD_API int fd_upsample_forward(fd_handle h, const float *x, const float *weight, const float *bias, int B, int64_t Lin, int ratio, float *y,
+                               void *stream);
+FD_API int fd_upsample_backward(fd_handle h, const float *x, const float *weight, const float *dy, int B, int64_t Lin, int ratio, float *dx,
+                                float *dweight, float *dbias, void *stream);
+
 /* Weight-norm of the training path: every Conv1d of the model carries torch.nn.utils.weight_norm (FastDiff_model.py:71-72,115-122), i.e.
  * its forward evaluates w = torch._weight_norm(v, g, 0): w[r, :] = v[r, :] * g[r] / ||v[r, :]|| on the [rows = out channels, cols = in * k]
  * view.  forward also leaves ||v[r]|| in norm [rows] for the backward, which turns dw into dv [rows, cols] and dg [rows]. */

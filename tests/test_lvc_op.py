@@ -349,3 +349,34 @@ def test_lvc_operator_on_layer_slices_without_copies(hop, T):
     slices, slots = split_layers(kc)
     sum((fastdiff_amd.location_variable_convolution(xs[i], slices[i], bs[i], 1, hop, grad_slot=slots[i]) * ds[i]).sum() for i in range(3)).backward()
     assert torch.equal(kc.grad[:, :3], ka.grad[:, :3]) and not kc.grad[:, 3].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Lin,r", [(2, 100, 8), (3, 37, 8), (2, 130, 4), (1, 1, 4), (1, 2, 8), (2, 800, 8), (20, 6400, 4)])
+def test_upsample_operator_forward_and_backward_match_torch_autograd(B, Lin, r):
+    """fastdiff_amd.lvc_op.upsample = an LVC block's `self.upsample(F.leaky_relu(x, 0.2))` (modules.py:163-166,205-206: ConvTranspose1d(32,
+    32, 2 r, stride r, padding r / 2)) forward and its three gradients on HIP kernels, against torch in float64 (the training shape:
+    float32 on the GPU as the yardstick): tile edges (lengths that are not multiples of the 64 / 32-position tiles), one position."""
+    import torch.nn.functional as F
+    from fastdiff_amd.lvc_op import upsample
+    g = torch.Generator().manual_seed(100 * Lin + r)
+    x = torch.randn(B, 32, Lin, generator=g)
+    x[0, 0, 0] = 0.0                                                              # the activation's kink
+    w = torch.randn(32, 32, 2 * r, generator=g) / 8.0
+    bias = torch.randn(32, generator=g)
+    dy = torch.randn(B, 32, Lin * r, generator=g)
+    big = B * Lin * r > 100000
+    dt, dev = (torch.float32, "cuda") if big else (torch.float64, "cpu")
+    x64, w64, b64 = (t.to(dev, dt).requires_grad_(True) for t in (x, w, bias))
+    ref = F.conv_transpose1d(F.leaky_relu(x64, 0.2), w64, b64, stride=r, padding=r // 2)
+    ref.backward(dy.to(dev, dt))
+    xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, bias))
+    y = upsample(xg, wg, bg, r)
+    y.backward(dy.cuda())
+    rel = lambda got, want: float((got.double().cpu() - want.double().cpu()).abs().max()) / max(1.0, float(want.abs().max()))      # noqa: E731
+    tol = 2e-5 if big else 3e-6
+    assert y.shape == ref.shape and rel(y.detach(), ref.detach()) < tol
+    assert rel(xg.grad, x64.grad) < tol and rel(wg.grad, w64.grad) < tol and rel(bg.grad, b64.grad) < tol
+    x2, w2, b2 = (t.cuda().requires_grad_(True) for t in (x, w, bias))           # fixed-order sums: the same bits again
+    upsample(x2, w2, b2, r).backward(dy.cuda())
+    assert torch.equal(w2.grad, wg.grad) and torch.equal(b2.grad, bg.grad) and torch.equal(x2.grad, xg.grad)

@@ -94,7 +94,8 @@ def test_training_step_on_the_hip_operator_matches_the_reference_backward(monkey
     assert calls == [8] * 4 + [64] * 4 + [256] * 4                       # the twelve LVC calls went through the HIP operator
     # ... and the small convolutions through theirs: the DBlocks at 384 and 48 columns (the third one runs on 6 columns, not a multiple
     # of 4: torch), the twelve LVC-block layers with their skip add
-    assert convs == [(384, d, False) for d in (1, 2, 4)] + [(48, d, False) for d in (1, 2, 4)] + \
+    # (each DBlock: its 1 x 1 residual convolution first, as the centre tap of a 3-tap one, then the three dilated ones)
+    assert convs == [(384, d, False) for d in (1, 1, 2, 4)] + [(48, d, False) for d in (1, 1, 2, 4)] + \
                     [(L, 3 ** i, True) for L in (48, 384, 1536) for i in range(4)], convs
     gap = abs(float(g["loss_f32"]) - float(g["loss_f64"]))
     print("loss %.9f: |d| vs float64 reference %.2e (the float32 reference: %.2e)" % (loss.item(), abs(loss.item() - float(g["loss_f64"])), gap))
