@@ -839,7 +839,12 @@ static hipError_t run_step(const Launch &L, const StepIO &io, int B, int T)
     // option overlap = gemm: block 0's predicted kernels first, then [LVC block 0 || GEMM block 1] and [LVC block 1 || GEMM block 2]:
     // the matrix-bound GEMM next to the memory-bound layers instead of in front of them, and block 0's records read while fresh
     const bool overlap = !hoisted && c->overlap_gemm && c->fast[ST_KP_GEMM] && c->side_stream && fd_pipe(c, c->gemm_f16 && c->w.gemm_f16_ok, 0) != PIPE_F32_ONLY;
+    // option order = split: block 0's predicted kernels alone, then LVC block 0 (its records are then the last 0.7 GB written, not
+    // buried under blocks 1 and 2's 1.4 GB), then the GEMM of blocks 1 and 2 -- all on the one stream
+    const bool split = c->gemm_split && !hoisted && !pfirst && !overlap && c->fast[ST_KP_GEMM] && fd_pipe(c, c->gemm_f16 && c->w.gemm_f16_ok, 0) == PIPE_F16_ONLY;
     if (hoisted || pfirst) {
+    } else if (split) {
+        if ((e = fast_kp_gemm(L, B, T, 0, 1, 2)) != hipSuccess) return e;
     } else if (!overlap) {
         if ((e = kp_gemm(L, B, T)) != hipSuccess) return e;
     } else {
@@ -857,6 +862,7 @@ static hipError_t run_step(const Launch &L, const StepIO &io, int B, int T)
     for (int n = 0; n < fd::NBLK; ++n) {
         float *xo = nullptr;
         if (overlap && n > 0 && (e = hipStreamWaitEvent(L.stream, c->ev_join[n - 1], 0)) != hipSuccess) return e;
+        if (split && n == 1 && (e = fast_kp_gemm(L, B, T, 1, 2, 2)) != hipSuccess) return e;
         if ((e = lvc_block_run(L, n, x, B, T, &xo)) != hipSuccess) return e;
         x = xo;
     }
@@ -983,7 +989,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
 static unsigned mode_signature(const fd_context *h)
 {
     unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_f16 ? 2u : 0u) | (h->lvc_f16 ? 4u : 0u) | (h->conv_f16 ? 8u : 0u) | (h->step_lens ? 16u : 0u) |
-                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u) | (h->overlap_gemm ? 128u : 0u) | ((unsigned)h->overlap_wg << 8) | (h->overlap_paths ? 1024u : 0u) | ((unsigned)h->hoist_np << 11) | (h->predictor_first ? (1u << 20) : 0u) | (h->hoist_chunk ? (1u << 21) : 0u) | (h->fuse_up ? (1u << 22) : 0u) | (h->fuse_advance ? (1u << 23) : 0u) | (h->lvc_variant ? (1u << 24) : 0u) | ((unsigned)h->first_variant << 25);
+                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u) | (h->overlap_gemm ? 128u : 0u) | ((unsigned)h->overlap_wg << 8) | (h->overlap_paths ? 1024u : 0u) | ((unsigned)h->hoist_np << 11) | (h->predictor_first ? (1u << 20) : 0u) | (h->hoist_chunk ? (1u << 21) : 0u) | (h->fuse_up ? (1u << 22) : 0u) | (h->fuse_advance ? (1u << 23) : 0u) | (h->lvc_variant ? (1u << 24) : 0u) | ((unsigned)h->first_variant << 25) | (h->gemm_split ? (1u << 28) : 0u);
     for (int i = 0; i < ST_COUNT; ++i) s = (s << 1) | (h->fast[i] ? 1u : 0u);
     return s ^ (h->fp32_mask * 2654435761u);
 }
@@ -1848,9 +1854,10 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
         return FD_OK;
     }
     if (k == "order") {
-        if (v == "predictor") h->predictor_first = true;
-        else if (v == "down") h->predictor_first = false;
-        else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: order expects predictor|down, got '%s'", value);
+        if (v == "predictor") { h->predictor_first = true; h->gemm_split = false; }
+        else if (v == "down") { h->predictor_first = false; h->gemm_split = false; }
+        else if (v == "split") { h->predictor_first = false; h->gemm_split = true; }
+        else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: order expects predictor|down|split, got '%s'", value);
         drop_graph(h);
         return FD_OK;
     }

@@ -225,6 +225,7 @@ struct fd_context {
     bool overlap_gemm = false;
     bool overlap_paths = false;               // option overlap = paths: the down path next to the predictor (see run_step)
     int overlap_wg = 1;
+    bool gemm_split = false;                  // option order = split: GEMM(block 0), LVC block 0, GEMM(blocks 1, 2), LVC blocks 1, 2
     bool predictor_first = false;             // option order = down (default) | predictor: front + GEMM behind the down path or in front of it
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};

@@ -270,7 +270,8 @@ FD_API int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_sa
  *          layer (same bits; one launch and one round trip of x less per block: B = 1 -5 %, B = 8 -2.6 %);
  * "embed_cache" = "1" (default) | "0": keep the step-embedding rows of the last schedule between fd_sample calls (same t values and B);
  * "fuse_advance" = "1" (default) | "0": the end-of-step bookkeeping inside the next step's first kernel (one launch less per step);
- * "order" = "down" (default: the reference's order of statements) | "predictor" (front + GEMM first, so that the GEMM's 2 GB of
+ * "order" = "down" (default: the reference's order of statements) | "split" (GEMM of block 0, LVC block 0, GEMM of blocks 1 and 2, the
+ *          rest: measured 1 % slower) | "predictor" (front + GEMM first, so that the GEMM's 2 GB of
  *          stores drain under the DBlocks and not under the first LVC layers; same bits, measured +-0: INTEGRATION.md);
  * "taps" = "1" | "0" (keep block outputs for fd_read_tap). */
 FD_API int fd_set_option(fd_handle h, const char *key, const char *value);
