@@ -925,8 +925,12 @@ static int follow_stream(fd_handle h, hipStream_t s)
         const int rc = settle(h);
         if (rc != FD_OK) return rc;
         if (!h->ev_switch) FD_HIP(h, hipEventCreateWithFlags(&h->ev_switch, hipEventDisableTiming));
-        FD_HIP(h, hipEventRecord(h->ev_switch, h->last_stream));
-        FD_HIP(h, hipStreamWaitEvent(s, h->ev_switch, 0));
+        if (hipEventRecord(h->ev_switch, h->last_stream) == hipSuccess) {
+            FD_HIP(h, hipStreamWaitEvent(s, h->ev_switch, 0));
+        } else {                                     // the old stream is gone (destroyed by its owner): wait for the device instead
+            (void)hipGetLastError();
+            FD_HIP(h, hipDeviceSynchronize());
+        }
     }
     h->last_stream = s;
     h->have_last_stream = true;

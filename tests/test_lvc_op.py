@@ -318,6 +318,23 @@ def test_conv7_operators_forward_and_backward_match_torch_autograd(which, B, L):
     assert torch.equal(w2.grad, wg.grad) and torch.equal(b2.grad, bg.grad)  # fixed-order sums: the same bits
 
 
+def test_split_layers_node_on_the_cpu():
+    """lvc_op.split_layers (no HIP involved): the slices are views of the input, and when their gradients do NOT come back as slices of
+    the node's own buffer (anything but the HIP operator with its grad_slot) the node stacks them, zeros for an unused layer -- what
+    torch's unbind would return."""
+    from fastdiff_amd.lvc_op import split_layers
+    g = torch.Generator().manual_seed(3)
+    k = torch.randn(2, 4, 3, 5, 3, 7, generator=g, dtype=torch.float64).requires_grad_(True)
+    slices, slots = split_layers(k)
+    assert len(slices) == 4 and all(s_.data_ptr() == k[:, i].data_ptr() and tuple(s_.shape) == (2, 3, 5, 3, 7) for i, s_ in enumerate(slices))
+    assert [s_[1] for s_ in slots] == [0, 1, 2, 3] and all(s_[2] == tuple(k.shape) for s_ in slots)
+    w = [torch.randn(2, 3, 5, 3, 7, generator=g, dtype=torch.float64) for _ in range(3)]
+    sum((slices[i] * w[i]).sum() for i in range(3)).backward()
+    k2 = k.detach().clone().requires_grad_(True)
+    sum((k2.unbind(1)[i] * w[i]).sum() for i in range(3)).backward()
+    assert torch.equal(k.grad, k2.grad) and not k.grad[:, 3].any()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("hop,T", [(8, 37), (64, 100), (256, 12)])
 def test_lvc_operator_on_layer_slices_without_copies(hop, T):
