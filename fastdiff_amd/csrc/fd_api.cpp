@@ -1574,6 +1574,90 @@ int fd_kconv_backward(fd_handle h, const float *x, const float *weight, const fl
     return FD_OK;
 }
 
+// "frames": kernel_conv and the operator joined through frame-major tensors (include/fastdiff_hip.h)
+static int kconv_scratch_reserve(fd_handle h, int B, int M, int T)
+{
+    const size_t bytes = sizeof(float) * fdk::kconv_scratch_floats(B, M, T);
+    if (h->kconv_scratch_bytes < bytes) {
+        if (h->kconv_scratch) FD_HIP(h, hipFree(h->kconv_scratch));
+        h->kconv_scratch = nullptr; h->kconv_scratch_bytes = 0;
+        FD_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->kconv_scratch), bytes));
+        h->kconv_scratch_bytes = bytes;
+    }
+    return FD_OK;
+}
+
+int fd_kconv_forward_frames(fd_handle h, const float *x, const float *weight, const float *bias, int B, int M, int T, float *frames, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!x || !weight || !bias || !frames) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_forward_frames: null pointer");
+    if (B <= 0 || B > 65535) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_forward_frames: B=%d", B);
+    if (!fdk::kconv_frames_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_forward_frames: M=%d (a multiple of 6144) and T=%d (1..128) only", M, T);
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::kconv_forward(La, x, weight, bias, frames, B, M, T, true);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_kconv_forward_frames: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+int fd_kconv_backward_frames(fd_handle h, const float *x, const float *weight, const float *dframes, int B, int M, int T, float *dx,
+                             float *dweight, float *dbias, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!dframes || ((dweight || dbias) && !x) || (dx && !weight)) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward_frames: null pointer");
+    if (B <= 0 || B > 65535) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward_frames: B=%d", B);
+    if (!fdk::kconv_frames_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_backward_frames: M=%d (a multiple of 6144) and T=%d (1..128) only", M, T);
+    FD_HIP(h, hipSetDevice(h->device));
+    const int rc = kconv_scratch_reserve(h, B, M, T);
+    if (rc != FD_OK) return rc;
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::kconv_backward(La, x, weight, dframes, dx, dweight, dbias, B, M, T, h->kconv_scratch, true);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_kconv_backward_frames: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+static int check_frames_stride(fd_handle h, int64_t st, int T, const char *who)
+{
+    if (st < (int64_t)T * 6144 || st % 4 != 0) FD_FAIL(h, FD_ERR_INVALID, "%s: a frame stride of %lld floats (at least T * 6144, a multiple of 4)", who, (long long)st);
+    return FD_OK;
+}
+
+int fd_lvc_forward_frames(fd_handle h, const float *x, const float *kernel_frames, int64_t kernel_bstride, const float *bias, int B, int T, int hop,
+                          float *out, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!x || !kernel_frames || !bias || !out) FD_FAIL(h, FD_ERR_INVALID, "fd_lvc_forward_frames: null pointer");
+    int rc = check_lvc_op(h, B, 32, 64, 3, T, hop, "fd_lvc_forward_frames");
+    if (rc != FD_OK) return rc;
+    if (!fdk::lvc_op_needs_scratch(32, 64, 3, hop)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_lvc_forward_frames: hop 8 / 64 / 256 only, got %d", hop);
+    if ((rc = check_frames_stride(h, kernel_bstride, T, "fd_lvc_forward_frames")) != FD_OK) return rc;
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch L = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::lvc_op_forward(L, x, kernel_frames, bias, out, B, 32, 64, 3, T, hop, nullptr, kernel_bstride, true);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_lvc_forward_frames: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+int fd_lvc_backward_frames(fd_handle h, const float *x, const float *kernel_frames, int64_t kernel_bstride, const float *dout, int B, int T,
+                           int hop, float *dx, float *dkernel_frames, int64_t dkernel_bstride, float *dbias, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!dout || ((dkernel_frames || dbias) && !x) || (dx && !kernel_frames)) FD_FAIL(h, FD_ERR_INVALID, "fd_lvc_backward_frames: null pointer");
+    int rc = check_lvc_op(h, B, 32, 64, 3, T, hop, "fd_lvc_backward_frames");
+    if (rc != FD_OK) return rc;
+    if (!fdk::lvc_op_needs_scratch(32, 64, 3, hop)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_lvc_backward_frames: hop 8 / 64 / 256 only, got %d", hop);
+    if (dx && (rc = check_frames_stride(h, kernel_bstride, T, "fd_lvc_backward_frames")) != FD_OK) return rc;
+    if (dkernel_frames && (rc = check_frames_stride(h, dkernel_bstride, T, "fd_lvc_backward_frames")) != FD_OK) return rc;
+    FD_HIP(h, hipSetDevice(h->device));
+    float *scratch = nullptr;
+    if ((rc = lvc_scratch(h, B, 32, 64, 3, T, hop, &scratch)) != FD_OK) return rc;      // the dx kernel's operand order
+    fdk::Launch L = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::lvc_op_backward(L, x, kernel_frames, dout, dx, dkernel_frames, dbias, B, 32, 64, 3, T, hop, scratch, kernel_bstride,
+                                        dkernel_bstride, true);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_lvc_backward_frames: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
 static int cconv_scratch_reserve(fd_handle h, size_t floats)
 {
     const size_t bytes = sizeof(float) * floats;

@@ -26,10 +26,12 @@ hipError_t fast_final(const Launch &L, const StepIO &io, const float *x32, int B
 bool lvc_op_needs_scratch(int Cin, int Cout, int ks, int hop);
 // kbs / dkbs: floats between two utterances of K / dK (0 = a tensor of its own; the model's shape also takes one layer's slice of a
 // [B, layers, Cin, Cout, ks, T] tensor)
+// frames (the model's shape): K / dK are frame-major ([T][6144] per utterance, fd_frame_order.h: K in ORDER_FWD, dK in ORDER_DK) as
+// kconv_forward / kconv_backward with frames = true write / read them; kbs / dkbs are then the floats between two utterances of those
 hipError_t lvc_op_forward(const Launch &L, const float *x, const float *K, const float *bias, float *out, int B, int Cin, int Cout, int ks,
-                          int T, int hop, float *scratch, int64_t kbs = 0);
+                          int T, int hop, float *scratch, int64_t kbs = 0, bool frames = false);
 hipError_t lvc_op_backward(const Launch &L, const float *x, const float *K, const float *dout, float *dx, float *dK, float *dbias, int B,
-                           int Cin, int Cout, int ks, int T, int hop, float *scratch, int64_t kbs = 0, int64_t dkbs = 0);
+                           int Cin, int Cout, int ks, int T, int hop, float *scratch, int64_t kbs = 0, int64_t dkbs = 0, bool frames = false);
 // the gate + residual of an LVC layer, one pass forward and one backward (modules.py:217)
 hipError_t gate_forward(const Launch &L, const float *x, const float *y, float *out, int B, int C, int64_t len);
 hipError_t gate_backward(const Launch &L, const float *y, const float *dout, float *dy, int B, int C, int64_t len);
@@ -37,9 +39,13 @@ hipError_t gate_backward(const Launch &L, const float *y, const float *dout, flo
 // scratch: kconv_scratch_floats(B, M, T) floats for the backward's partial sums
 bool kconv_supported(int M, int T);
 size_t kconv_scratch_floats(int B, int M, int T);
-hipError_t kconv_forward(const Launch &L, const float *h, const float *W, const float *bias, float *out, int B, int M, int T);
+// frames (M a multiple of 6144 = M / 6144 layers of the LVC operator's kernels): out is [B][layers][T][6144] with every frame in the
+// operator's forward operand order, dout the same shape in its dK accumulator order (fd_frame_order.h) -- the LVC kernels then read /
+// write the predictor's tensors where they lie
+bool kconv_frames_supported(int M, int T);
+hipError_t kconv_forward(const Launch &L, const float *h, const float *W, const float *bias, float *out, int B, int M, int T, bool frames = false);
 hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const float *dout, float *dh, float *dW, float *dbias, int B, int M,
-                          int T, float *scratch);
+                          int T, float *scratch, bool frames = false);
 // one layer's "x (+ skip) -> leaky_relu -> dilated Conv1d(32 -> 32, k3) -> bias -> (leaky_relu)" forward and backward for the training
 // path (fd_kernels_cconv.hip); scratch: cconv_scratch_floats() floats for the per-workgroup partial sums of dW / db
 bool cconv_supported(int dil, int64_t len);

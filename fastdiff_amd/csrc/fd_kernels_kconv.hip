@@ -18,6 +18,7 @@
 #include <algorithm>
 
 #include "fd_kernels.h"
+#include "fd_frame_order.h"
 
 namespace fdk_kconv {
 
@@ -46,7 +47,21 @@ __device__ __forceinline__ void zero_h(float *__restrict__ hs, int tid)      // 
     for (int idx = tid; idx < CI * LD; idx += 256) hs[idx] = 0.0f;
 }
 
+// FRAMES (the "frames" entry points; M = layers x 6144): the rows of a 32-row group are not consecutive rows of W but the 32 rows whose
+// coefficients lie next to each other in a frame of the LVC operator (group g of layer y: positions 32 g .. 32 g + 31 of the frame, row
+// y * 6144 + row_of<ORDER>(position)), and the tensor on the other side is [B][layers][T][6144].  A lane's weight row is 768 B of its own
+// either way, so the gather costs nothing.
+template <int ORDER>
+__device__ __forceinline__ int frame_row(int p0, int j)      // p0 = 32 x (group index over all layers), j = 0 .. 31
+{
+    const int layer = p0 / fdk_order::ME, e0 = p0 - layer * fdk_order::ME;
+    return layer * fdk_order::ME + fdk_order::row_of<ORDER>(e0 + j);
+}
+
 // ---- forward: workgroup = 128 output rows (wave = 32 rows, weights in 96 registers) x a range of utterances ------------------------
+// FRAMES: the operands change sides -- A = the h window (lane = t), B = W (lane = row) -- so that the accumulators hold out[t][row]
+// with the lanes along the rows: one 128 B line of a frame per store.
+template <bool FRAMES>
 __global__ void __launch_bounds__(256, 2) k_kc_fwd(const float *__restrict__ h, const float *__restrict__ W, const float *__restrict__ bias,
                                                    float *__restrict__ out, int B, int M, int T, int bchunk)
 {
@@ -57,15 +72,19 @@ __global__ void __launch_bounds__(256, 2) k_kc_fwd(const float *__restrict__ h, 
     // reduction index of step s in lane half hi: 96 hi + s = c * 3 + tap, i.e. the halves split the input channels (32 each):
     // A = 24 aligned float4 of the lane's weight row, B = hs[(32 hi + s / 3) * LD + s % 3 + t]: one base register + an immediate
     const bool live = p0 < M;      // M a multiple of 32, not necessarily of 128: the last workgroup's waves beyond M only stage and wait
+    const int prow = !live ? 0 : FRAMES ? frame_row<fdk_order::ORDER_FWD>(p0, l31) : p0 + l31;      // this lane's row of W
     float4 a[24];
     {
-        const float4 *wp = reinterpret_cast<const float4 *>(W + (int64_t)(live ? p0 + l31 : 0) * KK) + 24 * hi;
+        const float4 *wp = reinterpret_cast<const float4 *>(W + (int64_t)prow * KK) + 24 * hi;
 #pragma unroll
         for (int q = 0; q < 24; ++q) a[q] = wp[q];
     }
-    float bz[16];
+    float bz[FRAMES ? 1 : 16];
+    if constexpr (FRAMES) bz[0] = bias[prow];
+    else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bz[r] = bias[live ? p0 + drow(r, hi) : 0];
+        for (int r = 0; r < 16; ++r) bz[r] = bias[live ? p0 + drow(r, hi) : 0];
+    }
     const int nct = (T + 31) / 32;                      // <= 4 (T <= 128)
     const float *hb = hs + hi * 32 * LD + l31;
     zero_h(hs, tid);
@@ -81,25 +100,43 @@ __global__ void __launch_bounds__(256, 2) k_kc_fwd(const float *__restrict__ h, 
         for (int ct = 0; ct < 4; ++ct) {
             if (ct < nct) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[ct][r] = bz[r];
+                for (int r = 0; r < 16; ++r) acc[ct][r] = bz[FRAMES ? 0 : r];
 #pragma unroll
-                for (int s = 0; s < 96; ++s)      // h[c, t + tap - 1] = hs[c][t + tap]; columns behind the utterance read zeros
-                    acc[ct] = mfma32(f4c(a[s >> 2], s & 3), hb[(s / 3) * LD + (s % 3) + ct * 32], acc[ct]);
+                for (int s = 0; s < 96; ++s) {    // h[c, t + tap - 1] = hs[c][t + tap]; columns behind the utterance read zeros
+                    const float wv = f4c(a[s >> 2], s & 3), hv = hb[(s / 3) * LD + (s % 3) + ct * 32];
+                    acc[ct] = FRAMES ? mfma32(hv, wv, acc[ct]) : mfma32(wv, hv, acc[ct]);
+                }
             }
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float *orow = out + ((int64_t)b * M + p0 + drow(r, hi)) * T;
+        if constexpr (FRAMES) {      // acc[ct][r] = out[t = 32 ct + drow(r, hi)][row of lane l31]
+            // address = (wave-uniform frame base + a constant per (ct, r)) + a 32-bit lane offset: no address registers per store
+            const int layer = p0 / fdk_order::ME, e0 = p0 - layer * fdk_order::ME, nl = M / fdk_order::ME;
+            float *fu = out + ((int64_t)(b * nl + layer) * T) * fdk_order::ME + e0;
+            const int lane_off = 4 * hi * fdk_order::ME + l31;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct)
-                if (ct < nct && ct * 32 + l31 < T) orow[ct * 32 + l31] = acc[ct][r];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int tu = ct * 32 + (r & 3) + 8 * (r >> 2);      // t = tu + 4 hi
+                    if (ct < nct && tu + 4 * hi < T) fu[tu * fdk_order::ME + lane_off] = acc[ct][r];
+                }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float *orow = out + ((int64_t)b * M + p0 + drow(r, hi)) * T;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    if (ct < nct && ct * 32 + l31 < T) orow[ct * 32 + l31] = acc[ct][r];
+            }
         }
     }
 }
 
 // ---- dW and dbias: workgroup = 128 rows p (wave = 32 rows), all 192 columns (c, k) in six accumulator tiles, reduction over every
 //      (b, t); the A operand (dout) comes straight from global memory, one float4 = four reduction steps per lane -------------------
-template <bool ALIGNED>
+// FRAMES: dout is [B][layers][T][6144] in the dK accumulator order; a lane's row is then 6144 floats apart from t to t + 1 (one dword
+// per step and lane, 128 B per half-wave) instead of one float4 per four steps.
+template <bool ALIGNED, bool FRAMES>
 __global__ void __launch_bounds__(256, 2) k_kc_dw(const float *__restrict__ h, const float *__restrict__ dout, float *__restrict__ part,
                                                   int B, int M, int T, int bchunk)
 {
@@ -125,17 +162,30 @@ __global__ void __launch_bounds__(256, 2) k_kc_dw(const float *__restrict__ h, c
     float accb = 0.0f;
     const int nq = (T + 7) / 8;                    // <= 16
     const bool live = p0 < M;                      // (M a multiple of 32: see k_kc_fwd)
+    const int layer = p0 / fdk_order::ME, e0 = p0 - layer * fdk_order::ME, nl = M / fdk_order::ME;      // (FRAMES)
     zero_h(hs, tid);
     for (int b = b0; b < b1; ++b) {
         // this lane's row of dout: all of it is requested before h is staged, so the loads fly during the staging and the barriers
-        const float *dr = dout + ((int64_t)b * M + (live ? p0 + l31 : 0)) * T;
         float4 dv[16];
+        if constexpr (FRAMES) {      // (wave-uniform frame base + a constant per step) + a 32-bit lane offset
+            const float *du = dout + ((int64_t)(b * nl + (live ? layer : 0)) * T) * fdk_order::ME + (live ? e0 : 0);
+            const int lane_off = 4 * hi * fdk_order::ME + l31;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int t0 = 8 * q + 4 * hi;
-            if (q < nq) {
-                if (ALIGNED && t0 + 3 < T) dv[q] = *reinterpret_cast<const float4 *>(dr + t0);
-                else dv[q] = make_float4(t0 < T ? dr[t0] : 0.0f, t0 + 1 < T ? dr[t0 + 1] : 0.0f, t0 + 2 < T ? dr[t0 + 2] : 0.0f, t0 + 3 < T ? dr[t0 + 3] : 0.0f);
+            for (int q = 0; q < 16; ++q) {
+                const int t0 = 8 * q + 4 * hi;
+                if (q < nq)
+                    dv[q] = make_float4(t0 < T ? du[(8 * q) * fdk_order::ME + lane_off] : 0.0f, t0 + 1 < T ? du[(8 * q + 1) * fdk_order::ME + lane_off] : 0.0f,
+                                        t0 + 2 < T ? du[(8 * q + 2) * fdk_order::ME + lane_off] : 0.0f, t0 + 3 < T ? du[(8 * q + 3) * fdk_order::ME + lane_off] : 0.0f);
+            }
+        } else {
+            const float *dr = dout + ((int64_t)b * M + (live ? p0 + l31 : 0)) * T;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int t0 = 8 * q + 4 * hi;
+                if (q < nq) {
+                    if (ALIGNED && t0 + 3 < T) dv[q] = *reinterpret_cast<const float4 *>(dr + t0);
+                    else dv[q] = make_float4(t0 < T ? dr[t0] : 0.0f, t0 + 1 < T ? dr[t0 + 1] : 0.0f, t0 + 2 < T ? dr[t0 + 2] : 0.0f, t0 + 3 < T ? dr[t0 + 3] : 0.0f);
+                }
             }
         }
         __syncthreads();
@@ -159,11 +209,13 @@ __global__ void __launch_bounds__(256, 2) k_kc_dw(const float *__restrict__ h, c
     // partial sums of this utterance range: [range][M][192] and, behind them, [range][M] for the bias
     float *pw = part + (int64_t)blockIdx.y * M * KK;
 #pragma unroll
-    for (int ct = 0; ct < 6; ++ct)
+    for (int r = 0; r < 16; ++r) {
+        const int prow = FRAMES ? frame_row<fdk_order::ORDER_DK>(p0, drow(r, hi)) : p0 + drow(r, hi);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pw[(int64_t)(p0 + drow(r, hi)) * KK + ct * 32 + l31] = acc[ct][r];
+        for (int ct = 0; ct < 6; ++ct) pw[(int64_t)prow * KK + ct * 32 + l31] = acc[ct][r];
+    }
     accb += __shfl_xor(accb, 32, 64);
-    if (hi == 0) part[(int64_t)gridDim.y * M * KK + (int64_t)blockIdx.y * M + p0 + l31] = accb;
+    if (hi == 0) part[(int64_t)gridDim.y * M * KK + (int64_t)blockIdx.y * M + (FRAMES ? frame_row<fdk_order::ORDER_DK>(p0, l31) : p0 + l31)] = accb;
 }
 
 // the utterance ranges added up in a fixed order: dW [M][192] and dbias [M] (either may be null)
@@ -283,6 +335,9 @@ __global__ void __launch_bounds__(256, 2) k_kcs_dw(const float *__restrict__ h, 
 
 // ---- dh, first pass: workgroup = (slice of the rows p, utterance b): G_part[(c,k), t] = sum over the slice of W[p,(c,k)] dout[b,p,t];
 //      wave = one 32-column tile of t (T <= 128), all six 32-row tiles of (c,k); W and dout go through LDS 32 rows at a time ----------
+// FRAMES: a chunk is one 32-row group of a layer's frame order: its rows of W are gathered (768 B each), its piece of dout is 32
+// consecutive floats of every frame of the utterance.
+template <bool FRAMES>
 __global__ void __launch_bounds__(256, 2) k_kc_dh(const float *__restrict__ W, const float *__restrict__ dout, float *__restrict__ part,
                                                   int B, int M, int T, int prows)
 {
@@ -305,12 +360,27 @@ __global__ void __launch_bounds__(256, 2) k_kc_dh(const float *__restrict__ W, c
     float dvv[16];
     const int nd = (32 * T + 255) / 256;          // <= 16
     auto load_chunk = [&](int pc) {
+        if constexpr (FRAMES) {
+            const int layer = pc / fdk_order::ME, e0 = pc - layer * fdk_order::ME, nl = M / fdk_order::ME;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) wv[k] = reinterpret_cast<const f4n *>(W + (int64_t)pc * KK)[k * 256 + tid];
+            for (int k = 0; k < 6; ++k) {      // row j of the chunk = 48 float4
+                const int idx = k * 256 + tid, j = idx / 48, c4 = idx - j * 48;
+                wv[k] = reinterpret_cast<const f4n *>(W + (int64_t)frame_row<fdk_order::ORDER_DK>(pc, j) * KK)[c4];
+            }
+            const float *dr = dout + ((int64_t)(b * nl + layer) * T) * fdk_order::ME + e0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int idx = k * 256 + tid;
-            if (k < nd) dvv[k] = idx < 32 * T ? dout[((int64_t)b * M + pc + idx / T) * T + idx % T] : 0.0f;
+            for (int k = 0; k < 16; ++k) {      // (t, j): 32 consecutive floats per frame
+                const int idx = k * 256 + tid;
+                if (k < nd) dvv[k] = idx < 32 * T ? dr[(int64_t)(idx >> 5) * fdk_order::ME + (idx & 31)] : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wv[k] = reinterpret_cast<const f4n *>(W + (int64_t)pc * KK)[k * 256 + tid];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int idx = k * 256 + tid;
+                if (k < nd) dvv[k] = idx < 32 * T ? dout[((int64_t)b * M + pc + idx / T) * T + idx % T] : 0.0f;
+            }
         }
     };
     load_chunk(pbeg);
@@ -321,7 +391,10 @@ __global__ void __launch_bounds__(256, 2) k_kc_dh(const float *__restrict__ W, c
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int idx = k * 256 + tid;
-            if (k < nd && idx < 32 * T) dsm[(idx / T) * LDD + idx % T] = dvv[k];
+            if (k < nd && idx < 32 * T) {
+                if constexpr (FRAMES) dsm[(idx & 31) * LDD + (idx >> 5)] = dvv[k];
+                else dsm[(idx / T) * LDD + idx % T] = dvv[k];
+            }
         }
         __syncthreads();
         if (pc + 32 < pbeg + prows) load_chunk(pc + 32);
@@ -367,6 +440,7 @@ namespace fdk {
 using namespace fdk_kconv;
 
 bool kconv_supported(int M, int T) { return M > 0 && M % 32 == 0 && T >= 1 && T <= 128; }
+bool kconv_frames_supported(int M, int T) { return kconv_supported(M, T) && M % fdk_order::ME == 0 && M > 512; }
 
 // How many ranges to cut `units` (utterances / row chunks) into when `per_range` workgroups work on each range: the CUs take the
 // workgroups in turn, so the launch lasts (workgroups per CU) x (units per range); the smallest product wins, then the fewest ranges.
@@ -388,21 +462,24 @@ size_t kconv_scratch_floats(int B, int M, int T)
     return (size_t)KC_DH_SLICES * B * KK * T + (size_t)(M <= KC_SMALL_M ? std::max(B, KC_DW_RANGES) : KC_DW_RANGES) * M * (KK + 1);
 }
 
-hipError_t kconv_forward(const Launch &L, const float *h, const float *W, const float *bias, float *out, int B, int M, int T)
+hipError_t kconv_forward(const Launch &L, const float *h, const float *W, const float *bias, float *out, int B, int M, int T, bool frames)
 {
+    if (frames && !kconv_frames_supported(M, T)) return hipErrorInvalidValue;
     if (M <= KC_SMALL_M) {
         FD_LAUNCH(L, "kconv_forward_small", k_kcs_fwd, dim3(B, (M + 63) / 64), dim3(256), 0, h, W, bias, out, B, M, T);
         return hipSuccess;
     }
     const int gx = (M + 127) / 128;
     const int ny0 = pick_ranges(gx, B, 16, L.ctx->num_cus), bchunk = (B + ny0 - 1) / ny0, ny = (B + bchunk - 1) / bchunk;
-    FD_LAUNCH(L, "kconv_forward", k_kc_fwd, dim3(gx, ny), dim3(256), 0, h, W, bias, out, B, M, T, bchunk);
+    if (frames) FD_LAUNCH(L, "kconv_forward", k_kc_fwd<true>, dim3(gx, ny), dim3(256), 0, h, W, bias, out, B, M, T, bchunk);
+    else FD_LAUNCH(L, "kconv_forward", k_kc_fwd<false>, dim3(gx, ny), dim3(256), 0, h, W, bias, out, B, M, T, bchunk);
     return hipSuccess;
 }
 
 hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const float *dout, float *dh, float *dW, float *dbias, int B, int M,
-                          int T, float *scratch)
+                          int T, float *scratch, bool frames)
 {
+    if (frames && !kconv_frames_supported(M, T)) return hipErrorInvalidValue;
     float *part_h = scratch, *part_w = scratch + (size_t)KC_DH_SLICES * B * KK * T;
     if ((dW || dbias) && M <= KC_SMALL_M) {
         if (T % 4 == 0) FD_LAUNCH(L, "kconv_backward_w_small", k_kcs_dw<true>, dim3(B, (M + 63) / 64), dim3(256), 0, h, dout, part_w, B, M, T);
@@ -412,8 +489,9 @@ hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const
     } else if (dW || dbias) {
         const int gx = (M + 127) / 128;
         const int ny0 = pick_ranges(gx, B, KC_DW_RANGES, L.ctx->num_cus), bchunk = (B + ny0 - 1) / ny0, ny = (B + bchunk - 1) / bchunk;
-        if (T % 4 == 0) FD_LAUNCH(L, "kconv_backward_w", k_kc_dw<true>, dim3(gx, ny), dim3(256), 0, h, dout, part_w, B, M, T, bchunk);
-        else FD_LAUNCH(L, "kconv_backward_w", k_kc_dw<false>, dim3(gx, ny), dim3(256), 0, h, dout, part_w, B, M, T, bchunk);
+        if (frames) FD_LAUNCH(L, "kconv_backward_w", (k_kc_dw<false, true>), dim3(gx, ny), dim3(256), 0, h, dout, part_w, B, M, T, bchunk);
+        else if (T % 4 == 0) FD_LAUNCH(L, "kconv_backward_w", (k_kc_dw<true, false>), dim3(gx, ny), dim3(256), 0, h, dout, part_w, B, M, T, bchunk);
+        else FD_LAUNCH(L, "kconv_backward_w", (k_kc_dw<false, false>), dim3(gx, ny), dim3(256), 0, h, dout, part_w, B, M, T, bchunk);
         FD_LAUNCH(L, "kconv_backward_w_sum", k_kc_dw_sum, dim3((unsigned)(((int64_t)M * (KK + 1) + 255) / 256)), dim3(256), 0, (const float *)part_w, dW,
                   dbias, M, ny);
     }
@@ -425,7 +503,8 @@ hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const
             const int64_t cost = (int64_t)(((int64_t)n * B + L.ctx->num_cus - 1) / L.ctx->num_cus) * (chunks / n);
             if (cost < best) { best = cost; nks = n; }
         }
-        FD_LAUNCH(L, "kconv_backward_h", k_kc_dh, dim3(nks, B), dim3(256), 0, W, dout, part_h, B, M, T, M / nks);
+        if (frames) FD_LAUNCH(L, "kconv_backward_h", k_kc_dh<true>, dim3(nks, B), dim3(256), 0, W, dout, part_h, B, M, T, M / nks);
+        else FD_LAUNCH(L, "kconv_backward_h", k_kc_dh<false>, dim3(nks, B), dim3(256), 0, W, dout, part_h, B, M, T, M / nks);
         FD_LAUNCH(L, "kconv_backward_h_fold", k_kc_dh_fold, dim3((B * CI * T + 255) / 256), dim3(256), 0, (const float *)part_h, dh, B, T, nks);
     }
     return hipSuccess;

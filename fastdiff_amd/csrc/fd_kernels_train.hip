@@ -15,6 +15,7 @@
 // layout and a second transpose puts it back.  The scratch buffer of B*T*6144 floats comes from the caller (fd_api.cpp).
 // Any other shape takes the plain one-thread-per-output VALU kernels at the end of the file.
 #include "fd_kernels.h"
+#include "fd_frame_order.h"
 
 namespace fdk_train {
 
@@ -24,28 +25,7 @@ __device__ __forceinline__ float f4c(const float4 &v, int i) { return i == 0 ? v
 // D layout of the 32x32 tile: register r of lane (col = lane & 31, hi = lane >> 5) is row (r & 3) + 8 (r >> 2) + 4 hi
 __device__ __forceinline__ int drow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-constexpr int MI = 32, MO = 64, MK = 3, ME = MI * MO * MK;      // the model's operator: 6144 coefficients per frame
-
-// Frame-major orders: position e of a frame's 6144 floats -> row (i*64 + o)*3 + k of the reference layout [B, Cin, Cout, ks, T].
-// e = (group*64 + lane)*4 + j: the float4 a lane loads covers four consecutive k-steps (j) of one 32x32x2 operand column.
-enum { ORDER_FWD = 0, ORDER_DX = 1, ORDER_DK = 2 };
-template <int ORDER>
-__device__ __forceinline__ int row_of(int e)
-{
-    const int j = e & 3, lane = (e >> 2) & 63, grp = e >> 8, l31 = lane & 31, hi = lane >> 5;
-    int i, o, k;
-    if (ORDER == ORDER_FWD) {          // A[o][tap*32 + i]: grp = mt*12 + sq, k index = 2 (4 sq + j) + hi
-        const int mt = grp / 12, sq = grp - 12 * mt, kidx = 2 * (4 * sq + j) + hi;
-        o = 32 * mt + l31; k = kidx >> 5; i = kidx & 31;
-    } else if (ORDER == ORDER_DX) {    // A[i][tap*64 + o]: grp = sq (24), k index = 2 (4 sq + j) + hi
-        const int kidx = 2 * (4 * grp + j) + hi;
-        i = l31; k = kidx >> 6; o = kidx & 63;
-    } else {                           // the dK accumulators: grp = ((mt*3 + tap)*4 + g), rows 32 mt + 8 g + 4 hi + j, column i
-        const int g = grp & 3, t6 = grp >> 2, mt = t6 / 3;
-        k = t6 - 3 * mt; o = 32 * mt + 8 * g + 4 * hi + j; i = l31;
-    }
-    return (i * MO + o) * MK + k;
-}
+using namespace fdk_order;      // MI, MO, MK, ME, ORDER_*, row_of (fd_frame_order.h)
 
 // K [B][6144 rows][T] -> frame-major [B][T][6144] in ORDER (64 x 64 tiles through LDS, both sides coalesced).  kbs: floats between two
 // utterances of K (6144 T for a tensor of its own; 4 x that for one layer's slice of the predictor's [B, 4, 32, 64, 3, T] output)
@@ -83,6 +63,24 @@ __global__ void __launch_bounds__(256) k_lvc_unpack(const float *__restrict__ Kf
         const int el = w * 16 + r, l = l0 + lane;
         if (l < T) K[(int64_t)b * kbs + (int64_t)row_of<ORDER_DK>(e0 + el) * T + l] = tile[lane][el];
     }
+}
+
+// frame-major ORDER_FWD (the "frames" entry points: what kernel_conv wrote) -> frame-major ORDER_DX for the dx kernel: a permutation
+// inside each frame's 24 KB (gathered reads that stay in the L1 / L2 lines of the frame, coalesced writes).  kbs: floats between two
+// utterances of the source.
+__global__ void __launch_bounds__(256) k_lvc_reorder_dx(const float *__restrict__ Kf, float *__restrict__ Kx, int T, int64_t kbs)
+{
+    const int l = blockIdx.x, b = blockIdx.y;
+    const float *src = Kf + (int64_t)b * kbs + (int64_t)l * ME;
+    float *dst = Kx + ((int64_t)b * T + l) * ME;
+    float v[ME / 256];
+#pragma unroll
+    for (int r = 0; r < ME / 256; ++r) {
+        const int row = row_of<ORDER_DX>(r * 256 + threadIdx.x), k = row % MK, io = row / MK;
+        v[r] = src[fwd_pos_of(io / MO, io % MO, k)];
+    }
+#pragma unroll
+    for (int r = 0; r < ME / 256; ++r) dst[r * 256 + threadIdx.x] = v[r];
 }
 
 // Work split of the forward and dx kernels.  Workgroup = 256 threads = W columns: hop 256: one frame, hop 64: four frames, hop 8: four
@@ -125,7 +123,8 @@ __device__ __forceinline__ void stage_rows(float *__restrict__ lds, const float 
 
 template <int HOP>
 __global__ void __launch_bounds__(256, HOP == 256 ? 3 : 2) k_lvc_fwd_mfma(const float *__restrict__ x, const float *__restrict__ Kf,
-                                                                        const float *__restrict__ bias, float *__restrict__ out, int T)
+                                                                        const float *__restrict__ bias, float *__restrict__ out, int T,
+                                                                        int64_t kfs)      // kfs: floats between two utterances of Kf
 {
     using G = LvcGeo<HOP>;
     constexpr int W = G::W, LD = G::LD, NMT = HOP == 256 ? 1 : 2, NCT = HOP == 256 ? 4 : (HOP == 64 ? 2 : 1);
@@ -138,7 +137,7 @@ __global__ void __launch_bounds__(256, HOP == 256 ? 3 : 2) k_lvc_fwd_mfma(const 
     const bool wave_valid = f < T;
     float4 a[NMT][12];
     if (wave_valid) {
-        const float4 *ap = reinterpret_cast<const float4 *>(Kf + ((int64_t)b * T + f) * ME);
+        const float4 *ap = reinterpret_cast<const float4 *>(Kf + (int64_t)b * kfs + (int64_t)f * ME);
 #pragma unroll
         for (int m = 0; m < NMT; ++m)
 #pragma unroll
@@ -264,7 +263,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_dx_mfma(const float *__restrict_
 // under the current chunk's matrix work.  dK stays frame-major (ORDER_DK).
 template <int CH>
 __global__ void __launch_bounds__(192) k_lvc_dk_mfma(const float *__restrict__ x, const float *__restrict__ dout, float *__restrict__ dKf,
-                                                     float *__restrict__ dbias, int T, int hop)
+                                                     float *__restrict__ dbias, int T, int hop, int64_t dkfs)      // dkfs: floats between two utterances of dKf
 {
     constexpr int DLD = CH + 1, XLD = CH + 3, C4 = CH / 4;
     constexpr int ND = (MO * C4 + 191) / 192, NX = (MI * C4 + 191) / 192;
@@ -330,7 +329,7 @@ __global__ void __launch_bounds__(192) k_lvc_dk_mfma(const float *__restrict__ x
         for (int c = tap; c < CH; c += 3) accb += ds[lane * DLD + c];   // thread = (row lane, every third column)
     }
     if (dKf) {
-        float4 *dst = reinterpret_cast<float4 *>(dKf + ((int64_t)b * T + l) * ME);
+        float4 *dst = reinterpret_cast<float4 *>(dKf + (int64_t)b * dkfs + (int64_t)l * ME);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -502,30 +501,43 @@ hipError_t gate_backward(const Launch &L, const float *y, const float *dout, flo
 static bool model_shape(int Cin, int Cout, int ks, int hop) { return Cin == MI && Cout == MO && ks == MK && (hop == 8 || hop == 64 || hop == 256); }
 bool lvc_op_needs_scratch(int Cin, int Cout, int ks, int hop) { return model_shape(Cin, Cout, ks, hop); }
 
+// frames = true (the model's shape only): K is frame-major ORDER_FWD ([T][6144] per utterance, kbs floats between utterances: what
+// kconv_forward_frames wrote), dK leaves frame-major ORDER_DK (dkbs between utterances: what kconv_backward_frames reads) -- no
+// transposes; the scratch then only holds the ORDER_DX copy for the dx kernel
+static hipError_t launch_fwd_mfma(const Launch &L, const float *x, const float *Kf, const float *bias, float *out, int B, int T, int hop, int64_t kfs)
+{
+    if (hop == 256) FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd_mfma<256>, dim3(T, B), dim3(256), 0, x, Kf, bias, out, T, kfs);
+    else if (hop == 64) FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd_mfma<64>, dim3((T + 3) / 4, B), dim3(256), 0, x, Kf, bias, out, T, kfs);
+    else FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd_mfma<8>, dim3((T + 3) / 4, B), dim3(256), 0, x, Kf, bias, out, T, kfs);
+    return hipSuccess;
+}
+
 hipError_t lvc_op_forward(const Launch &L, const float *x, const float *K, const float *bias, float *out, int B, int Cin, int Cout, int ks,
-                          int T, int hop, float *scratch, int64_t kbs)
+                          int T, int hop, float *scratch, int64_t kbs, bool frames)
 {
     const int Ln = T * hop;
     if (kbs == 0) kbs = (int64_t)Cin * Cout * ks * T;
+    if (frames) {
+        if (!model_shape(Cin, Cout, ks, hop)) return hipErrorInvalidValue;
+        return launch_fwd_mfma(L, x, K, bias, out, B, T, hop, kbs);
+    }
     if (!scratch || !model_shape(Cin, Cout, ks, hop)) {
         if (kbs != (int64_t)Cin * Cout * ks * T) return hipErrorInvalidValue;      // the generic kernels take a tensor of its own only
         FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd, dim3((Ln + 255) / 256, Cout, B), dim3(256), 0, x, K, bias, out, Cin, Cout, ks, T, hop);
         return hipSuccess;
     }
     FD_LAUNCH(L, "lvc_op_pack", k_lvc_pack<ORDER_FWD>, dim3((T + 63) / 64, ME / 64, B), dim3(256), 0, K, scratch, T, kbs);
-    if (hop == 256) FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd_mfma<256>, dim3(T, B), dim3(256), 0, x, scratch, bias, out, T);
-    else if (hop == 64) FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd_mfma<64>, dim3((T + 3) / 4, B), dim3(256), 0, x, scratch, bias, out, T);
-    else FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd_mfma<8>, dim3((T + 3) / 4, B), dim3(256), 0, x, scratch, bias, out, T);
-    return hipSuccess;
+    return launch_fwd_mfma(L, x, scratch, bias, out, B, T, hop, (int64_t)T * ME);
 }
 
 hipError_t lvc_op_backward(const Launch &L, const float *x, const float *K, const float *dout, float *dx, float *dK, float *dbias, int B,
-                           int Cin, int Cout, int ks, int T, int hop, float *scratch, int64_t kbs, int64_t dkbs)
+                           int Cin, int Cout, int ks, int T, int hop, float *scratch, int64_t kbs, int64_t dkbs, bool frames)
 {
     const int Ln = T * hop;
     const int64_t own = (int64_t)Cin * Cout * ks * T;
     if (kbs == 0) kbs = own;
     if (dkbs == 0) dkbs = own;
+    if (frames && (!scratch || !model_shape(Cin, Cout, ks, hop))) return hipErrorInvalidValue;
     if (!scratch || !model_shape(Cin, Cout, ks, hop)) {
         if (kbs != own || dkbs != own) return hipErrorInvalidValue;
         if (dx) FD_LAUNCH(L, "lvc_op_backward_x", k_lvc_bwd_x, dim3((Ln + 255) / 256, Cin, B), dim3(256), 0, dout, K, dx, Cin, Cout, ks, T, hop);
@@ -540,16 +552,19 @@ hipError_t lvc_op_backward(const Launch &L, const float *x, const float *K, cons
         return hipSuccess;
     }
     if (dx) {
-        FD_LAUNCH(L, "lvc_op_pack", k_lvc_pack<ORDER_DX>, dim3((T + 63) / 64, ME / 64, B), dim3(256), 0, K, scratch, T, kbs);
+        if (frames) FD_LAUNCH(L, "lvc_op_reorder", k_lvc_reorder_dx, dim3(T, B), dim3(256), 0, K, scratch, T, kbs);
+        else FD_LAUNCH(L, "lvc_op_pack", k_lvc_pack<ORDER_DX>, dim3((T + 63) / 64, ME / 64, B), dim3(256), 0, K, scratch, T, kbs);
         if (hop == 256) FD_LAUNCH(L, "lvc_op_backward_x", k_lvc_dx_mfma<256>, dim3(T, B), dim3(256), 0, dout, scratch, dx, T);
         else if (hop == 64) FD_LAUNCH(L, "lvc_op_backward_x", k_lvc_dx_mfma<64>, dim3((T + 3) / 4, B), dim3(256), 0, dout, scratch, dx, T);
         else FD_LAUNCH(L, "lvc_op_backward_x", k_lvc_dx_mfma<8>, dim3((T + 3) / 4, B), dim3(256), 0, dout, scratch, dx, T);
     }
     if (dK || dbias) {
-        float *dKf = dK ? scratch : nullptr;      // (the dx kernels are done with the scratch: same stream)
-        if (hop == 8) FD_LAUNCH(L, "lvc_op_backward_k", k_lvc_dk_mfma<8>, dim3(T, B), dim3(192), 0, x, dout, dKf, dbias, T, hop);
-        else FD_LAUNCH(L, "lvc_op_backward_k", k_lvc_dk_mfma<64>, dim3(T, B), dim3(192), 0, x, dout, dKf, dbias, T, hop);
-        if (dK) FD_LAUNCH(L, "lvc_op_unpack", k_lvc_unpack, dim3((T + 63) / 64, ME / 64, B), dim3(256), 0, scratch, dK, T, dkbs);
+        // (the dx kernels are done with the scratch: same stream)
+        float *dKf = !dK ? nullptr : frames ? dK : scratch;
+        const int64_t dkfs = frames ? dkbs : (int64_t)T * ME;
+        if (hop == 8) FD_LAUNCH(L, "lvc_op_backward_k", k_lvc_dk_mfma<8>, dim3(T, B), dim3(192), 0, x, dout, dKf, dbias, T, hop, dkfs);
+        else FD_LAUNCH(L, "lvc_op_backward_k", k_lvc_dk_mfma<64>, dim3(T, B), dim3(192), 0, x, dout, dKf, dbias, T, hop, dkfs);
+        if (dK && !frames) FD_LAUNCH(L, "lvc_op_unpack", k_lvc_unpack, dim3((T + 63) / 64, ME / 64, B), dim3(256), 0, scratch, dK, T, dkbs);
     }
     return hipSuccess;
 }

@@ -418,3 +418,149 @@ def location_variable_convolution(x, kernel, bias, dilation=1, hop_size=256, gra
     if dilation != 1:
         raise NotImplementedError("location_variable_convolution: the HIP operator implements dilation = 1 (modules.py:216)")
     return _LVC.apply(x, kernel, bias, hop_size, grad_slot)
+
+
+# ---- "frames": kernel_conv and the operator joined through frame-major tensors (include/fastdiff_hip.h: fd_kconv_*_frames, fd_lvc_*_frames) ----
+
+FRAME = 32 * 64 * 3      # coefficients per frame of the model's operator
+
+
+def frame_order(order):
+    """LongTensor [6144]: position e of a frame -> row (i * 64 + o) * 3 + k of the reference's [32, 64, 3] coefficient block, for
+    order = "forward" (the frames kernel_conv writes: the operator's forward operand order) or "grad" (the frames of the gradient: its
+    dK accumulator order).  The Python statement of csrc/fd_frame_order.h: row_of, for tests and inspection."""
+    e = torch.arange(FRAME)
+    j, lane, grp = e & 3, (e >> 2) & 63, e >> 8
+    l31, hi = lane & 31, lane >> 5
+    if order == "forward":
+        mt, sq = grp // 12, grp % 12
+        kidx = 2 * (4 * sq + j) + hi
+        o, k, i = 32 * mt + l31, kidx >> 5, kidx & 31
+    elif order == "grad":
+        g, t6 = grp & 3, grp >> 2
+        mt = t6 // 3
+        k, o, i = t6 - 3 * mt, 32 * mt + 8 * g + 4 * hi + j, l31
+    else:
+        raise ValueError("frame_order: order must be 'forward' or 'grad'")
+    return (i * 64 + o) * 3 + k
+
+
+def frames_to_reference(frames, order="forward"):
+    """frames [B, layers, T, 6144] -> the reference's kernels [B, layers, 32, 64, 3, T] (modules.py:333-338)."""
+    B, nl, T, _ = frames.shape
+    out = torch.empty((B, nl, FRAME, T), device=frames.device, dtype=frames.dtype)
+    out[:, :, frame_order(order).to(frames.device)] = frames.transpose(2, 3)
+    return out.view(B, nl, 32, 64, 3, T)
+
+
+def reference_to_frames(kernels, order="forward"):
+    """the reference's kernels [B, layers, 32, 64, 3, T] -> frames [B, layers, T, 6144]."""
+    B, nl = kernels.shape[:2]
+    T = kernels.shape[-1]
+    return kernels.reshape(B, nl, FRAME, T)[:, :, frame_order(order).to(kernels.device)].transpose(2, 3).contiguous()
+
+
+class _KConvFrames(torch.autograd.Function):
+    """kernel_conv writing the LVC operator's frames directly (fd_kconv_forward_frames) and reading the gradient as frames
+    (fd_kconv_backward_frames): out [B, M / 6144, T, 6144]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.in_dtypes = (x.dtype, weight.dtype, bias.dtype)
+        x, weight, bias = x.contiguous().float(), weight.contiguous().float(), bias.contiguous().float()
+        B, _, T = x.shape
+        M = weight.shape[0]
+        out = torch.empty((B, M // FRAME, T, FRAME), device=x.device, dtype=torch.float32)
+        lib, h = _handle(x.device)
+        _capi.check(lib, h, lib.fd_kconv_forward_frames(h, x.data_ptr(), weight.data_ptr(), bias.data_ptr(), B, M, T, out.data_ptr(), _stream(x.device)),
+                    "fd_kconv_forward_frames")
+        ctx.save_for_backward(x, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight = ctx.saved_tensors
+        dout = dout.contiguous().float()
+        B, _, T = x.shape
+        M = weight.shape[0]
+        need_x, need_w, need_b = ctx.needs_input_grad
+        dx = torch.empty_like(x) if need_x else None
+        dw = torch.empty_like(weight) if need_w else None
+        db = torch.empty((M,), device=x.device, dtype=torch.float32) if need_b else None
+        lib, h = _handle(x.device)
+        _capi.check(lib, h, lib.fd_kconv_backward_frames(h, x.data_ptr(), weight.data_ptr(), dout.data_ptr(), B, M, T,
+                                                         None if dx is None else dx.data_ptr(), None if dw is None else dw.data_ptr(),
+                                                         None if db is None else db.data_ptr(), _stream(x.device)), "fd_kconv_backward_frames")
+        tx, tw, tb = ctx.in_dtypes
+        return (None if dx is None else dx.to(tx), None if dw is None else dw.to(tw), None if db is None else db.to(tb))
+
+
+def kernel_conv_frames_supported(x, weight):
+    """kernel_conv_supported() and a whole number of the operator's layers in the output channels (kernel_conv: 4 x 6144)."""
+    return kernel_conv_supported(x, weight) and weight.shape[0] % FRAME == 0 and x.dtype == weight.dtype == torch.float32
+
+
+def kernel_conv1d_frames(x, weight, bias):
+    """The predictor's kernel_conv with its result as frames [B, layers, T, 6144] (frames_to_reference() gives the reference's tensor)."""
+    return _KConvFrames.apply(x, weight, bias)
+
+
+class _LVCFrames(torch.autograd.Function):
+    """The location-variable convolution on one layer's frames: kernel [B, T, 6144] = frames[:, i] of kernel_conv1d_frames (batch-strided,
+    used where it lies); its gradient is written into the layer's slice of the shared buffer of split_layers (grad_slot)."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, bias, hop_size, grad_slot):
+        if not (x.is_cuda and kernel.is_cuda and bias.is_cuda):
+            raise RuntimeError("fastdiff_amd.location_variable_convolution_frames runs only on a HIP device (no CPU fallback)")
+        ctx.in_dtypes = (x.dtype, bias.dtype)
+        ctx.grad_slot = grad_slot
+        B, _, L = x.shape
+        T = kernel.shape[1]
+        # (the stride of a dimension of size 1 means nothing and torch reports what it likes there)
+        assert kernel.dtype == torch.float32 and tuple(kernel.shape) == (B, T, FRAME) and kernel.stride(2) == 1 and \
+            (T == 1 or kernel.stride(1) == FRAME) and (B == 1 or kernel.stride(0) >= T * FRAME), "frames [B, T, 6144]"
+        ctx.kbs = kernel.stride(0) if B > 1 else T * FRAME
+        assert L == T * int(hop_size), "length of (x, kernel) is not matched"
+        x, bias = x.contiguous().float(), bias.contiguous().float()
+        out = torch.empty((B, 64, L), device=x.device, dtype=torch.float32)
+        lib, h = _handle(x.device)
+        _capi.check(lib, h, lib.fd_lvc_forward_frames(h, x.data_ptr(), kernel.data_ptr(), ctx.kbs, bias.data_ptr(), B, T, int(hop_size),
+                                                      out.data_ptr(), _stream(x.device)), "fd_lvc_forward_frames")
+        ctx.save_for_backward(x, kernel)
+        ctx.hop = int(hop_size)
+        return out.to(ctx.in_dtypes[0])
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, kernel = ctx.saved_tensors
+        dout = dout.contiguous().float()
+        B, _, L = x.shape
+        T = kernel.shape[1]
+        need_x, need_k, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        dx = torch.empty_like(x) if need_x else None
+        dk = None
+        if need_k:
+            slot = ctx.grad_slot
+            if slot is not None:      # this layer's slice of the shared gradient buffer
+                holder, i, shape = slot
+                if holder.get("buf") is None:
+                    holder["buf"] = torch.empty(shape, device=x.device, dtype=torch.float32)
+                dk = holder["buf"][:, i]
+            else:
+                dk = torch.empty((B, T, FRAME), device=x.device, dtype=torch.float32)
+        db = torch.empty((B, 64, T), device=x.device, dtype=torch.float32) if need_b else None
+        lib, h = _handle(x.device)
+        _capi.check(lib, h, lib.fd_lvc_backward_frames(h, x.data_ptr(), kernel.data_ptr(), ctx.kbs, dout.data_ptr(), B, T, ctx.hop,
+                                                       None if dx is None else dx.data_ptr(), None if dk is None else dk.data_ptr(),
+                                                       0 if dk is None else (dk.stride(0) if B > 1 else T * FRAME),
+                                                       None if db is None else db.data_ptr(), _stream(x.device)),
+                    "fd_lvc_backward_frames")
+        tx, tb = ctx.in_dtypes
+        return (None if dx is None else dx.to(tx), dk, None if db is None else db.to(tb), None, None)
+
+
+def location_variable_convolution_frames(x, kernel_frames, bias, hop_size, grad_slot=None):
+    """location_variable_convolution for x [B, 32, L], one layer's frames [B, T, 6144] (forward order) and bias [B, 64, T]; the gradient
+    with respect to the frames comes back in the "grad" order (what kernel_conv1d_frames' backward reads)."""
+    return _LVCFrames.apply(x, kernel_frames, bias, hop_size, grad_slot)

@@ -71,9 +71,11 @@ def _dblock(p, x, cconv=None):
     return x + residual
 
 
-def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None, split=None):
+def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None, split=None, frames=None):
     """KernelPredictor.forward (modules.py:320-343).  kconv: the HIP operator for kernel_conv (64 -> 24576 channels: the largest
-    matrix product of the step) where its shapes fit, else the module's own convolution."""
+    matrix product of the step) where its shapes fit, else the module's own convolution.  frames (the product path): kernel_conv
+    writes the LVC operator's frame-major operand order directly -- [B, layers, T, 6144] instead of the reference's
+    [B, layers, 32, 64, 3, T] -- and reads the gradient that way (lvc_op: kernel_conv1d_frames); the third return value says so."""
     B, _, T = c.shape
 
     def conv(m, h):      # a 64 -> M, k3 convolution of the predictor: the HIP operator where its shapes fit, else the module itself
@@ -88,7 +90,12 @@ def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None, split=None):
     for m in p.residual_conv:                    # Dropout(p = 0), Conv1d 64 -> 64 k3, LeakyReLU(0.1), Conv1d, LeakyReLU, three times
         r = conv(m, r) if isinstance(m, torch.nn.Conv1d) else m(r)
     c = c + r
-    k = conv(p.kernel_conv, c)
+    kc = p.kernel_conv
+    if frames is not None and split is not None and (cin, cout, ks) == (32, 64, 3) and \
+            frames[2](c, kc.weight_v if hasattr(kc, "weight_v") else kc.weight):
+        kf = frames[0](c, _conv_weight(kc), kc.bias)                     # [B, layers, T, 6144]
+        return split(kf), conv(p.bias_conv, c).contiguous().view(B, layers, cout, T).unbind(1), True
+    k = conv(kc, c)
     # the reference slices kernels[:, i] (modules.py:213-214), whose backward builds a zero tensor of all four layers per slice and
     # adds the four up; unbind hands autograd the same views and gets one stack back.  (One kernel_conv call per layer on that
     # layer's weight rows -- contiguous kernels, no stack -- measured slower: 18.3 vs 17.1 ms per step; the slices of the WEIGHT then
@@ -96,7 +103,7 @@ def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None, split=None):
     k6 = k.contiguous().view(B, layers, cin, cout, ks, T)
     # on the product path the slices are used where they lie and their gradients land in one buffer (lvc_op.split_layers)
     return (split(k6) if split is not None else (k6.unbind(1), None),
-            conv(p.bias_conv, c).contiguous().view(B, layers, cout, T).unbind(1))
+            conv(p.bias_conv, c).contiguous().view(B, layers, cout, T).unbind(1), False)
 
 
 def _torch_gate(x, y):
@@ -104,12 +111,12 @@ def _torch_gate(x, y):
     return x + torch.sigmoid(y[:, :C]) * torch.tanh(y[:, C:])
 
 
-def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate, kconv=None, cconv=None, split=None):
+def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate, kconv=None, cconv=None, split=None, frames=None):
     """TimeAware_LVCBlock.forward (modules.py:189-218); the in-place `x += audio_down` of the reference written out of place."""
     C = cfg["inner_channels"]
     cond = c + p.fc_t(emb).unsqueeze(-1)
-    (kernels, slots), bias = _kernel_predictor(p.kernel_predictor, cond, cfg["lvc_layers_each_block"], C, 2 * C, cfg["lvc_kernel_size"], kconv,
-                                               split if kconv is not None else None)
+    (kernels, slots), bias, as_frames = _kernel_predictor(p.kernel_predictor, cond, cfg["lvc_layers_each_block"], C, 2 * C, cfg["lvc_kernel_size"],
+                                                          kconv, split if kconv is not None else None, frames if kconv is not None else None)
     if cconv is not None and x.is_cuda:
         from .lvc_op import upsample, upsample_supported
     if cconv is not None and x.is_cuda and upsample_supported(x, p.upsample):
@@ -123,19 +130,26 @@ def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate, kconv=None,
         else:
             x = x + audio_down
             y = F.leaky_relu(_conv(conv, F.leaky_relu(x, 0.2)), 0.2)
-        y = lvc(y, kernels[i], bias[i], 1, p.cond_hop_length) if slots is None else lvc(y, kernels[i], bias[i], 1, p.cond_hop_length, grad_slot=slots[i])
+        if as_frames:
+            y = frames[1](y, kernels[i], bias[i], p.cond_hop_length, grad_slot=slots[i])
+        else:
+            y = lvc(y, kernels[i], bias[i], 1, p.cond_hop_length) if slots is None else lvc(y, kernels[i], bias[i], 1, p.cond_hop_length, grad_slot=slots[i])
         x = gate(x, y)                                   # x + sigmoid(y[:, :C]) * tanh(y[:, C:])  (modules.py:217)
     return x
 
 
 def differentiable_forward(module, data, lvc=None):
     """eps = net((audio, c, diffusion_steps)) as FastDiff.forward (FastDiff_model.py:74-102), recorded by autograd."""
-    gate, kconv, cconv, split = _torch_gate, None, None, None
+    gate, kconv, cconv, split, frames = _torch_gate, None, None, None, None
     if lvc is None:                    # the product path: the layer's operators, its convolution and the predictor's kernel_conv on HIP kernels
-        from .lvc_op import location_variable_convolution as lvc, gated_residual as gate, kernel_conv1d, kernel_conv_supported, conv32, conv32_supported, split_layers
+        from .lvc_op import (location_variable_convolution as lvc, gated_residual as gate, kernel_conv1d, kernel_conv_supported, conv32,
+                             conv32_supported, split_layers, kernel_conv1d_frames, location_variable_convolution_frames,
+                             kernel_conv_frames_supported)
         kconv = (kernel_conv1d, kernel_conv_supported)
         cconv = (conv32, conv32_supported)
         split = split_layers
+        if getattr(module, "_train_frames", True):      # (False: the reference's kernel tensor between the two operators, for A/B runs)
+            frames = (kernel_conv1d_frames, location_variable_convolution_frames, kernel_conv_frames_supported)
     audio, c, diffusion_steps = data
     cfg = module._cfg
     if c.dim() == 2:
@@ -148,5 +162,5 @@ def differentiable_forward(module, data, lvc=None):
         skips.append(x)
         x = _dblock(down, x, cconv)
     for n, audio_down in enumerate(reversed(skips)):
-        x = _lvc_block(module.lvc_blocks[n], x, audio_down, c, emb, cfg, lvc, gate, kconv, cconv, split)
+        x = _lvc_block(module.lvc_blocks[n], x, audio_down, c, emb, cfg, lvc, gate, kconv, cconv, split, frames)
     return _conv(module.final_conv[0], x)

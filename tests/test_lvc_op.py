@@ -397,3 +397,89 @@ def test_upsample_operator_forward_and_backward_match_torch_autograd(B, Lin, r):
     x2, w2, b2 = (t.cuda().requires_grad_(True) for t in (x, w, bias))           # fixed-order sums: the same bits again
     upsample(x2, w2, b2, r).backward(dy.cuda())
     assert torch.equal(w2.grad, wg.grad) and torch.equal(b2.grad, bg.grad) and torch.equal(x2.grad, xg.grad)
+
+
+def test_frame_orders_are_permutations_and_round_trip():
+    """fastdiff_amd.lvc_op.frame_order (the Python statement of csrc/fd_frame_order.h) lists every coefficient of a frame exactly once in
+    both orders, and reference -> frames -> reference is the identity."""
+    from fastdiff_amd import lvc_op
+    for order in ("forward", "grad"):
+        assert sorted(lvc_op.frame_order(order).tolist()) == list(range(6144)), order
+    k = torch.randn(2, 4, 32, 64, 3, 5)
+    for order in ("forward", "grad"):
+        f = lvc_op.reference_to_frames(k, order)
+        assert tuple(f.shape) == (2, 4, 5, 6144) and torch.equal(lvc_op.frames_to_reference(f, order), k)
+    # forward order: the float4 of lane l, group g holds four consecutive k-steps of output row 32 (g / 12) + (l & 31)
+    r = lvc_op.frame_order("forward").view(24, 64, 4)
+    o = (r // 3) % 64
+    assert torch.equal(o, (32 * (torch.arange(24) // 12)).view(24, 1, 1) + (torch.arange(64) & 31).view(1, 64, 1) + torch.zeros(24, 64, 4, dtype=torch.long))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,layers", [(3, 100, 4), (2, 37, 4), (1, 128, 1), (2, 1, 2), (20, 100, 4)])
+def test_kernel_conv_frames_equal_the_reference_layout(B, T, layers):
+    """kernel_conv writing the operator's frames (fd_kconv_forward_frames) = the reference-layout kernel_conv (fd_kconv_forward) with the
+    rows gathered and the store transposed: frames_to_reference(out) must equal it bit for bit; the backward reading gradient frames
+    (fd_kconv_backward_frames) must give the bits of fd_kconv_backward fed with the same gradient in the reference's layout for the
+    weight and bias gradients (rows are independent), and its sums in another order for dx (the 24576 rows are added up frame group by
+    frame group instead of row by row: float32 rounding apart)."""
+    import fastdiff_amd
+    from fastdiff_amd import lvc_op
+    g = torch.Generator().manual_seed(100 * B + T)
+    M = layers * 6144
+    x = torch.randn(B, 64, T, generator=g).cuda()
+    w = (torch.randn(M, 64, 3, generator=g) / 13.9).cuda()
+    bias = torch.randn(M, generator=g).cuda()
+    dfr = torch.randn(B, layers, T, 6144, generator=g).cuda()                       # a gradient in the "grad" frame order
+    xa, wa, ba = (t.clone().requires_grad_(True) for t in (x, w, bias))
+    fr = lvc_op.kernel_conv1d_frames(xa, wa, ba)
+    assert tuple(fr.shape) == (B, layers, T, 6144)
+    fr.backward(dfr)
+    xb, wb, bb = (t.clone().requires_grad_(True) for t in (x, w, bias))
+    ref = fastdiff_amd.kernel_conv1d(xb, wb, bb)
+    ref.backward(lvc_op.frames_to_reference(dfr, "grad").reshape(B, M, T))
+    assert torch.equal(lvc_op.frames_to_reference(fr.detach(), "forward").reshape(B, M, T), ref.detach())
+    assert torch.equal(wa.grad, wb.grad) and torch.equal(ba.grad, bb.grad)
+    assert float((xa.grad - xb.grad).abs().max()) <= 2e-6 * float(xb.grad.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hop,T,B", [(8, 37, 2), (64, 100, 2), (256, 12, 3), (256, 1, 1), (8, 128, 1)])
+def test_lvc_operator_on_frames_equals_the_operator_on_the_reference_layout(hop, T, B):
+    """fd_lvc_forward_frames / fd_lvc_backward_frames take one layer's [T, 6144] block per utterance out of a [B, layers, T, 6144] tensor
+    where it lies and leave the kernel gradient as frames in the layer's slice of one buffer: output, dx, dbias and (after
+    frames_to_reference) dK equal fd_lvc_forward / fd_lvc_backward on the reference's tensors bit for bit -- the same kernels minus
+    the transposes."""
+    import fastdiff_amd
+    from fastdiff_amd import lvc_op
+    g = torch.Generator().manual_seed(hop + T)
+    layers = 4
+    k6 = (torch.randn(B, layers, 32, 64, 3, T, generator=g) / 9.8).cuda()
+    bias = torch.randn(B, layers, 64, T, generator=g).cuda()
+    xs = [torch.randn(B, 32, T * hop, generator=g).cuda() for _ in range(layers)]
+    douts = [torch.randn(B, 64, T * hop, generator=g).cuda() for _ in range(layers)]
+    # the reference layout, layer by layer
+    want = []
+    for i in range(layers):
+        x, k, b = xs[i].clone().requires_grad_(True), k6[:, i].clone().requires_grad_(True), bias[:, i].clone().requires_grad_(True)
+        y = fastdiff_amd.location_variable_convolution(x, k, b, 1, hop)
+        y.backward(douts[i])
+        want.append((y.detach(), x.grad, k.grad, b.grad))
+    # frames: one tensor for the four layers, split without copies, gradients into one buffer
+    fr = lvc_op.reference_to_frames(k6, "forward").requires_grad_(True)
+    slices, slots = lvc_op.split_layers(fr)
+    loss = 0.0
+    got = []
+    for i in range(layers):
+        x, b = xs[i].clone().requires_grad_(True), bias[:, i].clone().requires_grad_(True)
+        y = lvc_op.location_variable_convolution_frames(x, slices[i], b, hop, grad_slot=slots[i])
+        loss = loss + (y * douts[i]).sum()
+        got.append((y, x, b))
+    loss.backward()
+    assert tuple(fr.grad.shape) == (B, layers, T, 6144)
+    dk6 = lvc_op.frames_to_reference(fr.grad, "grad")
+    for i in range(layers):
+        y, x, b = got[i]
+        assert torch.equal(y.detach(), want[i][0]), i
+        assert torch.equal(x.grad, want[i][1]) and torch.equal(b.grad, want[i][3]), i
+        assert torch.equal(dk6[:, i], want[i][2]), i

@@ -73,12 +73,16 @@ def test_inference_entry_points_still_refuse_autograd_inputs_on_cpu():
 
 
 @pytest.mark.gpu
-def test_training_step_on_the_hip_operator_matches_the_reference_backward(monkeypatch):
+@pytest.mark.parametrize("frames", [True, False])
+def test_training_step_on_the_hip_operator_matches_the_reference_backward(monkeypatch, frames):
+    """frames: kernel_conv hands the LVC operator its frame-major operands directly (the product path); False: through the reference's
+    [B, layers, 32, 64, 3, T] tensor -- same kernels plus the transposes, kept for A/B runs (module._train_frames)."""
     import fastdiff_amd
     from fastdiff_amd import sampler
     g = load_golden("theta_grad")
     sched = load_golden("schedule")
     m = _module().cuda().train()
+    m._train_frames = frames
     monkeypatch.setattr(sampler, "std_normal", lambda size: torch.from_numpy(g["z"].copy()).view(*size).cuda())
     monkeypatch.setattr(torch, "randint", lambda *a, **k: torch.from_numpy(g["ts"].copy()))
     dh = {"T": 1000, "alpha": torch.from_numpy(sched["train_alpha"]).cuda()}
@@ -86,12 +90,18 @@ def test_training_step_on_the_hip_operator_matches_the_reference_backward(monkey
     calls = []
     real = fastdiff_amd.lvc_op.location_variable_convolution
     monkeypatch.setattr(fastdiff_amd.lvc_op, "location_variable_convolution", lambda x, k, b, d, h, **kw: (calls.append(h), real(x, k, b, d, h, **kw))[1])
+    fcalls = []
+    real_f = fastdiff_amd.lvc_op.location_variable_convolution_frames
+    monkeypatch.setattr(fastdiff_amd.lvc_op, "location_variable_convolution_frames",
+                        lambda x, k, b, h, **kw: (fcalls.append((h, tuple(k.shape[1:]))), real_f(x, k, b, h, **kw))[1])
     convs = []
     real_c = fastdiff_amd.lvc_op.conv32
     monkeypatch.setattr(fastdiff_amd.lvc_op, "conv32", lambda x, w, b, d, **k: (convs.append((x.shape[-1], d, "skip" in k)), real_c(x, w, b, d, **k))[1])
     loss = fastdiff_amd.theta_timestep_loss(m, (torch.from_numpy(g["mel"]).cuda(), audio), dh)
     loss.backward()
-    assert calls == [8] * 4 + [64] * 4 + [256] * 4                       # the twelve LVC calls went through the HIP operator
+    hops = [8] * 4 + [64] * 4 + [256] * 4                                # the twelve LVC calls went through the HIP operator
+    T = g["mel"].shape[-1]
+    assert (calls, fcalls) == (([], [(h, (T, 6144)) for h in hops]) if frames else (hops, []))
     # ... and the small convolutions through theirs: the DBlocks at 384 and 48 columns (the third one runs on 6 columns, not a multiple
     # of 4: torch), the twelve LVC-block layers with their skip add
     # (each DBlock: its 1 x 1 residual convolution first, as the centre tap of a 3-tap one, then the three dilated ones)

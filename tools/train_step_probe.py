@@ -55,11 +55,16 @@ def main():
             train.differentiable_forward(m, (x, mel, steps), lvc=lvc)
 
     print(f"training shape B={B} T={T} ({B * T * 256} samples)")
-    for name, lvc in (("HIP operator", None), ("unfold+einsum (PyTorch-ROCm eager)", lvc_unfold_einsum)):
+    # frames: kernel_conv hands the LVC operator its frame-major operands (the product path); reference tensor: through the reference's
+    # [B, layers, 32, 64, 3, T] kernels and the operator's transposes (module._train_frames = False)
+    for name, lvc, frames in (("HIP operator, frames", None, True), ("HIP operator, reference tensor", None, False),
+                              ("unfold+einsum (PyTorch-ROCm eager)", lvc_unfold_einsum, True)):
         try:
+            m._train_frames = frames
             print(f"  forward + backward, LVC = {name}: {timed(lambda: step(lvc)):8.2f} ms   forward only (no_grad): {timed(lambda: fwd(lvc)):8.2f} ms")
         except Exception as e:      # noqa: BLE001 -- e.g. out of memory in the unfold view's backward
             print(f"  LVC = {name}: failed: {e!r}")
+    m._train_frames = True
     # the same step captured once in a hipGraph (torch.cuda.graph) and replayed: what is left when the ~1500 kernel launches of a step
     # cost no host time
     try:
