@@ -1650,7 +1650,7 @@ int fd_lvc_backward_frames(fd_handle h, const float *x, const float *kernel_fram
     if (dkernel_frames && (rc = check_frames_stride(h, dkernel_bstride, T, "fd_lvc_backward_frames")) != FD_OK) return rc;
     FD_HIP(h, hipSetDevice(h->device));
     float *scratch = nullptr;
-    if ((rc = lvc_scratch(h, B, 32, 64, 3, T, hop, &scratch)) != FD_OK) return rc;      // the dx kernel's operand order
+    if (dx && !h->lvc_dx_gather && (rc = lvc_scratch(h, B, 32, 64, 3, T, hop, &scratch)) != FD_OK) return rc;      // option lvc_dx = copy: the dx kernel's operand order
     fdk::Launch L = {h, (hipStream_t)stream, false};
     hipError_t e = fdk::lvc_op_backward(L, x, kernel_frames, dout, dx, dkernel_frames, dbias, B, 32, 64, 3, T, hop, scratch, kernel_bstride,
                                         dkernel_bstride, true);
@@ -1923,6 +1923,10 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
     if (k == "fuse_final") { h->fuse_final = on; drop_graph(h); return FD_OK; }
     if (k == "fuse_up") { h->fuse_up = on; drop_graph(h); return FD_OK; }
     if (k == "fuse_advance") { h->fuse_advance = on; drop_graph(h); return FD_OK; }
+    if (k == "lvc_dx") {      // training operator, frames path: gather = dx reads the forward-order frames; copy = a reordered copy first
+        if (v != "gather" && v != "copy") FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: lvc_dx expects gather|copy, got '%s'", value);
+        h->lvc_dx_gather = (v == "gather"); return FD_OK;
+    }
     if (k == "first_variant") { h->first_variant = atoi(value) & 7; drop_graph(h); return FD_OK; }
     if (k == "lvc_variant") { h->lvc_variant = atoi(value) ? 1 : 0; drop_graph(h); return FD_OK; }
     if (k == "embed_cache") { h->embed_cache = on; return FD_OK; }

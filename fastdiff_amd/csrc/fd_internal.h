@@ -192,6 +192,7 @@ struct fd_context {
     bool final_fused = false;                // set by the last LVC layer's launch, consumed by fast_final
     bool fuse_advance = true;                // option "fuse_advance": between two steps of one graph / launch sequence the end-of-step
                                              // bookkeeping (k_advance) rides in the next step's first kernel instead of a launch of its own
+    bool lvc_dx_gather = true;               // option lvc_dx = gather | copy: the frames path's dx kernel reads kernel_conv's frames (fd_kernels_train.hip)
     bool advance_pending = false;            // set by enqueue_steps after a step whose bookkeeping the next first_conv will do
     // the step embedding and the three fc_t rows of every reverse step depend on the schedule's t values and the weights only: kept from
     // the previous fd_sample when those are unchanged (two launches per call)

@@ -184,9 +184,13 @@ __global__ void __launch_bounds__(256, HOP == 256 ? 3 : 2) k_lvc_fwd_mfma(const 
 //   dx[i, l hop] += sum_o dout[o, l hop - 1] K[i, o, 2, l-1]          dx[i, (l+1) hop - 1] += sum_o dout[o, (l+1) hop] K[i, o, 0, l+1],
 // 2 x 32 sums of 64 products per frame: the wave that owns the column computes them on VALU (lane = (i, parity of o): its eight
 // float4 of the neighbour frame's operand copy are exactly those coefficients) and adds them before the store.
-template <int HOP>
+// FRAMES: Kx is not the ORDER_DX copy but the frames as kernel_conv wrote them (ORDER_FWD, kbs floats between utterances): coefficient
+// (i, o, k) lies at (o >> 5) 3072 + k 1024 + (i >> 3) 256 + (i & 1) 128 + (o & 31) 4 + ((i >> 1) & 3) of its frame (fwd_pos_of), so a lane
+// (i = col, parity hi of o) finds its 96 + 32 coefficients at one lane offset plus compile-time constants: dword gathers inside the
+// frame's 24 KB (every line of it is used by some lane of the wave: L1 hits) instead of float4 loads of a transposed copy.
+template <int HOP, bool FRAMES>
 __global__ void __launch_bounds__(256, 2) k_lvc_dx_mfma(const float *__restrict__ dout, const float *__restrict__ Kx, float *__restrict__ dx,
-                                                        int T)
+                                                        int T, int64_t kbs)
 {
     using G = LvcGeo<HOP>;
     constexpr int W = G::W, LD = G::LD, NCT = HOP == 8 ? 1 : 2;
@@ -201,13 +205,33 @@ __global__ void __launch_bounds__(256, 2) k_lvc_dx_mfma(const float *__restrict_
     float4 a[24], ef[8], el[8];
     const bool edge_f = wave_valid && own_first && f > 0, edge_l = wave_valid && own_last && f + 1 < T;
     if (wave_valid) {
-        const float4 *ap = reinterpret_cast<const float4 *>(Kx + ((int64_t)b * T + f) * ME);
+        if constexpr (FRAMES) {
+            const float *fp = Kx + (int64_t)b * kbs + (int64_t)f * ME + ((col >> 3) * 256 + (col & 1) * 128 + ((col >> 1) & 3) + 4 * hi);
+            auto gather = [&](const float *frame, int sq) {      // the float4 of operand group sq: k index 2 (4 sq + j) + hi = tap * 64 + o
+                float v[4];
 #pragma unroll
-        for (int sq = 0; sq < 24; ++sq) a[sq] = ap[sq * 64 + lane];
+                for (int j = 0; j < 4; ++j) {
+                    const int oe = (8 * sq + 2 * j) & 63, tap = (8 * sq + 2 * j) >> 6;
+                    v[j] = frame[(oe >> 5) * 3072 + tap * 1024 + (oe & 31) * 4];
+                }
+                return make_float4(v[0], v[1], v[2], v[3]);
+            };
 #pragma unroll
-        for (int sq = 0; sq < 8; ++sq) {
-            ef[sq] = edge_f ? (ap - ME / 4)[(16 + sq) * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);      // frame f-1, tap 2
-            el[sq] = edge_l ? (ap + ME / 4)[sq * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);             // frame f+1, tap 0
+            for (int sq = 0; sq < 24; ++sq) a[sq] = gather(fp, sq);
+#pragma unroll
+            for (int sq = 0; sq < 8; ++sq) {
+                ef[sq] = edge_f ? gather(fp - ME, 16 + sq) : make_float4(0.f, 0.f, 0.f, 0.f);      // frame f-1, tap 2
+                el[sq] = edge_l ? gather(fp + ME, sq) : make_float4(0.f, 0.f, 0.f, 0.f);           // frame f+1, tap 0
+            }
+        } else {
+            const float4 *ap = reinterpret_cast<const float4 *>(Kx + ((int64_t)b * T + f) * ME);
+#pragma unroll
+            for (int sq = 0; sq < 24; ++sq) a[sq] = ap[sq * 64 + lane];
+#pragma unroll
+            for (int sq = 0; sq < 8; ++sq) {
+                ef[sq] = edge_f ? (ap - ME / 4)[(16 + sq) * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);      // frame f-1, tap 2
+                el[sq] = edge_l ? (ap + ME / 4)[sq * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);             // frame f+1, tap 0
+            }
         }
     }
     stage_rows<MO, W, LD>(ds, dout + (int64_t)b * MO * L, L, q0, tid);
@@ -537,8 +561,8 @@ hipError_t lvc_op_backward(const Launch &L, const float *x, const float *K, cons
     const int64_t own = (int64_t)Cin * Cout * ks * T;
     if (kbs == 0) kbs = own;
     if (dkbs == 0) dkbs = own;
-    if (frames && (!scratch || !model_shape(Cin, Cout, ks, hop))) return hipErrorInvalidValue;
-    if (!scratch || !model_shape(Cin, Cout, ks, hop)) {
+    if (frames && (!model_shape(Cin, Cout, ks, hop) || (dx && !L.ctx->lvc_dx_gather && !scratch))) return hipErrorInvalidValue;
+    if (!frames && (!scratch || !model_shape(Cin, Cout, ks, hop))) {
         if (kbs != own || dkbs != own) return hipErrorInvalidValue;
         if (dx) FD_LAUNCH(L, "lvc_op_backward_x", k_lvc_bwd_x, dim3((Ln + 255) / 256, Cin, B), dim3(256), 0, dout, K, dx, Cin, Cout, ks, T, hop);
         if (dK || dbias) {
@@ -551,12 +575,17 @@ hipError_t lvc_op_backward(const Launch &L, const float *x, const float *K, cons
         }
         return hipSuccess;
     }
-    if (dx) {
+    if (dx && frames && L.ctx->lvc_dx_gather) {      // the dx kernel reads kernel_conv's frames where they lie
+        if (hop == 256) FD_LAUNCH(L, "lvc_op_backward_x", (k_lvc_dx_mfma<256, true>), dim3(T, B), dim3(256), 0, dout, K, dx, T, kbs);
+        else if (hop == 64) FD_LAUNCH(L, "lvc_op_backward_x", (k_lvc_dx_mfma<64, true>), dim3((T + 3) / 4, B), dim3(256), 0, dout, K, dx, T, kbs);
+        else FD_LAUNCH(L, "lvc_op_backward_x", (k_lvc_dx_mfma<8, true>), dim3((T + 3) / 4, B), dim3(256), 0, dout, K, dx, T, kbs);
+    } else if (dx) {
         if (frames) FD_LAUNCH(L, "lvc_op_reorder", k_lvc_reorder_dx, dim3(T, B), dim3(256), 0, K, scratch, T, kbs);
         else FD_LAUNCH(L, "lvc_op_pack", k_lvc_pack<ORDER_DX>, dim3((T + 63) / 64, ME / 64, B), dim3(256), 0, K, scratch, T, kbs);
-        if (hop == 256) FD_LAUNCH(L, "lvc_op_backward_x", k_lvc_dx_mfma<256>, dim3(T, B), dim3(256), 0, dout, scratch, dx, T);
-        else if (hop == 64) FD_LAUNCH(L, "lvc_op_backward_x", k_lvc_dx_mfma<64>, dim3((T + 3) / 4, B), dim3(256), 0, dout, scratch, dx, T);
-        else FD_LAUNCH(L, "lvc_op_backward_x", k_lvc_dx_mfma<8>, dim3((T + 3) / 4, B), dim3(256), 0, dout, scratch, dx, T);
+        const int64_t own_fs = (int64_t)T * ME;
+        if (hop == 256) FD_LAUNCH(L, "lvc_op_backward_x", (k_lvc_dx_mfma<256, false>), dim3(T, B), dim3(256), 0, dout, scratch, dx, T, own_fs);
+        else if (hop == 64) FD_LAUNCH(L, "lvc_op_backward_x", (k_lvc_dx_mfma<64, false>), dim3((T + 3) / 4, B), dim3(256), 0, dout, scratch, dx, T, own_fs);
+        else FD_LAUNCH(L, "lvc_op_backward_x", (k_lvc_dx_mfma<8, false>), dim3((T + 3) / 4, B), dim3(256), 0, dout, scratch, dx, T, own_fs);
     }
     if (dK || dbias) {
         // (the dx kernels are done with the scratch: same stream)

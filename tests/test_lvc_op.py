@@ -445,13 +445,17 @@ def test_kernel_conv_frames_equal_the_reference_layout(B, T, layers):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("hop,T,B", [(8, 37, 2), (64, 100, 2), (256, 12, 3), (256, 1, 1), (8, 128, 1)])
-def test_lvc_operator_on_frames_equals_the_operator_on_the_reference_layout(hop, T, B):
+@pytest.mark.parametrize("dx_mode", ["gather", "copy"])
+def test_lvc_operator_on_frames_equals_the_operator_on_the_reference_layout(hop, T, B, dx_mode):
     """fd_lvc_forward_frames / fd_lvc_backward_frames take one layer's [T, 6144] block per utterance out of a [B, layers, T, 6144] tensor
     where it lies and leave the kernel gradient as frames in the layer's slice of one buffer: output, dx, dbias and (after
     frames_to_reference) dK equal fd_lvc_forward / fd_lvc_backward on the reference's tensors bit for bit -- the same kernels minus
-    the transposes."""
+    the transposes.  dx_mode (library option lvc_dx): the dx kernel gathers its operands out of the forward-order frames (default) or
+    reads a reordered copy."""
     import fastdiff_amd
     from fastdiff_amd import lvc_op
+    lib, h = lvc_op._handle(torch.device("cuda"))
+    assert lib.fd_set_option(h, b"lvc_dx", dx_mode.encode()) == 0
     g = torch.Generator().manual_seed(hop + T)
     layers = 4
     k6 = (torch.randn(B, layers, 32, 64, 3, T, generator=g) / 9.8).cuda()
@@ -483,3 +487,4 @@ def test_lvc_operator_on_frames_equals_the_operator_on_the_reference_layout(hop,
         assert torch.equal(y.detach(), want[i][0]), i
         assert torch.equal(x.grad, want[i][1]) and torch.equal(b.grad, want[i][3]), i
         assert torch.equal(dk6[:, i], want[i][2]), i
+    assert lib.fd_set_option(h, b"lvc_dx", b"gather") == 0

@@ -1,0 +1,12 @@
+#!/bin/bash
+# round 4, session 19: the frames path's dx kernel gathers its operands out of kernel_conv's forward-order frames (no reordered copy)
+set -u
+mkdir -p gpurun_out; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1
+echo "== tests"; timeout 1200 python -m pytest tests/test_lvc_op.py tests/test_training_path.py -m gpu -q -p no:cacheprovider -x 2>&1 | tail -4
+for m in gather copy gather copy; do echo "== lvc_dx=$m"; FD_LVC_DX=$m timeout 600 python tools/train_step_probe.py 2>&1 | grep "frames:\|hipGraph:" ; done | tee gpurun_out/train_step_probe_s19.txt
+echo "== families (gather)"
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_train -o train -- python $R/tools/train_step_profile.py 12 > $R/gpurun_out/rocprof_train.log 2>&1; echo "rocprof rc=$?"
+cd $R; KT=$(find gpurun_out/prof_train -name '*kernel_trace.csv' | head -1); python tools/train_step_profile.py --report $KT 12 > gpurun_out/train_step_families_s19.txt 2>&1; head -30 gpurun_out/train_step_families_s19.txt | cut -c1-150
+find gpurun_out/prof_train -name '*.csv' -size +8M -delete 2>/dev/null

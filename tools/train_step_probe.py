@@ -54,7 +54,11 @@ def main():
         with torch.no_grad():
             train.differentiable_forward(m, (x, mel, steps), lvc=lvc)
 
-    print(f"training shape B={B} T={T} ({B * T * 256} samples)")
+    if os.environ.get("FD_LVC_DX"):      # gather (default) | copy: how the frames path's dx kernel gets its operands
+        from fastdiff_amd import lvc_op
+        lib, h = lvc_op._handle(torch.device("cuda"))
+        assert lib.fd_set_option(h, b"lvc_dx", os.environ["FD_LVC_DX"].encode()) == 0
+    print(f"training shape B={B} T={T} ({B * T * 256} samples)" + (f", lvc_dx = {os.environ['FD_LVC_DX']}" if os.environ.get("FD_LVC_DX") else ""))
     # frames: kernel_conv hands the LVC operator its frame-major operands (the product path); reference tensor: through the reference's
     # [B, layers, 32, 64, 3, T] kernels and the operator's transposes (module._train_frames = False)
     for name, lvc, frames in (("HIP operator, frames", None, True), ("HIP operator, reference tensor", None, False),
