@@ -1538,43 +1538,6 @@ int fd_lvc_backward(fd_handle h, const float *x, const float *kernel, const floa
 // kernel_conv of the KernelPredictor (training path).  The backward adds up partial sums (row slices for dx, utterance ranges for
 // dweight / dbias, each in a fixed order) through a scratch buffer kept on the handle next to the LVC operator's (same rule: calls on
 // one handle are ordered on one stream).
-int fd_kconv_forward(fd_handle h, const float *x, const float *weight, const float *bias, int B, int M, int T, float *out, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!x || !weight || !bias || !out) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_forward: null pointer");
-    if (B <= 0 || B > 65535) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_forward: B=%d", B);
-    if (!fdk::kconv_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_forward: M=%d (a multiple of 32) and T=%d (1..128) only", M, T);
-    FD_HIP(h, hipSetDevice(h->device));
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::kconv_forward(La, x, weight, bias, out, B, M, T);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_kconv_forward: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_kconv_backward(fd_handle h, const float *x, const float *weight, const float *dout, int B, int M, int T, float *dx, float *dweight,
-                      float *dbias, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!dout || ((dweight || dbias) && !x) || (dx && !weight)) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward: null pointer");
-    if (B <= 0 || B > 65535) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward: B=%d", B);
-    if (!fdk::kconv_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_backward: M=%d (a multiple of 32) and T=%d (1..128) only", M, T);
-    FD_HIP(h, hipSetDevice(h->device));
-    {
-        const size_t bytes = sizeof(float) * fdk::kconv_scratch_floats(B, M, T);
-        if (h->kconv_scratch_bytes < bytes) {
-            if (h->kconv_scratch) FD_HIP(h, hipFree(h->kconv_scratch));
-            h->kconv_scratch = nullptr; h->kconv_scratch_bytes = 0;
-            FD_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->kconv_scratch), bytes));
-            h->kconv_scratch_bytes = bytes;
-        }
-    }
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::kconv_backward(La, x, weight, dout, dx, dweight, dbias, B, M, T, h->kconv_scratch);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_kconv_backward: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-// "frames": kernel_conv and the operator joined through frame-major tensors (include/fastdiff_hip.h)
 static int kconv_scratch_reserve(fd_handle h, int B, int M, int T)
 {
     const size_t bytes = sizeof(float) * fdk::kconv_scratch_floats(B, M, T);
@@ -1586,6 +1549,60 @@ static int kconv_scratch_reserve(fd_handle h, int B, int M, int T)
     }
     return FD_OK;
 }
+
+static int check_act(fd_handle h, int M, int T, float post, const char *who)
+{
+    if (!(post > 0.0f && post <= 1.0f)) FD_FAIL(h, FD_ERR_INVALID, "%s: the leaky-relu slope must lie in (0, 1] (1 = no activation), got %g", who, post);
+    if (post != 1.0f && !fdk::kconv_act_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "%s: the fused activation covers M <= 512 (the predictor's small convolutions), got M=%d", who, M);
+    return FD_OK;
+}
+
+int fd_kconv_forward_act(fd_handle h, const float *x, const float *weight, const float *bias, int B, int M, int T, float post_slope, float *out,
+                         void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!x || !weight || !bias || !out) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_forward: null pointer");
+    if (B <= 0 || B > 65535) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_forward: B=%d", B);
+    if (!fdk::kconv_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_forward: M=%d (a multiple of 32) and T=%d (1..128) only", M, T);
+    const int rc = check_act(h, M, T, post_slope, "fd_kconv_forward");
+    if (rc != FD_OK) return rc;
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::kconv_forward(La, x, weight, bias, out, B, M, T, false, post_slope);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_kconv_forward: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+int fd_kconv_forward(fd_handle h, const float *x, const float *weight, const float *bias, int B, int M, int T, float *out, void *stream)
+{
+    return fd_kconv_forward_act(h, x, weight, bias, B, M, T, 1.0f, out, stream);
+}
+
+int fd_kconv_backward_act(fd_handle h, const float *x, const float *weight, const float *y, const float *dout, int B, int M, int T,
+                          float post_slope, float *dx, float *dweight, float *dbias, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!dout || ((dweight || dbias) && !x) || (dx && !weight)) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward: null pointer");
+    if (B <= 0 || B > 65535) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward: B=%d", B);
+    if (!fdk::kconv_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_backward: M=%d (a multiple of 32) and T=%d (1..128) only", M, T);
+    int rc = check_act(h, M, T, post_slope, "fd_kconv_backward");
+    if (rc != FD_OK) return rc;
+    if (post_slope != 1.0f && !y) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward: a fused activation needs the forward's output y");
+    FD_HIP(h, hipSetDevice(h->device));
+    if ((rc = kconv_scratch_reserve(h, B, M, T)) != FD_OK) return rc;
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::kconv_backward(La, x, weight, dout, dx, dweight, dbias, B, M, T, h->kconv_scratch, false, post_slope != 1.0f ? y : nullptr, post_slope);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_kconv_backward: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+int fd_kconv_backward(fd_handle h, const float *x, const float *weight, const float *dout, int B, int M, int T, float *dx, float *dweight,
+                      float *dbias, void *stream)
+{
+    return fd_kconv_backward_act(h, x, weight, nullptr, dout, B, M, T, 1.0f, dx, dweight, dbias, stream);
+}
+
+// "frames": kernel_conv and the operator joined through frame-major tensors (include/fastdiff_hip.h)
 
 int fd_kconv_forward_frames(fd_handle h, const float *x, const float *weight, const float *bias, int B, int M, int T, float *frames, void *stream)
 {

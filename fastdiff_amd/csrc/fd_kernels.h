@@ -43,9 +43,13 @@ size_t kconv_scratch_floats(int B, int M, int T);
 // operator's forward operand order, dout the same shape in its dK accumulator order (fd_frame_order.h) -- the LVC kernels then read /
 // write the predictor's tensors where they lie
 bool kconv_frames_supported(int M, int T);
-hipError_t kconv_forward(const Launch &L, const float *h, const float *W, const float *bias, float *out, int B, int M, int T, bool frames = false);
+// post / y (M <= 512: the predictor's small convolutions): out = leaky_relu(conv, post); the backward is given that output (y) and
+// takes dout as the gradient behind the activation
+bool kconv_act_supported(int M, int T);
+hipError_t kconv_forward(const Launch &L, const float *h, const float *W, const float *bias, float *out, int B, int M, int T, bool frames = false,
+                         float post = 1.0f);
 hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const float *dout, float *dh, float *dW, float *dbias, int B, int M,
-                          int T, float *scratch, bool frames = false);
+                          int T, float *scratch, bool frames = false, const float *y = nullptr, float post = 1.0f);
 // one layer's "x (+ skip) -> leaky_relu -> dilated Conv1d(32 -> 32, k3) -> bias -> (leaky_relu)" forward and backward for the training
 // path (fd_kernels_cconv.hip); scratch: cconv_scratch_floats() floats for the per-workgroup partial sums of dW / db
 bool cconv_supported(int dil, int64_t len);

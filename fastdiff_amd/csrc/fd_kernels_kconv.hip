@@ -238,8 +238,10 @@ __global__ void __launch_bounds__(256) k_kc_dw_sum(const float *__restrict__ par
 // ---- small M (the predictor's 64 -> 64 convolutions and bias_conv, M = 64 / 256): the kernels above put 128 rows on a workgroup and
 //      walk the utterances one after the other -- with one or two row groups in all that leaves the chip empty (48 / 78 us per launch
 //      at M = 64).  Here a workgroup is (utterance, 64 rows): wave = (32-row tile, half of the column tiles), B * M / 64 workgroups.
+//      post: slope of a leaky-relu on the output (1 = none): the predictor follows each of these convolutions with LeakyReLU(0.1)
+//      (modules.py:296-314); the backward kernels then take the activated output y and scale dout by (y > 0 ? 1 : post) as they load it.
 __global__ void __launch_bounds__(256, 2) k_kcs_fwd(const float *__restrict__ h, const float *__restrict__ W, const float *__restrict__ bias,
-                                                    float *__restrict__ out, int B, int M, int T)
+                                                    float *__restrict__ out, int B, int M, int T, float post)
 {
     __shared__ float hs[CI * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -271,16 +273,16 @@ __global__ void __launch_bounds__(256, 2) k_kcs_fwd(const float *__restrict__ h,
         for (int s = 0; s < 96; ++s) acc = mfma32(f4c(a[s >> 2], s & 3), hb[(s / 3) * LD + (s % 3) + ct * 32], acc);
         if (ct * 32 + l31 < T) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) out[((int64_t)b * M + p0 + drow(r, hi)) * T + ct * 32 + l31] = acc[r];
+            for (int r = 0; r < 16; ++r) out[((int64_t)b * M + p0 + drow(r, hi)) * T + ct * 32 + l31] = acc[r] > 0.0f ? acc[r] : acc[r] * post;
         }
     }
 }
 
 // dW / dbias partial of ONE utterance: part [B][M][192] and, behind it, [B][M]; k_kc_dw_sum adds the utterances in order.
 // wave = (32-row tile, three of the six column tiles (c, k))
-template <bool ALIGNED>
+template <bool ALIGNED, bool ACT>
 __global__ void __launch_bounds__(256, 2) k_kcs_dw(const float *__restrict__ h, const float *__restrict__ dout, float *__restrict__ part,
-                                                   int B, int M, int T)
+                                                   int B, int M, int T, const float *__restrict__ y, float post)
 {
     __shared__ float hs[CI * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -289,19 +291,30 @@ __global__ void __launch_bounds__(256, 2) k_kcs_dw(const float *__restrict__ h, 
     const float *dr = dout + ((int64_t)b * M + (live ? p0 + l31 : 0)) * T;
     const int nq = (T + 7) / 8;
     float4 dv[16];
+    auto row4 = [&](const float *r, int t0) {
+        if (ALIGNED && t0 + 3 < T) return *reinterpret_cast<const float4 *>(r + t0);
+        return make_float4(t0 < T ? r[t0] : 0.0f, t0 + 1 < T ? r[t0 + 1] : 0.0f, t0 + 2 < T ? r[t0 + 2] : 0.0f, t0 + 3 < T ? r[t0 + 3] : 0.0f);
+    };
+    float4 yv[ACT ? 16 : 1];      // ACT: the activated output, requested together with dout (one round trip for both)
+    const float *yr = ACT ? y + ((int64_t)b * M + (live ? p0 + l31 : 0)) * T : nullptr;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int t0 = 8 * q + 4 * hi;
+    for (int q = 0; q < 16; ++q)
         if (q < nq) {
-            if (ALIGNED && t0 + 3 < T) dv[q] = *reinterpret_cast<const float4 *>(dr + t0);
-            else dv[q] = make_float4(t0 < T ? dr[t0] : 0.0f, t0 + 1 < T ? dr[t0 + 1] : 0.0f, t0 + 2 < T ? dr[t0 + 2] : 0.0f, t0 + 3 < T ? dr[t0 + 3] : 0.0f);
+            dv[q] = row4(dr, 8 * q + 4 * hi);
+            if constexpr (ACT) yv[q] = row4(yr, 8 * q + 4 * hi);
         }
-    }
     zero_h(hs, tid);
     __syncthreads();
     stage_h(hs, h, b, T, tid);
     __syncthreads();
     if (!live) return;
+    if constexpr (ACT) {      // the gradient in front of the fused activation
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (q < nq)
+                dv[q] = make_float4(yv[q].x > 0.0f ? dv[q].x : dv[q].x * post, yv[q].y > 0.0f ? dv[q].y : dv[q].y * post,
+                                    yv[q].z > 0.0f ? dv[q].z : dv[q].z * post, yv[q].w > 0.0f ? dv[q].w : dv[q].w * post);
+    }
     f32x16 acc[3];
     const float *hb[3];
 #pragma unroll
@@ -337,9 +350,9 @@ __global__ void __launch_bounds__(256, 2) k_kcs_dw(const float *__restrict__ h, 
 //      wave = one 32-column tile of t (T <= 128), all six 32-row tiles of (c,k); W and dout go through LDS 32 rows at a time ----------
 // FRAMES: a chunk is one 32-row group of a layer's frame order: its rows of W are gathered (768 B each), its piece of dout is 32
 // consecutive floats of every frame of the utterance.
-template <bool FRAMES>
+template <bool FRAMES, bool ACT = false>
 __global__ void __launch_bounds__(256, 2) k_kc_dh(const float *__restrict__ W, const float *__restrict__ dout, float *__restrict__ part,
-                                                  int B, int M, int T, int prows)
+                                                  int B, int M, int T, int prows, const float *__restrict__ y, float post)
 {
     __shared__ __attribute__((aligned(16))) float ws[32 * KK];
     __shared__ float dsm[32 * LDD];
@@ -357,7 +370,7 @@ __global__ void __launch_bounds__(256, 2) k_kc_dh(const float *__restrict__ W, c
     // the current chunk's matrix work
     typedef float f4n __attribute__((ext_vector_type(4)));
     f4n wv[6];      // (a native vector type: the HIP float4 struct kept this prefetch buffer in scratch)
-    float dvv[16];
+    float dvv[16], yvv[ACT ? 16 : 1];      // ACT: the activated output next to dout (k_kcs_fwd)
     const int nd = (32 * T + 255) / 256;          // <= 16
     auto load_chunk = [&](int pc) {
         if constexpr (FRAMES) {
@@ -379,7 +392,11 @@ __global__ void __launch_bounds__(256, 2) k_kc_dh(const float *__restrict__ W, c
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int idx = k * 256 + tid;
-                if (k < nd) dvv[k] = idx < 32 * T ? dout[((int64_t)b * M + pc + idx / T) * T + idx % T] : 0.0f;
+                if (k < nd) {
+                    const int64_t at = ((int64_t)b * M + pc + idx / T) * T + idx % T;
+                    dvv[k] = idx < 32 * T ? dout[at] : 0.0f;
+                    if constexpr (ACT) yvv[k] = idx < 32 * T ? y[at] : 1.0f;
+                }
             }
         }
     };
@@ -393,6 +410,7 @@ __global__ void __launch_bounds__(256, 2) k_kc_dh(const float *__restrict__ W, c
             const int idx = k * 256 + tid;
             if (k < nd && idx < 32 * T) {
                 if constexpr (FRAMES) dsm[(idx & 31) * LDD + (idx >> 5)] = dvv[k];
+                else if constexpr (ACT) dsm[(idx / T) * LDD + idx % T] = yvv[k] > 0.0f ? dvv[k] : dvv[k] * post;      // the gradient in front of the activation
                 else dsm[(idx / T) * LDD + idx % T] = dvv[k];
             }
         }
@@ -462,11 +480,14 @@ size_t kconv_scratch_floats(int B, int M, int T)
     return (size_t)KC_DH_SLICES * B * KK * T + (size_t)(M <= KC_SMALL_M ? std::max(B, KC_DW_RANGES) : KC_DW_RANGES) * M * (KK + 1);
 }
 
-hipError_t kconv_forward(const Launch &L, const float *h, const float *W, const float *bias, float *out, int B, int M, int T, bool frames)
+bool kconv_act_supported(int M, int T) { return kconv_supported(M, T) && M <= KC_SMALL_M; }
+
+hipError_t kconv_forward(const Launch &L, const float *h, const float *W, const float *bias, float *out, int B, int M, int T, bool frames, float post)
 {
     if (frames && !kconv_frames_supported(M, T)) return hipErrorInvalidValue;
+    if (post != 1.0f && !kconv_act_supported(M, T)) return hipErrorInvalidValue;
     if (M <= KC_SMALL_M) {
-        FD_LAUNCH(L, "kconv_forward_small", k_kcs_fwd, dim3(B, (M + 63) / 64), dim3(256), 0, h, W, bias, out, B, M, T);
+        FD_LAUNCH(L, "kconv_forward_small", k_kcs_fwd, dim3(B, (M + 63) / 64), dim3(256), 0, h, W, bias, out, B, M, T, post);
         return hipSuccess;
     }
     const int gx = (M + 127) / 128;
@@ -477,13 +498,16 @@ hipError_t kconv_forward(const Launch &L, const float *h, const float *W, const 
 }
 
 hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const float *dout, float *dh, float *dW, float *dbias, int B, int M,
-                          int T, float *scratch, bool frames)
+                          int T, float *scratch, bool frames, const float *y, float post)
 {
     if (frames && !kconv_frames_supported(M, T)) return hipErrorInvalidValue;
+    if (y && !kconv_act_supported(M, T)) return hipErrorInvalidValue;
     float *part_h = scratch, *part_w = scratch + (size_t)KC_DH_SLICES * B * KK * T;
     if ((dW || dbias) && M <= KC_SMALL_M) {
-        if (T % 4 == 0) FD_LAUNCH(L, "kconv_backward_w_small", k_kcs_dw<true>, dim3(B, (M + 63) / 64), dim3(256), 0, h, dout, part_w, B, M, T);
-        else FD_LAUNCH(L, "kconv_backward_w_small", k_kcs_dw<false>, dim3(B, (M + 63) / 64), dim3(256), 0, h, dout, part_w, B, M, T);
+#define FD_KCS_DW(AL_, ACT_) FD_LAUNCH(L, "kconv_backward_w_small", (k_kcs_dw<AL_, ACT_>), dim3(B, (M + 63) / 64), dim3(256), 0, h, dout, part_w, B, M, T, y, post)
+        if (T % 4 == 0) { if (y) FD_KCS_DW(true, true); else FD_KCS_DW(true, false); }
+        else { if (y) FD_KCS_DW(false, true); else FD_KCS_DW(false, false); }
+#undef FD_KCS_DW
         FD_LAUNCH(L, "kconv_backward_w_sum", k_kc_dw_sum, dim3((unsigned)(((int64_t)M * (KK + 1) + 255) / 256)), dim3(256), 0, (const float *)part_w, dW,
                   dbias, M, B);
     } else if (dW || dbias) {
@@ -503,8 +527,9 @@ hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const
             const int64_t cost = (int64_t)(((int64_t)n * B + L.ctx->num_cus - 1) / L.ctx->num_cus) * (chunks / n);
             if (cost < best) { best = cost; nks = n; }
         }
-        if (frames) FD_LAUNCH(L, "kconv_backward_h", k_kc_dh<true>, dim3(nks, B), dim3(256), 0, W, dout, part_h, B, M, T, M / nks);
-        else FD_LAUNCH(L, "kconv_backward_h", k_kc_dh<false>, dim3(nks, B), dim3(256), 0, W, dout, part_h, B, M, T, M / nks);
+        if (frames) FD_LAUNCH(L, "kconv_backward_h", (k_kc_dh<true, false>), dim3(nks, B), dim3(256), 0, W, dout, part_h, B, M, T, M / nks, (const float *)nullptr, 1.0f);
+        else if (y) FD_LAUNCH(L, "kconv_backward_h", (k_kc_dh<false, true>), dim3(nks, B), dim3(256), 0, W, dout, part_h, B, M, T, M / nks, y, post);
+        else FD_LAUNCH(L, "kconv_backward_h", (k_kc_dh<false, false>), dim3(nks, B), dim3(256), 0, W, dout, part_h, B, M, T, M / nks, y, post);
         FD_LAUNCH(L, "kconv_backward_h_fold", k_kc_dh_fold, dim3((B * CI * T + 255) / 256), dim3(256), 0, (const float *)part_h, dh, B, T, nks);
     }
     return hipSuccess;

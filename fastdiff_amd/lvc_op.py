@@ -163,37 +163,43 @@ def gated_residual(x, y):
 
 class _KConv(torch.autograd.Function):
     """KernelPredictor.kernel_conv (modules.py:315-318,330-331: Conv1d(64 -> M, k3, pad 1)) forward and backward on fp32-MFMA HIP
-    kernels (fd_kconv_forward / fd_kconv_backward), the reference's layouts."""
+    kernels (fd_kconv_forward / fd_kconv_backward), the reference's layouts.  post_slope != 1 (M <= 512): the LeakyReLU the predictor
+    puts behind its small convolutions (modules.py:296-314) inside the same launches (fd_kconv_forward_act / fd_kconv_backward_act)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, post_slope=1.0):
         ctx.in_dtypes = (x.dtype, weight.dtype, bias.dtype)
         x, weight, bias = x.contiguous().float(), weight.contiguous().float(), bias.contiguous().float()
         B, _, T = x.shape
         M = weight.shape[0]
         out = torch.empty((B, M, T), device=x.device, dtype=torch.float32)
         lib, h = _handle(x.device)
-        _capi.check(lib, h, lib.fd_kconv_forward(h, x.data_ptr(), weight.data_ptr(), bias.data_ptr(), B, M, T, out.data_ptr(), _stream(x.device)),
-                    "fd_kconv_forward")
-        ctx.save_for_backward(x, weight)
+        _capi.check(lib, h, lib.fd_kconv_forward_act(h, x.data_ptr(), weight.data_ptr(), bias.data_ptr(), B, M, T, float(post_slope), out.data_ptr(),
+                                                     _stream(x.device)), "fd_kconv_forward")
+        ctx.post = float(post_slope)
+        if ctx.post != 1.0:
+            ctx.save_for_backward(x, weight, out)
+        else:
+            ctx.save_for_backward(x, weight)
         return out.to(ctx.in_dtypes[0])
 
     @staticmethod
     def backward(ctx, dout):
-        x, weight = ctx.saved_tensors
+        x, weight = ctx.saved_tensors[:2]
+        y = ctx.saved_tensors[2] if ctx.post != 1.0 else None
         dout = dout.contiguous().float()
         B, _, T = x.shape
         M = weight.shape[0]
-        need_x, need_w, need_b = ctx.needs_input_grad
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
         dx = torch.empty_like(x) if need_x else None
         dw = torch.empty_like(weight) if need_w else None
         db = torch.empty((M,), device=x.device, dtype=torch.float32) if need_b else None
         lib, h = _handle(x.device)
-        _capi.check(lib, h, lib.fd_kconv_backward(h, x.data_ptr(), weight.data_ptr(), dout.data_ptr(), B, M, T,
-                                                  None if dx is None else dx.data_ptr(), None if dw is None else dw.data_ptr(),
-                                                  None if db is None else db.data_ptr(), _stream(x.device)), "fd_kconv_backward")
+        _capi.check(lib, h, lib.fd_kconv_backward_act(h, x.data_ptr(), weight.data_ptr(), None if y is None else y.data_ptr(), dout.data_ptr(), B, M, T,
+                                                      ctx.post, None if dx is None else dx.data_ptr(), None if dw is None else dw.data_ptr(),
+                                                      None if db is None else db.data_ptr(), _stream(x.device)), "fd_kconv_backward")
         tx, tw, tb = ctx.in_dtypes
-        return (None if dx is None else dx.to(tx), None if dw is None else dw.to(tw), None if db is None else db.to(tb))
+        return (None if dx is None else dx.to(tx), None if dw is None else dw.to(tw), None if db is None else db.to(tb), None)
 
 
 class _Conv7(torch.autograd.Function):
@@ -402,10 +408,11 @@ def kernel_conv_supported(x, weight):
             and weight.shape[0] % 32 == 0 and 1 <= x.shape[2] <= 128)
 
 
-def kernel_conv1d(x, weight, bias):
-    """conv1d(x [B,64,T], weight [M,64,3], bias [M], padding=1) -> [B,M,T] as a differentiable HIP operator (the predictor's
-    kernel_conv); shapes outside kernel_conv_supported() are refused by the library (FD_ERR_UNSUPPORTED)."""
-    return _KConv.apply(x, weight, bias)
+def kernel_conv1d(x, weight, bias, post_slope=1.0):
+    """leaky_relu(conv1d(x [B,64,T], weight [M,64,3], bias [M], padding=1), post_slope) -> [B,M,T] as a differentiable HIP operator
+    (the predictor's kernel_conv, and with post_slope = 0.1 and M = 64 its residual convolutions with their activation); shapes outside
+    kernel_conv_supported(), or an activation on M > 512, are refused by the library (FD_ERR_UNSUPPORTED)."""
+    return _KConv.apply(x, weight, bias, post_slope)
 
 
 def location_variable_convolution(x, kernel, bias, dilation=1, hop_size=256, grad_slot=None):

@@ -71,24 +71,37 @@ def _dblock(p, x, cconv=None):
     return x + residual
 
 
-def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None, split=None, frames=None):
+def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None, split=None, frames=None, fuse_act=True):
     """KernelPredictor.forward (modules.py:320-343).  kconv: the HIP operator for kernel_conv (64 -> 24576 channels: the largest
     matrix product of the step) where its shapes fit, else the module's own convolution.  frames (the product path): kernel_conv
     writes the LVC operator's frame-major operand order directly -- [B, layers, T, 6144] instead of the reference's
     [B, layers, 32, 64, 3, T] -- and reads the gradient that way (lvc_op: kernel_conv1d_frames); the third return value says so."""
     B, _, T = c.shape
 
+    def fits(m, h):
+        return kconv is not None and isinstance(m, torch.nn.Conv1d) and m.padding == (1,) and m.dilation == (1,) and \
+            kconv[1](h, m.weight_v if hasattr(m, "weight_v") else m.weight)
+
     def conv(m, h):      # a 64 -> M, k3 convolution of the predictor: the HIP operator where its shapes fit, else the module itself
-        if kconv is not None and isinstance(m, torch.nn.Conv1d) and m.padding == (1,) and m.dilation == (1,) and \
-                kconv[1](h, m.weight_v if hasattr(m, "weight_v") else m.weight):
+        if fits(m, h):
             return kconv[0](h, _conv_weight(m), m.bias)
         return _conv(m, h) if isinstance(m, torch.nn.Conv1d) else m(h)
 
-    for m in p.input_conv:                       # Conv1d 80 -> 64 k5, LeakyReLU(0.1)
-        c = conv(m, c)
-    r = c
-    for m in p.residual_conv:                    # Dropout(p = 0), Conv1d 64 -> 64 k3, LeakyReLU(0.1), Conv1d, LeakyReLU, three times
-        r = conv(m, r) if isinstance(m, torch.nn.Conv1d) else m(r)
+    def run(seq, h):     # a Sequential of the predictor; "Conv1d, LeakyReLU" pairs run as ONE operator where the convolution fits
+        mods, i = list(seq), 0
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if fuse_act and fits(m, h) and isinstance(nxt, torch.nn.LeakyReLU) and m.out_channels <= 512:
+                h = kconv[0](h, _conv_weight(m), m.bias, nxt.negative_slope)
+                i += 2
+            else:
+                h = conv(m, h)
+                i += 1
+        return h
+
+    c = run(p.input_conv, c)                     # Conv1d 80 -> 64 k5, LeakyReLU(0.1)
+    r = run(p.residual_conv, c)                  # Dropout(p = 0), Conv1d 64 -> 64 k3, LeakyReLU(0.1), Conv1d, LeakyReLU, three times
     c = c + r
     kc = p.kernel_conv
     if frames is not None and split is not None and (cin, cout, ks) == (32, 64, 3) and \
@@ -111,12 +124,12 @@ def _torch_gate(x, y):
     return x + torch.sigmoid(y[:, :C]) * torch.tanh(y[:, C:])
 
 
-def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate, kconv=None, cconv=None, split=None, frames=None):
+def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate, kconv=None, cconv=None, split=None, frames=None, fuse_act=True):
     """TimeAware_LVCBlock.forward (modules.py:189-218); the in-place `x += audio_down` of the reference written out of place."""
     C = cfg["inner_channels"]
     cond = c + p.fc_t(emb).unsqueeze(-1)
     (kernels, slots), bias, as_frames = _kernel_predictor(p.kernel_predictor, cond, cfg["lvc_layers_each_block"], C, 2 * C, cfg["lvc_kernel_size"],
-                                                          kconv, split if kconv is not None else None, frames if kconv is not None else None)
+                                                          kconv, split if kconv is not None else None, frames if kconv is not None else None, fuse_act)
     if cconv is not None and x.is_cuda:
         from .lvc_op import upsample, upsample_supported
     if cconv is not None and x.is_cuda and upsample_supported(x, p.upsample):
@@ -162,5 +175,6 @@ def differentiable_forward(module, data, lvc=None):
         skips.append(x)
         x = _dblock(down, x, cconv)
     for n, audio_down in enumerate(reversed(skips)):
-        x = _lvc_block(module.lvc_blocks[n], x, audio_down, c, emb, cfg, lvc, gate, kconv, cconv, split, frames)
+        x = _lvc_block(module.lvc_blocks[n], x, audio_down, c, emb, cfg, lvc, gate, kconv, cconv, split, frames,
+                       getattr(module, "_train_fuse_act", True))      # (False: the predictor's LeakyReLUs as torch nodes, for A/B runs)
     return _conv(module.final_conv[0], x)

@@ -188,6 +188,13 @@ FD_API int fd_lvc_backward_strided(fd_handle h, const float *x, const float *ker
 FD_API int fd_kconv_forward(fd_handle h, const float *x, const float *weight, const float *bias, int B, int M, int T, float *out, void *stream);
 FD_API int fd_kconv_backward(fd_handle h, const float *x, const float *weight, const float *dout, int B, int M, int T, float *dx,
                              float *dweight, float *dbias, void *stream);
+/* The same with the activation the predictor puts behind its small convolutions (modules.py:296-314: Conv1d, LeakyReLU(0.1)) inside:
+ * out = leaky_relu(conv, post_slope); the backward takes that output (y) and dout = the gradient behind the activation.  M <= 512
+ * (input and residual convolutions: M = 64); post_slope = 1 is the plain convolution (y may then be NULL). */
+FD_API int fd_kconv_forward_act(fd_handle h, const float *x, const float *weight, const float *bias, int B, int M, int T, float post_slope,
+                                float *out, void *stream);
+FD_API int fd_kconv_backward_act(fd_handle h, const float *x, const float *weight, const float *y, const float *dout, int B, int M, int T,
+                                 float post_slope, float *dx, float *dweight, float *dbias, void *stream);
 
 /* The same two operators joined without the reference's tensor in between ("frames").  The reference hands the predicted kernels from
  * kernel_conv to the location-variable convolution as [B, layers, 32, 64, 3, T] (modules.py:333-338; T innermost), which the matrix

@@ -197,6 +197,41 @@ def test_kernel_conv_operator_forward_and_backward_match_torch_autograd(shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 64, 100), (2, 64, 37), (20, 64, 100), (2, 256, 1), (1, 96, 128)])
+def test_kernel_conv_with_its_activation_inside_matches_torch_autograd(shape):
+    """kernel_conv1d(..., post_slope = 0.1) = `Conv1d(64 -> 64, k3), LeakyReLU(0.1)` of the predictor's residual stack (modules.py:296-314)
+    as ONE operator each way: output and the three gradients against the two torch modules in float64, zeros and negative values of the
+    pre-activation included; the plain operator followed by torch's leaky_relu gives the same bits (same kernels, the activation in the
+    store / in the load of dout).  M > 512 (kernel_conv itself has no activation) is refused."""
+    import fastdiff_amd
+    import torch.nn.functional as F
+    B, M, T = shape
+    g = torch.Generator().manual_seed(3 * M + T)
+    x = torch.randn(B, 64, T, generator=g)
+    w = torch.randn(M, 64, 3, generator=g) / 14.0
+    bias = torch.randn(M, generator=g)
+    w[0] = 0.0
+    bias[0] = 0.0                                                                   # a row whose pre-activation is exactly 0
+    dout = torch.randn(B, M, T, generator=g)
+    x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, bias))
+    ref = F.leaky_relu(F.conv1d(x64, w64, b64, padding=1), 0.1)
+    ref.backward(dout.double())
+    xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, bias))
+    out = fastdiff_amd.kernel_conv1d(xg, wg, bg, 0.1)
+    out.backward(dout.cuda())
+    rel = lambda got, want: float((got.double().cpu() - want).abs().max()) / max(1.0, float(want.abs().max()))      # noqa: E731
+    assert rel(out, ref.detach()) < 2e-6
+    assert rel(xg.grad, x64.grad) < 3e-6 and rel(wg.grad, w64.grad) < 3e-6 and rel(bg.grad, b64.grad) < 3e-6
+    xp, wp, bp = (t.cuda().requires_grad_(True) for t in (x, w, bias))
+    out2 = F.leaky_relu(fastdiff_amd.kernel_conv1d(xp, wp, bp), 0.1)
+    out2.backward(dout.cuda())
+    assert torch.equal(out2.detach(), out.detach())
+    assert torch.equal(xp.grad, xg.grad) and torch.equal(wp.grad, wg.grad) and torch.equal(bp.grad, bg.grad)
+    with pytest.raises(NotImplementedError, match="512"):
+        fastdiff_amd.kernel_conv1d(torch.zeros(1, 64, 8).cuda(), torch.zeros(1024, 64, 3).cuda(), torch.zeros(1024).cuda(), 0.1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,L,dil,skip,post", [(2, 1024, 1, True, 0.2), (3, 388, 3, True, 0.2), (1, 2560, 9, True, 0.2), (2, 904, 27, True, 0.2),
                                                 (2, 640, 1, False, 1.0), (1, 132, 2, False, 1.0), (3, 260, 4, False, 1.0), (1, 4, 27, True, 0.2),
                                                 (20, 25600, 27, True, 0.2)])

@@ -69,31 +69,42 @@ def main():
         except Exception as e:      # noqa: BLE001 -- e.g. out of memory in the unfold view's backward
             print(f"  LVC = {name}: failed: {e!r}")
     m._train_frames = True
-    # the same step captured once in a hipGraph (torch.cuda.graph) and replayed: what is left when the ~1500 kernel launches of a step
-    # cost no host time
-    try:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                step(None)
-        torch.cuda.current_stream().wait_stream(side)
-        m.zero_grad(set_to_none=True)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            eps = train.differentiable_forward(m, (x, mel, steps), lvc=None)
-            loss = F.mse_loss(eps, z)
-            loss.backward()
-        graph.replay()
-        torch.cuda.synchronize()
-        g_graph = {n: p.grad.clone() for n, p in m.named_parameters()}
-        loss_graph = float(loss)
-        step(None)
-        torch.cuda.synchronize()
-        worst = max(float((g_graph[n] - p.grad).abs().max()) / max(float(p.grad.abs().max()), 1e-20) for n, p in m.named_parameters())
-        print(f"  forward + backward, LVC = HIP operator, replayed from a hipGraph: {timed(graph.replay):8.2f} ms   (loss {loss_graph:.6f}; gradients vs the eager step: max relative difference {worst:.1e})")
-    except Exception as e:      # noqa: BLE001
-        print(f"  hipGraph capture of the training step failed: {e!r}")
+    # the same step captured once in a hipGraph (torch.cuda.graph) and replayed: what is left when the ~500 kernel launches of a step
+    # cost no host time.  Variants: FD_TRAIN_VARIANTS=1 also replays the step without frames / without the fused predictor activations
+    def graph_run(label, **attrs):
+        try:
+            for k, v in attrs.items():
+                setattr(m, k, v)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step(None)
+            torch.cuda.current_stream().wait_stream(side)
+            m.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                eps = train.differentiable_forward(m, (x, mel, steps), lvc=None)
+                loss = F.mse_loss(eps, z)
+                loss.backward()
+            graph.replay()
+            torch.cuda.synchronize()
+            g_graph = {n: p.grad.clone() for n, p in m.named_parameters()}
+            loss_graph = float(loss.detach())
+            step(None)
+            torch.cuda.synchronize()
+            worst = max(float((g_graph[n] - p.grad).abs().max()) / max(float(p.grad.abs().max()), 1e-20) for n, p in m.named_parameters())
+            print(f"  forward + backward, LVC = HIP operator{label}, replayed from a hipGraph: {timed(graph.replay):8.2f} ms   eager: {timed(lambda: step(None)):8.2f} ms   (loss {loss_graph:.6f}; gradients vs the eager step: max relative difference {worst:.1e})")
+        except Exception as e:      # noqa: BLE001
+            print(f"  hipGraph capture of the training step{label} failed: {e!r}")
+        finally:
+            m._train_frames, m._train_fuse_act = True, True
+
+    graph_run("")
+    if os.environ.get("FD_TRAIN_VARIANTS"):
+        graph_run(" [predictor activations as torch nodes]", _train_fuse_act=False)
+        graph_run(" [reference kernel tensor + transposes]", _train_frames=False)
+        graph_run("")
     for hop in (8, 64, 256):
         L = T * hop
         y = torch.randn(B, 32, L, device="cuda", requires_grad=True)
