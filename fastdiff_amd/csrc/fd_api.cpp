@@ -918,19 +918,24 @@ static int stage_commit(fd_handle h, fd_context::StageSlot *sl, hipStream_t stre
 }
 
 // One stream at a time per handle: a call on another stream than the previous one first settles what is pending there and then makes
-// the new stream wait for the old one (workspace, embedding rows and step parameters are reused from call to call).
+// the new stream wait for the tail of the handle's last call (workspace, embedding rows and step parameters are reused from call to
+// call).  The tail is an EVENT recorded at the end of every call (mark_tail), not the old stream itself: the caller may have
+// destroyed that stream since (its work done), and the runtime does not survive a call on a destroyed stream handle
+// (tools/stream_switch_probe.py: a hipEventRecord there takes the process down); an event outlives its stream.
+static int mark_tail(fd_handle h, hipStream_t s)
+{
+    if (!h->ev_switch) FD_HIP(h, hipEventCreateWithFlags(&h->ev_switch, hipEventDisableTiming));
+    FD_HIP(h, hipEventRecord(h->ev_switch, s));
+    h->tail_marked = true;
+    return FD_OK;
+}
+
 static int follow_stream(fd_handle h, hipStream_t s)
 {
     if (h->have_last_stream && h->last_stream != s) {
-        const int rc = settle(h);
+        const int rc = settle(h);      // (a pending check may redo its call on the old stream: that stream must live until the call is settled)
         if (rc != FD_OK) return rc;
-        if (!h->ev_switch) FD_HIP(h, hipEventCreateWithFlags(&h->ev_switch, hipEventDisableTiming));
-        if (hipEventRecord(h->ev_switch, h->last_stream) == hipSuccess) {
-            FD_HIP(h, hipStreamWaitEvent(s, h->ev_switch, 0));
-        } else {                                     // the old stream is gone (destroyed by its owner): wait for the device instead
-            (void)hipGetLastError();
-            FD_HIP(h, hipDeviceSynchronize());
-        }
+        if (h->tail_marked) FD_HIP(h, hipStreamWaitEvent(s, h->ev_switch, 0));
     }
     h->last_stream = s;
     h->have_last_stream = true;
@@ -987,7 +992,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
     if (e == hipSuccess) e = fdk::run_step(L, io, B, T);
     if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_forward: kernel launch failed: %s", hipGetErrorString(e));
     h->last_B = B; h->last_T = T;
-    return FD_OK;
+    return mark_tail(h, (hipStream_t)stream);
 }
 
 static unsigned mode_signature(const fd_context *h)
@@ -1283,7 +1288,7 @@ static int sample_core(fd_handle h, const fd_context::SampleArgs &a, unsigned fo
         FD_HIP(h, hipMemcpyAsync(a.out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
     }
     h->last_B = B; h->last_T = T;
-    return FD_OK;
+    return mark_tail(h, stream);      // (also behind a redo: resolve_call comes through here)
 }
 
 int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, const fd_step *table, int N, int ddim,

@@ -210,7 +210,8 @@ struct fd_context {
     // stream waits for everything the old one still holds (follow_stream in fd_api.cpp).
     hipStream_t last_stream = nullptr;
     bool have_last_stream = false;
-    hipEvent_t ev_switch = nullptr;
+    hipEvent_t ev_switch = nullptr;          // the tail of the handle's last compute call (fd_api.cpp: mark_tail / follow_stream)
+    bool tail_marked = false;
     // option overlap = gemm: the predictor GEMM of blocks 1 and 2 runs on `side_stream` next to the LVC layers of blocks 0 and 1
     // (fork / join through events; inside a captured step the side stream joins the capture).  overlap_wg: its workgroups per CU.
     // The predictor (front + GEMM) sees the mel and the step embedding only -- never x -- so for a short schedule on a small batch all N

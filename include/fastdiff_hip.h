@@ -11,8 +11,10 @@
  *   - a handle is bound to one device and is NOT thread safe (one handle per GPU/stream, like one
  *     reference process per GPU under mp.spawn, utils/trainer.py:94-107).  Its calls share one workspace and are ordered by the
  *     stream they run on: when fd_forward / fd_sample arrive on another stream than the previous call, a pending range check is
- *     settled first and the new stream is made to wait for the old one (an event), so consecutive calls may change streams but
- *     never overlap.
+ *     settled first and the new stream is made to wait for the tail of the previous call (an event recorded at the end of every
+ *     call), so consecutive calls may change streams but never overlap.  A stream may be destroyed once the calls made on it are
+ *     SETTLED (fd_sample_check / fd_sample_settle, or any later fd_sample / fd_forward on the handle has returned): a pending
+ *     range check may have to run its call again on that stream; the library never touches a previous call's stream otherwise.
  *   - device pointers are caller-owned; all work is enqueued asynchronously on `stream`
  *     (a hipStream_t passed as void*; NULL = the default stream).  No hidden synchronisation except
  *     in fd_create / fd_destroy / fd_commit_weights / fd_read_tap / workspace growth.

@@ -5,6 +5,9 @@ Tolerances: the reference's own fp32-vs-fp64 noise
 |y| <= 8, so  single forward  max|d| <= 2e-5;   N<=8 loop with injected noise  max|d| <= 1e-4;
 N=1000 loop: within 10x of the fp32 reference's own drift against its fp64 run.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -723,6 +726,50 @@ def test_embedding_table_kept_between_calls(gc, sched):
         audio = torch.from_numpy(synth.synth_audio(61, B, T)).cuda()
         m((audio, mel, torch.full((B, 1), 7.0).cuda()))                           # fd_forward writes its own rows into the table
         assert torch.equal(m.sample(mel, rows4, seed=3), want["4"])
+
+
+def test_consecutive_calls_may_change_streams(gc, sched):
+    """One handle, calls on different streams (fd_api.cpp: follow_stream): a call arriving on another stream than the previous one settles
+    the pending range check and waits for the tail of the previous call (an event recorded at the end of every call) -- deferred checks,
+    cached graphs, the shared workspace and the embedding table included.  Every result must equal a fresh handle's."""
+    import synth
+    B, T = 2, 33
+    mel = torch.from_numpy(synth.synth_mel(77, B, T)).cuda()
+    mel2 = torch.from_numpy(synth.synth_mel(78, 1, 50)).cuda()
+    rows, _ = gc.table_rows(sched, 4)
+    rows6, _ = gc.table_rows(sched, 6)
+    audio = torch.from_numpy(synth.synth_audio(77, B, T)).cuda()
+    steps = torch.full((B, 1), 7.0).cuda()
+    with torch.no_grad():
+        want_a = gc.make_model().sample(mel, rows, seed=3)
+        want_b = gc.make_model().sample(mel2, rows6, seed=4)
+        want_f = gc.make_model()((audio, mel, steps))
+        m = gc.make_model()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        got = []
+        for rnd in range(3):
+            with torch.cuda.stream(s1):
+                a = m.sample(mel, rows, seed=3, defer_check=True)          # its check is still pending when the next call arrives on s2
+            with torch.cuda.stream(s2):
+                b = m.sample(mel2, rows6, seed=4, defer_check=(rnd == 1))
+            f = m((audio, mel, steps))                                     # default stream
+            with torch.cuda.stream(s1):
+                a2 = m.sample(mel, rows, seed=3)
+            got.append((a, b, f, a2))
+        torch.cuda.synchronize()
+        assert m.check() is False
+        for a, b, f, a2 in got:
+            assert torch.equal(a, want_a) and torch.equal(a2, want_a) and torch.equal(b, want_b) and torch.equal(f, want_f)
+
+
+def test_a_stream_destroyed_between_two_calls():
+    """The library must not touch the stream of an earlier, settled call: the caller may have destroyed it (a hipEventRecord on a destroyed
+    stream handle takes the process down on this runtime -- which is why this runs in a process of its own)."""
+    import subprocess
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stream_switch_probe.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "destroyed stream: ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
 
 
 def test_graph_cache_alternating_shapes(gc, sched):
