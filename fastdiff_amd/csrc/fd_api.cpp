@@ -1607,6 +1607,52 @@ int fd_kconv_backward(fd_handle h, const float *x, const float *weight, const fl
     return fd_kconv_backward_act(h, x, weight, nullptr, dout, B, M, T, 1.0f, dx, dweight, dbias, stream);
 }
 
+// The predictor's input convolution (80 -> 64, k5) with its activation (fd_kernels_kconv.hip: k_ic_*); per-utterance partial sums of
+// the weight gradient in the kernel_conv scratch.
+static int check_input_conv(fd_handle h, int B, int T, float post, const char *who)
+{
+    if (B <= 0 || B > 65535) FD_FAIL(h, FD_ERR_INVALID, "%s: B=%d", who, B);
+    if (T < 1 || T > 128) FD_FAIL(h, FD_ERR_UNSUPPORTED, "%s: T=%d (1..128) only", who, T);
+    if (!(post > 0.0f && post <= 1.0f)) FD_FAIL(h, FD_ERR_INVALID, "%s: the leaky-relu slope must lie in (0, 1] (1 = no activation), got %g", who, post);
+    return FD_OK;
+}
+
+int fd_input_conv_forward(fd_handle h, const float *x, const float *weight, const float *bias, int B, int T, float post_slope, float *out, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!x || !weight || !bias || !out) FD_FAIL(h, FD_ERR_INVALID, "fd_input_conv_forward: null pointer");
+    const int rc = check_input_conv(h, B, T, post_slope, "fd_input_conv_forward");
+    if (rc != FD_OK) return rc;
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::input_conv_forward(La, x, weight, bias, out, B, T, post_slope);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_input_conv_forward: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+int fd_input_conv_backward(fd_handle h, const float *x, const float *weight, const float *y, const float *dout, int B, int T, float post_slope,
+                           float *dx, float *dweight, float *dbias, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!dout || !y || ((dweight || dbias) && !x) || (dx && !weight)) FD_FAIL(h, FD_ERR_INVALID, "fd_input_conv_backward: null pointer");
+    int rc = check_input_conv(h, B, T, post_slope, "fd_input_conv_backward");
+    if (rc != FD_OK) return rc;
+    FD_HIP(h, hipSetDevice(h->device));
+    {
+        const size_t bytes = sizeof(float) * fdk::input_conv_scratch_floats(B);
+        if (h->kconv_scratch_bytes < bytes) {
+            if (h->kconv_scratch) FD_HIP(h, hipFree(h->kconv_scratch));
+            h->kconv_scratch = nullptr; h->kconv_scratch_bytes = 0;
+            FD_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->kconv_scratch), bytes));
+            h->kconv_scratch_bytes = bytes;
+        }
+    }
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::input_conv_backward(La, x, weight, y, dout, dx, dweight, dbias, B, T, post_slope, h->kconv_scratch);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_input_conv_backward: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
 // "frames": kernel_conv and the operator joined through frame-major tensors (include/fastdiff_hip.h)
 
 int fd_kconv_forward_frames(fd_handle h, const float *x, const float *weight, const float *bias, int B, int M, int T, float *frames, void *stream)

@@ -50,6 +50,12 @@ hipError_t kconv_forward(const Launch &L, const float *h, const float *W, const 
                          float post = 1.0f);
 hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const float *dout, float *dh, float *dW, float *dbias, int B, int M,
                           int T, float *scratch, bool frames = false, const float *y = nullptr, float post = 1.0f);
+// the predictor's input convolution with its activation: leaky_relu(Conv1d(80 -> 64, k5, pad 2), post) (modules.py:292-295), T <= 128;
+// the backward takes the activated output y; scratch: input_conv_scratch_floats(B) floats
+size_t input_conv_scratch_floats(int B);
+hipError_t input_conv_forward(const Launch &L, const float *x, const float *w, const float *bias, float *out, int B, int T, float post);
+hipError_t input_conv_backward(const Launch &L, const float *x, const float *w, const float *y, const float *dy, float *dx, float *dw, float *db, int B,
+                               int T, float post, float *scratch);
 // one layer's "x (+ skip) -> leaky_relu -> dilated Conv1d(32 -> 32, k3) -> bias -> (leaky_relu)" forward and backward for the training
 // path (fd_kernels_cconv.hip); scratch: cconv_scratch_floats() floats for the per-workgroup partial sums of dW / db
 bool cconv_supported(int dil, int64_t len);

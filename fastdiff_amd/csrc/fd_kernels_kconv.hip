@@ -219,9 +219,10 @@ __global__ void __launch_bounds__(256, 2) k_kc_dw(const float *__restrict__ h, c
 }
 
 // the utterance ranges added up in a fixed order: dW [M][192] and dbias [M] (either may be null)
-__global__ void __launch_bounds__(256) k_kc_dw_sum(const float *__restrict__ part, float *__restrict__ dW, float *__restrict__ dbias, int M, int ny)
+__global__ void __launch_bounds__(256) k_kc_dw_sum(const float *__restrict__ part, float *__restrict__ dW, float *__restrict__ dbias, int M, int ny,
+                                                   int kk)      // kk: columns of dW (192; the input convolution: 400)
 {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, nW = (int64_t)M * KK;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, nW = (int64_t)M * kk;
     if (idx < nW) {
         if (!dW) return;
         float v = 0.0f;
@@ -452,6 +453,140 @@ __global__ void __launch_bounds__(256) k_kc_dh_fold(const float *__restrict__ pa
     dh[idx] = v;
 }
 
+// ---- the predictor's input convolution with its activation: Conv1d(80 -> 64, k5, pad 2), LeakyReLU (modules.py:292-295) -----------
+//      0.1 GFLOP at the training shape: plain VALU through LDS, workgroup = (utterance, 16 channels), thread = (channel, 8 frames).
+//      xs / gs rows: [2 zeros][T values][zeros up to IC_LD], so that a thread's 12-float window is three aligned ds_read_b128.
+constexpr int IC_CI = 80, IC_CO = 64, IC_K = 5, IC_KK = IC_CI * IC_K, IC_LD = 136;
+
+__device__ __forceinline__ void ic_stage_x(float *__restrict__ xs, const float *__restrict__ x, int b, int T, int tid)
+{
+    for (int idx = tid; idx < IC_CI * IC_LD; idx += 256) {
+        const int c = idx / IC_LD, t = idx - c * IC_LD - 2;
+        xs[idx] = (t >= 0 && t < T) ? x[((int64_t)b * IC_CI + c) * T + t] : 0.0f;
+    }
+}
+// the gradient in front of the activation: dy * (y > 0 ? 1 : post), rows o0 .. o0 + rows - 1
+__device__ __forceinline__ void ic_stage_g(float *__restrict__ gs, const float *__restrict__ dy, const float *__restrict__ y, int b, int o0, int rows,
+                                           int T, float post, int tid)
+{
+    for (int idx = tid; idx < rows * IC_LD; idx += 256) {
+        const int o = idx / IC_LD, t = idx - o * IC_LD - 2;
+        float v = 0.0f;
+        if (t >= 0 && t < T) {
+            const int64_t at = ((int64_t)b * IC_CO + o0 + o) * T + t;
+            v = y[at] > 0.0f ? dy[at] : dy[at] * post;
+        }
+        gs[idx] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ic_fwd(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                                                float *__restrict__ out, int T, float post)
+{
+    __shared__ __attribute__((aligned(16))) float xs[IC_CI * IC_LD];
+    const int b = blockIdx.x, tid = threadIdx.x, o = blockIdx.y * 16 + (tid >> 4), t0 = (tid & 15) * 8;
+    ic_stage_x(xs, x, b, T, tid);
+    __syncthreads();
+    if (t0 >= T) return;
+    float acc[8];
+    const float bv = bias[o];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bv;
+    const float *wr = w + (int64_t)o * IC_KK;
+    for (int c = 0; c < IC_CI; ++c) {
+        float win[12];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(xs + c * IC_LD + t0 + 4 * q);
+            win[4 * q] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int k = 0; k < IC_K; ++k) {      // x[t + k - 2] = xs[t + k]
+            const float wv = wr[c * IC_K + k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(wv, win[j + k], acc[j]);
+        }
+    }
+    float *orow = out + ((int64_t)b * IC_CO + o) * T + t0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (t0 + j < T) orow[j] = acc[j] > 0.0f ? acc[j] : acc[j] * post;
+}
+
+// dx[b, c, t] = sum_{o, k} w[o, c, k] g[b, o, t + 2 - k]: workgroup = (utterance, 16 input channels)
+__global__ void __launch_bounds__(256) k_ic_bwd_x(const float *__restrict__ w, const float *__restrict__ dy, const float *__restrict__ y,
+                                                  float *__restrict__ dx, int T, float post)
+{
+    __shared__ __attribute__((aligned(16))) float gs[IC_CO * IC_LD];
+    const int b = blockIdx.x, tid = threadIdx.x, c = blockIdx.y * 16 + (tid >> 4), t0 = (tid & 15) * 8;
+    ic_stage_g(gs, dy, y, b, 0, IC_CO, T, post, tid);
+    __syncthreads();
+    if (t0 >= T) return;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+    for (int o = 0; o < IC_CO; ++o) {
+        float win[12];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(gs + o * IC_LD + t0 + 4 * q);
+            win[4 * q] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
+        }
+        const float *wr = w + (int64_t)o * IC_KK + c * IC_K;
+#pragma unroll
+        for (int k = 0; k < IC_K; ++k) {      // g[t + 2 - k] = gs[t + 4 - k]
+            const float wv = wr[k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(wv, win[j + 4 - k], acc[j]);
+        }
+    }
+    float *drow = dx + ((int64_t)b * IC_CI + c) * T + t0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (t0 + j < T) drow[j] = acc[j];
+}
+
+// this utterance's share of dW[o, c, k] = sum_t g[o, t] x[c, t + k - 2] and of db[o] = sum_t g[o, t]: part [B][64][400], then [B][64]
+// (k_kc_dw_sum adds the utterances in order).  workgroup = (utterance, 16 output channels), thread = (channel o, 5 input channels)
+__global__ void __launch_bounds__(256) k_ic_bwd_w(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ y,
+                                                  float *__restrict__ part, int B, int T, float post)
+{
+    __shared__ __attribute__((aligned(16))) float xs[IC_CI * IC_LD];
+    __shared__ __attribute__((aligned(16))) float gs[16 * IC_LD];
+    const int b = blockIdx.x, tid = threadIdx.x, ol = tid >> 4, o = blockIdx.y * 16 + ol, c0 = (tid & 15) * 5;
+    ic_stage_x(xs, x, b, T, tid);
+    ic_stage_g(gs, dy, y, b, blockIdx.y * 16, 16, T, post, tid);
+    __syncthreads();
+    float acc[5][IC_K];
+#pragma unroll
+    for (int ci = 0; ci < 5; ++ci)
+#pragma unroll
+        for (int k = 0; k < IC_K; ++k) acc[ci][k] = 0.0f;
+    float accb = 0.0f;
+    for (int t = 0; t < T; t += 4) {      // (rows are zero behind T)
+        float g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = gs[ol * IC_LD + 2 + t + j];      // g[t + j] (the row starts 8 B into a 16 B slot: scalars)
+        accb += (g[0] + g[1]) + (g[2] + g[3]);
+#pragma unroll
+        for (int ci = 0; ci < 5; ++ci) {
+            float xw[8];      // x[t + j + k - 2] = xs[t + j + k], j < 4, k < 5
+            const float4 v0 = *reinterpret_cast<const float4 *>(xs + (c0 + ci) * IC_LD + t), v1 = *reinterpret_cast<const float4 *>(xs + (c0 + ci) * IC_LD + t + 4);
+            xw[0] = v0.x; xw[1] = v0.y; xw[2] = v0.z; xw[3] = v0.w; xw[4] = v1.x; xw[5] = v1.y; xw[6] = v1.z; xw[7] = v1.w;
+#pragma unroll
+            for (int k = 0; k < IC_K; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[ci][k] = fmaf(g[j], xw[j + k], acc[ci][k]);
+        }
+    }
+    float *pw = part + ((int64_t)b * IC_CO + o) * IC_KK + c0 * IC_K;
+#pragma unroll
+    for (int ci = 0; ci < 5; ++ci)
+#pragma unroll
+        for (int k = 0; k < IC_K; ++k) pw[ci * IC_K + k] = acc[ci][k];
+    if ((tid & 15) == 0) part[(int64_t)B * IC_CO * IC_KK + (int64_t)b * IC_CO + o] = accb;
+}
+
 }  // namespace fdk_kconv
 
 namespace fdk {
@@ -497,6 +632,26 @@ hipError_t kconv_forward(const Launch &L, const float *h, const float *W, const 
     return hipSuccess;
 }
 
+size_t input_conv_scratch_floats(int B) { return (size_t)B * IC_CO * (IC_KK + 1); }
+
+hipError_t input_conv_forward(const Launch &L, const float *x, const float *w, const float *bias, float *out, int B, int T, float post)
+{
+    FD_LAUNCH(L, "input_conv_forward", k_ic_fwd, dim3(B, IC_CO / 16), dim3(256), 0, x, w, bias, out, T, post);
+    return hipSuccess;
+}
+
+hipError_t input_conv_backward(const Launch &L, const float *x, const float *w, const float *y, const float *dy, float *dx, float *dw, float *db, int B,
+                               int T, float post, float *scratch)
+{
+    if (dx) FD_LAUNCH(L, "input_conv_backward_x", k_ic_bwd_x, dim3(B, IC_CI / 16), dim3(256), 0, w, dy, y, dx, T, post);
+    if (dw || db) {
+        FD_LAUNCH(L, "input_conv_backward_w", k_ic_bwd_w, dim3(B, IC_CO / 16), dim3(256), 0, x, dy, y, scratch, B, T, post);
+        FD_LAUNCH(L, "kconv_backward_w_sum", k_kc_dw_sum, dim3((unsigned)(((int64_t)IC_CO * (IC_KK + 1) + 255) / 256)), dim3(256), 0, (const float *)scratch, dw,
+                  db, IC_CO, B, IC_KK);
+    }
+    return hipSuccess;
+}
+
 hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const float *dout, float *dh, float *dW, float *dbias, int B, int M,
                           int T, float *scratch, bool frames, const float *y, float post)
 {
@@ -509,7 +664,7 @@ hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const
         else { if (y) FD_KCS_DW(false, true); else FD_KCS_DW(false, false); }
 #undef FD_KCS_DW
         FD_LAUNCH(L, "kconv_backward_w_sum", k_kc_dw_sum, dim3((unsigned)(((int64_t)M * (KK + 1) + 255) / 256)), dim3(256), 0, (const float *)part_w, dW,
-                  dbias, M, B);
+                  dbias, M, B, KK);
     } else if (dW || dbias) {
         const int gx = (M + 127) / 128;
         const int ny0 = pick_ranges(gx, B, KC_DW_RANGES, L.ctx->num_cus), bchunk = (B + ny0 - 1) / ny0, ny = (B + bchunk - 1) / bchunk;
@@ -517,7 +672,7 @@ hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const
         else if (T % 4 == 0) FD_LAUNCH(L, "kconv_backward_w", (k_kc_dw<true, false>), dim3(gx, ny), dim3(256), 0, h, dout, part_w, B, M, T, bchunk);
         else FD_LAUNCH(L, "kconv_backward_w", (k_kc_dw<false, false>), dim3(gx, ny), dim3(256), 0, h, dout, part_w, B, M, T, bchunk);
         FD_LAUNCH(L, "kconv_backward_w_sum", k_kc_dw_sum, dim3((unsigned)(((int64_t)M * (KK + 1) + 255) / 256)), dim3(256), 0, (const float *)part_w, dW,
-                  dbias, M, ny);
+                  dbias, M, ny, KK);
     }
     if (dh) {
         const int chunks = M / 32;                                        // slices of whole 32-row chunks, a power of two of them

@@ -202,6 +202,50 @@ class _KConv(torch.autograd.Function):
         return (None if dx is None else dx.to(tx), None if dw is None else dw.to(tw), None if db is None else db.to(tb), None)
 
 
+class _InputConv(torch.autograd.Function):
+    """KernelPredictor.input_conv (modules.py:292-295): leaky_relu(Conv1d(80 -> 64, k5, padding 2), slope), forward and backward on HIP
+    kernels (fd_input_conv_forward / fd_input_conv_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, post_slope):
+        ctx.in_dtypes = (x.dtype, weight.dtype, bias.dtype)
+        x, weight, bias = x.contiguous().float(), weight.contiguous().float(), bias.contiguous().float()
+        B, _, T = x.shape
+        y = torch.empty((B, 64, T), device=x.device, dtype=torch.float32)
+        lib, h = _handle(x.device)
+        _capi.check(lib, h, lib.fd_input_conv_forward(h, x.data_ptr(), weight.data_ptr(), bias.data_ptr(), B, T, float(post_slope), y.data_ptr(),
+                                                      _stream(x.device)), "fd_input_conv_forward")
+        ctx.post = float(post_slope)
+        ctx.save_for_backward(x, weight, y)
+        return y.to(ctx.in_dtypes[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        B, _, T = x.shape
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
+        dx = torch.empty_like(x) if need_x else None
+        dw = torch.empty_like(weight) if need_w else None
+        db = torch.empty(64, device=x.device, dtype=torch.float32) if need_b else None
+        lib, h = _handle(x.device)
+        _capi.check(lib, h, lib.fd_input_conv_backward(h, x.data_ptr(), weight.data_ptr(), y.data_ptr(), dy.data_ptr(), B, T, ctx.post,
+                                                       None if dx is None else dx.data_ptr(), None if dw is None else dw.data_ptr(),
+                                                       None if db is None else db.data_ptr(), _stream(x.device)), "fd_input_conv_backward")
+        tx, tw, tb = ctx.in_dtypes
+        return (None if dx is None else dx.to(tx), None if dw is None else dw.to(tw), None if db is None else db.to(tb), None)
+
+
+def input_conv_supported(x, weight):
+    """The predictor's input convolution as the model builds it: weight [64, 80, 5] on a HIP tensor [B, 80, T], T <= 128."""
+    return x.is_cuda and x.dim() == 3 and x.shape[1] == 80 and tuple(weight.shape) == (64, 80, 5) and 1 <= x.shape[2] <= 128
+
+
+def input_conv(x, weight, bias, post_slope=0.1):
+    """leaky_relu(conv1d(x [B,80,T], weight [64,80,5], bias, padding=2), post_slope) as a differentiable HIP operator."""
+    return _InputConv.apply(x, weight, bias, post_slope)
+
+
 class _Conv7(torch.autograd.Function):
     """first_audio_conv (which = 0: Conv1d(1, 32, 7, padding 3)) / final_conv (which = 1: Conv1d(32, 1, 7, padding 3)), FastDiff_model.py:
     34-36,67-68, forward and backward on HIP kernels (fd_conv7_forward / fd_conv7_backward)."""

@@ -95,6 +95,11 @@ def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None, split=None, frame
             if fuse_act and fits(m, h) and isinstance(nxt, torch.nn.LeakyReLU) and m.out_channels <= 512:
                 h = kconv[0](h, _conv_weight(m), m.bias, nxt.negative_slope)
                 i += 2
+            elif fuse_act and kconv is not None and isinstance(m, torch.nn.Conv1d) and isinstance(nxt, torch.nn.LeakyReLU) and \
+                    m.padding == (2,) and m.dilation == (1,) and m.stride == (1,) and \
+                    kconv[2](h, m.weight_v if hasattr(m, "weight_v") else m.weight):      # input_conv: Conv1d(80, 64, 5), LeakyReLU
+                h = kconv[3](h, _conv_weight(m), m.bias, nxt.negative_slope)
+                i += 2
             else:
                 h = conv(m, h)
                 i += 1
@@ -157,8 +162,8 @@ def differentiable_forward(module, data, lvc=None):
     if lvc is None:                    # the product path: the layer's operators, its convolution and the predictor's kernel_conv on HIP kernels
         from .lvc_op import (location_variable_convolution as lvc, gated_residual as gate, kernel_conv1d, kernel_conv_supported, conv32,
                              conv32_supported, split_layers, kernel_conv1d_frames, location_variable_convolution_frames,
-                             kernel_conv_frames_supported)
-        kconv = (kernel_conv1d, kernel_conv_supported)
+                             kernel_conv_frames_supported, input_conv, input_conv_supported)
+        kconv = (kernel_conv1d, kernel_conv_supported, input_conv_supported, input_conv)
         cconv = (conv32, conv32_supported)
         split = split_layers
         if getattr(module, "_train_frames", True):      # (False: the reference's kernel tensor between the two operators, for A/B runs)

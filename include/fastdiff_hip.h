@@ -198,6 +198,15 @@ FD_API int fd_kconv_forward_act(fd_handle h, const float *x, const float *weight
 FD_API int fd_kconv_backward_act(fd_handle h, const float *x, const float *weight, const float *y, const float *dout, int B, int M, int T,
                                  float post_slope, float *dx, float *dweight, float *dbias, void *stream);
 
+/* KernelPredictor.input_conv (modules.py:292-295: Conv1d(80 -> 64, kernel 5, padding 2), LeakyReLU(0.1)) for the training path as one
+ * operator each way: x [B,80,T], weight [64,80,5], bias [64], out / y / dout [B,64,T] (device, float32, contiguous), 1 <= T <= 128;
+ * out = leaky_relu(conv, post_slope); the backward takes that output (y) and dout = the gradient behind the activation, and writes the
+ * gradients whose pointer is not NULL (dweight / dbias: per-utterance partial sums added in a fixed order). */
+FD_API int fd_input_conv_forward(fd_handle h, const float *x, const float *weight, const float *bias, int B, int T, float post_slope, float *out,
+                                 void *stream);
+FD_API int fd_input_conv_backward(fd_handle h, const float *x, const float *weight, const float *y, const float *dout, int B, int T,
+                                  float post_slope, float *dx, float *dweight, float *dbias, void *stream);
+
 /* The same two operators joined without the reference's tensor in between ("frames").  The reference hands the predicted kernels from
  * kernel_conv to the location-variable convolution as [B, layers, 32, 64, 3, T] (modules.py:333-338; T innermost), which the matrix
  * kernels of the operator have to transpose into frame-major order before use (and the gradient back): three passes over 6144*B*T

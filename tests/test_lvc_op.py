@@ -232,6 +232,40 @@ def test_kernel_conv_with_its_activation_inside_matches_torch_autograd(shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(20, 100), (3, 37), (1, 128), (2, 1), (2, 8), (3, 9)])
+def test_input_conv_operator_forward_and_backward_match_torch_autograd(B, T):
+    """lvc_op.input_conv = KernelPredictor.input_conv, `Conv1d(80, 64, 5, padding=2), LeakyReLU(0.1)` (modules.py:292-295), as one HIP
+    operator each way, against the two torch modules in float64: output, dx, dW, db; frame counts that are not multiples of the
+    8-frame thread tiles, one frame, the training shape; the weight gradient is a fixed-order sum (same bits on a second run)."""
+    from fastdiff_amd import lvc_op
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(17 * B + T)
+    x = torch.randn(B, 80, T, generator=g)
+    w = torch.randn(64, 80, 5, generator=g) / 20.0
+    bias = torch.randn(64, generator=g)
+    w[0] = 0.0
+    bias[0] = 0.0                                                                   # a channel whose pre-activation is exactly 0
+    dout = torch.randn(B, 64, T, generator=g)
+    x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, bias))
+    ref = F.leaky_relu(F.conv1d(x64, w64, b64, padding=2), 0.1)
+    ref.backward(dout.double())
+    assert lvc_op.input_conv_supported(x.cuda(), w.cuda())
+    outs = []
+    for _ in range(2):
+        xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, bias))
+        out = lvc_op.input_conv(xg, wg, bg, 0.1)
+        out.backward(dout.cuda())
+        outs.append((out.detach(), xg.grad, wg.grad, bg.grad))
+    rel = lambda got, want: float((got.double().cpu() - want).abs().max()) / max(1.0, float(want.abs().max()))      # noqa: E731
+    out, dx, dw, db = outs[0]
+    assert rel(out, ref.detach()) < 2e-6
+    assert rel(dx, x64.grad) < 3e-6 and rel(dw, w64.grad) < 3e-6 and rel(db, b64.grad) < 3e-6
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    with pytest.raises(NotImplementedError, match="128"):
+        lvc_op.input_conv(torch.zeros(1, 80, 200).cuda(), w.cuda(), bias.cuda())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,L,dil,skip,post", [(2, 1024, 1, True, 0.2), (3, 388, 3, True, 0.2), (1, 2560, 9, True, 0.2), (2, 904, 27, True, 0.2),
                                                 (2, 640, 1, False, 1.0), (1, 132, 2, False, 1.0), (3, 260, 4, False, 1.0), (1, 4, 27, True, 0.2),
                                                 (20, 25600, 27, True, 0.2)])
