@@ -1607,6 +1607,33 @@ int fd_kconv_backward(fd_handle h, const float *x, const float *weight, const fl
     return fd_kconv_backward_act(h, x, weight, nullptr, dout, B, M, T, 1.0f, dx, dweight, dbias, stream);
 }
 
+// A skip tensor's fan-out (fd_kernels_train.hip: k_fan_*).
+int fd_fan_forward(fd_handle h, const float *x, int rows, int64_t L, int factor, float *picked, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!x || !picked) FD_FAIL(h, FD_ERR_INVALID, "fd_fan_forward: null pointer");
+    if (rows <= 0 || rows > 65535 || L <= 0 || factor < 1 || L % factor != 0) FD_FAIL(h, FD_ERR_INVALID, "fd_fan_forward: rows=%d L=%lld factor=%d", rows, (long long)L, factor);
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::fan_pick(La, x, picked, rows, L, factor);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_fan_forward: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+int fd_fan_backward(fd_handle h, const float *g0, const float *g1, const float *g2, const float *g3, const float *gpicked, int rows, int64_t L,
+                    int factor, float *dx, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!dx) FD_FAIL(h, FD_ERR_INVALID, "fd_fan_backward: null pointer");
+    if (rows <= 0 || rows > 65535 || L <= 0 || factor < 1 || L % factor != 0) FD_FAIL(h, FD_ERR_INVALID, "fd_fan_backward: rows=%d L=%lld factor=%d", rows, (long long)L, factor);
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    const float *g[4] = {g0, g1, g2, g3};
+    hipError_t e = fdk::fan_sum(La, g, gpicked, dx, rows, L, factor);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_fan_backward: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
 // The predictor's input convolution (80 -> 64, k5) with its activation (fd_kernels_kconv.hip: k_ic_*); per-utterance partial sums of
 // the weight gradient in the kernel_conv scratch.
 static int check_input_conv(fd_handle h, int B, int T, float post, const char *who)

@@ -35,6 +35,10 @@ hipError_t lvc_op_backward(const Launch &L, const float *x, const float *K, cons
 // the gate + residual of an LVC layer, one pass forward and one backward (modules.py:217)
 hipError_t gate_forward(const Launch &L, const float *x, const float *y, float *out, int B, int C, int64_t len);
 hipError_t gate_backward(const Launch &L, const float *y, const float *dout, float *dy, int B, int C, int64_t len);
+// a skip tensor's fan-out on the training path (fd_kernels_train.hip): out[r, j] = x[r, j f] (the DBlock's nearest pick), and the sum of
+// the gradients that come back: dx = g[0] + g[1] + g[2] + g[3] + scatter(gp) (null pointers = absent); rows = B * C
+hipError_t fan_pick(const Launch &L, const float *x, float *out, int rows, int64_t len, int f);
+hipError_t fan_sum(const Launch &L, const float *const g[4], const float *gp, float *dx, int rows, int64_t len, int f);
 // the KernelPredictor's kernel_conv (Conv1d 64 -> M, k3) forward and backward for the training path (fd_kernels_kconv.hip);
 // scratch: kconv_scratch_floats(B, M, T) floats for the backward's partial sums
 bool kconv_supported(int M, int T);

@@ -503,10 +503,62 @@ __global__ void __launch_bounds__(256) k_gate_bwd(const float *__restrict__ y, c
     }
 }
 
+// ---- a skip tensor's fan-out (FastDiff_model.py:91-98): x feeds the DiffusionDBlock below it -- which begins by picking every f-th
+//      column (F.interpolate, nearest: modules.py:128-131) -- and, as audio_down, the four layers of the LVC block at its rate
+//      (modules.py:209).  Forward: the pick.  Backward: dx = g0 + g1 + g2 + g3 + scatter(gp), one pass instead of a zero-fill, a
+//      strided scatter and four full-size additions under autograd.  rows = B * C; any gradient pointer may be null.
+__global__ void __launch_bounds__(256) k_fan_pick(const float *__restrict__ x, float *__restrict__ out, int64_t L, int64_t Lo, int f)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < Lo) out[(int64_t)blockIdx.y * Lo + j] = x[(int64_t)blockIdx.y * L + j * f];
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256) k_fan_sum(const float *__restrict__ g0, const float *__restrict__ g1, const float *__restrict__ g2,
+                                                 const float *__restrict__ g3, const float *__restrict__ gp, float *__restrict__ dx, int64_t L,
+                                                 int64_t Lo, int f)
+{
+    const int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (q >= L) return;
+    const int64_t at = (int64_t)blockIdx.y * L + q;
+    if (VEC == 4) {      // (f is a multiple of 4: column q is the only one of the quad that may have been picked)
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto add = [&](const float *g) { if (g) { const float4 t = *reinterpret_cast<const float4 *>(g + at); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; } };
+        add(g0); add(g1); add(g2); add(g3);
+        if (gp && q % f == 0 && q / f < Lo) v.x += gp[(int64_t)blockIdx.y * Lo + q / f];
+        *reinterpret_cast<float4 *>(dx + at) = v;
+    } else {
+        float v = 0.0f;
+        if (g0) v += g0[at];
+        if (g1) v += g1[at];
+        if (g2) v += g2[at];
+        if (g3) v += g3[at];
+        if (gp && q % f == 0 && q / f < Lo) v += gp[(int64_t)blockIdx.y * Lo + q / f];
+        dx[at] = v;
+    }
+}
+
 }  // namespace fdk_train
 
 namespace fdk {
 using namespace fdk_train;
+
+hipError_t fan_pick(const Launch &L, const float *x, float *out, int rows, int64_t len, int f)
+{
+    const int64_t Lo = len / f;
+    FD_LAUNCH(L, "fan_pick", k_fan_pick, dim3((unsigned)((Lo + 255) / 256), rows), dim3(256), 0, x, out, len, Lo, f);
+    return hipSuccess;
+}
+
+hipError_t fan_sum(const Launch &L, const float *const g[4], const float *gp, float *dx, int rows, int64_t len, int f)
+{
+    const int64_t Lo = len / f;
+    if (len % 4 == 0 && f % 4 == 0)
+        FD_LAUNCH(L, "fan_sum", k_fan_sum<4>, dim3((unsigned)((len / 4 + 255) / 256), rows), dim3(256), 0, g[0], g[1], g[2], g[3], gp, dx, len, Lo, f);
+    else
+        FD_LAUNCH(L, "fan_sum", k_fan_sum<1>, dim3((unsigned)((len + 255) / 256), rows), dim3(256), 0, g[0], g[1], g[2], g[3], gp, dx, len, Lo, f);
+    return hipSuccess;
+}
 
 hipError_t gate_forward(const Launch &L, const float *x, const float *y, float *out, int B, int C, int64_t len)
 {

@@ -202,6 +202,49 @@ class _KConv(torch.autograd.Function):
         return (None if dx is None else dx.to(tx), None if dw is None else dw.to(tw), None if db is None else db.to(tb), None)
 
 
+class _SkipFan(torch.autograd.Function):
+    """A skip tensor's fan-out (FastDiff_model.py:91-98): returns (x[..., ::factor] for the DiffusionDBlock below, whose nearest
+    F.interpolate picks exactly those columns (modules.py:128-131), and four aliases of x for the four layers of the LVC block that
+    adds it as audio_down).  Backward: the five gradients in one pass (fd_fan_backward) instead of autograd's zero-fill + strided
+    scatter + four full-size additions."""
+
+    @staticmethod
+    def forward(ctx, x, factor):
+        assert x.dtype == torch.float32 and x.dim() == 3 and x.shape[-1] % int(factor) == 0
+        x = x.contiguous()
+        B, C, L = x.shape
+        picked = torch.empty((B, C, L // int(factor)), device=x.device, dtype=torch.float32)
+        lib, h = _handle(x.device)
+        _capi.check(lib, h, lib.fd_fan_forward(h, x.data_ptr(), B * C, L, int(factor), picked.data_ptr(), _stream(x.device)), "fd_fan_forward")
+        ctx.factor, ctx.shape = int(factor), (B, C, L)
+        return (picked,) + tuple(x.view_as(x) for _ in range(4))
+
+    @staticmethod
+    def backward(ctx, gp, *gs):
+        B, C, L = ctx.shape
+        ref = next((g for g in (gp,) + gs if g is not None), None)
+        if ref is None:
+            return None, None
+        dx = torch.empty((B, C, L), device=ref.device, dtype=torch.float32)
+        ptr = lambda g: None if g is None else g.data_ptr()      # noqa: E731
+        gs = [None if g is None else g.contiguous().float() for g in gs]
+        gp = None if gp is None else gp.contiguous().float()
+        lib, h = _handle(ref.device)
+        _capi.check(lib, h, lib.fd_fan_backward(h, ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(gs[3]), ptr(gp), B * C, L, ctx.factor, dx.data_ptr(),
+                                                _stream(ref.device)), "fd_fan_backward")
+        return dx, None
+
+
+def skip_fan_supported(x, factor):
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[-1] % int(factor) == 0 and x.shape[0] * x.shape[1] <= 65535
+
+
+def skip_fan(x, factor):
+    """(x[..., ::factor], x, x, x, x) for a skip tensor x [B, C, L]: the picked columns for the DBlock below and one alias of x per
+    layer of the LVC block that adds it; the gradients of all five come back through one kernel."""
+    return _SkipFan.apply(x, factor)
+
+
 class _InputConv(torch.autograd.Function):
     """KernelPredictor.input_conv (modules.py:292-295): leaky_relu(Conv1d(80 -> 64, k5, padding 2), slope), forward and backward on HIP
     kernels (fd_input_conv_forward / fd_input_conv_backward)."""

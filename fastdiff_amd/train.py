@@ -50,13 +50,14 @@ def _conv(m, x):
     return m(x)
 
 
-def _dblock(p, x, cconv=None):
+def _dblock(p, x, cconv=None, picked=False):
     """DiffusionDBlock.forward (modules.py:127-138); F.interpolate(size = L // factor) in its default nearest mode picks every
     factor-th sample.  The reference runs the 1 x 1 residual convolution at the full rate and then picks (modules.py:129-130); a
     1 x 1 convolution commutes with picking columns, so here it runs on the picked columns: 1 / factor of the work, the same values
     and the same gradients (only the picked columns ever receive one).  cconv: the HIP operator for `layer(leaky_relu(x, 0.2))`."""
-    size = x.shape[-1] // p.factor
-    x = F.interpolate(x, size=size)
+    if not picked:                   # (picked: the caller's skip_fan has taken the columns already)
+        size = x.shape[-1] // p.factor
+        x = F.interpolate(x, size=size)
     rd = p.residual_dense
     if cconv is not None and rd.kernel_size == (1,) and rd.in_channels == rd.out_channels == 32 and cconv[1](x, torch.empty(32, 32, 3, device="meta"), 1):
         # the 1 x 1 residual convolution as the centre tap of a 3-tap one (zeros either side) on the same HIP operator, no activations
@@ -141,12 +142,14 @@ def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate, kconv=None,
         x = upsample(x, p.upsample.weight, p.upsample.bias, p.upsample.stride[0])      # leaky_relu + ConvTranspose1d in one HIP pass each way
     else:
         x = p.upsample(F.leaky_relu(x, 0.2))
+    # audio_down: the skip tensor, or one alias of it per layer (lvc_op.skip_fan: their gradients are then added up in one pass)
+    skip_of = (lambda i: audio_down[i]) if isinstance(audio_down, (list, tuple)) else (lambda i: audio_down)
     for i, conv in enumerate(p.convs):
         if cconv is not None and cconv[1](x, conv.weight_v if hasattr(conv, "weight_v") else conv.weight, conv.dilation[0]):
             # x += audio_down; leaky_relu; conv; leaky_relu (modules.py:209-212) in one HIP pass each way
-            x, y = cconv[0](x, _conv_weight(conv), conv.bias, conv.dilation[0], skip=audio_down, post_slope=0.2)
+            x, y = cconv[0](x, _conv_weight(conv), conv.bias, conv.dilation[0], skip=skip_of(i), post_slope=0.2)
         else:
-            x = x + audio_down
+            x = x + skip_of(i)
             y = F.leaky_relu(_conv(conv, F.leaky_relu(x, 0.2)), 0.2)
         if as_frames:
             y = frames[1](y, kernels[i], bias[i], p.cond_hop_length, grad_slot=slots[i])
@@ -176,9 +179,18 @@ def differentiable_forward(module, data, lvc=None):
     emb = _swish(module.fc_t2(_swish(module.fc_t1(emb))))
     x = _conv(module.first_audio_conv, audio)
     skips = []
+    fan = None
+    if cconv is not None and getattr(module, "_train_skip_fan", True):      # (False: autograd's own fan-out, for A/B runs)
+        from .lvc_op import skip_fan, skip_fan_supported
+        fan = (skip_fan, skip_fan_supported)
     for down in module.downsample:
-        skips.append(x)
-        x = _dblock(down, x, cconv)
+        if fan is not None and len(module.lvc_blocks[0].convs) == 4 and fan[1](x, down.factor):
+            picked, *aliases = fan[0](x, down.factor)      # the DBlock's nearest pick + one alias of x per LVC layer that adds it
+            skips.append(aliases)
+            x = _dblock(down, picked, cconv, picked=True)
+        else:
+            skips.append(x)
+            x = _dblock(down, x, cconv)
     for n, audio_down in enumerate(reversed(skips)):
         x = _lvc_block(module.lvc_blocks[n], x, audio_down, c, emb, cfg, lvc, gate, kconv, cconv, split, frames,
                        getattr(module, "_train_fuse_act", True))      # (False: the predictor's LeakyReLUs as torch nodes, for A/B runs)

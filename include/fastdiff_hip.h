@@ -198,6 +198,15 @@ FD_API int fd_kconv_forward_act(fd_handle h, const float *x, const float *weight
 FD_API int fd_kconv_backward_act(fd_handle h, const float *x, const float *weight, const float *y, const float *dout, int B, int M, int T,
                                  float post_slope, float *dx, float *dweight, float *dbias, void *stream);
 
+/* A skip tensor's fan-out on the training path (FastDiff_model.py:91-98): x [rows = B*C, L] is read by the DiffusionDBlock below it, which
+ * begins by picking every factor-th column (F.interpolate to L / factor, nearest: modules.py:128-131), and as `audio_down` by the four
+ * layers of the LVC block at its rate (modules.py:209).  fd_fan_forward: picked [rows, L / factor] = x[:, ::factor].  fd_fan_backward:
+ * dx = g0 + g1 + g2 + g3 + scatter(gpicked) in one pass (any of the five may be NULL = no gradient from that reader); under autograd
+ * the same is a zero-fill, a strided scatter and four full-size additions.  L a multiple of factor. */
+FD_API int fd_fan_forward(fd_handle h, const float *x, int rows, int64_t L, int factor, float *picked, void *stream);
+FD_API int fd_fan_backward(fd_handle h, const float *g0, const float *g1, const float *g2, const float *g3, const float *gpicked, int rows,
+                           int64_t L, int factor, float *dx, void *stream);
+
 /* KernelPredictor.input_conv (modules.py:292-295: Conv1d(80 -> 64, kernel 5, padding 2), LeakyReLU(0.1)) for the training path as one
  * operator each way: x [B,80,T], weight [64,80,5], bias [64], out / y / dout [B,64,T] (device, float32, contiguous), 1 <= T <= 128;
  * out = leaky_relu(conv, post_slope); the backward takes that output (y) and dout = the gradient behind the activation, and writes the

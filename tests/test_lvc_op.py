@@ -232,6 +232,30 @@ def test_kernel_conv_with_its_activation_inside_matches_torch_autograd(shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,L,f", [(2, 1024, 4), (3, 96, 8), (1, 8, 8), (2, 30, 3), (20, 25600, 4)])
+def test_skip_fan_out_picks_and_adds_up_like_autograd(B, L, f):
+    """lvc_op.skip_fan(x, f) = (x[..., ::f], x, x, x, x): the DBlock's nearest pick (F.interpolate to L / f, modules.py:128-131) and one
+    alias of the skip tensor per LVC layer; the five gradients come back as ONE sum.  Against torch autograd on the same readers --
+    all five, and with some of them unused (their gradient is then absent, not zero)."""
+    from fastdiff_amd import lvc_op
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(L + f)
+    x = torch.randn(B, 32, L, generator=g).cuda()
+    ws = [torch.randn(B, 32, L, generator=g).cuda() for _ in range(4)]
+    wp = torch.randn(B, 32, L // f, generator=g).cuda()
+    for used in ((0, 1, 2, 3, "p"), (1, 3), ("p",), (0, "p")):
+        xa = x.clone().requires_grad_(True)
+        picked, *al = lvc_op.skip_fan(xa, f)
+        assert torch.equal(picked.detach(), F.interpolate(x, size=L // f)) and all(torch.equal(a.detach(), x) for a in al)
+        loss = sum((al[i] * ws[i]).sum() for i in used if i != "p") + ((picked * wp).sum() if "p" in used else 0.0)
+        loss.backward()
+        xb = x.clone().requires_grad_(True)
+        lossb = sum((xb * ws[i]).sum() for i in used if i != "p") + ((F.interpolate(xb, size=L // f) * wp).sum() if "p" in used else 0.0)
+        lossb.backward()
+        assert float((xa.grad - xb.grad).abs().max()) <= 1e-6 * float(xb.grad.abs().max()), used
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,T", [(20, 100), (3, 37), (1, 128), (2, 1), (2, 8), (3, 9)])
 def test_input_conv_operator_forward_and_backward_match_torch_autograd(B, T):
     """lvc_op.input_conv = KernelPredictor.input_conv, `Conv1d(80, 64, 5, padding=2), LeakyReLU(0.1)` (modules.py:292-295), as one HIP
