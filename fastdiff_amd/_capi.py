@@ -79,8 +79,8 @@ def load():
     lib.fd_kconv_backward_act.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ct.c_float, vp, vp, vp, vp]
     lib.fd_kconv_forward_frames.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp]
     lib.fd_kconv_backward_frames.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp]
-    lib.fd_lvc_forward_frames.argtypes = [vp, vp, vp, ct.c_int64, vp, ci, ci, ci, vp, vp]
-    lib.fd_lvc_backward_frames.argtypes = [vp, vp, vp, ct.c_int64, vp, ci, ci, ci, vp, vp, ct.c_int64, vp, vp]
+    lib.fd_lvc_forward_frames.argtypes = [vp, vp, vp, ct.c_int64, vp, ct.c_int64, ci, ci, ci, vp, vp]
+    lib.fd_lvc_backward_frames.argtypes = [vp, vp, vp, ct.c_int64, vp, ci, ci, ci, vp, vp, ct.c_int64, vp, ct.c_int64, vp]
     lib.fd_conv32_forward.argtypes = [vp, vp, vp, vp, vp, ci, ct.c_int64, ci, cf, cf, vp, vp, vp]
     lib.fd_conv32_backward.argtypes = [vp, vp, vp, vp, vp, vp, ci, ct.c_int64, ci, cf, cf, vp, vp, vp, vp]
     lib.fd_conv7_forward.argtypes = [vp, ci, vp, vp, vp, ci, ct.c_int64, vp, vp]

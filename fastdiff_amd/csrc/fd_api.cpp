@@ -1717,8 +1717,8 @@ static int check_frames_stride(fd_handle h, int64_t st, int T, const char *who)
     return FD_OK;
 }
 
-int fd_lvc_forward_frames(fd_handle h, const float *x, const float *kernel_frames, int64_t kernel_bstride, const float *bias, int B, int T, int hop,
-                          float *out, void *stream)
+int fd_lvc_forward_frames(fd_handle h, const float *x, const float *kernel_frames, int64_t kernel_bstride, const float *bias, int64_t bias_bstride,
+                          int B, int T, int hop, float *out, void *stream)
 {
     if (!h) return FD_ERR_INVALID;
     if (!x || !kernel_frames || !bias || !out) FD_FAIL(h, FD_ERR_INVALID, "fd_lvc_forward_frames: null pointer");
@@ -1726,15 +1726,16 @@ int fd_lvc_forward_frames(fd_handle h, const float *x, const float *kernel_frame
     if (rc != FD_OK) return rc;
     if (!fdk::lvc_op_needs_scratch(32, 64, 3, hop)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_lvc_forward_frames: hop 8 / 64 / 256 only, got %d", hop);
     if ((rc = check_frames_stride(h, kernel_bstride, T, "fd_lvc_forward_frames")) != FD_OK) return rc;
+    if (bias_bstride != 0 && bias_bstride < (int64_t)64 * T) FD_FAIL(h, FD_ERR_INVALID, "fd_lvc_forward_frames: bias stride %lld < 64 * T", (long long)bias_bstride);
     FD_HIP(h, hipSetDevice(h->device));
     fdk::Launch L = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::lvc_op_forward(L, x, kernel_frames, bias, out, B, 32, 64, 3, T, hop, nullptr, kernel_bstride, true);
+    hipError_t e = fdk::lvc_op_forward(L, x, kernel_frames, bias, out, B, 32, 64, 3, T, hop, nullptr, kernel_bstride, true, bias_bstride);
     if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_lvc_forward_frames: %s", hipGetErrorString(e));
     return FD_OK;
 }
 
 int fd_lvc_backward_frames(fd_handle h, const float *x, const float *kernel_frames, int64_t kernel_bstride, const float *dout, int B, int T,
-                           int hop, float *dx, float *dkernel_frames, int64_t dkernel_bstride, float *dbias, void *stream)
+                           int hop, float *dx, float *dkernel_frames, int64_t dkernel_bstride, float *dbias, int64_t dbias_bstride, void *stream)
 {
     if (!h) return FD_ERR_INVALID;
     if (!dout || ((dkernel_frames || dbias) && !x) || (dx && !kernel_frames)) FD_FAIL(h, FD_ERR_INVALID, "fd_lvc_backward_frames: null pointer");
@@ -1743,12 +1744,13 @@ int fd_lvc_backward_frames(fd_handle h, const float *x, const float *kernel_fram
     if (!fdk::lvc_op_needs_scratch(32, 64, 3, hop)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_lvc_backward_frames: hop 8 / 64 / 256 only, got %d", hop);
     if (dx && (rc = check_frames_stride(h, kernel_bstride, T, "fd_lvc_backward_frames")) != FD_OK) return rc;
     if (dkernel_frames && (rc = check_frames_stride(h, dkernel_bstride, T, "fd_lvc_backward_frames")) != FD_OK) return rc;
+    if (dbias && dbias_bstride != 0 && dbias_bstride < (int64_t)64 * T) FD_FAIL(h, FD_ERR_INVALID, "fd_lvc_backward_frames: dbias stride %lld < 64 * T", (long long)dbias_bstride);
     FD_HIP(h, hipSetDevice(h->device));
     float *scratch = nullptr;
     if (dx && !h->lvc_dx_gather && (rc = lvc_scratch(h, B, 32, 64, 3, T, hop, &scratch)) != FD_OK) return rc;      // option lvc_dx = copy: the dx kernel's operand order
     fdk::Launch L = {h, (hipStream_t)stream, false};
     hipError_t e = fdk::lvc_op_backward(L, x, kernel_frames, dout, dx, dkernel_frames, dbias, B, 32, 64, 3, T, hop, scratch, kernel_bstride,
-                                        dkernel_bstride, true);
+                                        dkernel_bstride, true, dbias_bstride);
     if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_lvc_backward_frames: %s", hipGetErrorString(e));
     return FD_OK;
 }

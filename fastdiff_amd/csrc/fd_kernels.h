@@ -29,9 +29,10 @@ bool lvc_op_needs_scratch(int Cin, int Cout, int ks, int hop);
 // frames (the model's shape): K / dK are frame-major ([T][6144] per utterance, fd_frame_order.h: K in ORDER_FWD, dK in ORDER_DK) as
 // kconv_forward / kconv_backward with frames = true write / read them; kbs / dkbs are then the floats between two utterances of those
 hipError_t lvc_op_forward(const Launch &L, const float *x, const float *K, const float *bias, float *out, int B, int Cin, int Cout, int ks,
-                          int T, int hop, float *scratch, int64_t kbs = 0, bool frames = false);
+                          int T, int hop, float *scratch, int64_t kbs = 0, bool frames = false, int64_t bbs = 0);
 hipError_t lvc_op_backward(const Launch &L, const float *x, const float *K, const float *dout, float *dx, float *dK, float *dbias, int B,
-                           int Cin, int Cout, int ks, int T, int hop, float *scratch, int64_t kbs = 0, int64_t dkbs = 0, bool frames = false);
+                           int Cin, int Cout, int ks, int T, int hop, float *scratch, int64_t kbs = 0, int64_t dkbs = 0, bool frames = false,
+                           int64_t dbbs = 0);      // bbs / dbbs (frames only): floats between two utterances of bias / dbias (0 = Cout * T)
 // the gate + residual of an LVC layer, one pass forward and one backward (modules.py:217)
 hipError_t gate_forward(const Launch &L, const float *x, const float *y, float *out, int B, int C, int64_t len);
 hipError_t gate_backward(const Launch &L, const float *y, const float *dout, float *dy, int B, int C, int64_t len);

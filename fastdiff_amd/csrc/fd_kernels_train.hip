@@ -124,7 +124,7 @@ __device__ __forceinline__ void stage_rows(float *__restrict__ lds, const float 
 template <int HOP>
 __global__ void __launch_bounds__(256, HOP == 256 ? 3 : 2) k_lvc_fwd_mfma(const float *__restrict__ x, const float *__restrict__ Kf,
                                                                         const float *__restrict__ bias, float *__restrict__ out, int T,
-                                                                        int64_t kfs)      // kfs: floats between two utterances of Kf
+                                                                        int64_t kfs, int64_t bbs)      // kfs / bbs: floats between two utterances of Kf / bias
 {
     using G = LvcGeo<HOP>;
     constexpr int W = G::W, LD = G::LD, NMT = HOP == 256 ? 1 : 2, NCT = HOP == 256 ? 4 : (HOP == 64 ? 2 : 1);
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256, HOP == 256 ? 3 : 2) k_lvc_fwd_mfma(const 
     const int colc = HOP == 8 ? min(col, HOP - 1) : col;      // hop 8: a tile is one frame, 8 of its 32 columns exist
     float bz[NMT][16];
     {
-        const float *bp = bias + ((int64_t)b * MO + 32 * mt0 + 4 * hi) * T + f;
+        const float *bp = bias + (int64_t)b * bbs + (int64_t)(32 * mt0 + 4 * hi) * T + f;
 #pragma unroll
         for (int m = 0; m < NMT; ++m)
 #pragma unroll
@@ -287,7 +287,8 @@ __global__ void __launch_bounds__(256, 2) k_lvc_dx_mfma(const float *__restrict_
 // under the current chunk's matrix work.  dK stays frame-major (ORDER_DK).
 template <int CH>
 __global__ void __launch_bounds__(192) k_lvc_dk_mfma(const float *__restrict__ x, const float *__restrict__ dout, float *__restrict__ dKf,
-                                                     float *__restrict__ dbias, int T, int hop, int64_t dkfs)      // dkfs: floats between two utterances of dKf
+                                                     float *__restrict__ dbias, int T, int hop, int64_t dkfs,
+                                                     int64_t dbbs)      // dkfs / dbbs: floats between two utterances of dKf / dbias
 {
     constexpr int DLD = CH + 1, XLD = CH + 3, C4 = CH / 4;
     constexpr int ND = (MO * C4 + 191) / 192, NX = (MI * C4 + 191) / 192;
@@ -363,7 +364,7 @@ __global__ void __launch_bounds__(192) k_lvc_dk_mfma(const float *__restrict__ x
     if (dbias) {
         red[tap][lane] = accb;
         __syncthreads();
-        if (tid < MO) dbias[((int64_t)b * MO + tid) * T + l] = red[0][tid] + red[1][tid] + red[2][tid];
+        if (tid < MO) dbias[(int64_t)b * dbbs + (int64_t)tid * T + l] = red[0][tid] + red[1][tid] + red[2][tid];
     }
 }
 
@@ -580,35 +581,40 @@ bool lvc_op_needs_scratch(int Cin, int Cout, int ks, int hop) { return model_sha
 // frames = true (the model's shape only): K is frame-major ORDER_FWD ([T][6144] per utterance, kbs floats between utterances: what
 // kconv_forward_frames wrote), dK leaves frame-major ORDER_DK (dkbs between utterances: what kconv_backward_frames reads) -- no
 // transposes; the scratch then only holds the ORDER_DX copy for the dx kernel
-static hipError_t launch_fwd_mfma(const Launch &L, const float *x, const float *Kf, const float *bias, float *out, int B, int T, int hop, int64_t kfs)
+static hipError_t launch_fwd_mfma(const Launch &L, const float *x, const float *Kf, const float *bias, float *out, int B, int T, int hop, int64_t kfs,
+                                  int64_t bbs)
 {
-    if (hop == 256) FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd_mfma<256>, dim3(T, B), dim3(256), 0, x, Kf, bias, out, T, kfs);
-    else if (hop == 64) FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd_mfma<64>, dim3((T + 3) / 4, B), dim3(256), 0, x, Kf, bias, out, T, kfs);
-    else FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd_mfma<8>, dim3((T + 3) / 4, B), dim3(256), 0, x, Kf, bias, out, T, kfs);
+    if (bbs == 0) bbs = (int64_t)MO * T;
+    if (hop == 256) FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd_mfma<256>, dim3(T, B), dim3(256), 0, x, Kf, bias, out, T, kfs, bbs);
+    else if (hop == 64) FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd_mfma<64>, dim3((T + 3) / 4, B), dim3(256), 0, x, Kf, bias, out, T, kfs, bbs);
+    else FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd_mfma<8>, dim3((T + 3) / 4, B), dim3(256), 0, x, Kf, bias, out, T, kfs, bbs);
     return hipSuccess;
 }
 
 hipError_t lvc_op_forward(const Launch &L, const float *x, const float *K, const float *bias, float *out, int B, int Cin, int Cout, int ks,
-                          int T, int hop, float *scratch, int64_t kbs, bool frames)
+                          int T, int hop, float *scratch, int64_t kbs, bool frames, int64_t bbs)
 {
     const int Ln = T * hop;
     if (kbs == 0) kbs = (int64_t)Cin * Cout * ks * T;
     if (frames) {
         if (!model_shape(Cin, Cout, ks, hop)) return hipErrorInvalidValue;
-        return launch_fwd_mfma(L, x, K, bias, out, B, T, hop, kbs);
+        return launch_fwd_mfma(L, x, K, bias, out, B, T, hop, kbs, bbs);
     }
+    if (bbs != 0 && bbs != (int64_t)Cout * T) return hipErrorInvalidValue;      // (a batch-strided bias: the frames entry points only)
     if (!scratch || !model_shape(Cin, Cout, ks, hop)) {
         if (kbs != (int64_t)Cin * Cout * ks * T) return hipErrorInvalidValue;      // the generic kernels take a tensor of its own only
         FD_LAUNCH(L, "lvc_op_forward", k_lvc_fwd, dim3((Ln + 255) / 256, Cout, B), dim3(256), 0, x, K, bias, out, Cin, Cout, ks, T, hop);
         return hipSuccess;
     }
     FD_LAUNCH(L, "lvc_op_pack", k_lvc_pack<ORDER_FWD>, dim3((T + 63) / 64, ME / 64, B), dim3(256), 0, K, scratch, T, kbs);
-    return launch_fwd_mfma(L, x, scratch, bias, out, B, T, hop, (int64_t)T * ME);
+    return launch_fwd_mfma(L, x, scratch, bias, out, B, T, hop, (int64_t)T * ME, 0);
 }
 
 hipError_t lvc_op_backward(const Launch &L, const float *x, const float *K, const float *dout, float *dx, float *dK, float *dbias, int B,
-                           int Cin, int Cout, int ks, int T, int hop, float *scratch, int64_t kbs, int64_t dkbs, bool frames)
+                           int Cin, int Cout, int ks, int T, int hop, float *scratch, int64_t kbs, int64_t dkbs, bool frames, int64_t dbbs)
 {
+    if (dbbs != 0 && dbbs != (int64_t)Cout * T && !frames) return hipErrorInvalidValue;      // (a batch-strided dbias: the frames entry points only)
+    if (dbbs == 0) dbbs = (int64_t)Cout * T;
     const int Ln = T * hop;
     const int64_t own = (int64_t)Cin * Cout * ks * T;
     if (kbs == 0) kbs = own;
@@ -643,8 +649,8 @@ hipError_t lvc_op_backward(const Launch &L, const float *x, const float *K, cons
         // (the dx kernels are done with the scratch: same stream)
         float *dKf = !dK ? nullptr : frames ? dK : scratch;
         const int64_t dkfs = frames ? dkbs : (int64_t)T * ME;
-        if (hop == 8) FD_LAUNCH(L, "lvc_op_backward_k", k_lvc_dk_mfma<8>, dim3(T, B), dim3(192), 0, x, dout, dKf, dbias, T, hop, dkfs);
-        else FD_LAUNCH(L, "lvc_op_backward_k", k_lvc_dk_mfma<64>, dim3(T, B), dim3(192), 0, x, dout, dKf, dbias, T, hop, dkfs);
+        if (hop == 8) FD_LAUNCH(L, "lvc_op_backward_k", k_lvc_dk_mfma<8>, dim3(T, B), dim3(192), 0, x, dout, dKf, dbias, T, hop, dkfs, dbbs);
+        else FD_LAUNCH(L, "lvc_op_backward_k", k_lvc_dk_mfma<64>, dim3(T, B), dim3(192), 0, x, dout, dKf, dbias, T, hop, dkfs, dbbs);
         if (dK && !frames) FD_LAUNCH(L, "lvc_op_unpack", k_lvc_unpack, dim3((T + 63) / 64, ME / 64, B), dim3(256), 0, scratch, dK, T, dkbs);
     }
     return hipSuccess;

@@ -600,26 +600,32 @@ def kernel_conv1d_frames(x, weight, bias):
 
 
 class _LVCFrames(torch.autograd.Function):
-    """The location-variable convolution on one layer's frames: kernel [B, T, 6144] = frames[:, i] of kernel_conv1d_frames (batch-strided,
-    used where it lies); its gradient is written into the layer's slice of the shared buffer of split_layers (grad_slot)."""
+    """The location-variable convolution on one layer's frames: kernel [B, T, 6144] = frames[:, i] of kernel_conv1d_frames and bias
+    [B, 64, T] = bias_conv's output [:, i] (both batch-strided, used where they lie); their gradients are written into the layer's
+    slices of the shared buffers of split_layers (grad_slot, bias_slot)."""
 
     @staticmethod
-    def forward(ctx, x, kernel, bias, hop_size, grad_slot):
+    def forward(ctx, x, kernel, bias, hop_size, grad_slot, bias_slot):
         if not (x.is_cuda and kernel.is_cuda and bias.is_cuda):
             raise RuntimeError("fastdiff_amd.location_variable_convolution_frames runs only on a HIP device (no CPU fallback)")
         ctx.in_dtypes = (x.dtype, bias.dtype)
-        ctx.grad_slot = grad_slot
+        ctx.grad_slot, ctx.bias_slot = grad_slot, bias_slot
         B, _, L = x.shape
         T = kernel.shape[1]
         # (the stride of a dimension of size 1 means nothing and torch reports what it likes there)
         assert kernel.dtype == torch.float32 and tuple(kernel.shape) == (B, T, FRAME) and kernel.stride(2) == 1 and \
             (T == 1 or kernel.stride(1) == FRAME) and (B == 1 or kernel.stride(0) >= T * FRAME), "frames [B, T, 6144]"
-        ctx.kbs = kernel.stride(0) if B > 1 else T * FRAME
         assert L == T * int(hop_size), "length of (x, kernel) is not matched"
-        x, bias = x.contiguous().float(), bias.contiguous().float()
+        ctx.kbs = kernel.stride(0) if B > 1 else T * FRAME
+        x = x.contiguous().float()
+        # a layer's slice of bias_conv's [B, layers, 64, T] output is read where it lies
+        if not (bias.dtype == torch.float32 and tuple(bias.shape) == (B, 64, T) and (T == 1 or bias.stride(2) == 1) and bias.stride(1) == T and
+                (B == 1 or bias.stride(0) >= 64 * T)):
+            bias = bias.contiguous().float()
+        bbs = bias.stride(0) if B > 1 else 64 * T
         out = torch.empty((B, 64, L), device=x.device, dtype=torch.float32)
         lib, h = _handle(x.device)
-        _capi.check(lib, h, lib.fd_lvc_forward_frames(h, x.data_ptr(), kernel.data_ptr(), ctx.kbs, bias.data_ptr(), B, T, int(hop_size),
+        _capi.check(lib, h, lib.fd_lvc_forward_frames(h, x.data_ptr(), kernel.data_ptr(), ctx.kbs, bias.data_ptr(), bbs, B, T, int(hop_size),
                                                       out.data_ptr(), _stream(x.device)), "fd_lvc_forward_frames")
         ctx.save_for_backward(x, kernel)
         ctx.hop = int(hop_size)
@@ -633,28 +639,30 @@ class _LVCFrames(torch.autograd.Function):
         T = kernel.shape[1]
         need_x, need_k, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         dx = torch.empty_like(x) if need_x else None
-        dk = None
-        if need_k:
-            slot = ctx.grad_slot
-            if slot is not None:      # this layer's slice of the shared gradient buffer
-                holder, i, shape = slot
-                if holder.get("buf") is None:
-                    holder["buf"] = torch.empty(shape, device=x.device, dtype=torch.float32)
-                dk = holder["buf"][:, i]
-            else:
-                dk = torch.empty((B, T, FRAME), device=x.device, dtype=torch.float32)
-        db = torch.empty((B, 64, T), device=x.device, dtype=torch.float32) if need_b else None
+
+        def slot_or_new(slot, shape):      # this layer's slice of a shared gradient buffer (split_layers), or a tensor of its own
+            if slot is None:
+                return torch.empty(shape, device=x.device, dtype=torch.float32)
+            holder, i, full = slot
+            if holder.get("buf") is None:
+                holder["buf"] = torch.empty(full, device=x.device, dtype=torch.float32)
+            return holder["buf"][:, i]
+
+        dk = slot_or_new(ctx.grad_slot, (B, T, FRAME)) if need_k else None
+        db = slot_or_new(ctx.bias_slot if ctx.in_dtypes[1] == torch.float32 else None, (B, 64, T)) if need_b else None
         lib, h = _handle(x.device)
         _capi.check(lib, h, lib.fd_lvc_backward_frames(h, x.data_ptr(), kernel.data_ptr(), ctx.kbs, dout.data_ptr(), B, T, ctx.hop,
                                                        None if dx is None else dx.data_ptr(), None if dk is None else dk.data_ptr(),
                                                        0 if dk is None else (dk.stride(0) if B > 1 else T * FRAME),
-                                                       None if db is None else db.data_ptr(), _stream(x.device)),
+                                                       None if db is None else db.data_ptr(),
+                                                       0 if db is None else (db.stride(0) if B > 1 else 64 * T), _stream(x.device)),
                     "fd_lvc_backward_frames")
         tx, tb = ctx.in_dtypes
-        return (None if dx is None else dx.to(tx), dk, None if db is None else db.to(tb), None, None)
+        return (None if dx is None else dx.to(tx), dk, None if db is None else db.to(tb), None, None, None)
 
 
-def location_variable_convolution_frames(x, kernel_frames, bias, hop_size, grad_slot=None):
+def location_variable_convolution_frames(x, kernel_frames, bias, hop_size, grad_slot=None, bias_slot=None):
     """location_variable_convolution for x [B, 32, L], one layer's frames [B, T, 6144] (forward order) and bias [B, 64, T]; the gradient
-    with respect to the frames comes back in the "grad" order (what kernel_conv1d_frames' backward reads)."""
-    return _LVCFrames.apply(x, kernel_frames, bias, hop_size, grad_slot)
+    with respect to the frames comes back in the "grad" order (what kernel_conv1d_frames' backward reads).  grad_slot / bias_slot: the
+    slots split_layers hands out with the slices of the frames / of bias_conv's [B, layers, 64, T] output."""
+    return _LVCFrames.apply(x, kernel_frames, bias, hop_size, grad_slot, bias_slot)

@@ -113,7 +113,8 @@ def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None, split=None, frame
     if frames is not None and split is not None and (cin, cout, ks) == (32, 64, 3) and \
             frames[2](c, kc.weight_v if hasattr(kc, "weight_v") else kc.weight):
         kf = frames[0](c, _conv_weight(kc), kc.bias)                     # [B, layers, T, 6144]
-        return split(kf), conv(p.bias_conv, c).contiguous().view(B, layers, cout, T).unbind(1), True
+        # bias_conv's output likewise: the operator reads a layer's [B, 64, T] slice where it lies and writes its gradient into one buffer
+        return split(kf), split(conv(p.bias_conv, c).contiguous().view(B, layers, cout, T)), True
     k = conv(kc, c)
     # the reference slices kernels[:, i] (modules.py:213-214), whose backward builds a zero tensor of all four layers per slice and
     # adds the four up; unbind hands autograd the same views and gets one stack back.  (One kernel_conv call per layer on that
@@ -152,7 +153,7 @@ def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate, kconv=None,
             x = x + skip_of(i)
             y = F.leaky_relu(_conv(conv, F.leaky_relu(x, 0.2)), 0.2)
         if as_frames:
-            y = frames[1](y, kernels[i], bias[i], p.cond_hop_length, grad_slot=slots[i])
+            y = frames[1](y, kernels[i], bias[0][i], p.cond_hop_length, grad_slot=slots[i], bias_slot=bias[1][i])
         else:
             y = lvc(y, kernels[i], bias[i], 1, p.cond_hop_length) if slots is None else lvc(y, kernels[i], bias[i], 1, p.cond_hop_length, grad_slot=slots[i])
         x = gate(x, y)                                   # x + sigmoid(y[:, :C]) * tanh(y[:, C:])  (modules.py:217)

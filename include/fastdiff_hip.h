@@ -223,7 +223,8 @@ FD_API int fd_input_conv_backward(fd_handle h, const float *x, const float *weig
  *     frames [B, layers, T, 6144]      (M = layers * 6144; one frame = the operator's forward operand order)
  * and reads the gradient in the same shape (one frame = the operator's dK accumulator order), and the operator takes one layer's
  * [T, 6144] block per utterance where it lies: kernel_frames / dkernel_frames point at utterance 0's block of the layer, *_bstride =
- * floats between two utterances (layers * T * 6144).  Both orders are permutations of the 6144 coefficients of a frame, internal to
+ * floats between two utterances (layers * T * 6144); bias / dbias [64, T] per utterance likewise take the floats between two utterances
+ * (0 = 64 * T; layers * 64 * T for one layer's slice of bias_conv's [B, layers, 64, T] output).  Both orders are permutations of the 6144 coefficients of a frame, internal to
  * this library (csrc/fd_frame_order.h); fastdiff_amd.lvc_op.frames_to_reference / reference_to_frames convert for inspection.  Same
  * shapes and limits as above (operator: 32 -> 64 channels, k 3, hop 8 / 64 / 256; kernel_conv: M a multiple of 6144, 1 <= T <= 128);
  * results equal those of the entry points above bit for bit (same products, same summation order), except kernel_conv's dx, whose sum
@@ -232,10 +233,11 @@ FD_API int fd_kconv_forward_frames(fd_handle h, const float *x, const float *wei
                                    void *stream);
 FD_API int fd_kconv_backward_frames(fd_handle h, const float *x, const float *weight, const float *dframes, int B, int M, int T, float *dx,
                                     float *dweight, float *dbias, void *stream);
-FD_API int fd_lvc_forward_frames(fd_handle h, const float *x, const float *kernel_frames, int64_t kernel_bstride, const float *bias, int B,
-                                 int T, int hop, float *out, void *stream);
+FD_API int fd_lvc_forward_frames(fd_handle h, const float *x, const float *kernel_frames, int64_t kernel_bstride, const float *bias,
+                                 int64_t bias_bstride, int B, int T, int hop, float *out, void *stream);
 FD_API int fd_lvc_backward_frames(fd_handle h, const float *x, const float *kernel_frames, int64_t kernel_bstride, const float *dout, int B,
-                                  int T, int hop, float *dx, float *dkernel_frames, int64_t dkernel_bstride, float *dbias, void *stream);
+                                  int T, int hop, float *dx, float *dkernel_frames, int64_t dkernel_bstride, float *dbias,
+                                  int64_t dbias_bstride, void *stream);
 
 /* The gate of an LVC layer with its residual (modules.py:217) for the training path: out = x + sigmoid(y[:, :C]) * tanh(y[:, C:]),
  * x, out, dout [B,C,L], y, dy [B,2C,L] (device, float32, contiguous).  Under autograd the reference runs twelve elementwise kernels

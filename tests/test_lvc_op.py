@@ -565,19 +565,26 @@ def test_lvc_operator_on_frames_equals_the_operator_on_the_reference_layout(hop,
     # frames: one tensor for the four layers, split without copies, gradients into one buffer
     fr = lvc_op.reference_to_frames(k6, "forward").requires_grad_(True)
     slices, slots = lvc_op.split_layers(fr)
+    bias_all = bias.clone().requires_grad_(True)                                    # bias_conv's [B, layers, 64, T] output: slices where they lie
+    bslices, bslots = lvc_op.split_layers(bias_all)
     loss = 0.0
     got = []
     for i in range(layers):
-        x, b = xs[i].clone().requires_grad_(True), bias[:, i].clone().requires_grad_(True)
-        y = lvc_op.location_variable_convolution_frames(x, slices[i], b, hop, grad_slot=slots[i])
+        x = xs[i].clone().requires_grad_(True)
+        y = lvc_op.location_variable_convolution_frames(x, slices[i], bslices[i], hop, grad_slot=slots[i], bias_slot=bslots[i])
         loss = loss + (y * douts[i]).sum()
-        got.append((y, x, b))
+        got.append((y, x))
     loss.backward()
-    assert tuple(fr.grad.shape) == (B, layers, T, 6144)
+    assert tuple(fr.grad.shape) == (B, layers, T, 6144) and tuple(bias_all.grad.shape) == (B, layers, 64, T)
     dk6 = lvc_op.frames_to_reference(fr.grad, "grad")
     for i in range(layers):
-        y, x, b = got[i]
+        y, x = got[i]
         assert torch.equal(y.detach(), want[i][0]), i
-        assert torch.equal(x.grad, want[i][1]) and torch.equal(b.grad, want[i][3]), i
+        assert torch.equal(x.grad, want[i][1]) and torch.equal(bias_all.grad[:, i], want[i][3]), i
         assert torch.equal(dk6[:, i], want[i][2]), i
+    # a bias tensor of its own (no slot) goes the same way
+    x, b = xs[0].clone().requires_grad_(True), bias[:, 0].clone().requires_grad_(True)
+    y = lvc_op.location_variable_convolution_frames(x, fr.detach()[:, 0], b, hop)
+    y.backward(douts[0])
+    assert torch.equal(y.detach(), want[0][0]) and torch.equal(b.grad, want[0][3]) and torch.equal(x.grad, want[0][1])
     assert lib.fd_set_option(h, b"lvc_dx", b"gather") == 0
