@@ -97,17 +97,34 @@ __global__ void __launch_bounds__(256, 2) k_kc_fwd(const float *__restrict__ h, 
         // multiple of a cache line) then reach L2 back to back and leave it as whole lines
         f32x16 acc[4];
 #pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = bz[FRAMES ? 0 : r];
+#ifdef FD_KC_FWD_TILE_MAJOR      // (the first form: one column tile after the other, 96 dependent matrix instructions in a row)
+#pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             if (ct < nct) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[ct][r] = bz[FRAMES ? 0 : r];
-#pragma unroll
-                for (int s = 0; s < 96; ++s) {    // h[c, t + tap - 1] = hs[c][t + tap]; columns behind the utterance read zeros
+                for (int s = 0; s < 96; ++s) {
                     const float wv = f4c(a[s >> 2], s & 3), hv = hb[(s / 3) * LD + (s % 3) + ct * 32];
                     acc[ct] = FRAMES ? mfma32(hv, wv, acc[ct]) : mfma32(wv, hv, acc[ct]);
                 }
             }
         }
+#else
+        // step-major: the (up to) four column tiles of a k-step back to back -- independent accumulators, one weight register
+#pragma unroll
+        for (int s = 0; s < 96; ++s) {            // h[c, t + tap - 1] = hs[c][t + tap]; columns behind the utterance read zeros
+            const float wv = f4c(a[s >> 2], s & 3);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                if (ct < nct) {
+                    const float hv = hb[(s / 3) * LD + (s % 3) + ct * 32];
+                    acc[ct] = FRAMES ? mfma32(hv, wv, acc[ct]) : mfma32(wv, hv, acc[ct]);
+                }
+            }
+        }
+#endif
         if constexpr (FRAMES) {      // acc[ct][r] = out[t = 32 ct + drow(r, hi)][row of lane l31]
             // address = (wave-uniform frame base + a constant per (ct, r)) + a 32-bit lane offset: no address registers per store
             const int layer = p0 / fdk_order::ME, e0 = p0 - layer * fdk_order::ME, nl = M / fdk_order::ME;

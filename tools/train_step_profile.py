@@ -23,18 +23,19 @@ def family(name):
 
 def report(path, steps, warm=4):
     """path: rocprofv3's *_kernel_trace.csv of `steps` training steps; the first `warm` (MIOpen's find runs, allocator growth) are left
-    out: a step starts at the first k_kc_fwd launch after the previous step's last kernel (three per step: one per LVC block)."""
+    out."""
     rows = []
     for r in csv.DictReader(open(path)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
     marks = [i for i, r in enumerate(rows) if "k_kc_fwd" in r[2]]
     assert len(marks) == 3 * steps, (len(marks), steps)
-    # the step's first kernels (embedding, first conv, DBlocks) precede its first k_kc_fwd: cut between the last kernel of the backward
-    # (before the first k_kc_fwd of step `warm`) and them -- the longest launch gap in front of that mark is the zero_grad / loss host work
-    first = marks[3 * warm]
-    prev_last = marks[3 * warm - 1]
-    gaps = [(rows[i + 1][0] - rows[i][1], i + 1) for i in range(prev_last, first)]
+    # a step begins with the diffusion-step embedding (calc_diffusion_step_embedding: the only sin kernel of a step) and the zero_grad /
+    # loss host work in front of it: cut at the longest launch gap among the dozen launches that precede step `warm`'s sin kernel
+    sins = [i for i, r in enumerate(rows) if "sin_kernel" in r[2]]
+    assert len(sins) == steps, (len(sins), steps)
+    first = sins[warm]
+    gaps = [(rows[i + 1][0] - rows[i][1], i + 1) for i in range(max(first - 12, 0), first)]
     start = max(gaps)[1]
     rows = rows[start:]
     n = steps - warm
