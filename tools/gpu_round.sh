@@ -15,7 +15,7 @@ echo "== bench config4 (64 ragged utterances, N=6, host to host) on this one GPU
 echo "== the multi-rank path, 2 ranks sharing this GPU over gloo (FD_BENCH_OVERSUBSCRIBE: a code-path check, not a scaling number)"
 FD_BENCH_OVERSUBSCRIBE=1 timeout 900 python bench.py --gpus 2 --workload config4 --steps 3 --warmup 1 > gpurun_out/bench_config4_2ranks_1gpu.log 2>&1 ; grep '^{' gpurun_out/bench_config4_2ranks_1gpu.log | cut -c1-300
 echo "== bench --gpus 2 without the override must refuse" ; python bench.py --gpus 2 > gpurun_out/bench_gpus2_refused.log 2>&1 ; echo "rc=$?" ; tail -1 gpurun_out/bench_gpus2_refused.log
-echo "== training side: denoiser forward + backward, LVC operator vs unfold+einsum" ; timeout 600 python tools/train_step_probe.py 2>&1 | grep -v "Warning\|WeightNorm\|amdgpu.ids" | tee gpurun_out/train_step_probe.txt
+echo "== training side: denoiser forward + backward, LVC operator vs unfold+einsum" ; FD_TRAIN_VARIANTS=1 timeout 600 python tools/train_step_probe.py 2>&1 | grep -v "Warning\|WeightNorm\|amdgpu.ids\|loss_graph\|run_backward" | tee gpurun_out/train_step_probe.txt
 echo "== training step: kernel families of a steady-state step"
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_train -o train -- python $R/tools/train_step_profile.py 12 > $R/gpurun_out/rocprof_train.log 2>&1; echo "rocprof rc=$?"
 cd $R; KT=$(find gpurun_out/prof_train -name '*kernel_trace.csv' | head -1); python tools/train_step_profile.py --report $KT 12 > gpurun_out/train_step_families.txt 2>&1; head -12 gpurun_out/train_step_families.txt
