@@ -76,7 +76,7 @@ def load():
     lib.fd_input_conv_forward.argtypes = [vp, vp, vp, vp, ci, ci, ct.c_float, vp, vp]
     lib.fd_input_conv_backward.argtypes = [vp, vp, vp, vp, vp, ci, ci, ct.c_float, vp, vp, vp, vp]
     lib.fd_kconv_forward_act.argtypes = [vp, vp, vp, vp, ci, ci, ci, ct.c_float, vp, vp]
-    lib.fd_kconv_backward_act.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ct.c_float, vp, vp, vp, vp]
+    lib.fd_kconv_backward_act.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ct.c_float, ct.c_float, vp, vp, vp, vp]
     lib.fd_kconv_forward_frames.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp]
     lib.fd_kconv_backward_frames.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp]
     lib.fd_lvc_forward_frames.argtypes = [vp, vp, vp, ct.c_int64, vp, ct.c_int64, ci, ci, ci, vp, vp]

@@ -1584,7 +1584,7 @@ int fd_kconv_forward(fd_handle h, const float *x, const float *weight, const flo
 }
 
 int fd_kconv_backward_act(fd_handle h, const float *x, const float *weight, const float *y, const float *dout, int B, int M, int T,
-                          float post_slope, float *dx, float *dweight, float *dbias, void *stream)
+                          float post_slope, float in_slope, float *dx, float *dweight, float *dbias, void *stream)
 {
     if (!h) return FD_ERR_INVALID;
     if (!dout || ((dweight || dbias) && !x) || (dx && !weight)) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward: null pointer");
@@ -1593,10 +1593,13 @@ int fd_kconv_backward_act(fd_handle h, const float *x, const float *weight, cons
     int rc = check_act(h, M, T, post_slope, "fd_kconv_backward");
     if (rc != FD_OK) return rc;
     if (post_slope != 1.0f && !y) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward: a fused activation needs the forward's output y");
+    if (!(in_slope > 0.0f && in_slope <= 1.0f)) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward: in_slope must lie in (0, 1], got %g", in_slope);
+    if (in_slope != 1.0f && dx && !x) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward: in_slope needs x");
     FD_HIP(h, hipSetDevice(h->device));
     if ((rc = kconv_scratch_reserve(h, B, M, T)) != FD_OK) return rc;
     fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::kconv_backward(La, x, weight, dout, dx, dweight, dbias, B, M, T, h->kconv_scratch, false, post_slope != 1.0f ? y : nullptr, post_slope);
+    hipError_t e = fdk::kconv_backward(La, x, weight, dout, dx, dweight, dbias, B, M, T, h->kconv_scratch, false, post_slope != 1.0f ? y : nullptr, post_slope,
+                                       in_slope);
     if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_kconv_backward: %s", hipGetErrorString(e));
     return FD_OK;
 }
@@ -1604,7 +1607,7 @@ int fd_kconv_backward_act(fd_handle h, const float *x, const float *weight, cons
 int fd_kconv_backward(fd_handle h, const float *x, const float *weight, const float *dout, int B, int M, int T, float *dx, float *dweight,
                       float *dbias, void *stream)
 {
-    return fd_kconv_backward_act(h, x, weight, nullptr, dout, B, M, T, 1.0f, dx, dweight, dbias, stream);
+    return fd_kconv_backward_act(h, x, weight, nullptr, dout, B, M, T, 1.0f, 1.0f, dx, dweight, dbias, stream);
 }
 
 // A skip tensor's fan-out (fd_kernels_train.hip: k_fan_*).

@@ -54,7 +54,9 @@ bool kconv_act_supported(int M, int T);
 hipError_t kconv_forward(const Launch &L, const float *h, const float *W, const float *bias, float *out, int B, int M, int T, bool frames = false,
                          float post = 1.0f);
 hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const float *dout, float *dh, float *dW, float *dbias, int B, int M,
-                          int T, float *scratch, bool frames = false, const float *y = nullptr, float post = 1.0f);
+                          int T, float *scratch, bool frames = false, const float *y = nullptr, float post = 1.0f, float in_slope = 1.0f);
+// in_slope != 1 (a chain of such pairs): h is the activated output of the pair below and dh comes out multiplied by that activation's
+// mask (h > 0 ? 1 : in_slope), i.e. as the gradient in front of it
 // the predictor's input convolution with its activation: leaky_relu(Conv1d(80 -> 64, k5, pad 2), post) (modules.py:292-295), T <= 128;
 // the backward takes the activated output y; scratch: input_conv_scratch_floats(B) floats
 size_t input_conv_scratch_floats(int B);

@@ -453,7 +453,11 @@ __global__ void __launch_bounds__(256, 2) k_kc_dh(const float *__restrict__ W, c
 }
 
 // ---- dh, second pass: add the slices and fold the three taps: dh[b,c,t] = sum_ks sum_k G[ks][b][(c,k)][t - k + 1] --------------------
-__global__ void __launch_bounds__(256) k_kc_dh_fold(const float *__restrict__ part, float *__restrict__ dh, int B, int T, int nks)
+//      hin / in_slope (a chain of "Conv1d, LeakyReLU" pairs: the predictor's residual stack): h is itself the activated output of the
+//      pair below, and dh is wanted in front of THAT activation: dh *= (h > 0 ? 1 : in_slope) on the way out, so the pair below runs
+//      its backward on plain kernels (no mask loads in its two latency-bound launches).  hin = null: dh as it is.
+__global__ void __launch_bounds__(256) k_kc_dh_fold(const float *__restrict__ part, float *__restrict__ dh, int B, int T, int nks,
+                                                    const float *__restrict__ hin, float in_slope)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= B * CI * T) return;
@@ -467,7 +471,7 @@ __global__ void __launch_bounds__(256) k_kc_dh_fold(const float *__restrict__ pa
             if (tq >= 0 && tq < T) v += g[(int64_t)k * T + tq];
         }
     }
-    dh[idx] = v;
+    dh[idx] = (hin && !(hin[idx] > 0.0f)) ? v * in_slope : v;
 }
 
 // ---- the predictor's input convolution with its activation: Conv1d(80 -> 64, k5, pad 2), LeakyReLU (modules.py:292-295) -----------
@@ -670,7 +674,7 @@ hipError_t input_conv_backward(const Launch &L, const float *x, const float *w, 
 }
 
 hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const float *dout, float *dh, float *dW, float *dbias, int B, int M,
-                          int T, float *scratch, bool frames, const float *y, float post)
+                          int T, float *scratch, bool frames, const float *y, float post, float in_slope)
 {
     if (frames && !kconv_frames_supported(M, T)) return hipErrorInvalidValue;
     if (y && !kconv_act_supported(M, T)) return hipErrorInvalidValue;
@@ -702,7 +706,8 @@ hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const
         if (frames) FD_LAUNCH(L, "kconv_backward_h", (k_kc_dh<true, false>), dim3(nks, B), dim3(256), 0, W, dout, part_h, B, M, T, M / nks, (const float *)nullptr, 1.0f);
         else if (y) FD_LAUNCH(L, "kconv_backward_h", (k_kc_dh<false, true>), dim3(nks, B), dim3(256), 0, W, dout, part_h, B, M, T, M / nks, y, post);
         else FD_LAUNCH(L, "kconv_backward_h", (k_kc_dh<false, false>), dim3(nks, B), dim3(256), 0, W, dout, part_h, B, M, T, M / nks, y, post);
-        FD_LAUNCH(L, "kconv_backward_h_fold", k_kc_dh_fold, dim3((B * CI * T + 255) / 256), dim3(256), 0, (const float *)part_h, dh, B, T, nks);
+        FD_LAUNCH(L, "kconv_backward_h_fold", k_kc_dh_fold, dim3((B * CI * T + 255) / 256), dim3(256), 0, (const float *)part_h, dh, B, T, nks,
+                  in_slope != 1.0f ? h : (const float *)nullptr, in_slope);
     }
     return hipSuccess;
 }

@@ -196,7 +196,7 @@ class _KConv(torch.autograd.Function):
         db = torch.empty((M,), device=x.device, dtype=torch.float32) if need_b else None
         lib, h = _handle(x.device)
         _capi.check(lib, h, lib.fd_kconv_backward_act(h, x.data_ptr(), weight.data_ptr(), None if y is None else y.data_ptr(), dout.data_ptr(), B, M, T,
-                                                      ctx.post, None if dx is None else dx.data_ptr(), None if dw is None else dw.data_ptr(),
+                                                      ctx.post, 1.0, None if dx is None else dx.data_ptr(), None if dw is None else dw.data_ptr(),
                                                       None if db is None else db.data_ptr(), _stream(x.device)), "fd_kconv_backward")
         tx, tw, tb = ctx.in_dtypes
         return (None if dx is None else dx.to(tx), None if dw is None else dw.to(tw), None if db is None else db.to(tb), None)
@@ -287,6 +287,62 @@ def input_conv_supported(x, weight):
 def input_conv(x, weight, bias, post_slope=0.1):
     """leaky_relu(conv1d(x [B,80,T], weight [64,80,5], bias, padding=2), post_slope) as a differentiable HIP operator."""
     return _InputConv.apply(x, weight, bias, post_slope)
+
+
+class _KConvStack(torch.autograd.Function):
+    """A chain of `Conv1d(64, 64, 3, padding 1), LeakyReLU(slope)` pairs -- the predictor's residual stack (modules.py:297-314) -- as ONE
+    autograd node: n forward launches with the activation in the store; in the backward the gradient that a pair hands down is
+    multiplied by the mask of the pair below as it is written (fd_kconv_backward_act: in_slope), so only the top pair's two
+    latency-bound launches read an activation mask.  Inputs: x [B, 64, T], then weight_1, bias_1, ..., weight_n, bias_n."""
+
+    @staticmethod
+    def forward(ctx, x, slope, *params):
+        n = len(params) // 2
+        ctx.in_dtype = x.dtype
+        ctx.slope, ctx.n = float(slope), n
+        hs = [x.contiguous().float()]
+        ws = [params[2 * j].contiguous().float() for j in range(n)]
+        B, _, T = hs[0].shape
+        lib, h = _handle(x.device)
+        for j in range(n):
+            out = torch.empty((B, 64, T), device=x.device, dtype=torch.float32)
+            _capi.check(lib, h, lib.fd_kconv_forward_act(h, hs[-1].data_ptr(), ws[j].data_ptr(), params[2 * j + 1].contiguous().float().data_ptr(), B, 64, T,
+                                                         ctx.slope, out.data_ptr(), _stream(x.device)), "fd_kconv_forward")
+            hs.append(out)
+        ctx.save_for_backward(*hs, *ws)
+        return hs[-1].to(ctx.in_dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        n = ctx.n
+        hs, ws = ctx.saved_tensors[:n + 1], ctx.saved_tensors[n + 1:]
+        B, _, T = hs[0].shape
+        g = dout.contiguous().float()
+        grads = [None] * (2 * n)
+        lib, h = _handle(g.device)
+        for j in range(n - 1, -1, -1):
+            top, bottom = j == n - 1, j == 0
+            need_x = (not bottom) or ctx.needs_input_grad[0]
+            dx = torch.empty_like(hs[j]) if need_x else None
+            dw = torch.empty_like(ws[j]) if ctx.needs_input_grad[2 + 2 * j] else None
+            db = torch.empty(64, device=g.device, dtype=torch.float32) if ctx.needs_input_grad[3 + 2 * j] else None
+            # the top pair masks dout with its own output; every pair hands down the gradient in front of the activation below it
+            _capi.check(lib, h, lib.fd_kconv_backward_act(h, hs[j].data_ptr(), ws[j].data_ptr(), hs[j + 1].data_ptr() if top else None, g.data_ptr(), B, 64, T,
+                                                          ctx.slope if top else 1.0, 1.0 if bottom else ctx.slope,
+                                                          None if dx is None else dx.data_ptr(), None if dw is None else dw.data_ptr(),
+                                                          None if db is None else db.data_ptr(), _stream(g.device)), "fd_kconv_backward")
+            grads[2 * j], grads[2 * j + 1] = dw, db
+            g = dx
+        return (None if g is None else g.to(ctx.in_dtype), None) + tuple(grads)
+
+
+def kernel_conv_stack(x, weights, biases, slope):
+    """leaky_relu(conv1d(., w_j, b_j, padding=1), slope) applied n times in a row to x [B, 64, T] (every w_j [64, 64, 3]) as one
+    differentiable HIP operator: the predictor's residual stack without its Dropout(p = 0) modules."""
+    params = []
+    for w, b in zip(weights, biases):
+        params += [w, b]
+    return _KConvStack.apply(x, slope, *params)
 
 
 class _Conv7(torch.autograd.Function):

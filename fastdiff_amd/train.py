@@ -106,8 +106,19 @@ def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None, split=None, frame
                 i += 1
         return h
 
+    def stack(seq, h):   # a Sequential of nothing but "Conv1d(64, 64, 3), LeakyReLU(s)" pairs and Dropout(p = 0): ONE autograd node
+        mods = [m for m in seq if not (isinstance(m, torch.nn.Dropout) and (m.p == 0 or not m.training))]
+        convs, acts = mods[0::2], mods[1::2]
+        if not (fuse_act and kconv is not None and len(kconv) > 4 and len(mods) >= 2 and len(convs) == len(acts) and
+                all(isinstance(a, torch.nn.LeakyReLU) and a.negative_slope == acts[0].negative_slope for a in acts) and
+                all(fits(m, h) and m.out_channels == 64 for m in convs)):
+            return None
+        return kconv[4](h, [_conv_weight(m) for m in convs], [m.bias for m in convs], acts[0].negative_slope)
+
     c = run(p.input_conv, c)                     # Conv1d 80 -> 64 k5, LeakyReLU(0.1)
-    r = run(p.residual_conv, c)                  # Dropout(p = 0), Conv1d 64 -> 64 k3, LeakyReLU(0.1), Conv1d, LeakyReLU, three times
+    r = stack(p.residual_conv, c)                # Dropout(p = 0), Conv1d 64 -> 64 k3, LeakyReLU(0.1), Conv1d, LeakyReLU, three times
+    if r is None:
+        r = run(p.residual_conv, c)
     c = c + r
     kc = p.kernel_conv
     if frames is not None and split is not None and (cin, cout, ks) == (32, 64, 3) and \
@@ -166,8 +177,9 @@ def differentiable_forward(module, data, lvc=None):
     if lvc is None:                    # the product path: the layer's operators, its convolution and the predictor's kernel_conv on HIP kernels
         from .lvc_op import (location_variable_convolution as lvc, gated_residual as gate, kernel_conv1d, kernel_conv_supported, conv32,
                              conv32_supported, split_layers, kernel_conv1d_frames, location_variable_convolution_frames,
-                             kernel_conv_frames_supported, input_conv, input_conv_supported)
-        kconv = (kernel_conv1d, kernel_conv_supported, input_conv_supported, input_conv)
+                             kernel_conv_frames_supported, input_conv, input_conv_supported, kernel_conv_stack)
+        kconv = (kernel_conv1d, kernel_conv_supported, input_conv_supported, input_conv) + \
+            ((kernel_conv_stack,) if getattr(module, "_train_stack", True) else ())      # (False: one node per pair, for A/B runs)
         cconv = (conv32, conv32_supported)
         split = split_layers
         if getattr(module, "_train_frames", True):      # (False: the reference's kernel tensor between the two operators, for A/B runs)

@@ -192,11 +192,14 @@ FD_API int fd_kconv_backward(fd_handle h, const float *x, const float *weight, c
                              float *dweight, float *dbias, void *stream);
 /* The same with the activation the predictor puts behind its small convolutions (modules.py:296-314: Conv1d, LeakyReLU(0.1)) inside:
  * out = leaky_relu(conv, post_slope); the backward takes that output (y) and dout = the gradient behind the activation.  M <= 512
- * (input and residual convolutions: M = 64); post_slope = 1 is the plain convolution (y may then be NULL). */
+ * (input and residual convolutions: M = 64); post_slope = 1 is the plain convolution (y may then be NULL).
+ * in_slope (a chain of such pairs, e.g. the six of the predictor's residual stack, where x is itself the activated output of the
+ * pair below and has no other reader): dx comes out multiplied by THAT activation's mask (x > 0 ? 1 : in_slope), i.e. as the
+ * gradient in front of it, and the pair below is then called with post_slope = 1 on that gradient; 1 = dx as it is. */
 FD_API int fd_kconv_forward_act(fd_handle h, const float *x, const float *weight, const float *bias, int B, int M, int T, float post_slope,
                                 float *out, void *stream);
 FD_API int fd_kconv_backward_act(fd_handle h, const float *x, const float *weight, const float *y, const float *dout, int B, int M, int T,
-                                 float post_slope, float *dx, float *dweight, float *dbias, void *stream);
+                                 float post_slope, float in_slope, float *dx, float *dweight, float *dbias, void *stream);
 
 /* A skip tensor's fan-out on the training path (FastDiff_model.py:91-98): x [rows = B*C, L] is read by the DiffusionDBlock below it, which
  * begins by picking every factor-th column (F.interpolate to L / factor, nearest: modules.py:128-131), and as `audio_down` by the four

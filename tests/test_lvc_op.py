@@ -232,6 +232,49 @@ def test_kernel_conv_with_its_activation_inside_matches_torch_autograd(shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,T,n", [(3, 100, 6), (2, 37, 2), (1, 128, 1), (2, 1, 3), (20, 100, 6)])
+def test_residual_stack_as_one_node_equals_the_pairs_one_by_one(B, T, n):
+    """lvc_op.kernel_conv_stack = n `Conv1d(64, 64, 3), LeakyReLU(0.1)` pairs (the predictor's residual stack, modules.py:297-314) as one
+    autograd node whose backward hands the gradient down already multiplied by the activation mask of the pair below: against the
+    pairs one by one on kernel_conv1d(..., post_slope) -- same kernels, the mask applied one kernel earlier: bit-equal -- and against
+    torch in float64."""
+    import fastdiff_amd
+    from fastdiff_amd import lvc_op
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(B + T + n)
+    x = torch.randn(B, 64, T, generator=g)
+    ws = [torch.randn(64, 64, 3, generator=g) / 9.0 for _ in range(n)]
+    bs = [torch.randn(64, generator=g) * 0.3 for _ in range(n)]
+    dout = torch.randn(B, 64, T, generator=g)
+    x64 = x.double().requires_grad_(True)
+    p64 = [(w.double().requires_grad_(True), b.double().requires_grad_(True)) for w, b in zip(ws, bs)]
+    h = x64
+    for w, b in p64:
+        h = F.leaky_relu(F.conv1d(h, w, b, padding=1), 0.1)
+    h.backward(dout.double())
+    xa = x.cuda().requires_grad_(True)
+    pa = [(w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)) for w, b in zip(ws, bs)]
+    ya = lvc_op.kernel_conv_stack(xa, [w for w, _ in pa], [b for _, b in pa], 0.1)
+    ya.backward(dout.cuda())
+    xb = x.cuda().requires_grad_(True)
+    pb = [(w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)) for w, b in zip(ws, bs)]
+    yb = xb
+    for w, b in pb:
+        yb = fastdiff_amd.kernel_conv1d(yb, w, b, 0.1)
+    yb.backward(dout.cuda())
+    assert torch.equal(ya.detach(), yb.detach()) and torch.equal(xa.grad, xb.grad)
+    for (wa, ba), (wb, bb) in zip(pa, pb):
+        assert torch.equal(wa.grad, wb.grad) and torch.equal(ba.grad, bb.grad)
+    rel = lambda got, want: float((got.double().cpu() - want).abs().max()) / max(1.0, float(want.abs().max()))      # noqa: E731
+    assert rel(ya.detach(), h.detach()) < 5e-6 and rel(xa.grad, x64.grad) < 1e-5
+    for (wa, ba), (w6, b6) in zip(pa, p64):
+        assert rel(wa.grad, w6.grad) < 1e-5 and rel(ba.grad, b6.grad) < 1e-5
+    # only the parameters need gradients (the stack's input does not): no dx of the bottom pair
+    y2 = lvc_op.kernel_conv_stack(x.cuda(), [w.detach().requires_grad_(True) for w, _ in pa], [b for _, b in pa], 0.1)
+    y2.backward(dout.cuda())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,L,f", [(2, 1024, 4), (3, 96, 8), (1, 8, 8), (2, 30, 3), (20, 25600, 4)])
 def test_skip_fan_out_picks_and_adds_up_like_autograd(B, L, f):
     """lvc_op.skip_fan(x, f) = (x[..., ::f], x, x, x, x): the DBlock's nearest pick (F.interpolate to L / f, modules.py:128-131) and one
