@@ -1610,6 +1610,31 @@ int fd_kconv_backward(fd_handle h, const float *x, const float *weight, const fl
     return fd_kconv_backward_act(h, x, weight, nullptr, dout, B, M, T, 1.0f, 1.0f, dx, dweight, dbias, stream);
 }
 
+static int weight_norm_multi(fd_handle h, const fd_wn_item *items, int n, void *stream, bool backward, const char *who)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!items) FD_FAIL(h, FD_ERR_INVALID, "%s: null pointer", who);
+    if (n <= 0 || n > 4096) FD_FAIL(h, FD_ERR_INVALID, "%s: n=%d", who, n);
+    for (int i = 0; i < n; ++i) {
+        const fd_wn_item &I = items[i];
+        if (I.rows <= 0 || I.cols <= 0 || I.rows > ((int64_t)1 << 31) || !I.v || !I.g || !I.norm || (backward ? (!I.dv || !I.dg) : !I.w))
+            FD_FAIL(h, FD_ERR_INVALID, "%s: item %d: rows=%lld cols=%d or a null pointer", who, i, (long long)I.rows, I.cols);
+    }
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::weight_norm_multi(La, items, n, backward);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "%s: %s", who, hipGetErrorString(e));
+    return FD_OK;
+}
+int fd_weight_norm_multi_forward(fd_handle h, const fd_wn_item *items, int n, void *stream)
+{
+    return weight_norm_multi(h, items, n, stream, false, "fd_weight_norm_multi_forward");
+}
+int fd_weight_norm_multi_backward(fd_handle h, const fd_wn_item *items, int n, void *stream)
+{
+    return weight_norm_multi(h, items, n, stream, true, "fd_weight_norm_multi_backward");
+}
+
 // A skip tensor's fan-out (fd_kernels_train.hip: k_fan_*).
 int fd_fan_forward(fd_handle h, const float *x, int rows, int64_t L, int factor, float *picked, void *stream)
 {

@@ -85,4 +85,6 @@ hipError_t convt_backward(const Launch &L, const float *x, const float *w, const
 hipError_t weight_norm_forward(const Launch &L, const float *v, const float *g, float *w, float *norm, int64_t rows, int cols);
 hipError_t weight_norm_backward(const Launch &L, const float *v, const float *g, const float *norm, const float *dw, float *dv, float *dg,
                                 int64_t rows, int cols);
+// ... for n tensors in ceil(n / 28) launches: items in HOST memory (include/fastdiff_hip.h: fd_wn_item), passed on as kernel arguments
+hipError_t weight_norm_multi(const Launch &L, const fd_wn_item *items, int n, bool backward);
 }  // namespace fdk

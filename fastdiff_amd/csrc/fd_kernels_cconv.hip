@@ -628,6 +628,84 @@ namespace fdk {
 
 using namespace fdk_cconv;
 
+// ---- the same for MANY parameter tensors in one launch (the module has 53 weight-normed convolutions: 106 launches of a few
+//      microseconds each per training step otherwise).  The records travel as KERNEL ARGUMENTS (<= WN_CHUNK per launch: 2.1 KB of the
+//      4 KB a launch may carry), not through a table in device memory: nothing to upload, nothing whose lifetime a captured graph
+//      would depend on.  first_block: the first workgroup of each tensor (4 rows per workgroup); a workgroup finds its tensor by
+//      bisection.
+constexpr int WN_CHUNK = 28;
+struct WnChunk {
+    fd_wn_item it[WN_CHUNK];
+    int first_block[WN_CHUNK + 1];
+    int n;
+};
+
+__device__ __forceinline__ int wn_find_item(const WnChunk &c, int blk)
+{
+    int lo = 0, hi = c.n;      // first_block[lo] <= blk < first_block[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (c.first_block[mid] <= blk) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256) k_wn_multi_fwd(const WnChunk c)
+{
+    const int it = wn_find_item(c, blockIdx.x);
+    const fd_wn_item &I = c.it[it];
+    const int64_t r = (int64_t)(blockIdx.x - c.first_block[it]) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, cols = I.cols;
+    if (r >= I.rows) return;
+    const float *vr = I.v + r * cols;
+    float ss = 0.0f;
+    for (int k = lane; k < cols; k += 64) ss = fmaf(vr[k], vr[k], ss);
+    const float nrm = sqrtf(wave_sum(ss)), sc = I.g[r] / nrm;
+    for (int k = lane; k < cols; k += 64) I.w[r * cols + k] = vr[k] * sc;
+    if (lane == 0) I.norm[r] = nrm;
+}
+
+__global__ void __launch_bounds__(256) k_wn_multi_bwd(const WnChunk c)
+{
+    const int it = wn_find_item(c, blockIdx.x);
+    const fd_wn_item &I = c.it[it];
+    const int64_t r = (int64_t)(blockIdx.x - c.first_block[it]) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, cols = I.cols;
+    if (r >= I.rows) return;
+    if (!I.dw) {      // this weight took no part in the loss: zero gradients
+        for (int k = lane; k < cols; k += 64) I.dv[r * cols + k] = 0.0f;
+        if (lane == 0) I.dg[r] = 0.0f;
+        return;
+    }
+    const float *vr = I.v + r * cols, *dr = I.dw + r * cols;
+    float dot = 0.0f;
+    for (int k = lane; k < cols; k += 64) dot = fmaf(dr[k], vr[k], dot);
+    dot = wave_sum(dot);
+    const float nrm = I.norm[r], gn = I.g[r] / nrm, k2 = dot / (nrm * nrm);
+    for (int k = lane; k < cols; k += 64) I.dv[r * cols + k] = gn * (dr[k] - vr[k] * k2);
+    if (lane == 0) I.dg[r] = dot / nrm;
+}
+
+// items: HOST memory
+hipError_t weight_norm_multi(const Launch &L_, const fd_wn_item *items, int n, bool backward)
+{
+    for (int i0 = 0; i0 < n; i0 += WN_CHUNK) {
+        WnChunk c;
+        c.n = std::min(WN_CHUNK, n - i0);
+        int blocks = 0;
+        for (int i = 0; i < c.n; ++i) {
+            c.it[i] = items[i0 + i];
+            c.first_block[i] = blocks;
+            blocks += (int)((items[i0 + i].rows + 3) / 4);
+        }
+        for (int i = c.n; i <= WN_CHUNK; ++i) c.first_block[i] = blocks;
+        if (blocks == 0) continue;
+        if (backward) FD_LAUNCH(L_, "weight_norm_multi_bwd", k_wn_multi_bwd, dim3((unsigned)blocks), dim3(256), 0, c);
+        else FD_LAUNCH(L_, "weight_norm_multi_fwd", k_wn_multi_fwd, dim3((unsigned)blocks), dim3(256), 0, c);
+    }
+    return hipSuccess;
+}
+
 hipError_t weight_norm_forward(const Launch &L_, const float *v, const float *g, float *w, float *norm, int64_t rows, int cols)
 {
     FD_LAUNCH(L_, "weight_norm_fwd", k_wn_fwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, v, g, w, norm, rows, cols);

@@ -473,6 +473,66 @@ def weight_norm(v, g):
     return torch._weight_norm(v, g, 0)
 
 
+class _WeightNormAll(torch.autograd.Function):
+    """w_i = torch._weight_norm(v_i, g_i, 0) for ALL weight-normed convolutions of the module in one or two launches each way
+    (fd_weight_norm_multi_forward / _backward; inputs v_1, g_1, v_2, g_2, ...).  The w_i are views of one flat buffer, and so are the
+    gradients dv_i / dg_i (which become the parameters' .grad).  The host work per call is a few vectorised numpy statements and two
+    torch.split calls: in eager mode this operator sits at the very end of the backward, where nothing hides it."""
+
+    @staticmethod
+    def forward(ctx, *vg):
+        import numpy as np
+        n = len(vg) // 2
+        vs, gs = [t.contiguous() for t in vg[0::2]], [t.contiguous() for t in vg[1::2]]
+        dev = vs[0].device
+        rows = np.array([v.shape[0] for v in vs], dtype=np.int64)
+        numel = np.array([v.numel() for v in vs], dtype=np.int64)
+        ow, on = np.concatenate(([0], np.cumsum(numel)[:-1])), np.concatenate(([0], np.cumsum(rows)[:-1]))
+        W = torch.empty(int(numel.sum()), device=dev, dtype=torch.float32)
+        N = torch.empty(int(rows.sum()), device=dev, dtype=torch.float32)
+        tab = np.zeros((n, 9), dtype=np.int64)      # fd_wn_item: v, g, w, norm, dw, dv, dg, rows, cols (+ reserved)
+        tab[:, 0] = [v.data_ptr() for v in vs]
+        tab[:, 1] = [g.data_ptr() for g in gs]
+        tab[:, 2] = W.data_ptr() + 4 * ow
+        tab[:, 3] = N.data_ptr() + 4 * on
+        tab[:, 7] = rows
+        tab[:, 8] = numel // rows
+        lib, h = _handle(dev)
+        _capi.check(lib, h, lib.fd_weight_norm_multi_forward(h, tab.ctypes.data, n, _stream(dev)), "fd_weight_norm_multi_forward")
+        ctx.save_for_backward(N, *vs, *gs)
+        ctx.tab, ctx.ow, ctx.on, ctx.sizes = tab, ow, on, (numel.tolist(), rows.tolist())
+        return tuple(w.view(v.shape) for w, v in zip(W.split(ctx.sizes[0]), vs))
+
+    @staticmethod
+    def backward(ctx, *dws):
+        n = len(dws)
+        N, vs, gs = ctx.saved_tensors[0], ctx.saved_tensors[1:1 + n], ctx.saved_tensors[1 + n:]
+        dev = N.device
+        DV = torch.empty(sum(ctx.sizes[0]), device=dev, dtype=torch.float32)
+        DG = torch.empty(sum(ctx.sizes[1]), device=dev, dtype=torch.float32)
+        dws = [None if d is None else d.contiguous().float() for d in dws]      # (kept alive until the launch is enqueued)
+        tab = ctx.tab.copy()
+        tab[:, 4] = [0 if d is None else d.data_ptr() for d in dws]
+        tab[:, 5] = DV.data_ptr() + 4 * ctx.ow
+        tab[:, 6] = DG.data_ptr() + 4 * ctx.on
+        lib, h = _handle(dev)
+        _capi.check(lib, h, lib.fd_weight_norm_multi_backward(h, tab.ctypes.data, n, _stream(dev)), "fd_weight_norm_multi_backward")
+        out = []
+        for dv, dg, v, g in zip(DV.split(ctx.sizes[0]), DG.split(ctx.sizes[1]), vs, gs):
+            out.append(dv.view(v.shape))
+            out.append(dg.view(g.shape))
+        return tuple(out)
+
+
+def weight_norm_all(pairs):
+    """[torch._weight_norm(v, g, 0) for (v, g) in pairs] for float32 HIP tensors, all in one differentiable operator (one or two
+    launches each way whatever the number of tensors)."""
+    flat = []
+    for v, g in pairs:
+        flat += [v, g]
+    return list(_WeightNormAll.apply(*flat))
+
+
 class _Conv32(torch.autograd.Function):
     """xs = x (+ skip); y = post(bias + conv1d(pre(xs), weight, dilation, padding = dilation)) -- one of the denoiser's 21 small
     convolutions with everything the reference wraps around it (modules.py:136-137 and 209-212), forward in one HIP pass

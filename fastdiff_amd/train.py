@@ -27,9 +27,16 @@ def _swish(x):
     return x * torch.sigmoid(x)
 
 
+_WN = {}      # id(module) -> its effective weight for the forward being recorded (differentiable_forward: all of them from ONE operator)
+
+
 def _conv_weight(m):
     """The effective weight of a conv module: g * v / ||v|| while weight-norm is attached (what its forward hook computes: on HIP
-    tensors one launch of fastdiff_amd.lvc_op.weight_norm each way), the plain weight after remove_weight_norm()."""
+    tensors one operator for all convolutions of the module, lvc_op.weight_norm_all, else one launch of lvc_op.weight_norm each way per
+    convolution), the plain weight after remove_weight_norm()."""
+    w = _WN.get(id(m))
+    if w is not None:
+        return w
     if hasattr(m, "weight_g"):
         if m.weight_v.is_cuda:
             from .lvc_op import weight_norm
@@ -186,6 +193,24 @@ def differentiable_forward(module, data, lvc=None):
             frames = (kernel_conv1d_frames, location_variable_convolution_frames, kernel_conv_frames_supported)
     audio, c, diffusion_steps = data
     cfg = module._cfg
+    _WN.clear()
+    if cconv is not None and audio.is_cuda and getattr(module, "_train_wn_all", True):      # (False: one operator per convolution, for A/B runs)
+        from .lvc_op import weight_norm_all
+        cands = module.__dict__.get("_wn_candidates")      # (the module tree does not change between steps: walk it once)
+        if cands is None:
+            cands = module.__dict__["_wn_candidates"] = [m for m in module.modules() if isinstance(m, torch.nn.Conv1d)]
+        mods = [m for m in cands if hasattr(m, "weight_g") and m.weight_v.is_cuda and
+                m.weight_v.dtype == torch.float32 and m.weight_g.dtype == torch.float32 and m.weight_g.numel() == m.weight_v.shape[0]]
+        if mods:
+            for m, w in zip(mods, weight_norm_all([(m.weight_v, m.weight_g) for m in mods])):
+                _WN[id(m)] = w
+    try:
+        return _forward_body(module, audio, c, diffusion_steps, cfg, lvc, gate, kconv, cconv, split, frames)
+    finally:
+        _WN.clear()
+
+
+def _forward_body(module, audio, c, diffusion_steps, cfg, lvc, gate, kconv, cconv, split, frames):
     if c.dim() == 2:
         c = c.unsqueeze(0)
     emb = calc_diffusion_step_embedding(diffusion_steps.to(audio.dtype).view(audio.shape[0], 1), cfg["diffusion_step_embed_dim_in"])

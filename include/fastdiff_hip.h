@@ -273,6 +273,21 @@ FD_API int fd_upsample_backward(fd_handle h, const float *x, const float *weight
 FD_API int fd_weight_norm_forward(fd_handle h, const float *v, const float *g, int64_t rows, int cols, float *w, float *norm, void *stream);
 FD_API int fd_weight_norm_backward(fd_handle h, const float *v, const float *g, const float *norm, const float *dw, int64_t rows, int cols,
                                    float *dv, float *dg, void *stream);
+/* The same for n parameter tensors in ceil(n / 28) launches each way (the model has 53 weight-normed convolutions: 106 launches of a
+ * few microseconds per training step otherwise).  items: n records in HOST memory -- the library passes them on as kernel arguments, so
+ * nothing is uploaded and a captured graph depends on no table's lifetime; every pointer inside is a device pointer: forward reads
+ * v, g and writes w, norm; backward reads v, g, norm, dw and writes dv, dg (dw == NULL: that weight took no part in the loss, its dv and
+ * dg are zeroed). */
+typedef struct fd_wn_item {
+    const float *v, *g;      /* [rows, cols], [rows] */
+    float *w, *norm;         /* [rows, cols], [rows] */
+    const float *dw;         /* [rows, cols] or NULL */
+    float *dv, *dg;          /* [rows, cols], [rows] */
+    int64_t rows;
+    int32_t cols, reserved;
+} fd_wn_item;
+FD_API int fd_weight_norm_multi_forward(fd_handle h, const fd_wn_item *items, int n, void *stream);
+FD_API int fd_weight_norm_multi_backward(fd_handle h, const fd_wn_item *items, int n, void *stream);
 
 /* The denoiser's 21 small convolutions on the training path -- DiffusionDBlock.conv[0..2] applied as `layer(F.leaky_relu(x, 0.2))`
  * (modules/FastDiff/module/modules.py:120-125,136-137) and TimeAware_LVCBlock.convs[0..3] applied as `x += audio_down;

@@ -422,6 +422,33 @@ def test_weight_norm_operator_matches_torch(shape):
 
 
 @pytest.mark.gpu
+def test_weight_norm_of_all_convolutions_in_one_operator():
+    """lvc_op.weight_norm_all = torch._weight_norm(v, g, 0) for a list of tensors in one operator (the records travel as kernel
+    arguments, 28 per launch): 60 tensors of the model's shapes -- more than two launches' worth --, against the one-tensor operator
+    (same per-row code: same bits, forward and backward) and torch; a weight that takes no part in the loss gets zero gradients."""
+    from fastdiff_amd import lvc_op
+    g = torch.Generator().manual_seed(4)
+    shapes = [(24576, 64, 3), (256, 64, 3), (64, 80, 5), (32, 1, 7), (1, 32, 7), (32, 32, 1)] + [(64, 64, 3)] * 24 + [(32, 32, 3)] * 30
+    vs = [torch.randn(*sh, generator=g).cuda() for sh in shapes]
+    gs = [(torch.rand(sh[0], 1, 1, generator=g) + 0.5).cuda() for sh in shapes]
+    douts = [torch.randn(*sh, generator=g).cuda() for sh in shapes]
+    unused = {7, 41}
+    va, ga = [v.clone().requires_grad_(True) for v in vs], [x.clone().requires_grad_(True) for x in gs]
+    ws = lvc_op.weight_norm_all(list(zip(va, ga)))
+    sum((w * d).sum() for i, (w, d) in enumerate(zip(ws, douts)) if i not in unused).backward()
+    for i, sh in enumerate(shapes):
+        vb, gb = vs[i].clone().requires_grad_(True), gs[i].clone().requires_grad_(True)
+        wb = lvc_op.weight_norm(vb, gb)
+        assert torch.equal(ws[i].detach(), wb.detach()), i
+        assert torch.allclose(wb.detach(), torch._weight_norm(vs[i], gs[i], 0), rtol=1e-6, atol=1e-7), i
+        if i in unused:
+            assert float(va[i].grad.abs().max()) == 0.0 and float(ga[i].grad.abs().max()) == 0.0
+            continue
+        (wb * douts[i]).sum().backward()
+        assert torch.equal(va[i].grad, vb.grad) and torch.equal(ga[i].grad, gb.grad), i
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("which,B,L", [(0, 2, 1024), (1, 2, 1024), (0, 3, 260), (1, 3, 260), (0, 1, 4), (1, 1, 4), (0, 20, 25600), (1, 20, 25600)])
 def test_conv7_operators_forward_and_backward_match_torch_autograd(which, B, L):
     """fastdiff_amd.lvc_op.conv7 = first_audio_conv (Conv1d(1, 32, 7, padding 3), FastDiff_model.py:34-36) and final_conv (Conv1d(32, 1,
