@@ -2,17 +2,22 @@
 `theta_timestep_loss` (util.py:291-325).
 
 The inference path (fd_forward / fd_sample) is one hand-written pipeline with no saved activations; training needs them, and needs
-gradients with respect to 175 parameter tensors.  Split used here: the location-variable convolution -- twelve calls per forward,
-each reading a predicted kernel 6144 x T floats large, the operator the reference implements with unfold + einsum over a
-[B, C, T, hop + 2, 3] view (modules.py:220-253) -- runs forward AND backward on the HIP operator
-(fastdiff_amd.location_variable_convolution: fd_lvc_forward / fd_lvc_backward); the plain convolutions, linear layers and
-activations around it are torch.autograd nodes on the module's own parameters -- except the 21 small 32-channel convolutions (three per
-DiffusionDBlock, four per LVC block), each of which runs with its pre-activation, skip add, bias and post-activation as one HIP
-operator forward and backward (fastdiff_amd.conv32: fd_conv32_forward / fd_conv32_backward), the gate, and the predictor's
-kernel_conv; the rest stays on torch (weight-norm included: the sub-modules of
-fastdiff_amd.FastDiff are real nn.Conv1d / nn.Linear holders with the reference's weight_g / weight_v parametrisation), so the
-reference's optimizer, checkpointing and DDP wrapper see the module they expect.  FastDiff.forward takes this path when autograd is
-recording and the module is in train() mode or an input requires a gradient; everything else stays on the inference kernels.
+gradients with respect to 175 parameter tensors.  Here the network is a graph of torch.autograd.Function nodes over the C ABI's training
+operators (fastdiff_amd/lvc_op.py), forward and backward on HIP kernels:
+  * the location-variable convolution, twelve per forward -- the operator the reference states as unfold + einsum over a
+    [B, C, T, hop + 2, 3] view (modules.py:220-253) -- reading the predictor's kernel_conv output as frame-major operands
+    (kernel_conv1d_frames -> location_variable_convolution_frames: no transposes between the two), and the gate behind it;
+  * the 21 small 32-channel convolutions with their skip add, activations and bias (conv32), first_audio_conv / final_conv (conv7),
+    the up-samplers (upsample), the skip tensors' fan-out (skip_fan);
+  * the KernelPredictor: input convolution + activation (input_conv), the residual stack as one node (kernel_conv_stack),
+    kernel_conv and bias_conv;
+  * weight-norm of all 53 convolutions in one operator (weight_norm_all).
+What stays on torch: the step embedding's five linear layers and swish, three broadcast adds, the loss (4 % of the step's kernel time).
+The sub-modules of fastdiff_amd.FastDiff are real nn.Conv1d / nn.Linear holders with the reference's weight_g / weight_v
+parametrisation, so the reference's optimizer, checkpointing and DDP wrapper see the module they expect.  FastDiff.forward takes this
+path when autograd is recording and the module is in train() mode or an input requires a gradient; everything else stays on the
+inference kernels.  module._train_frames / _train_fuse_act / _train_skip_fan / _train_stack / _train_wn_all = False switch single
+pieces back to their predecessor (A/B runs: tools/train_step_probe.py).
 
 `lvc` (tests only): a replacement for the HIP operator with the same signature, so that the structure around it can be pinned on
 the reference's gradients on a machine without a GPU; the product never passes it.
