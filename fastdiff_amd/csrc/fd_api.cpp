@@ -1604,6 +1604,34 @@ int fd_kconv_backward_act(fd_handle h, const float *x, const float *weight, cons
     return FD_OK;
 }
 
+int fd_kconv_backward_w_multi(fd_handle h, int n, const float *const *x, const float *const *dout, const float *const *y, int B, int M, int T,
+                              float post_slope, float *const *dweight, float *const *dbias, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (!x || !dout || (!dweight && !dbias)) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward_w_multi: null pointer");
+    if (n < 1 || n > 8) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward_w_multi: n=%d outside 1..8", n);
+    if (B <= 0 || B > 65535) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward_w_multi: B=%d", B);
+    if (!fdk::kconv_act_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_backward_w_multi: M=%d (a multiple of 32, <= 512) and T=%d (1..128) only", M, T);
+    int rc = check_act(h, M, T, post_slope, "fd_kconv_backward_w_multi");
+    if (rc != FD_OK) return rc;
+    for (int i = 0; i < n; ++i)
+        if (!x[i] || !dout[i]) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward_w_multi: null pointer in item %d", i);
+    FD_HIP(h, hipSetDevice(h->device));
+    {
+        const size_t bytes = sizeof(float) * fdk::kconv_w_multi_scratch_floats(n, B, M);
+        if (h->kconv_scratch_bytes < bytes) {
+            if (h->kconv_scratch) FD_HIP(h, hipFree(h->kconv_scratch));
+            h->kconv_scratch = nullptr; h->kconv_scratch_bytes = 0;
+            FD_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->kconv_scratch), bytes));
+            h->kconv_scratch_bytes = bytes;
+        }
+    }
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::kconv_backward_w_multi(La, n, x, dout, y, post_slope, B, M, T, dweight, dbias, h->kconv_scratch);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_kconv_backward_w_multi: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
 int fd_kconv_backward(fd_handle h, const float *x, const float *weight, const float *dout, int B, int M, int T, float *dx, float *dweight,
                       float *dbias, void *stream)
 {

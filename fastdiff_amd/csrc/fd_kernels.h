@@ -55,6 +55,11 @@ hipError_t kconv_forward(const Launch &L, const float *h, const float *W, const 
                          float post = 1.0f);
 hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const float *dout, float *dh, float *dW, float *dbias, int B, int M,
                           int T, float *scratch, bool frames = false, const float *y = nullptr, float post = 1.0f, float in_slope = 1.0f);
+// the weight / bias gradients of n <= 8 small convolutions of ONE shape (M <= 512) in two launches (the six pairs of the predictor's residual
+// stack, once its dx chain has run); y[i] != null: dout[i] is masked with that activated output; scratch: kconv_w_multi_scratch_floats()
+size_t kconv_w_multi_scratch_floats(int n, int B, int M);
+hipError_t kconv_backward_w_multi(const Launch &L, int n, const float *const *h, const float *const *dout, const float *const *y, float post, int B,
+                                  int M, int T, float *const *dW, float *const *dbias, float *scratch);
 // in_slope != 1 (a chain of such pairs): h is the activated output of the pair below and dh comes out multiplied by that activation's
 // mask (h > 0 ? 1 : in_slope), i.e. as the gradient in front of it
 // the predictor's input convolution with its activation: leaky_relu(Conv1d(80 -> 64, k5, pad 2), post) (modules.py:292-295), T <= 128;

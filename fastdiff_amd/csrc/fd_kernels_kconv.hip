@@ -235,10 +235,22 @@ __global__ void __launch_bounds__(256, 2) k_kc_dw(const float *__restrict__ h, c
     if (hi == 0) part[(int64_t)gridDim.y * M * KK + (int64_t)blockIdx.y * M + (FRAMES ? frame_row<fdk_order::ORDER_DK>(p0, l31) : p0 + l31)] = accb;
 }
 
+// pointer tables that travel as kernel arguments (up to KCS_MULTI convolutions of one shape per launch: blockIdx.z / blockIdx.y)
+constexpr int KCS_MULTI = 8;
+struct KcsItems {
+    const float *h[KCS_MULTI], *dout[KCS_MULTI], *y[KCS_MULTI];
+    float *part[KCS_MULTI];
+};
+struct KcsSums {
+    const float *part[KCS_MULTI];
+    float *dW[KCS_MULTI], *dbias[KCS_MULTI];
+};
+
 // the utterance ranges added up in a fixed order: dW [M][192] and dbias [M] (either may be null)
-__global__ void __launch_bounds__(256) k_kc_dw_sum(const float *__restrict__ part, float *__restrict__ dW, float *__restrict__ dbias, int M, int ny,
-                                                   int kk)      // kk: columns of dW (192; the input convolution: 400)
+__global__ void __launch_bounds__(256) k_kc_dw_sum(const KcsSums sums, int M, int ny, int kk)      // kk: columns of dW (192; the input convolution: 400)
 {
+    const float *__restrict__ part = sums.part[blockIdx.y];
+    float *__restrict__ dW = sums.dW[blockIdx.y], *__restrict__ dbias = sums.dbias[blockIdx.y];
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, nW = (int64_t)M * kk;
     if (idx < nW) {
         if (!dW) return;
@@ -298,11 +310,16 @@ __global__ void __launch_bounds__(256, 2) k_kcs_fwd(const float *__restrict__ h,
 
 // dW / dbias partial of ONE utterance: part [B][M][192] and, behind it, [B][M]; k_kc_dw_sum adds the utterances in order.
 // wave = (32-row tile, three of the six column tiles (c, k))
+// Up to KCS_MULTI convolutions of the same shape in one launch (blockIdx.z; the pointers travel as kernel arguments): the six pairs of
+// the predictor's residual stack have their weight gradients computed together once the dx chain has run -- one launch of 120
+// workgroups instead of six latency-bound launches of 20.  y[z] = null: dout[z] is already the gradient in front of the activation.
+
 template <bool ALIGNED, bool ACT>
-__global__ void __launch_bounds__(256, 2) k_kcs_dw(const float *__restrict__ h, const float *__restrict__ dout, float *__restrict__ part,
-                                                   int B, int M, int T, const float *__restrict__ y, float post)
+__global__ void __launch_bounds__(256, 2) k_kcs_dw(const KcsItems items, int B, int M, int T, float post)
 {
     __shared__ float hs[CI * LD];
+    const float *__restrict__ h = items.h[blockIdx.z], *__restrict__ dout = items.dout[blockIdx.z], *__restrict__ y = items.y[blockIdx.z];
+    float *__restrict__ part = items.part[blockIdx.z];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int b = blockIdx.x, p0 = (blockIdx.y * 2 + (wave & 1)) * 32, ch = wave >> 1;      // ch: column tiles 3 ch .. 3 ch + 2
     const bool live = p0 < M;
@@ -314,12 +331,12 @@ __global__ void __launch_bounds__(256, 2) k_kcs_dw(const float *__restrict__ h, 
         return make_float4(t0 < T ? r[t0] : 0.0f, t0 + 1 < T ? r[t0 + 1] : 0.0f, t0 + 2 < T ? r[t0 + 2] : 0.0f, t0 + 3 < T ? r[t0 + 3] : 0.0f);
     };
     float4 yv[ACT ? 16 : 1];      // ACT: the activated output, requested together with dout (one round trip for both)
-    const float *yr = ACT ? y + ((int64_t)b * M + (live ? p0 + l31 : 0)) * T : nullptr;
+    const float *yr = (ACT && y) ? y + ((int64_t)b * M + (live ? p0 + l31 : 0)) * T : nullptr;
 #pragma unroll
     for (int q = 0; q < 16; ++q)
         if (q < nq) {
             dv[q] = row4(dr, 8 * q + 4 * hi);
-            if constexpr (ACT) yv[q] = row4(yr, 8 * q + 4 * hi);
+            if constexpr (ACT) yv[q] = yr ? row4(yr, 8 * q + 4 * hi) : make_float4(1.f, 1.f, 1.f, 1.f);      // (no y: mask = 1)
         }
     zero_h(hs, tid);
     __syncthreads();
@@ -661,15 +678,45 @@ hipError_t input_conv_forward(const Launch &L, const float *x, const float *w, c
     return hipSuccess;
 }
 
+static KcsSums one_sum(const float *part, float *dW, float *dbias)
+{
+    KcsSums s = {};
+    s.part[0] = part; s.dW[0] = dW; s.dbias[0] = dbias;
+    return s;
+}
+
 hipError_t input_conv_backward(const Launch &L, const float *x, const float *w, const float *y, const float *dy, float *dx, float *dw, float *db, int B,
                                int T, float post, float *scratch)
 {
     if (dx) FD_LAUNCH(L, "input_conv_backward_x", k_ic_bwd_x, dim3(B, IC_CI / 16), dim3(256), 0, w, dy, y, dx, T, post);
     if (dw || db) {
         FD_LAUNCH(L, "input_conv_backward_w", k_ic_bwd_w, dim3(B, IC_CO / 16), dim3(256), 0, x, dy, y, scratch, B, T, post);
-        FD_LAUNCH(L, "kconv_backward_w_sum", k_kc_dw_sum, dim3((unsigned)(((int64_t)IC_CO * (IC_KK + 1) + 255) / 256)), dim3(256), 0, (const float *)scratch, dw,
-                  db, IC_CO, B, IC_KK);
+        FD_LAUNCH(L, "kconv_backward_w_sum", k_kc_dw_sum, dim3((unsigned)(((int64_t)IC_CO * (IC_KK + 1) + 255) / 256)), dim3(256), 0, one_sum(scratch, dw, db),
+                  IC_CO, B, IC_KK);
     }
+    return hipSuccess;
+}
+
+// the weight / bias gradients of n <= KCS_MULTI small convolutions of one shape (M <= 512) in two launches; scratch as kconv_backward's
+size_t kconv_w_multi_scratch_floats(int n, int B, int M) { return (size_t)n * B * M * (KK + 1); }
+hipError_t kconv_backward_w_multi(const Launch &L, int n, const float *const *h, const float *const *dout, const float *const *y, float post, int B,
+                                  int M, int T, float *const *dW, float *const *dbias, float *scratch)
+{
+    if (n < 1 || n > KCS_MULTI || !kconv_act_supported(M, T)) return hipErrorInvalidValue;
+    KcsItems it = {};
+    KcsSums su = {};
+    bool any_y = false;
+    for (int i = 0; i < n; ++i) {
+        it.h[i] = h[i]; it.dout[i] = dout[i]; it.y[i] = y ? y[i] : nullptr;
+        it.part[i] = scratch + (size_t)i * B * M * (KK + 1);
+        su.part[i] = it.part[i]; su.dW[i] = dW ? dW[i] : nullptr; su.dbias[i] = dbias ? dbias[i] : nullptr;
+        any_y = any_y || it.y[i];
+    }
+#define FD_KCS_DW(AL_, ACT_) FD_LAUNCH(L, "kconv_backward_w_small", (k_kcs_dw<AL_, ACT_>), dim3(B, (M + 63) / 64, n), dim3(256), 0, it, B, M, T, post)
+    if (T % 4 == 0) { if (any_y) FD_KCS_DW(true, true); else FD_KCS_DW(true, false); }
+    else { if (any_y) FD_KCS_DW(false, true); else FD_KCS_DW(false, false); }
+#undef FD_KCS_DW
+    FD_LAUNCH(L, "kconv_backward_w_sum", k_kc_dw_sum, dim3((unsigned)(((int64_t)M * (KK + 1) + 255) / 256), n), dim3(256), 0, su, M, B, KK);
     return hipSuccess;
 }
 
@@ -680,20 +727,22 @@ hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const
     if (y && !kconv_act_supported(M, T)) return hipErrorInvalidValue;
     float *part_h = scratch, *part_w = scratch + (size_t)KC_DH_SLICES * B * KK * T;
     if ((dW || dbias) && M <= KC_SMALL_M) {
-#define FD_KCS_DW(AL_, ACT_) FD_LAUNCH(L, "kconv_backward_w_small", (k_kcs_dw<AL_, ACT_>), dim3(B, (M + 63) / 64), dim3(256), 0, h, dout, part_w, B, M, T, y, post)
+        KcsItems it = {};
+        it.h[0] = h; it.dout[0] = dout; it.y[0] = y; it.part[0] = part_w;
+#define FD_KCS_DW(AL_, ACT_) FD_LAUNCH(L, "kconv_backward_w_small", (k_kcs_dw<AL_, ACT_>), dim3(B, (M + 63) / 64), dim3(256), 0, it, B, M, T, post)
         if (T % 4 == 0) { if (y) FD_KCS_DW(true, true); else FD_KCS_DW(true, false); }
         else { if (y) FD_KCS_DW(false, true); else FD_KCS_DW(false, false); }
 #undef FD_KCS_DW
-        FD_LAUNCH(L, "kconv_backward_w_sum", k_kc_dw_sum, dim3((unsigned)(((int64_t)M * (KK + 1) + 255) / 256)), dim3(256), 0, (const float *)part_w, dW,
-                  dbias, M, B, KK);
+        FD_LAUNCH(L, "kconv_backward_w_sum", k_kc_dw_sum, dim3((unsigned)(((int64_t)M * (KK + 1) + 255) / 256)), dim3(256), 0, one_sum(part_w, dW, dbias),
+                  M, B, KK);
     } else if (dW || dbias) {
         const int gx = (M + 127) / 128;
         const int ny0 = pick_ranges(gx, B, KC_DW_RANGES, L.ctx->num_cus), bchunk = (B + ny0 - 1) / ny0, ny = (B + bchunk - 1) / bchunk;
         if (frames) FD_LAUNCH(L, "kconv_backward_w", (k_kc_dw<false, true>), dim3(gx, ny), dim3(256), 0, h, dout, part_w, B, M, T, bchunk);
         else if (T % 4 == 0) FD_LAUNCH(L, "kconv_backward_w", (k_kc_dw<true, false>), dim3(gx, ny), dim3(256), 0, h, dout, part_w, B, M, T, bchunk);
         else FD_LAUNCH(L, "kconv_backward_w", (k_kc_dw<false, false>), dim3(gx, ny), dim3(256), 0, h, dout, part_w, B, M, T, bchunk);
-        FD_LAUNCH(L, "kconv_backward_w_sum", k_kc_dw_sum, dim3((unsigned)(((int64_t)M * (KK + 1) + 255) / 256)), dim3(256), 0, (const float *)part_w, dW,
-                  dbias, M, ny, KK);
+        FD_LAUNCH(L, "kconv_backward_w_sum", k_kc_dw_sum, dim3((unsigned)(((int64_t)M * (KK + 1) + 255) / 256)), dim3(256), 0, one_sum(part_w, dW, dbias),
+                  M, ny, KK);
     }
     if (dh) {
         const int chunks = M / 32;                                        // slices of whole 32-row chunks, a power of two of them

@@ -318,21 +318,35 @@ class _KConvStack(torch.autograd.Function):
         hs, ws = ctx.saved_tensors[:n + 1], ctx.saved_tensors[n + 1:]
         B, _, T = hs[0].shape
         g = dout.contiguous().float()
-        grads = [None] * (2 * n)
         lib, h = _handle(g.device)
+        st = _stream(g.device)
+        gs = [None] * n
+        # the dx chain first: pair j's gradient in front of its activation (the top pair masks dout with its own output, every other
+        # pair receives it masked from the pair above) ...
         for j in range(n - 1, -1, -1):
             top, bottom = j == n - 1, j == 0
-            need_x = (not bottom) or ctx.needs_input_grad[0]
-            dx = torch.empty_like(hs[j]) if need_x else None
-            dw = torch.empty_like(ws[j]) if ctx.needs_input_grad[2 + 2 * j] else None
-            db = torch.empty(64, device=g.device, dtype=torch.float32) if ctx.needs_input_grad[3 + 2 * j] else None
-            # the top pair masks dout with its own output; every pair hands down the gradient in front of the activation below it
+            gs[j] = g
+            if bottom and not ctx.needs_input_grad[0]:
+                g = None
+                break
+            dx = torch.empty_like(hs[j])
             _capi.check(lib, h, lib.fd_kconv_backward_act(h, hs[j].data_ptr(), ws[j].data_ptr(), hs[j + 1].data_ptr() if top else None, g.data_ptr(), B, 64, T,
-                                                          ctx.slope if top else 1.0, 1.0 if bottom else ctx.slope,
-                                                          None if dx is None else dx.data_ptr(), None if dw is None else dw.data_ptr(),
-                                                          None if db is None else db.data_ptr(), _stream(g.device)), "fd_kconv_backward")
-            grads[2 * j], grads[2 * j + 1] = dw, db
+                                                          ctx.slope if top else 1.0, 1.0 if bottom else ctx.slope, dx.data_ptr(), None, None, st),
+                        "fd_kconv_backward")
             g = dx
+        # ... then the weight and bias gradients of all pairs in two launches
+        want = [j for j in range(n) if ctx.needs_input_grad[2 + 2 * j] or ctx.needs_input_grad[3 + 2 * j]]
+        grads = [None] * (2 * n)
+        for c0 in range(0, len(want), 8):
+            js = want[c0:c0 + 8]
+            dws = [torch.empty_like(ws[j]) if ctx.needs_input_grad[2 + 2 * j] else None for j in js]
+            dbs = [torch.empty(64, device=gs[0].device, dtype=torch.float32) if ctx.needs_input_grad[3 + 2 * j] else None for j in js]
+            arr = lambda ts: (ct.c_void_p * len(js))(*[None if t is None else t.data_ptr() for t in ts])      # noqa: E731
+            _capi.check(lib, h, lib.fd_kconv_backward_w_multi(h, len(js), arr([hs[j] for j in js]), arr([gs[j] for j in js]),
+                                                              arr([hs[j + 1] if j == n - 1 else None for j in js]), B, 64, T, ctx.slope,
+                                                              arr(dws), arr(dbs), st), "fd_kconv_backward_w_multi")
+            for j, dw, db in zip(js, dws, dbs):
+                grads[2 * j], grads[2 * j + 1] = dw, db
         return (None if g is None else g.to(ctx.in_dtype), None) + tuple(grads)
 
 

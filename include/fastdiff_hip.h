@@ -200,6 +200,12 @@ FD_API int fd_kconv_forward_act(fd_handle h, const float *x, const float *weight
                                 float *out, void *stream);
 FD_API int fd_kconv_backward_act(fd_handle h, const float *x, const float *weight, const float *y, const float *dout, int B, int M, int T,
                                  float post_slope, float in_slope, float *dx, float *dweight, float *dbias, void *stream);
+/* The weight and bias gradients of n <= 8 such convolutions of ONE shape in two launches: x, dout, y, dweight, dbias are HOST arrays of n
+ * device pointers (y[i] = NULL: dout[i] is already the gradient in front of the activation; y = NULL: none is masked).  For the six pairs
+ * of the predictor's residual stack once its dx chain (fd_kconv_backward_act with dweight = dbias = NULL) has run: one launch of
+ * 6 x B workgroups instead of six latency-bound launches of B. */
+FD_API int fd_kconv_backward_w_multi(fd_handle h, int n, const float *const *x, const float *const *dout, const float *const *y, int B, int M,
+                                     int T, float post_slope, float *const *dweight, float *const *dbias, void *stream);
 
 /* A skip tensor's fan-out on the training path (FastDiff_model.py:91-98): x [rows = B*C, L] is read by the DiffusionDBlock below it, which
  * begins by picking every factor-th column (F.interpolate to L / factor, nearest: modules.py:128-131), and as `audio_down` by the four
