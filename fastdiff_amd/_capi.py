@@ -26,7 +26,7 @@ class FdKernelStat(ct.Structure):
 
 
 EXPORTS = ["fd_default_config", "fd_create", "fd_destroy", "fd_last_error", "fd_set_weight", "fd_commit_weights",
-           "fd_forward", "fd_sample", "fd_sample_check", "fd_sample_ticket", "fd_sample_settle", "fd_set_noise_streams", "fd_peak_normalize_int16", "fd_peak_normalize_int16_ragged", "fd_mel_spectrogram", "fd_lvc_forward", "fd_lvc_backward", "fd_lvc_forward_strided", "fd_lvc_backward_strided", "fd_gate_forward", "fd_gate_backward", "fd_kconv_forward", "fd_kconv_backward", "fd_weight_norm_multi_forward", "fd_weight_norm_multi_backward", "fd_fan_forward", "fd_fan_backward", "fd_input_conv_forward", "fd_input_conv_backward", "fd_kconv_backward_w_multi", "fd_kconv_forward_act", "fd_kconv_backward_act", "fd_kconv_forward_frames", "fd_kconv_backward_frames", "fd_lvc_forward_frames", "fd_lvc_backward_frames", "fd_conv32_forward", "fd_conv32_backward", "fd_weight_norm_forward", "fd_weight_norm_backward", "fd_conv7_forward", "fd_conv7_backward", "fd_upsample_forward", "fd_upsample_backward", "fd_set_option", "fd_read_tap", "fd_kernel_index", "fd_bias_index",
+           "fd_forward", "fd_sample", "fd_sample_check", "fd_sample_ticket", "fd_sample_settle", "fd_set_noise_streams", "fd_peak_normalize_int16", "fd_peak_normalize_int16_ragged", "fd_mel_spectrogram", "fd_lvc_forward", "fd_lvc_backward", "fd_lvc_forward_strided", "fd_lvc_backward_strided", "fd_gate_forward", "fd_gate_backward", "fd_kconv_forward", "fd_kconv_backward", "fd_weight_norm_multi_forward", "fd_weight_norm_multi_backward", "fd_fan_forward", "fd_fan_backward", "fd_input_conv_forward", "fd_input_conv_backward", "fd_kconv_backward_w_multi", "fd_kconv_forward_act_multi", "fd_kconv_backward_x_multi", "fd_input_conv_forward_multi", "fd_input_conv_backward_multi", "fd_kconv_forward_act", "fd_kconv_backward_act", "fd_kconv_forward_frames", "fd_kconv_backward_frames", "fd_lvc_forward_frames", "fd_lvc_backward_frames", "fd_conv32_forward", "fd_conv32_backward", "fd_weight_norm_forward", "fd_weight_norm_backward", "fd_conv7_forward", "fd_conv7_backward", "fd_upsample_forward", "fd_upsample_backward", "fd_set_option", "fd_read_tap", "fd_kernel_index", "fd_bias_index",
            "fd_get_profile", "fd_reset_profile", "fd_get_counter", "fd_version"]
 
 _lib = None
@@ -79,6 +79,10 @@ def load():
     lib.fd_input_conv_backward.argtypes = [vp, vp, vp, vp, vp, ci, ci, ct.c_float, vp, vp, vp, vp]
     lib.fd_kconv_forward_act.argtypes = [vp, vp, vp, vp, ci, ci, ci, ct.c_float, vp, vp]
     lib.fd_kconv_backward_act.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ct.c_float, ct.c_float, vp, vp, vp, vp]
+    lib.fd_kconv_forward_act_multi.argtypes = [vp, ci, vp, vp, vp, ci, ci, ci, ct.c_float, vp, vp]
+    lib.fd_kconv_backward_x_multi.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, ct.c_float, ct.c_float, vp, vp]
+    lib.fd_input_conv_forward_multi.argtypes = [vp, ci, vp, vp, vp, ci, ci, ct.c_float, vp, vp]
+    lib.fd_input_conv_backward_multi.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ct.c_float, vp, vp, vp, vp]
     lib.fd_kconv_backward_w_multi.argtypes = [vp, ci, vp, vp, vp, ci, ci, ci, ct.c_float, vp, vp, vp]
     lib.fd_kconv_forward_frames.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp]
     lib.fd_kconv_backward_frames.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp]

@@ -1632,6 +1632,104 @@ int fd_kconv_backward_w_multi(fd_handle h, int n, const float *const *x, const f
     return FD_OK;
 }
 
+static int check_input_conv(fd_handle h, int B, int T, float post, const char *who);
+
+static int kconv_scratch_floats_reserve(fd_handle h, size_t floats)
+{
+    const size_t bytes = sizeof(float) * floats;
+    if (h->kconv_scratch_bytes < bytes) {
+        if (h->kconv_scratch) FD_HIP(h, hipFree(h->kconv_scratch));
+        h->kconv_scratch = nullptr; h->kconv_scratch_bytes = 0;
+        FD_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->kconv_scratch), bytes));
+        h->kconv_scratch_bytes = bytes;
+    }
+    return FD_OK;
+}
+
+static int check_multi(fd_handle h, int n, int B, const void *const *lists, int nlists, const char *who)
+{
+    if (n < 1 || n > 8) FD_FAIL(h, FD_ERR_INVALID, "%s: n=%d outside 1..8", who, n);
+    if (B <= 0 || B > 65535) FD_FAIL(h, FD_ERR_INVALID, "%s: B=%d", who, B);
+    for (int k = 0; k < nlists; ++k) {
+        const void *const *l = reinterpret_cast<const void *const *>(lists[k]);
+        if (!l) FD_FAIL(h, FD_ERR_INVALID, "%s: null pointer list", who);
+        for (int i = 0; i < n; ++i)
+            if (!l[i]) FD_FAIL(h, FD_ERR_INVALID, "%s: null pointer in item %d", who, i);
+    }
+    return FD_OK;
+}
+
+int fd_kconv_forward_act_multi(fd_handle h, int n, const float *const *x, const float *const *weight, const float *const *bias, int B, int M, int T,
+                               float post_slope, float *const *out, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    const void *lists[4] = {x, weight, bias, out};
+    int rc = check_multi(h, n, B, lists, 4, "fd_kconv_forward_act_multi");
+    if (rc != FD_OK) return rc;
+    if (!fdk::kconv_act_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_forward_act_multi: M=%d (a multiple of 32, <= 512) and T=%d (1..128) only", M, T);
+    if ((rc = check_act(h, M, T, post_slope, "fd_kconv_forward_act_multi")) != FD_OK) return rc;
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::kconv_forward_multi(La, n, x, weight, bias, out, B, M, T, post_slope);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_kconv_forward_act_multi: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+int fd_kconv_backward_x_multi(fd_handle h, int n, const float *const *x, const float *const *weight, const float *const *y, const float *const *dout,
+                              int B, int M, int T, float post_slope, float in_slope, float *const *dx, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    const void *lists[3] = {weight, dout, dx};
+    int rc = check_multi(h, n, B, lists, 3, "fd_kconv_backward_x_multi");
+    if (rc != FD_OK) return rc;
+    if (!fdk::kconv_act_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_backward_x_multi: M=%d (a multiple of 32, <= 512) and T=%d (1..128) only", M, T);
+    if ((rc = check_act(h, M, T, post_slope, "fd_kconv_backward_x_multi")) != FD_OK) return rc;
+    if (!(in_slope > 0.0f && in_slope <= 1.0f)) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward_x_multi: in_slope must lie in (0, 1], got %g", in_slope);
+    if (in_slope != 1.0f) {
+        const void *lx[1] = {x};
+        if ((rc = check_multi(h, n, B, lx, 1, "fd_kconv_backward_x_multi")) != FD_OK) return rc;
+    }
+    if (post_slope != 1.0f && !y) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward_x_multi: a fused activation needs the forward's outputs y");
+    FD_HIP(h, hipSetDevice(h->device));
+    if ((rc = kconv_scratch_floats_reserve(h, fdk::kconv_x_multi_scratch_floats(n, B, M, T))) != FD_OK) return rc;
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::kconv_backward_x_multi(La, n, x, weight, post_slope != 1.0f ? y : nullptr, dout, dx, B, M, T, post_slope, in_slope, h->kconv_scratch);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_kconv_backward_x_multi: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+int fd_input_conv_forward_multi(fd_handle h, int n, const float *const *x, const float *const *weight, const float *const *bias, int B, int T,
+                                float post_slope, float *const *out, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    const void *lists[4] = {x, weight, bias, out};
+    int rc = check_multi(h, n, B, lists, 4, "fd_input_conv_forward_multi");
+    if (rc != FD_OK) return rc;
+    if ((rc = check_input_conv(h, B, T, post_slope, "fd_input_conv_forward_multi")) != FD_OK) return rc;
+    FD_HIP(h, hipSetDevice(h->device));
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::input_conv_forward_multi(La, n, x, weight, bias, out, B, T, post_slope);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_input_conv_forward_multi: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
+int fd_input_conv_backward_multi(fd_handle h, int n, const float *const *x, const float *const *weight, const float *const *y, const float *const *dout,
+                                 int B, int T, float post_slope, float *const *dx, float *const *dweight, float *const *dbias, void *stream)
+{
+    if (!h) return FD_ERR_INVALID;
+    const void *lists[4] = {x, weight, y, dout};
+    int rc = check_multi(h, n, B, lists, 4, "fd_input_conv_backward_multi");
+    if (rc != FD_OK) return rc;
+    if ((rc = check_input_conv(h, B, T, post_slope, "fd_input_conv_backward_multi")) != FD_OK) return rc;
+    if (dx) { const void *l[1] = {dx}; if ((rc = check_multi(h, n, B, l, 1, "fd_input_conv_backward_multi")) != FD_OK) return rc; }
+    FD_HIP(h, hipSetDevice(h->device));
+    if ((rc = kconv_scratch_floats_reserve(h, fdk::input_conv_multi_scratch_floats(n, B))) != FD_OK) return rc;
+    fdk::Launch La = {h, (hipStream_t)stream, false};
+    hipError_t e = fdk::input_conv_backward_multi(La, n, x, weight, y, dout, dx, dweight, dbias, B, T, post_slope, h->kconv_scratch);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_input_conv_backward_multi: %s", hipGetErrorString(e));
+    return FD_OK;
+}
+
 int fd_kconv_backward(fd_handle h, const float *x, const float *weight, const float *dout, int B, int M, int T, float *dx, float *dweight,
                       float *dbias, void *stream)
 {

@@ -60,6 +60,18 @@ hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const
 size_t kconv_w_multi_scratch_floats(int n, int B, int M);
 hipError_t kconv_backward_w_multi(const Launch &L, int n, const float *const *h, const float *const *dout, const float *const *y, float post, int B,
                                   int M, int T, float *const *dW, float *const *dbias, float *scratch);
+// n <= 8 independent convolutions of one shape side by side in one launch each (the three KernelPredictors' front ends): forward of small
+// convolutions, one step of their dx chains (kconv_backward's dh part), the input convolution both ways.  Host arrays of device pointers.
+hipError_t kconv_forward_multi(const Launch &L, int n, const float *const *h, const float *const *W, const float *const *bias, float *const *out, int B,
+                               int M, int T, float post);
+size_t kconv_x_multi_scratch_floats(int n, int B, int M, int T);
+hipError_t kconv_backward_x_multi(const Launch &L, int n, const float *const *h, const float *const *W, const float *const *y, const float *const *dout,
+                                  float *const *dh, int B, int M, int T, float post, float in_slope, float *scratch);
+hipError_t input_conv_forward_multi(const Launch &L, int n, const float *const *x, const float *const *w, const float *const *bias, float *const *out,
+                                    int B, int T, float post);
+size_t input_conv_multi_scratch_floats(int n, int B);
+hipError_t input_conv_backward_multi(const Launch &L, int n, const float *const *x, const float *const *w, const float *const *y, const float *const *dy,
+                                     float *const *dx, float *const *dw, float *const *db, int B, int T, float post, float *scratch);
 // in_slope != 1 (a chain of such pairs): h is the activated output of the pair below and dh comes out multiplied by that activation's
 // mask (h > 0 ? 1 : in_slope), i.e. as the gradient in front of it
 // the predictor's input convolution with its activation: leaky_relu(Conv1d(80 -> 64, k5, pad 2), post) (modules.py:292-295), T <= 128;

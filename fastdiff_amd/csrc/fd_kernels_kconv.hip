@@ -237,6 +237,15 @@ __global__ void __launch_bounds__(256, 2) k_kc_dw(const float *__restrict__ h, c
 
 // pointer tables that travel as kernel arguments (up to KCS_MULTI convolutions of one shape per launch: blockIdx.z / blockIdx.y)
 constexpr int KCS_MULTI = 8;
+// n > 0: the kernel takes its three input pointers and its output pointer from slot blockIdx.z (k_kc_dh_fold: blockIdx.y) instead of
+// its own arguments: the same launch then serves n independent convolutions of one shape -- the three KernelPredictors of the network
+// have identical front ends (input convolution + residual stack) on different weights, each a chain of latency-bound launches of B
+// workgroups; side by side they are the same chain with 3 B.
+struct KcMulti {
+    int n;
+    const float *a[KCS_MULTI], *b[KCS_MULTI], *c[KCS_MULTI];
+    float *o[KCS_MULTI];
+};
 struct KcsItems {
     const float *h[KCS_MULTI], *dout[KCS_MULTI], *y[KCS_MULTI];
     float *part[KCS_MULTI];
@@ -271,9 +280,10 @@ __global__ void __launch_bounds__(256) k_kc_dw_sum(const KcsSums sums, int M, in
 //      post: slope of a leaky-relu on the output (1 = none): the predictor follows each of these convolutions with LeakyReLU(0.1)
 //      (modules.py:296-314); the backward kernels then take the activated output y and scale dout by (y > 0 ? 1 : post) as they load it.
 __global__ void __launch_bounds__(256, 2) k_kcs_fwd(const float *__restrict__ h, const float *__restrict__ W, const float *__restrict__ bias,
-                                                    float *__restrict__ out, int B, int M, int T, float post)
+                                                    float *__restrict__ out, int B, int M, int T, float post, const KcMulti m)
 {
     __shared__ float hs[CI * LD];
+    if (m.n) { h = m.a[blockIdx.z]; W = m.b[blockIdx.z]; bias = m.c[blockIdx.z]; out = m.o[blockIdx.z]; }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int b = blockIdx.x, p0 = (blockIdx.y * 2 + (wave & 1)) * 32, ch = wave >> 1;      // ch: column tiles 2 ch, 2 ch + 1
     const bool live = p0 < M;
@@ -387,8 +397,9 @@ __global__ void __launch_bounds__(256, 2) k_kcs_dw(const KcsItems items, int B, 
 // consecutive floats of every frame of the utterance.
 template <bool FRAMES, bool ACT = false>
 __global__ void __launch_bounds__(256, 2) k_kc_dh(const float *__restrict__ W, const float *__restrict__ dout, float *__restrict__ part,
-                                                  int B, int M, int T, int prows, const float *__restrict__ y, float post)
+                                                  int B, int M, int T, int prows, const float *__restrict__ y, float post, const KcMulti m)
 {
+    if (m.n) { W = m.a[blockIdx.z]; dout = m.b[blockIdx.z]; y = m.c[blockIdx.z]; part = m.o[blockIdx.z]; }
     __shared__ __attribute__((aligned(16))) float ws[32 * KK];
     __shared__ float dsm[32 * LDD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -430,7 +441,7 @@ __global__ void __launch_bounds__(256, 2) k_kc_dh(const float *__restrict__ W, c
                 if (k < nd) {
                     const int64_t at = ((int64_t)b * M + pc + idx / T) * T + idx % T;
                     dvv[k] = idx < 32 * T ? dout[at] : 0.0f;
-                    if constexpr (ACT) yvv[k] = idx < 32 * T ? y[at] : 1.0f;
+                    if constexpr (ACT) yvv[k] = (y && idx < 32 * T) ? y[at] : 1.0f;      // (no y for this item: mask = 1)
                 }
             }
         }
@@ -474,8 +485,9 @@ __global__ void __launch_bounds__(256, 2) k_kc_dh(const float *__restrict__ W, c
 //      pair below, and dh is wanted in front of THAT activation: dh *= (h > 0 ? 1 : in_slope) on the way out, so the pair below runs
 //      its backward on plain kernels (no mask loads in its two latency-bound launches).  hin = null: dh as it is.
 __global__ void __launch_bounds__(256) k_kc_dh_fold(const float *__restrict__ part, float *__restrict__ dh, int B, int T, int nks,
-                                                    const float *__restrict__ hin, float in_slope)
+                                                    const float *__restrict__ hin, float in_slope, const KcMulti m)
 {
+    if (m.n) { part = m.a[blockIdx.y]; hin = m.b[blockIdx.y]; dh = m.o[blockIdx.y]; }
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= B * CI * T) return;
     const int t = idx % T, c = (idx / T) % CI, b = idx / (T * CI);
@@ -519,9 +531,10 @@ __device__ __forceinline__ void ic_stage_g(float *__restrict__ gs, const float *
 }
 
 __global__ void __launch_bounds__(256) k_ic_fwd(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-                                                float *__restrict__ out, int T, float post)
+                                                float *__restrict__ out, int T, float post, const KcMulti m)
 {
     __shared__ __attribute__((aligned(16))) float xs[IC_CI * IC_LD];
+    if (m.n) { x = m.a[blockIdx.z]; w = m.b[blockIdx.z]; bias = m.c[blockIdx.z]; out = m.o[blockIdx.z]; }
     const int b = blockIdx.x, tid = threadIdx.x, o = blockIdx.y * 16 + (tid >> 4), t0 = (tid & 15) * 8;
     ic_stage_x(xs, x, b, T, tid);
     __syncthreads();
@@ -553,9 +566,10 @@ __global__ void __launch_bounds__(256) k_ic_fwd(const float *__restrict__ x, con
 
 // dx[b, c, t] = sum_{o, k} w[o, c, k] g[b, o, t + 2 - k]: workgroup = (utterance, 16 input channels)
 __global__ void __launch_bounds__(256) k_ic_bwd_x(const float *__restrict__ w, const float *__restrict__ dy, const float *__restrict__ y,
-                                                  float *__restrict__ dx, int T, float post)
+                                                  float *__restrict__ dx, int T, float post, const KcMulti m)
 {
     __shared__ __attribute__((aligned(16))) float gs[IC_CO * IC_LD];
+    if (m.n) { w = m.a[blockIdx.z]; dy = m.b[blockIdx.z]; y = m.c[blockIdx.z]; dx = m.o[blockIdx.z]; }
     const int b = blockIdx.x, tid = threadIdx.x, c = blockIdx.y * 16 + (tid >> 4), t0 = (tid & 15) * 8;
     ic_stage_g(gs, dy, y, b, 0, IC_CO, T, post, tid);
     __syncthreads();
@@ -587,9 +601,10 @@ __global__ void __launch_bounds__(256) k_ic_bwd_x(const float *__restrict__ w, c
 // this utterance's share of dW[o, c, k] = sum_t g[o, t] x[c, t + k - 2] and of db[o] = sum_t g[o, t]: part [B][64][400], then [B][64]
 // (k_kc_dw_sum adds the utterances in order).  workgroup = (utterance, 16 output channels), thread = (channel o, 5 input channels)
 __global__ void __launch_bounds__(256) k_ic_bwd_w(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ y,
-                                                  float *__restrict__ part, int B, int T, float post)
+                                                  float *__restrict__ part, int B, int T, float post, const KcMulti m)
 {
     __shared__ __attribute__((aligned(16))) float xs[IC_CI * IC_LD];
+    if (m.n) { x = m.a[blockIdx.z]; dy = m.b[blockIdx.z]; y = m.c[blockIdx.z]; part = m.o[blockIdx.z]; }
     __shared__ __attribute__((aligned(16))) float gs[16 * IC_LD];
     const int b = blockIdx.x, tid = threadIdx.x, ol = tid >> 4, o = blockIdx.y * 16 + ol, c0 = (tid & 15) * 5;
     ic_stage_x(xs, x, b, T, tid);
@@ -660,7 +675,7 @@ hipError_t kconv_forward(const Launch &L, const float *h, const float *W, const 
     if (frames && !kconv_frames_supported(M, T)) return hipErrorInvalidValue;
     if (post != 1.0f && !kconv_act_supported(M, T)) return hipErrorInvalidValue;
     if (M <= KC_SMALL_M) {
-        FD_LAUNCH(L, "kconv_forward_small", k_kcs_fwd, dim3(B, (M + 63) / 64), dim3(256), 0, h, W, bias, out, B, M, T, post);
+        FD_LAUNCH(L, "kconv_forward_small", k_kcs_fwd, dim3(B, (M + 63) / 64), dim3(256), 0, h, W, bias, out, B, M, T, post, KcMulti{});
         return hipSuccess;
     }
     const int gx = (M + 127) / 128;
@@ -674,7 +689,7 @@ size_t input_conv_scratch_floats(int B) { return (size_t)B * IC_CO * (IC_KK + 1)
 
 hipError_t input_conv_forward(const Launch &L, const float *x, const float *w, const float *bias, float *out, int B, int T, float post)
 {
-    FD_LAUNCH(L, "input_conv_forward", k_ic_fwd, dim3(B, IC_CO / 16), dim3(256), 0, x, w, bias, out, T, post);
+    FD_LAUNCH(L, "input_conv_forward", k_ic_fwd, dim3(B, IC_CO / 16), dim3(256), 0, x, w, bias, out, T, post, KcMulti{});
     return hipSuccess;
 }
 
@@ -688,11 +703,94 @@ static KcsSums one_sum(const float *part, float *dW, float *dbias)
 hipError_t input_conv_backward(const Launch &L, const float *x, const float *w, const float *y, const float *dy, float *dx, float *dw, float *db, int B,
                                int T, float post, float *scratch)
 {
-    if (dx) FD_LAUNCH(L, "input_conv_backward_x", k_ic_bwd_x, dim3(B, IC_CI / 16), dim3(256), 0, w, dy, y, dx, T, post);
+    if (dx) FD_LAUNCH(L, "input_conv_backward_x", k_ic_bwd_x, dim3(B, IC_CI / 16), dim3(256), 0, w, dy, y, dx, T, post, KcMulti{});
     if (dw || db) {
-        FD_LAUNCH(L, "input_conv_backward_w", k_ic_bwd_w, dim3(B, IC_CO / 16), dim3(256), 0, x, dy, y, scratch, B, T, post);
+        FD_LAUNCH(L, "input_conv_backward_w", k_ic_bwd_w, dim3(B, IC_CO / 16), dim3(256), 0, x, dy, y, scratch, B, T, post, KcMulti{});
         FD_LAUNCH(L, "kconv_backward_w_sum", k_kc_dw_sum, dim3((unsigned)(((int64_t)IC_CO * (IC_KK + 1) + 255) / 256)), dim3(256), 0, one_sum(scratch, dw, db),
                   IC_CO, B, IC_KK);
+    }
+    return hipSuccess;
+}
+
+// ---- n <= KCS_MULTI independent convolutions of one shape side by side (KcMulti) -------------------------------------------------
+static int dh_slices(int M, int B, int n, int num_cus)
+{
+    const int chunks = M / 32;
+    int nks = 1;
+    int64_t best = INT64_MAX;
+    for (int k = 1; k <= KC_DH_SLICES && chunks % k == 0; k *= 2) {
+        const int64_t cost = (int64_t)(((int64_t)k * B * n + num_cus - 1) / num_cus) * (chunks / k);
+        if (cost < best) { best = cost; nks = k; }
+    }
+    return nks;
+}
+
+hipError_t kconv_forward_multi(const Launch &L, int n, const float *const *h, const float *const *W, const float *const *bias, float *const *out, int B,
+                               int M, int T, float post)
+{
+    if (n < 1 || n > KCS_MULTI || !kconv_act_supported(M, T)) return hipErrorInvalidValue;
+    KcMulti m = {};
+    m.n = n;
+    for (int i = 0; i < n; ++i) { m.a[i] = h[i]; m.b[i] = W[i]; m.c[i] = bias[i]; m.o[i] = out[i]; }
+    FD_LAUNCH(L, "kconv_forward_small", k_kcs_fwd, dim3(B, (M + 63) / 64, n), dim3(256), 0, h[0], W[0], bias[0], out[0], B, M, T, post, m);
+    return hipSuccess;
+}
+
+size_t kconv_x_multi_scratch_floats(int n, int B, int M, int T) { return (size_t)n * KC_DH_SLICES * B * KK * T; }
+// dh[i] = conv_transpose(dout[i] masked with y[i] if given) (* mask of h[i] when in_slope != 1): one step of n dx chains
+hipError_t kconv_backward_x_multi(const Launch &L, int n, const float *const *h, const float *const *W, const float *const *y, const float *const *dout,
+                                  float *const *dh, int B, int M, int T, float post, float in_slope, float *scratch)
+{
+    if (n < 1 || n > KCS_MULTI || !kconv_act_supported(M, T)) return hipErrorInvalidValue;
+    const int nks = dh_slices(M, B, n, L.ctx->num_cus);
+    KcMulti m = {}, f = {};
+    m.n = f.n = n;
+    bool any_y = false;
+    for (int i = 0; i < n; ++i) {
+        float *part = scratch + (size_t)i * nks * B * KK * T;
+        m.a[i] = W[i]; m.b[i] = dout[i]; m.c[i] = y ? y[i] : nullptr; m.o[i] = part;
+        f.a[i] = part; f.b[i] = in_slope != 1.0f ? h[i] : nullptr; f.o[i] = dh[i];
+        any_y = any_y || m.c[i];
+    }
+    if (any_y) FD_LAUNCH(L, "kconv_backward_h", (k_kc_dh<false, true>), dim3(nks, B, n), dim3(256), 0, W[0], dout[0], m.o[0], B, M, T, M / nks, m.c[0], post, m);
+    else FD_LAUNCH(L, "kconv_backward_h", (k_kc_dh<false, false>), dim3(nks, B, n), dim3(256), 0, W[0], dout[0], m.o[0], B, M, T, M / nks, m.c[0], post, m);
+    FD_LAUNCH(L, "kconv_backward_h_fold", k_kc_dh_fold, dim3((B * CI * T + 255) / 256, n), dim3(256), 0, f.a[0], dh[0], B, T, nks, f.b[0], in_slope, f);
+    return hipSuccess;
+}
+
+hipError_t input_conv_forward_multi(const Launch &L, int n, const float *const *x, const float *const *w, const float *const *bias, float *const *out,
+                                    int B, int T, float post)
+{
+    if (n < 1 || n > KCS_MULTI) return hipErrorInvalidValue;
+    KcMulti m = {};
+    m.n = n;
+    for (int i = 0; i < n; ++i) { m.a[i] = x[i]; m.b[i] = w[i]; m.c[i] = bias[i]; m.o[i] = out[i]; }
+    FD_LAUNCH(L, "input_conv_forward", k_ic_fwd, dim3(B, IC_CO / 16, n), dim3(256), 0, x[0], w[0], bias[0], out[0], T, post, m);
+    return hipSuccess;
+}
+
+size_t input_conv_multi_scratch_floats(int n, int B) { return (size_t)n * input_conv_scratch_floats(B); }
+hipError_t input_conv_backward_multi(const Launch &L, int n, const float *const *x, const float *const *w, const float *const *y, const float *const *dy,
+                                     float *const *dx, float *const *dw, float *const *db, int B, int T, float post, float *scratch)
+{
+    if (n < 1 || n > KCS_MULTI) return hipErrorInvalidValue;
+    if (dx) {
+        KcMulti m = {};
+        m.n = n;
+        for (int i = 0; i < n; ++i) { m.a[i] = w[i]; m.b[i] = dy[i]; m.c[i] = y[i]; m.o[i] = dx[i]; }
+        FD_LAUNCH(L, "input_conv_backward_x", k_ic_bwd_x, dim3(B, IC_CI / 16, n), dim3(256), 0, w[0], dy[0], y[0], dx[0], T, post, m);
+    }
+    if (dw || db) {
+        KcMulti m = {};
+        KcsSums su = {};
+        m.n = n;
+        for (int i = 0; i < n; ++i) {
+            float *part = scratch + (size_t)i * input_conv_scratch_floats(B);
+            m.a[i] = x[i]; m.b[i] = dy[i]; m.c[i] = y[i]; m.o[i] = part;
+            su.part[i] = part; su.dW[i] = dw ? dw[i] : nullptr; su.dbias[i] = db ? db[i] : nullptr;
+        }
+        FD_LAUNCH(L, "input_conv_backward_w", k_ic_bwd_w, dim3(B, IC_CO / 16, n), dim3(256), 0, x[0], dy[0], y[0], m.o[0], B, T, post, m);
+        FD_LAUNCH(L, "kconv_backward_w_sum", k_kc_dw_sum, dim3((unsigned)(((int64_t)IC_CO * (IC_KK + 1) + 255) / 256), n), dim3(256), 0, su, IC_CO, B, IC_KK);
     }
     return hipSuccess;
 }
@@ -752,11 +850,11 @@ hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const
             const int64_t cost = (int64_t)(((int64_t)n * B + L.ctx->num_cus - 1) / L.ctx->num_cus) * (chunks / n);
             if (cost < best) { best = cost; nks = n; }
         }
-        if (frames) FD_LAUNCH(L, "kconv_backward_h", (k_kc_dh<true, false>), dim3(nks, B), dim3(256), 0, W, dout, part_h, B, M, T, M / nks, (const float *)nullptr, 1.0f);
-        else if (y) FD_LAUNCH(L, "kconv_backward_h", (k_kc_dh<false, true>), dim3(nks, B), dim3(256), 0, W, dout, part_h, B, M, T, M / nks, y, post);
-        else FD_LAUNCH(L, "kconv_backward_h", (k_kc_dh<false, false>), dim3(nks, B), dim3(256), 0, W, dout, part_h, B, M, T, M / nks, y, post);
+        if (frames) FD_LAUNCH(L, "kconv_backward_h", (k_kc_dh<true, false>), dim3(nks, B), dim3(256), 0, W, dout, part_h, B, M, T, M / nks, (const float *)nullptr, 1.0f, KcMulti{});
+        else if (y) FD_LAUNCH(L, "kconv_backward_h", (k_kc_dh<false, true>), dim3(nks, B), dim3(256), 0, W, dout, part_h, B, M, T, M / nks, y, post, KcMulti{});
+        else FD_LAUNCH(L, "kconv_backward_h", (k_kc_dh<false, false>), dim3(nks, B), dim3(256), 0, W, dout, part_h, B, M, T, M / nks, y, post, KcMulti{});
         FD_LAUNCH(L, "kconv_backward_h_fold", k_kc_dh_fold, dim3((B * CI * T + 255) / 256), dim3(256), 0, (const float *)part_h, dh, B, T, nks,
-                  in_slope != 1.0f ? h : (const float *)nullptr, in_slope);
+                  in_slope != 1.0f ? h : (const float *)nullptr, in_slope, KcMulti{});
     }
     return hipSuccess;
 }

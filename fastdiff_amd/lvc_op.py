@@ -350,6 +350,109 @@ class _KConvStack(torch.autograd.Function):
         return (None if g is None else g.to(ctx.in_dtype), None) + tuple(grads)
 
 
+def _ptrs(ts):
+    """A ctypes array of the tensors' device pointers (None -> NULL): the host-side pointer lists of the *_multi entry points."""
+    return (ct.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+
+class _PredictorFronts(torch.autograd.Function):
+    """The front ends of P KernelPredictors side by side (modules.py:292-314,328-329): for each, c = leaky_relu(input_conv(x)),
+    r = residual stack(c) (n pairs of Conv1d(64, 64, 3) + LeakyReLU), output c + r.  The P chains are independent and each launch of one
+    is latency-bound (B workgroups); here every step of the chain is ONE launch for all P (fd_*_multi: the pointers of the P
+    convolutions as kernel arguments), forward and backward.  Inputs: slope, n, x_1 .. x_P, then per predictor w_in, b_in, w_1, b_1,
+    ..., w_n, b_n.  Same kernels as input_conv / kernel_conv_stack: same bits."""
+
+    @staticmethod
+    def forward(ctx, slope, n, *args):
+        P = len(args) // (2 * n + 3)
+        xs = [t.contiguous().float() for t in args[:P]]
+        par = [t.contiguous().float() for t in args[P:]]
+        per = 2 * n + 2
+        win, bin_ = [par[p * per] for p in range(P)], [par[p * per + 1] for p in range(P)]
+        ws = [[par[p * per + 2 + 2 * j] for p in range(P)] for j in range(n)]
+        bs = [[par[p * per + 3 + 2 * j] for p in range(P)] for j in range(n)]
+        B, _, T = xs[0].shape
+        dev = xs[0].device
+        lib, h = _handle(dev)
+        st = _stream(dev)
+        H = [torch.empty((P, B, 64, T), device=dev, dtype=torch.float32) for _ in range(n + 1)]      # H[0] = c, H[j] = output of pair j
+        _capi.check(lib, h, lib.fd_input_conv_forward_multi(h, P, _ptrs(xs), _ptrs(win), _ptrs(bin_), B, T, float(slope), _ptrs(list(H[0].unbind(0))), st),
+                    "fd_input_conv_forward_multi")
+        for j in range(n):
+            _capi.check(lib, h, lib.fd_kconv_forward_act_multi(h, P, _ptrs(list(H[j].unbind(0))), _ptrs(ws[j]), _ptrs(bs[j]), B, 64, T, float(slope),
+                                                               _ptrs(list(H[j + 1].unbind(0))), st), "fd_kconv_forward_act_multi")
+        out = H[0] + H[n]
+        ctx.save_for_backward(*xs, *win, *[w for wj in ws for w in wj], *H)
+        ctx.slope, ctx.n, ctx.P = float(slope), n, P
+        return tuple(out.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *gout):
+        n, P, slope = ctx.n, ctx.P, ctx.slope
+        sv = ctx.saved_tensors
+        xs, win = sv[:P], sv[P:2 * P]
+        ws = [sv[2 * P + j * P:2 * P + (j + 1) * P] for j in range(n)]
+        H = sv[2 * P + n * P:]
+        B, _, T = xs[0].shape
+        dev = xs[0].device
+        lib, h = _handle(dev)
+        st = _stream(dev)
+        zero = None
+        g = []
+        for t in gout:      # a predictor whose output took no part in the loss: zeros
+            if t is None:
+                zero = torch.zeros((B, 64, T), device=dev, dtype=torch.float32) if zero is None else zero
+                t = zero
+            g.append(t.contiguous().float())
+        gtop = g
+        gs = [None] * n            # gs[j]: the gradients in front of pair j's activation (P tensors); the top pair's is masked in the kernels
+        cur = g
+        for j in range(n - 1, -1, -1):
+            top, bottom = j == n - 1, j == 0
+            gs[j] = cur
+            DX = torch.empty((P, B, 64, T), device=dev, dtype=torch.float32)
+            _capi.check(lib, h, lib.fd_kconv_backward_x_multi(h, P, _ptrs(list(H[j].unbind(0))), _ptrs(ws[j]), _ptrs(list(H[n].unbind(0))) if top else None,
+                                                              _ptrs(cur), B, 64, T, slope if top else 1.0, 1.0 if bottom else slope,
+                                                              _ptrs(list(DX.unbind(0))), st), "fd_kconv_backward_x_multi")
+            cur = list(DX.unbind(0))
+        # weight and bias gradients of all P * n pairs, eight per call
+        flat = [(p, j) for p in range(P) for j in range(n)]
+        dW = {k: torch.empty_like(ws[k[1]][k[0]]) for k in flat}
+        dB = {k: torch.empty(64, device=dev, dtype=torch.float32) for k in flat}
+        for c0 in range(0, len(flat), 8):
+            ks = flat[c0:c0 + 8]
+            _capi.check(lib, h, lib.fd_kconv_backward_w_multi(h, len(ks), _ptrs([H[j][p] for p, j in ks]), _ptrs([gs[j][p] for p, j in ks]),
+                                                              _ptrs([H[n][p] if j == n - 1 else None for p, j in ks]), B, 64, T, slope,
+                                                              _ptrs([dW[k] for k in ks]), _ptrs([dB[k] for k in ks]), st), "fd_kconv_backward_w_multi")
+        # c has two readers, the stack and the sum: dc = dx of the bottom pair + the output's gradient
+        torch._foreach_add_(cur, gtop)
+        need_x = any(ctx.needs_input_grad[2:2 + P])
+        DXin = torch.empty((P, B, 80, T), device=dev, dtype=torch.float32) if need_x else None
+        dwin = [torch.empty_like(w) for w in win]
+        dbin = [torch.empty(64, device=dev, dtype=torch.float32) for _ in range(P)]
+        _capi.check(lib, h, lib.fd_input_conv_backward_multi(h, P, _ptrs(xs), _ptrs(win), _ptrs(list(H[0].unbind(0))), _ptrs(cur), B, T, slope,
+                                                             None if DXin is None else _ptrs(list(DXin.unbind(0))), _ptrs(dwin), _ptrs(dbin), st),
+                    "fd_input_conv_backward_multi")
+        grads = [None, None] + ([None] * P if DXin is None else list(DXin.unbind(0)))
+        for p in range(P):
+            grads += [dwin[p], dbin[p]]
+            for j in range(n):
+                grads += [dW[(p, j)], dB[(p, j)]]
+        return tuple(grads)
+
+
+def predictor_fronts(xs, input_convs, stacks, slope):
+    """[leaky_relu(input_conv_p(x_p)) + stack_p(.) for p] for P predictors at once: xs = P tensors [B, 80, T]; input_convs = P pairs
+    (weight [64, 80, 5], bias); stacks = P lists of n pairs (weight [64, 64, 3], bias); one launch per chain step for all P."""
+    n = len(stacks[0])
+    flat = []
+    for (w, b), st in zip(input_convs, stacks):
+        flat += [w, b]
+        for wj, bj in st:
+            flat += [wj, bj]
+    return list(_PredictorFronts.apply(slope, n, *xs, *flat))
+
+
 def kernel_conv_stack(x, weights, biases, slope):
     """leaky_relu(conv1d(., w_j, b_j, padding=1), slope) applied n times in a row to x [B, 64, T] (every w_j [64, 64, 3]) as one
     differentiable HIP operator: the predictor's residual stack without its Dropout(p = 0) modules."""

@@ -84,7 +84,22 @@ def _dblock(p, x, cconv=None, picked=False):
     return x + residual
 
 
-def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None, split=None, frames=None, fuse_act=True):
+def _front_spec(p):
+    """(input conv, [stack convs], slope) if the predictor's front end is the model's: Sequential(Conv1d(80, 64, 5, padding 2), LeakyReLU)
+    and a residual Sequential of Conv1d(64, 64, 3, padding 1) + LeakyReLU pairs between Dropout(p = 0) modules, one slope throughout."""
+    ic = list(p.input_conv)
+    mods = [m for m in p.residual_conv if not (isinstance(m, torch.nn.Dropout) and (m.p == 0 or not m.training))]
+    convs, acts = mods[0::2], mods[1::2]
+    if not (len(ic) == 2 and isinstance(ic[0], torch.nn.Conv1d) and isinstance(ic[1], torch.nn.LeakyReLU) and ic[0].kernel_size == (5,) and
+            ic[0].padding == (2,) and ic[0].in_channels == 80 and ic[0].out_channels == 64 and len(convs) == len(acts) >= 1 and
+            all(isinstance(a, torch.nn.LeakyReLU) and a.negative_slope == ic[1].negative_slope for a in acts) and
+            all(isinstance(m, torch.nn.Conv1d) and m.kernel_size == (3,) and m.padding == (1,) and m.dilation == (1,) and
+                m.in_channels == 64 and m.out_channels == 64 for m in convs)):
+        return None
+    return ic[0], convs, ic[1].negative_slope
+
+
+def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None, split=None, frames=None, fuse_act=True, front=None):
     """KernelPredictor.forward (modules.py:320-343).  kconv: the HIP operator for kernel_conv (64 -> 24576 channels: the largest
     matrix product of the step) where its shapes fit, else the module's own convolution.  frames (the product path): kernel_conv
     writes the LVC operator's frame-major operand order directly -- [B, layers, T, 6144] instead of the reference's
@@ -127,11 +142,14 @@ def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None, split=None, frame
             return None
         return kconv[4](h, [_conv_weight(m) for m in convs], [m.bias for m in convs], acts[0].negative_slope)
 
-    c = run(p.input_conv, c)                     # Conv1d 80 -> 64 k5, LeakyReLU(0.1)
-    r = stack(p.residual_conv, c)                # Dropout(p = 0), Conv1d 64 -> 64 k3, LeakyReLU(0.1), Conv1d, LeakyReLU, three times
-    if r is None:
-        r = run(p.residual_conv, c)
-    c = c + r
+    if front is not None:                        # (computed for all predictors at once: lvc_op.predictor_fronts)
+        c = front
+    else:
+        c = run(p.input_conv, c)                 # Conv1d 80 -> 64 k5, LeakyReLU(0.1)
+        r = stack(p.residual_conv, c)            # Dropout(p = 0), Conv1d 64 -> 64 k3, LeakyReLU(0.1), Conv1d, LeakyReLU, three times
+        if r is None:
+            r = run(p.residual_conv, c)
+        c = c + r
     kc = p.kernel_conv
     if frames is not None and split is not None and (cin, cout, ks) == (32, 64, 3) and \
             frames[2](c, kc.weight_v if hasattr(kc, "weight_v") else kc.weight):
@@ -154,12 +172,14 @@ def _torch_gate(x, y):
     return x + torch.sigmoid(y[:, :C]) * torch.tanh(y[:, C:])
 
 
-def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate, kconv=None, cconv=None, split=None, frames=None, fuse_act=True):
-    """TimeAware_LVCBlock.forward (modules.py:189-218); the in-place `x += audio_down` of the reference written out of place."""
+def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate, kconv=None, cconv=None, split=None, frames=None, fuse_act=True, front=None):
+    """TimeAware_LVCBlock.forward (modules.py:189-218); the in-place `x += audio_down` of the reference written out of place.
+    front: (cond, the predictor's front-end output for it) when the caller computed the front ends of all blocks at once."""
     C = cfg["inner_channels"]
-    cond = c + p.fc_t(emb).unsqueeze(-1)
+    cond = front[0] if front is not None else c + p.fc_t(emb).unsqueeze(-1)
     (kernels, slots), bias, as_frames = _kernel_predictor(p.kernel_predictor, cond, cfg["lvc_layers_each_block"], C, 2 * C, cfg["lvc_kernel_size"],
-                                                          kconv, split if kconv is not None else None, frames if kconv is not None else None, fuse_act)
+                                                          kconv, split if kconv is not None else None, frames if kconv is not None else None, fuse_act,
+                                                          None if front is None else front[1])
     if cconv is not None and x.is_cuda:
         from .lvc_op import upsample, upsample_supported
     if cconv is not None and x.is_cuda and upsample_supported(x, p.upsample):
@@ -234,7 +254,19 @@ def _forward_body(module, audio, c, diffusion_steps, cfg, lvc, gate, kconv, ccon
         else:
             skips.append(x)
             x = _dblock(down, x, cconv)
+    fuse_act = getattr(module, "_train_fuse_act", True)       # (False: the predictor's LeakyReLUs as torch nodes, for A/B runs)
+    fronts = [None] * len(module.lvc_blocks)
+    if kconv is not None and len(kconv) > 4 and fuse_act and c.is_cuda and c.dtype == torch.float32 and c.shape[1] == 80 and \
+            1 <= c.shape[2] <= 128 and 2 <= len(module.lvc_blocks) <= 8 and getattr(module, "_train_fronts", True):
+        # the KernelPredictors see only the mel and the step embedding, never x: their front ends -- input convolution + residual stack,
+        # each a chain of latency-bound launches -- run side by side, one launch per chain step for all blocks (lvc_op.predictor_fronts)
+        specs = [_front_spec(b.kernel_predictor) for b in module.lvc_blocks]
+        if all(s is not None for s in specs) and len({(len(s[1]), s[2]) for s in specs}) == 1:
+            from .lvc_op import predictor_fronts
+            conds = [c + b.fc_t(emb).unsqueeze(-1) for b in module.lvc_blocks]
+            outs = predictor_fronts(conds, [(_conv_weight(s[0]), s[0].bias) for s in specs],
+                                    [[(_conv_weight(m), m.bias) for m in s[1]] for s in specs], specs[0][2])
+            fronts = list(zip(conds, outs))
     for n, audio_down in enumerate(reversed(skips)):
-        x = _lvc_block(module.lvc_blocks[n], x, audio_down, c, emb, cfg, lvc, gate, kconv, cconv, split, frames,
-                       getattr(module, "_train_fuse_act", True))      # (False: the predictor's LeakyReLUs as torch nodes, for A/B runs)
+        x = _lvc_block(module.lvc_blocks[n], x, audio_down, c, emb, cfg, lvc, gate, kconv, cconv, split, frames, fuse_act, fronts[n])
     return _conv(module.final_conv[0], x)

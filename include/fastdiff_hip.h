@@ -225,6 +225,23 @@ FD_API int fd_input_conv_forward(fd_handle h, const float *x, const float *weigh
 FD_API int fd_input_conv_backward(fd_handle h, const float *x, const float *weight, const float *y, const float *dout, int B, int T,
                                   float post_slope, float *dx, float *dweight, float *dbias, void *stream);
 
+/* Side by side: n <= 8 INDEPENDENT convolutions of one shape in one launch each.  The network's three KernelPredictors have identical
+ * front ends -- input convolution, then six Conv1d(64, 64, 3) + LeakyReLU pairs -- on different weights and inputs; each is a chain
+ * of latency-bound launches of B workgroups, the three together the same chain with 3 B.  Every pointer argument is a HOST array of n
+ * device pointers (the library passes them on as kernel arguments); shapes and meaning per item as in the one-convolution entry
+ * points above.  fd_kconv_backward_x_multi is one step of n dx chains (dx only: the weight gradients come from
+ * fd_kconv_backward_w_multi once the chains have run); y[i] / dweight[i] / dbias[i] may be NULL where the single entry point allows it. */
+FD_API int fd_kconv_forward_act_multi(fd_handle h, int n, const float *const *x, const float *const *weight, const float *const *bias, int B,
+                                      int M, int T, float post_slope, float *const *out, void *stream);
+FD_API int fd_kconv_backward_x_multi(fd_handle h, int n, const float *const *x, const float *const *weight, const float *const *y,
+                                     const float *const *dout, int B, int M, int T, float post_slope, float in_slope, float *const *dx,
+                                     void *stream);
+FD_API int fd_input_conv_forward_multi(fd_handle h, int n, const float *const *x, const float *const *weight, const float *const *bias, int B,
+                                       int T, float post_slope, float *const *out, void *stream);
+FD_API int fd_input_conv_backward_multi(fd_handle h, int n, const float *const *x, const float *const *weight, const float *const *y,
+                                        const float *const *dout, int B, int T, float post_slope, float *const *dx, float *const *dweight,
+                                        float *const *dbias, void *stream);
+
 /* The same two operators joined without the reference's tensor in between ("frames").  The reference hands the predicted kernels from
  * kernel_conv to the location-variable convolution as [B, layers, 32, 64, 3, T] (modules.py:333-338; T innermost), which the matrix
  * kernels of the operator have to transpose into frame-major order before use (and the gradient back): three passes over 6144*B*T

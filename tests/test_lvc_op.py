@@ -275,6 +275,38 @@ def test_residual_stack_as_one_node_equals_the_pairs_one_by_one(B, T, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("P,n,B,T", [(3, 6, 20, 100), (2, 2, 3, 37), (3, 1, 1, 128), (8, 3, 2, 5)])
+def test_predictor_front_ends_side_by_side_equal_one_by_one(P, n, B, T):
+    """lvc_op.predictor_fronts: the front ends of P KernelPredictors (input convolution + activation, n Conv1d + LeakyReLU pairs, c + r) with
+    one launch per chain step for all P, against input_conv + kernel_conv_stack + add per predictor -- same kernels, the pointers of the P
+    convolutions as kernel arguments: outputs and every gradient bit for bit; one predictor's output unused: its gradients are zero."""
+    from fastdiff_amd import lvc_op
+    g = torch.Generator().manual_seed(P * 100 + n * 10 + T)
+    xs = [torch.randn(B, 80, T, generator=g).cuda() for _ in range(P)]
+    ic = [((torch.randn(64, 80, 5, generator=g) / 20).cuda(), torch.randn(64, generator=g).cuda()) for _ in range(P)]
+    st = [[((torch.randn(64, 64, 3, generator=g) / 9).cuda(), (torch.randn(64, generator=g) * 0.3).cuda()) for _ in range(n)] for _ in range(P)]
+    douts = [torch.randn(B, 64, T, generator=g).cuda() for _ in range(P)]
+    for unused in (None, P - 1):
+        leaf = lambda t: t.clone().requires_grad_(True)      # noqa: E731
+        xa, ica, sta = [leaf(x) for x in xs], [(leaf(w), leaf(b)) for w, b in ic], [[(leaf(w), leaf(b)) for w, b in s_] for s_ in st]
+        outs = lvc_op.predictor_fronts(xa, ica, sta, 0.1)
+        sum((o * d).sum() for p, (o, d) in enumerate(zip(outs, douts)) if p != unused).backward()
+        xb, icb, stb = [leaf(x) for x in xs], [(leaf(w), leaf(b)) for w, b in ic], [[(leaf(w), leaf(b)) for w, b in s_] for s_ in st]
+        for p in range(P):
+            c = lvc_op.input_conv(xb[p], icb[p][0], icb[p][1], 0.1)
+            o = c + lvc_op.kernel_conv_stack(c, [w for w, _ in stb[p]], [b for _, b in stb[p]], 0.1)
+            assert torch.equal(o.detach(), outs[p].detach()), p
+            if p == unused:
+                assert float(xa[p].grad.abs().max()) == 0.0 and float(ica[p][0].grad.abs().max()) == 0.0 and float(sta[p][0][0].grad.abs().max()) == 0.0
+                continue
+            (o * douts[p]).sum().backward()
+            assert torch.equal(xa[p].grad, xb[p].grad), p
+            assert torch.equal(ica[p][0].grad, icb[p][0].grad) and torch.equal(ica[p][1].grad, icb[p][1].grad), p
+            for j in range(n):
+                assert torch.equal(sta[p][j][0].grad, stb[p][j][0].grad) and torch.equal(sta[p][j][1].grad, stb[p][j][1].grad), (p, j)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,L,f", [(2, 1024, 4), (3, 96, 8), (1, 8, 8), (2, 30, 3), (20, 25600, 4)])
 def test_skip_fan_out_picks_and_adds_up_like_autograd(B, L, f):
     """lvc_op.skip_fan(x, f) = (x[..., ::f], x, x, x, x): the DBlock's nearest pick (F.interpolate to L / f, modules.py:128-131) and one

@@ -98,10 +98,11 @@ def main():
         except Exception as e:      # noqa: BLE001
             print(f"  hipGraph capture of the training step{label} failed: {e!r}")
         finally:
-            m._train_frames, m._train_fuse_act, m._train_skip_fan, m._train_stack, m._train_wn_all = True, True, True, True, True
+            m._train_frames, m._train_fuse_act, m._train_skip_fan, m._train_stack, m._train_wn_all, m._train_fronts = True, True, True, True, True, True
 
     graph_run("")
     if os.environ.get("FD_TRAIN_VARIANTS"):
+        graph_run(" [predictor front ends one by one]", _train_fronts=False)
         graph_run(" [weight-norm: one operator per convolution]", _train_wn_all=False)
         graph_run(" [residual stack: one node per pair]", _train_stack=False)
         graph_run(" [skip fan-out by autograd]", _train_skip_fan=False)
