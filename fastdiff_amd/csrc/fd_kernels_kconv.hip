@@ -742,7 +742,7 @@ hipError_t kconv_backward_x_multi(const Launch &L, int n, const float *const *h,
                                   float *const *dh, int B, int M, int T, float post, float in_slope, float *scratch)
 {
     if (n < 1 || n > KCS_MULTI || !kconv_act_supported(M, T)) return hipErrorInvalidValue;
-    const int nks = dh_slices(M, B, n, L.ctx->num_cus);
+    const int nks = dh_slices(M, B, 1, L.ctx->num_cus);      // as for ONE convolution (kconv_backward): the same partial sums, the same bits
     KcMulti m = {}, f = {};
     m.n = f.n = n;
     bool any_y = false;

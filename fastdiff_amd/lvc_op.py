@@ -453,6 +453,66 @@ def predictor_fronts(xs, input_convs, stacks, slope):
     return list(_PredictorFronts.apply(slope, n, *xs, *flat))
 
 
+class _KConvSide(torch.autograd.Function):
+    """P independent small convolutions of one shape -- conv1d(x_p [B,64,T], w_p [M,64,3], b_p, padding 1), M <= 512: the three
+    predictors' bias_conv -- with one launch per kernel for all P (fd_kconv_forward_act_multi, fd_kconv_backward_x_multi,
+    fd_kconv_backward_w_multi).  Inputs: x_1 .. x_P, w_1, b_1, ..., w_P, b_P."""
+
+    @staticmethod
+    def forward(ctx, *args):
+        P = len(args) // 3
+        xs = [t.contiguous().float() for t in args[:P]]
+        ws = [t.contiguous().float() for t in args[P::2]]
+        bs = [t.contiguous().float() for t in args[P + 1::2]]
+        B, _, T = xs[0].shape
+        M = ws[0].shape[0]
+        dev = xs[0].device
+        out = torch.empty((P, B, M, T), device=dev, dtype=torch.float32)
+        lib, h = _handle(dev)
+        _capi.check(lib, h, lib.fd_kconv_forward_act_multi(h, P, _ptrs(xs), _ptrs(ws), _ptrs(bs), B, M, T, 1.0, _ptrs(list(out.unbind(0))), _stream(dev)),
+                    "fd_kconv_forward_act_multi")
+        ctx.save_for_backward(*xs, *ws)
+        ctx.P = P
+        return tuple(out.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *gout):
+        P = ctx.P
+        xs, ws = ctx.saved_tensors[:P], ctx.saved_tensors[P:]
+        B, _, T = xs[0].shape
+        M = ws[0].shape[0]
+        dev = xs[0].device
+        zero = None
+        g = []
+        for t in gout:
+            if t is None:
+                zero = torch.zeros((B, M, T), device=dev, dtype=torch.float32) if zero is None else zero
+                t = zero
+            g.append(t.contiguous().float())
+        lib, h = _handle(dev)
+        st = _stream(dev)
+        DX = torch.empty((P, B, 64, T), device=dev, dtype=torch.float32) if any(ctx.needs_input_grad[:P]) else None
+        if DX is not None:
+            _capi.check(lib, h, lib.fd_kconv_backward_x_multi(h, P, None, _ptrs(ws), None, _ptrs(g), B, M, T, 1.0, 1.0, _ptrs(list(DX.unbind(0))), st),
+                        "fd_kconv_backward_x_multi")
+        dws = [torch.empty_like(w) for w in ws]
+        dbs = [torch.empty(M, device=dev, dtype=torch.float32) for _ in range(P)]
+        _capi.check(lib, h, lib.fd_kconv_backward_w_multi(h, P, _ptrs(xs), _ptrs(g), None, B, M, T, 1.0, _ptrs(dws), _ptrs(dbs), st), "fd_kconv_backward_w_multi")
+        grads = [None] * P if DX is None else list(DX.unbind(0))
+        for dw, db in zip(dws, dbs):
+            grads += [dw, db]
+        return tuple(grads)
+
+
+def kernel_conv1d_side_by_side(xs, weights, biases):
+    """[conv1d(x_p, w_p, b_p, padding=1) for p] for P <= 8 inputs [B, 64, T] and weights [M, 64, 3] of one shape (M <= 512), one launch
+    per kernel for all P."""
+    flat = []
+    for w, b in zip(weights, biases):
+        flat += [w, b]
+    return list(_KConvSide.apply(*xs, *flat))
+
+
 def kernel_conv_stack(x, weights, biases, slope):
     """leaky_relu(conv1d(., w_j, b_j, padding=1), slope) applied n times in a row to x [B, 64, T] (every w_j [64, 64, 3]) as one
     differentiable HIP operator: the predictor's residual stack without its Dropout(p = 0) modules."""

@@ -99,7 +99,7 @@ def _front_spec(p):
     return ic[0], convs, ic[1].negative_slope
 
 
-def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None, split=None, frames=None, fuse_act=True, front=None):
+def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None, split=None, frames=None, fuse_act=True, front=None, bias_out=None):
     """KernelPredictor.forward (modules.py:320-343).  kconv: the HIP operator for kernel_conv (64 -> 24576 channels: the largest
     matrix product of the step) where its shapes fit, else the module's own convolution.  frames (the product path): kernel_conv
     writes the LVC operator's frame-major operand order directly -- [B, layers, T, 6144] instead of the reference's
@@ -155,7 +155,8 @@ def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None, split=None, frame
             frames[2](c, kc.weight_v if hasattr(kc, "weight_v") else kc.weight):
         kf = frames[0](c, _conv_weight(kc), kc.bias)                     # [B, layers, T, 6144]
         # bias_conv's output likewise: the operator reads a layer's [B, 64, T] slice where it lies and writes its gradient into one buffer
-        return split(kf), split(conv(p.bias_conv, c).contiguous().view(B, layers, cout, T)), True
+        bo = bias_out if bias_out is not None else conv(p.bias_conv, c)      # (bias_out: computed for all predictors at once)
+        return split(kf), split(bo.contiguous().view(B, layers, cout, T)), True
     k = conv(kc, c)
     # the reference slices kernels[:, i] (modules.py:213-214), whose backward builds a zero tensor of all four layers per slice and
     # adds the four up; unbind hands autograd the same views and gets one stack back.  (One kernel_conv call per layer on that
@@ -163,8 +164,8 @@ def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None, split=None, frame
     # pay the same zero-fill-and-add in their backward.)
     k6 = k.contiguous().view(B, layers, cin, cout, ks, T)
     # on the product path the slices are used where they lie and their gradients land in one buffer (lvc_op.split_layers)
-    return (split(k6) if split is not None else (k6.unbind(1), None),
-            conv(p.bias_conv, c).contiguous().view(B, layers, cout, T).unbind(1), False)
+    bo = bias_out if bias_out is not None else conv(p.bias_conv, c)
+    return (split(k6) if split is not None else (k6.unbind(1), None), bo.contiguous().view(B, layers, cout, T).unbind(1), False)
 
 
 def _torch_gate(x, y):
@@ -179,7 +180,7 @@ def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate, kconv=None,
     cond = front[0] if front is not None else c + p.fc_t(emb).unsqueeze(-1)
     (kernels, slots), bias, as_frames = _kernel_predictor(p.kernel_predictor, cond, cfg["lvc_layers_each_block"], C, 2 * C, cfg["lvc_kernel_size"],
                                                           kconv, split if kconv is not None else None, frames if kconv is not None else None, fuse_act,
-                                                          None if front is None else front[1])
+                                                          None if front is None else front[1], None if front is None else front[2])
     if cconv is not None and x.is_cuda:
         from .lvc_op import upsample, upsample_supported
     if cconv is not None and x.is_cuda and upsample_supported(x, p.upsample):
@@ -266,7 +267,13 @@ def _forward_body(module, audio, c, diffusion_steps, cfg, lvc, gate, kconv, ccon
             conds = [c + b.fc_t(emb).unsqueeze(-1) for b in module.lvc_blocks]
             outs = predictor_fronts(conds, [(_conv_weight(s[0]), s[0].bias) for s in specs],
                                     [[(_conv_weight(m), m.bias) for m in s[1]] for s in specs], specs[0][2])
-            fronts = list(zip(conds, outs))
+            fronts = list(zip(conds, outs, [None] * len(outs)))
+            # ... and their bias_conv (64 -> 256, k3) likewise
+            bcs = [b.kernel_predictor.bias_conv for b in module.lvc_blocks]
+            if all(isinstance(m, torch.nn.Conv1d) and m.kernel_size == (3,) and m.padding == (1,) and m.dilation == (1,) and m.in_channels == 64 and
+                   m.out_channels == bcs[0].out_channels and m.out_channels % 32 == 0 and m.out_channels <= 512 for m in bcs):
+                from .lvc_op import kernel_conv1d_side_by_side
+                fronts = list(zip(conds, outs, kernel_conv1d_side_by_side(outs, [_conv_weight(m) for m in bcs], [m.bias for m in bcs])))
     for n, audio_down in enumerate(reversed(skips)):
         x = _lvc_block(module.lvc_blocks[n], x, audio_down, c, emb, cfg, lvc, gate, kconv, cconv, split, frames, fuse_act, fronts[n])
     return _conv(module.final_conv[0], x)

@@ -307,6 +307,30 @@ def test_predictor_front_ends_side_by_side_equal_one_by_one(P, n, B, T):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("P,M,B,T", [(3, 256, 20, 100), (2, 64, 3, 37), (8, 96, 1, 5)])
+def test_small_convolutions_side_by_side_equal_one_by_one(P, M, B, T):
+    """lvc_op.kernel_conv1d_side_by_side (the three predictors' bias_conv in one launch per kernel) against kernel_conv1d per
+    convolution: outputs and gradients bit for bit."""
+    import fastdiff_amd
+    from fastdiff_amd import lvc_op
+    g = torch.Generator().manual_seed(P + M + T)
+    xs = [torch.randn(B, 64, T, generator=g).cuda() for _ in range(P)]
+    ws = [(torch.randn(M, 64, 3, generator=g) / 14).cuda() for _ in range(P)]
+    bs = [torch.randn(M, generator=g).cuda() for _ in range(P)]
+    douts = [torch.randn(B, M, T, generator=g).cuda() for _ in range(P)]
+    leaf = lambda t: t.clone().requires_grad_(True)      # noqa: E731
+    xa, wa, ba = [leaf(t) for t in xs], [leaf(t) for t in ws], [leaf(t) for t in bs]
+    outs = lvc_op.kernel_conv1d_side_by_side(xa, wa, ba)
+    sum((o * d).sum() for o, d in zip(outs, douts)).backward()
+    for p in range(P):
+        xb, wb, bb = leaf(xs[p]), leaf(ws[p]), leaf(bs[p])
+        o = fastdiff_amd.kernel_conv1d(xb, wb, bb)
+        o.backward(douts[p])
+        assert torch.equal(o.detach(), outs[p].detach()), p
+        assert torch.equal(xa[p].grad, xb.grad) and torch.equal(wa[p].grad, wb.grad) and torch.equal(ba[p].grad, bb.grad), p
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,L,f", [(2, 1024, 4), (3, 96, 8), (1, 8, 8), (2, 30, 3), (20, 25600, 4)])
 def test_skip_fan_out_picks_and_adds_up_like_autograd(B, L, f):
     """lvc_op.skip_fan(x, f) = (x[..., ::f], x, x, x, x): the DBlock's nearest pick (F.interpolate to L / f, modules.py:128-131) and one
