@@ -9,14 +9,15 @@ operators (fastdiff_amd/lvc_op.py), forward and backward on HIP kernels:
     (kernel_conv1d_frames -> location_variable_convolution_frames: no transposes between the two), and the gate behind it;
   * the 21 small 32-channel convolutions with their skip add, activations and bias (conv32), first_audio_conv / final_conv (conv7),
     the up-samplers (upsample), the skip tensors' fan-out (skip_fan);
-  * the KernelPredictor: input convolution + activation (input_conv), the residual stack as one node (kernel_conv_stack),
-    kernel_conv and bias_conv;
+  * the KernelPredictors: their front ends (input convolution + activation, residual stack, c + r) for all three blocks side by side
+    in one node (predictor_fronts: a predictor never sees x, so the three latency-bound chains run as one), bias_conv likewise
+    (kernel_conv1d_side_by_side), kernel_conv per block;
   * weight-norm of all 53 convolutions in one operator (weight_norm_all).
 What stays on torch: the step embedding's five linear layers and swish, three broadcast adds, the loss (4 % of the step's kernel time).
 The sub-modules of fastdiff_amd.FastDiff are real nn.Conv1d / nn.Linear holders with the reference's weight_g / weight_v
 parametrisation, so the reference's optimizer, checkpointing and DDP wrapper see the module they expect.  FastDiff.forward takes this
 path when autograd is recording and the module is in train() mode or an input requires a gradient; everything else stays on the
-inference kernels.  module._train_frames / _train_fuse_act / _train_skip_fan / _train_stack / _train_wn_all = False switch single
+inference kernels.  module._train_frames / _train_fuse_act / _train_skip_fan / _train_stack / _train_wn_all / _train_fronts = False switch single
 pieces back to their predecessor (A/B runs: tools/train_step_probe.py).
 
 `lvc` (tests only): a replacement for the HIP operator with the same signature, so that the structure around it can be pinned on
