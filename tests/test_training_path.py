@@ -37,6 +37,34 @@ def _compare(model, daudio, g, tol, tag="f64"):
     return worst, da
 
 
+def test_predictor_front_end_is_recognised_only_in_the_models_shape():
+    """train._front_spec decides whether the three predictors' front ends may run side by side (lvc_op.predictor_fronts): the model's own
+    KernelPredictor (modules.py:292-314) qualifies -- input convolution 80 -> 64 k5 + LeakyReLU(0.1), six 64 -> 64 k3 convolutions each
+    followed by the same activation, Dropout(p = 0) in between --; a live dropout, another slope or another convolution does not (the
+    forward then takes the predictors one by one)."""
+    from fastdiff_amd import train
+    m = _module().train()
+    specs = [train._front_spec(b.kernel_predictor) for b in m.lvc_blocks]
+    assert len(specs) == 3
+    for s, b in zip(specs, m.lvc_blocks):
+        ic, convs, slope = s
+        assert ic is b.kernel_predictor.input_conv[0] and len(convs) == 6 and slope == pytest.approx(0.1)
+        assert all(isinstance(c, torch.nn.Conv1d) and c.in_channels == c.out_channels == 64 for c in convs)
+    kp = m.lvc_blocks[1].kernel_predictor
+    drop = next(x for x in kp.residual_conv if isinstance(x, torch.nn.Dropout))
+    drop.p = 0.1
+    assert train._front_spec(kp) is None                      # a live dropout sits between the pairs: not a plain chain
+    m.eval()
+    assert train._front_spec(kp) is not None                  # ... which eval() turns off again
+    m.train()
+    drop.p = 0.0
+    act = next(x for x in kp.residual_conv if isinstance(x, torch.nn.LeakyReLU))
+    act.negative_slope = 0.2
+    assert train._front_spec(kp) is None                      # two slopes in one chain
+    act.negative_slope = kp.input_conv[1].negative_slope
+    assert train._front_spec(kp) is not None
+
+
 def test_gradient_fixture_lists_every_parameter_of_the_module():
     g = load_golden("theta_grad")
     m = _module()
