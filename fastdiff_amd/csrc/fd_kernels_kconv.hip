@@ -648,17 +648,33 @@ using namespace fdk_kconv;
 bool kconv_supported(int M, int T) { return M > 0 && M % 32 == 0 && T >= 1 && T <= 128; }
 bool kconv_frames_supported(int M, int T) { return kconv_supported(M, T) && M % fdk_order::ME == 0 && M > 512; }
 
-// How many ranges to cut `units` (utterances / row chunks) into when `per_range` workgroups work on each range: the CUs take the
-// workgroups in turn, so the launch lasts (workgroups per CU) x (units per range); the smallest product wins, then the fewest ranges.
-static int pick_ranges(int per_range, int units, int max_ranges, int num_cus)
+// How many ranges to cut `units` (utterances / row chunks) into when `per_range` workgroups work on each range: the launch lasts
+// (rounds of workgroups over the chip's slots) x (units per range); the smallest product wins, then the fewest ranges.  slots: the
+// workgroups the chip holds at a time -- TWO per CU for the kernels below (195-226 registers, 33-41 KB of LDS).  Round 4 found the model
+// counting one per CU: kernel_conv at the training shape then got 768 workgroups of 5 utterances = two rounds of 5 on 512 slots where
+// 960 workgroups of 4 are two rounds of 4 (forward and dW -20 %), and the dh pass 1280 workgroups (2.5 rounds) where 24 slices fill one.
+static int pick_ranges(int per_range, int units, int max_ranges, int slots)
 {
     int best = 1;
     int64_t best_cost = INT64_MAX;
     for (int n = 1; n <= std::min(units, max_ranges); ++n) {
-        const int64_t cost = (int64_t)(((int64_t)per_range * n + num_cus - 1) / num_cus) * ((units + n - 1) / n);
+        const int64_t cost = (int64_t)(((int64_t)per_range * n + slots - 1) / slots) * ((units + n - 1) / n);
         if (cost < best_cost) { best_cost = cost; best = n; }
     }
     return best;
+}
+// the dh pass: slices of whole 32-row chunks (any divisor of their number up to KC_DH_SLICES), `per_slice` workgroups each
+static int dh_slices(int M, int per_slice, int slots)
+{
+    const int chunks = M / 32;
+    int nks = 1;
+    int64_t best = INT64_MAX;
+    for (int k = 1; k <= 64 && k <= chunks; ++k) {
+        if (chunks % k) continue;
+        const int64_t cost = (int64_t)(((int64_t)k * per_slice + slots - 1) / slots) * (chunks / k);
+        if (cost < best) { best = cost; nks = k; }
+    }
+    return nks;
 }
 constexpr int KC_DW_RANGES = 8, KC_DH_SLICES = 64;
 // scratch: the dh pass's row slices [slices][B][192][T], then the dW pass's utterance ranges [ranges][M][192] + [ranges][M]
@@ -679,7 +695,7 @@ hipError_t kconv_forward(const Launch &L, const float *h, const float *W, const 
         return hipSuccess;
     }
     const int gx = (M + 127) / 128;
-    const int ny0 = pick_ranges(gx, B, 16, L.ctx->num_cus), bchunk = (B + ny0 - 1) / ny0, ny = (B + bchunk - 1) / bchunk;
+    const int ny0 = pick_ranges(gx, B, 16, 2 * L.ctx->num_cus), bchunk = (B + ny0 - 1) / ny0, ny = (B + bchunk - 1) / bchunk;
     if (frames) FD_LAUNCH(L, "kconv_forward", k_kc_fwd<true>, dim3(gx, ny), dim3(256), 0, h, W, bias, out, B, M, T, bchunk);
     else FD_LAUNCH(L, "kconv_forward", k_kc_fwd<false>, dim3(gx, ny), dim3(256), 0, h, W, bias, out, B, M, T, bchunk);
     return hipSuccess;
@@ -713,18 +729,6 @@ hipError_t input_conv_backward(const Launch &L, const float *x, const float *w, 
 }
 
 // ---- n <= KCS_MULTI independent convolutions of one shape side by side (KcMulti) -------------------------------------------------
-static int dh_slices(int M, int B, int n, int num_cus)
-{
-    const int chunks = M / 32;
-    int nks = 1;
-    int64_t best = INT64_MAX;
-    for (int k = 1; k <= KC_DH_SLICES && chunks % k == 0; k *= 2) {
-        const int64_t cost = (int64_t)(((int64_t)k * B * n + num_cus - 1) / num_cus) * (chunks / k);
-        if (cost < best) { best = cost; nks = k; }
-    }
-    return nks;
-}
-
 hipError_t kconv_forward_multi(const Launch &L, int n, const float *const *h, const float *const *W, const float *const *bias, float *const *out, int B,
                                int M, int T, float post)
 {
@@ -742,7 +746,7 @@ hipError_t kconv_backward_x_multi(const Launch &L, int n, const float *const *h,
                                   float *const *dh, int B, int M, int T, float post, float in_slope, float *scratch)
 {
     if (n < 1 || n > KCS_MULTI || !kconv_act_supported(M, T)) return hipErrorInvalidValue;
-    const int nks = dh_slices(M, B, 1, L.ctx->num_cus);      // as for ONE convolution (kconv_backward): the same partial sums, the same bits
+    const int nks = dh_slices(M, B, 2 * L.ctx->num_cus);      // as for ONE convolution (kconv_backward): the same partial sums, the same bits
     KcMulti m = {}, f = {};
     m.n = f.n = n;
     bool any_y = false;
@@ -835,7 +839,7 @@ hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const
                   M, B, KK);
     } else if (dW || dbias) {
         const int gx = (M + 127) / 128;
-        const int ny0 = pick_ranges(gx, B, KC_DW_RANGES, L.ctx->num_cus), bchunk = (B + ny0 - 1) / ny0, ny = (B + bchunk - 1) / bchunk;
+        const int ny0 = pick_ranges(gx, B, KC_DW_RANGES, 2 * L.ctx->num_cus), bchunk = (B + ny0 - 1) / ny0, ny = (B + bchunk - 1) / bchunk;
         if (frames) FD_LAUNCH(L, "kconv_backward_w", (k_kc_dw<false, true>), dim3(gx, ny), dim3(256), 0, h, dout, part_w, B, M, T, bchunk);
         else if (T % 4 == 0) FD_LAUNCH(L, "kconv_backward_w", (k_kc_dw<true, false>), dim3(gx, ny), dim3(256), 0, h, dout, part_w, B, M, T, bchunk);
         else FD_LAUNCH(L, "kconv_backward_w", (k_kc_dw<false, false>), dim3(gx, ny), dim3(256), 0, h, dout, part_w, B, M, T, bchunk);
@@ -843,13 +847,7 @@ hipError_t kconv_backward(const Launch &L, const float *h, const float *W, const
                   M, ny, KK);
     }
     if (dh) {
-        const int chunks = M / 32;                                        // slices of whole 32-row chunks, a power of two of them
-        int nks = 1;
-        int64_t best = INT64_MAX;
-        for (int n = 1; n <= KC_DH_SLICES && chunks % n == 0; n *= 2) {
-            const int64_t cost = (int64_t)(((int64_t)n * B + L.ctx->num_cus - 1) / L.ctx->num_cus) * (chunks / n);
-            if (cost < best) { best = cost; nks = n; }
-        }
+        const int nks = dh_slices(M, B, 2 * L.ctx->num_cus);
         if (frames) FD_LAUNCH(L, "kconv_backward_h", (k_kc_dh<true, false>), dim3(nks, B), dim3(256), 0, W, dout, part_h, B, M, T, M / nks, (const float *)nullptr, 1.0f, KcMulti{});
         else if (y) FD_LAUNCH(L, "kconv_backward_h", (k_kc_dh<false, true>), dim3(nks, B), dim3(256), 0, W, dout, part_h, B, M, T, M / nks, y, post, KcMulti{});
         else FD_LAUNCH(L, "kconv_backward_h", (k_kc_dh<false, false>), dim3(nks, B), dim3(256), 0, W, dout, part_h, B, M, T, M / nks, y, post, KcMulti{});
