@@ -85,6 +85,9 @@ int main(int argc, char **argv)
     hipStream_t stream;
     HIP(hipStreamCreate(&stream));
     FD(h, fd_sample(h, mel_d, B, T, NULL, table, N, ddim, xT_d, z_d, 0, out_d, NULL, stream));
+    /* the result is provisional until the call's fp16-range check has been looked at: fd_sample_check waits for the call and, if an
+     * operand left the fp16 range, runs it again on the fp32 kernels (returns 1 then, 0 otherwise) -- mandatory before reading out_d */
+    if (fd_sample_check(h) < 0) DIE("fd_sample_check: %s", fd_last_error(h));
     HIP(hipStreamSynchronize(stream));
     HIP(hipMemcpy(host, out_d, sizeof(float) * n_x, hipMemcpyDeviceToHost));
 

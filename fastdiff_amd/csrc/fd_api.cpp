@@ -13,7 +13,7 @@
 static std::string g_create_error;
 static int settle(fd_handle h);      // fallback = host: look at the flags of a pending fd_sample before touching device state
 
-// rows of the predictor GEMM's fp16 image per utterance (gx_rows in fd_kernels_fast.hip: 128-frame windows + 2 halo rows)
+// rows of the predictor GEMM's fp16 image per utterance (gx_rows in fd_kernels_kp.hip: 128-frame windows + 2 halo rows)
 static inline int gx_rows_host(int T) { return ((T + 127) / 128) * 128 + 2; }
 
 #define FD_FAIL(h, code, ...)                                   \
@@ -147,6 +147,8 @@ int fd_default_config(fd_config *cfg)
 
 const char *fd_last_error(fd_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+static void release_handle(fd_context *h);
+
 int fd_create(const fd_config *cfg, int device, fd_handle *out)
 {
     fd_context *nullh = nullptr;
@@ -178,41 +180,24 @@ int fd_create(const fd_config *cfg, int device, fd_handle *out)
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
     }
     for (int i = 0; i < ST_COUNT; ++i) c->fast[i] = true;
-    if ((e = hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&c->ev_join[0], hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&c->ev_join[1], hipEventDisableTiming)) != hipSuccess ||
-        (e = hipMalloc(&c->scratch, 65536)) != hipSuccess) {
-        g_create_error = std::string("fd_create: ") + hipGetErrorString(e);
-        delete c;
+    // every resource of the handle lives in *c from the moment it exists, so one failure path (fd_destroy's own release code) frees
+    // whatever was created before the failing call
+    auto fail = [&](hipError_t err) {
+        g_create_error = std::string("fd_create: ") + hipGetErrorString(err);
+        release_handle(c);
         return FD_ERR_HIP;
-    }
-    if ((e = hipHostMalloc(reinterpret_cast<void **>(&c->flags_host), 256, hipHostMallocDefault)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&c->flags_done, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&c->flags_done2, hipEventDisableTiming)) != hipSuccess) {
-        if (c->flags_host) hipHostFree(c->flags_host);
-        hipFree(c->scratch);
-        hipStreamDestroy(c->cap_stream);
-        g_create_error = std::string("fd_create: ") + hipGetErrorString(e);
-        delete c;
-        return FD_ERR_HIP;
-    }
+    };
+    if ((e = hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&c->scratch, 65536)) != hipSuccess) return fail(e);
+    if ((e = hipHostMalloc(reinterpret_cast<void **>(&c->flags_host), 256, hipHostMallocDefault)) != hipSuccess) return fail(e);
     memset(c->flags_host, 0, 256);
+    if ((e = hipEventCreateWithFlags(&c->flags_done, hipEventDisableTiming)) != hipSuccess) return fail(e);
+    if ((e = hipEventCreateWithFlags(&c->flags_done2, hipEventDisableTiming)) != hipSuccess) return fail(e);
     // the staging ring is allocated here (64 KB per slot covers the step table and a few thousand utterances): a call only
     // allocates pinned memory again for a larger batch than that
     for (auto &sl : c->stage) {
-        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&sl.host), 65536, hipHostMallocDefault);
-        if (e == hipSuccess) sl.cap = 65536;
-    }
-    if (e != hipSuccess) {
-        for (auto &sl : c->stage)
-            if (sl.host) hipHostFree(sl.host);
-        hipFree(c->scratch);
-        hipStreamDestroy(c->cap_stream);
-        g_create_error = std::string("fd_create: ") + hipGetErrorString(e);
-        delete c;
-        return FD_ERR_HIP;
+        if ((e = hipHostMalloc(reinterpret_cast<void **>(&sl.host), 65536, hipHostMallocDefault)) != hipSuccess) return fail(e);
+        sl.cap = 65536;
     }
     *out = c;
     return FD_OK;
@@ -237,13 +222,9 @@ static void drop_graph(fd_context *c)
     c->graphs.clear();
 }
 
-int fd_destroy(fd_handle h)
+// Frees everything a handle owns (each member is null until created): the tail of fd_destroy and the failure path of fd_create.
+static void release_handle(fd_context *h)
 {
-    if (!h) return FD_ERR_INVALID;
-    hipSetDevice(h->device);
-    settle(h);
-    hipDeviceSynchronize();
-    prof_drain(h);
     if (h->flags_host) hipHostFree(h->flags_host);
     if (h->flags_done) hipEventDestroy(h->flags_done);
     if (h->flags_done2) hipEventDestroy(h->flags_done2);
@@ -262,10 +243,17 @@ int fd_destroy(fd_handle h)
     for (void *p : h->mel_allocs) hipFree(p);
     if (h->ev_switch) hipEventDestroy(h->ev_switch);
     if (h->cap_stream) hipStreamDestroy(h->cap_stream);
-    if (h->side_stream) hipStreamDestroy(h->side_stream);
-    for (hipEvent_t ev : {h->ev_fork, h->ev_join[0], h->ev_join[1]})
-        if (ev) hipEventDestroy(ev);
     delete h;
+}
+
+int fd_destroy(fd_handle h)
+{
+    if (!h) return FD_ERR_INVALID;
+    hipSetDevice(h->device);
+    settle(h);
+    hipDeviceSynchronize();
+    prof_drain(h);
+    release_handle(h);
     return FD_OK;
 }
 
@@ -811,58 +799,20 @@ static hipError_t run_step(const Launch &L, const StepIO &io, int B, int T)
     fd_context *c = L.ctx;
     Workspace &ws = c->ws;
     hipError_t e;
-    // option overlap = paths: the down path (first conv, DBlocks: reads x only) on the side stream next to the predictor (front + GEMM:
-    // reads the mel only); joined before the first LVC block, which needs both
-    const bool paths = c->overlap_paths && c->side_stream && !c->overlap_gemm;
-    const bool hoisted = c->hoist_np > 1;      // the predictor of all N steps ran in front of the loop (sample_core)
-    // option order = predictor: the predictor first, so that the GEMM's 2 GB of dirty lines drain under the down path and not under
-    // the first LVC layers
-    const bool pfirst = c->predictor_first && !hoisted && !c->overlap_gemm && !c->overlap_paths;
-    if (pfirst) {
+    // the reference's order of statements: down path (first conv, DBlocks), predictor (front + GEMM), the three LVC blocks.  With a
+    // hoisted predictor (hoist_np > 1) front + GEMM of all N steps ran in front of the loop (sample_core).  Other orders and a second
+    // stream were measured and did not pay (LABBOOK.md: overlap = gemm | paths, order = split | predictor).
+    const bool hoisted = c->hoist_np > 1;
+    if ((e = first_conv(L, io, B, T)) != hipSuccess) return e;
+    for (int d = 0; d < fd::NBLK; ++d)
+        if ((e = dblock(L, io, d, B, T)) != hipSuccess) return e;
+    if (!hoisted) {
         if ((e = kp_front(L, io, B, T)) != hipSuccess) return e;
         if ((e = kp_gemm(L, B, T)) != hipSuccess) return e;
     }
-    if (paths) {
-        if ((e = hipEventRecord(c->ev_fork, L.stream)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(c->side_stream, c->ev_fork, 0)) != hipSuccess) return e;
-        const Launch Ls = {c, c->side_stream, L.capturing};
-        if ((e = first_conv(Ls, io, B, T)) != hipSuccess) return e;
-        for (int d = 0; d < fd::NBLK; ++d)
-            if ((e = dblock(Ls, io, d, B, T)) != hipSuccess) return e;
-        if ((e = hipEventRecord(c->ev_join[0], c->side_stream)) != hipSuccess) return e;
-    } else {
-        if ((e = first_conv(L, io, B, T)) != hipSuccess) return e;
-        for (int d = 0; d < fd::NBLK; ++d)
-            if ((e = dblock(L, io, d, B, T)) != hipSuccess) return e;
-    }
-    if (!hoisted && !pfirst && (e = kp_front(L, io, B, T)) != hipSuccess) return e;
-    // option overlap = gemm: block 0's predicted kernels first, then [LVC block 0 || GEMM block 1] and [LVC block 1 || GEMM block 2]:
-    // the matrix-bound GEMM next to the memory-bound layers instead of in front of them, and block 0's records read while fresh
-    const bool overlap = !hoisted && c->overlap_gemm && c->fast[ST_KP_GEMM] && c->side_stream && fd_pipe(c, c->gemm_f16 && c->w.gemm_f16_ok, 0) != PIPE_F32_ONLY;
-    // option order = split: block 0's predicted kernels alone, then LVC block 0 (its records are then the last 0.7 GB written, not
-    // buried under blocks 1 and 2's 1.4 GB), then the GEMM of blocks 1 and 2 -- all on the one stream
-    const bool split = c->gemm_split && !hoisted && !pfirst && !overlap && c->fast[ST_KP_GEMM] && fd_pipe(c, c->gemm_f16 && c->w.gemm_f16_ok, 0) == PIPE_F16_ONLY;
-    if (hoisted || pfirst) {
-    } else if (split) {
-        if ((e = fast_kp_gemm(L, B, T, 0, 1, 2)) != hipSuccess) return e;
-    } else if (!overlap) {
-        if ((e = kp_gemm(L, B, T)) != hipSuccess) return e;
-    } else {
-        if ((e = fast_kp_gemm(L, B, T, 0, 1, 2)) != hipSuccess) return e;        // + the fp32 fallback of all three blocks behind it
-        if ((e = hipEventRecord(c->ev_fork, L.stream)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(c->side_stream, c->ev_fork, 0)) != hipSuccess) return e;
-        const Launch Ls = {c, c->side_stream, L.capturing};
-        for (int n = 1; n < fd::NBLK; ++n) {
-            if ((e = fast_kp_gemm(Ls, B, T, n, 1, c->overlap_wg)) != hipSuccess) return e;
-            if ((e = hipEventRecord(c->ev_join[n - 1], c->side_stream)) != hipSuccess) return e;
-        }
-    }
-    if (paths && (e = hipStreamWaitEvent(L.stream, c->ev_join[0], 0)) != hipSuccess) return e;
     float *x = ws.a[3];
     for (int n = 0; n < fd::NBLK; ++n) {
         float *xo = nullptr;
-        if (overlap && n > 0 && (e = hipStreamWaitEvent(L.stream, c->ev_join[n - 1], 0)) != hipSuccess) return e;
-        if (split && n == 1 && (e = fast_kp_gemm(L, B, T, 1, 2, 2)) != hipSuccess) return e;
         if ((e = lvc_block_run(L, n, x, B, T, &xo)) != hipSuccess) return e;
         x = xo;
     }
@@ -998,7 +948,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
 static unsigned mode_signature(const fd_context *h)
 {
     unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_f16 ? 2u : 0u) | (h->lvc_f16 ? 4u : 0u) | (h->conv_f16 ? 8u : 0u) | (h->step_lens ? 16u : 0u) |
-                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u) | (h->overlap_gemm ? 128u : 0u) | ((unsigned)h->overlap_wg << 8) | (h->overlap_paths ? 1024u : 0u) | ((unsigned)h->hoist_np << 11) | (h->predictor_first ? (1u << 20) : 0u) | (h->hoist_chunk ? (1u << 21) : 0u) | (h->fuse_up ? (1u << 22) : 0u) | (h->fuse_advance ? (1u << 23) : 0u) | (h->lvc_variant ? (1u << 24) : 0u) | ((unsigned)h->first_variant << 25) | (h->gemm_split ? (1u << 28) : 0u);
+                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u) | ((unsigned)h->hoist_np << 11) | (h->hoist_chunk ? (1u << 21) : 0u) | (h->fuse_up ? (1u << 22) : 0u) | (h->fuse_advance ? (1u << 23) : 0u);
     for (int i = 0; i < ST_COUNT; ++i) s = (s << 1) | (h->fast[i] ? 1u : 0u);
     return s ^ (h->fp32_mask * 2654435761u);
 }
@@ -1034,9 +984,8 @@ static int enqueue_steps(fd_handle h, int B, int T, int count, unsigned fp32_mas
         return e == hipSuccess ? fdk::kp_gemm(L, B * np, T) : e;
     };
     if (h->hoist_chunk) h->hoist_np = 1;          // (the signature below must not depend on the piece that ran last)
-    // between two steps of one sequence the bookkeeping can ride in the next step's first kernel -- when that kernel is the fast one,
-    // on the main stream (not option overlap = paths) and the first of the step (not option order = predictor with an in-step predictor)
-    const bool defer_advance = h->fuse_advance && h->fast[ST_FIRST] && !h->overlap_paths && !(h->predictor_first && h->hoist_np <= 1 && !h->hoist_chunk);
+    // between two steps of one sequence the bookkeeping rides in the next step's first kernel -- when that kernel is the fast one
+    const bool defer_advance = h->fuse_advance && h->fast[ST_FIRST];
     h->advance_pending = false;
     if (!(h->use_graph && !h->profile)) {
         fdk::Launch L = {h, stream, false};
@@ -1121,7 +1070,7 @@ static int sample_core(fd_handle h, const fd_context::SampleArgs &a, unsigned fo
 static int hoist_mult(const fd_context *h, int B, int T, int N)
 {
     if (h->hoist_mode == 0 || N < 2) return 1;
-    if (!(h->fast[ST_KP_FRONT] && h->fast[ST_KP_GEMM] && h->fast[ST_LVC]) || h->keep_taps || h->overlap_gemm) return 1;
+    if (!(h->fast[ST_KP_FRONT] && h->fast[ST_KP_GEMM] && h->fast[ST_LVC]) || h->keep_taps) return 1;
     const int np = std::min(N, 8);             // a longer schedule hoists per 8-step graph piece (fd_context::hoist_chunk)
     if (h->hoist_mode == 2) return np;
     return (int64_t)B * T <= 4096 ? np : 1;        // measured at T = 864: B = 1 -7.8 %, 2 -6.2 %, 3 -4.1 %, 4 -1.9 %, 8 and 16 +-0 (profiles/r03/s20_*)
@@ -2178,37 +2127,12 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
         if (v != "gather" && v != "copy") FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: lvc_dx expects gather|copy, got '%s'", value);
         h->lvc_dx_gather = (v == "gather"); return FD_OK;
     }
-    if (k == "first_variant") { h->first_variant = atoi(value) & 7; drop_graph(h); return FD_OK; }
-    if (k == "lvc_variant") { h->lvc_variant = atoi(value) ? 1 : 0; drop_graph(h); return FD_OK; }
     if (k == "embed_cache") { h->embed_cache = on; return FD_OK; }
     if (k == "hoist") {
         if (v == "auto") h->hoist_mode = 1;
         else if (v == "on") h->hoist_mode = 2;
         else if (v == "off") h->hoist_mode = 0;
         else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: hoist expects auto|on|off, got '%s'", value);
-        return FD_OK;
-    }
-    if (k == "overlap") {
-        if (v == "gemm") { h->overlap_gemm = true; h->overlap_paths = false; }
-        else if (v == "paths") { h->overlap_paths = true; h->overlap_gemm = false; }
-        else if (v == "off") { h->overlap_gemm = false; h->overlap_paths = false; }
-        else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: overlap expects gemm|paths|off, got '%s'", value);
-        drop_graph(h);
-        return FD_OK;
-    }
-    if (k == "order") {
-        if (v == "predictor") { h->predictor_first = true; h->gemm_split = false; }
-        else if (v == "down") { h->predictor_first = false; h->gemm_split = false; }
-        else if (v == "split") { h->predictor_first = false; h->gemm_split = true; }
-        else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: order expects predictor|down|split, got '%s'", value);
-        drop_graph(h);
-        return FD_OK;
-    }
-    if (k == "overlap_wg") {
-        const int n = atoi(value);
-        if (n < 1 || n > 2) FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: overlap_wg expects 1 or 2, got '%s'", value);
-        h->overlap_wg = n;
-        drop_graph(h);
         return FD_OK;
     }
     if (k == "graph") { h->use_graph = on; return FD_OK; }

@@ -173,7 +173,7 @@ struct fd_context {
     //                    fp32_mask set (option fallback = host: fd_sample_check)
     //   fp32_mask        bit i set: the stage whose flag word is i runs its fp32 kernel outright
     bool lvc_h8_mfma = true;                  // option "lvc_h8" = "mfma": the hop-8 layers on 16x16x32 fp16 tiles (k_lvc_h8m) | "valu" (k_lvc_h8)
-    bool host_fallback = false;               // option "fallback" = "host"
+    bool host_fallback = true;                // option "fallback" = "host" (default) | "graph"
     bool inline_fallback = true;
     unsigned fp32_mask = 0;
     bool h_image_ready = false;               // set by fast_kp_front when it wrote the GEMM's fp16 image of h for this step
@@ -185,10 +185,6 @@ struct fd_context {
     bool fuse_up = true;                     // option "fuse_up": the ConvTranspose of blocks 1 and 2 inside their first LVC layer (when both
                                              // stages run fp16x2-only, i.e. under fallback = host or a forced mask without them).  Same
                                              // bits, one launch and one round trip of x less per block: B=1 -5.2 %, B=8 -2.6 %
-    int lvc_variant = 1;                       // option "lvc_variant": 1 = phase-major parking area + early record request in k_lvc_h2<.., UP> (round 4) | 0 = round 3's form
-    int first_variant = 1;                   // option "first_variant": 1 (default since round 4) = k_first_conv takes its weights through vector
-                                             // loads + LDS; 0 = through scalar loads (round 1-3: the form a short-lived neighbour process on
-                                             // the same compute units disturbs); 2, 3 = probe forms (fd_kernels_fast.hip)
     bool final_fused = false;                // set by the last LVC layer's launch, consumed by fast_final
     bool fuse_advance = true;                // option "fuse_advance": between two steps of one graph / launch sequence the end-of-step
                                              // bookkeeping (k_advance) rides in the next step's first kernel instead of a launch of its own
@@ -212,8 +208,6 @@ struct fd_context {
     bool have_last_stream = false;
     hipEvent_t ev_switch = nullptr;          // the tail of the handle's last compute call (fd_api.cpp: mark_tail / follow_stream)
     bool tail_marked = false;
-    // option overlap = gemm: the predictor GEMM of blocks 1 and 2 runs on `side_stream` next to the LVC layers of blocks 0 and 1
-    // (fork / join through events; inside a captured step the side stream joins the capture).  overlap_wg: its workgroups per CU.
     // The predictor (front + GEMM) sees the mel and the step embedding only -- never x -- so for a short schedule on a small batch all N
     // steps' kernels are predicted by ONE pair of launches in front of the loop (batch entry n * B + b = step n of utterance b): at
     // B = 1 the front's seven-layer latency chain and the GEMM's fill are paid once per call instead of once per step.  hoist_np = N
@@ -224,13 +218,6 @@ struct fd_context {
     int hoist_mode = 1;                       // 0 off, 1 auto, 2 on
     int hoist_np = 1, hoist_step = 0;
     bool hoist_chunk = false;                 // a long schedule (N > 8): the predictor of each 8-step graph piece is hoisted to the piece's front
-    bool overlap_gemm = false;
-    bool overlap_paths = false;               // option overlap = paths: the down path next to the predictor (see run_step)
-    int overlap_wg = 1;
-    bool gemm_split = false;                  // option order = split: GEMM(block 0), LVC block 0, GEMM(blocks 1, 2), LVC blocks 1, 2
-    bool predictor_first = false;             // option order = down (default) | predictor: front + GEMM behind the down path or in front of it
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     // captured denoiser steps, one per (B, T, mode): micro-batches of different padded length alternate without re-capturing
     struct StepGraph { int B, T, steps; unsigned sig; hipGraph_t graph; hipGraphExec_t exec; unsigned long long last_use; };   // `steps` denoiser steps per launch
     std::vector<StepGraph> graphs;           // at most FD_MAX_GRAPHS, least recently used evicted

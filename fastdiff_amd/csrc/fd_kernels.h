@@ -12,11 +12,11 @@ hipError_t naive_convt(const Launch &L, int n, const float *x_in, float *x_out, 
 hipError_t naive_lvc_layer(const Launch &L, int n, int layer, float *x, const float *skip, float *y, int B, int T);
 hipError_t naive_final_eps(const Launch &L, const float *x32, float *eps, int B, int T);
 hipError_t naive_update(const Launch &L, float *x, const float *eps, int64_t n);
-// fast set (fd_kernels_fast.hip)
+// fast set (fd_kernels_first_final / _dblock / _kp / _convt / _lvc .hip)
 hipError_t fast_first_conv(const Launch &L, const StepIO &io, int B, int T);
 hipError_t fast_dblock(const Launch &L, int d, int B, int T, const float *audio);
 hipError_t fast_kp_front(const Launch &L, const StepIO &io, int B, int T);
-hipError_t fast_kp_gemm(const Launch &L, int B, int T, int blk0 = 0, int nblk = fd::NBLK, int wg_per_cu = 2);
+hipError_t fast_kp_gemm(const Launch &L, int B, int T);
 hipError_t fast_convt(const Launch &L, int n, const float *x_in, float *x_out, int B, int Lin);
 // up: layer 0 of block n >= 1 with the block's ConvTranspose inside it -- x_in is then the block's input (fp16x2-only launches)
 hipError_t fast_lvc_layer(const Launch &L, int n, int layer, const float *x_in, const float *skip, float *x_out, int B, int T, bool up = false);

@@ -1,0 +1,141 @@
+// fd_kernels_common.h -- device helpers shared by the stage files of the gfx950 kernel set (fd_kernels_*.hip).
+//
+// Everything with a channel contraction runs on the exact-fp32 matrix pipe, v_mfma_f32_32x32x2_f32
+// (bit-for-bit an fp32 fmaf chain, so the fp32 parity bar of the reference holds):
+//   D[row][col] += A[row][k] * B[k][col],   wave64 operand layout (MI355X_MICROARCH / cdna_hip guide 3):
+//     A: lane l holds A[row = l&31][k = l>>5]          (1 VGPR)
+//     B: lane l holds B[k = l>>5][col = l&31]          (1 VGPR)
+//     D: lane l, reg r holds D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]   (16 VGPRs)
+// Convolutions map as: row = output channel, col = time, k = (tap, input channel); the B operand is read
+// straight out of an LDS-staged sliding window (32 consecutive time samples per half-wave: conflict free),
+// the A operand (weights, or the predicted per-frame kernel of the location-variable convolution) sits in
+// registers, pre-packed in HBM as [s4 = step/4][lane][4] so each lane fetches 4 k-steps with one 16 B load.
+#ifndef FD_KERNELS_COMMON_H
+#define FD_KERNELS_COMMON_H
+#include "fd_kernels.h"
+#include "fd_device.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace fdk_fast {
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int drow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+// On gfx950 fp32 VALU instructions do NOT execute under a running fp32 MFMA (tools/ubench/coexec_probe.hip: every extra
+// VALU op costs ~4 cycles of matrix-pipe time, also when it comes from the other wave of the SIMD), so the inner loops
+// must not spend VALU on addressing.  The compiler likes to pair LDS reads of neighbouring taps into ds_read2_b32, whose
+// 8-bit offsets then force a fresh v_add per row.  Hiding the relation between the per-tap offsets keeps every read a
+// plain ds_read_b32 with a 16-bit immediate from three fixed base registers.
+__device__ __forceinline__ int opaque(int x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ float lrelu(float v, float s)   // 0 < s < 1:  max(v, s*v)
+{
+    // median(v, s*v, +inf) == max(v, s*v).  One v_med3_f32 instead of fmaxf()'s canonicalise + v_max pair, and -- unlike
+    // an inline-asm v_max -- visible to the compiler's VALU->MFMA hazard padding.
+    return __builtin_amdgcn_fmed3f(v, v * s, __builtin_inff());
+}
+__device__ __forceinline__ float f4c(const float4 &v, int r) { return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w)); }
+
+// Ragged batches: `lens` (nullable, device) holds the valid frames of every utterance of a zero-padded batch.  Every kernel
+// then treats utterance b as if it were lens[b] frames long: positions behind it read as the zero padding a convolution sees
+// at the end of a signal, tiles behind it are skipped.  Inside [0, lens[b]) the result is bit-identical to running the
+// utterance alone (tests/test_gpu_parity.py); what the output buffers hold behind it is unspecified.
+__device__ __forceinline__ int frames_of(const int *lens, int b, int T) { return lens ? lens[b] : T; }
+
+// Range flags (Workspace::range_flag): word i = "an operand of fp16-pipe launch i did not fit in this step", word 32 + i = the
+// same for the previous step of the sampler (copied by k_advance).  A launch whose flag was raised in the previous step does
+// not try again: it raises its flag at once and leaves the step to the fp32 kernel behind it -- a trajectory that has left the
+// fp16 range (an untrained network over 1000 steps does) then costs the fp32 kernels only, not both.
+__device__ __forceinline__ bool skip_after_previous_overflow(int *flag)
+{
+    if (flag[32] == 0) return false;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) atomicOr(flag, 1);
+    return true;
+}
+
+// ---- 2-piece fp16 operands: v = v1 + 2^-11 v2, v1 = fp16(v), v2 = fp16((v - v1) * 2^11) ----------------
+constexpr float GX_SCALE = 2048.0f, GX_INV_SCALE = 1.0f / 2048.0f;
+constexpr float GX_LIMIT = 32768.0f;            // magnitudes from here on do not fit: the kernels raise a range flag
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_f16(const float4 &a, const float4 &b, f32x16 c)
+{
+    union { float4 f; f16x8 h; } ua, ub;
+    ua.f = a;
+    ub.f = b;
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(ua.h, ub.h, c, 0, 0, 0);
+}
+
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
+{
+    const f2_t v = {a, b};
+    const h2_t h = __builtin_convertvector(v, h2_t);                       // v_cvt_pk_f16_f32, round to nearest even
+    const f2_t r = (v - __builtin_convertvector(h, f2_t)) * GX_SCALE;       // exact
+    const h2_t l = __builtin_convertvector(r, h2_t);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ void split8(const float (&v)[8], float4 &hi, float4 &lo)
+{
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split2(v[2 * i], v[2 * i + 1], h[i], l[i]);
+    hi = make_float4(__uint_as_float(h[0]), __uint_as_float(h[1]), __uint_as_float(h[2]), __uint_as_float(h[3]));
+    lo = make_float4(__uint_as_float(l[0]), __uint_as_float(l[1]), __uint_as_float(l[2]), __uint_as_float(l[3]));
+}
+__device__ __forceinline__ float amax4(float m, const float4 &v) { return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w))); }
+// byte offset of 16 B slot `slot` (piece*4 + channel/8) of row `row` in a [row][128 B] piece image
+__device__ __forceinline__ int h2_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+// 8 channels (image slot `slot`, 0..3) of one conv tap at image row `row`: the products the matrix pipe forms for the other
+// columns -- a1 += w1.x1, a2 += w1.x2 + w2.x1, fp32 accumulation -- on v_dot2_f32_f16.  w1/w2 = the weight pieces of those channels.
+__device__ __forceinline__ void halo_dot(const char *xs, int row, int slot, const float4 &w1f, const float4 &w2f, float &a1, float &a2)
+{
+    union { float4 f; h2_t h[4]; } x1, x2, w1, w2;
+    x1.f = *reinterpret_cast<const float4 *>(xs + h2_off(row, slot));
+    x2.f = *reinterpret_cast<const float4 *>(xs + h2_off(row, 4 + slot));
+    w1.f = w1f;
+    w2.f = w2f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        a1 = __builtin_amdgcn_fdot2(w1.h[q], x1.h[q], a1, false);
+        a2 = __builtin_amdgcn_fdot2(w1.h[q], x2.h[q], a2, false);
+        a2 = __builtin_amdgcn_fdot2(w2.h[q], x1.h[q], a2, false);
+    }
+}
+
+
+// Cache policy of the big streams.  FD_LVC_NT bits: which accesses carry the nt (non-temporal) bit -- hop-64/256 LVC layers: 1 = x
+// loads, 2 = out stores, 4 = the frame's record, 8 = skip loads; 16 = hop-8 LVC out stores, 32 = ConvTranspose out stores, 64 =
+// first_conv out stores.  Measured (profiles/r03/s40_s41_nt_policy.txt): 2 pays (layer -3 % alone, call -0.75 % at B=8, -1.9 % at B=1),
+// 4 costs 6 % (both waves of a row tile read the record: it has to stay in L1/L2), the rest +-0.
+#ifndef FD_LVC_NT
+#define FD_LVC_NT 2
+#endif
+typedef float lvc_f4 __attribute__((ext_vector_type(4)));
+template <int BIT>
+__device__ __forceinline__ float4 lvc_ld(const float4 *p)
+{
+    if constexpr ((FD_LVC_NT & BIT) != 0) {
+        const lvc_f4 v = __builtin_nontemporal_load(reinterpret_cast<const lvc_f4 *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else return *p;
+}
+template <int BIT>
+__device__ __forceinline__ void lvc_st(float *p, float v) { if constexpr ((FD_LVC_NT & BIT) != 0) __builtin_nontemporal_store(v, p); else *p = v; }
+template <int BIT>
+__device__ __forceinline__ void lvc_st(float4 *p, const float4 &v)
+{
+    if constexpr ((FD_LVC_NT & BIT) != 0) __builtin_nontemporal_store(lvc_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<lvc_f4 *>(p));
+    else *p = v;
+}
+
+}  // namespace fdk_fast
+#endif /* FD_KERNELS_COMMON_H */

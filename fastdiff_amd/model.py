@@ -122,8 +122,8 @@ class FastDiff(nn.Module):
         self.last_ticket = 0
         # Library options of this module's handle.  "fallback": "host" -- the range check of a sample() call is read on the host
         # instead of trailing every fp16x2 kernel with an early-exit fp32 launch (21 launches per reverse step less: -3 % at B=8,
-        # -7 % at B=1); sample() / check() / settle() below keep that safe for every caller of this class.  The C ABI's own
-        # default stays "graph" (a caller that reads `out` without fd_sample_check must never see a provisional result).
+        # -7 % at B=1); sample() / check() / settle() below keep that safe for every caller of this class.  It is also the
+        # library's own default (a C caller calls fd_sample_check before it reads `out`: include/fastdiff_hip.h).
         self._options = {"fallback": "host"}
 
     # ---- reference API --------------------------------------------------------------------------------
@@ -187,7 +187,7 @@ class FastDiff(nn.Module):
         and lens[b] frames long (its first lens[b]*256 samples are exactly that result; the rest of its row is unspecified).
         stream_ids: optional [B] integers (fd_set_noise_streams): utterance b draws its noise from Philox stream (seed, stream_ids[b])
         over its own samples, i.e. independently of its place in the batch.
-        defer_check: this class runs the library with option fallback = "host" (self._options; the C ABI's own default is "graph"): a
+        defer_check: this class runs the library with option fallback = "host" (self._options; also the C ABI's default): a
         result is final only after its range check has been looked at (fd_sample_check: one stream synchronisation and, rarely, a
         second pass on the fp32 kernels).  sample() does that before returning unless told to defer.  A deferred call is settled ONLY by
         check(), settle(ticket), forward(), the next sample() (which looks at it after enqueuing itself), set_option and a weight
@@ -247,7 +247,7 @@ class FastDiff(nn.Module):
         """Pipelined host check (option fallback = "host", sample(..., defer_check=True)): make the sample() call whose `last_ticket`
         was `ticket` final -- waiting for it only if nothing has looked at it yet; the next sample() on the module does so after
         enqueuing itself -- and return True if it had to be run again on the fp32 kernels: whatever the caller computed from its
-        output in the meantime (epilogue, copies) must then be computed again.  With the default in-graph fallbacks: False."""
+        output in the meantime (epilogue, copies) must then be computed again.  With in-graph fallbacks (option fallback = "graph"): False."""
         if self._handle is None:
             return False
         lib = _capi.load()

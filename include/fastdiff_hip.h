@@ -119,15 +119,16 @@ FD_API int fd_sample(fd_handle h, const float *mel, int B, int T, const int *len
                      int ddim, const float *x_T, const float *z, uint64_t seed, float *out, float *seq_out,
                      void *stream);
 
-/* Option "fallback" = "host": fd_sample enqueues only the fp16x2 kernels (no early-exit fp32 launch behind each of them: 17 launches
- * per reverse step less); whether an operand left the fp16 range is then known on the HOST, after the work has run:
+/* The range check of fd_sample (option "fallback" = "host", the default on both sides of the boundary): fd_sample enqueues only the
+ * fp16x2 kernels; whether an operand left the fp16 range is then known on the HOST, after the work has run, and a C caller MUST call
+ * fd_sample_check (or fd_sample_settle) before it reads `out`:
  *   fd_sample_check waits for the last fd_sample of this handle and, if one of its kernels raised a range flag, runs it again from
  *   the saved start with the flagged stages on their fp32 kernels.  Returns 1 if the call was redone, 0 if not, < 0 on error.
  * Until it has returned, `out` / `seq_out` of that fd_sample are provisional and its `z` must stay valid.  fd_forward, fd_sample (see
  * the pipelined form below), fd_commit_weights, fd_set_option, fd_read_tap and fd_destroy settle a pending check first, so nothing
  * is ever lost; fd_peak_normalize_int16[_ragged] and fd_mel_spectrogram do NOT (since round 3: they run on the provisional result
  * without waiting) -- a caller that reads `out`, or anything computed from it, must call fd_sample_check / fd_sample_settle before.  Schedules longer than 8 steps are checked (with a stream synchronisation) every 8 steps inside fd_sample.
- * With the default ("graph") fd_sample_check is a no-op returning 0.
+ * With option "fallback" = "graph" (fp32 twins inside the graph) fd_sample_check is a no-op returning 0.
  *
  * Pipelined form (round 3; schedules of up to 8 steps, i.e. one graph launch per call): the next fd_sample on the handle does NOT
  * wait for the pending call -- it enqueues its own work first and looks at the previous call's flags afterwards, when the host's
@@ -338,33 +339,26 @@ FD_API int fd_conv32_backward(fd_handle h, const float *xs, const float *y, cons
  * zero-padded (needs n_samples > 512), filters.mel(22050, 1024, 80, 0, 8000), ln(clamp(., 1e-5)). */
 FD_API int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_samples, float *mel, int T, void *stream);
 
-/* Options: "kernels" = "fast" | "naive" (all stages), "kernels.<stage>" for one stage
- * (embed, first, dblock, kp_front, kp_gemm, convt, lvc, final); "graph" = "1" | "0"; "profile" = "1" | "0";
- * "gemm" = "f16x2" (default: predictor GEMM on the fp16 matrix pipe with 2-piece operands, 22 bits each; error below
- *          an fp32 sgemm; operands outside the fp16 range fall back to fp32 on the device) | "fp32";
- * "lvc"  = "f16x2" (default: the same for the LVC layers of hop 64 and 256) | "fp32";
- * "conv" = "f16x2" (default: the same for the DBlocks and the ConvTranspose upsamplers) | "fp32";
- * "fuse_final" = "1" (default: the last LVC layer applies final_conv to its own tile instead of writing 32 channels for a separate
- *          kernel to read back; off automatically with "taps") | "0";
- * "mel"  = "pwg" (default) | "tacotron": which of the reference's two mel front-ends fd_mel_spectrogram computes;
- * "lvc_h8" = "mfma" (default: the hop-8 LVC layers on 16x16x32 fp16 matrix tiles, 2-piece operands; needs "lvc" = "f16x2") | "valu"
- *          (the all-VALU fp32 kernel, which is also the fallback);
- * "fallback" = "graph" (default: every fp16x2 kernel is followed by its fp32 twin, which exits at once unless the first raised its
- *          range flag -- no host round trip, fully asynchronous) | "host" (see fd_sample_check);
- * "hoist" = "auto" (default) | "on" | "off": the predictor (front + GEMM) sees the mel and the step embedding only, never x, so fd_sample can
- *          predict the kernels of ALL N reverse steps with one launch pair in front of the loop (batch entry = (step, utterance)) -- at a
- *          small batch its latency chain and fill are then paid once per call, not once per step (B = 1: -8 %); costs N x the
- *          predicted-kernel memory.  A schedule of more than 8 steps does it per captured 8-step piece (N = 1000 at B = 1: -8 %).
- *          auto: N >= 2 and B * T <= 4096 frames;
- * "overlap" = "off" (default) | "gemm" | "paths", "overlap_wg": measured variants of the step on two streams;
- * "fuse_up" = "1" (default) | "0": under "fallback" = "host" the ConvTranspose of blocks 1 and 2 runs inside the block's first LVC
- *          layer (same bits; one launch and one round trip of x less per block: B = 1 -5 %, B = 8 -2.6 %);
- * "embed_cache" = "1" (default) | "0": keep the step-embedding rows of the last schedule between fd_sample calls (same t values and B);
- * "fuse_advance" = "1" (default) | "0": the end-of-step bookkeeping inside the next step's first kernel (one launch less per step);
- * "order" = "down" (default: the reference's order of statements) | "split" (GEMM of block 0, LVC block 0, GEMM of blocks 1 and 2, the
- *          rest: measured 1 % slower) | "predictor" (front + GEMM first, so that the GEMM's 2 GB of
- *          stores drain under the DBlocks and not under the first LVC layers; same bits, measured +-0: INTEGRATION.md);
- * "taps" = "1" | "0" (keep block outputs for fd_read_tap). */
+/* Options (key = value; the first value is the default).  Each one selects between code paths that ship tested; measured-and-rejected
+ * variants are not options (LABBOOK.md keeps their numbers).
+ *   "gemm" | "lvc" | "conv" = "f16x2" | "fp32"   the predictor GEMM / the LVC layers / DBlocks + ConvTranspose + predictor front on the fp16
+ *                          matrix pipe with 2-piece operands (22 significant bits, fp32 accumulation) or on the exact-fp32 matrix instruction
+ *   "lvc_h8"   = "mfma" | "valu"   hop-8 LVC layers on 16x16x32 fp16 tiles, or the all-VALU fp32 kernel (also their fp32 twin)
+ *   "fallback" = "host" | "graph"  what happens when an operand does not fit fp16 in fd_sample.  host: only the fp16x2 kernels are enqueued,
+ *                          their range flags are read on the host behind the work and a flagged call is run again on fp32 kernels
+ *                          (fd_sample_check / fd_sample_settle make a result final: mandatory before `out` is read).  graph: every fp16x2
+ *                          kernel is followed by its fp32 twin, which exits at once unless the flag is up (no host step, 21 more
+ *                          launches per reverse step: +3 % at B = 8, +7 % at B = 1); fd_sample_check is then a no-op
+ *   "hoist"    = "auto" | "on" | "off"   predict the kernels of all N <= 8 steps (or of each 8-step piece) with one front + GEMM launch pair
+ *                          in front of the loop; auto: B * T <= 4096 frames
+ *   "fuse_up" | "fuse_final" | "fuse_advance" | "embed_cache" = "1" | "0"   the block's ConvTranspose inside its first LVC layer (blocks 1, 2;
+ *                          needs fallback = host) / final_conv inside the last LVC layer / the end-of-step bookkeeping inside the next
+ *                          step's first kernel / the step-embedding rows kept between calls with the same schedule.  Same bits either way
+ *   "mel"      = "pwg" | "tacotron"      which of the reference's two mel front-ends fd_mel_spectrogram computes
+ *   "graph"    = "1" | "0"               replay the reverse loop from captured hipGraphs, or launch kernel by kernel
+ * Test / measurement hooks: "kernels" = "fast" | "naive" and "kernels.<stage>" (embed, first, dblock, kp_front, kp_gemm, convt, lvc, final:
+ * the one-thread-per-output kernel set), "taps" = "0" | "1" (keep block outputs for fd_read_tap), "profile" = "0" | "1" | "events"
+ * (per-kernel timing, graph off), "lvc_dx" = "gather" | "copy" (training operator). */
 FD_API int fd_set_option(fd_handle h, const char *key, const char *value);
 
 /* Test / introspection hooks (not on the reference's API surface) -------------------------------------- */

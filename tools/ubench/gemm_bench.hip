@@ -1,5 +1,5 @@
 // gemm_bench.hip -- standalone timing harness for k_kp_gemm
-#include "../../fastdiff_amd/csrc/fd_kernels_fast.hip"
+#include "../../fastdiff_amd/csrc/fd_kernels_kp.hip"
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>

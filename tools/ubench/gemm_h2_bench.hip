@@ -1,5 +1,5 @@
 // gemm_h2_bench.hip -- standalone timing harness for k_h_split + k_kp_gemm_h2 (build variants with -DFD_GX_NO_STORE / -DFD_GX_NO_FETCH)
-#include "../../fastdiff_amd/csrc/fd_kernels_fast.hip"
+#include "../../fastdiff_amd/csrc/fd_kernels_kp.hip"
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>

@@ -1,5 +1,5 @@
 // lvc_bench.hip -- standalone timing harness for k_lvc_layer (phase stamps with s_memtime when FD_LVC_TIMING is set)
-#include "../../fastdiff_amd/csrc/fd_kernels_fast.hip"
+#include "../../fastdiff_amd/csrc/fd_kernels_lvc.hip"
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>

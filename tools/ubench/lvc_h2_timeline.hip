@@ -1,7 +1,7 @@
 // lvc_h2_timeline.hip -- when is every workgroup of k_lvc_h2<256> in which phase, and on which CU?
 // Build: hipcc -O3 --offload-arch=gfx950 -DFD_LVC_TIMELINE -o lvc_h2_timeline lvc_h2_timeline.hip ; writes <out>.bin:
 // per workgroup 10 x int64 = stamps 0..7 (100 MHz s_memrealtime), HW_ID, XCC_ID.
-#include "../../fastdiff_amd/csrc/fd_kernels_fast.hip"
+#include "../../fastdiff_amd/csrc/fd_kernels_lvc.hip"
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>

@@ -1,6 +1,6 @@
 // lvc_h8_bench.hip -- standalone timing harness for the hop-8 layer: k_lvc_h8m (16x16x32 fp16 matrix tiles) and k_lvc_h8 (all VALU, fp32).  Repetitions re-read the same 172 MB of records, which then sit in the
 // 256 MB memory-side cache: the number is the kernel's own ceiling (42 us, 4.5 TB/s algorithmic), not what it sees behind the GEMM.
-#include "../../fastdiff_amd/csrc/fd_kernels_fast.hip"
+#include "../../fastdiff_amd/csrc/fd_kernels_lvc.hip"
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
