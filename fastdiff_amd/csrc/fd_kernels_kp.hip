@@ -551,6 +551,14 @@ __device__ __forceinline__ void gx_item(char *lds, const GxItem &cur, bool more,
         if (acc[0] != 12345.678f) continue;
 #endif
         if (FULL) {
+#ifdef FD_GX_STORE_AUX_B0     // probe (tools/gpu_r5_s1.sh): block 0's records -- the ones the hop-8 layers right behind this kernel read -- under a policy of their own
+            if (cur.blk == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaf(lo[r], GX_INV_SCALE, acc[r])), rs, loff * 4u,
+                                                          (tile * 32 + (r & 3) + 8 * (r >> 2)) * fd::KREC * 4, FD_GX_STORE_AUX_B0);
+            } else
+#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaf(lo[r], GX_INV_SCALE, acc[r])), rs, loff * 4u,

@@ -398,13 +398,24 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
         float hx[8], hs[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
+#ifdef FD_LVC_PROBE_NOLOADX   // probe (tools/ubench, pair-fusion bound): x and skip already on chip -- values made from the lane number, no loads
+            const float pv_ = __int_as_float(0x3c000000 | (lane << 8) | (c << 4));
+            if constexpr (UP == 0) xa[c] = make_float4(pv_, -pv_, pv_ * 0.5f, pv_ * 0.25f);
+            sa[c] = make_float4(pv_ * 0.125f, pv_, -pv_, pv_ * 2.0f);
+#else
             if constexpr (UP == 0) xa[c] = ok ? lvc_ld<1>(reinterpret_cast<const float4 *>(xr + (int64_t)c * Ln + g)) : make_float4(0.f, 0.f, 0.f, 0.f);
             sa[c] = ok ? lvc_ld<8>(reinterpret_cast<const float4 *>(sr + (int64_t)c * Ln + g)) : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
+#ifdef FD_LVC_PROBE_NOLOADX
+            if constexpr (UP == 0) hx[c] = __int_as_float(0x3b000000 | (lane << 8) | (c << 4));
+            hs[c] = hok ? 0.03125f : 0.0f;
+#else
             if constexpr (UP == 0) hx[c] = hok ? xr[(int64_t)c * Ln + hg] : 0.0f;
             hs[c] = hok ? sr[(int64_t)c * Ln + hg] : 0.0f;
+#endif
         }
         if constexpr (UP > 0) {
             // ---- the block's ConvTranspose (see the head of the kernel); skip is on its way from HBM meanwhile -----------------
@@ -686,7 +697,11 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
                     const int chl = 16 * (mt0 + m) + (r & 3) + 8 * (r >> 2);     // channel minus 4*hi
                     const float zs = fmaf(al[r], GX_INV_SCALE, ah[r]), zt = fmaf(al[r + 8], GX_INV_SCALE, ah[r + 8]);
                     if constexpr (FINAL) resid[nt][m * 8 + r] += gate(zs, zt);
+#ifdef FD_LVC_PROBE_NOSTORE   // probe (pair-fusion bound): the first layer of a pair keeps its output on chip
+                    else { const float keep_ = resid[nt][m * 8 + r] + gate(zs, zt); asm volatile("" :: "v"(keep_)); (void)xo; (void)Lnu; (void)chl; }
+#else
                     else lvc_st<2>(xo + ((unsigned)chl * Lnu + (unsigned)(nt * 32)), resid[nt][m * 8 + r] + gate(zs, zt));
+#endif
                 }
             }
         }

@@ -37,7 +37,7 @@ int main(int argc, char **argv)
     for (int i = 0; i < 2; ++i) run();
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    const int reps = 5;
+    const int reps = argc > 4 ? atoi(argv[4]) : 5;      // (tools/power_trace.py runs ~2 s of it)
     for (int i = 0; i < reps; ++i) run();
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
