@@ -26,7 +26,7 @@ class FdKernelStat(ct.Structure):
 
 
 EXPORTS = ["fd_default_config", "fd_create", "fd_destroy", "fd_last_error", "fd_set_weight", "fd_commit_weights",
-           "fd_forward", "fd_sample", "fd_sample_check", "fd_sample_ticket", "fd_sample_settle", "fd_set_noise_streams", "fd_peak_normalize_int16", "fd_peak_normalize_int16_ragged", "fd_mel_spectrogram", "fd_lvc_forward", "fd_lvc_backward", "fd_lvc_forward_strided", "fd_lvc_backward_strided", "fd_gate_forward", "fd_gate_backward", "fd_kconv_forward", "fd_kconv_backward", "fd_weight_norm_multi_forward", "fd_weight_norm_multi_backward", "fd_fan_forward", "fd_fan_backward", "fd_input_conv_forward", "fd_input_conv_backward", "fd_kconv_backward_w_multi", "fd_kconv_forward_act_multi", "fd_kconv_backward_x_multi", "fd_input_conv_forward_multi", "fd_input_conv_backward_multi", "fd_kconv_forward_act", "fd_kconv_backward_act", "fd_kconv_forward_frames", "fd_kconv_backward_frames", "fd_lvc_forward_frames", "fd_lvc_backward_frames", "fd_conv32_forward", "fd_conv32_backward", "fd_weight_norm_forward", "fd_weight_norm_backward", "fd_conv7_forward", "fd_conv7_backward", "fd_upsample_forward", "fd_upsample_backward", "fd_set_option", "fd_read_tap", "fd_kernel_index", "fd_bias_index",
+           "fd_forward", "fd_sample", "fd_sample_check", "fd_sample_ticket", "fd_sample_settle", "fd_set_noise_streams", "fd_peak_normalize_int16", "fd_peak_normalize_int16_ragged", "fd_mel_spectrogram", "fd_set_mel_filterbank", "fd_get_mel_filterbank", "fd_lvc_forward", "fd_lvc_backward", "fd_lvc_forward_strided", "fd_lvc_backward_strided", "fd_gate_forward", "fd_gate_backward", "fd_kconv_forward", "fd_kconv_backward", "fd_weight_norm_multi_forward", "fd_weight_norm_multi_backward", "fd_fan_forward", "fd_fan_backward", "fd_input_conv_forward", "fd_input_conv_backward", "fd_kconv_backward_w_multi", "fd_kconv_forward_act_multi", "fd_kconv_backward_x_multi", "fd_input_conv_forward_multi", "fd_input_conv_backward_multi", "fd_kconv_forward_act", "fd_kconv_backward_act", "fd_kconv_forward_frames", "fd_kconv_backward_frames", "fd_lvc_forward_frames", "fd_lvc_backward_frames", "fd_conv32_forward", "fd_conv32_backward", "fd_weight_norm_forward", "fd_weight_norm_backward", "fd_conv7_forward", "fd_conv7_backward", "fd_upsample_forward", "fd_upsample_backward", "fd_set_option", "fd_read_tap", "fd_kernel_index", "fd_bias_index",
            "fd_get_profile", "fd_reset_profile", "fd_get_counter", "fd_version"]
 
 _lib = None
@@ -65,6 +65,8 @@ def load():
     lib.fd_peak_normalize_int16.argtypes = [vp, vp, ci, ct.c_int64, vp, vp]
     lib.fd_peak_normalize_int16_ragged.argtypes = [vp, vp, ci, ct.c_int64, vp, vp, vp]
     lib.fd_mel_spectrogram.argtypes = [vp, vp, ci, ct.c_int64, vp, ci, vp]
+    lib.fd_set_mel_filterbank.argtypes = [vp, vp, ci, ci]
+    lib.fd_get_mel_filterbank.argtypes = [vp, vp, ci, ci]
     lib.fd_lvc_forward.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]
     lib.fd_lvc_backward.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp]
     lib.fd_lvc_forward_strided.argtypes = [vp, vp, vp, ct.c_int64, vp, ci, ci, ci, ci, ci, ci, vp, vp]

@@ -1330,64 +1330,128 @@ int fd_set_noise_streams(fd_handle h, const uint64_t *stream_ids, int B)
     return FD_OK;
 }
 
-// Tables of the mel front-end, in double precision: twiddles, periodic Hann window, and librosa.filters.mel(22050, 1024, 80, fmin,
-// fmax) restated (Slaney mel scale, triangular weights on the FFT bin centres, each filter scaled by 2 / (f[m+2] - f[m])) for the
-// two front-ends of the reference: 'pwg' (fmin 80, fmax 7600; base.yaml:8-9) and Tacotron (0, 8000; FastDiff_tacotron.yaml:20-21).
+// The DEFAULT filter bank of a front-end, dense [80][513]: librosa.filters.mel(22050, 1024, 80, fmin, fmax) restated in double
+// precision (Slaney mel scale, triangular weights on the FFT bin centres, each filter scaled by 2 / (f[m+2] - f[m])) for 'pwg' (fmin
+// 80, fmax 7600; base.yaml:8-9) and Tacotron (0, 8000; FastDiff_tacotron.yaml:20-21).  librosa is not in this image, so these values
+// are a restatement pinned only against an independent derivation (tests/test_mel_frontend.py); a deployment that has librosa hands
+// its own matrix to fd_set_mel_filterbank and this function is then not used.
+static const int MEL_NM = 80, MEL_NB = 513;
+static std::vector<float> default_mel_bank(int variant)
+{
+    const double sr = 22050.0;
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
+    auto hz_to_mel = [&](double f) { return f >= min_log_hz ? min_log_mel + log(f / min_log_hz) / logstep : f / f_sp; };
+    auto mel_to_hz = [&](double m) { return m >= min_log_mel ? min_log_hz * exp(logstep * (m - min_log_mel)) : f_sp * m; };
+    const double band[MEL_VARIANTS][2] = {{80.0, 7600.0}, {0.0, 8000.0}};
+    std::vector<double> mf(MEL_NM + 2);
+    const double m0 = hz_to_mel(band[variant][0]), m1 = hz_to_mel(band[variant][1]);
+    for (int i = 0; i < MEL_NM + 2; ++i) mf[i] = mel_to_hz(m0 + (m1 - m0) * i / (MEL_NM + 1));
+    std::vector<float> fb((size_t)MEL_NM * MEL_NB, 0.0f);
+    for (int m = 0; m < MEL_NM; ++m) {
+        const double enorm = 2.0 / (mf[m + 2] - mf[m]);
+        for (int k = 0; k < MEL_NB; ++k) {
+            const double fk = (sr / 2.0) * k / (MEL_NB - 1);
+            const double lower = (fk - mf[m]) / (mf[m + 1] - mf[m]), upper = (mf[m + 2] - fk) / (mf[m + 2] - mf[m + 1]);
+            const double wv = std::max(0.0, std::min(lower, upper));
+            if (wv > 0.0) fb[(size_t)m * MEL_NB + k] = (float)(wv * enorm);
+        }
+    }
+    return fb;
+}
+
+static int mel_upload(fd_handle h, const void *src, size_t bytes, const void **dst)
+{
+    void *d = nullptr;
+    FD_HIP(h, hipMalloc(&d, bytes));
+    h->mel_allocs.push_back(d);        // freed at fd_destroy: a replaced table stays valid for launches still in flight
+    FD_HIP(h, hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+    *dst = d;
+    return FD_OK;
+}
+
+// A dense bank [80][513] as the kernel reads it: per filter the first non-zero bin, the span up to the last non-zero one, and the
+// weights of that span exactly as given (k_mel_frontend adds w[k] * |X_k| over the span in ascending k; a zero inside it adds zero).
+static int upload_mel_bank(fd_handle h, int variant, const float *fb)
+{
+    std::vector<int> lo(MEL_NM, 0), cnt(MEL_NM, 0), off(MEL_NM, 0);
+    std::vector<float> wts;
+    for (int m = 0; m < MEL_NM; ++m) {
+        int first = -1, last = -1;
+        for (int k = 0; k < MEL_NB; ++k)
+            if (fb[(size_t)m * MEL_NB + k] != 0.0f) { if (first < 0) first = k; last = k; }
+        off[m] = (int)wts.size();
+        if (first >= 0) {
+            lo[m] = first; cnt[m] = last - first + 1;
+            wts.insert(wts.end(), fb + (size_t)m * MEL_NB + first, fb + (size_t)m * MEL_NB + last + 1);
+        }
+    }
+    if (wts.empty()) wts.push_back(0.0f);
+    MelTables t = h->mel[variant];
+    int rc;
+    if ((rc = mel_upload(h, lo.data(), lo.size() * sizeof(int), reinterpret_cast<const void **>(&t.fb_lo))) != FD_OK) return rc;
+    if ((rc = mel_upload(h, cnt.data(), cnt.size() * sizeof(int), reinterpret_cast<const void **>(&t.fb_n))) != FD_OK) return rc;
+    if ((rc = mel_upload(h, off.data(), off.size() * sizeof(int), reinterpret_cast<const void **>(&t.fb_off))) != FD_OK) return rc;
+    if ((rc = mel_upload(h, wts.data(), wts.size() * sizeof(float), reinterpret_cast<const void **>(&t.fb_w))) != FD_OK) return rc;
+    h->mel[variant] = t;
+    h->mel_bank[variant].assign(fb, fb + (size_t)MEL_NM * MEL_NB);
+    return FD_OK;
+}
+
+// Tables of the mel front-end: twiddles and the periodic Hann window in double precision (shared), and each front-end's filter bank
+// (the caller's, if fd_set_mel_filterbank supplied one before the first use, else the default above).
 static int ensure_mel_tables(fd_handle h)
 {
     if (h->mel[MEL_VARIANTS - 1].tab) return FD_OK;
-    const int NF = 1024, NB = NF / 2 + 1, NM = 80;
-    const double sr = 22050.0, pi = 3.14159265358979323846;
+    const int NF = 1024;
+    const double pi = 3.14159265358979323846;
     std::vector<float> tab(3 * NF);
     for (int i = 0; i < NF; ++i) {
         tab[i] = (float)cos(2.0 * pi * i / NF);
         tab[NF + i] = (float)sin(2.0 * pi * i / NF);
         tab[2 * NF + i] = (float)(0.5 - 0.5 * cos(2.0 * pi * i / NF));
     }
-    auto up = [&](const void *src, size_t bytes, const void **dst) -> int {
-        void *d = nullptr;
-        FD_HIP(h, hipMalloc(&d, bytes));
-        h->mel_allocs.push_back(d);
-        FD_HIP(h, hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
-        *dst = d;
-        return FD_OK;
-    };
     const float *tab_dev = nullptr;
     int rc;
-    if ((rc = up(tab.data(), tab.size() * sizeof(float), reinterpret_cast<const void **>(&tab_dev))) != FD_OK) return rc;
-    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
-    auto hz_to_mel = [&](double f) { return f >= min_log_hz ? min_log_mel + log(f / min_log_hz) / logstep : f / f_sp; };
-    auto mel_to_hz = [&](double m) { return m >= min_log_mel ? min_log_hz * exp(logstep * (m - min_log_mel)) : f_sp * m; };
-    const double band[MEL_VARIANTS][2] = {{80.0, 7600.0}, {0.0, 8000.0}};
+    if ((rc = mel_upload(h, tab.data(), tab.size() * sizeof(float), reinterpret_cast<const void **>(&tab_dev))) != FD_OK) return rc;
     for (int v = 0; v < MEL_VARIANTS; ++v) {
-        std::vector<double> mf(NM + 2);
-        const double m0 = hz_to_mel(band[v][0]), m1 = hz_to_mel(band[v][1]);
-        for (int i = 0; i < NM + 2; ++i) mf[i] = mel_to_hz(m0 + (m1 - m0) * i / (NM + 1));
-        std::vector<int> lo(NM), cnt(NM), off(NM);
-        std::vector<float> wts;
-        for (int m = 0; m < NM; ++m) {
-            lo[m] = 0; cnt[m] = 0; off[m] = (int)wts.size();
-            const double enorm = 2.0 / (mf[m + 2] - mf[m]);
-            for (int k = 0; k < NB; ++k) {
-                const double fk = (sr / 2.0) * k / (NB - 1);
-                const double lower = (fk - mf[m]) / (mf[m + 1] - mf[m]), upper = (mf[m + 2] - fk) / (mf[m + 2] - mf[m + 1]);
-                const double wv = std::max(0.0, std::min(lower, upper));
-                if (wv > 0.0) {
-                    if (cnt[m] == 0) lo[m] = k;
-                    wts.push_back((float)(wv * enorm));
-                    ++cnt[m];
-                }
-            }
+        if (!h->mel[v].fb_w) {
+            const std::vector<float> fb = default_mel_bank(v);
+            if ((rc = upload_mel_bank(h, v, fb.data())) != FD_OK) return rc;
         }
-        if (wts.empty()) wts.push_back(0.0f);
-        MelTables &t = h->mel[v];
-        if ((rc = up(lo.data(), lo.size() * sizeof(int), reinterpret_cast<const void **>(&t.fb_lo))) != FD_OK) return rc;
-        if ((rc = up(cnt.data(), cnt.size() * sizeof(int), reinterpret_cast<const void **>(&t.fb_n))) != FD_OK) return rc;
-        if ((rc = up(off.data(), off.size() * sizeof(int), reinterpret_cast<const void **>(&t.fb_off))) != FD_OK) return rc;
-        if ((rc = up(wts.data(), wts.size() * sizeof(float), reinterpret_cast<const void **>(&t.fb_w))) != FD_OK) return rc;
-        t.tab = tab_dev;                                   // last: marks this variant ready
+        h->mel[v].tab = tab_dev;                           // last: marks this variant ready
     }
     return FD_OK;
+}
+
+int fd_set_mel_filterbank(fd_handle h, const float *fb, int n_mels, int n_bins)
+{
+    if (!h) return FD_ERR_INVALID;
+    if (n_mels != MEL_NM || n_bins != MEL_NB)
+        FD_FAIL(h, FD_ERR_INVALID, "fd_set_mel_filterbank: the front-end is 80 filters over the 513 bins of a 1024-point FFT, got [%d][%d]", n_mels, n_bins);
+    FD_HIP(h, hipSetDevice(h->device));
+    const int v = h->mel_variant;
+    if (!fb) {                                             // back to the restated default
+        const std::vector<float> def = default_mel_bank(v);
+        h->mel_bank_user[v] = false;
+        return upload_mel_bank(h, v, def.data());
+    }
+    for (size_t i = 0; i < (size_t)MEL_NM * MEL_NB; ++i)
+        if (!(fb[i] == fb[i]) || fb[i] > 3.0e38f || fb[i] < -3.0e38f) FD_FAIL(h, FD_ERR_INVALID, "fd_set_mel_filterbank: element %zu is not finite", i);
+    const int rc = upload_mel_bank(h, v, fb);
+    if (rc == FD_OK) h->mel_bank_user[v] = true;
+    return rc;
+}
+
+int fd_get_mel_filterbank(fd_handle h, float *fb_out, int n_mels, int n_bins)
+{
+    if (!h || !fb_out) return FD_ERR_INVALID;
+    if (n_mels != MEL_NM || n_bins != MEL_NB) FD_FAIL(h, FD_ERR_INVALID, "fd_get_mel_filterbank: expects [80][513], got [%d][%d]", n_mels, n_bins);
+    FD_HIP(h, hipSetDevice(h->device));
+    const int rc = ensure_mel_tables(h);
+    if (rc != FD_OK) return rc;
+    const int v = h->mel_variant;
+    memcpy(fb_out, h->mel_bank[v].data(), sizeof(float) * MEL_NM * MEL_NB);
+    return h->mel_bank_user[v] ? 1 : 0;
 }
 
 int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_samples, float *mel, int T, void *stream)

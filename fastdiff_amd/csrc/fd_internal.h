@@ -198,6 +198,8 @@ struct fd_context {
     bool embed_cache = true;                 // option "embed_cache"
     MelTables mel[MEL_VARIANTS];             // [MEL_PWG]: fmin 80, fmax 7600; [MEL_TACOTRON]: fmin 0, fmax 8000 (twiddles/window shared)
     int mel_variant = MEL_PWG;               // option "mel"
+    std::vector<float> mel_bank[MEL_VARIANTS];   // the dense [80][513] bank each front-end uses (host copy: fd_get_mel_filterbank)
+    bool mel_bank_user[MEL_VARIANTS] = {false, false};   // supplied through fd_set_mel_filterbank (else the restated default)
     std::vector<void *> mel_allocs;           // device memory behind `mel` (built on first use, freed at fd_destroy)
     int last_B = 0, last_T = 0;
     hipStream_t cap_stream = nullptr;

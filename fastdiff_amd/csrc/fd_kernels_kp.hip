@@ -429,8 +429,12 @@ constexpr int GX_ROWB = 2 * 128;                // bytes per row of the piece im
 constexpr int GX_WINB = GX_ROWS * GX_ROWB;      // 33280 B per item window
 constexpr int GX_NDMA = (GX_WINB + 4095) / 4096;   // 4 KB (256 lanes x 16 B) DMA rounds per window: 8 full + 1 partial
 constexpr int GX_BUFB = GX_NDMA * 4096;         // LDS bytes per buffer (the partial round is padded to a whole wave)
+// Cache policy bits of the predicted-kernel stores (1 = sc0, 2 = nt, 16 = sc1).  nt since round 5: the 2 GB of records stream past L2
+// instead of turning it over under the window reads, and fewer dirty lines are left for the hop-8 layers behind this kernel to
+// wait on -- A/B in one session on a box of the slower kind (profiles/r05/s1_gemm_store_policy.txt): kernel 706 -> 567 us, the first
+// hop-8 layer 82.8 -> 65.0 us, a reverse step 2575 -> 2416 us; sc0 sc1 (write-through) 671 us; nt on block 0's records only 582 us.
 #ifndef FD_GX_STORE_AUX
-#define FD_GX_STORE_AUX 0      // cache policy bits of the predicted-kernel stores (2 = nt)
+#define FD_GX_STORE_AUX 2
 #endif
 
 __host__ __device__ inline int gx_rows(int T) { return ((T + GX_CT * 32 - 1) / (GX_CT * 32)) * (GX_CT * 32) + 2; }   // image rows per (block, utterance)

@@ -371,6 +371,9 @@ def main(argv=None):
     ap.add_argument("--test_input_dir", required=True, help="directory of [T,80] .npy mels, or of .wav recordings with --from_wav")
     ap.add_argument("--from_wav", action="store_true", help="inputs are recordings: compute the mels on the device first")
     ap.add_argument("--mel_variant", default="pwg", choices=("pwg", "tacotron"), help="front-end for --from_wav (base.yaml / FastDiff_tacotron.yaml features)")
+    ap.add_argument("--mel_basis", default=None, metavar="FILE.npy",
+                    help="with --from_wav: an [80, 513] float32 filter bank to use instead of the library's restated default, e.g. saved "
+                         "from librosa.filters.mel(sr=22050, n_fft=1024, n_mels=80, fmin=80, fmax=7600) (data_gen_utils.py:122-134)")
     ap.add_argument("--out_dir", required=True)
     ap.add_argument("--N", type=int, default=4, help="reverse steps: 3, 4, 6, 8, 200 or 1000 (FastDiff.py:76-93)")
     ap.add_argument("--ckpt", default=None, help="reference checkpoint (state_dict under ['state_dict']['model'])")
@@ -384,6 +387,8 @@ def main(argv=None):
     model = FastDiff().cuda().eval()
     if args.ckpt:
         model.load_state_dict(torch.load(args.ckpt, map_location="cpu")["state_dict"]["model"], strict=True)
+    if args.mel_basis:
+        model.set_mel_filterbank(np.load(args.mel_basis), variant=args.mel_variant)
     items = load_wav_inputs(model, args.test_input_dir, mel_variant=args.mel_variant) if args.from_wav else load_mel_inputs(args.test_input_dir)
     mine = [dict(items[i], uid=i) for i in sorted(set(distributed_sampler_indices(len(items), rank, world)))]
     paths = save_wavs(synthesize(model, mine, args.N, args.max_batch, args.seed), args.out_dir)

@@ -56,7 +56,10 @@ class _LVC(torch.autograd.Function):
         _, _, Cout, ks, T = kernel.shape
         model_shape = (Cin, Cout, ks) == (32, 64, 3) and int(hop_size) in (8, 64, 256)
         x, bias = x.contiguous().float(), bias.contiguous().float()
-        if not (kernel.dtype == torch.float32 and model_shape and _batch_strided(kernel)):      # (a slice stays where it lies)
+        # a layer's slice stays where it lies, and its gradient may go into the shared slot, only for the shape whose kernels take a
+        # batch stride (fd_lvc_*_strided: the model's own); every other shape runs on a contiguous copy and owns its gradient
+        ctx.strided_ok = kernel.dtype == torch.float32 and model_shape and _batch_strided(kernel)
+        if not ctx.strided_ok:
             kernel = kernel.contiguous().float()
         out = torch.empty((B, Cout, L), device=x.device, dtype=torch.float32)
         lib, h = _handle(x.device)
@@ -77,7 +80,7 @@ class _LVC(torch.autograd.Function):
         dk = None
         if need_k:
             slot = ctx.grad_slot
-            if slot is not None and ctx.in_dtypes[1] == torch.float32:      # this layer's slice of the shared gradient buffer
+            if slot is not None and ctx.strided_ok:      # this layer's slice of the shared gradient buffer
                 holder, i, shape = slot
                 if holder.get("buf") is None:
                     holder["buf"] = torch.empty(shape, device=x.device, dtype=torch.float32)

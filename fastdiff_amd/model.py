@@ -292,6 +292,40 @@ class FastDiff(nn.Module):
         _capi.check(lib, h, lib.fd_mel_spectrogram(h, wav.data_ptr(), B, n, mel.data_ptr(), T, self._stream(wav.device)), "fd_mel_spectrogram")
         return mel
 
+    def set_mel_filterbank(self, fb, variant="pwg", device=None):
+        """Use `fb` [80, 513] (numpy / tensor, float32; librosa.filters.mel's own layout) as the filter bank of front-end `variant`
+        instead of the library's restated default -- what a deployment that has librosa passes
+        (`librosa.filters.mel(sr=22050, n_fft=1024, n_mels=80, fmin=80, fmax=7600)`; Tacotron: fmin 0, fmax 8000;
+        data_gen/tts/data_gen_utils.py:122-134, tacotron/layers.py:42-60).  The weights are used bit for bit.  fb None: back to the default."""
+        import numpy as np
+        if variant not in ("pwg", "tacotron"):
+            raise ValueError(f"set_mel_filterbank: variant must be 'pwg' or 'tacotron', got {variant!r}")
+        dev = device if device is not None else next(self.parameters()).device
+        lib, h = self._ready(torch.device(dev))
+        _capi.check(lib, h, lib.fd_set_option(h, b"mel", variant.encode()), "fd_set_option")
+        banks = self.__dict__.setdefault("_mel_banks", {})
+        if fb is None:
+            banks.pop(variant, None)
+            _capi.check(lib, h, lib.fd_set_mel_filterbank(h, None, 80, 513), "fd_set_mel_filterbank")
+            return
+        a = np.ascontiguousarray(fb.detach().cpu().numpy() if torch.is_tensor(fb) else fb, dtype=np.float32)
+        if a.shape != (80, 513):
+            raise ValueError(f"set_mel_filterbank: expected [80, 513] (80 mel filters over the bins of a 1024-point FFT), got {list(a.shape)}")
+        _capi.check(lib, h, lib.fd_set_mel_filterbank(h, a.ctypes.data, 80, 513), "fd_set_mel_filterbank")
+        banks[variant] = a.copy()
+
+    def mel_filterbank(self, variant="pwg", device=None):
+        """(bank [80, 513] float32 numpy, supplied_by_caller) of front-end `variant` as the library uses it."""
+        import numpy as np
+        dev = device if device is not None else next(self.parameters()).device
+        lib, h = self._ready(torch.device(dev))
+        _capi.check(lib, h, lib.fd_set_option(h, b"mel", variant.encode()), "fd_set_option")
+        out = np.empty((80, 513), np.float32)
+        rc = lib.fd_get_mel_filterbank(h, out.ctypes.data, 80, 513)
+        if rc < 0:
+            _capi.check(lib, h, rc, "fd_get_mel_filterbank")
+        return out, bool(rc)
+
     # ---- options / introspection (tests, bench) ---------------------------------------------------------
     def set_option(self, key, value):
         self._options[key] = str(value)
@@ -389,6 +423,9 @@ class FastDiff(nn.Module):
             self._handle, self._handle_device, self._synced_state = h, idx, None
             for k, v in self._options.items():
                 _capi.check(lib, h, lib.fd_set_option(h, k.encode(), v.encode()), "fd_set_option")
+            for variant, a in self.__dict__.get("_mel_banks", {}).items():      # caller-supplied filter banks follow the module to a new device
+                _capi.check(lib, h, lib.fd_set_option(h, b"mel", variant.encode()), "fd_set_option")
+                _capi.check(lib, h, lib.fd_set_mel_filterbank(h, a.ctypes.data, 80, 513), "fd_set_mel_filterbank")
         sig = self._state_signature()
         if sig != self._synced_state:
             self._upload_weights(lib)

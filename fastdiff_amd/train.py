@@ -100,7 +100,7 @@ def _front_spec(p):
     return ic[0], convs, ic[1].negative_slope
 
 
-def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None, split=None, frames=None, fuse_act=True, front=None, bias_out=None):
+def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None, split=None, frames=None, fuse_act=True, front=None, bias_out=None, hop=None):
     """KernelPredictor.forward (modules.py:320-343).  kconv: the HIP operator for kernel_conv (64 -> 24576 channels: the largest
     matrix product of the step) where its shapes fit, else the module's own convolution.  frames (the product path): kernel_conv
     writes the LVC operator's frame-major operand order directly -- [B, layers, T, 6144] instead of the reference's
@@ -152,7 +152,9 @@ def _kernel_predictor(p, c, layers, cin, cout, ks, kconv=None, split=None, frame
             r = run(p.residual_conv, c)
         c = c + r
     kc = p.kernel_conv
-    if frames is not None and split is not None and (cin, cout, ks) == (32, 64, 3) and \
+    # the frames pair exists for the model's own shape only (fd_lvc_*_frames: Cin 32, Cout 64, ks 3, hop 8 / 64 / 256); any other
+    # configuration the constructor accepts takes the reference's kernel tensor through the generic operator below
+    if frames is not None and split is not None and (cin, cout, ks) == (32, 64, 3) and hop in (8, 64, 256) and \
             frames[2](c, kc.weight_v if hasattr(kc, "weight_v") else kc.weight):
         kf = frames[0](c, _conv_weight(kc), kc.bias)                     # [B, layers, T, 6144]
         # bias_conv's output likewise: the operator reads a layer's [B, 64, T] slice where it lies and writes its gradient into one buffer
@@ -181,7 +183,8 @@ def _lvc_block(p, x, audio_down, c, emb, cfg, lvc, gate=_torch_gate, kconv=None,
     cond = front[0] if front is not None else c + p.fc_t(emb).unsqueeze(-1)
     (kernels, slots), bias, as_frames = _kernel_predictor(p.kernel_predictor, cond, cfg["lvc_layers_each_block"], C, 2 * C, cfg["lvc_kernel_size"],
                                                           kconv, split if kconv is not None else None, frames if kconv is not None else None, fuse_act,
-                                                          None if front is None else front[1], None if front is None else front[2])
+                                                          None if front is None else front[1], None if front is None else front[2],
+                                                          hop=int(p.cond_hop_length))
     if cconv is not None and x.is_cuda:
         from .lvc_op import upsample, upsample_supported
     if cconv is not None and x.is_cuda and upsample_supported(x, p.upsample):

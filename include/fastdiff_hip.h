@@ -339,6 +339,20 @@ FD_API int fd_conv32_backward(fd_handle h, const float *xs, const float *y, cons
  * zero-padded (needs n_samples > 512), filters.mel(22050, 1024, 80, 0, 8000), ln(clamp(., 1e-5)). */
 FD_API int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_samples, float *mel, int T, void *stream);
 
+/* The mel filter bank of the front-end selected by option "mel" -- the matrix the reference gets from
+ * librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax) at data_gen/tts/data_gen_utils.py:122-134 ('pwg') and
+ * data_gen/tts/tacotron/layers.py:42-60 (TacotronSTFT.mel_basis).
+ *   fd_set_mel_filterbank: fb [80][513] HOST, row-major (librosa's own layout) -- the weights are then used exactly as given (per filter
+ *     the span first..last non-zero bin, summed in ascending bin order); fb NULL restores the default.  A deployment that has librosa
+ *     passes `librosa.filters.mel(sr=22050, n_fft=1024, n_mels=80, fmin=80, fmax=7600)` ('pwg') or `(..., fmin=0, fmax=8000)`
+ *     (Tacotron) itself.  Takes effect for the calls enqueued after it; n_mels / n_bins must be 80 / 513.
+ *   fd_get_mel_filterbank: copies the bank in use to fb_out [80][513] host; returns 1 if it was supplied by the caller, 0 if it is the
+ *     default, < 0 on error.
+ * The DEFAULT is a restatement of librosa's published algorithm (Slaney scale, area-normalised triangles) -- librosa is absent from the
+ * build image, so its values are checked against an independent derivation only (tests/test_mel_frontend.py), not against librosa. */
+FD_API int fd_set_mel_filterbank(fd_handle h, const float *fb, int n_mels, int n_bins);
+FD_API int fd_get_mel_filterbank(fd_handle h, float *fb_out, int n_mels, int n_bins);
+
 /* Options (key = value; the first value is the default).  Each one selects between code paths that ship tested; measured-and-rejected
  * variants are not options (LABBOOK.md keeps their numbers).
  *   "gemm" | "lvc" | "conv" = "f16x2" | "fp32"   the predictor GEMM / the LVC layers / DBlocks + ConvTranspose + predictor front on the fp16

@@ -163,3 +163,112 @@ def test_device_front_end_matches_the_oracle():
     assert np.abs(m2[0] - mf.log_mel(cases["noise"][:8000].astype(np.float64))[:, :20]).max() < 2e-4
     with pytest.raises(Exception, match="fd_mel_spectrogram"):
         model.mel_spectrogram(two, n_frames=40)
+
+
+def _independent_mel_bank(sr, n_fft, n_mels, fmin, fmax):
+    """A second derivation of librosa.filters.mel(norm="slaney", htk=False) that shares no expression with oracle/mel_frontend.py or
+    the library's default_mel_bank: the band edges are found by INVERTING the forward scale numerically (bisection on hz -> mel, no
+    closed-form mel -> hz), each filter is the piecewise-linear hat through (f[m], 0), (f[m+1], 1), (f[m+2], 0) evaluated with
+    np.interp, and its height is fixed by the analytic unit-area condition of that hat (area = base / 2 -> height 2 / base)."""
+    def hz2mel(f):                                     # Slaney's scale as Auditory Toolbox defines it: 3 mel per 200 Hz up to 1 kHz,
+        return 3.0 * f / 200.0 if f < 1000.0 else 15.0 + 27.0 * np.log(f / 1000.0) / np.log(6.4)      # then 27 mel per factor 6.4
+
+    def mel2hz(m):
+        lo, hi = 0.0, 1.0e5
+        for _ in range(200):
+            mid = 0.5 * (lo + hi)
+            lo, hi = (mid, hi) if hz2mel(mid) < m else (lo, mid)
+        return 0.5 * (lo + hi)
+    m0, m1 = hz2mel(fmin), hz2mel(fmax)
+    edges = np.array([mel2hz(m0 + (m1 - m0) * i / (n_mels + 1)) for i in range(n_mels + 2)])
+    bins = np.arange(n_fft // 2 + 1) * (sr / n_fft)
+    fb = np.zeros((n_mels, len(bins)))
+    for m in range(n_mels):
+        hat = np.interp(bins, edges[m:m + 3], [0.0, 1.0, 0.0], left=0.0, right=0.0)
+        fb[m] = hat * (2.0 / (edges[m + 2] - edges[m]))
+    return fb
+
+
+def test_mel_filterbank_against_an_independent_derivation():
+    for args in ((22050, 1024, 80, 80.0, 7600.0), (22050, 1024, 80, 0.0, 8000.0), (22050, 2048, 128, 0.0, 11025.0)):
+        a, b = mf.mel_basis(*args), _independent_mel_bank(*args)
+        assert a.shape == b.shape
+        assert np.abs(a - b).max() <= 1e-12 * b.max() + 1e-15, args
+        assert (np.nonzero(a)[0] == np.nonzero(b)[0]).all() and (np.nonzero(a)[1] == np.nonzero(b)[1]).all()
+
+
+def test_mel_scale_and_filterbank_values_printed_in_librosas_documentation():
+    """The numbers librosa's own docstrings print (librosa 0.8 - 0.10: `mel_frequencies`, `hz_to_mel`, `mel_to_hz`, `filters.mel`),
+    quoted here as the only librosa-originated values available offline.  They pin the Slaney scale completely (40 band edges to
+    1e-3 Hz) and the filter normalisation to the digits the docstring shows."""
+    doc_mel_frequencies_40 = [0., 85.317, 170.635, 255.952, 341.269, 426.586, 511.904, 597.221, 682.538, 767.855, 853.173, 938.49,
+                              1024.856, 1119.114, 1222.042, 1334.436, 1457.167, 1591.187, 1737.532, 1897.337, 2071.84, 2262.393, 2470.47,
+                              2697.686, 2945.799, 3216.731, 3512.582, 3835.643, 4188.417, 4573.636, 4994.285, 5453.621, 5955.205, 6502.92,
+                              7101.009, 7754.107, 8467.272, 9246.028, 10096.408, 11025.]      # librosa.mel_frequencies(n_mels=40)
+    ours = mf.mel_to_hz(np.linspace(mf.hz_to_mel(0.0), mf.hz_to_mel(11025.0), 40))
+    assert np.abs(ours - np.array(doc_mel_frequencies_40)).max() < 5.1e-4
+    assert abs(float(mf.hz_to_mel(60.0)) - 0.9) < 1e-12                                    # librosa.hz_to_mel(60) -> 0.9
+    assert np.abs(mf.hz_to_mel([110.0, 220.0, 440.0]) - [1.65, 3.3, 6.6]).max() < 1e-12    # -> array([1.65, 3.3, 6.6])
+    assert abs(float(mf.mel_to_hz(3.0)) - 200.0) < 1e-12                                   # librosa.mel_to_hz(3) -> 200.
+    assert np.abs(mf.mel_to_hz([1, 2, 3, 4, 5]) - [66.667, 133.333, 200.0, 266.667, 333.333]).max() < 5.1e-4
+    # librosa.filters.mel(sr=22050, n_fft=2048) prints [[0., 0.016, ..., 0., 0.], ...]; with fmax=8000: [[0., 0.02, ..., 0., 0.], ...]
+    full, clipped = mf.mel_basis(22050, 2048, 128, 0.0, 11025.0), mf.mel_basis(22050, 2048, 128, 0.0, 8000.0)
+    assert full.shape == (128, 1025) and full[0, 0] == 0.0 and round(float(full[0, 1]), 3) == 0.016 and full[0, -1] == 0.0 and (full[-1, :2] == 0.0).all()
+    assert round(float(clipped[0, 1]), 2) == 0.02 and clipped[0, 0] == 0.0 and (clipped[:, -1] == 0.0).all()
+
+
+@pytest.mark.gpu
+def test_library_default_filter_banks_are_the_restated_ones_and_a_supplied_bank_is_used_bit_for_bit():
+    """fd_get / fd_set_mel_filterbank (include/fastdiff_hip.h; reference: data_gen_utils.py:122-134, tacotron/layers.py:42-60).  The default
+    banks are the oracle's restatement in float32; a bank handed in by the caller is what the kernel applies, value for value: with
+    two filter rows exchanged the output rows are exchanged and nothing else changes (torch.equal), scaled by a power of two the
+    linear mel scales by exactly that, and NULL restores the default."""
+    import fastdiff_amd
+    torch.manual_seed(1234)
+    model = fastdiff_amd.FastDiff().cuda().eval()
+    g = load_golden("frontend_lj001_0002")
+    wav = torch.from_numpy(g["pcm"].astype(np.float32) / 32768.0).cuda()
+    for variant, band in (("pwg", (80.0, 7600.0)), ("tacotron", (0.0, 8000.0))):
+        bank, user = model.mel_filterbank(variant)
+        ref = mf.mel_basis(fmin=band[0], fmax=band[1])
+        assert not user and bank.shape == (80, 513) and bank.dtype == np.float32
+        assert np.array_equal(bank != 0, ref != 0)
+        assert np.abs(bank.astype(np.float64) - ref).max() <= 6e-8 * ref.max()            # float32 rounding of the same numbers
+        assert np.abs(bank.astype(np.float64) - _independent_mel_bank(22050, 1024, 80, *band)).max() <= 6e-8 * ref.max()
+        base = model.mel_spectrogram(wav, variant=variant)
+        # (1) the same matrix handed back: identical output, and the library says whose it is
+        model.set_mel_filterbank(bank, variant)
+        got, user = model.mel_filterbank(variant)
+        assert user and np.array_equal(got, bank)
+        assert torch.equal(model.mel_spectrogram(wav, variant=variant), base)
+        # (2) rows 7 and 55 exchanged: the output rows are exchanged, every other value keeps its bits
+        perm = bank.copy()
+        perm[[7, 55]] = perm[[55, 7]]
+        model.set_mel_filterbank(perm, variant)
+        out = model.mel_spectrogram(wav, variant=variant)
+        idx = list(range(80)); idx[7], idx[55] = 55, 7
+        assert torch.equal(out, base[:, idx])
+        assert np.array_equal(model.mel_filterbank(variant)[0], perm)
+        # (3) every weight doubled: the mel doubles exactly, i.e. its log moves by log(2) in the front-end's own base
+        model.set_mel_filterbank(2.0 * bank, variant)
+        out2 = model.mel_spectrogram(wav, variant=variant).cpu().numpy().astype(np.float64)
+        b = base.cpu().numpy().astype(np.float64)
+        floor = -6.0 if variant == "pwg" else np.log(1e-5)
+        loud = b > floor + 1.0
+        step = np.log10(2.0) if variant == "pwg" else np.log(2.0)
+        assert np.abs(out2 - b - step)[loud].max() < 2e-6 * max(1.0, np.abs(b).max())
+        # (4) back to the default
+        model.set_mel_filterbank(None, variant)
+        assert not model.mel_filterbank(variant)[1]
+        assert torch.equal(model.mel_spectrogram(wav, variant=variant), base)
+    # the other front-end's bank was never touched by the calls on the first, and a malformed bank is refused
+    with pytest.raises(ValueError):
+        model.set_mel_filterbank(np.zeros((80, 512), np.float32))
+    bad = model.mel_filterbank("pwg")[0].copy()
+    bad[3, 40] = np.nan
+    with pytest.raises(AssertionError, match="not finite"):
+        model.set_mel_filterbank(bad)
+    # a supplied bank follows the module to a new handle
+    model.set_mel_filterbank(perm, "tacotron")
+    model._release()
+    assert model.mel_filterbank("tacotron")[1] and np.array_equal(model.mel_filterbank("tacotron")[0], perm)

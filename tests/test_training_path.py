@@ -158,3 +158,36 @@ def test_eval_mode_keeps_the_inference_kernels_and_train_mode_agrees_with_them()
     assert float((y_tr.detach() - y_inf).abs().max()) <= 2e-5            # the forward tolerance of the parity tests
     with torch.no_grad():
         assert m((x, mel, steps)).grad_fn is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [dict(upsample_ratios=[4, 4, 4], inner_channels=16), dict(upsample_ratios=[2, 4, 4]), dict(lvc_layers_each_block=3)])
+def test_training_path_of_a_non_reference_configuration_falls_back_and_matches_torch(cfg):
+    """the constructor accepts other `inner_channels` / `upsample_ratios` / `lvc_layers_each_block`; the frames pair and
+    the shared gradient slot exist for the model's own operator shape only (Cin 32, Cout 64, ks 3, hop 8 / 64 / 256).  Such a module
+    must train through the generic operators -- same loss and gradients as the same graph on torch ops in float64 on the CPU."""
+    import fastdiff_amd
+    from fastdiff_amd import train
+    from torch_eager import EagerFastDiff
+    torch.manual_seed(7)
+    m = fastdiff_amd.FastDiff(**cfg).train()
+    hop = int(np.prod(m._cfg["upsample_ratios"]))
+    B, T = 2, 6
+    x = torch.randn(B, 1, T * hop)
+    mel = torch.rand(B, 80, T) * 7.5 - 6.0
+    ts = torch.tensor([[437.0], [12.0]])
+    z = torch.randn(B, 1, T * hop)
+    ref = fastdiff_amd.FastDiff(**cfg)
+    ref.load_state_dict(m.state_dict(), strict=True)
+    ref = ref.double().train()
+    eps_ref = train.differentiable_forward(ref, (x.double(), mel.double(), ts.double()), lvc=lambda y, k, b, dil, h: EagerFastDiff.lvc(y, k, b, h))
+    torch.nn.functional.mse_loss(eps_ref, z.double()).backward()
+    g = m.cuda()
+    eps = g((x.cuda(), mel.cuda(), ts.cuda()))
+    assert eps.grad_fn is not None
+    torch.nn.functional.mse_loss(eps, z.cuda()).backward()
+    assert float((eps.detach().cpu().double() - eps_ref.detach()).abs().max()) <= 2e-5 * max(1.0, float(eps_ref.abs().max()))
+    for (n, p), (_, q) in zip(g.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None and q.grad is not None, n
+        scale = max(float(q.grad.abs().max()), 1e-9)
+        assert float((p.grad.cpu().double() - q.grad).abs().max()) <= 2e-4 * scale, (n, cfg)
