@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
-SOURCES = ["fd_api.cpp", "fd_kernels_naive.hip", "fd_kernels_first_final.hip", "fd_kernels_dblock.hip", "fd_kernels_kp.hip", "fd_kernels_convt.hip", "fd_kernels_lvc.hip", "fd_kernels_mel.hip", "fd_kernels_train.hip", "fd_kernels_kconv.hip", "fd_kernels_cconv.hip"]
+SOURCES = ["fd_api.cpp", "fd_kernels_naive.hip", "fd_generic.hip", "fd_kernels_first_final.hip", "fd_kernels_dblock.hip", "fd_kernels_kp.hip", "fd_kernels_convt.hip", "fd_kernels_lvc.hip", "fd_kernels_mel.hip", "fd_kernels_train.hip", "fd_kernels_kconv.hip", "fd_kernels_cconv.hip"]
 HEADERS = ["fd_internal.h", "fd_kernels.h", "fd_device.h", "fd_kernels_common.h", os.path.join("..", "..", "include", "fastdiff_hip.h")]
 LIB = os.path.join(LIBDIR, "libfastdiff_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

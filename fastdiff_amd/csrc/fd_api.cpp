@@ -94,28 +94,30 @@ struct ParamSpec { std::string name; std::vector<int64_t> dims; bool weight_norm
 
 static const int KP_RES_IDX[6] = {1, 3, 6, 8, 11, 13};
 
-static std::vector<ParamSpec> param_specs()
+// the state_dict of FastDiff(**cfg): names, shapes and registration facts (weight-normed Conv1d, plain ConvTranspose1d / Linear)
+static std::vector<ParamSpec> param_specs(const fd_config &c)
 {
-    using namespace fd;
+    const int64_t C = c.inner_channels, COND = c.cond_channels, HID = c.kpnet_hidden_channels, KS = c.lvc_kernel_size, KK = c.kpnet_conv_size;
+    const int64_t LAYERS = c.lvc_layers_each_block, E_IN = c.diffusion_step_embed_dim_in, E_MID = c.diffusion_step_embed_dim_mid, E_OUT = c.diffusion_step_embed_dim_out;
     std::vector<ParamSpec> s;
     s.push_back({"first_audio_conv", {C, 1, 7}, true, false, false});
     s.push_back({"fc_t1", {E_MID, E_IN}, false, false, true});
     s.push_back({"fc_t2", {E_OUT, E_MID}, false, false, true});
-    for (int n = 0; n < NBLK; ++n) {
+    for (int n = 0; n < c.n_upsample; ++n) {
         const std::string p = "lvc_blocks." + std::to_string(n);
-        s.push_back({p + ".upsample", {C, C, 2 * ratio(n)}, false, true, false});
+        s.push_back({p + ".upsample", {C, C, 2 * (int64_t)c.upsample_ratios[n]}, false, true, false});
         s.push_back({p + ".kernel_predictor.input_conv.0", {HID, COND, 5}, true, false, false});
         for (int j = 0; j < 6; ++j)
-            s.push_back({p + ".kernel_predictor.residual_conv." + std::to_string(KP_RES_IDX[j]), {HID, HID, 3}, true, false, false});
-        s.push_back({p + ".kernel_predictor.kernel_conv", {KW, HID, 3}, true, false, false});
-        s.push_back({p + ".kernel_predictor.bias_conv", {KB, HID, 3}, true, false, false});
+            s.push_back({p + ".kernel_predictor.residual_conv." + std::to_string(KP_RES_IDX[j]), {HID, HID, KK}, true, false, false});
+        s.push_back({p + ".kernel_predictor.kernel_conv", {LAYERS * C * 2 * C * KS, HID, KK}, true, false, false});
+        s.push_back({p + ".kernel_predictor.bias_conv", {LAYERS * 2 * C, HID, KK}, true, false, false});
         s.push_back({p + ".fc_t", {COND, E_OUT}, false, false, true});
-        for (int i = 0; i < LAYERS; ++i) s.push_back({p + ".convs." + std::to_string(i), {C, C, 3}, true, false, false});
+        for (int i = 0; i < LAYERS; ++i) s.push_back({p + ".convs." + std::to_string(i), {C, C, KS}, true, false, false});
         const std::string d = "downsample." + std::to_string(n);
         s.push_back({d + ".residual_dense", {C, C, 1}, true, false, false});
         for (int i = 0; i < 3; ++i) s.push_back({d + ".conv." + std::to_string(i), {C, C, 3}, true, false, false});
     }
-    s.push_back({"final_conv.0", {1, C, 7}, true, false, false});
+    s.push_back({"final_conv.0", {c.audio_channels, C, 7}, true, false, false});
     return s;
 }
 
@@ -155,17 +157,20 @@ int fd_create(const fd_config *cfg, int device, fd_handle *out)
     if (!cfg || !out) FD_FAIL(nullh, FD_ERR_INVALID, "fd_create: null argument");
     fd_config ref;
     fd_default_config(&ref);
-    if (cfg->audio_channels != ref.audio_channels || cfg->inner_channels != ref.inner_channels ||
-        cfg->cond_channels != ref.cond_channels || cfg->n_upsample != ref.n_upsample ||
-        cfg->upsample_ratios[0] != 8 || cfg->upsample_ratios[1] != 8 || cfg->upsample_ratios[2] != 4 ||
-        cfg->lvc_layers_each_block != ref.lvc_layers_each_block || cfg->lvc_kernel_size != ref.lvc_kernel_size ||
-        cfg->kpnet_hidden_channels != ref.kpnet_hidden_channels || cfg->kpnet_conv_size != ref.kpnet_conv_size ||
-        cfg->diffusion_step_embed_dim_in != ref.diffusion_step_embed_dim_in ||
-        cfg->diffusion_step_embed_dim_mid != ref.diffusion_step_embed_dim_mid ||
-        cfg->diffusion_step_embed_dim_out != ref.diffusion_step_embed_dim_out)
-        FD_FAIL(nullh, FD_ERR_UNSUPPORTED,
-                "fd_create: only the base.yaml architecture (inner 32, cond 80, ratios [8,8,4], 4 LVC layers k3, kpnet 64/k3, "
-                "embed 128/512/512) has gfx950 kernels");
+    // base.yaml's architecture (every shipped YAML) runs on the tuned gfx950 kernel set; any other configuration the reference
+    // constructor accepts (FastDiff_model.py:13-26) on the runtime-shaped kernels of fd_generic.hip
+    bool is_base = cfg->audio_channels == ref.audio_channels && cfg->inner_channels == ref.inner_channels &&
+                   cfg->cond_channels == ref.cond_channels && cfg->n_upsample == ref.n_upsample &&
+                   cfg->lvc_layers_each_block == ref.lvc_layers_each_block && cfg->lvc_kernel_size == ref.lvc_kernel_size &&
+                   cfg->kpnet_hidden_channels == ref.kpnet_hidden_channels && cfg->kpnet_conv_size == ref.kpnet_conv_size &&
+                   cfg->diffusion_step_embed_dim_in == ref.diffusion_step_embed_dim_in &&
+                   cfg->diffusion_step_embed_dim_mid == ref.diffusion_step_embed_dim_mid &&
+                   cfg->diffusion_step_embed_dim_out == ref.diffusion_step_embed_dim_out;
+    for (int i = 0; is_base && i < ref.n_upsample; ++i) is_base = cfg->upsample_ratios[i] == ref.upsample_ratios[i];
+    if (!is_base) {
+        std::string why;
+        if (fdg::validate(*cfg, why) != FD_OK) FD_FAIL(nullh, FD_ERR_UNSUPPORTED, "fd_create: %s", why.c_str());
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -199,6 +204,7 @@ int fd_create(const fd_config *cfg, int device, fd_handle *out)
         if ((e = hipHostMalloc(reinterpret_cast<void **>(&sl.host), 65536, hipHostMallocDefault)) != hipSuccess) return fail(e);
         sl.cap = 65536;
     }
+    if (!is_base) fdg::create(c);
     *out = c;
     return FD_OK;
 }
@@ -225,6 +231,7 @@ static void drop_graph(fd_context *c)
 // Frees everything a handle owns (each member is null until created): the tail of fd_destroy and the failure path of fd_create.
 static void release_handle(fd_context *h)
 {
+    fdg::destroy(h);
     if (h->flags_host) hipHostFree(h->flags_host);
     if (h->flags_done) hipEventDestroy(h->flags_done);
     if (h->flags_done2) hipEventDestroy(h->flags_done2);
@@ -265,7 +272,7 @@ int fd_set_weight(fd_handle h, const char *name, const float *host_data, const i
     if (!h || !name || !host_data || !dims || ndim <= 0 || ndim > 4) return FD_ERR_INVALID;
     const std::string key(name);
     // find the owning parameter and the expected shape of this tensor
-    static const std::vector<ParamSpec> specs = param_specs();
+    const std::vector<ParamSpec> specs = param_specs(h->cfg);
     std::vector<int64_t> expect;
     for (const auto &s : specs) {
         if (key.compare(0, s.name.size(), s.name) != 0 || key.size() <= s.name.size() || key[s.name.size()] != '.') continue;
@@ -293,7 +300,7 @@ int fd_set_weight(fd_handle h, const char *name, const float *host_data, const i
 
 namespace {
 
-struct Folded { std::vector<float> w, b; };
+typedef FoldedParam Folded;
 
 // w = v * (g / ||v||), norm over everything but dim 0 (torch._weight_norm(v, g, 0)); plain weights pass through
 int fold_param(fd_context *h, const ParamSpec &s, Folded &out)
@@ -434,9 +441,14 @@ int fd_commit_weights(fd_handle h)
     drop_graph(h);
 
     std::map<std::string, Folded> f;
-    for (const auto &s : param_specs()) {
+    for (const auto &s : param_specs(h->cfg)) {
         int rc = fold_param(h, s, f[s.name]);
         if (rc != FD_OK) return rc;
+    }
+    if (h->gen) {      // another architecture than base.yaml's: folded reference-layout weights, no operand packing
+        const int rcg = fdg::commit(h, f);
+        if (rcg == FD_OK) h->committed = true;
+        return rcg;
     }
     DevWeights &w = h->w;
     int rc;
@@ -838,7 +850,7 @@ static int check_common(fd_handle h, int B, int T, const char *who)
     if (!h) return FD_ERR_INVALID;
     if (!h->committed) FD_FAIL(h, FD_ERR_STATE, "%s: weights not committed (call fd_commit_weights after fd_set_weight)", who);
     if (B <= 0 || T <= 0) FD_FAIL(h, FD_ERR_INVALID, "%s: B=%d T=%d must be positive", who, B, T);
-    if ((int64_t)B * T * fd::HOPT * fd::C >= (int64_t)1 << 31)
+    if ((int64_t)B * T * fdg::hop_total(h) * (h->gen ? h->cfg.inner_channels : fd::C) >= (int64_t)1 << 31)
         FD_FAIL(h, FD_ERR_INVALID, "%s: B*T too large for one call (B=%d, T=%d); split the batch", who, B, T);
     FD_HIP(h, hipSetDevice(h->device));
     return FD_OK;
@@ -926,6 +938,11 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
     h->embed_valid = false;                      // fd_forward writes its own rows into the same table
     if (!x || !mel || !steps || !eps_out) FD_FAIL(h, FD_ERR_INVALID, "fd_forward: null pointer");
     if (x == eps_out) FD_FAIL(h, FD_ERR_INVALID, "fd_forward: eps_out must not alias x");
+    if (h->gen) {      // (lens is ignored: the padded batch is computed as the reference computes it)
+        if ((rc = fdg::forward(h, x, mel, steps, B, T, eps_out, (hipStream_t)stream)) != FD_OK) return rc;
+        h->last_B = B; h->last_T = T;
+        return mark_tail(h, (hipStream_t)stream);
+    }
     if ((rc = ensure_workspace(h, B, T)) != FD_OK) return rc;
     if (lens) {
         fd_context::StageSlot *sl = nullptr;
@@ -1248,6 +1265,15 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
     int rc = check_common(h, B, T, "fd_sample");
     if (rc != FD_OK) return rc;
     if ((rc = follow_stream(h, (hipStream_t)stream_)) != FD_OK) return rc;
+    if (h->gen) {      // a configuration other than base.yaml's: exact-fp32 kernels, nothing provisional, no graph
+        if (!mel || !table || !out) FD_FAIL(h, FD_ERR_INVALID, "fd_sample: null pointer");
+        if (N <= 0 || N > 1024) FD_FAIL(h, FD_ERR_INVALID, "fd_sample: N=%d outside 1..1024", N);
+        if (!ids.empty() && (int)ids.size() != B) FD_FAIL(h, FD_ERR_INVALID, "fd_sample: fd_set_noise_streams gave %d stream ids but B=%d", (int)ids.size(), B);
+        if ((rc = fdg::sample(h, mel, B, T, table, N, ddim, x_T, z, seed, ids, out, seq_out, (hipStream_t)stream_)) != FD_OK) return rc;
+        ++h->ticket_counter;
+        h->last_B = B; h->last_T = T;
+        return mark_tail(h, (hipStream_t)stream_);
+    }
     // A lazily checked previous call (fallback = host, <= 8 steps) is looked at AFTER this call has enqueued its own work -- unless
     // this call cannot be lazy itself, or the workspace must grow first (that waits for the device anyway).
     const bool lazy = h->host_fallback && N >= 1 && N <= 8;
@@ -2212,6 +2238,7 @@ int64_t fd_read_tap(fd_handle h, const char *name, float *host_dst, int64_t capa
         const int rcs = settle(h);
         if (rcs != FD_OK) return rcs;
     }
+    if (h->gen) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_read_tap: intermediates are kept by the tuned kernel set only (base.yaml's architecture)");
     const int B = h->last_B, T = h->last_T;
     if (B == 0) FD_FAIL(h, FD_ERR_STATE, "fd_read_tap: no forward has run yet");
     const Workspace &w = h->ws;

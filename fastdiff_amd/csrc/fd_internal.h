@@ -151,8 +151,25 @@ struct MelTables {
 };
 enum MelVariant { MEL_PWG = 0, MEL_TACOTRON = 1, MEL_VARIANTS = 2 };
 
+// A parameter as fd_commit_weights folds it (weight-norm applied, reference layout) and the configuration-generic path that takes them
+// (fd_generic.hip: any architecture the reference constructor accepts, on runtime-shaped kernels; gen == nullptr for base.yaml's
+// architecture, which runs on the tuned kernel set).
+struct FoldedParam { std::vector<float> w, b; };
+namespace fdg {
+struct Net;
+int validate(const fd_config &c, std::string &why);
+int create(fd_context *c);
+void destroy(fd_context *c);
+int hop_total(const fd_context *c);
+int commit(fd_context *c, const std::map<std::string, FoldedParam> &f);
+int forward(fd_context *c, const float *x, const float *mel, const float *steps, int B, int T, float *eps_out, hipStream_t stream);
+int sample(fd_context *c, const float *mel, int B, int T, const fd_step *table, int N, int ddim, const float *x_T, const float *z,
+           unsigned long long seed, const std::vector<unsigned long long> &ids, float *out, float *seq_out, hipStream_t stream);
+}  // namespace fdg
+
 struct fd_context {
     fd_config cfg;
+    fdg::Net *gen = nullptr;                  // set for a configuration other than base.yaml's: every compute call goes to fd_generic.hip
     int device = 0;
     int num_cus = 256;
     std::string err;

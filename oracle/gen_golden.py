@@ -651,6 +651,65 @@ def gen_test_step(dh):
     np.savez_compressed(os.path.join(GOLD, "test_step.npz"), **out)
 
 
+# Configurations other than base.yaml's that the reference constructor accepts (FastDiff_model.py:13-26): the product runs them on
+# its runtime-shaped kernels (fastdiff_amd/csrc/fd_generic.hip); these fixtures are the reference's own outputs for them.
+OTHER_CFGS = {
+    "cfgA": dict(inner_channels=16, upsample_ratios=[4, 4, 4]),
+    "cfgB": dict(inner_channels=8, cond_channels=40, upsample_ratios=[2, 5, 3], lvc_layers_each_block=3, lvc_kernel_size=5,
+                 kpnet_hidden_channels=32, kpnet_conv_size=5, diffusion_step_embed_dim_in=64, diffusion_step_embed_dim_mid=256,
+                 diffusion_step_embed_dim_out=128),
+    "cfgC": dict(upsample_ratios=[16, 16], lvc_layers_each_block=2, kpnet_hidden_channels=48),
+}
+
+
+def gen_forward_cfg(dh):
+    """Per configuration: one forward (B = 2, fractional steps) and one N = 4 reverse loop with replayed noise, float32 and float64,
+    on FastDiff(**cfg) with the hash weights of synth.synth_state_dict(seed, cfg)."""
+    import json
+    for ci, (name, cfg) in enumerate(OTHER_CFGS.items()):
+        full = synth.full_cfg(cfg)
+        hop = int(np.prod(full["upsample_ratios"]))
+        sd = {k: torch.from_numpy(v.copy()) for k, v in synth.synth_state_dict(SEED + 7, cfg).items()}
+        models = {}
+        for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            m = FastDiff(**cfg).eval()
+            missing, unexpected = m.load_state_dict(sd, strict=True)
+            assert not missing and not unexpected
+            models[tag] = m.to(dt)
+        B, T, N = 2, 5, 4
+        mel = synth.synth_mel(SEED + 300 + ci, B, T, cond=full["cond_channels"])
+        audio = synth.synth_audio(SEED + 300 + ci, B, T, hop=hop)
+        st = torch.tensor([7.413235306739807, 498.05368650332093], dtype=torch.float32).view(B, 1)
+        out = {"cfg": np.array(json.dumps(cfg)), "seed": np.int64(SEED + 7), "mel": mel, "audio": audio, "steps": st.numpy(), "hop": np.int64(hop)}
+        with torch.no_grad():
+            out["y_f32"] = models["f32"]((torch.from_numpy(audio), torch.from_numpy(mel), st)).numpy()
+            out["y_f64"] = models["f64"]((torch.from_numpy(audio).double(), torch.from_numpy(mel).double(), st.double())).numpy()
+        n_el = B * T * hop
+        x_T = synth.hash_normal(SEED + 300 + ci, 1, n_el).reshape(B, 1, T * hop)
+        z = np.zeros((N, B, 1, T * hop), np.float32)
+        for n in range(1, N):
+            z[n] = synth.hash_normal(SEED + 300 + ci, 2 + n, n_el).reshape(B, 1, T * hop)
+        noises = [x_T] + [z[n] for n in range(N - 1, 0, -1)]
+        out["x_T"], out["z"] = x_T, z          # z[n] is added after step n (n > 0)
+        for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            model = models[tag]
+            it = iter(noises)
+            orig = ref_util.std_normal
+            ref_util.std_normal = lambda size: torch.from_numpy(next(it).copy()).to(dt).view(*size).clone()
+            net = model if dt == torch.float32 else (lambda data: model((data[0], data[1], data[2].double())))
+            try:
+                stdout, sys.stdout = sys.stdout, open(os.devnull, "w")
+                res = ref_util.sampling_given_noise_schedule(net, (B, 1, T * hop), {k: dh[k] for k in ("T", "alpha", "beta", "sigma")}, schedule_tensor(N),
+                                                             condition=torch.from_numpy(mel).to(dt), ddim=False, return_sequence=True)
+            finally:
+                sys.stdout = stdout
+                ref_util.std_normal = orig
+            out[f"seq_{tag}"] = np.stack([r.numpy() for r in res])
+        np.savez_compressed(os.path.join(GOLD, f"forward_{name}.npz"), **out)
+        print(name, cfg, "hop", hop, "max|y|", float(np.abs(out["y_f32"]).max()), "f32-vs-f64 forward", float(np.abs(out["y_f32"] - out["y_f64"]).max()),
+              "loop", float(np.abs(out["seq_f32"] - out["seq_f64"]).max()))
+
+
 def gen_statedict_manifest():
     """Key set + shapes of the reference module's state_dict, and a default-init digest, for the drop-in shim test."""
     torch.manual_seed(SEED)
@@ -667,7 +726,7 @@ def gen_statedict_manifest():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["schedule", "embed", "ops", "forward", "sample", "manifest", "collate", "collater", "frontend", "frontend_tacotron",
-                             "frontend_pwg", "noise_scheduling", "theta_loss", "phi_loss", "theta_grad", "lvc_grad", "test_step"]
+                             "frontend_pwg", "noise_scheduling", "theta_loss", "phi_loss", "theta_grad", "lvc_grad", "test_step", "forward_cfg"]
     dh = gen_schedule()
     if "embed" in which:
         gen_embed()
@@ -702,6 +761,8 @@ if __name__ == "__main__":
         gen_noise_scheduling(dh)
     if "test_step" in which:
         gen_test_step(dh)
+    if "forward_cfg" in which:
+        gen_forward_cfg(dh)
     if "frontend_tacotron" in which:
         gen_frontend_tacotron()
     print("golden fixtures written to", GOLD)

@@ -22,21 +22,27 @@ class _Cfg(ct.Structure):
                 ("embed_mid", ct.c_int), ("embed_out", ct.c_int)]
 
 
-def _default_cfg():
+def _cfg_struct(cfg=None):
+    """fdo_config of the reference constructor's arguments (FastDiff_model.py:13-26); cfg: those that differ from base.yaml's."""
+    d = _synth.full_cfg(cfg)
+    assert d["audio_channels"] == 1 and 1 <= len(d["upsample_ratios"]) <= 8
     c = _Cfg()
-    c.inner_channels, c.cond_channels, c.n_blocks = _synth.C, _synth.COND, 3
-    for i, r in enumerate(_synth.RATIOS):
+    c.inner_channels, c.cond_channels, c.n_blocks = d["inner_channels"], d["cond_channels"], len(d["upsample_ratios"])
+    for i, r in enumerate(d["upsample_ratios"]):
         c.ratios[i] = r
-    c.lvc_layers, c.lvc_kernel_size, c.kp_hidden, c.kp_conv_size = _synth.LAYERS, _synth.KS, _synth.HID, 3
-    c.embed_in, c.embed_mid, c.embed_out = _synth.E_IN, _synth.E_MID, _synth.E_OUT
+    c.lvc_layers, c.lvc_kernel_size, c.kp_hidden, c.kp_conv_size = (d["lvc_layers_each_block"], d["lvc_kernel_size"],
+                                                                    d["kpnet_hidden_channels"], d["kpnet_conv_size"])
+    c.embed_in, c.embed_mid, c.embed_out = d["diffusion_step_embed_dim_in"], d["diffusion_step_embed_dim_mid"], d["diffusion_step_embed_dim_out"]
     return c
 
 
-def canonical_weights(sd: dict, dtype) -> list:
+def canonical_weights(sd: dict, dtype, cfg=None) -> list:
     """Reference-named state_dict (numpy) -> folded weights in fdo_forward's canonical order.
 
     The weight-norm fold w = v * (g/||v||) is evaluated in `dtype` (the reference folds in the model dtype)."""
     dtype = np.dtype(dtype)
+    d = _synth.full_cfg(cfg)
+    n_blocks, layers = len(d["upsample_ratios"]), d["lvc_layers_each_block"]
 
     def wb(name):
         if name + ".weight_v" in sd:
@@ -49,17 +55,17 @@ def canonical_weights(sd: dict, dtype) -> list:
         return [np.ascontiguousarray(w, dtype=dtype), np.ascontiguousarray(np.asarray(sd[name + ".bias"]), dtype=dtype)]
 
     out = wb("first_audio_conv") + wb("fc_t1") + wb("fc_t2")
-    for d in range(3):
-        out += wb(f"downsample.{d}.residual_dense")
+    for dd in range(n_blocks):
+        out += wb(f"downsample.{dd}.residual_dense")
         for i in range(3):
-            out += wb(f"downsample.{d}.conv.{i}")
-    for n in range(3):
+            out += wb(f"downsample.{dd}.conv.{i}")
+    for n in range(n_blocks):
         p = f"lvc_blocks.{n}"
         out += wb(f"{p}.fc_t") + wb(f"{p}.upsample") + wb(f"{p}.kernel_predictor.input_conv.0")
         for j in _synth.KP_RES_IDX:
             out += wb(f"{p}.kernel_predictor.residual_conv.{j}")
         out += wb(f"{p}.kernel_predictor.kernel_conv") + wb(f"{p}.kernel_predictor.bias_conv")
-        for i in range(_synth.LAYERS):
+        for i in range(layers):
             out += wb(f"{p}.convs.{i}")
     out += wb("final_conv.0")
     return out
@@ -68,16 +74,20 @@ def canonical_weights(sd: dict, dtype) -> list:
 class Oracle:
     """precision: 'f64' (truth) or 'f32' (rounds like the reference's fp32 path, no FMA contraction)."""
 
-    def __init__(self, precision: str = "f64"):
+    def __init__(self, precision: str = "f64", cfg=None):
+        """cfg: the reference constructor's arguments that differ from base.yaml's (FastDiff_model.py:13-26); None = the default model."""
         libs = _build.build()
         self.lib = ct.CDLL(libs[precision])
         self.dtype = np.dtype(np.float64 if precision == "f64" else np.float32)
         assert self.lib.fdo_real_bytes() == self.dtype.itemsize
-        self.cfg = _default_cfg()
+        self.cfg_dict = _synth.full_cfg(cfg)
+        self.is_default = self.cfg_dict == _synth.full_cfg(None)
+        self.cfg = _cfg_struct(cfg)
+        self.hop = int(np.prod(self.cfg_dict["upsample_ratios"]))
         self.lib.fdo_map_noise_scale_to_time_step.restype = ct.c_double
         self._w = None
         self._wptr = None
-        self.table = self.embed_table()
+        self.table = self.embed_table(self.cfg_dict["diffusion_step_embed_dim_in"] // 2)
 
     def set_threads(self, n):
         """OpenMP threads used by the oracle; returns the count in effect."""
@@ -98,7 +108,7 @@ class Oracle:
         return arr
 
     def set_weights(self, sd: dict):
-        self._w = canonical_weights(sd, self.dtype)
+        self._w = canonical_weights(sd, self.dtype, self.cfg_dict)
         assert len(self._w) == self.lib.fdo_num_weights(ct.byref(self.cfg))
         self._wptr = self._ptr_array(self._w)
 
@@ -162,11 +172,12 @@ class Oracle:
         assert self._wptr is not None, "set_weights first"
         audio = self._a(audio); mel = self._a(mel); steps = self._a(steps).reshape(-1)
         B, _, T = mel.shape
-        L = T * 256
-        assert audio.shape == (B, 1, L)
+        L = T * self.hop
+        assert audio.shape == (B, 1, L) and mel.shape[1] == self.cfg_dict["cond_channels"]
         out = np.empty((B, 1, L), self.dtype)
         tap_arrays, tap_ptr = None, None
         if taps:
+            assert self.is_default, "taps are laid out for the default architecture"
             C = _synth.C
             lens = [L, L // 4, L // 32, T]
             tap_arrays = [np.empty((B, _synth.E_OUT), self.dtype)]

@@ -19,26 +19,44 @@ L_B = 2 * C * LAYERS            # 256
 KP_RES_IDX = (1, 3, 6, 8, 11, 13)   # Conv1d positions inside KernelPredictor.residual_conv (modules.py:298-313)
 
 
-def param_spec():
-    """[(name, shape, kind)] in reference state_dict naming; kind: 'wn' (weight-normed Conv1d -> _g/_v), 'plain'."""
-    spec = [("first_audio_conv", (C, 1, 7), "wn"),
-            ("fc_t1", (E_MID, E_IN), "plain"), ("fc_t2", (E_OUT, E_MID), "plain")]
-    for n, r in enumerate(RATIOS):
+DEFAULT_CFG = dict(audio_channels=1, inner_channels=C, cond_channels=COND, upsample_ratios=list(RATIOS), lvc_layers_each_block=LAYERS,
+                   lvc_kernel_size=KS, kpnet_hidden_channels=HID, kpnet_conv_size=3, diffusion_step_embed_dim_in=E_IN,
+                   diffusion_step_embed_dim_mid=E_MID, diffusion_step_embed_dim_out=E_OUT)
+
+
+def full_cfg(cfg=None) -> dict:
+    """The reference constructor's keyword arguments (FastDiff_model.py:13-26) with base.yaml's values for what `cfg` leaves out."""
+    out = dict(DEFAULT_CFG)
+    out.update(cfg or {})
+    out["upsample_ratios"] = [int(r) for r in out["upsample_ratios"]]
+    return out
+
+
+def param_spec(cfg=None):
+    """[(name, shape, kind)] in reference state_dict naming; kind: 'wn' (weight-normed Conv1d -> _g/_v), 'plain'.
+    cfg: constructor arguments that differ from base.yaml's (None = the default architecture, in the order the fixtures were made with)."""
+    c = full_cfg(cfg)
+    ch, cond, hid, layers, ks, kk = (c["inner_channels"], c["cond_channels"], c["kpnet_hidden_channels"], c["lvc_layers_each_block"],
+                                     c["lvc_kernel_size"], c["kpnet_conv_size"])
+    e_in, e_mid, e_out = c["diffusion_step_embed_dim_in"], c["diffusion_step_embed_dim_mid"], c["diffusion_step_embed_dim_out"]
+    spec = [("first_audio_conv", (ch, 1, 7), "wn"),
+            ("fc_t1", (e_mid, e_in), "plain"), ("fc_t2", (e_out, e_mid), "plain")]
+    for n, r in enumerate(c["upsample_ratios"]):
         p = f"lvc_blocks.{n}"
-        spec.append((f"{p}.upsample", (C, C, 2 * r), "plain"))
-        spec.append((f"{p}.kernel_predictor.input_conv.0", (HID, COND, 5), "wn"))
+        spec.append((f"{p}.upsample", (ch, ch, 2 * r), "plain"))
+        spec.append((f"{p}.kernel_predictor.input_conv.0", (hid, cond, 5), "wn"))
         for j in KP_RES_IDX:
-            spec.append((f"{p}.kernel_predictor.residual_conv.{j}", (HID, HID, 3), "wn"))
-        spec.append((f"{p}.kernel_predictor.kernel_conv", (L_W, HID, 3), "wn"))
-        spec.append((f"{p}.kernel_predictor.bias_conv", (L_B, HID, 3), "wn"))
-        spec.append((f"{p}.fc_t", (COND, E_OUT), "plain"))
-        for i in range(LAYERS):
-            spec.append((f"{p}.convs.{i}", (C, C, 3), "wn"))
+            spec.append((f"{p}.kernel_predictor.residual_conv.{j}", (hid, hid, kk), "wn"))
+        spec.append((f"{p}.kernel_predictor.kernel_conv", (ch * 2 * ch * ks * layers, hid, kk), "wn"))
+        spec.append((f"{p}.kernel_predictor.bias_conv", (2 * ch * layers, hid, kk), "wn"))
+        spec.append((f"{p}.fc_t", (cond, e_out), "plain"))
+        for i in range(layers):
+            spec.append((f"{p}.convs.{i}", (ch, ch, ks), "wn"))
         d = f"downsample.{n}"
-        spec.append((f"{d}.residual_dense", (C, C, 1), "wn"))
+        spec.append((f"{d}.residual_dense", (ch, ch, 1), "wn"))
         for i in range(3):
-            spec.append((f"{d}.conv.{i}", (C, C, 3), "wn"))
-    spec.append(("final_conv.0", (1, C, 7), "wn"))
+            spec.append((f"{d}.conv.{i}", (ch, ch, 3), "wn"))
+    spec.append(("final_conv.0", (c["audio_channels"], ch, 7), "wn"))
     return spec
 
 
@@ -71,10 +89,11 @@ def hash_normal(seed: int, stream: int, n: int) -> np.ndarray:
     return (acc - 6.0).astype(np.float32)
 
 
-def synth_state_dict(seed: int = 1234) -> dict:
-    """Reference-named float32 state_dict: weight_v/weight_g/bias for weight-normed convs, weight/bias otherwise."""
+def synth_state_dict(seed: int = 1234, cfg=None) -> dict:
+    """Reference-named float32 state_dict: weight_v/weight_g/bias for weight-normed convs, weight/bias otherwise.
+    cfg: see param_spec (another architecture gets its own shapes from the same hash streams)."""
     sd = {}
-    for stream, (name, shape, kind) in enumerate(param_spec()):
+    for stream, (name, shape, kind) in enumerate(param_spec(cfg)):
         n = int(np.prod(shape))
         if name.endswith(".upsample"):
             fan_in = shape[1] * shape[2]     # ConvTranspose1d: torch computes fan_in from dim 1
@@ -95,14 +114,14 @@ def synth_state_dict(seed: int = 1234) -> dict:
     return sd
 
 
-def synth_mel(seed: int, B: int, T: int, lo: float = -6.0, hi: float = 1.5) -> np.ndarray:
-    """Uniform on [mel_vmin, mel_vmax] (base.yaml:15-16), shape [B,80,T]."""
-    u = hash_uniform(seed, 900001, B * COND * T) * np.float32(0.5) + np.float32(0.5)
-    return (u * np.float32(hi - lo) + np.float32(lo)).reshape(B, COND, T).astype(np.float32)
+def synth_mel(seed: int, B: int, T: int, lo: float = -6.0, hi: float = 1.5, cond: int = COND) -> np.ndarray:
+    """Uniform on [mel_vmin, mel_vmax] (base.yaml:15-16), shape [B,80,T] (cond: another cond_channels)."""
+    u = hash_uniform(seed, 900001, B * cond * T) * np.float32(0.5) + np.float32(0.5)
+    return (u * np.float32(hi - lo) + np.float32(lo)).reshape(B, cond, T).astype(np.float32)
 
 
-def synth_audio(seed: int, B: int, T: int, stream: int = 900002) -> np.ndarray:
-    return hash_normal(seed, stream, B * T * 256).reshape(B, 1, T * 256)
+def synth_audio(seed: int, B: int, T: int, stream: int = 900002, hop: int = 256) -> np.ndarray:
+    return hash_normal(seed, stream, B * T * hop).reshape(B, 1, T * hop)
 
 
 def stub_noise_pred_batch(x, cond):

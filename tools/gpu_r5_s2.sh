@@ -27,4 +27,5 @@ echo "== 8 ranks sharing this GPU: config4 (sharded job, bit-equality against th
 FD_BENCH_OVERSUBSCRIBE=1 timeout 900 python bench.py --gpus 8 --workload config4 --steps 3 --warmup 1 > $O/bench_config4_8ranks_1gpu.log 2>&1; echo "rc=$?"; grep '^{' $O/bench_config4_8ranks_1gpu.log | cut -c1-1800; grep -i "error\|Traceback" $O/bench_config4_8ranks_1gpu.log | head -5
 echo "== 8 ranks sharing this GPU: configs1"
 FD_BENCH_OVERSUBSCRIBE=1 timeout 900 python bench.py --gpus 8 --steps 3 --warmup 1 > $O/bench_configs1_8ranks_1gpu.log 2>&1; echo "rc=$?"; grep '^{' $O/bench_configs1_8ranks_1gpu.log | cut -c1-900; grep -i "error\|Traceback" $O/bench_configs1_8ranks_1gpu.log | head -5
-echo "== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -8 $O/pytest_gpu.log
+echo "== pytest gpu: the new tests first, verbosely"; timeout 900 python -m pytest tests/test_generic_config.py tests/test_mel_frontend.py tests/test_training_path.py tests/test_c_host.py -m gpu -q -s -p no:cacheprovider > $O/pytest_new.log 2>&1; echo "rc=$?"; grep -v "Warning\|warn\|WeightNorm" $O/pytest_new.log | tail -25
+echo "== pytest gpu (all)"; timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -8 $O/pytest_gpu.log
