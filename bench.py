@@ -341,7 +341,7 @@ def _oracle_table(rows):
             "c3": [r["c3"] for r in ex]}
 
 
-PORT_VS_REFERENCE = "the port takes 0.86x (8 threads) / 0.85x (1 thread) of the reference's own time on one CPU, outputs 4e-6 apart (profiles/r04_ref_vs_port_cpu.json)"
+PORT_VS_REFERENCE = "port = 0.86x / 0.85x (8 / 1 threads) of the reference's own time, outputs 4e-6 apart (profiles/r04_ref_vs_port_cpu.json)"
 
 
 def cpu_baseline(T, rows):

@@ -12,23 +12,32 @@ There is no CPU path: CPU tensors raise.
 """
 import ctypes as ct
 
+import threading
+
 import torch
 
 from . import _capi
 
 _handles = {}
+_handles_lock = threading.Lock()
 
 
 def _handle(device):
-    """One library handle per device: the operator is stateless, the handle supplies the device and the error text."""
+    """One library handle per device: it supplies the device, the error text and the scratch buffers the backward kernels sum their
+    partial results in (grown with hipFree + hipMalloc on first use of a larger shape).  Consequence, as for any handle of the library:
+    the operators of this module must be ordered on ONE stream per device -- what torch.autograd does for a forward and its backward --
+    and their first call at a new shape must not sit inside a graph capture (warm up before capturing).  Two models
+    training concurrently on one device from different threads or streams need a process each."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if idx not in _handles:
-        lib = _capi.load()
-        cfg = _capi.FdConfig()
-        lib.fd_default_config(ct.byref(cfg))
-        h = ct.c_void_p()
-        _capi.check(lib, None, lib.fd_create(ct.byref(cfg), idx, ct.byref(h)), "fd_create")
-        _handles[idx] = h
+        with _handles_lock:
+            if idx not in _handles:
+                lib = _capi.load()
+                cfg = _capi.FdConfig()
+                lib.fd_default_config(ct.byref(cfg))
+                h = ct.c_void_p()
+                _capi.check(lib, None, lib.fd_create(ct.byref(cfg), idx, ct.byref(h)), "fd_create")
+                _handles[idx] = h
     return _capi.load(), _handles[idx]
 
 
@@ -898,7 +907,12 @@ def kernel_conv1d_frames(x, weight, bias):
 class _LVCFrames(torch.autograd.Function):
     """The location-variable convolution on one layer's frames: kernel [B, T, 6144] = frames[:, i] of kernel_conv1d_frames and bias
     [B, 64, T] = bias_conv's output [:, i] (both batch-strided, used where they lie); their gradients are written into the layer's
-    slices of the shared buffers of split_layers (grad_slot, bias_slot)."""
+    slices of the shared buffers of split_layers (grad_slot, bias_slot).
+    INVARIANT of the frames pair: the gradient this node returns for `kernel` is in the operator's GRADIENT element order, not the
+    forward tensor's, and _KConvFrames.backward (fd_kconv_backward_frames) is its only legal consumer -- the frames tensor is an
+    internal edge between kernel_conv1d_frames and this node, created and consumed inside train._kernel_predictor / _lvc_block.  Do not
+    attach hooks, retain_grad or a second reader to it, and do not ask torch.autograd.grad for it: take
+    lvc_op.frames_to_reference(frames) (a real tensor in the reference's layout, with an ordinary gradient) for anything of that kind."""
 
     @staticmethod
     def forward(ctx, x, kernel, bias, hop_size, grad_slot, bias_slot):

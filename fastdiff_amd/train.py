@@ -23,6 +23,8 @@ pieces back to their predecessor (A/B runs: tools/train_step_probe.py).
 `lvc` (tests only): a replacement for the HIP operator with the same signature, so that the structure around it can be pinned on
 the reference's gradients on a machine without a GPU; the product never passes it.
 """
+import threading
+
 import torch
 import torch.nn.functional as F
 
@@ -33,14 +35,23 @@ def _swish(x):
     return x * torch.sigmoid(x)
 
 
-_WN = {}      # id(module) -> its effective weight for the forward being recorded (differentiable_forward: all of them from ONE operator)
+class _ForwardWeights(threading.local):
+    """conv module -> its effective weight for the forward being recorded (differentiable_forward: all of them from ONE operator).
+    Per thread, and keyed on the module OBJECT (held alive by the key): forwards recorded concurrently by replicas in other threads
+    neither see nor clear each other's entries, and a recycled id() can never hand out another module's weight."""
+
+    def __init__(self):
+        self.map = {}
+
+
+_WN = _ForwardWeights()
 
 
 def _conv_weight(m):
     """The effective weight of a conv module: g * v / ||v|| while weight-norm is attached (what its forward hook computes: on HIP
     tensors one operator for all convolutions of the module, lvc_op.weight_norm_all, else one launch of lvc_op.weight_norm each way per
     convolution), the plain weight after remove_weight_norm()."""
-    w = _WN.get(id(m))
+    w = _WN.map.get(m)
     if w is not None:
         return w
     if hasattr(m, "weight_g"):
@@ -223,21 +234,24 @@ def differentiable_forward(module, data, lvc=None):
             frames = (kernel_conv1d_frames, location_variable_convolution_frames, kernel_conv_frames_supported)
     audio, c, diffusion_steps = data
     cfg = module._cfg
-    _WN.clear()
+    _WN.map.clear()
     if cconv is not None and audio.is_cuda and getattr(module, "_train_wn_all", True):      # (False: one operator per convolution, for A/B runs)
         from .lvc_op import weight_norm_all
-        cands = module.__dict__.get("_wn_candidates")      # (the module tree does not change between steps: walk it once)
-        if cands is None:
-            cands = module.__dict__["_wn_candidates"] = [m for m in module.modules() if isinstance(m, torch.nn.Conv1d)]
+        n_mod = sum(1 for _ in module.modules())          # (the walk is cached while the module tree keeps its size: a convolution that
+        cached = module.__dict__.get("_wn_candidates")    # is added or replaced later is picked up on the next step)
+        if cached is None or cached[0] != n_mod or any(a is not b for a, b in zip(cached[2], module.modules())):
+            mods_now = list(module.modules())
+            cached = module.__dict__["_wn_candidates"] = (n_mod, [m for m in mods_now if isinstance(m, torch.nn.Conv1d)], mods_now)
+        cands = cached[1]
         mods = [m for m in cands if hasattr(m, "weight_g") and m.weight_v.is_cuda and
                 m.weight_v.dtype == torch.float32 and m.weight_g.dtype == torch.float32 and m.weight_g.numel() == m.weight_v.shape[0]]
         if mods:
             for m, w in zip(mods, weight_norm_all([(m.weight_v, m.weight_g) for m in mods])):
-                _WN[id(m)] = w
+                _WN.map[m] = w
     try:
         return _forward_body(module, audio, c, diffusion_steps, cfg, lvc, gate, kconv, cconv, split, frames)
     finally:
-        _WN.clear()
+        _WN.map.clear()
 
 
 def _forward_body(module, audio, c, diffusion_steps, cfg, lvc, gate, kconv, cconv, split, frames):
