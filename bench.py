@@ -364,9 +364,23 @@ def cpu_baseline(T, rows):
     x_t = torch.from_numpy(synth.hash_normal(1, 1, T * HOP).reshape(1, 1, T * HOP))
     by_threads = {}
     try:
+        skipped = {}
         for th in sorted({cores, min(cores, 32), 1}, reverse=True):
             torch.set_num_threads(th)
             reps = 3 if th > 1 else 2      # (one thread: ~10 s per run; best of 2 keeps the default bench inside its minutes)
+            if th > 32:
+                # On the pool's 256-core hosts torch's OpenMP team of all cores costs ~150 ms per small op (the run took 223 s, RTF 0.045:
+                # profiles/r05/s2_*): probe one small convolution first and leave the leg out -- with the probe's figure -- when it is that
+                # slow, so that the default bench stays inside its minutes.  The 32-thread leg is the CPU's best case either way.
+                xp, wp = torch.randn(1, 32, 4096), torch.randn(32, 32, 3)
+                torch.nn.functional.conv1d(xp, wp, padding=1)
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    torch.nn.functional.conv1d(xp, wp, padding=1)
+                per_op = (time.perf_counter() - t0) / 10
+                if per_op > 0.01:
+                    skipped[th] = "left out: one 32x32x3 conv1d over 4096 samples takes %.0f ms at %d threads (thread-team overhead; ~1500 such ops per run)" % (per_op * 1e3, th)
+                    continue
             with torch.no_grad():
                 m.sample(mel_t[:, :, :32], rows, x_t[:, :, : 32 * HOP])          # warm-up: thread pool, op caches
                 best = float("inf")
@@ -393,10 +407,14 @@ def cpu_baseline(T, rows):
     dt = time.perf_counter() - t0
     out = {"value": round(audio_s / by_threads[th_best], 3), "unit": "x real-time", "cores": th_best, "kind": "port",
            "sample": "torch_eager port, B=1 T=%d N=%d, warm-up + best of 3 (2 at 1 thread); best = %d threads of %d cores" % (T, N, th_best, cores),
+           "threads_tried": sorted(list(by_threads) + list(skipped)),
            "samples_per_s": round(T * HOP / by_threads[th_best], 1), "port_vs_reference": PORT_VS_REFERENCE}
     for th, dt_t in by_threads.items():
         out["rtf_%dt" % th] = round(audio_s / dt_t, 3)
         out["s_%dt" % th] = round(dt_t, 3)
+    for th, why in skipped.items():
+        out["rtf_%dt" % th] = None
+        out["note_%dt" % th] = why
     out["rtf_c_port_%dt" % threads] = round(audio_s / dt, 3)
     return out
 

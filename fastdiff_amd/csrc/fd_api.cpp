@@ -1461,8 +1461,11 @@ int fd_set_mel_filterbank(fd_handle h, const float *fb, int n_mels, int n_bins)
         h->mel_bank_user[v] = false;
         return upload_mel_bank(h, v, def.data());
     }
-    for (size_t i = 0; i < (size_t)MEL_NM * MEL_NB; ++i)
-        if (!(fb[i] == fb[i]) || fb[i] > 3.0e38f || fb[i] < -3.0e38f) FD_FAIL(h, FD_ERR_INVALID, "fd_set_mel_filterbank: element %zu is not finite", i);
+    for (size_t i = 0; i < (size_t)MEL_NM * MEL_NB; ++i) {      // (on the bit pattern: this file is built with -fno-honor-nans)
+        uint32_t bits;
+        memcpy(&bits, fb + i, sizeof(bits));
+        if ((bits & 0x7F800000u) == 0x7F800000u) FD_FAIL(h, FD_ERR_INVALID, "fd_set_mel_filterbank: element %zu is not finite", i);
+    }
     const int rc = upload_mel_bank(h, v, fb);
     if (rc == FD_OK) h->mel_bank_user[v] = true;
     return rc;
