@@ -22,6 +22,10 @@ def main():
         elif "k_kp_gemm_h2" in n:
             pick["gemm"] = avg
             calls_gemm = calls
+        elif "k_first_conv" in n:
+            pick["first"] = avg
+        elif "k_dblock_h2<4" in n:
+            pick["dblock4"] = avg
         else:
             m = re.search(r"k_lvc_h2<(\d+), *(\d+), *(\w+), *(\d+)", n)
             if m:
@@ -30,7 +34,7 @@ def main():
     keys = ["gemm", "h8_d1", "h8_d3", "h8_d9", "h8_d27"]
     print("%-14s " % label + "  ".join("%s %.1f" % (k, pick.get(k, float("nan"))) for k in keys) +
           "  | gemm+h8 %.1f  | all kernels per step %.1f us" % (pick.get("gemm", 0.0) + h8, total / max(calls_gemm, 1)) +
-          "  | " + "  ".join("%s %.1f" % (k, v) for k, v in sorted(pick.items()) if k.startswith("h64") or k.startswith("h256")))
+          "  | " + "  ".join("%s %.1f" % (k, v) for k, v in sorted(pick.items()) if k.startswith("h64") or k.startswith("h256") or k in ("first", "dblock4")))
 
 
 if __name__ == "__main__":
