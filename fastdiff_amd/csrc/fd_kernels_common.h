@@ -114,7 +114,7 @@ __device__ __forceinline__ void halo_dot(const char *xs, int row, int slot, cons
 
 // Cache policy of the big streams.  FD_LVC_NT bits: which accesses carry the nt (non-temporal) bit -- hop-64/256 LVC layers: 1 = x
 // loads, 2 = out stores, 4 = the frame's record, 8 = skip loads; 16 = hop-8 LVC out stores, 32 = ConvTranspose out stores, 64 =
-// first_conv out stores.  Shipped: 2 | 64.
+// first_conv out stores, 128 = the hop-8 layers' record loads (one reader per record).  Shipped: 2 | 64.
 //   2 (round 3, profiles/r03/s40_s41_nt_policy.txt): the layer alone -3 %, a call -0.75 % at B=8, -1.9 % at B=1; 4 costs 6 % (both waves of
 //     a row tile read the record: it has to stay in L1 / L2); 1, 8, 32: +-0 or worse.
 //   64 (round 5, profiles/r05/s3_lvc_nt_policy.txt, s4_lvc_nt_policy_bits.txt; A/B inside one session on two boxes): the 226 MB of a0 are

@@ -932,8 +932,8 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h8m(const float *__restrict__ xi
 #pragma unroll
                 for (int tap = 0; tap < 3; ++tap) {
                     const int e8 = (mt * 6 + 2 * tap + (g4 >> 1)) * 64 + 16 * hf + c16 + 32 * (g4 & 1);
-                    ka[mt][hf][tap][0] = kp4[2 * e8];
-                    ka[mt][hf][tap][1] = kp4[2 * e8 + 1];
+                    ka[mt][hf][tap][0] = lvc_ld<128>(kp4 + 2 * e8);          // (bit 128: a hop-8 record has exactly one reader, this wave)
+                    ka[mt][hf][tap][1] = lvc_ld<128>(kp4 + 2 * e8 + 1);
                 }
                 bz[mt][hf] = *reinterpret_cast<const float4 *>(rec + fd::KW + layer * 64 + mt * 32 + 16 * hf + 4 * g4);
             }
