@@ -326,7 +326,10 @@ def measure_roofline(model, mel, rows, B, T, nsteps, lens=None, replay=None):
         roof["lvc12_frac_survey_bytes"] = a["frac_survey_8d_bytes"]
     for k in ("lvc_layer_h8", "lvc_layer_h64", "lvc_up_h64", "lvc_up_h256", "lvc_final_h256"):
         if k in table and "hbm_frac" in table[k]:
-            roof["frac_" + k.replace("lvc_", "").replace("layer_", "")] = table[k]["hbm_frac"]
+            roof["frac_" + k.replace("lvc_", "").replace("layer_", "")] = table[k]["hbm_frac"]      # on the launch's OWN minimal bytes
+            if not k.startswith("lvc_layer_h"):      # ... and on SURVEY 8(d)'s unit: the launch is one LVC layer call, 4 B T (96 hop + 6208) bytes
+                b8d = 4.0 * B * T * (96 * int(k.split("_h")[1]) + 6208)
+                roof["frac8d_" + k.replace("lvc_", "")] = round(b8d / (table[k]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
     if "kp_gemm_f16x2" in table:
         roof["gemm_us"] = table["kp_gemm_f16x2"]["avg_us"]
         roof["gemm_hbm_frac"] = table["kp_gemm_f16x2"].get("hbm_frac")
@@ -1013,7 +1016,7 @@ def main():
             summ["torch_eager_like_reference_gpu_ms"] = line["torch_eager_baseline"].get("like_the_reference", {}).get("ms_per_step")
         roof = line.get("roofline") or {}
         for k in ("frac", "avg_launch_us", "lvc12_frac_min_bytes", "lvc12_frac_survey_bytes", "frac_h8", "frac_h64", "frac_up_h64", "frac_up_h256",
-                  "frac_final_h256", "gemm_us", "gemm_hbm_frac", "gemm_tflops_executed"):
+                  "frac_final_h256", "frac8d_up_h64", "frac8d_up_h256", "frac8d_final_h256", "gemm_us", "gemm_hbm_frac", "gemm_tflops_executed"):
             if roof.get(k) is not None:
                 summ[("roofline_" + k) if k in ("frac", "avg_launch_us") else k] = roof[k]
         cb = line.get("cpu_baseline") or {}

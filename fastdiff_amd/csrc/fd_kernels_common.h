@@ -121,6 +121,7 @@ __device__ __forceinline__ void halo_dot(const char *xs, int row, int slot, cons
 //     written at the head of the step and not read before the last block -- streamed past L2 / the memory-side cache they leave it to the
 //     predictor GEMM's window reads and to the records: first_conv itself +3.7 us, the first hop-8 layers -5.8 / -1.6 us, the GEMM -5 us,
 //     a reverse step -0.8 % (2118 -> 2101 us; with 16 as well: 2108).  16 alone: +-0 (2120 us).
+//   128 (profiles/r05/s5_lvc_nt_h8_records.txt): costs -- the hop-8 layers 42-45 -> 46-52 us, a reverse step +0.6 ... +1.4 %.
 #ifndef FD_LVC_NT
 #define FD_LVC_NT 66
 #endif
