@@ -18,12 +18,12 @@ FD_BENCH_OVERSUBSCRIBE=1 timeout 900 python bench.py --gpus 8 --workload config4
 FD_BENCH_OVERSUBSCRIBE=1 timeout 900 python bench.py --gpus 8 --steps 3 --warmup 1 > gpurun_out/bench_configs1_8ranks_1gpu.log 2>&1 ; grep '^{' gpurun_out/bench_configs1_8ranks_1gpu.log | cut -c1-300
 echo "== bench --gpus 2 without the override must refuse" ; python bench.py --gpus 2 > gpurun_out/bench_gpus2_refused.log 2>&1 ; echo "rc=$?" ; tail -1 gpurun_out/bench_gpus2_refused.log
 echo "== rocprof kernel-trace"
-cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o kt -- python $R/bench.py --steps 5 --warmup 1 --no-roofline --no-cpu-baseline --no-fp32-pipe --no-host-io --no-b1 > $R/gpurun_out/rocprof.log 2>&1 ; echo "rocprof rc=$?"
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o kt -- python $R/bench.py --steps 5 --warmup 1 --no-roofline --no-cpu-baseline --no-fp32-pipe --no-host-io --no-b1 --no-torch-eager-baseline > $R/gpurun_out/rocprof.log 2>&1 ; echo "rocprof rc=$?"
 cd $R; find gpurun_out/prof -name '*kernel_trace.csv' -size +20M -delete 2>/dev/null
 ST=$(find gpurun_out/prof -name '*kernel_stats.csv' | head -1); python tools/kernel_stats_fracs.py $ST --bench-json gpurun_out/bench.log > gpurun_out/fracs_from_kernel_stats.txt 2>&1; head -14 gpurun_out/fracs_from_kernel_stats.txt
 echo "== PMC"
 OUT=$R/gpurun_out/pmc; mkdir -p $OUT; cd /tmp
-CMD="python $R/bench.py --steps 2 --warmup 1 --no-roofline --no-cpu-baseline --no-graph --no-fp32-pipe --no-host-io --no-b1"
+CMD="python $R/bench.py --steps 2 --warmup 1 --no-roofline --no-cpu-baseline --no-graph --no-fp32-pipe --no-host-io --no-b1 --no-torch-eager-baseline"
 pass() { name=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT -o $name -- $CMD > $OUT/$name.log 2>&1; echo "$name rc=$?"; }
 pass p1 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
 pass p2 FETCH_SIZE
