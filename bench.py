@@ -77,7 +77,7 @@ def kernel_model(name, B, T):
         return "mfma", 3 * 4.0 * (B * T * 24832 + 24832 * 192 + B * T * 64), 3 * 2.0 * 24832 * 192 * B * T
     if name == "kp_gemm_f16x2":
         # the same product on the fp16 pipe with 2-piece operands (three MFMA passes: 3x these flops are EXECUTED, see
-        # executed_flops); the 2.06 GB of predicted kernels it writes is what bounds it (DESIGN.md 3.2)
+        # executed_flops); the 2.06 GB of predicted kernels it writes is what bounds it (DESIGN.md 3.1)
         return "hbm", 3 * 4.0 * (B * T * 24832 + 24832 * 192 + B * T * 64), 3 * 2.0 * 24832 * 192 * B * T
     if name == "kp_front":
         # input conv (K=400) + six 64->64 k3 convs (K=192) for the three predictors, fused through LDS

@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(256) k_cconv_reduce(const float *__restrict__ 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // The two 7-tap convolutions at the ends of the network on the training path: first_audio_conv = Conv1d(1, 32, 7, pad 3)
 // (FastDiff_model.py:34-36,89) and final_conv = Conv1d(32, 1, 7, pad 3) (FastDiff_model.py:67-68,100).  K = 7 is nothing for the matrix
-// pipe: plain VALU, tiles of 256 columns through LDS, the weights through vector loads + LDS (never scalar loads: DESIGN.md section 4).
+// pipe: plain VALU, tiles of 256 columns through LDS, the weights through vector loads + LDS (never scalar loads: LABBOOK.md section 4).
 // Both weight gradients are the same correlation of a 32-row tile R with ONE row s,  C[r][k] = sum_t R[r][t] s[t + sgn (k - 3)]:
 //   first conv:  R = dy [32 rows], s = x,  sgn = +1;      final conv:  R = x [32 rows], s = dy,  sgn = -1
 // thread = (row r, eighth of the tile's columns, interleaved), 7 running sums kept over all tiles of the persistent workgroup, the

@@ -59,7 +59,7 @@ __device__ __forceinline__ bool skip_after_previous_overflow(int *flag)
     return true;
 }
 
-// ---- 2-piece fp16 operands (DESIGN.md section 3.2): v = v1 + 2^-11 v2, v1 = fp16(v), v2 = fp16((v - v1) * 2^11) ----------------
+// ---- 2-piece fp16 operands (DESIGN.md section 3.1): v = v1 + 2^-11 v2, v1 = fp16(v), v2 = fp16((v - v1) * 2^11) ----------------
 constexpr float GX_SCALE = 2048.0f, GX_INV_SCALE = 1.0f / 2048.0f;
 constexpr float GX_LIMIT = 32768.0f;            // magnitudes from here on do not fit: the kernels raise a range flag
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256, 2) k_convt(const float *__restrict__ xin,
     }
 }
 
-// The same ConvTranspose on the fp16 matrix pipe with 2-piece operands (DESIGN.md section 3.2): 12 MFMAs of 32 cycles per
+// The same ConvTranspose on the fp16 matrix pipe with 2-piece operands (DESIGN.md section 3.1): 12 MFMAs of 32 cycles per
 // output phase instead of 32 of 64.  leaky_relu(x) is split once into a [position][piece][32 ch] fp16 image (row = q - q0 + 1).
 #ifndef FD_CONVT_OCC
 #define FD_CONVT_OCC(R) 2      // workgroups per CU the register budget is cut for.  r = 4 fits three (168 VGPRs, no spills) and is

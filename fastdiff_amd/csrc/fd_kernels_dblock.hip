@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256, 2) k_dblock(const float *__restrict__ xin
     }
 }
 
-// The same DBlock on the fp16 matrix pipe with 2-piece operands (DESIGN.md section 3.2): 57 MFMAs of 32 cycles per wave
+// The same DBlock on the fp16 matrix pipe with 2-piece operands (DESIGN.md section 3.1): 57 MFMAs of 32 cycles per wave
 // instead of 160 of 64.  Activations live in LDS as [column][piece][32 ch] fp16 images (128 B per column, slots swizzled as
 // in k_lvc_h2); an image holds leaky_relu of the layer output because that is the only form the next layer reads; the raw
 // pick of x gets its own image for the 1x1 residual.  Same tiling: 128 columns, 114 valid.
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256, FD_DBLOCK_OCC) k_dblock_h2(const float *_
     if (blockIdx.x * DB_STRIDE >= Lob || skip_after_previous_overflow(range_flag)) return;
     float mx = 0.0f;
     // AUDIO: the first conv's weights (224) and biases (32) through vector loads and LDS, not through scalar loads of a uniform index:
-    // scalar DATA loads are what a short-lived neighbour process on the same compute units can disturb (k_first_conv)
+    // scalar DATA loads are what a short-lived neighbour process on the same compute units can disturb (k_first_conv, LABBOOK.md section 4)
     __shared__ float fwl[AUDIO ? 256 : 1];
     if constexpr (AUDIO) {
         fwl[tid] = tid < 224 ? fw[tid] : fb[tid - 224];

@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256, 2) k_kp_front(const float *__restrict__ m
     }
 }
 
-// The same seven layers on the fp16 matrix pipe with 2-piece operands (DESIGN.md section 3.2): 291 MFMAs of 32 cycles per
+// The same seven layers on the fp16 matrix pipe with 2-piece operands (DESIGN.md section 3.1): 291 MFMAs of 32 cycles per
 // wave instead of 776 of 64.  Images: mel + noise as [column][piece][80 ch] fp16, 336 B per column (320 + 16: a row stride of
 // 84 dwords = 4 x odd spreads the 16-lane groups of ds_read_b128 over all banks without a swizzle); activations as
 // [column + 1][piece][64 ch], 256 B per column, slots swizzled by row & 15 -- the layout of the GEMM's h image, which the last
@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm(const float *__restrict__ h 
 //   hi = W1.h1 (fp32 accumulate)     lo = W1.h2 + W2.h1 (separate fp32 accumulator)     result = bias + hi + 2^-11 * lo
 // three v_mfma_f32_32x32x16_f16 per 16 k (32 cycles each) instead of eight v_mfma_f32_32x32x2f32 (64 cycles each).  The
 // neglected W2.h2 term is 2^-22 relative, the same order as the representation error; measured against a float64 product
-// the result is closer than an fp32 sgemm (DESIGN.md section 3.2).  fp16 subnormals are honoured by v_cvt and by the MFMA
+// the result is closer than an fp32 sgemm (DESIGN.md section 3.1).  fp16 subnormals are honoured by v_cvt and by the MFMA
 // (tools/ubench/f16_probe.hip), so small values lose nothing; operands of magnitude >= 32768 do not fit: k_h_split raises
 // a flag for them, this kernel then leaves the step to the fp32 kernel that follows it in the stream.
 constexpr int GX_CT = 4;                        // frame tiles per item

@@ -883,7 +883,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h8(const float *__restrict__ xin
 // =================================================================================================
 // The hop-8 layer on the matrix pipe.  A frame is only 8 columns wide, so the 32x32 tiles of the other layers do not fit (one tile
 // would straddle four predicted kernels); v_mfma_f32_16x16x32_f16 does: rows = 16 output channels, cols = 16 columns of which a
-// frame uses 8, k = one tap x 32 input channels.  With the 2-piece fp16 operands of the rest of the pipe (DESIGN.md 3.2):
+// frame uses 8, k = one tap x 32 input channels.  With the 2-piece fp16 operands of the rest of the pipe (DESIGN.md 3.1):
 //   conv   32 -> 32 channels over the workgroup's 32 columns = four 16x16 tiles, one per wave: 9 MFMAs (3 taps x 3 piece products);
 //   LVC    wave = frame: Z[64 x 8] = K_f[64 x 96] Y[96 x 8] = four 16-row tiles x 3 taps x 3 piece products = 36 MFMAs; the frame
 //          record's layout ([mt][kg][row32 + 32 g][8], fd_internal.h) already is the A operand of this instruction: lane (r, g4) of

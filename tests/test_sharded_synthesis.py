@@ -218,7 +218,7 @@ def test_synthesize_sharded_world2_hip_vocoder_equals_single_process():
     """Both ranks drive the real HIP vocoder on cuda:0 (the test box has one GPU); every waveform of the sharded job must be bit-equal
     to the single-process one.  The ranks take turns on the GPU here.  Why: two processes vocoding on the SAME compute units can
     disturb each other -- round 2 saw ~3 % of concurrent runs with one utterance off in a few hundred samples; round 3 narrowed it
-    down (profiles/r03/two_processes_one_gpu.txt, tools/xproc_hunt.py): it takes a second process that starts,
+    down (LABBOOK.md section 4, profiles/r03/two_processes_one_gpu.txt, tools/xproc_hunt.py): it takes a second process that starts,
     runs this library's sampler and exits while sharing CUs with the victim; long-lived neighbours, allocation churn, code-object
     loads and foreign kernels do nothing, and with the two processes on disjoint CU masks it does not happen (next test).
     One process per GPU, which is what the sharded path is for, has no second process on its device."""

@@ -1,5 +1,5 @@
 """A/B of library options inside ONE process and ONE GPU session (box-to-box variation is +-4 %, in-session +-0.3 %):
-    python tools/ab_opts.py [--batch 8] [--frames 864] [--nsteps 4] [--reps 3] [--steps 20] "" "overlap=gemm" "overlap=gemm,overlap_wg=2" ...
+    python tools/ab_opts.py [--batch 8] [--frames 864] [--nsteps 4] [--reps 3] [--steps 20] "" "fuse_up=0" "hoist=off" ...
 Every argument is one configuration ("k=v,k=v"; "" = defaults).  The configurations are timed in turn, `reps` times round-robin, on the
 same model and the same mel (HBM-resident in and out, like bench.py's `value`); printed: ms per sample call, per round and the mean.
 Every configuration is its own model instance with its own workspace, and two instances of the SAME configuration can differ by ~1.4 %

@@ -1,4 +1,4 @@
-// copy_mix_probe.hip -- what the memory system gives hand-written kernels with the LVC layer's traffic mix:
+// copy_mix_probe.hip -- what the memory system gives hand-written kernels with the LVC layer's traffic mix (LABBOOK.md 3.1):
 //   copy      out = a                                  1 read : 1 write, float4 per lane, linear
 //   mix21     out = a + b                              2 reads : 1 write (x, skip -> x'), linear
 //   lvc256    the global-memory instructions of k_lvc_h2<256,*> and nothing else: per workgroup one 256-column tile of 32

@@ -1,4 +1,4 @@
-// xproc_repro.hip -- standalone attempt to reproduce the two-processes-on-one-GPU disturbance (DESIGN.md section 4,
+// xproc_repro.hip -- standalone attempt to reproduce the two-processes-on-one-GPU disturbance (LABBOOK.md section 4,
 // profiles/r03/two_processes_one_gpu.txt) WITHOUT this library and without torch: plain HIP, one file.
 //
 //   hipcc --offload-arch=gfx950 -O3 -o tools/ubench/xproc_repro tools/ubench/xproc_repro.hip
