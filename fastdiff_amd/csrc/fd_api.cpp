@@ -938,8 +938,10 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
     h->embed_valid = false;                      // fd_forward writes its own rows into the same table
     if (!x || !mel || !steps || !eps_out) FD_FAIL(h, FD_ERR_INVALID, "fd_forward: null pointer");
     if (x == eps_out) FD_FAIL(h, FD_ERR_INVALID, "fd_forward: eps_out must not alias x");
-    if (h->gen) {      // (lens is ignored: the padded batch is computed as the reference computes it)
-        if ((rc = fdg::forward(h, x, mel, steps, B, T, eps_out, (hipStream_t)stream)) != FD_OK) return rc;
+    if (h->gen) {
+        for (int b = 0; lens && b < B; ++b)
+            if (lens[b] < 1 || lens[b] > T) FD_FAIL(h, FD_ERR_INVALID, "fd_forward: lens[%d] = %d outside [1, T=%d]", b, lens[b], T);
+        if ((rc = fdg::forward(h, x, mel, steps, B, T, lens, eps_out, (hipStream_t)stream)) != FD_OK) return rc;
         h->last_B = B; h->last_T = T;
         return mark_tail(h, (hipStream_t)stream);
     }
@@ -1269,7 +1271,9 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
         if (!mel || !table || !out) FD_FAIL(h, FD_ERR_INVALID, "fd_sample: null pointer");
         if (N <= 0 || N > 1024) FD_FAIL(h, FD_ERR_INVALID, "fd_sample: N=%d outside 1..1024", N);
         if (!ids.empty() && (int)ids.size() != B) FD_FAIL(h, FD_ERR_INVALID, "fd_sample: fd_set_noise_streams gave %d stream ids but B=%d", (int)ids.size(), B);
-        if ((rc = fdg::sample(h, mel, B, T, table, N, ddim, x_T, z, seed, ids, out, seq_out, (hipStream_t)stream_)) != FD_OK) return rc;
+        for (int b = 0; lens && b < B; ++b)
+            if (lens[b] < 1 || lens[b] > T) FD_FAIL(h, FD_ERR_INVALID, "fd_sample: lens[%d] = %d outside [1, T=%d]", b, lens[b], T);
+        if ((rc = fdg::sample(h, mel, B, T, lens, table, N, ddim, x_T, z, seed, ids, out, seq_out, (hipStream_t)stream_)) != FD_OK) return rc;
         ++h->ticket_counter;
         h->last_B = B; h->last_T = T;
         return mark_tail(h, (hipStream_t)stream_);

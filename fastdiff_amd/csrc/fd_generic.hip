@@ -7,7 +7,8 @@
 // created with another configuration runs here: runtime-shaped kernels, one thread per output element, fp32 multiply-adds in a fixed
 // order, tensors in the reference's own layouts ([B, C, time]; the predicted kernels as kernel_conv leaves them, [B, layers*C*2C*ks, T]
 // with T innermost: modules.py:333-338).  Correctness path, not a fast one: nothing here is tiled, staged through LDS or captured in a
-// graph.  `lens` is ignored (the padded batch is computed as the reference computes it), fd_read_tap / profiling are not offered.
+// graph; fd_read_tap / profiling are not offered.  `lens` means what it means on the tuned path: utterance b is computed as if it were alone
+// and lens[b] frames long (every kernel treats positions behind it as the zero padding at the end of a signal and skips the outputs there).
 #include "fd_internal.h"
 #include "fd_device.h"
 #include "fd_kernels.h"
@@ -65,21 +66,24 @@ __global__ void g_linear(const float *in, const float *W, const float *bias, flo
 //   xin(b, i, p) = 0 outside [0, Lout), else x[b][i][p * in_stride] (+ in_add[b][i]: the predictor's `c + noise`, modules.py:203 --
 //   added to the signal, not to its zero padding).  in_stride > 1 reads every in_stride-th sample: nearest-neighbour down-sampling by
 //   an integer factor (DiffusionDBlock, modules.py:127-134) without materialising the picked sequence.
+//   lens (nullable) / spf: utterance b is lens[b] * spf output samples long; behind that nothing is computed and nothing is read.
 __global__ void g_conv1d(const float *x, const float *W, const float *bias, float *y, int B, int Cin, int Cout, int K, int dil, int pad,
                          int64_t Lx, int64_t Lout, int in_stride, const float *in_add, float pre, float post, const float *add,
-                         int64_t Ladd, int add_stride)
+                         int64_t Ladd, int add_stride, const int *lens, int spf)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)B * Cout * Lout) return;
     const int64_t t = i % Lout;
     const int o = (int)((i / Lout) % Cout), b = (int)(i / (Lout * Cout));
+    const int64_t Lb = lens ? (int64_t)lens[b] * spf : Lout;
+    if (t >= Lb) return;
     float acc = bias[o];
     for (int c = 0; c < Cin; ++c) {
         const float *xr = x + ((int64_t)b * Cin + c) * Lx;
         const float ia = in_add ? in_add[(int64_t)b * Cin + c] : 0.0f;
         for (int k = 0; k < K; ++k) {
             const int64_t p = t + (int64_t)k * dil - pad;
-            if (p >= 0 && p < Lout) acc += W[((int64_t)o * Cin + c) * K + k] * act(xr[p * in_stride] + ia, pre);
+            if (p >= 0 && p < Lb) acc += W[((int64_t)o * Cin + c) * K + k] * act(xr[p * in_stride] + ia, pre);
         }
     }
     acc = act(acc, post);
@@ -89,17 +93,20 @@ __global__ void g_conv1d(const float *x, const float *W, const float *bias, floa
 
 // ConvTranspose1d(C, C, 2r, stride r, padding r/2 + r%2, output_padding r%2) of leaky_relu(x, 0.2) (modules.py:163-166,205-206):
 // y[o][t] = b[o] + sum_i sum_j lrelu(x[i][j]) * W[i][o][t + p - j*r] over the j with 0 <= t + p - j*r < 2r; out length = r * in length
-__global__ void g_convt(const float *x, const float *W, const float *bias, float *y, int B, int C, int r, int pad, int64_t Lin)
+__global__ void g_convt(const float *x, const float *W, const float *bias, float *y, int B, int C, int r, int pad, int64_t Lin,
+                        const int *lens, int spf_in)
 {
     const int64_t Lo = Lin * r;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)B * C * Lo) return;
     const int64_t t = i % Lo;
     const int o = (int)((i / Lo) % C), b = (int)(i / (Lo * C));
+    const int64_t Lib = lens ? (int64_t)lens[b] * spf_in : Lin;      // this utterance's input length
+    if (t >= Lib * r) return;
     float acc = bias[o];
     const int64_t q = t + pad, j_hi = q / r;      // the kernel spans 2r taps at stride r: exactly two inputs reach an output
     for (int64_t j = j_hi - 1; j <= j_hi; ++j) {
-        if (j < 0 || j >= Lin) continue;
+        if (j < 0 || j >= Lib) continue;
         const int k = (int)(q - j * r);             // in [0, 2r)
         for (int c = 0; c < C; ++c)
             acc += act(x[((int64_t)b * C + c) * Lin + j], 0.2f) * W[((int64_t)c * C + o) * (2 * r) + k];
@@ -107,23 +114,27 @@ __global__ void g_convt(const float *x, const float *W, const float *bias, float
     y[i] = acc;
 }
 
-__global__ void g_add_inplace(float *x, const float *s, int64_t n)
+__global__ void g_add_inplace(float *x, const float *s, int64_t n, int64_t Lrow, int C, const int *lens, int spf)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) x[i] += s[i];
+    if (i >= n) return;
+    if (lens && (i % Lrow) >= (int64_t)lens[(int)(i / (Lrow * C))] * spf) return;
+    x[i] += s[i];
 }
 
 // location_variable_convolution + gate + residual (modules.py:213-217,220-253; its dilation argument is always 1):
 //   z[o][l*hop + s] = bias[layer][o][l] + sum_{c,k} ypad[c][l*hop + s + k - (ks-1)/2] * K[layer][c][o][k][l]     (zero pad of the WHOLE signal)
 //   out = x + sigmoid(z[ch]) * tanh(z[ch + C]);   thread = (b, ch, t).  kernels [B][layers*C*2C*ks][T], biases [B][layers*2C][T].
 __global__ void g_lvc_gate(const float *y, const float *kernels, const float *biases, const float *x, float *out, int B, int C, int ks,
-                           int layers, int layer, int hop, int T)
+                           int layers, int layer, int hop, int T, const int *lens)
 {
     const int64_t Ln = (int64_t)T * hop;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)B * C * Ln) return;
     const int64_t t = i % Ln;
     const int ch = (int)((i / Ln) % C), b = (int)(i / (Ln * C));
+    const int64_t Lnb = lens ? (int64_t)lens[b] * hop : Ln;
+    if (t >= Lnb) return;
     const int l = (int)(t / hop), half = (ks - 1) / 2;
     const float *kb = kernels + (int64_t)b * layers * C * 2 * C * ks * T;
     const float *bb = biases + (int64_t)b * layers * 2 * C * T;
@@ -132,7 +143,7 @@ __global__ void g_lvc_gate(const float *y, const float *kernels, const float *bi
         const float *yr = y + ((int64_t)b * C + c) * Ln;
         for (int k = 0; k < ks; ++k) {
             const int64_t p = t + k - half;
-            if (p < 0 || p >= Ln) continue;
+            if (p < 0 || p >= Lnb) continue;
             const float v = yr[p];
             const int64_t base = (((int64_t)layer * C + c) * 2 * C) * ks;
             zs += v * kb[(base + (int64_t)ch * ks + k) * T + l];
@@ -145,10 +156,11 @@ __global__ void g_lvc_gate(const float *y, const float *kernels, const float *bi
 // One reverse step of sampling_given_noise_schedule on x (util.py:219-229), scalar form of fdk::sampler_update4: the same Philox
 // counters, so with a sample count per utterance that is a multiple of 4 the draws are the tuned path's.
 __global__ void g_update(float *x, const float *eps, fd_step st, int k, int ddim, const float *z, unsigned long long seed,
-                         const unsigned long long *uids, int64_t L, int64_t n, float *seq)
+                         const unsigned long long *uids, int64_t L, int64_t n, float *seq, const int *lens, int spf)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (lens && (i % L) >= (int64_t)lens[(int)(i / L)] * spf) return;
     const float xv = x[i], e = eps[i];
     float o;
     if (ddim) o = (st.c1 * xv + st.c2 * e) + st.c3 * e;
@@ -292,7 +304,7 @@ int commit(fd_context *c, const std::map<std::string, FoldedParam> &f)
 // workspace layout of one call (floats)
 struct Plan {
     int64_t L, T;
-    size_t emb, mid, eout, noise, a[9], h0, h1, res, kph[3], kc, bc, xa, xb, y, eps, xs, uid, total;
+    size_t emb, mid, eout, noise, a[9], h0, h1, res, kph[3], kc, bc, xa, xb, y, eps, xs, uid, lens, total;
 };
 
 static Plan plan(const Net *n, int B, int T)
@@ -320,6 +332,7 @@ static Plan plan(const Net *n, int B, int T)
     p.xa = take((size_t)B * C * p.L); p.xb = take((size_t)B * C * p.L); p.y = take((size_t)B * C * p.L);
     p.eps = take((size_t)B * p.L); p.xs = take((size_t)B * p.L);
     p.uid = take((size_t)2 * B);
+    p.lens = take((size_t)B);
     p.total = off;
     return p;
 }
@@ -341,7 +354,7 @@ static int ensure_ws(fd_context *c, const Plan &p)
 
 // eps = net((x, mel, t)): FastDiff.forward, FastDiff_model.py:74-102.  steps [B] device, or NULL with one value t_all for every utterance.
 static hipError_t forward_dev(Net *n, const Plan &p, const float *x, const float *mel, const float *steps, float t_all, int B, float *eps_out,
-                              hipStream_t stream)
+                              const int *lens, hipStream_t stream)
 {
     const fd_config &c = n->cfg;
     float *w = n->ws;
@@ -356,20 +369,21 @@ static hipError_t forward_dev(Net *n, const Plan &p, const float *x, const float
     for (int b = 0; b < n->nb; ++b)
         G_LAUNCH(g_linear, (int64_t)B * CC, (const float *)(w + p.eout), n->blk[b].fc_t.w, n->blk[b].fc_t.b, w + p.noise + (size_t)b * B * CC, B, E_OUT, CC, 0);
     // a3: first_audio_conv
-    G_LAUNCH(g_conv1d, (int64_t)B * C * p.L, x, n->first.w, n->first.b, w + p.a[0], B, 1, C, 7, 1, 3, p.L, p.L, 1, none, 1.0f, 1.0f, none, (int64_t)0, 1);
+    G_LAUNCH(g_conv1d, (int64_t)B * C * p.L, x, n->first.w, n->first.b, w + p.a[0], B, 1, C, 7, 1, 3, p.L, p.L, 1, none, 1.0f, 1.0f, none, (int64_t)0, 1, lens, n->hop_total);
     // a4: the DBlocks, factors = the ratios reversed (FastDiff_model.py:63); block d consumes a[d], leaves a[d + 1]
     int64_t len = p.L;
     for (int d = 0; d < n->nb; ++d) {
         const int f = c.upsample_ratios[n->nb - 1 - d];
         const int64_t lo = len / f;
+        const int spf = (int)(lo / T);                // samples per frame at this DBlock's output rate
         const Net::Blk &k = n->blk[d];
         const float *src = w + p.a[d];
         // res = Conv1x1(x) picked at every f-th sample; h = the picked x through three (lrelu 0.2, conv k3 dilation 1, 2, 4); out = h + res
-        G_LAUNCH(g_conv1d, (int64_t)B * C * lo, src, k.res.w, k.res.b, w + p.res, B, C, C, 1, 1, 0, len, lo, f, none, 1.0f, 1.0f, none, (int64_t)0, 1);
-        G_LAUNCH(g_conv1d, (int64_t)B * C * lo, src, k.dconv[0].w, k.dconv[0].b, w + p.h0, B, C, C, 3, 1, 1, len, lo, f, none, 0.2f, 1.0f, none, (int64_t)0, 1);
-        G_LAUNCH(g_conv1d, (int64_t)B * C * lo, (const float *)(w + p.h0), k.dconv[1].w, k.dconv[1].b, w + p.h1, B, C, C, 3, 2, 2, lo, lo, 1, none, 0.2f, 1.0f, none, (int64_t)0, 1);
+        G_LAUNCH(g_conv1d, (int64_t)B * C * lo, src, k.res.w, k.res.b, w + p.res, B, C, C, 1, 1, 0, len, lo, f, none, 1.0f, 1.0f, none, (int64_t)0, 1, lens, spf);
+        G_LAUNCH(g_conv1d, (int64_t)B * C * lo, src, k.dconv[0].w, k.dconv[0].b, w + p.h0, B, C, C, 3, 1, 1, len, lo, f, none, 0.2f, 1.0f, none, (int64_t)0, 1, lens, spf);
+        G_LAUNCH(g_conv1d, (int64_t)B * C * lo, (const float *)(w + p.h0), k.dconv[1].w, k.dconv[1].b, w + p.h1, B, C, C, 3, 2, 2, lo, lo, 1, none, 0.2f, 1.0f, none, (int64_t)0, 1, lens, spf);
         G_LAUNCH(g_conv1d, (int64_t)B * C * lo, (const float *)(w + p.h1), k.dconv[2].w, k.dconv[2].b, w + p.a[d + 1], B, C, C, 3, 4, 4, lo, lo, 1, none, 0.2f, 1.0f,
-                 (const float *)(w + p.res), lo, 1);
+                 (const float *)(w + p.res), lo, 1, lens, spf);
         len = lo;
     }
     // the LVC blocks (modules.py:189-218): x starts as the bottom of the down path
@@ -383,30 +397,30 @@ static hipError_t forward_dev(Net *n, const Plan &p, const float *x, const float
         const float *nz = w + p.noise + (size_t)b * B * CC;
         // a5: KernelPredictor on c + noise: input conv k5 + lrelu 0.1; h + six (conv, lrelu 0.1); kernel_conv, bias_conv
         float *h0 = w + p.kph[0], *ha = w + p.kph[1], *hb = w + p.kph[2];
-        G_LAUNCH(g_conv1d, (int64_t)B * HID * T, mel, k.kp_in.w, k.kp_in.b, h0, B, CC, HID, 5, 1, 2, (int64_t)T, (int64_t)T, 1, nz, 1.0f, 0.1f, none, (int64_t)0, 1);
+        G_LAUNCH(g_conv1d, (int64_t)B * HID * T, mel, k.kp_in.w, k.kp_in.b, h0, B, CC, HID, 5, 1, 2, (int64_t)T, (int64_t)T, 1, nz, 1.0f, 0.1f, none, (int64_t)0, 1, lens, 1);
         const float *cur = h0;
         for (int j = 0; j < 6; ++j) {
             float *dst = (j & 1) ? hb : ha;
             const bool last = j == 5;
             G_LAUNCH(g_conv1d, (int64_t)B * HID * T, cur, k.kp_res[j].w, k.kp_res[j].b, dst, B, HID, HID, KK, 1, (KK - 1) / 2, (int64_t)T, (int64_t)T, 1, none, 1.0f, 0.1f,
-                     last ? (const float *)h0 : none, (int64_t)T, 1);
+                     last ? (const float *)h0 : none, (int64_t)T, 1, lens, 1);
             cur = dst;
         }
         G_LAUNCH(g_conv1d, (int64_t)B * LY * C * 2 * C * KS * T, cur, k.kc.w, k.kc.b, w + p.kc, B, HID, LY * C * 2 * C * KS, KK, 1, (KK - 1) / 2, (int64_t)T, (int64_t)T, 1, none,
-                 1.0f, 1.0f, none, (int64_t)0, 1);
+                 1.0f, 1.0f, none, (int64_t)0, 1, lens, 1);
         G_LAUNCH(g_conv1d, (int64_t)B * LY * 2 * C * T, cur, k.bc.w, k.bc.b, w + p.bc, B, HID, LY * 2 * C, KK, 1, (KK - 1) / 2, (int64_t)T, (int64_t)T, 1, none, 1.0f, 1.0f,
-                 none, (int64_t)0, 1);
+                 none, (int64_t)0, 1, lens, 1);
         // a6: x = upsample(lrelu(x, 0.2)) into the ping-pong buffer the input does not occupy
         float *dst = (xcur == w + p.xa) ? w + p.xb : w + p.xa;
         float *oth = (dst == w + p.xa) ? w + p.xb : w + p.xa;
-        G_LAUNCH(g_convt, (int64_t)B * C * ln, xcur, k.up.w, k.up.b, dst, B, C, r, r / 2 + r % 2, lin);
+        G_LAUNCH(g_convt, (int64_t)B * C * ln, xcur, k.up.w, k.up.b, dst, B, C, r, r / 2 + r % 2, lin, lens, (int)(lin / T));
         // a7-a9: per layer x += skip; y = lrelu(conv_{ks, dilation 3^i}(lrelu(x))); x = x + gate(LVC(y))
         int dil = 1;
         for (int i = 0; i < LY; ++i) {
-            G_LAUNCH(g_add_inplace, (int64_t)B * C * ln, dst, skip, (int64_t)B * C * ln);
+            G_LAUNCH(g_add_inplace, (int64_t)B * C * ln, dst, skip, (int64_t)B * C * ln, ln, C, lens, hop);
             G_LAUNCH(g_conv1d, (int64_t)B * C * ln, (const float *)dst, k.convs[i].w, k.convs[i].b, w + p.y, B, C, C, KS, dil, dil * ((KS - 1) / 2), ln, ln, 1, none, 0.2f, 0.2f,
-                     none, (int64_t)0, 1);
-            G_LAUNCH(g_lvc_gate, (int64_t)B * C * ln, (const float *)(w + p.y), (const float *)(w + p.kc), (const float *)(w + p.bc), (const float *)dst, oth, B, C, KS, LY, i, hop, T);
+                     none, (int64_t)0, 1, lens, hop);
+            G_LAUNCH(g_lvc_gate, (int64_t)B * C * ln, (const float *)(w + p.y), (const float *)(w + p.kc), (const float *)(w + p.bc), (const float *)dst, oth, B, C, KS, LY, i, hop, T, lens);
             std::swap(dst, oth);
             dil *= 3;
         }
@@ -414,22 +428,37 @@ static hipError_t forward_dev(Net *n, const Plan &p, const float *x, const float
         lin = ln;
     }
     // a10: final_conv
-    G_LAUNCH(g_conv1d, (int64_t)B * p.L, xcur, n->final_.w, n->final_.b, eps_out, B, C, 1, 7, 1, 3, p.L, p.L, 1, none, 1.0f, 1.0f, none, (int64_t)0, 1);
+    G_LAUNCH(g_conv1d, (int64_t)B * p.L, xcur, n->final_.w, n->final_.b, eps_out, B, C, 1, 7, 1, 3, p.L, p.L, 1, none, 1.0f, 1.0f, none, (int64_t)0, 1, lens, n->hop_total);
     return hipSuccess;
 }
 
-int forward(fd_context *c, const float *x, const float *mel, const float *steps, int B, int T, float *eps_out, hipStream_t stream)
+// the caller's `lens` (host, nullable) -> the workspace's device copy, or NULL when every utterance fills the batch
+static const int *upload_lens(Net *n, const Plan &p, const int *lens, int B, int T, hipStream_t stream, hipError_t *err)
+{
+    *err = hipSuccess;
+    if (!lens) return nullptr;
+    bool ragged = false;
+    for (int b = 0; b < B; ++b) ragged = ragged || lens[b] < T;
+    if (!ragged) return nullptr;
+    int *d = reinterpret_cast<int *>(n->ws + p.lens);
+    *err = hipMemcpyAsync(d, lens, sizeof(int) * B, hipMemcpyHostToDevice, stream);      // pageable source: staged by the runtime before it returns
+    return d;
+}
+
+int forward(fd_context *c, const float *x, const float *mel, const float *steps, int B, int T, const int *lens, float *eps_out, hipStream_t stream)
 {
     Net *n = c->gen;
     const Plan p = plan(n, B, T);
     int rc = ensure_ws(c, p);
     if (rc != FD_OK) return rc;
-    const hipError_t e = forward_dev(n, p, x, mel, steps, 0.0f, B, eps_out, stream);
+    hipError_t e = hipSuccess;
+    const int *dl = upload_lens(n, p, lens, B, T, stream, &e);
+    if (e == hipSuccess) e = forward_dev(n, p, x, mel, steps, 0.0f, B, eps_out, dl, stream);
     if (e != hipSuccess) { c->err = std::string("fd_forward (generic configuration): ") + hipGetErrorString(e); return FD_ERR_HIP; }
     return FD_OK;
 }
 
-int sample(fd_context *c, const float *mel, int B, int T, const fd_step *table, int N, int ddim, const float *x_T, const float *z,
+int sample(fd_context *c, const float *mel, int B, int T, const int *lens, const fd_step *table, int N, int ddim, const float *x_T, const float *z,
            unsigned long long seed, const std::vector<unsigned long long> &ids, float *out, float *seq_out, hipStream_t stream)
 {
     Net *n = c->gen;
@@ -440,7 +469,8 @@ int sample(fd_context *c, const float *mel, int B, int T, const fd_step *table, 
     float *xs = n->ws + p.xs, *eps = n->ws + p.eps;
     unsigned long long *uids = nullptr;
     hipError_t e = hipSuccess;
-    if (!ids.empty()) {
+    const int *dl = upload_lens(n, p, lens, B, T, stream, &e);
+    if (e == hipSuccess && !ids.empty()) {
         uids = reinterpret_cast<unsigned long long *>(n->ws + p.uid);
         e = hipMemcpyAsync(uids, ids.data(), sizeof(unsigned long long) * B, hipMemcpyHostToDevice, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);      // `ids` is the caller's vector: gone when we return
@@ -450,9 +480,9 @@ int sample(fd_context *c, const float *mel, int B, int T, const fd_step *table, 
         else G_LAUNCH(g_init_noise, cnt, xs, seed, (const unsigned long long *)uids, p.L, cnt);
         if (seq_out && hipMemcpyAsync(seq_out, xs, sizeof(float) * cnt, hipMemcpyDeviceToDevice, stream) != hipSuccess) return hipGetLastError();
         for (int k = 0; k < N; ++k) {
-            const hipError_t ef = forward_dev(n, p, xs, mel, nullptr, table[k].t, B, eps, stream);
+            const hipError_t ef = forward_dev(n, p, xs, mel, nullptr, table[k].t, B, eps, dl, stream);
             if (ef != hipSuccess) return ef;
-            G_LAUNCH(g_update, cnt, xs, (const float *)eps, table[k], k, ddim, z, seed, (const unsigned long long *)uids, p.L, cnt, seq_out);
+            G_LAUNCH(g_update, cnt, xs, (const float *)eps, table[k], k, ddim, z, seed, (const unsigned long long *)uids, p.L, cnt, seq_out, dl, n->hop_total);
         }
         if (hipMemcpyAsync(out, xs, sizeof(float) * cnt, hipMemcpyDeviceToDevice, stream) != hipSuccess) return hipGetLastError();
         return hipSuccess;

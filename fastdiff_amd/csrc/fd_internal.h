@@ -162,8 +162,8 @@ int create(fd_context *c);
 void destroy(fd_context *c);
 int hop_total(const fd_context *c);
 int commit(fd_context *c, const std::map<std::string, FoldedParam> &f);
-int forward(fd_context *c, const float *x, const float *mel, const float *steps, int B, int T, float *eps_out, hipStream_t stream);
-int sample(fd_context *c, const float *mel, int B, int T, const fd_step *table, int N, int ddim, const float *x_T, const float *z,
+int forward(fd_context *c, const float *x, const float *mel, const float *steps, int B, int T, const int *lens, float *eps_out, hipStream_t stream);
+int sample(fd_context *c, const float *mel, int B, int T, const int *lens, const fd_step *table, int N, int ddim, const float *x_T, const float *z,
            unsigned long long seed, const std::vector<unsigned long long> &ids, float *out, float *seq_out, hipStream_t stream);
 }  // namespace fdg
 

@@ -80,7 +80,7 @@ FD_API int fd_default_config(fd_config *cfg);
  * Replaces: FastDiff.__init__ + .cuda() (FastDiff_model.py:13-72; FastDiff.py:17-29,  egs/demo.ipynb cell 0).
  * Any configuration the reference constructor accepts is taken.  base.yaml's architecture (the defaults above: every shipped YAML) runs
  * on the tuned gfx950 kernel set; any other one (other channel counts, ratios incl. odd ones, 1..8 LVC layers, odd kernel sizes, other
- * embedding widths) on runtime-shaped exact-fp32 kernels (csrc/fd_generic.hip: a correctness path -- no graph, `lens` ignored, no
+ * embedding widths) on runtime-shaped exact-fp32 kernels (csrc/fd_generic.hip: a correctness path -- no graph, no
  * fd_read_tap).  FD_ERR_UNSUPPORTED only for what the reference's own forward / sampler cannot run: audio_channels != 1 (first_audio_conv
  * is Conv1d(1, C), FastDiff_model.py:34), even lvc_kernel_size / kpnet_conv_size (the sequence length changes, modules.py:183-187,293-318),
  * odd diffusion_step_embed_dim_in (util.py:423). */

@@ -91,3 +91,39 @@ def test_a_configuration_the_fixtures_do_not_hold_against_the_oracle():
     with torch.no_grad():
         y = m((torch.from_numpy(audio).cuda(), torch.from_numpy(mel).cuda(), torch.from_numpy(steps).view(B, 1).cuda()))
     assert float(np.abs(y.cpu().numpy() - ref).max()) <= 2e-5
+
+
+@pytest.mark.gpu
+def test_ragged_batch_on_the_generic_kernels_equals_each_utterance_alone():
+    """`lens` on a non-default architecture means what it means on the tuned path: every utterance of a zero-padded batch gets, inside
+    its own length, the bits it gets when it runs alone (forward with injected x, the N=4 loop on per-utterance noise streams); without
+    `lens` the padded batch is computed as the reference computes it and the short utterance's tail differs."""
+    import fastdiff_amd
+    import gpu_common as gc
+    sch = load_golden("schedule")
+    cfg = dict(inner_channels=8, cond_channels=40, upsample_ratios=[2, 5, 3], lvc_layers_each_block=3, lvc_kernel_size=5, kpnet_hidden_channels=32,
+               kpnet_conv_size=5, diffusion_step_embed_dim_in=64, diffusion_step_embed_dim_mid=256, diffusion_step_embed_dim_out=128)
+    m = fastdiff_amd.FastDiff(**cfg)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.synth_state_dict(21, cfg).items()}, strict=True)
+    m = m.cuda().eval()
+    hop, T, lens = m.hop_length, 9, [9, 4, 1]
+    B = len(lens)
+    mel = synth.synth_mel(8, B, T, cond=40)
+    x = synth.synth_audio(8, B, T, hop=hop)
+    for b, t in enumerate(lens):
+        mel[b, :, t:] = 0.0
+    steps = torch.tensor([[3.0], [40.5], [700.0]]).cuda()
+    rows, _ = gc.table_rows(sch, 4)
+    with torch.no_grad():
+        y = m.forward((torch.from_numpy(x).cuda(), torch.from_numpy(mel).cuda(), steps), lens=lens)
+        w = m.sample(torch.from_numpy(mel).cuda(), rows, seed=3, lens=lens, stream_ids=[5, 6, 7])
+        w_padded = m.sample(torch.from_numpy(mel).cuda(), rows, seed=3, stream_ids=[5, 6, 7])
+        for b, t in enumerate(lens):
+            one = m.sample(torch.from_numpy(np.ascontiguousarray(mel[b:b + 1, :, :t])).cuda(), rows, seed=3, stream_ids=[5 + b])
+            assert torch.equal(w[b, :, : t * hop], one[0]), b
+            y1 = m((torch.from_numpy(np.ascontiguousarray(x[b:b + 1, :, : t * hop])).cuda(), torch.from_numpy(np.ascontiguousarray(mel[b:b + 1, :, :t])).cuda(), steps[b:b + 1]))
+            assert torch.equal(y[b, :, : t * hop], y1[0]), b
+        assert torch.equal(w_padded[0], w[0])                                  # the full-length utterance needs no lens
+        assert not torch.equal(w_padded[1, :, : lens[1] * hop], w[1, :, : lens[1] * hop])   # the padded computation is a different signal near the end
+    with pytest.raises(AssertionError, match="lens"):
+        m.sample(torch.from_numpy(mel).cuda(), rows, lens=[9, 4, 10])
