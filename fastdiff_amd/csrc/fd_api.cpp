@@ -205,11 +205,6 @@ int fd_create(const fd_config *cfg, int device, fd_handle *out)
         sl.cap = 65536;
     }
     if (!is_base) fdg::create(c);
-    if (is_base && getenv("FD_EXP_FRONT_FORK") && atoi(getenv("FD_EXP_FRONT_FORK")) == 1) {      // experiment of session 8 (run_step)
-        if ((e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e);
-        if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail(e);
-        if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return fail(e);
-    }
     *out = c;
     return FD_OK;
 }
@@ -255,9 +250,6 @@ static void release_handle(fd_context *h)
     for (void *p : h->mel_allocs) hipFree(p);
     if (h->ev_switch) hipEventDestroy(h->ev_switch);
     if (h->cap_stream) hipStreamDestroy(h->cap_stream);
-    if (h->side_stream) hipStreamDestroy(h->side_stream);
-    if (h->ev_fork) hipEventDestroy(h->ev_fork);
-    if (h->ev_join) hipEventDestroy(h->ev_join);
     delete h;
 }
 
@@ -824,22 +816,10 @@ static hipError_t run_step(const Launch &L, const StepIO &io, int B, int T)
     // stream were measured and did not pay (LABBOOK.md: overlap = gemm | paths, order = split | predictor).
     const bool hoisted = c->hoist_np > 1;
     if ((e = first_conv(L, io, B, T)) != hipSuccess) return e;
-    // EXPERIMENT (FD_EXP_FRONT_FORK=1, session 8): the predictor front (mel + step embedding only; latency-bound, 432 workgroups) on a second
-    // stream next to the three DBlocks (latency-bound too), joined in front of the GEMM.  Forked BEHIND first_conv: its first workgroup
-    // advances the step counter the front reads.
-    const bool fork = c->side_stream && !hoisted && c->fast[ST_KP_FRONT] && c->fast[ST_DBLOCK];
-    if (fork) {
-        if ((e = hipEventRecord(c->ev_fork, L.stream)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(c->side_stream, c->ev_fork, 0)) != hipSuccess) return e;
-        const Launch Ls = {c, c->side_stream, L.capturing};
-        if ((e = kp_front(Ls, io, B, T)) != hipSuccess) return e;
-        if ((e = hipEventRecord(c->ev_join, c->side_stream)) != hipSuccess) return e;
-    }
     for (int d = 0; d < fd::NBLK; ++d)
         if ((e = dblock(L, io, d, B, T)) != hipSuccess) return e;
-    if (fork && (e = hipStreamWaitEvent(L.stream, c->ev_join, 0)) != hipSuccess) return e;
     if (!hoisted) {
-        if (!fork && (e = kp_front(L, io, B, T)) != hipSuccess) return e;
+        if ((e = kp_front(L, io, B, T)) != hipSuccess) return e;
         if ((e = kp_gemm(L, B, T)) != hipSuccess) return e;
     }
     float *x = ws.a[3];

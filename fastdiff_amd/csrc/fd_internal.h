@@ -220,8 +220,6 @@ struct fd_context {
     std::vector<void *> mel_allocs;           // device memory behind `mel` (built on first use, freed at fd_destroy)
     int last_B = 0, last_T = 0;
     hipStream_t cap_stream = nullptr;
-    hipStream_t side_stream = nullptr;        // experiment FD_EXP_FRONT_FORK (fd_api.cpp run_step): null unless the variable is set at fd_create
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // Calls on one handle share the workspace, the embedding rows and the pending range check: they are ordered by the stream they run
     // on.  When a caller moves to another stream (fd_forward / fd_sample), a pending check is settled on the old stream and the new
     // stream waits for everything the old one still holds (follow_stream in fd_api.cpp).
