@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round 5, session 8: the predictor front on a second stream next to the DBlocks (FD_EXP_FRONT_FORK=1), A/B inside one session, and the
-# parity suite with the fork on.
+# Round 5, session 8 (record): the predictor front on a second stream next to the DBlocks (FD_EXP_FRONT_FORK=1), A/B inside one session, and the
+# parity suite with the fork on.  The experiment code lived in commit ed8f950 only (+0.6 %: LABBOOK R5.6); this script needs that commit.
 set -u
 mkdir -p gpurun_out/r5s8
 export TMPDIR=/tmp
