@@ -794,7 +794,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="configs1", choices=("configs1", "config4", "config5"))
-    ap.add_argument("--batch", type=int, default=None, help="utterances per fd_sample call: default 8 (config4: micro-batch size; config5: 16)")
+    ap.add_argument("--batch", type=int, default=None, help="utterances per fd_sample call: default 8 (config4: micro-batch size, default 16; config5: 16)")
     ap.add_argument("--frames", type=int, default=864)
     ap.add_argument("--nsteps", type=int, default=None, help="reverse steps N (3,4,6,8,200,1000); default 4 (config4: 6)")
     ap.add_argument("--no-roofline", action="store_true")
@@ -814,8 +814,8 @@ def main():
     args = ap.parse_args()
     if args.nsteps is None:
         args.nsteps = 6 if args.workload == "config4" else 4
-    if args.batch is None:
-        args.batch = 16 if args.workload == "config5" else 8
+    if args.batch is None:      # (config4 on one GPU: micro-batches of 16 take 64.0 ms per job, of 8 68.1 ms: profiles/r05/s9_config4_microbatch.txt)
+        args.batch = 16 if args.workload in ("config5", "config4") else 8
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
 
