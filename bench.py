@@ -519,51 +519,19 @@ def torch_eager_baseline(mel, rows, audio_s, reps=3):
 def host_inclusive(model, mel, rows, lens, audio_s, reps=20):
     """SURVEY.md 8d's wall clock: mel resident on the HOST -> int16 waveform resident on the HOST (pinned buffers, PCIe both ways,
     the waveform epilogue on the device).  Reported beside `value`, never as `value`: the boundary takes device pointers."""
-    from fastdiff_amd import infer
     mel_h = mel.cpu().pin_memory()
     B, _, T = mel.shape
-    pcm_hs = [torch.empty((B, T * HOP), dtype=torch.int16).pin_memory() for _ in range(2)]
-    pcm_h = pcm_hs[0]
-    # as infer.synthesize drives it: the two PCIe legs on copy streams of their own (FD_INFER_COPY_LANES=0: on the compute stream), two
-    # host PCM buffers used alternately -- call i's PCM is still travelling while call i + 1 computes
-    main = torch.cuda.current_stream()
-    up, down = infer._copy_lanes(model)
-    landed = [None, None]
+    pcm_h = torch.empty((B, T * HOP), dtype=torch.int16).pin_memory()
     with torch.no_grad():
         def one(i):
-            k = i & 1
-            if up is not None:
-                with torch.cuda.stream(up):
-                    m = mel_h.to(mel.device, non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record(up)
-                main.wait_event(ev)
-                m.record_stream(main)
-            else:
-                m = mel_h.to(mel.device, non_blocking=True)
+            m = mel_h.to(mel.device, non_blocking=True)
             wav = model.sample(m, rows, seed=i, lens=lens, defer_check=True)
-            pcm = model.peak_normalize_int16(wav)
-            if landed[k] is not None:
-                landed[k].synchronize()          # the consumer of this host buffer (two calls ago) has its PCM
-            landed[k] = torch.cuda.Event()
-            if down is not None:
-                ready = torch.cuda.Event()
-                ready.record(main)
-                with torch.cuda.stream(down):
-                    down.wait_event(ready)
-                    pcm_hs[k].copy_(pcm, non_blocking=True)
-                    landed[k].record(down)
-                pcm.record_stream(down)
-            else:
-                pcm_hs[k].copy_(pcm, non_blocking=True)
-                landed[k].record()
-            return model.last_ticket, wav, k
+            pcm_h.copy_(model.peak_normalize_int16(wav), non_blocking=True)
+            return model.last_ticket, wav
 
         def settle(prev):      # option fallback = host: a call that had to be redone on fp32 gets its epilogue and copy again
             if prev is not None and model.settle(prev[0]):
-                if landed[prev[2]] is not None:
-                    landed[prev[2]].synchronize()
-                pcm_hs[prev[2]].copy_(model.peak_normalize_int16(prev[1]), non_blocking=True)
+                pcm_h.copy_(model.peak_normalize_int16(prev[1]), non_blocking=True)
         one(0)
         model.check()
         torch.cuda.synchronize()
@@ -590,8 +558,7 @@ def host_inclusive(model, mel, rows, lens, audio_s, reps=20):
             dt = (time.perf_counter() - t0) / 10
             legs[name] = {"ms": round(dt * 1e3, 4), "GBps": round(nbytes / dt / 1e9, 2)}
     return {"ms_per_step": round(ms, 4), "value": round(audio_s / (ms / 1e3), 2), "unit": "x real-time",
-            "path": "pinned host mel -> device -> fd_sample -> fd_peak_normalize_int16 -> pinned host int16 PCM",
-            "copy_lanes": up is not None, "pcie": legs}
+            "path": "pinned host mel -> device -> fd_sample -> fd_peak_normalize_int16 -> pinned host int16 PCM", "pcie": legs}
 
 
 def b1_object(model, mel, rows, steps):

@@ -155,23 +155,6 @@ def _pinned_staging(model, n_mel: int, n_pcm: int):
     return pin
 
 
-# The two PCIe legs of a micro-batch (mel up, PCM down) run on streams of their own, so that the copy engines move micro-batch k + 1 in and
-# micro-batch k - 1 out while the compute stream vocodes micro-batch k.  FD_INFER_COPY_LANES=0 puts them back on the compute stream.
-COPY_LANES = os.environ.get("FD_INFER_COPY_LANES", "1") != "0"
-
-
-def _copy_lanes(model):
-    """(upload stream, download stream) kept on the model, or (None, None)."""
-    if not COPY_LANES:
-        return None, None
-    cache = _job_cache(model)
-    dev = torch.cuda.current_device()
-    lanes = cache.get("lanes")
-    if lanes is None or lanes[0] != dev:
-        lanes = cache["lanes"] = (dev, torch.cuda.Stream(), torch.cuda.Stream())
-    return lanes[1], lanes[2]
-
-
 def _collate_on_device(items: Sequence[dict], drop_last_frame: bool):
     """collate_test_batch for mels that already live on the GPU (the RCCL scatter of synthesize_sharded delivers them there):
     the same padded [B, 80, T'] batch, built with device copies -- no round trip over PCIe."""
@@ -223,8 +206,6 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
     # itself (FastDiff.settle); until then the waveform and everything computed from it is provisional
     host_check = getattr(model, "_options", {}).get("fallback") == "host"
     prev_dev = None                # return_device: (ticket, wav, names, lens) of the micro-batch nobody has settled yet
-    main = torch.cuda.current_stream()
-    lane_up, lane_down = _copy_lanes(model) if not (on_device and return_device) else (None, None)
 
     def settle_on_device(p):
         # the library remembers a bounded number of redone tickets (fd_sample_settle), so a micro-batch is settled as soon as the
@@ -258,17 +239,9 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
         uid_of = {items[i]["item_name"]: int(items[i].get("uid", i)) for i in batch_idx}
         B, _, T = mels.shape
         if not on_device:
-            if lane_up is not None:      # the upload on its own stream; the compute stream waits for it, the allocator is told who reads the tensor
-                with torch.cuda.stream(lane_up):
-                    mels = mel_pin[k & 1][: B * 80 * T].view(B, 80, T).cuda(non_blocking=True)
-                    mel_up[k & 1] = torch.cuda.Event()
-                    mel_up[k & 1].record(lane_up)
-                main.wait_event(mel_up[k & 1])
-                mels.record_stream(main)
-            else:
-                mels = mel_pin[k & 1][: B * 80 * T].view(B, 80, T).cuda(non_blocking=True)
-                mel_up[k & 1] = torch.cuda.Event()
-                mel_up[k & 1].record()
+            mels = mel_pin[k & 1][: B * 80 * T].view(B, 80, T).cuda(non_blocking=True)
+            mel_up[k & 1] = torch.cuda.Event()
+            mel_up[k & 1].record()
         with torch.no_grad():
             wav = model.sample(mels, rows, ddim=False, seed=seed, lens=lens, stream_ids=[uid_of[n] for n in names], defer_check=host_check)
         ticket = getattr(model, "last_ticket", 0)
@@ -283,18 +256,9 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
             k += 1
             continue
         host = pcm_pin[k & 1][: B * T * hop].view(B, T * hop)
+        host.copy_(pcm, non_blocking=True)
         done = torch.cuda.Event()
-        if lane_down is not None:        # the download on its own stream, behind the epilogue
-            ready = torch.cuda.Event()
-            ready.record(main)
-            with torch.cuda.stream(lane_down):
-                lane_down.wait_event(ready)
-                host.copy_(pcm, non_blocking=True)
-                done.record(lane_down)
-            pcm.record_stream(lane_down)
-        else:
-            host.copy_(pcm, non_blocking=True)
-            done.record()
+        done.record()
         if pending is not None:
             collect(pending)
         pending = (done, host, names, lens, ticket, wav)

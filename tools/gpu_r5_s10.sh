@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round 5, session 10: the two PCIe legs of a micro-batch on copy streams of their own (infer.synthesize, bench host_inclusive): A/B through
-# FD_INFER_COPY_LANES, then the driver / sharding tests with the lanes on.
+# Round 5, session 10 (record): the two PCIe legs of a micro-batch on copy streams of their own, A/B through FD_INFER_COPY_LANES.  The code
+# lived in the commit before this note only (slower by 1 %: LABBOOK R5.7); this script needs that commit.
 set -u
 mkdir -p gpurun_out/r5s10
 O=$GRAFT_REPO_ROOT/gpurun_out/r5s10
