@@ -900,8 +900,11 @@ __device__ __forceinline__ f32x4 mfma16(const float4 &a, const float4 &b, f32x4 
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(ua.h, ub.h, c, 0, 0, 0);
 }
 
+#ifndef FD_H8M_OCC
+#define FD_H8M_OCC 2      // workgroups per CU the register budget is cut for (the kernel needs 166 VGPRs: three fit; 4 = 128 VGPRs, probe of session 12)
+#endif
 template <int DIL>
-__global__ void __launch_bounds__(256, 2) k_lvc_h8m(const float *__restrict__ xin, const float *__restrict__ skip, float *__restrict__ xout,
+__global__ void __launch_bounds__(256, FD_H8M_OCC) k_lvc_h8m(const float *__restrict__ xin, const float *__restrict__ skip, float *__restrict__ xout,
                                                     const float *__restrict__ kpack, int layer, const float4 *__restrict__ wpack16,
                                                     const float *__restrict__ wref, const float *__restrict__ cbias,
                                                     int *__restrict__ range_flag, int T, const int *__restrict__ lens)
