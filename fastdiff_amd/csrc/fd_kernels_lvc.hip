@@ -900,11 +900,8 @@ __device__ __forceinline__ f32x4 mfma16(const float4 &a, const float4 &b, f32x4 
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(ua.h, ub.h, c, 0, 0, 0);
 }
 
-#ifndef FD_H8M_OCC
-#define FD_H8M_OCC 2      // workgroups per CU the register budget is cut for (the kernel needs 166 VGPRs: three fit; 4 = 128 VGPRs, probe of session 12)
-#endif
 template <int DIL>
-__global__ void __launch_bounds__(256, FD_H8M_OCC) k_lvc_h8m(const float *__restrict__ xin, const float *__restrict__ skip, float *__restrict__ xout,
+__global__ void __launch_bounds__(256, 2) k_lvc_h8m(const float *__restrict__ xin, const float *__restrict__ skip, float *__restrict__ xout,
                                                     const float *__restrict__ kpack, int layer, const float4 *__restrict__ wpack16,
                                                     const float *__restrict__ wref, const float *__restrict__ cbias,
                                                     int *__restrict__ range_flag, int T, const int *__restrict__ lens)
@@ -925,50 +922,22 @@ __global__ void __launch_bounds__(256, FD_H8M_OCC) k_lvc_h8m(const float *__rest
     // (a) the frame's predicted kernel, fp32, in the A-operand order of the 16x16x32 tiles: [mt][half][tap] x 8 consecutive k
     float4 ka[2][2][3][2];
     float4 bz[2][2];
-    // (c) conv weights of this wave's 16-row tile: A operand pieces [row tile][tap][piece][lane] x 8 fp16 (L2); the halo outputs' fp32 weights
-    const int rt = wave & 1, ctl = wave >> 1;
-    const int hside = tid >> 7, ho = (tid & 127) >> 2, hq = tid & 3;
-    float4 wa[3][2], cb4, hwt[6];
-    float hbias;
-    auto load_conv_weights = [&]() {
+    if (frame_valid) {
+        const float *rec = kpack + ((int64_t)b * T + f) * fd::KREC;
+        const float4 *kp4 = reinterpret_cast<const float4 *>(rec + layer * fd::KLAYER);
 #pragma unroll
-        for (int tap = 0; tap < 3; ++tap)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) wa[tap][p] = wpack16[((rt * 3 + tap) * 2 + p) * 64 + lane];
-        cb4 = *reinterpret_cast<const float4 *>(cbias + 16 * rt + 4 * g4);
-    };
-    auto load_halo_weights = [&]() {
+            for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) hwt[j] = reinterpret_cast<const float4 *>(wref + (ho * fd::C + 8 * hq) * 3)[j];
-        hbias = cbias[ho];
-    };
-    auto load_record = [&]() {
-#ifdef FD_H8M_XFIRST
-        {   // (no branch around the loads: a wave behind the utterance's end reads the last valid frame's record and never uses it --
-            //  straight-line code lets the compiler wait for the x / skip loads alone, vmcnt(#record loads), in front of the staging)
-            const float *rec = kpack + ((int64_t)b * T + min(f, Tb - 1)) * fd::KREC;
-#else
-        if (frame_valid) {
-            const float *rec = kpack + ((int64_t)b * T + f) * fd::KREC;
-#endif
-            const float4 *kp4 = reinterpret_cast<const float4 *>(rec + layer * fd::KLAYER);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-                    for (int tap = 0; tap < 3; ++tap) {
-                        const int e8 = (mt * 6 + 2 * tap + (g4 >> 1)) * 64 + 16 * hf + c16 + 32 * (g4 & 1);
-                        ka[mt][hf][tap][0] = lvc_ld<128>(kp4 + 2 * e8);          // (bit 128: a hop-8 record has exactly one reader, this wave)
-                        ka[mt][hf][tap][1] = lvc_ld<128>(kp4 + 2 * e8 + 1);
-                    }
-                    bz[mt][hf] = *reinterpret_cast<const float4 *>(rec + fd::KW + layer * 64 + mt * 32 + 16 * hf + 4 * g4);
+                for (int tap = 0; tap < 3; ++tap) {
+                    const int e8 = (mt * 6 + 2 * tap + (g4 >> 1)) * 64 + 16 * hf + c16 + 32 * (g4 & 1);
+                    ka[mt][hf][tap][0] = lvc_ld<128>(kp4 + 2 * e8);          // (bit 128: a hop-8 record has exactly one reader, this wave)
+                    ka[mt][hf][tap][1] = lvc_ld<128>(kp4 + 2 * e8 + 1);
                 }
-        }
-    };
-#ifndef FD_H8M_XFIRST
-    load_record();
-#endif
+                bz[mt][hf] = *reinterpret_cast<const float4 *>(rec + fd::KW + layer * 64 + mt * 32 + 16 * hf + 4 * g4);
+            }
+    }
     // (b) x + skip with halo: thread = (channel quad, column quad)
     {
         const int q = tid / NQ, c4 = tid - q * NQ, g = w0 - H + 4 * c4;
@@ -980,15 +949,6 @@ __global__ void __launch_bounds__(256, FD_H8M_OCC) k_lvc_h8m(const float *__rest
             xa[c] = ok ? *reinterpret_cast<const float4 *>(xp + (int64_t)c * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
             sa[c] = ok ? *reinterpret_cast<const float4 *>(sp + (int64_t)c * Ln + g) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-#ifdef FD_H8M_XFIRST      // probe (session 13): x, skip and the conv weights requested in FRONT of the record, so that staging and conv
-        __builtin_amdgcn_sched_barrier(0);      // (vmcnt retires in order) do not wait for its 24.8 KB
-#if FD_H8M_XFIRST >= 2
-        load_conv_weights();
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        load_record();
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         if (unit) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -1010,10 +970,19 @@ __global__ void __launch_bounds__(256, FD_H8M_OCC) k_lvc_h8m(const float *__rest
             }
         }
     }
-#if !defined(FD_H8M_XFIRST) || FD_H8M_XFIRST < 2
-    load_conv_weights();
-#endif
-    load_halo_weights();      // (behind the record in every order: the halo outputs are needed where the record is, in front of the LVC phase)
+    // (c) conv weights of this wave's 16-row tile: A operand pieces [row tile][tap][piece][lane] x 8 fp16 (L2)
+    const int rt = wave & 1, ctl = wave >> 1;
+    float4 wa[3][2];
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) wa[tap][p] = wpack16[((rt * 3 + tap) * 2 + p) * 64 + lane];
+    const float4 cb4 = *reinterpret_cast<const float4 *>(cbias + 16 * rt + 4 * g4);
+    const int hside = tid >> 7, ho = (tid & 127) >> 2, hq = tid & 3;
+    float4 hwt[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) hwt[j] = reinterpret_cast<const float4 *>(wref + (ho * fd::C + 8 * hq) * 3)[j];
+    const float hbias = cbias[ho];
     __syncthreads();
     // ---- dilated conv: wave = (16 output channels, 16 columns); y = leaky_relu(conv) goes to the y image as pieces ----------------
     {

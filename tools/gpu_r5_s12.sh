@@ -1,7 +1,6 @@
 #!/bin/bash
-# Round 5, session 12: the hop-8 LVC layer at four workgroups per CU (128 VGPRs, 156 B of scratch per lane) instead of three (166 VGPRs):
-# 1728 workgroups are 2.25 rounds of 768 slots -- three latency-bound rounds of ~14 us -- and 1.7 rounds of 1024.
-set -u
+# Round 5, session 12 (record): the hop-8 LVC layer at four workgroups per CU (probe macro FD_H8M_OCC, in the history only: commit 8f3c0a1..;
+# LABBOOK R5.8).
 mkdir -p gpurun_out/r5s12
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

@@ -1,8 +1,5 @@
 #!/bin/bash
-# Round 5, session 13: load order of the hop-8 LVC layer.  vmcnt retires in order, so whatever is requested behind the frame's 24.8 KB record
-# waits for it: x / skip requested in FRONT of the record (x1: staging no longer waits), the conv weights too (x2: 190 VGPRs, two workgroups
-# per CU; x2o3: held to three with 84 B of scratch per lane).  Results must be bit-equal (same arithmetic).
-set -u
+# Round 5, session 13 (record): load order of the hop-8 LVC layer (probe macro FD_H8M_XFIRST, in the history only; LABBOOK R5.8).
 mkdir -p gpurun_out/r5s13
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
