@@ -1,6 +1,7 @@
 #!/bin/bash
-# Round 5, session 12 (record): the hop-8 LVC layer at four workgroups per CU (probe macro FD_H8M_OCC, in the history only: commit 8f3c0a1..;
+# Round 5, session 12 (record): the hop-8 LVC layer at four workgroups per CU (probe macro FD_H8M_OCC, in the history only: commits 79c419f, 8cea3b3;
 # LABBOOK R5.8).
+set -u
 mkdir -p gpurun_out/r5s12
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

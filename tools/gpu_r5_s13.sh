@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round 5, session 13 (record): load order of the hop-8 LVC layer (probe macro FD_H8M_XFIRST, in the history only; LABBOOK R5.8).
+set -u
 mkdir -p gpurun_out/r5s13
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
