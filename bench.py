@@ -733,6 +733,68 @@ def run_config5(args, model):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def stream_items(seed=4321, n=256, t_lo=200, t_hi=864):
+    """The reference CLI's own call pattern (modules/FastDiff/task/FastDiff.py:97-103 with config/base.yaml:53 max_valid_sentences 1,
+    tasks/vocoder/dataset_utils.py:114-125): one utterance per sampling call and a DIFFERENT length each time.  n utterances whose
+    lengths are all distinct, drawn without replacement from {t_lo..t_hi} (seeded), in the order of arrival."""
+    g = torch.Generator().manual_seed(seed)
+    lens = (torch.randperm(t_hi - t_lo + 1, generator=g)[:n] + t_lo).tolist()
+    return [{"item_name": "req%03d" % i, "mel": torch.rand(t, 80, generator=g) * 7.5 - 6.0, "len": t} for i, t in enumerate(lens)]
+
+
+def run_stream(args, model):
+    """One step = one pass over the whole stream of 256 requests, host mel -> host int16 PCM (infer.synthesize: pinned staging, the
+    int16 epilogue on the device, the previous request collected while the next one runs).  Legs:
+      b1 / b1_again   one request per fd_sample call in the order of arrival, first pass and a second pass over the same stream (what
+                      the graph cache has kept by then is all the difference between the two);
+      b1_no_graph     the same with option graph = 0 (every kernel launched by itself: nothing to capture, nothing to miss);
+      b8              length-sorted micro-batches of 8 (padded, `lens`): 32 calls;
+      fixed           the control: 256 calls of ONE length (the stream's mean), i.e. every call replays a warm graph."""
+    from fastdiff_amd import infer
+    items = stream_items(n=args.stream_requests)
+    N = args.nsteps
+    lens = [it["len"] for it in items]
+    frames = sum(lens)
+    audio_s = frames * HOP / SR
+    t_mean = int(round(frames / len(lens)))
+    fixed = [{"item_name": "fix%03d" % i, "mel": items[i]["mel"].new_empty(t_mean, 80).uniform_(-6.0, 1.5), "len": t_mean} for i in range(len(items))]
+
+    def one_pass(its, batch, seed, sort):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = infer.synthesize(model, its, n_steps=N, max_batch=batch, seed=seed, drop_last_frame=False, sort=sort)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert len(out) == len(its)
+        for it in its[:: max(1, len(its) // 8)]:
+            a = out[it["item_name"]]
+            assert a.shape == (it["len"] * HOP,) and int(abs(a).max()) == 32767, it["item_name"]
+        return dt
+
+    def leg(its, batch, sort, passes, audio):
+        ts = [one_pass(its, batch, 7 + k, sort) for k in range(passes)]
+        return {"ms_per_request": [round(t / len(its) * 1e3, 4) for t in ts], "rtf": [round(audio / t, 1) for t in ts]}
+
+    res = {"requests": len(items), "frames_min_mean_max": [min(lens), t_mean, max(lens)], "distinct_lengths": len(set(lens)),
+           "reverse_steps": N, "audio_s": round(audio_s, 2)}
+    one_pass(fixed[:4], 1, 1, False)                      # the library's buffers and the pinned staging at their final size
+    one_pass(sorted(items, key=lambda it: -it["len"])[:1], 1, 1, False)
+    res["fixed_shape_control"] = leg(fixed, 1, False, 2, t_mean * len(fixed) * HOP / SR)
+    res["b1"] = leg(items, 1, False, 3, audio_s)
+    res["b8"] = leg(items, 8, True, 3, audio_s)
+    model.set_option("graph", "0")
+    res["b1_no_graph"] = leg(items, 1, False, 2, audio_s)
+    res["b8_no_graph"] = leg(items, 8, True, 2, audio_s)
+    model.set_option("graph", "0" if args.no_graph else "1")
+    try:
+        res["graph_cache"] = {k: model.counter(k) for k in ("graph_captures", "graph_hits", "graph_evictions", "graphs_resident")}
+    except Exception as e:      # noqa: BLE001 -- a library without these counters
+        res["graph_cache"] = {"error": repr(e)[:100]}
+    # the headline of this workload: the LAST pass of the one-request-per-call leg (steady state of a long-running server / test set)
+    elapsed = res["b1"]["ms_per_request"][-1] * len(items) / 1e3
+    return elapsed, frames, res
+
+
 def project_sharded(args, model, items, t_full, dev):
     """A PROJECTION, labelled as one (a gpurun box has one GPU): what a `project_ranks`-GPU run of this job would take, from pieces
     measured here.  t_share = the slowest of the R shares the LPT partition hands out, each run through the same per-rank code
@@ -793,7 +855,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="configs1", choices=("configs1", "config4", "config5"))
+    ap.add_argument("--workload", default="configs1", choices=("configs1", "config4", "config5", "stream"))
+    ap.add_argument("--stream-requests", type=int, default=256, help="--workload stream: number of requests (all lengths distinct)")
     ap.add_argument("--batch", type=int, default=None, help="utterances per fd_sample call: default 8 (config4: micro-batch size, default 16; config5: 16)")
     ap.add_argument("--frames", type=int, default=864)
     ap.add_argument("--nsteps", type=int, default=None, help="reverse steps N (3,4,6,8,200,1000); default 4 (config4: 6)")
@@ -877,7 +940,16 @@ def main():
             dist.barrier() if oversub else dist.barrier(device_ids=[local_rank])
 
     lens = None
-    if args.workload == "config5":
+    if args.workload == "stream":
+        if world != 1:
+            raise SystemExit("bench.py: --workload stream is a one-GPU workload")
+        elapsed, frames, projection = run_stream(args, model)
+        args.steps = 1
+        total_frames, padded_frames = frames, frames
+        scaling = "weak"
+        B, T = 1, projection["frames_min_mean_max"][2]
+        workload = "reference CLI pattern: %d requests, 1 utterance per call, every T distinct in {200..864}, N=%d, host mel -> host PCM" % (projection["requests"], N)
+    elif args.workload == "config5":
         if world != 1:
             raise SystemExit("bench.py: --workload config5 is BASELINE configs[4], a one-GPU configuration")
         elapsed, frames, projection = run_config5(args, model)
@@ -939,9 +1011,10 @@ def main():
         "config": {"workload": workload,
                    "batch_per_gpu": B, "frames": T, "reverse_steps": N,
                    "sharding": ("utterances/rank, no data-path collective" if args.workload == "configs1" else
-                                "one GPU" if args.workload == "config5" else "LPT partition, one packed p2p message per peer each way (RCCL)"),
+                                "one GPU" if args.workload in ("config5", "stream") else "LPT partition, one packed p2p message per peer each way (RCCL)"),
                    "value_is": ("HBM-resident mel -> HBM waveform (bench contract); SURVEY 8d host-to-host = value_host_to_host" if args.workload == "configs1"
-                                else "files of a directory -> host int16 PCM" if args.workload == "config5" else "host mel -> host int16 PCM (rank 0)"),
+                                else "files of a directory -> host int16 PCM" if args.workload == "config5"
+                                else "host mel -> host int16 PCM, last pass of the one-request-per-call leg" if args.workload == "stream" else "host mel -> host int16 PCM (rank 0)"),
                    "graph": not args.no_graph, "weights": "random init seed 1234 (no checkpoint offline)",
                    "range_fallback": ("host-checked, pipelined (each call looked at after the next is enqueued, the last inside the timed region)"
                                       if model._options.get("fallback") == "host" else "in-graph fp32 twin behind every fp16x2 kernel"),
@@ -961,6 +1034,12 @@ def main():
             line["projection" if world == 1 else "sharded_job_check"] = projection
         if args.workload == "config5":
             line["config5"] = projection
+        if args.workload == "stream":
+            line["stream"] = projection
+            line["stream_b1_ms"], line["stream_b1_rtf"] = projection["b1"]["ms_per_request"][-1], projection["b1"]["rtf"][-1]
+            line["stream_b1_first_pass_ms"] = projection["b1"]["ms_per_request"][0]
+            line["stream_b8_ms"], line["stream_b1_no_graph_ms"] = projection["b8"]["ms_per_request"][-1], projection["b1_no_graph"]["ms_per_request"][-1]
+            line["stream_fixed_shape_ms"] = projection["fixed_shape_control"]["ms_per_request"][-1]
     if rank == 0 and world == 1 and args.workload == "configs1":
         use_lens = None if args.no_lens else lens
         if not args.no_host_io:

@@ -4,9 +4,9 @@
  *
  *   cc -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/c_host.c -o examples/c_host \
  *      -Lfastdiff_amd/lib -lfastdiff_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/fastdiff_amd/lib -Wl,-rpath,/opt/rocm/lib
- *   examples/c_host job.bin out.f32 [pad_MiB]
+ *   examples/c_host job.bin out.f32 [pad_MiB [key=value,...]]
  *   (pad_MiB, optional: reserve that much device memory before anything else -- a testing aid that moves the addresses of everything
- *   the library allocates afterwards; tools/xproc_hunt.py uses it)
+ *   the library allocates afterwards; tools/xproc_hunt.py uses it.  key=value,...: library options, fd_set_option)
  *
  * job.bin (little endian, written by tests/test_c_host.py):
  *   int32 n_tensors; per tensor: int32 name_len, name bytes, int32 ndim, int64 dims[ndim], float data[]      -- the state_dict
@@ -18,7 +18,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <string.h>
+
 #include "fastdiff_hip.h"
+#include "fastdiff_hip_ext.h"      /* fd_get_counter: only to SHOW what the range check did; the sampling itself needs fastdiff_hip.h alone */
 
 #define DIE(...) do { fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); exit(1); } while (0)
 #define HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) DIE("%s: %s", #x, hipGetErrorString(e_)); } while (0)
@@ -28,10 +31,10 @@ static void rd(FILE *f, void *dst, size_t n) { if (fread(dst, 1, n, f) != n) DIE
 
 int main(int argc, char **argv)
 {
-    if (argc != 3 && argc != 4) DIE("usage: %s job.bin out.f32 [pad_MiB]", argv[0]);
+    if (argc < 3 || argc > 5) DIE("usage: %s job.bin out.f32 [pad_MiB [key=value,...]]", argv[0]);
     FILE *f = fopen(argv[1], "rb");
     if (!f) DIE("cannot open %s", argv[1]);
-    if (argc == 4 && atol(argv[3]) > 0) {
+    if (argc >= 4 && atol(argv[3]) > 0) {
         void *pad;
         HIP(hipMalloc(&pad, (size_t)atol(argv[3]) << 20));      /* kept until exit */
     }
@@ -40,6 +43,18 @@ int main(int argc, char **argv)
     fd_handle h = NULL;
     fd_default_config(&cfg);
     FD(NULL, fd_create(&cfg, 0, &h));
+    if (fd_abi_revision() < 2) DIE("this host reads fd_sample's result without fd_sample_check: it needs ABI revision >= 2");
+    if (argc == 5) {
+        char *opts = (char *)malloc(strlen(argv[4]) + 1);      /* (strdup is not C99) */
+        strcpy(opts, argv[4]);
+        for (char *kv = strtok(opts, ","); kv; kv = strtok(NULL, ",")) {
+            char *eq = strchr(kv, '=');
+            if (!eq) DIE("option '%s' is not key=value", kv);
+            *eq = 0;
+            FD(h, fd_set_option(h, kv, eq + 1));
+        }
+        free(opts);
+    }
 
     int32_t n_tensors;
     rd(f, &n_tensors, 4);
@@ -84,10 +99,10 @@ int main(int argc, char **argv)
 
     hipStream_t stream;
     HIP(hipStreamCreate(&stream));
+    /* call, synchronise, read -- the reference's contract (util.py:215-235).  With the library's defaults fd_sample has looked at its own
+     * fp16-range check by the time it returns (and has run the call again on the fp32 kernels if an operand did not fit): nothing else
+     * to call before out_d is read.  (The pipelined form -- option defer_check = 1, fd_sample_settle -- is opt-in.) */
     FD(h, fd_sample(h, mel_d, B, T, NULL, table, N, ddim, xT_d, z_d, 0, out_d, NULL, stream));
-    /* the result is provisional until the call's fp16-range check has been looked at: fd_sample_check waits for the call and, if an
-     * operand left the fp16 range, runs it again on the fp32 kernels (returns 1 then, 0 otherwise) -- mandatory before reading out_d */
-    if (fd_sample_check(h) < 0) DIE("fd_sample_check: %s", fd_last_error(h));
     HIP(hipStreamSynchronize(stream));
     HIP(hipMemcpy(host, out_d, sizeof(float) * n_x, hipMemcpyDeviceToHost));
 
@@ -96,7 +111,8 @@ int main(int argc, char **argv)
     fclose(o);
     double acc = 0.0;
     for (size_t i = 0; i < n_x; ++i) acc += host[i] >= 0 ? host[i] : -host[i];
-    printf("%s: B=%d T=%d N=%d  mean|x_0| = %.6f\n", fd_version(), B, T, N, acc / (double)n_x);
+    printf("%s: B=%d T=%d N=%d  mean|x_0| = %.6f  calls_redone=%lld\n", fd_version(), B, T, N, acc / (double)n_x,
+           (long long)fd_get_counter(h, "calls_redone"));
     FD(h, fd_destroy(h));
     return 0;
 }

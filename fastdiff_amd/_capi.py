@@ -1,4 +1,4 @@
-"""ctypes binding of libfastdiff_hip.so (include/fastdiff_hip.h).  No torch types cross this boundary."""
+"""ctypes binding of libfastdiff_hip.so (include/fastdiff_hip.h, fastdiff_hip_ext.h, fastdiff_hip_train.h).  No torch types cross this boundary."""
 import ctypes as ct
 import os
 
@@ -25,9 +25,18 @@ class FdKernelStat(ct.Structure):
     _fields_ = [("name", ct.c_char * 48), ("launches", ct.c_int64), ("total_ms", ct.c_double)]
 
 
+def step_table(rows):
+    """[{t, c_eps, c_div, sigma, c1, c2, c3, add_noise}] (executed first -> last) -> the fd_step array fd_sample takes."""
+    steps = (FdStep * len(rows))()
+    for k, row in enumerate(rows):
+        steps[k] = FdStep(float(row["t"]), float(row["c_eps"]), float(row["c_div"]), float(row["sigma"]),
+                          float(row["c1"]), float(row["c2"]), float(row["c3"]), int(row["add_noise"]))
+    return steps
+
+
 EXPORTS = ["fd_default_config", "fd_create", "fd_destroy", "fd_last_error", "fd_set_weight", "fd_commit_weights",
            "fd_forward", "fd_sample", "fd_sample_check", "fd_sample_ticket", "fd_sample_settle", "fd_set_noise_streams", "fd_peak_normalize_int16", "fd_peak_normalize_int16_ragged", "fd_mel_spectrogram", "fd_set_mel_filterbank", "fd_get_mel_filterbank", "fd_lvc_forward", "fd_lvc_backward", "fd_lvc_forward_strided", "fd_lvc_backward_strided", "fd_gate_forward", "fd_gate_backward", "fd_kconv_forward", "fd_kconv_backward", "fd_weight_norm_multi_forward", "fd_weight_norm_multi_backward", "fd_fan_forward", "fd_fan_backward", "fd_input_conv_forward", "fd_input_conv_backward", "fd_kconv_backward_w_multi", "fd_kconv_forward_act_multi", "fd_kconv_backward_x_multi", "fd_input_conv_forward_multi", "fd_input_conv_backward_multi", "fd_kconv_forward_act", "fd_kconv_backward_act", "fd_kconv_forward_frames", "fd_kconv_backward_frames", "fd_lvc_forward_frames", "fd_lvc_backward_frames", "fd_conv32_forward", "fd_conv32_backward", "fd_weight_norm_forward", "fd_weight_norm_backward", "fd_conv7_forward", "fd_conv7_backward", "fd_upsample_forward", "fd_upsample_backward", "fd_set_option", "fd_read_tap", "fd_kernel_index", "fd_bias_index",
-           "fd_get_profile", "fd_reset_profile", "fd_get_counter", "fd_version"]
+           "fd_get_profile", "fd_reset_profile", "fd_get_counter", "fd_version", "fd_abi_revision"]
 
 _lib = None
 

@@ -133,7 +133,9 @@ static int64_t numel(const std::vector<int64_t> &d)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-const char *fd_version(void) { return "fastdiff_hip 0.1 (gfx950)"; }
+const char *fd_version(void) { return "fastdiff_hip 0.2 (gfx950)"; }
+// 2: fd_sample settles its own range check before returning unless option defer_check = 1 (revision 1: always deferred)
+int fd_abi_revision(void) { return 2; }
 
 int fd_default_config(fd_config *cfg)
 {
@@ -219,13 +221,31 @@ static void free_workspace(fd_context *c)
     w = Workspace();
 }
 
-static void drop_graph(fd_context *c)
+// Destroys the retired graphs whose last launch has completed (all of them when `wait`: the caller has synchronised the device).
+static void reap_retired(fd_context *c, bool wait)
 {
+    for (size_t i = 0; i < c->retired.size();) {
+        fd_context::RetiredGraph &r = c->retired[i];
+        if (!wait && r.done && hipEventQuery(r.done) != hipSuccess) { (void)hipGetLastError(); ++i; continue; }
+        if (r.exec) hipGraphExecDestroy(r.exec);
+        if (r.graph) hipGraphDestroy(r.graph);
+        if (r.done) hipEventDestroy(r.done);
+        c->retired.erase(c->retired.begin() + i);
+    }
+}
+
+// Drops every captured graph.  synced: the caller has just synchronised the device (workspace growth, fd_commit_weights, fd_destroy);
+// otherwise (an option that changes what a step launches) the device is synchronised here -- a replay may still be queued, and the
+// stream it is queued on may be gone by now, so there is nothing to record an event on.
+static void drop_graph(fd_context *c, bool synced = false)
+{
+    if (!synced && !(c->graphs.empty() && c->retired.empty())) hipDeviceSynchronize();
     for (auto &g : c->graphs) {
         if (g.exec) hipGraphExecDestroy(g.exec);
         if (g.graph) hipGraphDestroy(g.graph);
     }
     c->graphs.clear();
+    reap_retired(c, true);
 }
 
 // Frees everything a handle owns (each member is null until created): the tail of fd_destroy and the failure path of fd_create.
@@ -236,7 +256,7 @@ static void release_handle(fd_context *h)
     if (h->flags_done) hipEventDestroy(h->flags_done);
     if (h->flags_done2) hipEventDestroy(h->flags_done2);
     for (auto ev : h->event_pool) hipEventDestroy(ev);
-    drop_graph(h);
+    drop_graph(h, true);
     free_workspace(h);
     for (void *p : h->dev_allocs) hipFree(p);
     if (h->scratch) hipFree(h->scratch);
@@ -435,10 +455,11 @@ int fd_commit_weights(fd_handle h)
     }
     h->embed_valid = false;
     FD_HIP(h, hipDeviceSynchronize());
+    h->committed = false;            // until the new set is complete: a failed re-commit must not leave the old flag over freed weights
     for (void *p : h->dev_allocs) hipFree(p);
     h->dev_allocs.clear();
     h->w = DevWeights();
-    drop_graph(h);
+    drop_graph(h, true);
 
     std::map<std::string, Folded> f;
     for (const auto &s : param_specs(h->cfg)) {
@@ -717,7 +738,7 @@ static int ensure_workspace(fd_context *h, int B, int T, int pmult = 1)
     const int64_t frames = (int64_t)B * T, rows = (int64_t)B * gx_rows_host(T);
     if (workspace_fits(h, B, T, pmult)) return FD_OK;
     FD_HIP(h, hipDeviceSynchronize());
-    drop_graph(h);
+    drop_graph(h, true);
     // grow to the largest of each quantity seen so far, so that alternating shapes settle; if that does not fit, this call's own
     // needs alone are tried before giving up
     const int64_t own[6] = {B, frames, rows, frames * pmult, rows * pmult, (int64_t)B * pmult};
@@ -1031,18 +1052,24 @@ static int enqueue_steps(fd_handle h, int B, int T, int count, unsigned fp32_mas
             if (g.B == B && g.T == T && g.sig == sig && g.steps == steps) {
                 g.last_use = ++h->graph_clock;
                 *out = g.exec;
+                ++h->n_graph_hits;
                 return FD_OK;
             }
-        constexpr size_t FD_MAX_GRAPHS = 16;
-        if (h->graphs.size() >= FD_MAX_GRAPHS) {        // evict the least recently used one (it may still be running)
+        reap_retired(h, false);
+        while (h->graphs.size() >= (size_t)std::max(1, h->max_graphs)) {
+            // evict the least recently used one.  It may still be running (or be queued behind the work on `stream`): retired with an
+            // event recorded here, destroyed by a later call once that event has completed -- no wait on this path
             size_t lru = 0;
             for (size_t i = 1; i < h->graphs.size(); ++i)
                 if (h->graphs[i].last_use < h->graphs[lru].last_use) lru = i;
-            FD_HIP(h, hipStreamSynchronize(stream));
-            hipGraphExecDestroy(h->graphs[lru].exec);
-            hipGraphDestroy(h->graphs[lru].graph);
+            fd_context::RetiredGraph r = {h->graphs[lru].graph, h->graphs[lru].exec, nullptr};
+            FD_HIP(h, hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
+            FD_HIP(h, hipEventRecord(r.done, stream));
+            h->retired.push_back(r);
             h->graphs.erase(h->graphs.begin() + lru);
+            ++h->n_graph_evictions;
         }
+        ++h->n_graph_captures;
         FD_HIP(h, hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
         fdk::Launch Lc = {h, h->cap_stream, true};
         hipError_t ec = h->hoist_chunk ? piece_predictor(Lc, steps) : hipSuccess;
@@ -1085,6 +1112,17 @@ static int enqueue_steps(fd_handle h, int B, int T, int count, unsigned fp32_mas
 
 static int sample_core(fd_handle h, const fd_context::SampleArgs &a, unsigned force_mask, long long ticket);
 
+// Frames of the library's own buffers for a sample call of T frames (fd_context::t_bucket): T rounded up to the bucket when the call
+// is replayed from graphs and every stage runs the kernel set that honours `lens`; T itself otherwise.
+static int bucket_frames(const fd_context *h, int T)
+{
+    if (h->t_bucket <= 1 || !h->use_graph || h->profile || h->keep_taps) return T;
+    for (int i = ST_FIRST; i < ST_COUNT; ++i)
+        if (!h->fast[i]) return T;
+    const int64_t tp = ((int64_t)T + h->t_bucket - 1) / h->t_bucket * h->t_bucket;
+    return tp > 0x3fffffff ? T : (int)tp;
+}
+
 // How many reverse steps' kernels one predictor launch pair computes for this call: N (hoisted) or 1 (the predictor stays in the step)
 static int hoist_mult(const fd_context *h, int B, int T, int N)
 {
@@ -1124,7 +1162,10 @@ static int resolve_call(fd_handle h, const fd_context::PendingCall &p, unsigned 
     if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample_check: %s", hipGetErrorString(e));
     int rc = enqueue_steps(h, p.B, p.T, p.count, *mask, true, p.stream);
     if (rc != FD_OK) return rc;
-    if (p.first + p.count == p.N) FD_HIP(h, hipMemcpyAsync(p.out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, p.stream));
+    if (p.first + p.count == p.N) {
+        e = fdk::copy_rows(L, p.out, (int64_t)p.T_io * fd::HOPT, ws.x, (int64_t)p.T * fd::HOPT, p.T_io * fd::HOPT, p.B);
+        if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample_check: %s", hipGetErrorString(e));
+    }
     return 1;
 }
 
@@ -1140,18 +1181,23 @@ static int resolve_pending(fd_handle h, unsigned *mask)
 static int sample_core(fd_handle h, const fd_context::SampleArgs &a, unsigned force_mask, long long ticket)
 {
     int rc;
-    const int B = a.B, T = a.T, N = a.N;
+    // T: frames of the library's buffers (the caller's T_io rounded up to the bucket); the caller's tensors keep their dense T_io layout
+    const int B = a.B, T_io = a.T, T = bucket_frames(h, a.T), N = a.N;
+    const int64_t L_io = (int64_t)T_io * fd::HOPT, Lp = (int64_t)T * fd::HOPT;
     hipStream_t stream = a.stream;
     Workspace &ws = h->ws;
     const size_t n_el = (size_t)B * T * fd::HOPT;
     const std::vector<unsigned long long> &ids = a.ids;
+    std::vector<int> own_lens;                  // a bucketed call without `lens`: every utterance is T_io of the T frames long
+    const int *lens_eff = a.has_lens ? a.lens.data() : nullptr;
+    if (!lens_eff && T != T_io) { own_lens.assign(B, T_io); lens_eff = own_lens.data(); }
     // per-call parameters -> device block the captured kernels read.  Staged through the pinned ring: the call returns
     // without waiting for the stream, so the host prepares the next call while this one runs.
     {
         fd_context::StageSlot *sl = nullptr;
         const size_t off_lens = sizeof(StepParams), off_ids = off_lens + ((sizeof(int) * B + 7) & ~(size_t)7);
         if ((rc = stage_acquire(h, off_ids + sizeof(unsigned long long) * B, &sl)) != FD_OK) return rc;
-        if ((rc = set_lens(h, a.has_lens ? a.lens.data() : nullptr, B, T, stream, "fd_sample", reinterpret_cast<int *>(sl->host + off_lens))) != FD_OK) return rc;
+        if ((rc = set_lens(h, lens_eff, B, T, stream, "fd_sample", reinterpret_cast<int *>(sl->host + off_lens))) != FD_OK) return rc;
         if (!ids.empty()) {
             memcpy(sl->host + off_ids, ids.data(), sizeof(unsigned long long) * B);
             FD_HIP(h, hipMemcpyAsync(ws.uid_dev, sl->host + off_ids, sizeof(unsigned long long) * B, hipMemcpyHostToDevice, stream));
@@ -1160,6 +1206,7 @@ static int sample_core(fd_handle h, const fd_context::SampleArgs &a, unsigned fo
         memcpy(p->table, a.table.data(), sizeof(fd_step) * N);
         p->z = a.z; p->seq = a.seq_out; p->seed = a.seed; p->n_steps = N; p->ddim = a.ddim ? 1 : 0; p->step_idx = 0; p->l4 = T * (fd::HOPT / 4);
         p->uids = ids.empty() ? nullptr : ws.uid_dev;
+        p->l4_io = T_io * (fd::HOPT / 4); p->n4_io = (long long)B * p->l4_io;
         // only the used prefix of the table plus the trailer needs to travel
         const size_t head = sizeof(fd_step) * N;
         FD_HIP(h, hipMemcpyAsync(ws.params, p, head, hipMemcpyHostToDevice, stream));
@@ -1168,13 +1215,20 @@ static int sample_core(fd_handle h, const fd_context::SampleArgs &a, unsigned fo
                                  hipMemcpyHostToDevice, stream));
         if ((rc = stage_commit(h, sl, stream)) != FD_OK) return rc;
     }
-    FD_HIP(h, hipMemcpyAsync(ws.mel, a.mel, sizeof(float) * (size_t)B * fd::COND * T, hipMemcpyDeviceToDevice, stream));
     fdk::Launch L = {h, stream, false};
-    hipError_t e = hipSuccess;
-    if (a.x_T) FD_HIP(h, hipMemcpyAsync(ws.x, a.x_T, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
-    else if ((e = fdk::init_noise(L, ws.x, (int64_t)n_el, a.seed, ids.empty() ? nullptr : ws.uid_dev, T * (fd::HOPT / 4))) != hipSuccess)
+    hipError_t e = fdk::copy_rows(L, ws.mel, T, a.mel, T_io, T_io, B * fd::COND);
+    if (e == hipSuccess && a.x_T) e = fdk::copy_rows(L, ws.x, Lp, a.x_T, L_io, (int)L_io, B);
+    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample: input copy failed: %s", hipGetErrorString(e));
+    if (!a.x_T && (e = fdk::init_noise(L, ws.x, B, T * (fd::HOPT / 4), T_io * (fd::HOPT / 4), a.seed, ids.empty() ? nullptr : ws.uid_dev)) != hipSuccess)
         FD_FAIL(h, FD_ERR_HIP, "fd_sample: init_noise failed: %s", hipGetErrorString(e));
-    if (a.seq_out) FD_HIP(h, hipMemcpyAsync(a.seq_out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
+    if (a.seq_out && (e = fdk::copy_rows(L, a.seq_out, L_io, ws.x, Lp, (int)L_io, B)) != hipSuccess)
+        FD_FAIL(h, FD_ERR_HIP, "fd_sample: sequence copy failed: %s", hipGetErrorString(e));
+    // the waveform back into the caller's dense tensor
+    auto copy_out = [&]() -> int {
+        const hipError_t eo = fdk::copy_rows(L, a.out, L_io, ws.x, Lp, (int)L_io, B);
+        if (eo != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_sample: output copy failed: %s", hipGetErrorString(eo));
+        return FD_OK;
+    };
 
     StepIO io = {ws.x, ws.mel, nullptr, nullptr, 1};
     {   // the embedding rows of this schedule: still in ws.noise from the previous call?
@@ -1215,7 +1269,7 @@ static int sample_core(fd_handle h, const fd_context::SampleArgs &a, unsigned fo
     }
     if (force_mask != 0) {
         if ((rc = enqueue_steps(h, B, T, N, force_mask, true, stream)) != FD_OK) return rc;
-        FD_HIP(h, hipMemcpyAsync(a.out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
+        if ((rc = copy_out()) != FD_OK) return rc;
     } else if (h->host_fallback && N <= CHUNK) {
         // fallback = host, one graph launch: no fp32 launch trails the fp16x2 kernels; their flags accumulate on the device and travel
         // to the host behind the work.  Looked at lazily: by the next fd_sample after it has enqueued itself, or by fd_sample_check /
@@ -1224,9 +1278,9 @@ static int sample_core(fd_handle h, const fd_context::SampleArgs &a, unsigned fo
         const int slot = (int)(ticket & 1);
         FD_HIP(h, hipMemcpyAsync(h->flags_host + 32 * slot, ws.range_flag + 64, sizeof(int) * 32, hipMemcpyDeviceToHost, stream));
         FD_HIP(h, hipEventRecord(slot ? h->flags_done2 : h->flags_done, stream));
-        FD_HIP(h, hipMemcpyAsync(a.out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));      // provisional until checked
+        if ((rc = copy_out()) != FD_OK) return rc;      // provisional until checked
         h->pending.active = true; h->pending.lazy = true; h->pending.slot = slot; h->pending.ticket = ticket;
-        h->pending.B = B; h->pending.T = T; h->pending.N = N; h->pending.first = 0; h->pending.count = N; h->pending.out = a.out;
+        h->pending.B = B; h->pending.T = T; h->pending.T_io = T_io; h->pending.N = N; h->pending.first = 0; h->pending.count = N; h->pending.out = a.out;
         h->pending.stream = stream; h->pending.args = a;
     } else if (h->host_fallback) {
         // a long schedule: each 8-step piece is checked (one stream synchronisation) before the next is enqueued, and redone from the
@@ -1244,16 +1298,16 @@ static int sample_core(fd_handle h, const fd_context::SampleArgs &a, unsigned fo
             FD_HIP(h, hipMemcpyAsync(h->flags_host, ws.range_flag + 64, sizeof(int) * 32, hipMemcpyDeviceToHost, stream));
             FD_HIP(h, hipEventRecord(h->flags_done, stream));
             h->pending.active = true; h->pending.lazy = false; h->pending.slot = 0; h->pending.ticket = ticket;
-            h->pending.B = B; h->pending.T = T; h->pending.N = N; h->pending.first = first; h->pending.count = count; h->pending.out = a.out;
+            h->pending.B = B; h->pending.T = T; h->pending.T_io = T_io; h->pending.N = N; h->pending.first = first; h->pending.count = count; h->pending.out = a.out;
             h->pending.stream = stream;
             if (last) break;                      // the caller's fd_sample_check (or the next call on this handle) looks at it
             int redone = resolve_pending(h, &mask);
             if (redone < 0) return redone;
         }
-        FD_HIP(h, hipMemcpyAsync(a.out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));      // (provisional while a check is pending)
+        if ((rc = copy_out()) != FD_OK) return rc;      // (provisional while a check is pending)
     } else {
         if ((rc = enqueue_steps(h, B, T, N, 0u, true, stream)) != FD_OK) return rc;
-        FD_HIP(h, hipMemcpyAsync(a.out, ws.x, sizeof(float) * n_el, hipMemcpyDeviceToDevice, stream));
+        if ((rc = copy_out()) != FD_OK) return rc;
     }
     h->last_B = B; h->last_T = T;
     return mark_tail(h, stream);      // (also behind a redo: resolve_call comes through here)
@@ -1281,8 +1335,10 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
     // A lazily checked previous call (fallback = host, <= 8 steps) is looked at AFTER this call has enqueued its own work -- unless
     // this call cannot be lazy itself, or the workspace must grow first (that waits for the device anyway).
     const bool lazy = h->host_fallback && N >= 1 && N <= 8;
-    const int np = (N >= 1 && N <= 1024) ? hoist_mult(h, B, T, N) : 1;
-    const bool ws_ok = workspace_fits(h, B, T, np);
+    const int Tp = bucket_frames(h, T);          // frames of the library's own buffers (t_bucket): what the workspace and the graphs are sized for
+    if ((rc = check_common(h, B, Tp, "fd_sample")) != FD_OK) return rc;
+    const int np = (N >= 1 && N <= 1024) ? hoist_mult(h, B, Tp, N) : 1;
+    const bool ws_ok = workspace_fits(h, B, Tp, np);
     fd_context::PendingCall prev;
     if (lazy && ws_ok && h->pending.active && h->pending.lazy) {
         prev = h->pending;
@@ -1304,7 +1360,12 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
         finish_prev();
         FD_FAIL(h, FD_ERR_INVALID, "fd_sample: fd_set_noise_streams gave %d stream ids but B=%d", (int)ids.size(), B);
     }
-    if ((rc = ensure_workspace(h, B, T, np)) != FD_OK) { finish_prev(); return rc; }
+    for (int b = 0; lens && b < B; ++b)
+        if (lens[b] < 1 || lens[b] > T) {
+            finish_prev();
+            FD_FAIL(h, FD_ERR_INVALID, "fd_sample: lens[%d] = %d outside [1, T=%d]", b, lens[b], T);
+        }
+    if ((rc = ensure_workspace(h, B, Tp, np)) != FD_OK) { finish_prev(); return rc; }
     fd_context::SampleArgs a;
     a.mel = mel; a.B = B; a.T = T; a.N = N; a.ddim = ddim;
     a.has_lens = lens != nullptr;
@@ -1317,8 +1378,13 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
     h->call_fp32_mask = 0;
     rc = sample_core(h, a, 0u, ticket);
     const int rc_prev = finish_prev();
-    h->last_B = B; h->last_T = T;                // (a redo of the previous call has just run with that call's shape)
-    return rc != FD_OK ? rc : rc_prev;
+    h->last_B = B; h->last_T = Tp;               // (a redo of the previous call has just run with that call's shape)
+    if (rc != FD_OK || rc_prev != FD_OK) return rc != FD_OK ? rc : rc_prev;
+    // The contract of the reference call is "call, then read" (util.py:215-235): unless the caller opted into the pipelined check
+    // (option defer_check = 1: tickets, fd_sample_check / fd_sample_settle), the range check of this call is settled before fd_sample
+    // returns -- one wait for the call's own work and, if an operand left the fp16 range, the second pass on the fp32 kernels.
+    if (!h->defer_check) return settle(h);
+    return FD_OK;
 }
 
 int64_t fd_sample_ticket(fd_handle h) { return h ? (int64_t)h->ticket_counter : FD_ERR_INVALID; }
@@ -2233,6 +2299,16 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
         return FD_OK;
     }
     if (k == "graph") { h->use_graph = on; return FD_OK; }
+    if (k == "defer_check") { h->defer_check = on; return FD_OK; }
+    if (k == "t_bucket" || k == "graph_cache") {
+        char *end = nullptr;
+        const long n = strtol(value, &end, 10);
+        if (end == value || *end != 0 || n < 0 || n > 65536 || (k == "graph_cache" && n < 1))
+            FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: %s expects an integer (t_bucket: frames, 0 = exact T; graph_cache: graphs kept, >= 1), got '%s'", key, value);
+        if (k == "t_bucket") h->t_bucket = (int)n;
+        else h->max_graphs = (int)n;
+        return FD_OK;
+    }
     if (k == "profile") { h->profile = (v == "events") ? 2 : (on ? 1 : 0); return FD_OK; }
     if (k == "taps") { h->keep_taps = on; return FD_OK; }
     FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: unknown option '%s'", key);
@@ -2305,6 +2381,11 @@ int64_t fd_get_counter(fd_handle h, const char *name)
     if (k == "pieces_fp32") return h->n_pieces_fp32;
     if (k == "fp32_mask") return (int64_t)h->call_fp32_mask;
     if (k == "calls_redone") return h->n_calls_redone;
+    if (k == "graph_captures") return h->n_graph_captures;
+    if (k == "graph_hits") return h->n_graph_hits;
+    if (k == "graph_evictions") return h->n_graph_evictions;
+    if (k == "graphs_resident") return (int64_t)h->graphs.size();
+    if (k == "graphs_retired") return (int64_t)h->retired.size();
     FD_FAIL(h, FD_ERR_INVALID, "fd_get_counter: unknown counter '%s'", name);
 }
 

@@ -36,9 +36,13 @@ __device__ inline float4 philox_normal4(unsigned long long seed, uint32_t stream
     return make_float4(ra * c0, ra * s0, rb * c1, rb * s1);
 }
 
-// The reverse-step update (util.py:219-229) on 4 consecutive samples; eps in, x in/out.
-__device__ inline float4 sampler_update4(float4 x, float4 e, const StepParams *p, int64_t i4, int64_t n4_total)
+// The reverse-step update (util.py:219-229) on 4 consecutive samples; eps in, x in/out.  (b, off4) = utterance and float4 offset inside
+// it.  The library's own buffers may be padded to a frame bucket (StepParams::l4 float4s per utterance); whatever belongs to the CALLER
+// -- injected noise, the returned sequence, the position a Philox draw is keyed on -- is addressed with the caller's own length
+// (l4_io per utterance, n4_io per step), so a bucketed call reads, draws and writes exactly what the unpadded call does.
+__device__ inline float4 sampler_update4(float4 x, float4 e, const StepParams *p, int b, int64_t off4)
 {
+    const int64_t i4 = (int64_t)b * p->l4_io + off4, n4_total = p->n4_io;
     const int k = p->step_idx;
     const fd_step st = p->table[k];
     float4 o;
@@ -55,10 +59,8 @@ __device__ inline float4 sampler_update4(float4 x, float4 e, const StepParams *p
         if (st.add_noise) {
             float4 z;
             if (p->z) z = reinterpret_cast<const float4 *>(p->z)[(int64_t)k * n4_total + i4];
-            else if (p->uids) {
-                const int b = (int)(i4 / p->l4);
-                z = philox_normal4(p->seed, (uint32_t)k, (uint64_t)(i4 - (int64_t)b * p->l4), p->uids[b]);
-            } else z = philox_normal4(p->seed, (uint32_t)k, (uint64_t)i4);
+            else if (p->uids) z = philox_normal4(p->seed, (uint32_t)k, (uint64_t)off4, p->uids[b]);
+            else z = philox_normal4(p->seed, (uint32_t)k, (uint64_t)i4);
             o.x += st.sigma * z.x; o.y += st.sigma * z.y; o.z += st.sigma * z.z; o.w += st.sigma * z.w;
         }
     }

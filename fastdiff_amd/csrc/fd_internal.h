@@ -8,6 +8,8 @@
 #include <vector>
 
 #include "../../include/fastdiff_hip.h"
+#include "../../include/fastdiff_hip_ext.h"
+#include "../../include/fastdiff_hip_train.h"
 
 // ---------------------------------------------------------------------------------------------
 // Fixed architecture of this build (modules/FastDiff/config/base.yaml:21-33).  fd_create rejects
@@ -106,6 +108,9 @@ struct StepParams {
     int step_idx;          // advanced on device at the end of every captured step
     int l4;                // samples / 4 of one (padded) utterance of this call: splits a flat float4 index into (utterance, offset)
     const unsigned long long *uids;   // [B] per-utterance noise stream ids (fd_set_noise_streams) or null: see philox_normal4
+    int l4_io;             // samples / 4 of one utterance as the CALLER lays it out (x_T, z, seq_out, out): == l4 unless the call's frames were
+                           // rounded up to a bucket (fd_context::t_bucket); also what a Philox draw's position is counted in
+    long long n4_io;       // B * l4_io: one step's stride in z / seq_out
 };
 
 enum Stage { ST_EMBED = 0, ST_FIRST, ST_DBLOCK, ST_KP_FRONT, ST_KP_GEMM, ST_CONVT, ST_LVC, ST_FINAL, ST_COUNT };
@@ -190,7 +195,7 @@ struct fd_context {
     //                    fp32_mask set (option fallback = host: fd_sample_check)
     //   fp32_mask        bit i set: the stage whose flag word is i runs its fp32 kernel outright
     bool lvc_h8_mfma = true;                  // option "lvc_h8" = "mfma": the hop-8 layers on 16x16x32 fp16 tiles (k_lvc_h8m) | "valu" (k_lvc_h8)
-    bool host_fallback = true;                // option "fallback" = "host" (default) | "graph"
+    bool host_fallback = true;                // option "fallback" = "host" (default; settled inside fd_sample unless defer_check) | "graph"
     bool inline_fallback = true;
     unsigned fp32_mask = 0;
     bool h_image_ready = false;               // set by fast_kp_front when it wrote the GEMM's fp16 image of h for this step
@@ -239,8 +244,21 @@ struct fd_context {
     bool hoist_chunk = false;                 // a long schedule (N > 8): the predictor of each 8-step graph piece is hoisted to the piece's front
     // captured denoiser steps, one per (B, T, mode): micro-batches of different padded length alternate without re-capturing
     struct StepGraph { int B, T, steps; unsigned sig; hipGraph_t graph; hipGraphExec_t exec; unsigned long long last_use; };   // `steps` denoiser steps per launch
-    std::vector<StepGraph> graphs;           // at most FD_MAX_GRAPHS, least recently used evicted
+    std::vector<StepGraph> graphs;           // at most max_graphs, least recently used evicted
     unsigned long long graph_clock = 0;
+    // An evicted graph may still be running: it is parked here with an event recorded behind everything enqueued so far and destroyed
+    // by a later call once that event has completed (no stream-wide wait on the eviction path).
+    struct RetiredGraph { hipGraph_t graph; hipGraphExec_t exec; hipEvent_t done; };
+    std::vector<RetiredGraph> retired;
+    int max_graphs = 64;                     // option "graph_cache"
+    // The reference CLI vocodes one utterance per call with a different length each time (FastDiff.py:97-103, base.yaml:53): a graph
+    // keyed on the exact T would be captured once per utterance.  fd_sample therefore rounds the frames of its OWN buffers up to a
+    // multiple of t_bucket (option "t_bucket", 0 / 1 = off) and runs the call with `lens` -- whose contract already is "as if the
+    // utterance were alone and lens[b] frames long", bit for bit -- so one graph serves every length of a bucket; the caller's
+    // tensors keep their own dense layout (StepParams::l4_io).
+    int t_bucket = 32;
+    long long n_graph_captures = 0, n_graph_hits = 0, n_graph_evictions = 0;
+    bool defer_check = false;                // option "defer_check": fd_sample returns with its range check still pending (tickets)
     // Pinned staging ring for everything a call uploads from the host (step table, lens, noise stream ids, valid counts): a slot
     // is rewritten only after the event recorded behind its last upload has completed, so no call waits for the stream and no
     // asynchronous copy ever reads memory the next call has already overwritten.
@@ -270,7 +288,8 @@ struct fd_context {
         bool lazy = false;
         int slot = 0;                                       // which of the two flag buffers / events
         long long ticket = 0;
-        int B = 0, T = 0, N = 0, first = 0, count = 0;      // steps [first, first + count) were enqueued without fallbacks
+        int B = 0, T = 0, N = 0, first = 0, count = 0;      // steps [first, first + count) were enqueued without fallbacks; T: frames of the
+        int T_io = 0;                                       // library's buffers (bucketed), T_io: the caller's
         float *out = nullptr;
         hipStream_t stream = nullptr;
         SampleArgs args;
@@ -327,7 +346,8 @@ hipError_t kp_gemm(const Launch &L, int B, int T);
 hipError_t advance_step(const Launch &L);
 hipError_t clear_range_flags(const Launch &L, int set_step = 0);     // before the first step of a call / of a redo: step counter := set_step
 hipError_t mel_frontend(const Launch &L, const float *wav, int B, int64_t n_samples, float *mel, int T);
-hipError_t init_noise(const Launch &L, float *x, int64_t n, unsigned long long seed, const unsigned long long *uids, int l4);
+hipError_t init_noise(const Launch &L, float *x, int B, int l4, int l4_io, unsigned long long seed, const unsigned long long *uids);
+hipError_t copy_rows(const Launch &L, float *dst, int64_t dpitch, const float *src, int64_t spitch, int width, int rows);
 hipError_t peak_normalize_int16(const Launch &L, const float *wav, int B, int64_t len, int16_t *pcm, const long long *valid_dev);
 }  // namespace fdk
 

@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(256) k_first_conv(const float *__restrict__ x,
 // plain k_final behind this launch (run_if) redoes the conv from the fp32 kernel's output.
 __global__ void __launch_bounds__(256) k_final_acc(float *__restrict__ eps_acc, const float *__restrict__ bias, float *__restrict__ eps_out,
                                                    float *__restrict__ xstate, const StepParams *params, int sampler, int L,
-                                                   int64_t n4_total, const int *__restrict__ lens, const int *__restrict__ overflow)
+                                                   const int *__restrict__ lens, const int *__restrict__ overflow)
 {
     const int b = blockIdx.y;
     const int t0 = (blockIdx.x * 256 + threadIdx.x) * 4;
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(256) k_final_acc(float *__restrict__ eps_acc, 
         reinterpret_cast<float4 *>(eps_out)[i4] = acc;
     } else {
         const float4 xv = reinterpret_cast<const float4 *>(xstate)[i4];
-        reinterpret_cast<float4 *>(xstate)[i4] = fdk::sampler_update4(xv, acc, params, i4, n4_total);
+        reinterpret_cast<float4 *>(xstate)[i4] = fdk::sampler_update4(xv, acc, params, b, (int64_t)(t0 >> 2));
     }
 }
 
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(256) k_final_acc(float *__restrict__ eps_acc, 
 __global__ void __launch_bounds__(256) k_final(const float *__restrict__ x32, const float *__restrict__ w,
                                                const float *__restrict__ bias, float *__restrict__ eps_out,
                                                float *__restrict__ xstate, const StepParams *params, int sampler, int L,
-                                               int64_t n4_total, const int *__restrict__ lens, const int *__restrict__ run_if)
+                                               const int *__restrict__ lens, const int *__restrict__ run_if)
 {
     if (run_if && *run_if == 0) return;      // fallback launch behind k_final_acc: only when the fused last layer flagged its operands
     const int b = blockIdx.y;
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256) k_final(const float *__restrict__ x32, co
         reinterpret_cast<float4 *>(eps_out)[i4] = acc;
     } else {
         const float4 xv = reinterpret_cast<const float4 *>(xstate)[i4];
-        reinterpret_cast<float4 *>(xstate)[i4] = fdk::sampler_update4(xv, acc, params, i4, n4_total);
+        reinterpret_cast<float4 *>(xstate)[i4] = fdk::sampler_update4(xv, acc, params, b, (int64_t)(t0 >> 2));
     }
 }
 
@@ -156,14 +156,14 @@ hipError_t fast_final(const Launch &L, const StepIO &io, const float *x32, int B
     if (c->final_fused) {       // the last LVC layer already left the conv sums in eps_acc
         const int *flag = c->ws.range_flag + 1 + 2 * fd::LAYERS + 3;
         FD_LAUNCH(L, "final_update", k_final_acc, dim3((Lf + 1023) / 1024, B), dim3(256), 0, c->ws.eps_acc, w.final_.b, io.eps_out, c->ws.x,
-                  (const StepParams *)c->ws.params, io.sampler, Lf, (int64_t)B * Lf / 4, c->step_lens, flag);
+                  (const StepParams *)c->ws.params, io.sampler, Lf, c->step_lens, flag);
         run_if = flag;
         name = "final_conv_fallback";
         c->final_fused = false;
         if (!c->inline_fallback) return hipSuccess;      // fallback = host: a flagged last layer is redone from the host
     }
     FD_LAUNCH(L, name, k_final, dim3((Lf + 1023) / 1024, B), dim3(256), 0, x32, w.final_.w, w.final_.b, io.eps_out,
-              c->ws.x, (const StepParams *)c->ws.params, io.sampler, Lf, (int64_t)B * Lf / 4, c->step_lens, run_if);
+              c->ws.x, (const StepParams *)c->ws.params, io.sampler, Lf, c->step_lens, run_if);
     return hipSuccess;
 }
 

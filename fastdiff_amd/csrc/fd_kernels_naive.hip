@@ -339,22 +339,45 @@ hipError_t embed(const Launch &L, const StepIO &io, int B, int n_steps)
     return hipSuccess;
 }
 
-__global__ void k_init_noise(float *x, int64_t n4, unsigned long long seed, const unsigned long long *uids, int l4)
+// x [B][l4 float4s]; the draw of utterance b at offset off is keyed as in a batch of l4_io float4s per utterance (the caller's own
+// length: the library's buffer may be padded to a frame bucket, fd_api.cpp) -- offsets behind l4_io are padding and stay untouched
+__global__ void k_init_noise(float *x, int l4, int l4_io, unsigned long long seed, const unsigned long long *uids)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    if (uids) {
-        const int b = (int)(i / l4);
-        reinterpret_cast<float4 *>(x)[i] = philox_normal4(seed, 0xFFFFFFFFu, (uint64_t)(i - (int64_t)b * l4), uids[b]);
-    } else {
-        reinterpret_cast<float4 *>(x)[i] = philox_normal4(seed, 0xFFFFFFFFu, (uint64_t)i);
-    }
+    const int off = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (off >= l4_io) return;
+    const int64_t i = (int64_t)b * l4 + off;
+    if (uids) reinterpret_cast<float4 *>(x)[i] = philox_normal4(seed, 0xFFFFFFFFu, (uint64_t)off, uids[b]);
+    else reinterpret_cast<float4 *>(x)[i] = philox_normal4(seed, 0xFFFFFFFFu, (uint64_t)((int64_t)b * l4_io + off));
 }
 
-hipError_t init_noise(const Launch &L, float *x, int64_t n, unsigned long long seed, const unsigned long long *uids, int l4)
+hipError_t init_noise(const Launch &L, float *x, int B, int l4, int l4_io, unsigned long long seed, const unsigned long long *uids)
 {
-    const int64_t n4 = n / 4;   // n = B*T*256 is a multiple of 4
-    FD_LAUNCH(L, "init_noise", k_init_noise, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, x, n4, seed, uids, l4);
+    FD_LAUNCH(L, "init_noise", k_init_noise, dim3((unsigned)((l4_io + 255) / 256), B), dim3(256), 0, x, l4, l4_io, seed, uids);
+    return hipSuccess;
+}
+
+// rows x width floats between two pitched buffers (pitches in floats): the library's frame-bucketed buffers <-> the caller's dense ones
+__global__ void k_copy_rows(float *__restrict__ dst, int64_t dpitch, const float *__restrict__ src, int64_t spitch, int width, int vec)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = blockIdx.y;
+    if (vec) {
+        if (i * 4 < width) reinterpret_cast<float4 *>(dst + r * dpitch)[i] = reinterpret_cast<const float4 *>(src + r * spitch)[i];
+    } else if (i < width) dst[r * dpitch + i] = src[r * spitch + i];
+}
+
+hipError_t copy_rows(const Launch &L, float *dst, int64_t dpitch, const float *src, int64_t spitch, int width, int rows)
+{
+    if (rows <= 0 || width <= 0) return hipSuccess;
+    if (dpitch == width && spitch == width)
+        return hipMemcpyAsync(dst, src, sizeof(float) * (size_t)width * rows, hipMemcpyDeviceToDevice, L.stream);
+    const bool vec = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0 && ((dpitch | spitch | width) & 3) == 0;
+    const int n = vec ? width / 4 : width;
+    for (int r0 = 0; r0 < rows; r0 += 65535) {
+        const int nr = rows - r0 < 65535 ? rows - r0 : 65535;
+        FD_LAUNCH(L, "copy_rows", k_copy_rows, dim3((unsigned)((n + 255) / 256), nr), dim3(256), 0, dst + r0 * dpitch, dpitch, src + r0 * spitch, spitch,
+                  width, vec ? 1 : 0);
+    }
     return hipSuccess;
 }
 
@@ -364,7 +387,8 @@ __global__ void k_update(float *x, const float *eps, const StepParams *p, int64_
     if (i >= n4) return;
     const float4 xv = reinterpret_cast<const float4 *>(x)[i];
     const float4 ev = reinterpret_cast<const float4 *>(eps)[i];
-    reinterpret_cast<float4 *>(x)[i] = sampler_update4(xv, ev, p, i, n4);
+    const int b = (int)(i / p->l4);          // (the naive path is never frame-bucketed: l4_io == l4)
+    reinterpret_cast<float4 *>(x)[i] = sampler_update4(xv, ev, p, b, i - (int64_t)b * p->l4);
 }
 
 hipError_t naive_update(const Launch &L, float *x, const float *eps, int64_t n)

@@ -176,14 +176,14 @@ def _collate_on_device(items: Sequence[dict], drop_last_frame: bool):
 
 
 def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 8, seed: int = 0, drop_last_frame: bool = True,
-               noise_schedule=None, diffusion_hyperparams=None, return_device: bool = False) -> Dict[str, np.ndarray]:
+               noise_schedule=None, diffusion_hyperparams=None, return_device: bool = False, sort: bool = True) -> Dict[str, np.ndarray]:
     """item_name -> int16 PCM of its own length (hop 256 x frames), through length-sorted padded micro-batches.
     Noise: utterance `it` draws x_T and z from Philox stream (seed, it["uid"]) over its own samples (fd_set_noise_streams); "uid"
     defaults to the item's position in `items`, callers that shard a job put the utterance's index in the WHOLE job there, so a
     waveform does not depend on the micro-batch, rank or world size that produced it.
     Mels may live on the host ([T, 80] tensors or arrays: collated in numpy straight into pinned memory) or on the GPU (collated
     there).  return_device: the values are int16 device tensors instead of host arrays (no device-to-host copy at all: what
-    synthesize_sharded hands to the RCCL gather)."""
+    synthesize_sharded hands to the RCCL gather).  sort=False: micro-batches in the order of arrival instead of longest first."""
     # the step table depends on the schedule only: derived once per schedule and model (sampling_given_noise_schedule derives it on
     # every call, as the reference does), the same rows then drive every micro-batch
     rows = _step_rows(model, n_steps, noise_schedule, diffusion_hyperparams)
@@ -226,7 +226,7 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
             out[name] = host[b, : t * hop].numpy().copy()
 
     k = 0
-    for batch_idx in shard.micro_batches(range(len(items)), lengths, max_batch):
+    for batch_idx in shard.micro_batches(range(len(items)), lengths, max_batch, sort=sort):
         batch_items = [items[i] for i in batch_idx]
         if on_device:
             mels, lens, names = _collate_on_device(batch_items, drop_last_frame)

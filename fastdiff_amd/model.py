@@ -122,9 +122,11 @@ class FastDiff(nn.Module):
         self.last_ticket = 0
         # Library options of this module's handle.  "fallback": "host" -- the range check of a sample() call is read on the host
         # instead of trailing every fp16x2 kernel with an early-exit fp32 launch (21 launches per reverse step less: -3 % at B=8,
-        # -7 % at B=1); sample() / check() / settle() below keep that safe for every caller of this class.  It is also the
-        # library's own default (a C caller calls fd_sample_check before it reads `out`: include/fastdiff_hip.h).
-        self._options = {"fallback": "host"}
+        # -7 % at B=1).  "defer_check": "1" -- the library does not settle that check inside fd_sample (its default for a C caller,
+        # include/fastdiff_hip.h): sample() / check() / settle() below do it, which lets sample(..., defer_check=True) pipeline calls.
+        self._options = {"fallback": "host", "defer_check": "1"}
+        self._param_list = None                # the parameter tensors _state_signature last walked (see there)
+        self._sig_calls = 0
 
     # ---- reference API --------------------------------------------------------------------------------
     def apply_weight_norm(self):
@@ -132,6 +134,7 @@ class FastDiff(nn.Module):
             if isinstance(m, (nn.Conv1d, nn.Conv2d)):
                 torch.nn.utils.weight_norm(m)
         self.apply(_apply)
+        self.__dict__["_param_list"] = None
 
     def remove_weight_norm(self):
         def _remove(m):
@@ -140,6 +143,7 @@ class FastDiff(nn.Module):
             except ValueError:
                 return
         self.apply(_remove)
+        self._invalidate_params()
 
     def forward(self, data, lens=None):
         """eps = net((audio [B,1,L], c [B,80,T] or [80,T], diffusion_steps [B,1])) -- FastDiff_model.py:74-102.
@@ -199,10 +203,9 @@ class FastDiff(nn.Module):
         T = condition.shape[-1]
         L = T * self.hop_length
         N = len(table)
-        steps = (_capi.FdStep * N)()
-        for k, row in enumerate(table):
-            steps[k] = _capi.FdStep(float(row["t"]), float(row["c_eps"]), float(row["c_div"]), float(row["sigma"]),
-                                    float(row["c1"]), float(row["c2"]), float(row["c3"]), int(row["add_noise"]))
+        steps = getattr(table, "fd_steps", None)      # sampler.StepRows: the ctypes table built once per schedule
+        if steps is None or len(steps) != N:
+            steps = _capi.step_table(table)
         dev = condition.device
         out = torch.empty((B, 1, L), device=dev, dtype=torch.float32)
         seq = torch.empty((N + 1, B, 1, L), device=dev, dtype=torch.float32) if return_sequence else None
@@ -390,11 +393,32 @@ class FastDiff(nn.Module):
     def _stream(device):
         return ct.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
+    _SIG_WALK_EVERY = 64
+
     def _state_signature(self):
-        # (name, storage, version) of every parameter: changes when a tensor is replaced (load_state_dict, .cuda(), remove_weight_norm)
-        # or written in place.  named_parameters() instead of state_dict(): the latter walks every module's hooks (1-5 ms per call,
-        # more than a B=1 sample call takes on the GPU)
-        return tuple((k, v.data_ptr(), v._version) for k, v in self.named_parameters())
+        # (storage, version) of every parameter: changes when a tensor is moved (.cuda()), loaded (load_state_dict copies in place) or
+        # written in place.  The walk over the module tree that finds the tensors (named_parameters(): ~150-250 us for 175 parameters,
+        # a sixth of what a one-utterance sample call takes on the GPU) is done when the set of parameters can have changed
+        # (_invalidate_params: _apply, load_state_dict, apply / remove_weight_norm) and otherwise on every 64th call, which catches a
+        # parameter object replaced behind the module's back (torch.nn.utils.remove_weight_norm on a sub-module, an assignment);
+        # in between only the known tensors are looked at (~30 us).
+        self._sig_calls += 1
+        if self._param_list is None or self._sig_calls % self._SIG_WALK_EVERY == 0:
+            named = list(self.named_parameters())
+            self._param_names = tuple(k for k, _ in named)
+            self._param_list = [v for _, v in named]
+        return self._param_names, tuple((v.data_ptr(), v._version) for v in self._param_list)
+
+    def _invalidate_params(self):
+        self._param_list = None
+
+    def _apply(self, fn, *args, **kwargs):
+        self._invalidate_params()
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._invalidate_params()
+        return super().load_state_dict(*args, **kwargs)
 
     def _ready(self, device):
         """Create the context on `device` if needed and (re)upload weights when any parameter changed."""

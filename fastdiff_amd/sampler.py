@@ -114,8 +114,9 @@ class InferenceSchedule:
             print('begin sampling, total number of reverse steps = %s' % self.N)
 
     def rows(self):
-        """fd_step rows in EXECUTION order (n = N-1 .. 0); each scalar is the reference's 0-d fp32 expression."""
-        out = []
+        """fd_step rows in EXECUTION order (n = N-1 .. 0); each scalar is the reference's 0-d fp32 expression.  A StepRows: a list of
+        read-only mappings that also carries the ctypes table FastDiff.sample hands to fd_sample, built once per schedule."""
+        out = StepRows()
         for n in reversed(range(self.N)):
             b, a = self.beta[n], self.alpha_hat[n]
             a_next = a / (1 - b).sqrt()                      # util.py:220
@@ -128,7 +129,21 @@ class InferenceSchedule:
                         "sigma": self.sigma_hat[n].item(),               # :229
                         "c1": c1.item(), "c2": c2.item(), "c3": c3.item(),
                         "add_noise": int(n > 0)})                        # :228
-        return out
+        return out.freeze()
+
+
+class StepRows(list):
+    """The step table of one schedule.  Its rows are read-only (copy them -- `[dict(r) for r in rows]`, a slice -- to edit: the copy
+    is a plain list), so the fd_step array derived from them can be kept: one utterance per call (the reference CLI's mode) builds
+    it once per schedule instead of once per call."""
+    fd_steps = None
+
+    def freeze(self):
+        import types
+        from . import _capi
+        self[:] = [types.MappingProxyType(dict(r)) for r in self]
+        self.fd_steps = _capi.step_table(self)
+        return self
 
 
 # ---------------------------------------------------------------------------------------------------------

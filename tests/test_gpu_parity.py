@@ -728,6 +728,82 @@ def test_embedding_table_kept_between_calls(gc, sched):
         assert torch.equal(m.sample(mel, rows4, seed=3), want["4"])
 
 
+def test_frame_bucketed_call_equals_the_exact_length_call(gc, sched):
+    """The reference CLI vocodes one utterance per call, a different length each time (FastDiff.py:97-103, base.yaml:53,
+    dataset_utils.py:114-125).  fd_sample sizes its own buffers and graphs for T rounded up to a multiple of 32 frames (option
+    t_bucket) and runs the call with `lens`; the caller's tensors keep their dense layout.  For 20 random lengths the bucketed call
+    must be torch.equal to the exact-T call (t_bucket = 0) -- with device noise (flat and per-utterance streams), with injected x_T / z
+    and the returned sequence, for a batch of two with and without `lens` -- and one graph must have served every length of a bucket."""
+    import synth
+    rng = np.random.default_rng(20)
+    lengths = sorted(set([3, 31, 32, 33, 64, 95] + rng.integers(3, 200, 20).tolist()))
+    rows, _ = gc.table_rows(sched, 4)
+    rows6, _ = gc.table_rows(sched, 6)
+    exact, bucketed = gc.make_model(), gc.make_model()
+    exact.set_option("t_bucket", "0")
+    with torch.no_grad():
+        for m in (exact, bucketed):      # the workspace at its final size first: growing it drops the graphs captured so far
+            m.sample(torch.zeros(2, 80, max(lengths)).cuda(), rows6, seed=1)
+        base = {m: m.counter("graph_captures") for m in (exact, bucketed)}
+        for T in lengths:
+            mel = torch.from_numpy(synth.synth_mel(300 + T, 2, T)).cuda()
+            L = T * 256
+            x_T = torch.from_numpy(synth.hash_normal(T, 1, 2 * L).reshape(2, 1, L)).cuda()
+            z = torch.from_numpy(np.stack([synth.hash_normal(T, 2 + k, 2 * L).reshape(2, 1, L) for k in range(4)])).cuda()
+            lens = [T, max(1, T - 1 - T // 3)]
+            cases = {
+                "philox_b1": lambda m: m.sample(mel[:1], rows, seed=5),
+                "philox_b2_streams": lambda m: m.sample(mel, rows, seed=6, stream_ids=[11, 4]),
+                "injected_seq": lambda m: torch.stack(list(m.sample(mel, rows, x_T=x_T, noise=z, return_sequence=True))),
+                "ragged_lens": lambda m: m.sample(mel, rows6, seed=7, lens=lens, stream_ids=[0, 1]),
+                "ddim": lambda m: m.sample(mel[:1], rows, seed=8, ddim=True),
+            }
+            for name, fn in cases.items():
+                a, b = fn(exact), fn(bucketed)
+                if name == "ragged_lens":      # behind an utterance's own length the output is unspecified
+                    a, b = [a[i, :, : lens[i] * 256] for i in range(2)], [b[i, :, : lens[i] * 256] for i in range(2)]
+                    assert all(torch.equal(x, y) for x, y in zip(a, b)), (T, name)
+                else:
+                    assert torch.isfinite(a).all() and torch.equal(a, b), (T, name)
+    buckets = len({(T + 31) // 32 for T in lengths})
+    # per bucket: (B=1, N=4) shared by the DDPM and "ddim" calls, (B=2, N=4) with and without streams, (B=2, N=6): three graphs (a
+    # length that IS a multiple of 32 runs without `lens` and has its own); the exact-T handle captured three per LENGTH
+    exact_mult = sum(1 for T in lengths if T % 32 == 0)
+    got_b, got_e = bucketed.counter("graph_captures") - base[bucketed], exact.counter("graph_captures") - base[exact]
+    assert 3 * buckets - 1 <= got_b <= 3 * buckets + 2 * exact_mult, (got_b, buckets)      # (- 1: the warm-up call's own graph)
+    assert 3 * len(lengths) - 1 <= got_e <= 3 * len(lengths), (got_e, len(lengths))
+
+
+def test_graph_cache_evicts_without_waiting_and_keeps_results(gc, sched):
+    """A graph cache of 2 under a stream of calls from 5 buckets: every call's result equals a fresh handle's, evicted graphs are
+    retired behind an event (not destroyed under a running replay, no stream-wide wait) and reaped by later calls."""
+    import synth
+    rows, _ = gc.table_rows(sched, 4)
+    lengths = [20, 40, 70, 100, 130]
+    mels = {T: torch.from_numpy(synth.synth_mel(T, 1, T)).cuda() for T in lengths}
+    with torch.no_grad():
+        want = {T: gc.make_model().sample(mels[T], rows, seed=T) for T in lengths}
+        m = gc.make_model()
+        m.set_option("graph_cache", "2")
+        m.sample(mels[130], rows, seed=1)      # the workspace at its final size (growing it drops every graph, uncounted)
+        outs = []
+        for rnd in range(4):
+            for T in lengths:
+                outs.append((T, m.sample(mels[T], rows, seed=T, defer_check=True)))
+        m.check()
+        torch.cuda.synchronize()
+    for T, y in outs:
+        assert torch.equal(y, want[T]), T
+    assert m.counter("graphs_resident") == 2
+    # 5 buckets in a cycle through an LRU of 2: every call misses (the warm-up's graph is gone by the time its bucket comes round)
+    assert m.counter("graph_captures") == 21 and m.counter("graph_evictions") == 19 and m.counter("graph_hits") == 0
+    with torch.no_grad():
+        m.sample(mels[20], rows, seed=20)      # everything retired so far has completed: the next look-up that misses reaps it
+        torch.cuda.synchronize()
+        m.sample(mels[70], rows, seed=70)
+    assert m.counter("graphs_retired") <= 2
+
+
 def test_consecutive_calls_may_change_streams(gc, sched):
     """One handle, calls on different streams (fd_api.cpp: follow_stream): a call arriving on another stream than the previous one settles
     the pending range check and waits for the tail of the previous call (an event recorded at the end of every call) -- deferred checks,

@@ -118,13 +118,22 @@ def test_constructor_rejects_training_only_options():
 
 def test_capi_exports_every_declared_symbol():
     lib = _capi.load()
-    header = open(os.path.join(ROOT, "include", "fastdiff_hip.h")).read()
-    declared = sorted(set(re.findall(r"FD_API\s+[\w\s\*]+?\b(fd_\w+)\s*\(", header)))
-    assert declared, "no FD_API declarations parsed"
+    per_header = {}
+    for name in ("fastdiff_hip.h", "fastdiff_hip_ext.h", "fastdiff_hip_train.h"):      # the inference boundary, the rows next to it + hooks, training
+        header = open(os.path.join(ROOT, "include", name)).read()
+        per_header[name] = set(re.findall(r"FD_API\s+[\w\s\*]+?\b(fd_\w+)\s*\(", header))
+        assert per_header[name], f"no FD_API declarations parsed in {name}"
+    assert not (per_header["fastdiff_hip.h"] & per_header["fastdiff_hip_train.h"]) and not (per_header["fastdiff_hip.h"] & per_header["fastdiff_hip_ext.h"])
+    # the inference boundary stays thin: construction, weights, forward, the sampler and its options
+    assert per_header["fastdiff_hip.h"] == {"fd_version", "fd_abi_revision", "fd_default_config", "fd_create", "fd_destroy", "fd_last_error", "fd_set_weight",
+                                            "fd_commit_weights", "fd_forward", "fd_sample", "fd_sample_check", "fd_sample_ticket", "fd_sample_settle",
+                                            "fd_set_noise_streams", "fd_set_option"}
+    declared = sorted(set().union(*per_header.values()))
     assert sorted(_capi.EXPORTS) == declared
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.fd_version().startswith(b"fastdiff_hip")
+    assert lib.fd_abi_revision() >= 2          # fd_sample settles its own range check unless the caller opts into defer_check
     # layout introspection is pure host code
     idx = {lib.fd_kernel_index(l, i, o, k) for l in range(4) for i in range(32) for o in range(64) for k in range(3)}
     assert idx == set(range(24576)), "kernel_index must be a bijection onto the packed record"
