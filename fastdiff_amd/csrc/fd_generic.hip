@@ -206,13 +206,25 @@ int validate(const fd_config &c, std::string &why)
     if (c.audio_channels != 1) return bad("audio_channels != 1: first_audio_conv is Conv1d(1, inner_channels) in the reference too (FastDiff_model.py:34), its sampler feeds it one channel");
     if (c.inner_channels < 1 || c.cond_channels < 1 || c.kpnet_hidden_channels < 1) return bad("channel counts must be positive");
     if (c.n_upsample < 1 || c.n_upsample > 8) return bad("1..8 upsample stages");
-    for (int n = 0; n < c.n_upsample; ++n)
-        if (c.upsample_ratios[n] < 1) return bad("upsample ratios must be >= 1");
+    int64_t hop = 1;
+    for (int n = 0; n < c.n_upsample; ++n) {
+        // ratio 1: the reference builds ConvTranspose1d(stride = 1, output_padding = 1), which torch refuses (output padding must be
+        // smaller than the stride, modules.py:163-166)
+        if (c.upsample_ratios[n] < 2) return bad("upsample ratios must be >= 2 (the reference's ConvTranspose1d(stride = r, output_padding = r % 2) does not exist for r = 1)");
+        hop *= c.upsample_ratios[n];
+        if (hop > 65536) return bad("the product of the upsample ratios (samples per frame) must be <= 65536");
+    }
+    // the kernels index channels and per-frame coefficient blocks with int: bound every product they form
+    if (c.inner_channels > 1024 || c.cond_channels > 4096 || c.kpnet_hidden_channels > 4096) return bad("inner_channels <= 1024, cond_channels <= 4096, kpnet_hidden_channels <= 4096");
+    if (c.lvc_kernel_size > 31 || c.kpnet_conv_size > 31) return bad("kernel sizes <= 31");
+    if (c.diffusion_step_embed_dim_in > 65536 || c.diffusion_step_embed_dim_mid > 65536 || c.diffusion_step_embed_dim_out > 65536) return bad("embedding widths <= 65536");
     if (c.lvc_layers_each_block < 1 || c.lvc_layers_each_block > 8) return bad("1..8 LVC layers per block (dilation 3^i)");
     if (c.lvc_kernel_size < 1 || (c.lvc_kernel_size & 1) == 0) return bad("an even lvc_kernel_size changes the sequence length: the reference's own forward fails on it (modules.py:183-187,217)");
     if (c.kpnet_conv_size < 1 || (c.kpnet_conv_size & 1) == 0) return bad("an even kpnet_conv_size changes the frame count: the reference's own forward fails on it (modules.py:293-318)");
     if (c.diffusion_step_embed_dim_in < 4 || (c.diffusion_step_embed_dim_in & 1)) return bad("diffusion_step_embed_dim_in must be even (util.py:423) and >= 4");
     if (c.diffusion_step_embed_dim_mid < 1 || c.diffusion_step_embed_dim_out < 1) return bad("embedding widths must be positive");
+    if ((int64_t)c.lvc_layers_each_block * 2 * c.inner_channels * c.inner_channels * c.lvc_kernel_size > ((int64_t)1 << 24))
+        return bad("layers * 2 * inner_channels^2 * lvc_kernel_size (kernel_conv's output channels) must be <= 2^24");
     return FD_OK;
 }
 
@@ -441,7 +453,8 @@ static const int *upload_lens(Net *n, const Plan &p, const int *lens, int B, int
     for (int b = 0; b < B; ++b) ragged = ragged || lens[b] < T;
     if (!ragged) return nullptr;
     int *d = reinterpret_cast<int *>(n->ws + p.lens);
-    *err = hipMemcpyAsync(d, lens, sizeof(int) * B, hipMemcpyHostToDevice, stream);      // pageable source: staged by the runtime before it returns
+    *err = hipMemcpyAsync(d, lens, sizeof(int) * B, hipMemcpyHostToDevice, stream);
+    if (*err == hipSuccess) *err = hipStreamSynchronize(stream);      // `lens` is the caller's array: it may be reused as soon as we return
     return d;
 }
 

@@ -271,7 +271,7 @@ def synthesize(model, items: Sequence[dict], n_steps: int = 4, max_batch: int = 
 
 
 def synthesize_sharded(model, items, n_steps: int = 4, max_batch: int = 8, seed: int = 0, drop_last_frame: bool = True, src: int = 0,
-                       device=None, force_collectives: int = 0) -> Dict[str, np.ndarray]:
+                       device=None, force_collectives: int = 0, gather: str = "src", balance: str = "time") -> Dict[str, np.ndarray]:
     """BASELINE config 4 as north_star words it: rank `src` holds all utterances (items; None elsewhere) -> length-balanced
     partition (shard.partition_utterances) -> scatter of the mels -> every rank vocodes its share in padded micro-batches on its
     own GPU -> gather of the int16 PCM on `src`, which returns item_name -> PCM (the other ranks return {}).  The process group
@@ -282,7 +282,16 @@ def synthesize_sharded(model, items, n_steps: int = 4, max_batch: int = 8, seed:
     device-to-host copy.
     force_collectives = R > 1 in a process group of ONE rank (a box with a single GPU): the job still takes the multi-rank route --
     the broadcast of names / ids / lengths, a partition into R parts, and parts 1 .. R-1 scattered and gathered as packed messages
-    from this rank to itself through the backend (shard loopback) -- so every line a real peer would execute runs on RCCL too."""
+    from this rank to itself through the backend (shard loopback) -- so every line a real peer would execute runs on RCCL too.
+    gather = "none": the job ends the way the reference's does (FastDiff.py:107-118: every rank writes the wavs of its own
+    utterances, nothing is collected): each rank returns item_name -> PCM of ITS share, brought to its own host behind its own
+    micro-batches; no message travels back and `src` does no work the other ranks do not do.
+    balance = "time" (default): the partition weighs an utterance as frames + a per-utterance constant (shard.utterance_cost);
+    "frames": by frames alone (rounds 1-5)."""
+    if gather not in ("src", "none"):
+        raise ValueError(f"synthesize_sharded: gather must be 'src' or 'none', got {gather!r}")
+    if balance not in ("time", "frames"):
+        raise ValueError(f"synthesize_sharded: balance must be 'time' or 'frames', got {balance!r}")
     import torch.distributed as dist
     loop = int(force_collectives) if (dist.is_available() and dist.is_initialized() and dist.get_world_size() == 1) else 0
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and loop < 2):
@@ -295,10 +304,13 @@ def synthesize_sharded(model, items, n_steps: int = 4, max_batch: int = 8, seed:
         meta = [([it["item_name"] for _, it in kept], [int(it.get("uid", i)) for i, it in kept], [int(m.shape[0]) for m in mels])]
     dist.broadcast_object_list(meta, src=src)          # names, noise-stream ids and lengths in one message
     names, uids, lens = meta[0]
-    parts = shard.partition_utterances(lens, loop or world)
+    parts = shard.partition_utterances(lens, loop or world, cost="time" if balance == "time" else None)
     mine, _ = shard.scatter_utterances(mels if rank == src else None, parts, src=src, device=device, lens=lens, frames_first=True, loopback=bool(loop))
     on_gpu = device is not None and torch.device(device).type == "cuda"
     local = [{"item_name": str(i), "mel": m, "len": m.shape[0], "uid": uids[i]} for i, m in mine]
+    if gather == "none":      # the reference's own ending: this rank's waveforms on this rank's host, nothing sent back
+        pcm = synthesize(model, local, n_steps, max_batch, seed, drop_last_frame=False)
+        return {names[i]: pcm[str(i)] for i, _ in mine}
     pcm = synthesize(model, local, n_steps, max_batch, seed, drop_last_frame=False, return_device=on_gpu)
     wavs = [(i, pcm[str(i)] if on_gpu else torch.from_numpy(pcm[str(i)])) for i, _ in mine]
     out = shard.gather_waveforms(wavs, lens, parts, hop=model.hop_length, dst=src, device=device, dtype=torch.int16, loopback=bool(loop))

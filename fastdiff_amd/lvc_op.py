@@ -807,15 +807,39 @@ def kernel_conv1d(x, weight, bias, post_slope=1.0):
     return _KConv.apply(x, weight, bias, post_slope)
 
 
+def lvc_operator_supported(in_channels, out_channels, kernel_size):
+    """The shapes fd_lvc_forward / fd_lvc_backward have kernels for (fd_api.cpp: check_lvc_op): the coefficient block of a frame fits
+    the operator's staging (Cin * Cout * ks <= 8192, Cout <= 256) -- with ks = 3 that is inner_channels <= 36."""
+    return in_channels * out_channels * kernel_size <= 8192 and out_channels <= 256 and kernel_size % 2 == 1
+
+
+def _lvc_torch(x, kernel, bias, hop_size):
+    """out[b, o, l * hop + s] = bias[b, o, l] + sum_{i, k} xpad[b, i, l * hop + s + k] * kernel[b, i, o, k, l] (modules.py:220-253 with
+    dilation 1) on torch ops, differentiable by autograd: for the configurations the constructor accepts but the HIP operator has no
+    kernel for (a frame's coefficient block beyond its staging: inner_channels > 36) -- a correctness path, like fd_generic.hip's."""
+    B, Cin, L = x.shape
+    _, _, Cout, ks, T = kernel.shape
+    pad = (ks - 1) // 2
+    win = torch.nn.functional.pad(x, (pad, pad)).unfold(2, hop_size + 2 * pad, hop_size).unfold(3, ks, 1)      # [B, Cin, T, hop, ks]
+    out = torch.einsum("bilsk,biokl->bols", win, kernel) + bias.unsqueeze(-1)
+    return out.reshape(B, Cout, L)
+
+
 def location_variable_convolution(x, kernel, bias, dilation=1, hop_size=256, grad_slot=None):
     """(batch, in_channels, in_length), (batch, in_channels, out_channels, kernel_size, kernel_length), (batch, out_channels,
     kernel_length) -> (batch, out_channels, in_length); same assert as the reference (modules.py:236).  dilation must be 1: it is
-    the only value the model ever passes (modules.py:216).  grad_slot (train.py only): see split_layers."""
+    the only value the model ever passes (modules.py:216).  grad_slot (train.py only): see split_layers.
+    Shapes outside the HIP operator's limits (lvc_operator_supported) run on torch ops (_lvc_torch) -- still on the device, still
+    differentiable; a shared gradient slot is then not used (autograd owns the gradient of that layer's slice)."""
     batch, in_channels, in_length = x.shape
     batch, in_channels, out_channels, kernel_size, kernel_length = kernel.shape
     assert in_length == (kernel_length * hop_size), "length of (x, kernel) is not matched"
     if dilation != 1:
         raise NotImplementedError("location_variable_convolution: the HIP operator implements dilation = 1 (modules.py:216)")
+    if not lvc_operator_supported(in_channels, out_channels, kernel_size):
+        if not x.is_cuda:
+            raise RuntimeError("fastdiff_amd.location_variable_convolution runs only on a HIP device (no CPU fallback)")
+        return _lvc_torch(x, kernel, bias, int(hop_size))
     return _LVC.apply(x, kernel, bias, hop_size, grad_slot)
 
 

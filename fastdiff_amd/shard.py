@@ -14,15 +14,32 @@ import torch
 import torch.distributed as dist
 
 
-def partition_utterances(lengths: Sequence[int], world_size: int) -> List[List[int]]:
-    """Greedy LPT: utterance indices per rank with ~equal total frames.  Deterministic; every index appears once."""
-    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
-    loads = [0] * world_size
+# What one utterance costs a rank, in frames: its own T_i plus a per-utterance constant -- the part of a reverse step that does not
+# shrink with the utterance (launch chains of the predictor front, the DBlocks and the hop-8 layers, the epilogue, collation, its
+# slice of the PCM copy).  Fitted on one MI355X from fd_sample calls of B = 1..16 at 200..864 frames, N = 6 (tools/cost_model.py,
+# profiles/r06_cost_model.json): ms(call) ~ c0 + c1 * B + c2 * sum(T_i), c1 / c2 ~ 60 frames.
+UTTERANCE_OVERHEAD_FRAMES = 60.0
+
+
+def utterance_cost(frames: int, overhead: float = UTTERANCE_OVERHEAD_FRAMES) -> float:
+    return float(frames) + overhead
+
+
+def partition_utterances(lengths: Sequence[int], world_size: int, cost=None, preload: Sequence[float] = None) -> List[List[int]]:
+    """Greedy LPT: utterance indices per rank with ~equal total cost.  Deterministic; every index appears once.
+    cost: None = frames (T_i); "time" = utterance_cost (frames + the per-utterance constant: a rank that gets many short utterances
+    is as busy as one that gets few long ones); or a callable frames -> cost.  preload[r]: cost rank r carries before the first
+    utterance is dealt (e.g. the source rank's packing / gathering work, in the same unit), so it is handed less."""
+    fn = (lambda t: float(t)) if cost is None else (utterance_cost if cost == "time" else cost)
+    costs = [fn(int(t)) for t in lengths]
+    order = sorted(range(len(lengths)), key=lambda i: (-costs[i], i))
+    loads = [float(v) for v in preload] if preload is not None else [0.0] * world_size
+    assert len(loads) == world_size
     parts: List[List[int]] = [[] for _ in range(world_size)]
     for i in order:
         r = min(range(world_size), key=lambda k: (loads[k], k))
         parts[r].append(i)
-        loads[r] += int(lengths[i])
+        loads[r] += costs[i]
     return [sorted(p) for p in parts]
 
 

@@ -42,9 +42,9 @@ def unpack_kpack(kpack, B, T):
     return kern, bias
 
 
-def make_model(seed=1234, device="cuda"):
+def make_model(seed=1234, device="cuda", contractive=False):
     m = fastdiff_amd.FastDiff()
-    sd = {k: torch.from_numpy(v.copy()) for k, v in synth.synth_state_dict(seed).items()}
+    sd = {k: torch.from_numpy(v.copy()) for k, v in synth.synth_state_dict(seed, contractive=contractive).items()}
     m.load_state_dict(sd, strict=True)
     m = m.to(device).eval()
     for kv in filter(None, os.environ.get("FD_TEST_OPTS", "").split(",")):      # bisecting aid: library options for every test model
@@ -97,3 +97,50 @@ def table_rows(sch, N):
 def exec_order_noise(z):
     """z[n] (added after reverse index n) -> noise[k] for the k-th executed step (n = N-1-k)."""
     return np.ascontiguousarray(z[::-1])
+
+
+# ---- torch twin of oracle/synth.py's counter hash (integer arithmetic only: bit-identical on any device) --------------------------
+_M_GOLD, _M_A, _M_B = 0x9E3779B97F4A7C15, 0xBF58476D1CE4E5B9, 0x94D049BB133111EB
+
+
+def _i64(v):
+    """A Python int (mod 2^64) as the int64 with the same bits."""
+    v &= 0xFFFFFFFFFFFFFFFF
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def _lsr(x, k):
+    """Logical right shift of int64 bit patterns (torch's >> is arithmetic)."""
+    return (x >> k) & ((1 << (64 - k)) - 1)
+
+
+def _splitmix64_torch(x):
+    x = x + _i64(_M_GOLD)
+    z = (x ^ _lsr(x, 30)) * _i64(_M_A)
+    z = (z ^ _lsr(z, 27)) * _i64(_M_B)
+    return z ^ _lsr(z, 31)
+
+
+def _splitmix64_int(x):
+    m = 0xFFFFFFFFFFFFFFFF
+    x = (x + _M_GOLD) & m
+    z = ((x ^ (x >> 30)) * _M_A) & m
+    z = ((z ^ (z >> 27)) * _M_B) & m
+    return z ^ (z >> 31)
+
+
+def hash_uniform_torch(seed, stream, n, device="cuda"):
+    """synth.hash_uniform(seed, stream, n) computed with torch int64 ops on `device` (two's-complement wrap-around = mod 2^64)."""
+    base = _i64(_splitmix64_int((seed * 0x100000001B3 + stream) & 0xFFFFFFFFFFFFFFFF))
+    idx = torch.arange(n, dtype=torch.int64, device=device)
+    h = _splitmix64_torch(idx ^ base)
+    u24 = _lsr(h, 40)
+    return ((u24 - (1 << 23)).to(torch.float32) / float(1 << 23))
+
+
+def hash_normal_torch(seed, stream, n, device="cuda"):
+    """synth.hash_normal(seed, stream, n): the sum of 12 hash uniforms, accumulated in float64 in the same order."""
+    acc = torch.zeros(n, dtype=torch.float64, device=device)
+    for k in range(12):
+        acc += hash_uniform_torch(seed, stream * 16 + k, n, device).to(torch.float64) * 0.5 + 0.5
+    return (acc - 6.0).to(torch.float32)

@@ -182,6 +182,14 @@ def test_unsupported_architecture_is_refused():
         assert rc == _capi.FD_ERR_HIP and b"no HIP device" in lib.fd_last_error(None)
     cfg.inner_channels, cfg.lvc_kernel_size = 32, 4
     assert lib.fd_create(ct.byref(cfg), 0, ct.byref(h)) == _capi.FD_ERR_UNSUPPORTED
+    # an upsample ratio of 1 (the reference's ConvTranspose1d(stride = 1, output_padding = 1) raises in torch) and sizes whose
+    # channel products would overflow the kernels' int indices are refused too
+    lib.fd_default_config(ct.byref(cfg))
+    cfg.upsample_ratios[1] = 1
+    assert lib.fd_create(ct.byref(cfg), 0, ct.byref(h)) == _capi.FD_ERR_UNSUPPORTED and b"ratio" in lib.fd_last_error(None)
+    lib.fd_default_config(ct.byref(cfg))
+    cfg.inner_channels, cfg.lvc_layers_each_block, cfg.lvc_kernel_size = 1024, 8, 31
+    assert lib.fd_create(ct.byref(cfg), 0, ct.byref(h)) == _capi.FD_ERR_UNSUPPORTED and b"2^24" in lib.fd_last_error(None)
 
 
 def test_foreign_net_host_loop_matches_oracle_update(oracle64):
@@ -381,3 +389,42 @@ def test_no_kernel_spills_to_scratch():
                 if any(k in n for k in ("k_lvc_h2I", "k_kp_gemm_h2", "k_kp_front_h2", "k_convt_h2I", "k_lvc_h8mI")):
                     assert o >= 2 and l <= 80 * 1024, (n, o, l)
     assert seen >= 70
+
+
+def test_torch_twin_of_the_synthetic_hash_is_bit_identical():
+    """tests/gpu_common.py rebuilds synth.hash_normal with torch int64 ops (on the GPU: the 885 MB of injected noise of the N = 1000,
+    T = 864 trajectory test) -- it must reproduce the numpy hash bit for bit."""
+    import sys
+    import synth
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gpu_common as gc
+    for seed, stream in ((1341, 1), (1341, 1001), (7, 900001)):
+        assert np.array_equal(synth.hash_uniform(seed, stream, 10007), gc.hash_uniform_torch(seed, stream, 10007, "cpu").numpy())
+        assert np.array_equal(synth.hash_normal(seed, stream, 5003), gc.hash_normal_torch(seed, stream, 5003, "cpu").numpy())
+
+
+def test_contractive_weights_change_only_final_conv():
+    import synth
+    a, b = synth.synth_state_dict(1234), synth.synth_state_dict(1234, contractive=True)
+    assert [k for k in a if not np.array_equal(a[k], b[k])] == ["final_conv.0.weight_v", "final_conv.0.weight_g"]
+    assert b["final_conv.0.weight_v"].shape == (1, 32, 7) and b["final_conv.0.weight_v"].dtype == np.float32
+
+
+def test_the_shipped_build_defines_no_probe_macro():
+    """the kernels keep measurement probes behind FD_* macros (tools/build_variant.sh builds variants with them).  The
+    regular build must define none of them: its flags carry no -D at all, and nothing in csrc #defines one of the switches itself."""
+    from fastdiff_amd import build
+    assert not [f for f in build.FLAGS if f.startswith("-D")], build.FLAGS
+    csrc = os.path.join(ROOT, "fastdiff_amd", "csrc")
+    switches, defined = set(), set()
+    for fn in os.listdir(csrc):
+        text = open(os.path.join(csrc, fn), encoding="utf-8", errors="replace").read()
+        switches |= set(re.findall(r"#\s*(?:ifdef|ifndef|elif defined\(|if defined\()\s*(FD_[A-Z0-9_]+)", text))
+        defined |= set(re.findall(r"#\s*define\s+(FD_[A-Z0-9_]+)", text))
+    probes = {s for s in switches if not s.endswith("_H")}
+    assert probes, "no probe switch found: the pattern no longer matches"
+    # a switch may only be #defined inside its own #ifndef default block (FD_LVC_NT, FD_*_OCC: tunables with a shipped default)
+    defaults = {"FD_LVC_NT", "FD_DBLOCK_OCC", "FD_CONVT_OCC", "FD_GX_STORE_AUX"}
+    assert (probes & defined) <= defaults, sorted((probes & defined) - defaults)
+    script = open(os.path.join(ROOT, "tools", "build_variant.sh")).read()
+    assert "build.FLAGS" in script and "--offload-arch" not in script      # the variant build takes its flags from build.py

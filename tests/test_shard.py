@@ -23,6 +23,22 @@ def test_partition_covers_everything_and_balances():
     assert shard.partition_utterances(lens, 8) == parts       # deterministic
 
 
+def test_partition_by_time_counts_the_per_utterance_constant():
+    """balance = "time" (shard.utterance_cost): an utterance costs its frames plus a constant, so a rank is not handed twice as many
+    short utterances as another gets long ones just because the frames add up."""
+    lens = [800] * 4 + [100] * 32                                   # 3200 + 3200 frames
+    by_frames = shard.partition_utterances(lens, 2)
+    by_time = shard.partition_utterances(lens, 2, cost="time")
+    assert sorted(i for p in by_time for i in p) == list(range(36))
+    cost = lambda p: sum(shard.utterance_cost(lens[i]) for i in p)      # noqa: E731
+    assert abs(cost(by_time[0]) - cost(by_time[1])) <= shard.utterance_cost(800)
+    assert abs(cost(by_time[0]) - cost(by_time[1])) <= abs(cost(by_frames[0]) - cost(by_frames[1]))
+    # a preloaded rank (the source's own packing / gathering work) is handed less
+    pre = shard.partition_utterances([100] * 16, 2, cost="time", preload=[4 * shard.utterance_cost(100), 0.0])
+    assert len(pre[0]) == 6 and len(pre[1]) == 10
+    assert shard.partition_utterances(lens, 2, cost=lambda t: 1.0) == [sorted(range(0, 36, 2)), sorted(range(1, 36, 2))]
+
+
 def test_partition_edge_cases():
     assert shard.partition_utterances([], 4) == [[], [], [], []]
     assert shard.partition_utterances([5], 2) == [[0], []]

@@ -96,6 +96,50 @@ def test_synthesize_sharded_uneven_and_empty_jobs(world, lens):
     _run_cpu_group(world, lens)
 
 
+def _no_gather_worker(rank, world, port, ret, lens):
+    """gather = "none": the job ends as the reference's does (FastDiff.py:107-118), every rank keeps the PCM of its own share."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        infer.synthesize = _stub_synthesize
+        real_x = infer.shard._exchange
+        sent = []
+        infer.shard._exchange = lambda ops: (sent.extend(op for op in ops if op.op is dist.isend), real_x(ops))[1]
+        lens = list(lens)
+        items = _items(3, lens)                               # (every rank can build them here: only rank 0 hands them in)
+        out = infer.synthesize_sharded(_Hop(), items if rank == 0 else None, n_steps=4, max_batch=3, seed=5, drop_last_frame=True, src=0,
+                                       device=None, gather="none")
+        kept = {it["item_name"]: (i, it) for i, it in enumerate(items) if it["len"] >= 2}
+        for name, pcm in out.items():
+            uid, it = kept[name]
+            assert pcm.dtype == np.int16 and np.array_equal(pcm, _stub_pcm(it["mel"][:-1], uid)), name
+        assert rank == 0 or not sent                          # no message travels back: only the source rank ever sends
+        ret.put((rank, sorted(out)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,lens", [(3, (9, 4, 13, 2, 7, 7, 1, 5)), (3, (5, 3)), (2, ())])
+def test_synthesize_sharded_without_gather_every_rank_keeps_its_share(world, lens):
+    ctx = mp.get_context("spawn")
+    ret = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_no_gather_worker, args=(r, world, port, ret, tuple(lens))) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(ret.get() for _ in range(world))
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    names = [n for r in range(world) for n in got[r]]
+    kept = [f"utt{i:02d}.npy" for i, t in enumerate(lens) if t >= 2]
+    assert sorted(names) == sorted(kept) and len(set(names)) == len(names)      # every utterance on exactly one rank
+    if len(kept) >= world:
+        assert all(got[r] for r in range(world))                                # and the source is not the only one working
+
+
 def _loopback_cpu_worker(port, ret, parts):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

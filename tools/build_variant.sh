@@ -7,11 +7,14 @@ set -eu
 OUT=$1; SRCS=$2; DEFS=$3
 B=fastdiff_amd/build
 TMP=$(mktemp -d)
+# the regular build's own compiler and flags (fastdiff_amd/build.py), so a variant differs from it by the probe macros only
+HIPCC=$(python -c "from fastdiff_amd import build; print(build.HIPCC)")
+FLAGS=$(python -c "from fastdiff_amd import build; print(' '.join(build.FLAGS))")
 for SRC in ${SRCS//,/ }; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -fno-honor-nans -x hip $DEFS -c fastdiff_amd/csrc/$SRC -o $TMP/$(basename $SRC .hip).o &
+  $HIPCC $FLAGS $DEFS -c fastdiff_amd/csrc/$SRC -o $TMP/$(basename $SRC .hip).o &
 done
 wait
 OBJS=""
 for o in $B/*.o; do [ -f $TMP/$(basename $o) ] && OBJS="$OBJS $TMP/$(basename $o)" || OBJS="$OBJS $o"; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS
+$HIPCC $(python -c "from fastdiff_amd import build; print(build.FLAGS[0])") -shared -fPIC -o $OUT $OBJS
 rm -rf $TMP
