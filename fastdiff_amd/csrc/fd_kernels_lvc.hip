@@ -417,6 +417,18 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
             hs[c] = hok ? sr[(int64_t)c * Ln + hg] : 0.0f;
 #endif
         }
+#ifdef FD_LVC_PROBE_UP_NOCONVT   // probe (round 6 gate): the fused up-sampler's own cost -- x made from the lane number, no ConvTranspose phase at all
+        if constexpr (UP > 0) {
+            load_conv_weights();
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float pv_ = __int_as_float(0x3c000000 | (lane << 8) | (c << 4));
+                xa[c] = make_float4(pv_, -pv_, pv_ * 0.5f, pv_ * 0.25f);
+                hx[c] = pv_ * 0.125f;
+            }
+            (void)xp_img; (void)hsk; (void)up_pack16; (void)up_bias;
+        }
+#else
         if constexpr (UP > 0) {
             // ---- the block's ConvTranspose (see the head of the kernel); skip is on its way from HBM meanwhile -----------------
             constexpr int R = UP, NT = (UPN + 31) / 32, PHW = R / 4;
@@ -513,6 +525,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
 #pragma unroll
             for (int c = 0; c < 8; ++c) hx[c] = hc < 2 * H ? hsk[(wave * 8 + c) * (2 * H) + hc] : 0.0f;
         }
+#endif
 #ifdef FD_LVC_LATE_KERNEL
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (HOP == 256 && UP == 0) load_kernel(0);
@@ -706,6 +719,15 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
             }
         }
     }
+#ifdef FD_LVC_PROBE_FINAL_NOFOLD   // probe (round 6 gate): the fused final conv's own cost -- the gate results are kept alive, nothing is folded or stored
+    if constexpr (FINAL) {
+#pragma unroll
+        for (int nt = 0; nt < LN; ++nt)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) asm volatile("" :: "v"(resid[nt][r]));
+        (void)eps_acc; (void)ffs;
+    }
+#else
     if constexpr (FINAL) {
         // hop 256: utterance lengths are whole tiles, so every wave of a live workgroup is valid and reaches the barrier
         float *pb = reinterpret_cast<float *>(xs);                   // [part = 2 mt + hi][7 taps][256 columns]
@@ -749,6 +771,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
             if (w0 + t >= 0 && w0 + t < Lnb) atomicAdd(ea + t, column_sum(t));
         }
     }
+#endif
     if (!(mx < GX_LIMIT)) {      // also inf; a NaN operand gives a NaN result on either path
         atomicOr(range_flag, 1);
         if constexpr (UP > 0) atomicOr(up_flag, 1);

@@ -17,8 +17,10 @@ import torch.distributed as dist
 # What one utterance costs a rank, in frames: its own T_i plus a per-utterance constant -- the part of a reverse step that does not
 # shrink with the utterance (launch chains of the predictor front, the DBlocks and the hop-8 layers, the epilogue, collation, its
 # slice of the PCM copy).  Fitted on one MI355X from fd_sample calls of B = 1..16 at 200..864 frames, N = 6 (tools/cost_model.py,
-# profiles/r06_cost_model.json): ms(call) ~ c0 + c1 * B + c2 * sum(T_i), c1 / c2 ~ 60 frames.
-UTTERANCE_OVERHEAD_FRAMES = 60.0
+# profiles/r06_cost_model.json): ms(call) = 1.12 + 0.055 * B + 0.001586 * sum(T_i) (rms residual 0.19 ms), c1 / c2 = 35 frames.  The
+# constant PER CALL (c0: 708 frames' worth -- the latency chains of a reverse step that do not shrink with the batch) is what a strong-
+# scaling job pays once per rank; the partition cannot balance it away.
+UTTERANCE_OVERHEAD_FRAMES = 35.0
 
 
 def utterance_cost(frames: int, overhead: float = UTTERANCE_OVERHEAD_FRAMES) -> float:
