@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
-SOURCES = ["fd_api.cpp", "fd_kernels_naive.hip", "fd_generic.hip", "fd_kernels_first_final.hip", "fd_kernels_dblock.hip", "fd_kernels_kp.hip", "fd_kernels_convt.hip", "fd_kernels_lvc.hip", "fd_kernels_mel.hip", "fd_kernels_train.hip", "fd_kernels_kconv.hip", "fd_kernels_cconv.hip"]
+SOURCES = ["fd_api.cpp", "fd_api_ext.cpp", "fd_api_train.cpp", "fd_kernels_naive.hip", "fd_generic.hip", "fd_kernels_first_final.hip", "fd_kernels_dblock.hip", "fd_kernels_kp.hip", "fd_kernels_convt.hip", "fd_kernels_lvc.hip", "fd_kernels_mel.hip", "fd_kernels_train.hip", "fd_kernels_kconv.hip", "fd_kernels_cconv.hip"]
 LIB = os.path.join(LIBDIR, "libfastdiff_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-honor-nans: lets fmaxf() be one v_max_f32 (no canonicalising v_max(v,v) first); fp32 VALU work is not hidden under

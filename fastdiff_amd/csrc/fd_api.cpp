@@ -1,5 +1,6 @@
-// fd_api.cpp -- host side of libfastdiff_hip.so: context, state_dict ingestion (weight-norm fold + repack),
-// workspace, the denoiser step sequence, the hipGraph-replayed reverse loop, taps and profiling.
+// fd_api.cpp -- host side of libfastdiff_hip.so, the inference boundary (include/fastdiff_hip.h): context, state_dict ingestion (weight-norm
+// fold + repack), workspace, the denoiser step sequence, the hipGraph-replayed reverse loop, options.  The rows next to the path and the
+// hooks: fd_api_ext.cpp (fastdiff_hip_ext.h); the training operators: fd_api_train.cpp (fastdiff_hip_train.h).
 #include <math.h>
 #include <stddef.h>
 #include <stdio.h>
@@ -9,26 +10,12 @@
 #include <algorithm>
 
 #include "fd_kernels.h"
+#include "fd_host.h"
 
-static std::string g_create_error;
-static int settle(fd_handle h);      // fallback = host: look at the flags of a pending fd_sample before touching device state
+std::string g_create_error;
 
 // rows of the predictor GEMM's fp16 image per utterance (gx_rows in fd_kernels_kp.hip: 128-frame windows + 2 halo rows)
 static inline int gx_rows_host(int T) { return ((T + 127) / 128) * 128 + 2; }
-
-#define FD_FAIL(h, code, ...)                                   \
-    do {                                                        \
-        char buf__[512];                                        \
-        snprintf(buf__, sizeof(buf__), __VA_ARGS__);            \
-        if (h) (h)->err = buf__; else g_create_error = buf__;   \
-        return (code);                                          \
-    } while (0)
-
-#define FD_HIP(h, expr)                                                                                   \
-    do {                                                                                                  \
-        hipError_t e__ = (expr);                                                                          \
-        if (e__ != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__));    \
-    } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // profiling helpers (declared in fd_internal.h)
@@ -72,7 +59,7 @@ void fd_prof_end(const fdk::Launch &L)
     hipEventRecord(c->prof_pending.back().e1, L.stream);
 }
 
-static void prof_drain(fd_context *c)
+void fd_prof_drain(fd_context *c)
 {
     for (auto &pe : c->prof_pending) {
         float ms = 0.0f;
@@ -277,9 +264,9 @@ int fd_destroy(fd_handle h)
 {
     if (!h) return FD_ERR_INVALID;
     hipSetDevice(h->device);
-    settle(h);
+    fd_settle(h);
     hipDeviceSynchronize();
-    prof_drain(h);
+    fd_prof_drain(h);
     release_handle(h);
     return FD_OK;
 }
@@ -450,7 +437,7 @@ int fd_commit_weights(fd_handle h)
     if (!h) return FD_ERR_INVALID;
     FD_HIP(h, hipSetDevice(h->device));
     {
-        const int rcs = settle(h);      // a pending host check would otherwise run its call again on the NEW weights
+        const int rcs = fd_settle(h);      // a pending host check would otherwise run its call again on the NEW weights
         if (rcs != FD_OK) return rcs;
     }
     h->embed_valid = false;
@@ -864,7 +851,6 @@ static hipError_t run_step(const Launch &L, const StepIO &io, int B, int T)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-static int settle(fd_handle h);
 
 static int check_common(fd_handle h, int B, int T, const char *who)
 {
@@ -878,7 +864,7 @@ static int check_common(fd_handle h, int B, int T, const char *who)
 }
 
 // Pinned staging (fd_context::stage): the next slot of the ring with room for `bytes`, free to be written by the host.
-static int stage_acquire(fd_handle h, size_t bytes, fd_context::StageSlot **out)
+int fd_stage_acquire(fd_handle h, size_t bytes, fd_context::StageSlot **out)
 {
     fd_context::StageSlot &sl = h->stage[h->stage_next++ % fd_context::STAGE_SLOTS];
     if (sl.done) FD_HIP(h, hipEventSynchronize(sl.done));             // the uploads that last used this slot (8 calls ago)
@@ -894,7 +880,7 @@ static int stage_acquire(fd_handle h, size_t bytes, fd_context::StageSlot **out)
     return FD_OK;
 }
 // ... and the mark behind the copies that read it
-static int stage_commit(fd_handle h, fd_context::StageSlot *sl, hipStream_t stream)
+int fd_stage_commit(fd_handle h, fd_context::StageSlot *sl, hipStream_t stream)
 {
     FD_HIP(h, hipEventRecord(sl->done, stream));
     return FD_OK;
@@ -916,7 +902,7 @@ static int mark_tail(fd_handle h, hipStream_t s)
 static int follow_stream(fd_handle h, hipStream_t s)
 {
     if (h->have_last_stream && h->last_stream != s) {
-        const int rc = settle(h);      // (a pending check may redo its call on the old stream: that stream must live until the call is settled)
+        const int rc = fd_settle(h);      // (a pending check may redo its call on the old stream: that stream must live until the call is settled)
         if (rc != FD_OK) return rc;
         if (h->tail_marked) FD_HIP(h, hipStreamWaitEvent(s, h->ev_switch, 0));
     }
@@ -952,7 +938,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
     if (h) h->noise_ids.clear();                 // stream ids are for the next fd_sample only: a forward in between drops them
     int rc = check_common(h, B, T, "fd_forward");
     if (rc != FD_OK) return rc;
-    if ((rc = settle(h)) != FD_OK) return rc;
+    if ((rc = fd_settle(h)) != FD_OK) return rc;
     if ((rc = follow_stream(h, (hipStream_t)stream)) != FD_OK) return rc;
     h->inline_fallback = true; h->fp32_mask = 0;      // a single forward always carries its fallbacks inline
     h->hoist_np = 1; h->hoist_step = 0; h->hoist_chunk = false;
@@ -969,9 +955,9 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
     if ((rc = ensure_workspace(h, B, T)) != FD_OK) return rc;
     if (lens) {
         fd_context::StageSlot *sl = nullptr;
-        if ((rc = stage_acquire(h, sizeof(int) * B, &sl)) != FD_OK) return rc;
+        if ((rc = fd_stage_acquire(h, sizeof(int) * B, &sl)) != FD_OK) return rc;
         if ((rc = set_lens(h, lens, B, T, (hipStream_t)stream, "fd_forward", reinterpret_cast<int *>(sl->host))) != FD_OK) return rc;
-        if ((rc = stage_commit(h, sl, (hipStream_t)stream)) != FD_OK) return rc;
+        if ((rc = fd_stage_commit(h, sl, (hipStream_t)stream)) != FD_OK) return rc;
     } else {
         h->step_lens = nullptr;
     }
@@ -995,7 +981,7 @@ static unsigned mode_signature(const fd_context *h)
 
 static int resolve_pending(fd_handle h, unsigned *mask);
 // Every entry point that touches device state first settles a pending fallback = host check (no-op otherwise).
-static int settle(fd_handle h)
+int fd_settle(fd_handle h)
 {
     if (!h->pending.active) return FD_OK;
     unsigned mask = 0;
@@ -1196,7 +1182,7 @@ static int sample_core(fd_handle h, const fd_context::SampleArgs &a, unsigned fo
     {
         fd_context::StageSlot *sl = nullptr;
         const size_t off_lens = sizeof(StepParams), off_ids = off_lens + ((sizeof(int) * B + 7) & ~(size_t)7);
-        if ((rc = stage_acquire(h, off_ids + sizeof(unsigned long long) * B, &sl)) != FD_OK) return rc;
+        if ((rc = fd_stage_acquire(h, off_ids + sizeof(unsigned long long) * B, &sl)) != FD_OK) return rc;
         if ((rc = set_lens(h, lens_eff, B, T, stream, "fd_sample", reinterpret_cast<int *>(sl->host + off_lens))) != FD_OK) return rc;
         if (!ids.empty()) {
             memcpy(sl->host + off_ids, ids.data(), sizeof(unsigned long long) * B);
@@ -1213,7 +1199,7 @@ static int sample_core(fd_handle h, const fd_context::SampleArgs &a, unsigned fo
         const size_t off = offsetof(StepParams, z);
         FD_HIP(h, hipMemcpyAsync(reinterpret_cast<char *>(ws.params) + off, reinterpret_cast<const char *>(p) + off, sizeof(StepParams) - off,
                                  hipMemcpyHostToDevice, stream));
-        if ((rc = stage_commit(h, sl, stream)) != FD_OK) return rc;
+        if ((rc = fd_stage_commit(h, sl, stream)) != FD_OK) return rc;
     }
     fdk::Launch L = {h, stream, false};
     hipError_t e = fdk::copy_rows(L, ws.mel, T, a.mel, T_io, T_io, B * fd::COND);
@@ -1343,7 +1329,7 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
     if (lazy && ws_ok && h->pending.active && h->pending.lazy) {
         prev = h->pending;
         h->pending.active = false;
-    } else if ((rc = settle(h)) != FD_OK) return rc;
+    } else if ((rc = fd_settle(h)) != FD_OK) return rc;
     auto finish_prev = [&]() -> int {
         if (!prev.active) return FD_OK;
         unsigned mask = 0;
@@ -1383,7 +1369,7 @@ int fd_sample(fd_handle h, const float *mel, int B, int T, const int *lens, cons
     // The contract of the reference call is "call, then read" (util.py:215-235): unless the caller opted into the pipelined check
     // (option defer_check = 1: tickets, fd_sample_check / fd_sample_settle), the range check of this call is settled before fd_sample
     // returns -- one wait for the call's own work and, if an operand left the fp16 range, the second pass on the fp32 kernels.
-    if (!h->defer_check) return settle(h);
+    if (!h->defer_check) return fd_settle(h);
     return FD_OK;
 }
 
@@ -1426,795 +1412,6 @@ int fd_set_noise_streams(fd_handle h, const uint64_t *stream_ids, int B)
     return FD_OK;
 }
 
-// The DEFAULT filter bank of a front-end, dense [80][513]: librosa.filters.mel(22050, 1024, 80, fmin, fmax) restated in double
-// precision (Slaney mel scale, triangular weights on the FFT bin centres, each filter scaled by 2 / (f[m+2] - f[m])) for 'pwg' (fmin
-// 80, fmax 7600; base.yaml:8-9) and Tacotron (0, 8000; FastDiff_tacotron.yaml:20-21).  librosa is not in this image, so these values
-// are a restatement pinned only against an independent derivation (tests/test_mel_frontend.py); a deployment that has librosa hands
-// its own matrix to fd_set_mel_filterbank and this function is then not used.
-static const int MEL_NM = 80, MEL_NB = 513;
-static std::vector<float> default_mel_bank(int variant)
-{
-    const double sr = 22050.0;
-    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
-    auto hz_to_mel = [&](double f) { return f >= min_log_hz ? min_log_mel + log(f / min_log_hz) / logstep : f / f_sp; };
-    auto mel_to_hz = [&](double m) { return m >= min_log_mel ? min_log_hz * exp(logstep * (m - min_log_mel)) : f_sp * m; };
-    const double band[MEL_VARIANTS][2] = {{80.0, 7600.0}, {0.0, 8000.0}};
-    std::vector<double> mf(MEL_NM + 2);
-    const double m0 = hz_to_mel(band[variant][0]), m1 = hz_to_mel(band[variant][1]);
-    for (int i = 0; i < MEL_NM + 2; ++i) mf[i] = mel_to_hz(m0 + (m1 - m0) * i / (MEL_NM + 1));
-    std::vector<float> fb((size_t)MEL_NM * MEL_NB, 0.0f);
-    for (int m = 0; m < MEL_NM; ++m) {
-        const double enorm = 2.0 / (mf[m + 2] - mf[m]);
-        for (int k = 0; k < MEL_NB; ++k) {
-            const double fk = (sr / 2.0) * k / (MEL_NB - 1);
-            const double lower = (fk - mf[m]) / (mf[m + 1] - mf[m]), upper = (mf[m + 2] - fk) / (mf[m + 2] - mf[m + 1]);
-            const double wv = std::max(0.0, std::min(lower, upper));
-            if (wv > 0.0) fb[(size_t)m * MEL_NB + k] = (float)(wv * enorm);
-        }
-    }
-    return fb;
-}
-
-static int mel_upload(fd_handle h, const void *src, size_t bytes, const void **dst)
-{
-    void *d = nullptr;
-    FD_HIP(h, hipMalloc(&d, bytes));
-    h->mel_allocs.push_back(d);        // freed at fd_destroy: a replaced table stays valid for launches still in flight
-    FD_HIP(h, hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
-    *dst = d;
-    return FD_OK;
-}
-
-// A dense bank [80][513] as the kernel reads it: per filter the first non-zero bin, the span up to the last non-zero one, and the
-// weights of that span exactly as given (k_mel_frontend adds w[k] * |X_k| over the span in ascending k; a zero inside it adds zero).
-static int upload_mel_bank(fd_handle h, int variant, const float *fb)
-{
-    std::vector<int> lo(MEL_NM, 0), cnt(MEL_NM, 0), off(MEL_NM, 0);
-    std::vector<float> wts;
-    for (int m = 0; m < MEL_NM; ++m) {
-        int first = -1, last = -1;
-        for (int k = 0; k < MEL_NB; ++k)
-            if (fb[(size_t)m * MEL_NB + k] != 0.0f) { if (first < 0) first = k; last = k; }
-        off[m] = (int)wts.size();
-        if (first >= 0) {
-            lo[m] = first; cnt[m] = last - first + 1;
-            wts.insert(wts.end(), fb + (size_t)m * MEL_NB + first, fb + (size_t)m * MEL_NB + last + 1);
-        }
-    }
-    if (wts.empty()) wts.push_back(0.0f);
-    MelTables t = h->mel[variant];
-    int rc;
-    if ((rc = mel_upload(h, lo.data(), lo.size() * sizeof(int), reinterpret_cast<const void **>(&t.fb_lo))) != FD_OK) return rc;
-    if ((rc = mel_upload(h, cnt.data(), cnt.size() * sizeof(int), reinterpret_cast<const void **>(&t.fb_n))) != FD_OK) return rc;
-    if ((rc = mel_upload(h, off.data(), off.size() * sizeof(int), reinterpret_cast<const void **>(&t.fb_off))) != FD_OK) return rc;
-    if ((rc = mel_upload(h, wts.data(), wts.size() * sizeof(float), reinterpret_cast<const void **>(&t.fb_w))) != FD_OK) return rc;
-    h->mel[variant] = t;
-    h->mel_bank[variant].assign(fb, fb + (size_t)MEL_NM * MEL_NB);
-    return FD_OK;
-}
-
-// Tables of the mel front-end: twiddles and the periodic Hann window in double precision (shared), and each front-end's filter bank
-// (the caller's, if fd_set_mel_filterbank supplied one before the first use, else the default above).
-static int ensure_mel_tables(fd_handle h)
-{
-    if (h->mel[MEL_VARIANTS - 1].tab) return FD_OK;
-    const int NF = 1024;
-    const double pi = 3.14159265358979323846;
-    std::vector<float> tab(3 * NF);
-    for (int i = 0; i < NF; ++i) {
-        tab[i] = (float)cos(2.0 * pi * i / NF);
-        tab[NF + i] = (float)sin(2.0 * pi * i / NF);
-        tab[2 * NF + i] = (float)(0.5 - 0.5 * cos(2.0 * pi * i / NF));
-    }
-    const float *tab_dev = nullptr;
-    int rc;
-    if ((rc = mel_upload(h, tab.data(), tab.size() * sizeof(float), reinterpret_cast<const void **>(&tab_dev))) != FD_OK) return rc;
-    for (int v = 0; v < MEL_VARIANTS; ++v) {
-        if (!h->mel[v].fb_w) {
-            const std::vector<float> fb = default_mel_bank(v);
-            if ((rc = upload_mel_bank(h, v, fb.data())) != FD_OK) return rc;
-        }
-        h->mel[v].tab = tab_dev;                           // last: marks this variant ready
-    }
-    return FD_OK;
-}
-
-int fd_set_mel_filterbank(fd_handle h, const float *fb, int n_mels, int n_bins)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (n_mels != MEL_NM || n_bins != MEL_NB)
-        FD_FAIL(h, FD_ERR_INVALID, "fd_set_mel_filterbank: the front-end is 80 filters over the 513 bins of a 1024-point FFT, got [%d][%d]", n_mels, n_bins);
-    FD_HIP(h, hipSetDevice(h->device));
-    const int v = h->mel_variant;
-    if (!fb) {                                             // back to the restated default
-        const std::vector<float> def = default_mel_bank(v);
-        h->mel_bank_user[v] = false;
-        return upload_mel_bank(h, v, def.data());
-    }
-    for (size_t i = 0; i < (size_t)MEL_NM * MEL_NB; ++i) {      // (on the bit pattern: this file is built with -fno-honor-nans)
-        uint32_t bits;
-        memcpy(&bits, fb + i, sizeof(bits));
-        if ((bits & 0x7F800000u) == 0x7F800000u) FD_FAIL(h, FD_ERR_INVALID, "fd_set_mel_filterbank: element %zu is not finite", i);
-    }
-    const int rc = upload_mel_bank(h, v, fb);
-    if (rc == FD_OK) h->mel_bank_user[v] = true;
-    return rc;
-}
-
-int fd_get_mel_filterbank(fd_handle h, float *fb_out, int n_mels, int n_bins)
-{
-    if (!h || !fb_out) return FD_ERR_INVALID;
-    if (n_mels != MEL_NM || n_bins != MEL_NB) FD_FAIL(h, FD_ERR_INVALID, "fd_get_mel_filterbank: expects [80][513], got [%d][%d]", n_mels, n_bins);
-    FD_HIP(h, hipSetDevice(h->device));
-    const int rc = ensure_mel_tables(h);
-    if (rc != FD_OK) return rc;
-    const int v = h->mel_variant;
-    memcpy(fb_out, h->mel_bank[v].data(), sizeof(float) * MEL_NM * MEL_NB);
-    return h->mel_bank_user[v] ? 1 : 0;
-}
-
-int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_samples, float *mel, int T, void *stream)
-{
-    if (!h || !wav || !mel || B <= 0 || n_samples <= 0 || B > 65535) return FD_ERR_INVALID;
-    if (T < 1 || T > 1 + n_samples / 256) FD_FAIL(h, FD_ERR_INVALID, "fd_mel_spectrogram: T=%d outside 1..1+n_samples/256=%lld", T, (long long)(1 + n_samples / 256));
-    if (h->mel_variant == MEL_TACOTRON && n_samples <= 512)      // F.pad(mode='reflect') needs pad < length (tacotron/stft.py:84-88)
-        FD_FAIL(h, FD_ERR_INVALID, "fd_mel_spectrogram: reflect padding of 512 needs more than 512 samples, got %lld", (long long)n_samples);
-    FD_HIP(h, hipSetDevice(h->device));
-    int rc = (h->pending.active && h->pending.lazy) ? FD_OK : settle(h);      // the front-end touches no sampler state
-    if (rc != FD_OK) return rc;
-    rc = ensure_mel_tables(h);
-    if (rc != FD_OK) return rc;
-    fdk::Launch L = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::mel_frontend(L, wav, B, n_samples, mel, T);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_mel_spectrogram: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-static int check_lvc_op(fd_handle h, int B, int Cin, int Cout, int ks, int T, int hop, const char *who)
-{
-    if (B <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || hop <= 0 || ks <= 0 || (ks & 1) == 0)
-        FD_FAIL(h, FD_ERR_INVALID, "%s: B=%d Cin=%d Cout=%d ks=%d T=%d hop=%d must be positive, ks odd", who, B, Cin, Cout, ks, T, hop);
-    if ((int64_t)Cin * Cout * ks > 8192 || Cout > 256)
-        FD_FAIL(h, FD_ERR_UNSUPPORTED, "%s: Cin*Cout*ks = %lld > 8192 (or Cout > 256) has no kernel", who, (long long)Cin * Cout * ks);
-    if ((int64_t)B * std::max(Cin, Cout) * T * hop >= (int64_t)1 << 31)
-        FD_FAIL(h, FD_ERR_INVALID, "%s: tensor too large for one call", who);
-    if (B > 65535 || std::max(Cin, Cout) > 65535) FD_FAIL(h, FD_ERR_INVALID, "%s: B, channels <= 65535", who);
-    return FD_OK;
-}
-
-// The matrix-pipe kernels of the operator read the predicted kernels frame-major: room for one copy (B*T*Cin*Cout*ks floats), kept on
-// the handle and grown when a call needs more (hipFree waits for the device, so work in flight on the old buffer is safe).  Calls on
-// one handle share it: they must be ordered on one stream, as torch.autograd orders a forward and its backward.
-static int lvc_scratch(fd_handle h, int B, int Cin, int Cout, int ks, int T, int hop, float **out)
-{
-    *out = nullptr;
-    if (!fdk::lvc_op_needs_scratch(Cin, Cout, ks, hop)) return FD_OK;
-    const size_t bytes = sizeof(float) * (size_t)B * T * Cin * Cout * ks;
-    if (h->lvc_scratch_bytes < bytes) {
-        if (h->lvc_scratch) FD_HIP(h, hipFree(h->lvc_scratch));
-        h->lvc_scratch = nullptr; h->lvc_scratch_bytes = 0;
-        FD_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->lvc_scratch), bytes));
-        h->lvc_scratch_bytes = bytes;
-    }
-    *out = h->lvc_scratch;
-    return FD_OK;
-}
-
-int fd_lvc_forward_strided(fd_handle h, const float *x, const float *kernel, int64_t kernel_bstride, const float *bias, int B, int Cin, int Cout,
-                           int ks, int T, int hop, float *out, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!x || !kernel || !bias || !out) FD_FAIL(h, FD_ERR_INVALID, "fd_lvc_forward: null pointer");
-    int rc = check_lvc_op(h, B, Cin, Cout, ks, T, hop, "fd_lvc_forward");
-    if (rc != FD_OK) return rc;
-    const int64_t own = (int64_t)Cin * Cout * ks * T;
-    if (kernel_bstride != 0 && kernel_bstride != own && (kernel_bstride < own || !fdk::lvc_op_needs_scratch(Cin, Cout, ks, hop)))
-        FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_lvc_forward: a batch-strided kernel (stride %lld) needs the model's shape (32 -> 64, k3, hop 8 / 64 / 256)", (long long)kernel_bstride);
-    FD_HIP(h, hipSetDevice(h->device));
-    float *scratch = nullptr;
-    if ((rc = lvc_scratch(h, B, Cin, Cout, ks, T, hop, &scratch)) != FD_OK) return rc;
-    fdk::Launch L = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::lvc_op_forward(L, x, kernel, bias, out, B, Cin, Cout, ks, T, hop, scratch, kernel_bstride);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_lvc_forward: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_lvc_forward(fd_handle h, const float *x, const float *kernel, const float *bias, int B, int Cin, int Cout, int ks, int T, int hop,
-                   float *out, void *stream)
-{
-    return fd_lvc_forward_strided(h, x, kernel, 0, bias, B, Cin, Cout, ks, T, hop, out, stream);
-}
-
-int fd_lvc_backward_strided(fd_handle h, const float *x, const float *kernel, int64_t kernel_bstride, const float *dout, int B, int Cin, int Cout,
-                            int ks, int T, int hop, float *dx, float *dkernel, int64_t dkernel_bstride, float *dbias, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!dout || ((dkernel || dbias) && !x) || (dx && !kernel)) FD_FAIL(h, FD_ERR_INVALID, "fd_lvc_backward: null pointer");
-    int rc = check_lvc_op(h, B, Cin, Cout, ks, T, hop, "fd_lvc_backward");
-    if (rc != FD_OK) return rc;
-    const int64_t own = (int64_t)Cin * Cout * ks * T;
-    for (int64_t st : {kernel_bstride, dkernel_bstride})
-        if (st != 0 && st != own && (st < own || !fdk::lvc_op_needs_scratch(Cin, Cout, ks, hop)))
-            FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_lvc_backward: a batch-strided kernel / dkernel (stride %lld) needs the model's shape (32 -> 64, k3, hop 8 / 64 / 256)", (long long)st);
-    FD_HIP(h, hipSetDevice(h->device));
-    float *scratch = nullptr;
-    if ((rc = lvc_scratch(h, B, Cin, Cout, ks, T, hop, &scratch)) != FD_OK) return rc;
-    if (scratch && dx && !kernel) FD_FAIL(h, FD_ERR_INVALID, "fd_lvc_backward: null pointer");
-    fdk::Launch L = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::lvc_op_backward(L, x, kernel, dout, dx, dkernel, dbias, B, Cin, Cout, ks, T, hop, scratch, kernel_bstride, dkernel_bstride);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_lvc_backward: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_lvc_backward(fd_handle h, const float *x, const float *kernel, const float *dout, int B, int Cin, int Cout, int ks, int T, int hop,
-                    float *dx, float *dkernel, float *dbias, void *stream)
-{
-    return fd_lvc_backward_strided(h, x, kernel, 0, dout, B, Cin, Cout, ks, T, hop, dx, dkernel, 0, dbias, stream);
-}
-
-// kernel_conv of the KernelPredictor (training path).  The backward adds up partial sums (row slices for dx, utterance ranges for
-// dweight / dbias, each in a fixed order) through a scratch buffer kept on the handle next to the LVC operator's (same rule: calls on
-// one handle are ordered on one stream).
-static int kconv_scratch_reserve(fd_handle h, int B, int M, int T)
-{
-    const size_t bytes = sizeof(float) * fdk::kconv_scratch_floats(B, M, T);
-    if (h->kconv_scratch_bytes < bytes) {
-        if (h->kconv_scratch) FD_HIP(h, hipFree(h->kconv_scratch));
-        h->kconv_scratch = nullptr; h->kconv_scratch_bytes = 0;
-        FD_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->kconv_scratch), bytes));
-        h->kconv_scratch_bytes = bytes;
-    }
-    return FD_OK;
-}
-
-static int check_act(fd_handle h, int M, int T, float post, const char *who)
-{
-    if (!(post > 0.0f && post <= 1.0f)) FD_FAIL(h, FD_ERR_INVALID, "%s: the leaky-relu slope must lie in (0, 1] (1 = no activation), got %g", who, post);
-    if (post != 1.0f && !fdk::kconv_act_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "%s: the fused activation covers M <= 512 (the predictor's small convolutions), got M=%d", who, M);
-    return FD_OK;
-}
-
-int fd_kconv_forward_act(fd_handle h, const float *x, const float *weight, const float *bias, int B, int M, int T, float post_slope, float *out,
-                         void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!x || !weight || !bias || !out) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_forward: null pointer");
-    if (B <= 0 || B > 65535) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_forward: B=%d", B);
-    if (!fdk::kconv_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_forward: M=%d (a multiple of 32) and T=%d (1..128) only", M, T);
-    const int rc = check_act(h, M, T, post_slope, "fd_kconv_forward");
-    if (rc != FD_OK) return rc;
-    FD_HIP(h, hipSetDevice(h->device));
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::kconv_forward(La, x, weight, bias, out, B, M, T, false, post_slope);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_kconv_forward: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_kconv_forward(fd_handle h, const float *x, const float *weight, const float *bias, int B, int M, int T, float *out, void *stream)
-{
-    return fd_kconv_forward_act(h, x, weight, bias, B, M, T, 1.0f, out, stream);
-}
-
-int fd_kconv_backward_act(fd_handle h, const float *x, const float *weight, const float *y, const float *dout, int B, int M, int T,
-                          float post_slope, float in_slope, float *dx, float *dweight, float *dbias, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!dout || ((dweight || dbias) && !x) || (dx && !weight)) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward: null pointer");
-    if (B <= 0 || B > 65535) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward: B=%d", B);
-    if (!fdk::kconv_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_backward: M=%d (a multiple of 32) and T=%d (1..128) only", M, T);
-    int rc = check_act(h, M, T, post_slope, "fd_kconv_backward");
-    if (rc != FD_OK) return rc;
-    if (post_slope != 1.0f && !y) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward: a fused activation needs the forward's output y");
-    if (!(in_slope > 0.0f && in_slope <= 1.0f)) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward: in_slope must lie in (0, 1], got %g", in_slope);
-    if (in_slope != 1.0f && dx && !x) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward: in_slope needs x");
-    FD_HIP(h, hipSetDevice(h->device));
-    if ((rc = kconv_scratch_reserve(h, B, M, T)) != FD_OK) return rc;
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::kconv_backward(La, x, weight, dout, dx, dweight, dbias, B, M, T, h->kconv_scratch, false, post_slope != 1.0f ? y : nullptr, post_slope,
-                                       in_slope);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_kconv_backward: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_kconv_backward_w_multi(fd_handle h, int n, const float *const *x, const float *const *dout, const float *const *y, int B, int M, int T,
-                              float post_slope, float *const *dweight, float *const *dbias, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!x || !dout || (!dweight && !dbias)) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward_w_multi: null pointer");
-    if (n < 1 || n > 8) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward_w_multi: n=%d outside 1..8", n);
-    if (B <= 0 || B > 65535) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward_w_multi: B=%d", B);
-    if (!fdk::kconv_act_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_backward_w_multi: M=%d (a multiple of 32, <= 512) and T=%d (1..128) only", M, T);
-    int rc = check_act(h, M, T, post_slope, "fd_kconv_backward_w_multi");
-    if (rc != FD_OK) return rc;
-    for (int i = 0; i < n; ++i)
-        if (!x[i] || !dout[i]) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward_w_multi: null pointer in item %d", i);
-    FD_HIP(h, hipSetDevice(h->device));
-    {
-        const size_t bytes = sizeof(float) * fdk::kconv_w_multi_scratch_floats(n, B, M);
-        if (h->kconv_scratch_bytes < bytes) {
-            if (h->kconv_scratch) FD_HIP(h, hipFree(h->kconv_scratch));
-            h->kconv_scratch = nullptr; h->kconv_scratch_bytes = 0;
-            FD_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->kconv_scratch), bytes));
-            h->kconv_scratch_bytes = bytes;
-        }
-    }
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::kconv_backward_w_multi(La, n, x, dout, y, post_slope, B, M, T, dweight, dbias, h->kconv_scratch);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_kconv_backward_w_multi: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-static int check_input_conv(fd_handle h, int B, int T, float post, const char *who);
-
-static int kconv_scratch_floats_reserve(fd_handle h, size_t floats)
-{
-    const size_t bytes = sizeof(float) * floats;
-    if (h->kconv_scratch_bytes < bytes) {
-        if (h->kconv_scratch) FD_HIP(h, hipFree(h->kconv_scratch));
-        h->kconv_scratch = nullptr; h->kconv_scratch_bytes = 0;
-        FD_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->kconv_scratch), bytes));
-        h->kconv_scratch_bytes = bytes;
-    }
-    return FD_OK;
-}
-
-static int check_multi(fd_handle h, int n, int B, const void *const *lists, int nlists, const char *who)
-{
-    if (n < 1 || n > 8) FD_FAIL(h, FD_ERR_INVALID, "%s: n=%d outside 1..8", who, n);
-    if (B <= 0 || B > 65535) FD_FAIL(h, FD_ERR_INVALID, "%s: B=%d", who, B);
-    for (int k = 0; k < nlists; ++k) {
-        const void *const *l = reinterpret_cast<const void *const *>(lists[k]);
-        if (!l) FD_FAIL(h, FD_ERR_INVALID, "%s: null pointer list", who);
-        for (int i = 0; i < n; ++i)
-            if (!l[i]) FD_FAIL(h, FD_ERR_INVALID, "%s: null pointer in item %d", who, i);
-    }
-    return FD_OK;
-}
-
-int fd_kconv_forward_act_multi(fd_handle h, int n, const float *const *x, const float *const *weight, const float *const *bias, int B, int M, int T,
-                               float post_slope, float *const *out, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    const void *lists[4] = {x, weight, bias, out};
-    int rc = check_multi(h, n, B, lists, 4, "fd_kconv_forward_act_multi");
-    if (rc != FD_OK) return rc;
-    if (!fdk::kconv_act_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_forward_act_multi: M=%d (a multiple of 32, <= 512) and T=%d (1..128) only", M, T);
-    if ((rc = check_act(h, M, T, post_slope, "fd_kconv_forward_act_multi")) != FD_OK) return rc;
-    FD_HIP(h, hipSetDevice(h->device));
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::kconv_forward_multi(La, n, x, weight, bias, out, B, M, T, post_slope);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_kconv_forward_act_multi: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_kconv_backward_x_multi(fd_handle h, int n, const float *const *x, const float *const *weight, const float *const *y, const float *const *dout,
-                              int B, int M, int T, float post_slope, float in_slope, float *const *dx, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    const void *lists[3] = {weight, dout, dx};
-    int rc = check_multi(h, n, B, lists, 3, "fd_kconv_backward_x_multi");
-    if (rc != FD_OK) return rc;
-    if (!fdk::kconv_act_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_backward_x_multi: M=%d (a multiple of 32, <= 512) and T=%d (1..128) only", M, T);
-    if ((rc = check_act(h, M, T, post_slope, "fd_kconv_backward_x_multi")) != FD_OK) return rc;
-    if (!(in_slope > 0.0f && in_slope <= 1.0f)) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward_x_multi: in_slope must lie in (0, 1], got %g", in_slope);
-    if (in_slope != 1.0f) {
-        const void *lx[1] = {x};
-        if ((rc = check_multi(h, n, B, lx, 1, "fd_kconv_backward_x_multi")) != FD_OK) return rc;
-    }
-    if (post_slope != 1.0f && !y) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward_x_multi: a fused activation needs the forward's outputs y");
-    FD_HIP(h, hipSetDevice(h->device));
-    if ((rc = kconv_scratch_floats_reserve(h, fdk::kconv_x_multi_scratch_floats(n, B, M, T))) != FD_OK) return rc;
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::kconv_backward_x_multi(La, n, x, weight, post_slope != 1.0f ? y : nullptr, dout, dx, B, M, T, post_slope, in_slope, h->kconv_scratch);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_kconv_backward_x_multi: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_input_conv_forward_multi(fd_handle h, int n, const float *const *x, const float *const *weight, const float *const *bias, int B, int T,
-                                float post_slope, float *const *out, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    const void *lists[4] = {x, weight, bias, out};
-    int rc = check_multi(h, n, B, lists, 4, "fd_input_conv_forward_multi");
-    if (rc != FD_OK) return rc;
-    if ((rc = check_input_conv(h, B, T, post_slope, "fd_input_conv_forward_multi")) != FD_OK) return rc;
-    FD_HIP(h, hipSetDevice(h->device));
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::input_conv_forward_multi(La, n, x, weight, bias, out, B, T, post_slope);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_input_conv_forward_multi: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_input_conv_backward_multi(fd_handle h, int n, const float *const *x, const float *const *weight, const float *const *y, const float *const *dout,
-                                 int B, int T, float post_slope, float *const *dx, float *const *dweight, float *const *dbias, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    const void *lists[4] = {x, weight, y, dout};
-    int rc = check_multi(h, n, B, lists, 4, "fd_input_conv_backward_multi");
-    if (rc != FD_OK) return rc;
-    if ((rc = check_input_conv(h, B, T, post_slope, "fd_input_conv_backward_multi")) != FD_OK) return rc;
-    if (dx) { const void *l[1] = {dx}; if ((rc = check_multi(h, n, B, l, 1, "fd_input_conv_backward_multi")) != FD_OK) return rc; }
-    FD_HIP(h, hipSetDevice(h->device));
-    if ((rc = kconv_scratch_floats_reserve(h, fdk::input_conv_multi_scratch_floats(n, B))) != FD_OK) return rc;
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::input_conv_backward_multi(La, n, x, weight, y, dout, dx, dweight, dbias, B, T, post_slope, h->kconv_scratch);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_input_conv_backward_multi: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_kconv_backward(fd_handle h, const float *x, const float *weight, const float *dout, int B, int M, int T, float *dx, float *dweight,
-                      float *dbias, void *stream)
-{
-    return fd_kconv_backward_act(h, x, weight, nullptr, dout, B, M, T, 1.0f, 1.0f, dx, dweight, dbias, stream);
-}
-
-static int weight_norm_multi(fd_handle h, const fd_wn_item *items, int n, void *stream, bool backward, const char *who)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!items) FD_FAIL(h, FD_ERR_INVALID, "%s: null pointer", who);
-    if (n <= 0 || n > 4096) FD_FAIL(h, FD_ERR_INVALID, "%s: n=%d", who, n);
-    for (int i = 0; i < n; ++i) {
-        const fd_wn_item &I = items[i];
-        if (I.rows <= 0 || I.cols <= 0 || I.rows > ((int64_t)1 << 31) || !I.v || !I.g || !I.norm || (backward ? (!I.dv || !I.dg) : !I.w))
-            FD_FAIL(h, FD_ERR_INVALID, "%s: item %d: rows=%lld cols=%d or a null pointer", who, i, (long long)I.rows, I.cols);
-    }
-    FD_HIP(h, hipSetDevice(h->device));
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::weight_norm_multi(La, items, n, backward);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "%s: %s", who, hipGetErrorString(e));
-    return FD_OK;
-}
-int fd_weight_norm_multi_forward(fd_handle h, const fd_wn_item *items, int n, void *stream)
-{
-    return weight_norm_multi(h, items, n, stream, false, "fd_weight_norm_multi_forward");
-}
-int fd_weight_norm_multi_backward(fd_handle h, const fd_wn_item *items, int n, void *stream)
-{
-    return weight_norm_multi(h, items, n, stream, true, "fd_weight_norm_multi_backward");
-}
-
-// A skip tensor's fan-out (fd_kernels_train.hip: k_fan_*).
-int fd_fan_forward(fd_handle h, const float *x, int rows, int64_t L, int factor, float *picked, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!x || !picked) FD_FAIL(h, FD_ERR_INVALID, "fd_fan_forward: null pointer");
-    if (rows <= 0 || rows > 65535 || L <= 0 || factor < 1 || L % factor != 0) FD_FAIL(h, FD_ERR_INVALID, "fd_fan_forward: rows=%d L=%lld factor=%d", rows, (long long)L, factor);
-    FD_HIP(h, hipSetDevice(h->device));
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::fan_pick(La, x, picked, rows, L, factor);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_fan_forward: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_fan_backward(fd_handle h, const float *g0, const float *g1, const float *g2, const float *g3, const float *gpicked, int rows, int64_t L,
-                    int factor, float *dx, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!dx) FD_FAIL(h, FD_ERR_INVALID, "fd_fan_backward: null pointer");
-    if (rows <= 0 || rows > 65535 || L <= 0 || factor < 1 || L % factor != 0) FD_FAIL(h, FD_ERR_INVALID, "fd_fan_backward: rows=%d L=%lld factor=%d", rows, (long long)L, factor);
-    FD_HIP(h, hipSetDevice(h->device));
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    const float *g[4] = {g0, g1, g2, g3};
-    hipError_t e = fdk::fan_sum(La, g, gpicked, dx, rows, L, factor);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_fan_backward: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-// The predictor's input convolution (80 -> 64, k5) with its activation (fd_kernels_kconv.hip: k_ic_*); per-utterance partial sums of
-// the weight gradient in the kernel_conv scratch.
-static int check_input_conv(fd_handle h, int B, int T, float post, const char *who)
-{
-    if (B <= 0 || B > 65535) FD_FAIL(h, FD_ERR_INVALID, "%s: B=%d", who, B);
-    if (T < 1 || T > 128) FD_FAIL(h, FD_ERR_UNSUPPORTED, "%s: T=%d (1..128) only", who, T);
-    if (!(post > 0.0f && post <= 1.0f)) FD_FAIL(h, FD_ERR_INVALID, "%s: the leaky-relu slope must lie in (0, 1] (1 = no activation), got %g", who, post);
-    return FD_OK;
-}
-
-int fd_input_conv_forward(fd_handle h, const float *x, const float *weight, const float *bias, int B, int T, float post_slope, float *out, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!x || !weight || !bias || !out) FD_FAIL(h, FD_ERR_INVALID, "fd_input_conv_forward: null pointer");
-    const int rc = check_input_conv(h, B, T, post_slope, "fd_input_conv_forward");
-    if (rc != FD_OK) return rc;
-    FD_HIP(h, hipSetDevice(h->device));
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::input_conv_forward(La, x, weight, bias, out, B, T, post_slope);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_input_conv_forward: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_input_conv_backward(fd_handle h, const float *x, const float *weight, const float *y, const float *dout, int B, int T, float post_slope,
-                           float *dx, float *dweight, float *dbias, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!dout || !y || ((dweight || dbias) && !x) || (dx && !weight)) FD_FAIL(h, FD_ERR_INVALID, "fd_input_conv_backward: null pointer");
-    int rc = check_input_conv(h, B, T, post_slope, "fd_input_conv_backward");
-    if (rc != FD_OK) return rc;
-    FD_HIP(h, hipSetDevice(h->device));
-    {
-        const size_t bytes = sizeof(float) * fdk::input_conv_scratch_floats(B);
-        if (h->kconv_scratch_bytes < bytes) {
-            if (h->kconv_scratch) FD_HIP(h, hipFree(h->kconv_scratch));
-            h->kconv_scratch = nullptr; h->kconv_scratch_bytes = 0;
-            FD_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->kconv_scratch), bytes));
-            h->kconv_scratch_bytes = bytes;
-        }
-    }
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::input_conv_backward(La, x, weight, y, dout, dx, dweight, dbias, B, T, post_slope, h->kconv_scratch);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_input_conv_backward: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-// "frames": kernel_conv and the operator joined through frame-major tensors (include/fastdiff_hip.h)
-
-int fd_kconv_forward_frames(fd_handle h, const float *x, const float *weight, const float *bias, int B, int M, int T, float *frames, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!x || !weight || !bias || !frames) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_forward_frames: null pointer");
-    if (B <= 0 || B > 65535) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_forward_frames: B=%d", B);
-    if (!fdk::kconv_frames_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_forward_frames: M=%d (a multiple of 6144) and T=%d (1..128) only", M, T);
-    FD_HIP(h, hipSetDevice(h->device));
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::kconv_forward(La, x, weight, bias, frames, B, M, T, true);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_kconv_forward_frames: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_kconv_backward_frames(fd_handle h, const float *x, const float *weight, const float *dframes, int B, int M, int T, float *dx,
-                             float *dweight, float *dbias, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!dframes || ((dweight || dbias) && !x) || (dx && !weight)) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward_frames: null pointer");
-    if (B <= 0 || B > 65535) FD_FAIL(h, FD_ERR_INVALID, "fd_kconv_backward_frames: B=%d", B);
-    if (!fdk::kconv_frames_supported(M, T)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_kconv_backward_frames: M=%d (a multiple of 6144) and T=%d (1..128) only", M, T);
-    FD_HIP(h, hipSetDevice(h->device));
-    const int rc = kconv_scratch_reserve(h, B, M, T);
-    if (rc != FD_OK) return rc;
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::kconv_backward(La, x, weight, dframes, dx, dweight, dbias, B, M, T, h->kconv_scratch, true);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_kconv_backward_frames: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-static int check_frames_stride(fd_handle h, int64_t st, int T, const char *who)
-{
-    if (st < (int64_t)T * 6144 || st % 4 != 0) FD_FAIL(h, FD_ERR_INVALID, "%s: a frame stride of %lld floats (at least T * 6144, a multiple of 4)", who, (long long)st);
-    return FD_OK;
-}
-
-int fd_lvc_forward_frames(fd_handle h, const float *x, const float *kernel_frames, int64_t kernel_bstride, const float *bias, int64_t bias_bstride,
-                          int B, int T, int hop, float *out, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!x || !kernel_frames || !bias || !out) FD_FAIL(h, FD_ERR_INVALID, "fd_lvc_forward_frames: null pointer");
-    int rc = check_lvc_op(h, B, 32, 64, 3, T, hop, "fd_lvc_forward_frames");
-    if (rc != FD_OK) return rc;
-    if (!fdk::lvc_op_needs_scratch(32, 64, 3, hop)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_lvc_forward_frames: hop 8 / 64 / 256 only, got %d", hop);
-    if ((rc = check_frames_stride(h, kernel_bstride, T, "fd_lvc_forward_frames")) != FD_OK) return rc;
-    if (bias_bstride != 0 && bias_bstride < (int64_t)64 * T) FD_FAIL(h, FD_ERR_INVALID, "fd_lvc_forward_frames: bias stride %lld < 64 * T", (long long)bias_bstride);
-    FD_HIP(h, hipSetDevice(h->device));
-    fdk::Launch L = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::lvc_op_forward(L, x, kernel_frames, bias, out, B, 32, 64, 3, T, hop, nullptr, kernel_bstride, true, bias_bstride);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_lvc_forward_frames: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_lvc_backward_frames(fd_handle h, const float *x, const float *kernel_frames, int64_t kernel_bstride, const float *dout, int B, int T,
-                           int hop, float *dx, float *dkernel_frames, int64_t dkernel_bstride, float *dbias, int64_t dbias_bstride, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!dout || ((dkernel_frames || dbias) && !x) || (dx && !kernel_frames)) FD_FAIL(h, FD_ERR_INVALID, "fd_lvc_backward_frames: null pointer");
-    int rc = check_lvc_op(h, B, 32, 64, 3, T, hop, "fd_lvc_backward_frames");
-    if (rc != FD_OK) return rc;
-    if (!fdk::lvc_op_needs_scratch(32, 64, 3, hop)) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_lvc_backward_frames: hop 8 / 64 / 256 only, got %d", hop);
-    if (dx && (rc = check_frames_stride(h, kernel_bstride, T, "fd_lvc_backward_frames")) != FD_OK) return rc;
-    if (dkernel_frames && (rc = check_frames_stride(h, dkernel_bstride, T, "fd_lvc_backward_frames")) != FD_OK) return rc;
-    if (dbias && dbias_bstride != 0 && dbias_bstride < (int64_t)64 * T) FD_FAIL(h, FD_ERR_INVALID, "fd_lvc_backward_frames: dbias stride %lld < 64 * T", (long long)dbias_bstride);
-    FD_HIP(h, hipSetDevice(h->device));
-    float *scratch = nullptr;
-    if (dx && !h->lvc_dx_gather && (rc = lvc_scratch(h, B, 32, 64, 3, T, hop, &scratch)) != FD_OK) return rc;      // option lvc_dx = copy: the dx kernel's operand order
-    fdk::Launch L = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::lvc_op_backward(L, x, kernel_frames, dout, dx, dkernel_frames, dbias, B, 32, 64, 3, T, hop, scratch, kernel_bstride,
-                                        dkernel_bstride, true, dbias_bstride);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_lvc_backward_frames: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-static int cconv_scratch_reserve(fd_handle h, size_t floats)
-{
-    const size_t bytes = sizeof(float) * floats;
-    if (h->cconv_scratch_bytes < bytes) {
-        if (h->cconv_scratch) FD_HIP(h, hipFree(h->cconv_scratch));
-        h->cconv_scratch = nullptr; h->cconv_scratch_bytes = 0;
-        FD_HIP(h, hipMalloc(reinterpret_cast<void **>(&h->cconv_scratch), bytes));
-        h->cconv_scratch_bytes = bytes;
-    }
-    return FD_OK;
-}
-
-// The small convolutions of the training path (fd_kernels_cconv.hip).  The backward's per-workgroup partial sums live in a scratch
-// buffer on the handle (calls on one handle are ordered on one stream, as for the operators above).
-static int check_conv32(fd_handle h, int B, int64_t L, int dil, float pre, float post, const char *who)
-{
-    if (B <= 0 || B > 65535 || L <= 0) FD_FAIL(h, FD_ERR_INVALID, "%s: B=%d L=%lld", who, B, (long long)L);
-    if (!(pre > 0.0f && pre <= 1.0f) || !(post > 0.0f && post <= 1.0f))
-        FD_FAIL(h, FD_ERR_INVALID, "%s: leaky-relu slopes must lie in (0, 1] (1 = no activation), got %g / %g", who, pre, post);
-    if (!fdk::cconv_supported(dil, L))
-        FD_FAIL(h, FD_ERR_UNSUPPORTED, "%s: dilation %d (1, 2, 3, 4, 9, 27) and a length that is a multiple of 4 only, got L=%lld", who, dil, (long long)L);
-    if ((int64_t)B * 32 * L >= (int64_t)1 << 40) FD_FAIL(h, FD_ERR_INVALID, "%s: tensor too large", who);
-    return FD_OK;
-}
-
-int fd_conv32_forward(fd_handle h, const float *x, const float *skip, const float *weight, const float *bias, int B, int64_t L, int dilation,
-                      float pre_slope, float post_slope, float *xs_out, float *y, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!x || !weight || !bias || !y || (skip && !xs_out)) FD_FAIL(h, FD_ERR_INVALID, "fd_conv32_forward: null pointer (xs_out is needed with a skip)");
-    int rc = check_conv32(h, B, L, dilation, pre_slope, post_slope, "fd_conv32_forward");
-    if (rc != FD_OK) return rc;
-    FD_HIP(h, hipSetDevice(h->device));
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::cconv_forward(La, x, skip, weight, bias, xs_out, y, B, L, dilation, pre_slope, post_slope);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_conv32_forward: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_conv32_backward(fd_handle h, const float *xs, const float *y, const float *weight, const float *dy, const float *gxs, int B, int64_t L,
-                       int dilation, float pre_slope, float post_slope, float *dxs, float *dweight, float *dbias, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!xs || !y || !weight || !dy) FD_FAIL(h, FD_ERR_INVALID, "fd_conv32_backward: null pointer");
-    int rc = check_conv32(h, B, L, dilation, pre_slope, post_slope, "fd_conv32_backward");
-    if (rc != FD_OK) return rc;
-    FD_HIP(h, hipSetDevice(h->device));
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    rc = cconv_scratch_reserve(h, fdk::cconv_scratch_floats(La, dilation, B, L));
-    if (rc != FD_OK) return rc;
-    hipError_t e = fdk::cconv_backward(La, xs, y, weight, dy, gxs, dxs, dweight, dbias, B, L, dilation, pre_slope, post_slope, h->cconv_scratch);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_conv32_backward: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_conv7_forward(fd_handle h, int which, const float *x, const float *weight, const float *bias, int B, int64_t L, float *y, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!x || !weight || !bias || !y) FD_FAIL(h, FD_ERR_INVALID, "fd_conv7_forward: null pointer");
-    if ((which != 0 && which != 1) || B <= 0 || B > 65535 || L < 4 || L % 4 != 0 || L >= ((int64_t)1 << 25))
-        FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_conv7_forward: which=%d (0 first_audio_conv, 1 final_conv), B=%d, L=%lld (a multiple of 4)", which, B, (long long)L);
-    FD_HIP(h, hipSetDevice(h->device));
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::conv7_forward(La, which, x, weight, bias, y, B, L);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_conv7_forward: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_conv7_backward(fd_handle h, int which, const float *x, const float *weight, const float *dy, int B, int64_t L, float *dx, float *dweight,
-                      float *dbias, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!x || !weight || !dy) FD_FAIL(h, FD_ERR_INVALID, "fd_conv7_backward: null pointer");
-    if ((which != 0 && which != 1) || B <= 0 || B > 65535 || L < 4 || L % 4 != 0 || L >= ((int64_t)1 << 25))
-        FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_conv7_backward: which=%d (0 first_audio_conv, 1 final_conv), B=%d, L=%lld (a multiple of 4)", which, B, (long long)L);
-    FD_HIP(h, hipSetDevice(h->device));
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    int rc = cconv_scratch_reserve(h, fdk::conv7_scratch_floats(La, B, L));
-    if (rc != FD_OK) return rc;
-    hipError_t e = fdk::conv7_backward(La, which, x, weight, dy, dx, dweight, dbias, B, L, h->cconv_scratch);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_conv7_backward: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_upsample_forward(fd_handle h, const float *x, const float *weight, const float *bias, int B, int64_t Lin, int ratio, float *y, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!x || !weight || !bias || !y) FD_FAIL(h, FD_ERR_INVALID, "fd_upsample_forward: null pointer");
-    if ((ratio != 4 && ratio != 8) || B <= 0 || B > 65535 || Lin < 1 || Lin * ratio >= ((int64_t)1 << 25))
-        FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_upsample_forward: ratio %d (4 or 8), B=%d, Lin=%lld", ratio, B, (long long)Lin);
-    FD_HIP(h, hipSetDevice(h->device));
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::convt_forward(La, x, weight, bias, y, B, Lin, ratio);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_upsample_forward: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_upsample_backward(fd_handle h, const float *x, const float *weight, const float *dy, int B, int64_t Lin, int ratio, float *dx, float *dweight,
-                         float *dbias, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!x || !weight || !dy) FD_FAIL(h, FD_ERR_INVALID, "fd_upsample_backward: null pointer");
-    if ((ratio != 4 && ratio != 8) || B <= 0 || B > 65535 || Lin < 1 || Lin * ratio >= ((int64_t)1 << 25))
-        FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_upsample_backward: ratio %d (4 or 8), B=%d, Lin=%lld", ratio, B, (long long)Lin);
-    FD_HIP(h, hipSetDevice(h->device));
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    int rc = cconv_scratch_reserve(h, fdk::convt_scratch_floats(La, ratio, B, Lin));
-    if (rc != FD_OK) return rc;
-    hipError_t e = fdk::convt_backward(La, x, weight, dy, dx, dweight, dbias, B, Lin, ratio, h->cconv_scratch);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_upsample_backward: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_weight_norm_forward(fd_handle h, const float *v, const float *g, int64_t rows, int cols, float *w, float *norm, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!v || !g || !w || !norm) FD_FAIL(h, FD_ERR_INVALID, "fd_weight_norm_forward: null pointer");
-    if (rows <= 0 || cols <= 0 || rows > ((int64_t)1 << 31)) FD_FAIL(h, FD_ERR_INVALID, "fd_weight_norm_forward: rows=%lld cols=%d", (long long)rows, cols);
-    FD_HIP(h, hipSetDevice(h->device));
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::weight_norm_forward(La, v, g, w, norm, rows, cols);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_weight_norm_forward: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_weight_norm_backward(fd_handle h, const float *v, const float *g, const float *norm, const float *dw, int64_t rows, int cols, float *dv,
-                            float *dg, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!v || !g || !norm || !dw || !dv || !dg) FD_FAIL(h, FD_ERR_INVALID, "fd_weight_norm_backward: null pointer");
-    if (rows <= 0 || cols <= 0 || rows > ((int64_t)1 << 31)) FD_FAIL(h, FD_ERR_INVALID, "fd_weight_norm_backward: rows=%lld cols=%d", (long long)rows, cols);
-    FD_HIP(h, hipSetDevice(h->device));
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::weight_norm_backward(La, v, g, norm, dw, dv, dg, rows, cols);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_weight_norm_backward: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_gate_forward(fd_handle h, const float *x, const float *y, int B, int C, int64_t L, float *out, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!x || !y || !out) FD_FAIL(h, FD_ERR_INVALID, "fd_gate_forward: null pointer");
-    if (B <= 0 || C <= 0 || L <= 0 || B > 65535 || C > 65535) FD_FAIL(h, FD_ERR_INVALID, "fd_gate_forward: B=%d C=%d L=%lld", B, C, (long long)L);
-    FD_HIP(h, hipSetDevice(h->device));
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::gate_forward(La, x, y, out, B, C, L);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_gate_forward: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_gate_backward(fd_handle h, const float *y, const float *dout, int B, int C, int64_t L, float *dy, void *stream)
-{
-    if (!h) return FD_ERR_INVALID;
-    if (!y || !dout || !dy) FD_FAIL(h, FD_ERR_INVALID, "fd_gate_backward: null pointer");
-    if (B <= 0 || C <= 0 || L <= 0 || B > 65535 || C > 65535) FD_FAIL(h, FD_ERR_INVALID, "fd_gate_backward: B=%d C=%d L=%lld", B, C, (long long)L);
-    FD_HIP(h, hipSetDevice(h->device));
-    fdk::Launch La = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::gate_backward(La, y, dout, dy, B, C, L);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_gate_backward: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_peak_normalize_int16_ragged(fd_handle h, const float *wav, int B, int64_t len, const int64_t *valid, int16_t *pcm, void *stream)
-{
-    if (!h || !wav || !pcm || B <= 0 || len <= 0 || B > 4096) return FD_ERR_INVALID;
-    FD_HIP(h, hipSetDevice(h->device));
-    if (!(h->pending.active && h->pending.lazy)) {      // a lazily checked call stays pending: the epilogue's result is provisional with it
-        const int rcs = settle(h);
-        if (rcs != FD_OK) return rcs;
-    }
-    const long long *valid_dev = nullptr;
-    if (valid) {
-        for (int b = 0; b < B; ++b)
-            if (valid[b] < 1 || valid[b] > len) FD_FAIL(h, FD_ERR_INVALID, "fd_peak_normalize_int16_ragged: valid[%d] = %lld outside [1, %lld]", b, (long long)valid[b], (long long)len);
-        fd_context::StageSlot *sl = nullptr;
-        int rc = stage_acquire(h, sizeof(long long) * B, &sl);
-        if (rc != FD_OK) return rc;
-        for (int b = 0; b < B; ++b) reinterpret_cast<long long *>(sl->host)[b] = valid[b];
-        long long *dst = reinterpret_cast<long long *>(reinterpret_cast<char *>(h->scratch) + 32768);      // behind the abs-max words
-        FD_HIP(h, hipMemcpyAsync(dst, sl->host, sizeof(long long) * B, hipMemcpyHostToDevice, (hipStream_t)stream));
-        if ((rc = stage_commit(h, sl, (hipStream_t)stream)) != FD_OK) return rc;
-        valid_dev = dst;
-    }
-    fdk::Launch L = {h, (hipStream_t)stream, false};
-    hipError_t e = fdk::peak_normalize_int16(L, wav, B, len, pcm, valid_dev);
-    if (e != hipSuccess) FD_FAIL(h, FD_ERR_HIP, "fd_peak_normalize_int16: %s", hipGetErrorString(e));
-    return FD_OK;
-}
-
-int fd_peak_normalize_int16(fd_handle h, const float *wav, int B, int64_t len, int16_t *pcm, void *stream)
-{
-    return fd_peak_normalize_int16_ragged(h, wav, B, len, nullptr, pcm, stream);
-}
-
 // ------------------------------------------------------------------------------------------------
 // options, taps, profile
 // ------------------------------------------------------------------------------------------------
@@ -2222,7 +1419,7 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
 {
     if (!h || !key || !value) return FD_ERR_INVALID;
     {
-        const int rcs = settle(h);
+        const int rcs = fd_settle(h);
         if (rcs != FD_OK) return rcs;
     }
     const std::string k(key), v(value);
@@ -2312,107 +1509,6 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
     if (k == "profile") { h->profile = (v == "events") ? 2 : (on ? 1 : 0); return FD_OK; }
     if (k == "taps") { h->keep_taps = on; return FD_OK; }
     FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: unknown option '%s'", key);
-}
-
-int64_t fd_read_tap(fd_handle h, const char *name, float *host_dst, int64_t capacity)
-{
-    if (!h || !name) return FD_ERR_INVALID;
-    {
-        const int rcs = settle(h);
-        if (rcs != FD_OK) return rcs;
-    }
-    if (h->gen) FD_FAIL(h, FD_ERR_UNSUPPORTED, "fd_read_tap: intermediates are kept by the tuned kernel set only (base.yaml's architecture)");
-    const int B = h->last_B, T = h->last_T;
-    if (B == 0) FD_FAIL(h, FD_ERR_STATE, "fd_read_tap: no forward has run yet");
-    const Workspace &w = h->ws;
-    const int64_t L = (int64_t)T * fd::HOPT;
-    const std::string k(name);
-    const float *src = nullptr;
-    int64_t n = 0;
-    if (k == "noise") { src = w.noise; n = (int64_t)B * fd::NBLK * fd::COND; }
-    else if (k == "a0") { src = w.a[0]; n = B * fd::C * L; }
-    else if (k == "a1") { src = w.a[1]; n = B * fd::C * L / 4; }
-    else if (k == "a2") { src = w.a[2]; n = B * fd::C * L / 32; }
-    else if (k == "a3") { src = w.a[3]; n = (int64_t)B * fd::C * T; }
-    else if (k.size() == 6 && k.compare(0, 5, "kpack") == 0 && k[5] >= '0' && k[5] <= '2') {
-        n = (int64_t)B * T * fd::KREC; src = w.kpack + (k[5] - '0') * n;
-    } else if (k.size() == 5 && k.compare(0, 4, "kp_h") == 0 && k[4] >= '0' && k[4] <= '2') {
-        n = (int64_t)B * fd::HID * T; src = w.kp_hB + (k[4] - '0') * n;
-    } else if (k.size() == 2 && k[0] == 'x' && k[1] >= '0' && k[1] <= '2') {
-        if (!h->keep_taps) FD_FAIL(h, FD_ERR_STATE, "fd_read_tap: set option taps=1 before the forward to keep block outputs");
-        const int blk = k[1] - '0';
-        src = w.xtap[blk]; n = (int64_t)B * fd::C * T * fd::hop(blk);
-    } else if (k == "range_flags") {       // 32 int32 (bit patterns): fp16-range flags of the last step, see Workspace::range_flag
-        src = reinterpret_cast<const float *>(w.range_flag); n = 32;
-    } else if (k == "range_flags_call") {  // the same, OR-ed over every step since the start of the last call (words 64..95)
-        src = reinterpret_cast<const float *>(w.range_flag + 64); n = 32;
-    } else FD_FAIL(h, FD_ERR_INVALID, "fd_read_tap: unknown tap '%s'", name);
-    if (!host_dst) return n;
-    if (capacity < n) FD_FAIL(h, FD_ERR_INVALID, "fd_read_tap: capacity %lld < %lld", (long long)capacity, (long long)n);
-    FD_HIP(h, hipSetDevice(h->device));
-    FD_HIP(h, hipDeviceSynchronize());
-    FD_HIP(h, hipMemcpy(host_dst, src, sizeof(float) * n, hipMemcpyDeviceToHost));
-    return n;
-}
-
-int fd_kernel_index(int layer, int in_ch, int out_ch, int tap)
-{
-    if (layer < 0 || layer >= fd::LAYERS || in_ch < 0 || in_ch >= fd::C || out_ch < 0 || out_ch >= 2 * fd::C || tap < 0 || tap >= 3)
-        return FD_ERR_INVALID;
-    return fd::kernel_index(layer, in_ch, out_ch, tap);
-}
-
-int fd_bias_index(int layer, int out_ch)
-{
-    if (layer < 0 || layer >= fd::LAYERS || out_ch < 0 || out_ch >= 2 * fd::C) return FD_ERR_INVALID;
-    return fd::bias_index(layer, out_ch);
-}
-
-int64_t fd_get_counter(fd_handle h, const char *name)
-{
-    if (!h || !name) return FD_ERR_INVALID;
-    const std::string k(name);
-    if (k == "pieces_redone" || k == "fp32_mask") {      // the last piece of a long call may still be waiting for its check
-        const int rcs = settle(h);
-        if (rcs != FD_OK) return rcs;
-    }
-    if (k == "pieces") return h->n_pieces;
-    if (k == "pieces_redone") return h->n_pieces_redone;
-    if (k == "pieces_fp32") return h->n_pieces_fp32;
-    if (k == "fp32_mask") return (int64_t)h->call_fp32_mask;
-    if (k == "calls_redone") return h->n_calls_redone;
-    if (k == "graph_captures") return h->n_graph_captures;
-    if (k == "graph_hits") return h->n_graph_hits;
-    if (k == "graph_evictions") return h->n_graph_evictions;
-    if (k == "graphs_resident") return (int64_t)h->graphs.size();
-    if (k == "graphs_retired") return (int64_t)h->retired.size();
-    FD_FAIL(h, FD_ERR_INVALID, "fd_get_counter: unknown counter '%s'", name);
-}
-
-int fd_get_profile(fd_handle h, fd_kernel_stat *stats, int capacity)
-{
-    if (!h) return FD_ERR_INVALID;
-    hipSetDevice(h->device);
-    prof_drain(h);
-    int i = 0;
-    for (const auto &kv : h->prof_acc) {
-        if (stats && i < capacity) {
-            memset(&stats[i], 0, sizeof(fd_kernel_stat));
-            strncpy(stats[i].name, kv.first.c_str(), sizeof(stats[i].name) - 1);
-            stats[i].launches = kv.second.first;
-            stats[i].total_ms = kv.second.second;
-        }
-        ++i;
-    }
-    return i;
-}
-
-int fd_reset_profile(fd_handle h)
-{
-    if (!h) return FD_ERR_INVALID;
-    prof_drain(h);
-    h->prof_acc.clear();
-    return FD_OK;
 }
 
 }  // extern "C"
