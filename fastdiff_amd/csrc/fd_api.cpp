@@ -734,6 +734,9 @@ static int ensure_workspace(fd_context *h, int B, int T, int pmult = 1)
     bool same = true;
     for (int i = 0; i < 6; ++i) {
         want[0][i] = std::max(own[i], seen[i]);
+        // a stream of requests of growing length (the reference CLI's pattern) would otherwise re-allocate -- a device synchronisation,
+        // every buffer freed and allocated again, every graph dropped -- once per new maximum: grow by at least a quarter
+        if (own[i] > seen[i] && seen[i] > 0) want[0][i] = std::max(own[i], seen[i] + seen[i] / 4);
         want[1][i] = own[i];
         same = same && want[0][i] == want[1][i];
     }
@@ -912,7 +915,8 @@ static int follow_stream(fd_handle h, hipStream_t s)
 }
 
 // `lens` (host, nullable): valid frames per utterance of a zero-padded batch, uploaded for the kernels from the pinned area `staged`.
-static int set_lens(fd_handle h, const int *lens, int B, int T, hipStream_t stream, const char *who, int *staged)
+// reps: the hoisted predictor's batch holds every utterance once per reverse step (entry n * B + b): its lengths are staged that often
+static int set_lens(fd_handle h, const int *lens, int B, int T, hipStream_t stream, const char *who, int *staged, int reps = 1)
 {
     h->step_lens = nullptr;
     if (!lens) return FD_OK;
@@ -926,8 +930,8 @@ static int set_lens(fd_handle h, const int *lens, int B, int T, hipStream_t stre
         if (!h->fast[i])
             FD_FAIL(h, FD_ERR_UNSUPPORTED, "%s: a ragged batch (lens) needs the fast kernel set; the naive kernels (option kernels.<stage> = naive) "
                                            "compute the padded tensor and would silently ignore the lengths", who);
-    memcpy(staged, lens, sizeof(int) * B);
-    FD_HIP(h, hipMemcpyAsync(h->ws.lens_dev, staged, sizeof(int) * B, hipMemcpyHostToDevice, stream));
+    for (int n = 0; n < reps; ++n) memcpy(staged + (size_t)n * B, lens, sizeof(int) * B);
+    FD_HIP(h, hipMemcpyAsync(h->ws.lens_dev, staged, sizeof(int) * B * reps, hipMemcpyHostToDevice, stream));
     h->step_lens = h->ws.lens_dev;
     return FD_OK;
 }
@@ -1181,9 +1185,10 @@ static int sample_core(fd_handle h, const fd_context::SampleArgs &a, unsigned fo
     // without waiting for the stream, so the host prepares the next call while this one runs.
     {
         fd_context::StageSlot *sl = nullptr;
-        const size_t off_lens = sizeof(StepParams), off_ids = off_lens + ((sizeof(int) * B + 7) & ~(size_t)7);
+        const int np = hoist_mult(h, B, T, N);      // the hoisted predictor's batch: np reverse steps x B utterances (below)
+        const size_t off_lens = sizeof(StepParams), off_ids = off_lens + ((sizeof(int) * B * np + 7) & ~(size_t)7);
         if ((rc = fd_stage_acquire(h, off_ids + sizeof(unsigned long long) * B, &sl)) != FD_OK) return rc;
-        if ((rc = set_lens(h, lens_eff, B, T, stream, "fd_sample", reinterpret_cast<int *>(sl->host + off_lens))) != FD_OK) return rc;
+        if ((rc = set_lens(h, lens_eff, B, T, stream, "fd_sample", reinterpret_cast<int *>(sl->host + off_lens), np)) != FD_OK) return rc;
         if (!ids.empty()) {
             memcpy(sl->host + off_ids, ids.data(), sizeof(unsigned long long) * B);
             FD_HIP(h, hipMemcpyAsync(ws.uid_dev, sl->host + off_ids, sizeof(unsigned long long) * B, hipMemcpyHostToDevice, stream));
@@ -1235,13 +1240,10 @@ static int sample_core(fd_handle h, const fd_context::SampleArgs &a, unsigned fo
     h->hoist_np = hoist_mult(h, B, T, N);
     h->hoist_step = 0;
     h->hoist_chunk = h->hoist_np > 1 && N > CHUNK;
-    if (h->hoist_np > 1) {
-        const size_t mel_n = (size_t)B * fd::COND * T;
-        for (int n = 0; n < h->hoist_np; ++n)
-            FD_HIP(h, hipMemcpyAsync(ws.mel_rep + n * mel_n, ws.mel, sizeof(float) * mel_n, hipMemcpyDeviceToDevice, stream));
-        if (h->step_lens)
-            for (int n = 1; n < h->hoist_np; ++n)
-                FD_HIP(h, hipMemcpyAsync(ws.lens_dev + n * B, ws.lens_dev, sizeof(int) * B, hipMemcpyDeviceToDevice, stream));
+    if (h->hoist_np > 1) {      // the mel once per predicted step: ONE launch (the lengths were staged that often by set_lens)
+        const int64_t mel_n = (int64_t)B * fd::COND * T;
+        if ((e = fdk::copy_rows(L, ws.mel_rep, T, ws.mel, T, T, B * fd::COND, h->hoist_np, mel_n)) != hipSuccess)
+            FD_FAIL(h, FD_ERR_HIP, "fd_sample: mel replication failed: %s", hipGetErrorString(e));
     }
     if (h->hoist_chunk) h->hoist_np = 1;          // enqueue_steps sets it piece by piece
     else if (h->hoist_np > 1) {

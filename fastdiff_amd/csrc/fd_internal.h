@@ -347,7 +347,8 @@ hipError_t advance_step(const Launch &L);
 hipError_t clear_range_flags(const Launch &L, int set_step = 0);     // before the first step of a call / of a redo: step counter := set_step
 hipError_t mel_frontend(const Launch &L, const float *wav, int B, int64_t n_samples, float *mel, int T);
 hipError_t init_noise(const Launch &L, float *x, int B, int l4, int l4_io, unsigned long long seed, const unsigned long long *uids);
-hipError_t copy_rows(const Launch &L, float *dst, int64_t dpitch, const float *src, int64_t spitch, int width, int rows);
+hipError_t copy_rows(const Launch &L, float *dst, int64_t dpitch, const float *src, int64_t spitch, int width, int rows, int reps = 1,
+                     int64_t rep_stride = 0);
 hipError_t peak_normalize_int16(const Launch &L, const float *wav, int B, int64_t len, int16_t *pcm, const long long *valid_dev);
 }  // namespace fdk
 

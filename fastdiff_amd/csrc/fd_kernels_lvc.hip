@@ -29,11 +29,22 @@ __device__ long long fd_dbg[64 * 4 * 8];
 #elif defined(FD_LVC_TIMELINE)
 // every workgroup's wave 0: s_memrealtime at each phase boundary + where it ran (tools/ubench/lvc_h2_timeline.hip)
 __device__ long long *fd_tl;
-#define FD_STAMP(i) do { if (threadIdx.x == 0) { long long *q_ = fd_tl + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 10; \
+#define FD_STAMP_AT(i) do { if (threadIdx.x == 0) { long long *q_ = fd_tl + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 10; \
         q_[i] = (long long)__builtin_amdgcn_s_memrealtime(); \
         if ((i) == 0) { q_[8] = __builtin_amdgcn_s_getreg(63492); q_[9] = __builtin_amdgcn_s_getreg(63508); } } } while (0)
+#if defined(FD_TL_VARIANT)
+// the fused variants' own phases (round 6): slots 1..4 go to FD_STAMP_X(1..4) inside the up-sampler / the final-conv fold, the regular
+// stamps keep 0, 1 (-> slot 5: staging barrier), 6, 7
+#define FD_STAMP(i) do { if ((i) == 0 || (i) == 6 || (i) == 7) FD_STAMP_AT(i); else if ((i) == 1) FD_STAMP_AT(5); } while (0)
+#define FD_STAMP_X(i) FD_STAMP_AT(i)
+#else
+#define FD_STAMP(i) FD_STAMP_AT(i)
+#endif
 #else
 #define FD_STAMP(i)
+#endif
+#ifndef FD_STAMP_X
+#define FD_STAMP_X(i)
 #endif
 
 // sigmoid(a) * tanh(b) with two exponentials and one reciprocal:  (1 - v) / ((1 + u)(1 + v)),  u = e^-a, v = e^-2b.
@@ -466,6 +477,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
 #pragma unroll
                 for (int kg = 0; kg < 4; ++kg) wun[p][kg] = up_pack16[(((wave * PHW) * 2 + p) * 4 + kg) * 64 + lane];
             __syncthreads();
+            FD_STAMP_X(1);
             // (b) wave = PHW output phases; per phase and 32-position tile the ConvTranspose's 12 MFMAs; x goes to the parking area
             //     ([32][256] fp32 in the y area; the 2H halo columns to hsk), zero outside the utterance like the loads of the other path
             float *park = reinterpret_cast<float *>(ys);
@@ -484,6 +496,9 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
                         for (int kg = 0; kg < 4; ++kg) wun[p][kg] = up_pack16[(((ph + 1) * 2 + p) * 4 + kg) * 64 + lane];
                 }
                 const int offA = (ph < R / 2) ? 0 : 1, offB = offA - 1;      // sel 0 reads position q + offA, sel 1 position q + offB
+                // (round 6, measured and not kept: the tile's 8 B operands requested one tile ahead + the frame record requested behind
+                // this phase to free its 64 registers -- the phase stayed at 3.1 us of a workgroup's life, the layer 243 -> 248 us: the
+                // phase is issue time shared with the CU's other workgroup, not LDS latency; LABBOOK R6.5)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const int ql = 32 * t + l31, qc = min(ql, UPN - 1);        // position index in the tile (row qc + 1 of the image)
@@ -513,7 +528,9 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
                     }
                 }
             }
+            FD_STAMP_X(2);
             __syncthreads();
+            FD_STAMP_X(3);
             load_conv_weights();
             {   // columns 4 lane + j: r = 4 -> position lane of phase j; r = 8 -> position lane / 2 of phase 4 (lane & 1) + j
                 const float *pk = reinterpret_cast<const float *>(ys) + wave * 8 * W +
@@ -524,6 +541,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
             }
 #pragma unroll
             for (int c = 0; c < 8; ++c) hx[c] = hc < 2 * H ? hsk[(wave * 8 + c) * (2 * H) + hc] : 0.0f;
+            FD_STAMP_X(4);
         }
 #endif
 #ifdef FD_LVC_LATE_KERNEL
@@ -730,6 +748,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
 #else
     if constexpr (FINAL) {
         // hop 256: utterance lengths are whole tiles, so every wave of a live workgroup is valid and reaches the barrier
+        FD_STAMP_X(1);
         float *pb = reinterpret_cast<float *>(xs);                   // [part = 2 mt + hi][7 taps][256 columns]
         {
             const int part = 2 * mt0 + hi;
@@ -749,7 +768,9 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
                     pb[(part * 7 + k) * W + lcw + nt * 32 + l31] = pk;
                 }
         }
+        FD_STAMP_X(2);
         __syncthreads();
+        FD_STAMP_X(3);
         auto column_sum = [&](int t) {      // eps[t] = sum_k w[k] . out[t + k - 3], restricted to this tile's columns
             float e = 0.0f;
 #pragma unroll
@@ -770,6 +791,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
             const int j = tid - 64, t = j < 3 ? j - 3 : W + j - 3;
             if (w0 + t >= 0 && w0 + t < Lnb) atomicAdd(ea + t, column_sum(t));
         }
+        FD_STAMP_X(4);
     }
 #endif
     if (!(mx < GX_LIMIT)) {      // also inf; a NaN operand gives a NaN result on either path

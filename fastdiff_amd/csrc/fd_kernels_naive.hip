@@ -357,26 +357,30 @@ hipError_t init_noise(const Launch &L, float *x, int B, int l4, int l4_io, unsig
 }
 
 // rows x width floats between two pitched buffers (pitches in floats): the library's frame-bucketed buffers <-> the caller's dense ones
-__global__ void k_copy_rows(float *__restrict__ dst, int64_t dpitch, const float *__restrict__ src, int64_t spitch, int width, int vec)
+// (blockIdx.z = replica: the same rows written `gridDim.z` times, rep_stride floats apart -- the hoisted predictor's batch holds the
+// mel once per reverse step)
+__global__ void k_copy_rows(float *__restrict__ dst, int64_t dpitch, const float *__restrict__ src, int64_t spitch, int width, int vec,
+                            int64_t rep_stride)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t r = blockIdx.y;
+    dst += blockIdx.z * rep_stride;
     if (vec) {
         if (i * 4 < width) reinterpret_cast<float4 *>(dst + r * dpitch)[i] = reinterpret_cast<const float4 *>(src + r * spitch)[i];
     } else if (i < width) dst[r * dpitch + i] = src[r * spitch + i];
 }
 
-hipError_t copy_rows(const Launch &L, float *dst, int64_t dpitch, const float *src, int64_t spitch, int width, int rows)
+hipError_t copy_rows(const Launch &L, float *dst, int64_t dpitch, const float *src, int64_t spitch, int width, int rows, int reps, int64_t rep_stride)
 {
-    if (rows <= 0 || width <= 0) return hipSuccess;
-    if (dpitch == width && spitch == width)
+    if (rows <= 0 || width <= 0 || reps <= 0) return hipSuccess;
+    if (dpitch == width && spitch == width && reps == 1)
         return hipMemcpyAsync(dst, src, sizeof(float) * (size_t)width * rows, hipMemcpyDeviceToDevice, L.stream);
-    const bool vec = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0 && ((dpitch | spitch | width) & 3) == 0;
+    const bool vec = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0 && ((dpitch | spitch | width | rep_stride) & 3) == 0;
     const int n = vec ? width / 4 : width;
     for (int r0 = 0; r0 < rows; r0 += 65535) {
         const int nr = rows - r0 < 65535 ? rows - r0 : 65535;
-        FD_LAUNCH(L, "copy_rows", k_copy_rows, dim3((unsigned)((n + 255) / 256), nr), dim3(256), 0, dst + r0 * dpitch, dpitch, src + r0 * spitch, spitch,
-                  width, vec ? 1 : 0);
+        FD_LAUNCH(L, "copy_rows", k_copy_rows, dim3((unsigned)((n + 255) / 256), nr, reps), dim3(256), 0, dst + r0 * dpitch, dpitch, src + r0 * spitch, spitch,
+                  width, vec ? 1 : 0, rep_stride);
     }
     return hipSuccess;
 }
