@@ -780,7 +780,7 @@ def stream_items(seed=4321, n=256, t_lo=200, t_hi=864):
     return [{"item_name": "req%03d" % i, "mel": torch.rand(t, 80, generator=g) * 7.5 - 6.0, "len": t} for i, t in enumerate(lens)]
 
 
-def run_stream(args, model):
+def run_stream(args, model, quick=False):
     """One step = one pass over the whole stream of 256 requests, host mel -> host int16 PCM (infer.synthesize: pinned staging, the
     int16 epilogue on the device, the previous request collected while the next one runs).  Legs:
       b1 / b1_again   one request per fd_sample call in the order of arrival, first pass and a second pass over the same stream (what
@@ -789,10 +789,11 @@ def run_stream(args, model):
       b8              length-sorted micro-batches of 8 (padded, `lens`): 32 calls;
       b1_sync         the reference's loop body with nothing pipelined: upload, sample, normalise, download, wait -- per request;
       *_exact_T_graphs  option t_bucket = 0: one graph per exact T, i.e. one capture per request (what round 5 shipped);
-      fixed           the control: 256 calls of ONE length (the stream's mean), i.e. every call replays a warm graph."""
+      fixed           the control: 256 calls of ONE length (the stream's mean), i.e. every call replays a warm graph.
+    quick (the object the DEFAULT bench line carries): the control, b1 (two passes), b8 and b1_sync only, N = 4."""
     from fastdiff_amd import infer
     items = stream_items(n=args.stream_requests)
-    N = args.nsteps
+    N = 4 if quick else args.nsteps
     lens = [it["len"] for it in items]
     frames = sum(lens)
     audio_s = frames * HOP / SR
@@ -846,9 +847,13 @@ def run_stream(args, model):
     one_pass(fixed[:4], 1, 1, False)                      # the library's buffers and the pinned staging at their final size
     one_pass(sorted(items, key=lambda it: -it["len"])[:1], 1, 1, False)
     res["fixed_shape_control"] = leg(fixed, 1, False, 2, t_mean * len(fixed) * HOP / SR)
-    res["b1"] = leg(items, 1, False, 3, audio_s)
-    res["b8"] = leg(items, 8, True, 3, audio_s)
-    res["b1_sync"] = sync_leg(items, 2, audio_s)
+    res["b1"] = leg(items, 1, False, 2 if quick else 3, audio_s)
+    res["b8"] = leg(items, 8, True, 2 if quick else 3, audio_s)
+    res["b1_sync"] = sync_leg(items, 1 if quick else 2, audio_s)
+    if quick:
+        res["graph_cache"] = {k: model.counter(k) for k in ("graph_captures", "graph_hits", "graph_evictions", "graphs_resident")}
+        res["all_legs"] = "python bench.py --workload stream"
+        return res["b1"]["ms_per_request"][-1] * len(items) / 1e3, frames, res
     model.set_option("graph", "0")
     res["b1_no_graph"] = leg(items, 1, False, 2, audio_s)
     res["b8_no_graph"] = leg(items, 8, True, 2, audio_s)
@@ -941,6 +946,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (cpu_baseline and parity)")
     ap.add_argument("--no-fp32-pipe", action="store_true")
     ap.add_argument("--no-b1", action="store_true", help="skip the one-utterance-per-call (reference CLI mode) object")
+    ap.add_argument("--no-stream", action="store_true", help="skip the short stream object (256 requests of 256 different lengths, one per call) of the default line")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--ragged", action="store_true",
                     help="BASELINE config 4 style batch: T_i ~ U{200..frames}, zero-padded; RTF counts the valid audio only")
@@ -1203,6 +1209,16 @@ def main():
                 line["b1"] = b1_object(model, mel, rows, args.steps)
             except Exception as e:      # noqa: BLE001
                 line["b1"] = {"error": repr(e)}
+        if N <= 8 and not args.ragged and not args.no_stream and not args.no_graph:
+            # the reference CLI's own call pattern (one utterance per call, a new length every call): the short form of --workload stream
+            try:
+                _, _, st = run_stream(args, model, quick=True)
+                line["stream"] = st
+                line["stream_b1_ms"], line["stream_b1_rtf"] = st["b1"]["ms_per_request"][-1], st["b1"]["rtf"][-1]
+                line["stream_b1_sync_ms"], line["stream_b8_ms"] = st["b1_sync"]["ms_per_request"][-1], st["b8"]["ms_per_request"][-1]
+                line["stream_fixed_shape_ms"] = st["fixed_shape_control"]["ms_per_request"][-1]
+            except Exception as e:      # noqa: BLE001
+                line["stream"] = {"error": repr(e)}
         if not args.no_fp32_pipe:
             try:
                 line["fp32_pipe"] = fp32_pipe(model, mel, rows, use_lens, audio_s)
@@ -1233,6 +1249,9 @@ def main():
         if isinstance(line.get("b1"), dict) and "ms_per_step" in line["b1"]:
             summ["b1_ms"], summ["b1_rtf"] = line["b1"]["ms_per_step"], line["b1"]["value"]
             summ["b1_host_us"] = line["b1"].get("host_us_per_call_median")
+        for k in ("stream_b1_ms", "stream_b1_rtf", "stream_b1_sync_ms", "stream_b8_ms", "stream_fixed_shape_ms"):
+            if k in line:
+                summ[k] = line[k]
             summ["b1_lvc12_frac_min_bytes"] = line["b1"].get("lvc_all_12_launches_frac_minimal_bytes")
         if isinstance(line.get("fp32_pipe"), dict) and "ms_per_step" in line["fp32_pipe"]:
             summ["fp32_pipe_ms"], summ["fp32_pipe_rtf"] = line["fp32_pipe"]["ms_per_step"], line["fp32_pipe"]["value"]
@@ -1253,7 +1272,7 @@ def main():
         for k, v in summ.items():
             if k not in line:
                 line[k] = v
-        for k in ("b1_ms", "fp32_pipe_ms", "parity_f16x2", "parity_fp32", "value_host_to_host", "torch_eager_gpu_ms"):
+        for k in ("b1_ms", "stream_b1_ms", "fp32_pipe_ms", "parity_f16x2", "parity_fp32", "value_host_to_host", "torch_eager_gpu_ms"):
             if k in summ:
                 line["config"][k] = summ[k]
 

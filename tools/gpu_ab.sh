@@ -6,7 +6,7 @@ cp $LIB /tmp/keep.so
 for i in $(seq 1 ${3:-3}); do
   for v in $1 $2 ${AB_MORE:-}; do
     cp $v $LIB
-    python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-host-io ${AB_ARGS:-} > /tmp/ab.log 2>&1
+    python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-host-io --no-stream ${AB_ARGS:-} > /tmp/ab.log 2>&1
     python - "$v" <<'PY'
 import json, sys
 for line in open('/tmp/ab.log'):

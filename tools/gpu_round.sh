@@ -23,7 +23,7 @@ FD_BENCH_OVERSUBSCRIBE=1 timeout 900 python bench.py --gpus 8 --steps 3 --warmup
 echo "== bench --gpus 2 without the override must refuse" ; python bench.py --gpus 2 > gpurun_out/bench_gpus2_refused.log 2>&1 ; echo "rc=$?" ; tail -1 gpurun_out/bench_gpus2_refused.log
 echo "== training step (the training operators stay exercised every round)" ; timeout 600 python tools/train_step_probe.py > gpurun_out/train_step_probe.txt 2>&1 ; echo "train probe rc=$?" ; tail -4 gpurun_out/train_step_probe.txt | cut -c1-300
 echo "== rocprof kernel-trace"
-cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o kt -- python $R/bench.py --steps 5 --warmup 1 --no-roofline --no-cpu-baseline --no-fp32-pipe --no-host-io --no-b1 --no-torch-eager-baseline > $R/gpurun_out/rocprof.log 2>&1 ; echo "rocprof rc=$?"
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o kt -- python $R/bench.py --steps 5 --warmup 1 --no-roofline --no-cpu-baseline --no-fp32-pipe --no-host-io --no-b1 --no-stream --no-torch-eager-baseline > $R/gpurun_out/rocprof.log 2>&1 ; echo "rocprof rc=$?"
 cd $R; find gpurun_out/prof -name '*kernel_trace.csv' -size +20M -delete 2>/dev/null
 ST=$(find gpurun_out/prof -name '*kernel_stats.csv' | head -1); python tools/kernel_stats_fracs.py $ST --bench-json gpurun_out/bench.log > gpurun_out/fracs_from_kernel_stats.txt 2>&1; head -14 gpurun_out/fracs_from_kernel_stats.txt
 echo "== PMC"
