@@ -395,6 +395,9 @@ def main(argv=None):
     from . import FastDiff
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    if world > 1:      # one process per GPU (utils/trainer.py:94-107): each on its own slice of the cores next to its GPU
+        from . import affinity
+        affinity.bind_rank(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     torch.manual_seed(args.seed)
     model = FastDiff().cuda().eval()
     if args.ckpt:

@@ -768,8 +768,19 @@ def test_frame_bucketed_call_equals_the_exact_length_call(gc, sched):
     buckets = len({(T + 31) // 32 for T in lengths})
     # per bucket: (B=1, N=4) shared by the DDPM and "ddim" calls, (B=2, N=4) with and without streams, (B=2, N=6): three graphs (a
     # length that IS a multiple of 32 runs without `lens` and has its own); the exact-T handle captured three per LENGTH
+    captures = (bucketed.counter("graph_captures"), exact.counter("graph_captures"))
+    with torch.no_grad():
+        # a long schedule (N = 19: two 8-step pieces + a remainder, each with its own hoisted predictor) and the benchmark's own length - 1
+        rows19 = [{"t": 190.0 - 9.5 * k, "c_eps": 0.02, "c_div": 0.99, "sigma": 0.05, "c1": 1.0, "c2": 0.0, "c3": 0.0, "add_noise": int(k < 18)}
+                  for k in range(19)]
+        mel45 = torch.from_numpy(synth.synth_mel(45, 2, 45)).cuda()
+        a, b = exact.sample(mel45, rows19, seed=3, lens=[45, 17]), bucketed.sample(mel45, rows19, seed=3, lens=[45, 17])
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1, :, : 17 * 256], b[1, :, : 17 * 256])
+        mel863 = torch.from_numpy(synth.synth_mel(863, 1, 863)).cuda()
+        a, b = exact.sample(mel863, rows, seed=9), bucketed.sample(mel863, rows, seed=9)
+        assert torch.isfinite(a).all() and torch.equal(a, b)
     exact_mult = sum(1 for T in lengths if T % 32 == 0)
-    got_b, got_e = bucketed.counter("graph_captures") - base[bucketed], exact.counter("graph_captures") - base[exact]
+    got_b, got_e = captures[0] - base[bucketed], captures[1] - base[exact]
     assert 3 * buckets - 1 <= got_b <= 3 * buckets + 2 * exact_mult, (got_b, buckets)      # (- 1: the warm-up call's own graph)
     assert 3 * len(lengths) - 1 <= got_e <= 3 * len(lengths), (got_e, len(lengths))
 
