@@ -345,7 +345,7 @@ def _oracle_table(rows):
             "c3": [r["c3"] for r in ex]}
 
 
-PORT_VS_REFERENCE = "port = 0.86x / 0.85x (8 / 1 threads) of the reference's own time, outputs 4e-6 apart (profiles/r04_ref_vs_port_cpu.json)"
+PORT_VS_REFERENCE = "port = 0.89x / 0.71x (8 / 1 threads) of the reference's own time, outputs 4e-6 apart (profiles/r06_ref_vs_port_cpu.json, round 6)"
 
 
 def cpu_baseline(T, rows):

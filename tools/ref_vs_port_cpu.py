@@ -1,6 +1,6 @@
 """The reference itself against its port, on the SAME CPU with the SAME threads (build container only: needs /root/reference).
 
-    PYTHONDONTWRITEBYTECODE=1 python tools/ref_vs_port_cpu.py [threads ...]        -> profiles/r04_ref_vs_port_cpu.json
+    PYTHONDONTWRITEBYTECODE=1 python tools/ref_vs_port_cpu.py [threads ...]        -> profiles/r06_ref_vs_port_cpu.json
 
 bench.py's `cpu_baseline` is `oracle/torch_eager.py` (kind "port") because /root/reference cannot travel to the GPU box.  This
 records what that substitution is worth: the reference's own `sampling_given_noise_schedule(FastDiff(), (1,1,221184), dh,
@@ -96,7 +96,7 @@ def main():
     res["reading"] = ("cpu_baseline.value in bench.py is the lean port's RTF on the GPU box's host; the reference itself on the same CPU and threads "
                       "takes port_lean_over_reference^-1 x that time here")
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-    with open(os.path.join(ROOT, "profiles", "r04_ref_vs_port_cpu.json"), "w") as fh:
+    with open(os.path.join(ROOT, "profiles", "r06_ref_vs_port_cpu.json"), "w") as fh:
         json.dump(res, fh, indent=1)
 
 
