@@ -1249,10 +1249,10 @@ def main():
         if isinstance(line.get("b1"), dict) and "ms_per_step" in line["b1"]:
             summ["b1_ms"], summ["b1_rtf"] = line["b1"]["ms_per_step"], line["b1"]["value"]
             summ["b1_host_us"] = line["b1"].get("host_us_per_call_median")
+            summ["b1_lvc12_frac_min_bytes"] = line["b1"].get("lvc_all_12_launches_frac_minimal_bytes")
         for k in ("stream_b1_ms", "stream_b1_rtf", "stream_b1_sync_ms", "stream_b8_ms", "stream_fixed_shape_ms"):
             if k in line:
                 summ[k] = line[k]
-            summ["b1_lvc12_frac_min_bytes"] = line["b1"].get("lvc_all_12_launches_frac_minimal_bytes")
         if isinstance(line.get("fp32_pipe"), dict) and "ms_per_step" in line["fp32_pipe"]:
             summ["fp32_pipe_ms"], summ["fp32_pipe_rtf"] = line["fp32_pipe"]["ms_per_step"], line["fp32_pipe"]["value"]
         if isinstance(line.get("parity"), dict) and "max_abs_diff_f16x2" in line["parity"]:
