@@ -182,9 +182,6 @@ int fd_create(const fd_config *cfg, int device, fd_handle *out)
         return FD_ERR_HIP;
     };
     if ((e = hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e);
-    if ((e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e);
-    if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail(e);
-    if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&c->scratch, 65536)) != hipSuccess) return fail(e);
     if ((e = hipHostMalloc(reinterpret_cast<void **>(&c->flags_host), 256, hipHostMallocDefault)) != hipSuccess) return fail(e);
     memset(c->flags_host, 0, 256);
@@ -260,9 +257,6 @@ static void release_handle(fd_context *h)
     for (void *p : h->mel_allocs) hipFree(p);
     if (h->ev_switch) hipEventDestroy(h->ev_switch);
     if (h->cap_stream) hipStreamDestroy(h->cap_stream);
-    if (h->side_stream) hipStreamDestroy(h->side_stream);
-    if (h->ev_fork) hipEventDestroy(h->ev_fork);
-    if (h->ev_join) hipEventDestroy(h->ev_join);
     delete h;
 }
 
@@ -832,16 +826,9 @@ static hipError_t run_step(const Launch &L, const StepIO &io, int B, int T)
     // hoisted predictor (hoist_np > 1) front + GEMM of all N steps ran in front of the loop (sample_core).  Other orders and a second
     // stream were measured and did not pay (LABBOOK.md: overlap = gemm | paths, order = split | predictor).
     const bool hoisted = c->hoist_np > 1;
-    // option first_side (fd_internal.h): first_conv on a side branch, joined in front of the last block (the only reader of a0); needs
-    // the fast first DBlock (it recomputes its columns from the audio) and the fast LVC set (naive_lvc reads nothing else, but keep it simple)
-    const bool side = c->first_side && io.sampler && c->side_stream && c->fast[ST_FIRST] && c->fast[ST_DBLOCK] && c->fast[ST_LVC] && !c->keep_taps;
-    if (side) {
-        if ((e = hipEventRecord(c->ev_fork, L.stream)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(c->side_stream, c->ev_fork, 0)) != hipSuccess) return e;
-        const Launch Ls = {c, c->side_stream, L.capturing};
-        if ((e = first_conv(Ls, io, B, T)) != hipSuccess) return e;
-        if ((e = hipEventRecord(c->ev_join, c->side_stream)) != hipSuccess) return e;
-    } else if ((e = first_conv(L, io, B, T)) != hipSuccess) return e;
+    // (round 6, measured and not kept: first_conv -- whose output a0 has no reader before the last block -- on a side branch of the
+    // graph next to the DBlocks, joined in front of block 2, bit-identical: B=8 +0.5 %, B=1 +6 %; LABBOOK R6.7)
+    if ((e = first_conv(L, io, B, T)) != hipSuccess) return e;
     for (int d = 0; d < fd::NBLK; ++d)
         if ((e = dblock(L, io, d, B, T)) != hipSuccess) return e;
     if (!hoisted) {
@@ -851,7 +838,6 @@ static hipError_t run_step(const Launch &L, const StepIO &io, int B, int T)
     float *x = ws.a[3];
     for (int n = 0; n < fd::NBLK; ++n) {
         float *xo = nullptr;
-        if (side && n == fd::NBLK - 1 && (e = hipStreamWaitEvent(L.stream, c->ev_join, 0)) != hipSuccess) return e;      // a0 is this block's skip
         if ((e = lvc_block_run(L, n, x, B, T, &xo)) != hipSuccess) return e;
         x = xo;
     }
@@ -994,7 +980,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
 static unsigned mode_signature(const fd_context *h)
 {
     unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_f16 ? 2u : 0u) | (h->lvc_f16 ? 4u : 0u) | (h->conv_f16 ? 8u : 0u) | (h->step_lens ? 16u : 0u) |
-                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u) | ((unsigned)h->hoist_np << 11) | (h->hoist_chunk ? (1u << 21) : 0u) | (h->fuse_up ? (1u << 22) : 0u) | (h->fuse_advance ? (1u << 23) : 0u) | (h->first_side ? (1u << 24) : 0u);
+                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u) | ((unsigned)h->hoist_np << 11) | (h->hoist_chunk ? (1u << 21) : 0u) | (h->fuse_up ? (1u << 22) : 0u) | (h->fuse_advance ? (1u << 23) : 0u);
     for (int i = 0; i < ST_COUNT; ++i) s = (s << 1) | (h->fast[i] ? 1u : 0u);
     return s ^ (h->fp32_mask * 2654435761u);
 }
@@ -1031,8 +1017,7 @@ static int enqueue_steps(fd_handle h, int B, int T, int count, unsigned fp32_mas
     };
     if (h->hoist_chunk) h->hoist_np = 1;          // (the signature below must not depend on the piece that ran last)
     // between two steps of one sequence the bookkeeping rides in the next step's first kernel -- when that kernel is the fast one
-    // (not with first_conv on a side branch: the bookkeeping would then run next to kernels that read the flags it rotates)
-    const bool defer_advance = h->fuse_advance && h->fast[ST_FIRST] && !h->first_side;
+    const bool defer_advance = h->fuse_advance && h->fast[ST_FIRST];
     h->advance_pending = false;
     if (!(h->use_graph && !h->profile)) {
         fdk::Launch L = {h, stream, false};
@@ -1502,7 +1487,6 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
     if (k == "fuse_final") { h->fuse_final = on; drop_graph(h); return FD_OK; }
     if (k == "fuse_up") { h->fuse_up = on; drop_graph(h); return FD_OK; }
     if (k == "fuse_advance") { h->fuse_advance = on; drop_graph(h); return FD_OK; }
-    if (k == "first_side") { h->first_side = on; return FD_OK; }
     if (k == "lvc_dx") {      // training operator, frames path: gather = dx reads the forward-order frames; copy = a reordered copy first
         if (v != "gather" && v != "copy") FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: lvc_dx expects gather|copy, got '%s'", value);
         h->lvc_dx_gather = (v == "gather"); return FD_OK;

@@ -225,12 +225,6 @@ struct fd_context {
     std::vector<void *> mel_allocs;           // device memory behind `mel` (built on first use, freed at fd_destroy)
     int last_B = 0, last_T = 0;
     hipStream_t cap_stream = nullptr;
-    // option "first_side": first_audio_conv's output a0 has no reader before the LAST block (it is that block's skip tensor; the first
-    // DBlock recomputes its picked columns from the audio), so the 226 MB write stream of first_conv can run on a side branch next to the
-    // latency-bound down path and join in front of block 2 instead of standing at the head of the step's chain.
-    bool first_side = false;
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // Calls on one handle share the workspace, the embedding rows and the pending range check: they are ordered by the stream they run
     // on.  When a caller moves to another stream (fd_forward / fd_sample), a pending check is settled on the old stream and the new
     // stream waits for everything the old one still holds (follow_stream in fd_api.cpp).
