@@ -59,3 +59,25 @@ def test_bind_rank_reports_what_it_would_do(tmp_path, monkeypatch):
     assert info["applied"] is False and info["numa_known"] and info["gpu_pci"] == addr[1] and info["cpus"] >= 1
     monkeypatch.setenv("FD_NO_AFFINITY", "1")
     assert affinity.bind_rank(0, 2, gpu_of_rank=lambda r: addr[r], sysfs=sysfs) == {"applied": False, "why": "FD_NO_AFFINITY=1"}
+
+
+def test_bind_rank_really_pins_the_process(tmp_path):
+    """In a child process (so that pytest keeps its own cores): rank 1 of 2 ends up on exactly the cores the plan hands it."""
+    import subprocess
+    import sys
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 2:
+        import pytest
+        pytest.skip("needs two cores")
+    half = len(allowed) // 2
+    gpus = {affinity.pci_address(0, 0x30 + r, 0): r for r in range(2)}
+    sysfs = fake_sysfs(tmp_path, gpus, {0: ",".join(map(str, allowed[:half])), 1: ",".join(map(str, allowed[half:]))})
+    code = ("import os, sys, json; sys.path.insert(0, %r); from fastdiff_amd import affinity; addr = %r; "
+            "info = affinity.bind_rank(1, 2, gpu_of_rank=lambda r: addr[r], sysfs=%r); "
+            "print(json.dumps({'info': info, 'now': sorted(os.sched_getaffinity(0))}))") % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), list(gpus), sysfs)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    import json
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["info"]["applied"] is True and res["now"] == allowed[half:]
