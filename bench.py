@@ -1000,8 +1000,11 @@ def main():
     dev = torch.device("cuda", gpu_index)
     placement = None
     if world > 1:      # one rank per GPU on a many-core host: each rank on its own slice of the cores next to its GPU (fastdiff_amd/affinity.py)
-        from fastdiff_amd import affinity
-        placement = affinity.bind_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        try:
+            from fastdiff_amd import affinity
+            placement = affinity.bind_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        except Exception as e:      # noqa: BLE001 -- placement is best effort, never a reason not to measure
+            placement = {"applied": False, "why": repr(e)[:100]}
     rccl_ranks = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
