@@ -40,7 +40,8 @@ FD_API int fd_mel_spectrogram(fd_handle h, const float *wav, int B, int64_t n_sa
  *   fd_get_mel_filterbank: copies the bank in use to fb_out [80][513] host; returns 1 if it was supplied by the caller, 0 if it is the
  *     default, < 0 on error.
  * The DEFAULT is a restatement of librosa's published algorithm (Slaney scale, area-normalised triangles) -- librosa is absent from the
- * build image, so its values are checked against an independent derivation only (tests/test_mel_frontend.py), not against librosa. */
+ * build image; its values are pinned on an independent derivation and on a third-party implementation of librosa.filters.mel
+ * (transformers.audio_utils.mel_filter_bank, slaney / slaney: equal to 2e-16; tests/test_mel_frontend.py), not on librosa itself. */
 FD_API int fd_set_mel_filterbank(fd_handle h, const float *fb, int n_mels, int n_bins);
 FD_API int fd_get_mel_filterbank(fd_handle h, float *fb_out, int n_mels, int n_bins);
 

@@ -722,6 +722,23 @@ def gen_statedict_manifest():
     asums = np.array([float(v.double().abs().sum()) for v in sd.values()])
     np.savez_compressed(os.path.join(GOLD, "state_dict_manifest.npz"), names=names, shapes=shapes, sums=sums, asums=asums)
 
+def gen_mel_bank_third_party():
+    """The mel filter banks of the two front-ends as a THIRD-PARTY implementation of librosa.filters.mel computes them: Hugging Face
+    transformers' `audio_utils.mel_filter_bank(norm="slaney", mel_scale="slaney")` (present in the build image; librosa, which the reference
+    calls at data_gen/tts/data_gen_utils.py:122-134 and tacotron/layers.py:42-60, is not).  transformers documents and tests that function as
+    matching librosa's; it shares no code with this repo's restatement (oracle/mel_frontend.py, fd_api_ext.cpp: default_mel_bank).  Stored
+    as float64 [80, 513], librosa's own layout."""
+    import transformers
+    from transformers.audio_utils import mel_filter_bank
+    out = {"transformers_version": np.array(transformers.__version__)}
+    for name, fmin, fmax in (("pwg", 80.0, 7600.0), ("tacotron", 0.0, 8000.0)):
+        fb = mel_filter_bank(num_frequency_bins=513, num_mel_filters=80, min_frequency=fmin, max_frequency=fmax, sampling_rate=22050,
+                             norm="slaney", mel_scale="slaney")
+        out[name] = np.ascontiguousarray(np.asarray(fb, np.float64).T)
+    np.savez_compressed(os.path.join(GOLD, "mel_bank_third_party.npz"), **out)
+    print("mel banks by transformers", transformers.__version__, {k: v.shape for k, v in out.items() if k != "transformers_version"})
+
+
 def gen_sample_long(dh):
     """BASELINE configs[2] at its own size (round 6): B = 1, T = 864, the full N = 1000 schedule (FastDiff.py:76-78) through the
     reference's sampler (util.py:158-235) in float32 and float64, on the CONTRACTIVE synthetic weights (synth.make_contractive: x stays
@@ -759,7 +776,7 @@ def gen_sample_long(dh):
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["schedule", "embed", "ops", "forward", "sample", "manifest", "collate", "collater", "frontend", "frontend_tacotron",
-                             "frontend_pwg", "noise_scheduling", "theta_loss", "phi_loss", "theta_grad", "lvc_grad", "test_step", "forward_cfg"]
+                             "frontend_pwg", "noise_scheduling", "theta_loss", "phi_loss", "theta_grad", "lvc_grad", "test_step", "forward_cfg", "mel_bank"]
     dh = gen_schedule()
     if "embed" in which:
         gen_embed()
@@ -772,6 +789,8 @@ if __name__ == "__main__":
     for w in which:                       # "sample:s6" regenerates one sampler case
         if w.startswith("sample:"):
             gen_sample(dh, only=w.split(":", 1)[1].split(","))
+    if "mel_bank" in which:
+        gen_mel_bank_third_party()
     if "sample_long" in which:            # not in the default list: ~25 minutes
         gen_sample_long(dh)
     if "manifest" in which:

@@ -197,6 +197,28 @@ def test_mel_filterbank_against_an_independent_derivation():
         assert (np.nonzero(a)[0] == np.nonzero(b)[0]).all() and (np.nonzero(a)[1] == np.nonzero(b)[1]).all()
 
 
+def test_mel_filterbank_against_a_third_party_implementation_of_librosas():
+    """Round 6: librosa itself is not in the image, but Hugging Face transformers is, and its `audio_utils.mel_filter_bank(norm="slaney",
+    mel_scale="slaney")` is an independent implementation of `librosa.filters.mel` (documented and tested upstream as matching it).
+    `tests/golden/mel_bank_third_party.npz` holds what it returns for the two front-ends' arguments (oracle/gen_golden.py mel_bank): the
+    restated default banks must equal it to float64 rounding, zero pattern included -- and, where transformers is importable, the
+    fixture must be what that library returns here."""
+    g = load_golden("mel_bank_third_party")
+    for name, band in (("pwg", (80.0, 7600.0)), ("tacotron", (0.0, 8000.0))):
+        ref, ours = g[name], mf.mel_basis(fmin=band[0], fmax=band[1])
+        assert ref.shape == (80, 513) and ref.dtype == np.float64
+        assert np.array_equal(ours != 0, ref != 0)
+        assert np.abs(ours - ref).max() <= 1e-14 * ref.max(), (name, float(np.abs(ours - ref).max()))
+    try:
+        from transformers.audio_utils import mel_filter_bank
+    except Exception:      # noqa: BLE001 -- the fixture is the pin; regenerating it is a bonus
+        return
+    for name, band in (("pwg", (80.0, 7600.0)), ("tacotron", (0.0, 8000.0))):
+        fb = mel_filter_bank(num_frequency_bins=513, num_mel_filters=80, min_frequency=band[0], max_frequency=band[1], sampling_rate=22050,
+                             norm="slaney", mel_scale="slaney")
+        assert np.abs(np.asarray(fb, np.float64).T - g[name]).max() <= 1e-15
+
+
 def test_mel_scale_and_filterbank_values_printed_in_librosas_documentation():
     """The numbers librosa's own docstrings print (librosa 0.8 - 0.10: `mel_frequencies`, `hz_to_mel`, `mel_to_hz`, `filters.mel`),
     quoted here as the only librosa-originated values available offline.  They pin the Slaney scale completely (40 band edges to
@@ -235,6 +257,8 @@ def test_library_default_filter_banks_are_the_restated_ones_and_a_supplied_bank_
         assert np.array_equal(bank != 0, ref != 0)
         assert np.abs(bank.astype(np.float64) - ref).max() <= 6e-8 * ref.max()            # float32 rounding of the same numbers
         assert np.abs(bank.astype(np.float64) - _independent_mel_bank(22050, 1024, 80, *band)).max() <= 6e-8 * ref.max()
+        third = load_golden("mel_bank_third_party")[variant]                                  # transformers' implementation of librosa.filters.mel
+        assert np.array_equal(bank != 0, third != 0) and np.abs(bank.astype(np.float64) - third).max() <= 6e-8 * third.max()
         base = model.mel_spectrogram(wav, variant=variant)
         # (1) the same matrix handed back: identical output, and the library says whose it is
         model.set_mel_filterbank(bank, variant)
