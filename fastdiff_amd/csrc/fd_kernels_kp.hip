@@ -546,7 +546,9 @@ __device__ __forceinline__ void gx_item(char *lds, const GxItem &cur, bool more,
             }
             acc = mfma_f16(a1, wq[0][kg], kg == 0 ? zero : acc);
             lo = mfma_f16(a2, wq[0][kg], kg == 0 ? bias_lo : lo);
+#ifndef FD_GX_PROBE_TWO_MFMA   // probe (round 6): two of the three matrix instructions per k group -- what would a third less matrix work buy?
             lo = mfma_f16(a1, wq[1][kg], lo);
+#endif
             a1 = n1;
             a2 = n2;
         }
