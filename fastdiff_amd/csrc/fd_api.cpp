@@ -15,7 +15,8 @@
 std::string g_create_error;
 
 // rows of the predictor GEMM's fp16 image per utterance (gx_rows in fd_kernels_kp.hip: 128-frame windows + 2 halo rows)
-static inline int gx_rows_host(int T) { return ((T + 127) / 128) * 128 + 2; }
+// (... or, for the Winograd form k_kp_gemm_w, 32 frame PAIRS of four 256-byte sub-rows per 64-frame window: whichever is larger)
+static inline int gx_rows_host(int T) { return std::max(((T + 127) / 128) * 128 + 2, ((T + 63) / 64) * 128); }
 
 // ------------------------------------------------------------------------------------------------
 // profiling helpers (declared in fd_internal.h)
@@ -496,7 +497,7 @@ int fd_commit_weights(fd_handle h)
         }
         UP(table, w.embed_table);
     }
-    bool f16_ok = true, lvc_ok = true, dblock_ok = true, convt_ok = true, kpf_ok = true;
+    bool f16_ok = true, w_ok = true, lvc_ok = true, dblock_ok = true, convt_ok = true, kpf_ok = true;
     for (int n = 0; n < fd::NBLK; ++n) {
         const std::string p = "lvc_blocks." + std::to_string(n), d = "downsample." + std::to_string(n);
         if ((rc = up_conv(d + ".residual_dense", w.down[n].res)) != FD_OK) return rc;
@@ -640,9 +641,42 @@ int fd_commit_weights(fd_handle h)
                 }
             if ((rc = upload(h, gx.data(), gx.size() * sizeof(uint16_t), reinterpret_cast<const void **>(&w.gemm_h2_pack[n]))) != FD_OK)
                 return rc;
+            // Winograd F(2,3) over the frame axis (kernel_conv is a k = 3 convolution over frames, modules.py:315-318): per pair of
+            // output frames  y[2p] = m0 + m1 + m2,  y[2p+1] = m1 - m2 + m3  with  m_j = V_j . u_j (K = 64 each),
+            //   V0 = g0, V1 = (g0 + g1 + g2) / 2, V2 = (g0 - g1 + g2) / 2, V3 = -g2        (g_tap = the column's weights of that tap)
+            //   u0 = h[2p-1] - h[2p+1], u1 = h[2p] + h[2p+1], u2 = h[2p+1] - h[2p], u3 = h[2p] - h[2p+2]   (k_h_wino)
+            // B operand: lane = col + 32*g holds the 8 consecutive k = kg*16 + 8g + e, kg = 4 j + k4, channel = 16 k4 + 8 g + e
+            std::vector<uint16_t> gw((size_t)(fd::KREC / 32) * 2 * 16 * 64 * 8);
+            for (int pt = 0; pt < fd::KREC / 32; ++pt)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int pp = pt * 32 + (lane & 31), g = lane >> 5;
+                    const float *wrow;
+                    if (pp < fd::KW) {
+                        int layer, in, out, tap;
+                        unpack_kernel_index(pp, layer, in, out, tap);
+                        wrow = kc.data() + (size_t)(((layer * fd::C + in) * 2 * fd::C + out) * 3 + tap) * fd::HID * 3;
+                    } else {
+                        const int q = pp - fd::KW, layer = q >> 6, mt = (q >> 5) & 1, row = q & 31;
+                        wrow = bc.data() + (size_t)(layer * 64 + 16 * mt + (row & 15) + 32 * (row >> 4)) * fd::HID * 3;
+                    }
+                    for (int kg = 0; kg < 16; ++kg)
+                        for (int e = 0; e < 8; ++e) {
+                            const int j = kg >> 2, ch = (kg & 3) * 16 + g * 8 + e;
+                            const double g0 = wrow[ch * 3 + 0], g1 = wrow[ch * 3 + 1], g2 = wrow[ch * 3 + 2];
+                            const float v = (float)(j == 0 ? g0 : (j == 1 ? 0.5 * (g0 + g1 + g2) : (j == 2 ? 0.5 * (g0 - g1 + g2) : -g2)));
+                            if (!(fabsf(v) < 32768.0f)) w_ok = false;
+                            const uint16_t p1 = f16_from_f32(v);
+                            const uint16_t p2 = f16_from_f32((v - f32_from_f16(p1)) * 2048.0f);
+                            gw[((((size_t)pt * 2 + 0) * 16 + kg) * 64 + lane) * 8 + e] = p1;
+                            gw[((((size_t)pt * 2 + 1) * 16 + kg) * 64 + lane) * 8 + e] = p2;
+                        }
+                }
+            if ((rc = upload(h, gw.data(), gw.size() * sizeof(uint16_t), reinterpret_cast<const void **>(&w.gemm_w_pack[n]))) != FD_OK)
+                return rc;
         }
     }
     w.gemm_f16_ok = f16_ok;
+    w.gemm_w_ok = w_ok;
     w.lvc_f16_ok = lvc_ok;
     w.dblock_f16_ok = dblock_ok;
     w.convt_f16_ok = convt_ok;
@@ -980,7 +1014,7 @@ int fd_forward(fd_handle h, const float *x, const float *mel, const float *steps
 static unsigned mode_signature(const fd_context *h)
 {
     unsigned s = (h->keep_taps ? 1u : 0u) | (h->gemm_f16 ? 2u : 0u) | (h->lvc_f16 ? 4u : 0u) | (h->conv_f16 ? 8u : 0u) | (h->step_lens ? 16u : 0u) |
-                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u) | ((unsigned)h->hoist_np << 11) | (h->hoist_chunk ? (1u << 21) : 0u) | (h->fuse_up ? (1u << 22) : 0u) | (h->fuse_advance ? (1u << 23) : 0u);
+                 (h->inline_fallback ? 32u : 0u) | (h->lvc_h8_mfma ? 64u : 0u) | ((unsigned)h->hoist_np << 11) | (h->hoist_chunk ? (1u << 21) : 0u) | (h->fuse_up ? (1u << 22) : 0u) | (h->fuse_advance ? (1u << 23) : 0u) | (h->gemm_wino ? (1u << 24) : 0u);
     for (int i = 0; i < ST_COUNT; ++i) s = (s << 1) | (h->fast[i] ? 1u : 0u);
     return s ^ (h->fp32_mask * 2654435761u);
 }
@@ -1451,6 +1485,12 @@ int fd_set_option(fd_handle h, const char *key, const char *value)
         if (v == "f16x2") h->gemm_f16 = true;
         else if (v == "fp32") h->gemm_f16 = false;
         else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: gemm expects f16x2|fp32, got '%s'", value);
+        return FD_OK;
+    }
+    if (k == "gemm_form") {      // how the fp16x2 predictor GEMM evaluates kernel_conv's three taps
+        if (v == "winograd") h->gemm_wino = true;
+        else if (v == "direct") h->gemm_wino = false;
+        else FD_FAIL(h, FD_ERR_INVALID, "fd_set_option: gemm_form expects winograd|direct, got '%s'", value);
         return FD_OK;
     }
     if (k == "lvc") {

@@ -87,6 +87,10 @@ struct DevWeights {
     const float *gemm_bias[fd::NBLK] = {};        // [24832] conv biases in packed order
     const uint16_t *gemm_h2_pack[fd::NBLK] = {};  // same weights as two fp16 pieces (w1, (w-w1)*2^11): [776 ptile][2][12 kg][64 lane][8]
     bool gemm_f16_ok = false;                     // every GEMM weight fits the fp16 range
+    // the same weights transformed for Winograd F(2,3) over the frame axis of kernel_conv (k_kp_gemm_w): per packed column four K = 64
+    // blocks g0, (g0+g1+g2)/2, (g0-g1+g2)/2, -g2 (formed in double, rounded to fp32, split): [776 ptile][2 pieces][16 kg][64 lane][8]
+    const uint16_t *gemm_w_pack[fd::NBLK] = {};
+    bool gemm_w_ok = false;                       // ... and every transformed weight fits the fp16 range
     const float *up_pack[fd::NBLK] = {};          // ConvTranspose as per-phase A operands: [r phases][8 s4][64][4]
     const uint16_t *up_h2[fd::NBLK] = {};         // ConvTranspose per-phase slices as fp16 pieces: [ph][piece][4 kg][64 lane][8]
     bool convt_f16_ok = false;
@@ -184,6 +188,7 @@ struct fd_context {
     int profile = 0;                          // option "profile": 0 off | 1 the kernels' own begin / end timestamps | 2 ("events") stream events around each launch
     bool keep_taps = false;
     bool gemm_f16 = true;                     // kp_gemm on the fp16 matrix pipe with the 2-piece operand split
+    bool gemm_wino = true;                    // option "gemm_form" = "winograd" | "direct": ... as Winograd F(2,3) over the frame axis (2/3 of the matrix work)
     bool lvc_f16 = true;                      // LVC layers (hop 64, 256) likewise
     bool conv_f16 = true;                     // DBlocks, ConvTranspose upsamplers and the predictor front likewise
     const int *step_lens = nullptr;           // device copy of the caller's `lens` for this call (ragged batch), or null

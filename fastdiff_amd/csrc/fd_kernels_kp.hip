@@ -713,6 +713,251 @@ __global__ void __launch_bounds__(256, 2) k_kp_gemm_h2(const char *__restrict__ 
 #endif
 }
 
+// =================================================================================================
+// The same product as Winograd F(2,3) over the FRAME axis (round 6).  kernel_conv is a k = 3 convolution over frames
+// (modules.py:315-318), and k_kp_gemm_h2 is bound by its matrix instructions at the power-capped clock (LABBOOK R6.8: with two of
+// its three instructions per k group it runs in 407 instead of 514 us).  Per pair of output frames (2p, 2p+1) four K = 64 products
+// replace six:
+//   u0 = h[2p-1] - h[2p+1]   u1 = h[2p] + h[2p+1]   u2 = h[2p+1] - h[2p]   u3 = h[2p] - h[2p+2]        (fp32, then the 2-piece split)
+//   V0 = g0   V1 = (g0 + g1 + g2) / 2   V2 = (g0 - g1 + g2) / 2   V3 = -g2                              (fd_commit_weights)
+//   m_j = V_j . u_j        y[2p] = bias + m0 + m1 + m2        y[2p+1] = bias + m1 - m2 + m3
+// Every m_j is a 2-piece product with fp32 accumulation like the direct form's; the sums of three of them add three fp32 roundings.
+// Image: [block][entry][pair p][j][piece][64 ch] fp16 = 1 KB per pair, 16-byte slot s of a 256-byte sub-row stored at s ^ (p & 15).
+// A work item = (block, 128-column group, entry, 32 pairs = 64 frames): its 32 KB window is one linear DMA; 48 matrix instructions and
+// 32 stores per wave.  Registers: 128 of stationary weight pieces, acc + lo, and the two output tiles as finished fp32 values.
+// =================================================================================================
+constexpr int GW_PAIRS = 32;                      // pairs per item (64 frames)
+constexpr int GW_ROWB = 1024;                     // bytes per pair row: [4 j][2 pieces][64 ch] fp16
+constexpr int GW_WINB = GW_PAIRS * GW_ROWB;       // 32 KB per window = 8 DMA rounds of 4 KB
+__host__ __device__ inline int gw_pairs(int T) { return ((T + 2 * GW_PAIRS - 1) / (2 * GW_PAIRS)) * GW_PAIRS; }      // image rows (pairs) per (block, entry)
+
+// h (fp32 [3][B][64][T]) -> the transformed piece image.  Thread = (pair p, 8-channel group g): eight neighbouring lanes write the eight
+// 16-byte slots of one 128-byte half of a sub-row (whole lines), and read their channels' four frames 2p-1 .. 2p+2 (the inner two as one
+// 8-byte load); frames outside the utterance are zero, pairs behind it are written as zeros.
+__global__ void __launch_bounds__(256) k_h_wino(const float *__restrict__ h, char *__restrict__ wx, int *__restrict__ range_flag, int B, int T,
+                                                int P, const int *__restrict__ lens)
+{
+    const int bb = blockIdx.y;                           // blk*B + b
+    const int e = blockIdx.x * 256 + threadIdx.x, p = e >> 3, g = e & 7;
+    if (p >= P) return;
+    if (range_flag[32] != 0) {      // h did not fit in the previous step: the fp32 GEMM takes this one as well
+        if (e == 0 && bb == 0) atomicOr(range_flag, 1);
+        return;
+    }
+    const int Tb = frames_of(lens, bb % B, T);
+    const float *hb = h + ((int64_t)bb * fd::HID + 8 * g) * T;
+    const int t1 = 2 * p;                                // frames t1 - 1, t1, t1 + 1, t1 + 2
+    float d[8][4];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float *hc = hb + (int64_t)c * T;
+        d[c][0] = (t1 - 1 >= 0 && t1 - 1 < Tb) ? hc[t1 - 1] : 0.0f;
+        d[c][1] = (t1 < Tb) ? hc[t1] : 0.0f;
+        d[c][2] = (t1 + 1 < Tb) ? hc[t1 + 1] : 0.0f;
+        d[c][3] = (t1 + 2 < Tb) ? hc[t1 + 2] : 0.0f;
+    }
+    float mx = 0.0f;
+    char *row = wx + ((int64_t)bb * P + p) * GW_ROWB;
+    const int sw = p & 15;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float u[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            u[c] = j == 0 ? d[c][0] - d[c][2] : (j == 1 ? d[c][1] + d[c][2] : (j == 2 ? d[c][2] - d[c][1] : d[c][1] - d[c][3]));
+            mx = fmaxf(mx, fabsf(u[c]));
+        }
+        float4 ph, pl;
+        split8(u, ph, pl);
+        *reinterpret_cast<float4 *>(row + j * 256 + ((g ^ sw) << 4)) = ph;
+        *reinterpret_cast<float4 *>(row + j * 256 + (((g + 8) ^ sw) << 4)) = pl;
+    }
+    if (!(mx < GX_LIMIT)) atomicOr(range_flag, 1);      // also catches NaN / inf
+}
+
+__device__ __forceinline__ void gw_dma(const char *wx, char *lds_buf, const GxItem &it, int B, int P, int wave_u, int lane)
+{
+    const char *src = wx + (((int64_t)it.blk * B + it.b) * P + it.chunk * GW_PAIRS) * GW_ROWB + wave_u * 1024;    // uniform
+    const unsigned dst = (unsigned)(uintptr_t)(lds_ptr_t)(lds_buf + wave_u * 1024);
+    const unsigned voff = lane * 16;
+    unsigned keep;
+#pragma unroll
+    for (int j = 0; j < GW_WINB / 4096; ++j)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(src + j * 4096), "s"(dst + j * 4096)
+                     : "memory");
+}
+
+// One item: 32 pairs.  Vector-memory order per item: [DMA of the next window] [16 stores of the even frames] [16 of the odd ones].
+// Order of the four products, chosen for register life: m1, then m2 ON TOP of m1 (the matrix instruction's C operand: s = m1 + m2 comes out
+// of the accumulator, d = 2 m1 - s = m1 - m2), then m0 on top of s (-> y[2p], stored), then m3 on top of d (-> y[2p+1], stored): never more
+// than one finished tile next to acc + lo.  The bias enters through the cross-term accumulator of the m0 and m3 chains.
+template <int BUF, bool FULL>
+__device__ __forceinline__ void gw_item(char *lds, const GxItem &cur, bool more, const GxItem &nxt, const char *wx, float *kpack,
+                                        const float4 (&wq)[2][16], float bias_lo, const int (&aoff)[2][4], int B, int T, int P,
+                                        int wave_u, int lane, int Tb)
+{
+    const int l31 = lane & 31, hi = lane >> 5;
+    if (more) gw_dma(wx, lds + (BUF ^ 1) * GW_WINB, nxt, B, P, wave_u, lane);
+    const int t_begin = cur.chunk * (2 * GW_PAIRS);
+    float *krow = kpack + (((int64_t)cur.blk * B + cur.b) * T + t_begin) * fd::KREC + (cur.xg * 4 + wave_u) * 32;     // uniform
+    // pair row of register r: (r & 3) + 8 (r >> 2) + 4 hi -> frame 2 * that (+ 1): the lane part goes into the per-lane offset
+    const unsigned loff = (unsigned)(8 * hi) * (unsigned)fd::KREC + (unsigned)l31;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(krow, 0, 2 * GW_PAIRS * fd::KREC * 4, 0x00020000);
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const char *hb = lds + BUF * GW_WINB;
+    constexpr int ORDER[4] = {1, 2, 0, 3};
+    f32x16 keep;      // m1, then d = m1 - m2
+    f32x16 acc = zero, lo = zero;
+    float4 a1 = *reinterpret_cast<const float4 *>(hb + aoff[0][0] + ORDER[0] * 256), a2 = *reinterpret_cast<const float4 *>(hb + aoff[1][0] + ORDER[0] * 256);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int j = ORDER[s];
+        if (s == 2 || s == 3) {      // (acc already holds s / d: see below); 2048 * bias in every register of the cross-term accumulator
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lo[r] = bias_lo;
+        } else lo = zero;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const int kg = j * 4 + k4;
+            float4 n1 = a1, n2 = a2;
+            if (k4 + 1 < 4) {
+                n1 = *reinterpret_cast<const float4 *>(hb + aoff[0][k4 + 1] + j * 256);
+                n2 = *reinterpret_cast<const float4 *>(hb + aoff[1][k4 + 1] + j * 256);
+            } else if (s + 1 < 4) {
+                n1 = *reinterpret_cast<const float4 *>(hb + aoff[0][0] + ORDER[s + 1 < 4 ? s + 1 : 3] * 256);
+                n2 = *reinterpret_cast<const float4 *>(hb + aoff[1][0] + ORDER[s + 1 < 4 ? s + 1 : 3] * 256);
+            }
+            acc = mfma_f16(a1, wq[0][kg], acc);
+            lo = mfma_f16(a2, wq[0][kg], lo);
+            lo = mfma_f16(a1, wq[1][kg], lo);
+            a1 = n1;
+            a2 = n2;
+        }
+        if (s == 0) {                // m1: kept, and the start of the m2 chain
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { keep[r] = fmaf(lo[r], GX_INV_SCALE, acc[r]); acc[r] = keep[r]; }
+        } else if (s == 1) {         // s = m1 + m2 (the start of the m0 chain), d = 2 m1 - s = m1 - m2
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[r] = fmaf(lo[r], GX_INV_SCALE, acc[r]); keep[r] = fmaf(2.0f, keep[r], -acc[r]); }
+        } else {                     // y[2p] = s + m0 (+ bias), then y[2p+1] = d + m3 (+ bias)
+            const int odd = (s == 3) ? 1 : 0;
+            if (FULL) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaf(lo[r], GX_INV_SCALE, acc[r])), rs, loff * 4u,
+                                                          (2 * ((r & 3) + 8 * (r >> 2)) + odd) * fd::KREC * 4, FD_GX_STORE_AUX);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t_begin + 2 * drow(r, hi) + odd < Tb) (krow + (2 * ((r & 3) + 8 * (r >> 2)) + odd) * fd::KREC)[loff] = fmaf(lo[r], GX_INV_SCALE, acc[r]);
+            }
+            if (s == 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = keep[r];      // the m3 chain starts from d
+            }
+        }
+    }
+    if (more) {      // the DMA has landed; this item's 32 buffer stores may still fly
+        if (FULL) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+}
+
+__global__ void __launch_bounds__(256, 2) k_kp_gemm_w(const char *__restrict__ wx /*[3][B][P][4][2][64] fp16*/, float *__restrict__ kpack,
+                                                      const float4 *g0, const float4 *g1, const float4 *g2, const float *gb0,
+                                                      const float *gb1, const float *gb2, const int *__restrict__ range_flag, int B,
+                                                      int T, int P, int chunks_per_utt, int n_items, const int *__restrict__ lens)
+{
+    __shared__ __attribute__((aligned(16))) char lds[2 * GW_WINB];     // 2 x 32 KB
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int XG = fd::KREC / 128;
+    if (*range_flag != 0) return;      // out-of-range operands: the fp32 kernel behind us does this step
+    // the schedule of k_kp_gemm_h2: whole column groups in step first (a window is fetched from HBM once per XCD), equal id ranges last
+    const int ny = B * chunks_per_utt, n_wg = gridDim.x, w = blockIdx.x;
+    const int q = (fd::NBLK * XG) / n_wg, base = q * n_wg * ny, rest = n_items - base;
+    const int r0 = (int)((int64_t)w * rest / n_wg), r1 = (int)((int64_t)(w + 1) * rest / n_wg);
+    const int n_mine = q * ny + (r1 - r0);
+    if (n_mine <= 0) return;
+    auto decode = [&](int id) {
+        GxItem it;
+        it.blk = id / (XG * ny);
+        const int rem = id - it.blk * (XG * ny);
+        it.xg = rem / ny;
+        const int yy = rem - it.xg * ny;
+        it.b = yy / chunks_per_utt;
+        it.chunk = yy - it.b * chunks_per_utt;
+        return it;
+    };
+    auto advance = [&](GxItem it) {
+        if (++it.chunk == chunks_per_utt) {
+            it.chunk = 0;
+            if (++it.b == B) {
+                it.b = 0;
+                if (++it.xg == XG) { it.xg = 0; ++it.blk; }
+            }
+        }
+        return it;
+    };
+    int run = 0, left = (q > 0) ? ny : (r1 - r0);
+    GxItem cur = decode((q > 0) ? w * ny : base + r0);
+    // byte offsets of the A-operand reads: pair row l31, slot = (8*piece + 2*k4 + hi) ^ (row & 15); the sub-row j adds the constant 256 j
+    int aoff[2][4];
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) aoff[q2][k4] = l31 * GW_ROWB + (((q2 * 8 + k4 * 2 + hi) ^ (l31 & 15)) << 4);
+    gw_dma(wx, lds, cur, B, P, wave_u, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float4 wq[2][16];
+    float bias_lo = 0.0f;      // 2048 * bias of this lane's column (one register: gw_item copies it into the accumulator twice per item)
+    int have_blk = -1, have_xg = -1;
+#pragma unroll 1
+    for (int i = 0; i < n_mine; i += 2) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half == 1 && i + 1 >= n_mine) break;
+            if (cur.blk != have_blk || cur.xg != have_xg) {
+                const float4 *gp = cur.blk == 0 ? g0 : (cur.blk == 1 ? g1 : g2);
+                const float *gb = cur.blk == 0 ? gb0 : (cur.blk == 1 ? gb1 : gb2);
+                const int ptile = cur.xg * 4 + wave_u;
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                    for (int kg = 0; kg < 16; ++kg) wq[q2][kg] = gp[(((int64_t)ptile * 2 + q2) * 16 + kg) * 64 + lane];
+                bias_lo = gb[ptile * 32 + l31] * GX_SCALE;
+                have_blk = cur.blk; have_xg = cur.xg;
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+            }
+            const bool more = (i + half + 1 < n_mine);
+            GxItem nxt = cur;
+            if (more) {
+                if (left > 1) nxt = advance(cur);
+                else {
+                    ++run;
+                    nxt = decode(run < q ? (run * n_wg + w) * ny : base + r0);
+                    left = (run < q ? ny : r1 - r0) + 1;
+                }
+            }
+            --left;
+            const int Tb = frames_of(lens, cur.b, T);
+            const bool full = cur.chunk * (2 * GW_PAIRS) + 2 * GW_PAIRS <= Tb;
+            if (half == 0) {
+                if (full) gw_item<0, true>(lds, cur, more, nxt, wx, kpack, wq, bias_lo, aoff, B, T, P, wave_u, lane, Tb);
+                else gw_item<0, false>(lds, cur, more, nxt, wx, kpack, wq, bias_lo, aoff, B, T, P, wave_u, lane, Tb);
+            } else {
+                if (full) gw_item<1, true>(lds, cur, more, nxt, wx, kpack, wq, bias_lo, aoff, B, T, P, wave_u, lane, Tb);
+                else gw_item<1, false>(lds, cur, more, nxt, wx, kpack, wq, bias_lo, aoff, B, T, P, wave_u, lane, Tb);
+            }
+            cur = nxt;
+        }
+    }
+}
+
 }  // namespace fdk_fast
 
 // ------------------------------------------------------------------------------------------------
@@ -766,7 +1011,18 @@ hipError_t fast_kp_gemm(const Launch &L, int B, int T)
     const int grid = n_items < 2 * c->num_cus ? n_items : 2 * c->num_cus;              // persistent: 2 workgroups per CU
     const Pipe pipe = fd_pipe(c, c->gemm_f16 && w.gemm_f16_ok, 0);
     const bool f16 = pipe != PIPE_F32_ONLY;
-    if (f16) {
+    if (f16 && c->gemm_wino && w.gemm_w_ok) {
+        // Winograd F(2,3) over the frame axis: the transformed piece image from the front's fp32 h, then 2/3 of the direct form's matrix work
+        const int P = gw_pairs(T), chunks = P / GW_PAIRS, items = fd::NBLK * (fd::KREC / 128) * B * chunks;
+        const int grid2 = items < 2 * c->num_cus ? items : 2 * c->num_cus;
+        FD_LAUNCH(L, "h_wino", k_h_wino, dim3((8 * P + 255) / 256, fd::NBLK * B), dim3(256), 0, (const float *)c->ws.kp_hB,
+                  reinterpret_cast<char *>(c->ws.h_f16), c->ws.range_flag, B, T, P, c->step_lens);
+        FD_LAUNCH(L, "kp_gemm_f16x2", k_kp_gemm_w, dim3(grid2), dim3(256), 0, reinterpret_cast<const char *>(c->ws.h_f16), c->ws.kpack,
+                  reinterpret_cast<const float4 *>(w.gemm_w_pack[0]), reinterpret_cast<const float4 *>(w.gemm_w_pack[1]),
+                  reinterpret_cast<const float4 *>(w.gemm_w_pack[2]), w.gemm_bias[0], w.gemm_bias[1], w.gemm_bias[2],
+                  (const int *)c->ws.range_flag, B, T, P, chunks, items, c->step_lens);
+        if (pipe == PIPE_F16_ONLY) return hipSuccess;
+    } else if (f16) {
         const int R = gx_rows(T);
         const int chunks = (T + GX_CT * 32 - 1) / (GX_CT * 32), items = fd::NBLK * (fd::KREC / 128) * B * chunks;
         const int grid2 = items < 2 * c->num_cus ? items : 2 * c->num_cus;
