@@ -96,10 +96,14 @@ def kernel_model(name, B, T):
     return "hbm", None, None
 
 
+GEMM_FORM = "winograd"      # set from the library option gemm_form in main()
+
+
 def executed_flops(name, B, T):
-    """Matrix-pipe flops a launch really issues when that differs from the algorithmic count: the fp16x2 GEMM forms h.h, h.l and l.h."""
+    """Matrix-pipe flops a launch really issues when that differs from the algorithmic count: the fp16x2 GEMM forms h.h, h.l and l.h
+    (3x), and as Winograd F(2,3) over the frame axis four K = 64 products per pair of frames instead of six (x 2/3)."""
     if name == "kp_gemm_f16x2":
-        return 3 * kernel_model(name, B, T)[2]
+        return 3 * kernel_model(name, B, T)[2] * (2.0 / 3.0 if GEMM_FORM == "winograd" else 1.0)
     return None
 
 
@@ -134,7 +138,7 @@ def template_group(fam_name):
     return fam_name
 
 
-ROCPROF_NAME = {"k_kp_gemm_h2": "kp_gemm_f16x2", "k_final_acc": "final_update", "k_first_conv": "first_conv", "k_kp_front_h2": "kp_front",
+ROCPROF_NAME = {"k_kp_gemm_h2": "kp_gemm_f16x2", "k_kp_gemm_w": "kp_gemm_f16x2", "k_h_wino": "h_wino", "k_final_acc": "final_update", "k_first_conv": "first_conv", "k_kp_front_h2": "kp_front",
                 "k_advance": "advance_step", "k_init_noise": "init_noise", "k_embed_mlp": "embed", "k_embed_fct": "embed_fct", "k_kp_gemm": "kp_gemm",
                 "k_final": "final_conv_update", "k_h_split": "h_split"}
 
@@ -1033,6 +1037,8 @@ def main():
         model.set_option("graph", "0")
     for kv in args.opt:
         model.set_option(*kv.split("=", 1))
+    global GEMM_FORM
+    GEMM_FORM = model._options.get("gemm_form", "winograd")
     dh = schedules.training_hyperparams()
     rows = sampler.InferenceSchedule(dh, schedules.noise_schedule_for(N), verbose=False).rows()
 

@@ -19,7 +19,7 @@ def main():
         m = re.search(r"k_lvc_h8m<(\d+)", n)
         if m:
             pick["h8_d" + m.group(1)] = avg
-        elif "k_kp_gemm_h2" in n:
+        elif "k_kp_gemm_h2" in n or "k_kp_gemm_w" in n:
             pick["gemm"] = avg
             calls_gemm = calls
         elif "k_first_conv" in n:

@@ -16,7 +16,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-BENCH_NAME = {"k_kp_gemm": "kp_gemm_fp32_fallback", "k_kp_gemm_h2": "kp_gemm_f16x2", "k_h_split": "h_split", "k_final": "final_conv_fallback", "k_final_acc": "final_update",
+BENCH_NAME = {"k_kp_gemm": "kp_gemm_fp32_fallback", "k_kp_gemm_h2": "kp_gemm_f16x2", "k_kp_gemm_w": "kp_gemm_f16x2", "k_h_wino": "h_wino", "k_h_split": "h_split", "k_final": "final_conv_fallback", "k_final_acc": "final_update",
               "k_first_conv": "first_conv", "k_embed_mlp": "embed", "k_embed_fct": "embed_fct", "k_dblock_h2": "dblock", "k_dblock": "dblock_fp32_fallback",
               "k_convt_h2": "convt", "k_convt": "convt_fp32_fallback", "k_kp_front_h2": "kp_front", "k_kp_front": "kp_front_fp32_fallback",
               "k_advance": "advance_step", "k_init_noise": "init_noise"}
