@@ -777,6 +777,9 @@ __global__ void __launch_bounds__(256) k_h_wino(const float *__restrict__ h, cha
 
 __device__ __forceinline__ void gw_dma(const char *wx, char *lds_buf, const GxItem &it, int B, int P, int wave_u, int lane)
 {
+#ifdef FD_GW_NO_FETCH      // probe: what do the window copies cost the short items?
+    return;
+#endif
     const char *src = wx + (((int64_t)it.blk * B + it.b) * P + it.chunk * GW_PAIRS) * GW_ROWB + wave_u * 1024;    // uniform
     const unsigned dst = (unsigned)(uintptr_t)(lds_ptr_t)(lds_buf + wave_u * 1024);
     const unsigned voff = lane * 16;
@@ -790,9 +793,11 @@ __device__ __forceinline__ void gw_dma(const char *wx, char *lds_buf, const GxIt
 }
 
 // One item: 32 pairs.  Vector-memory order per item: [DMA of the next window] [16 stores of the even frames] [16 of the odd ones].
-// Order of the four products, chosen for register life: m1, then m2 ON TOP of m1 (the matrix instruction's C operand: s = m1 + m2 comes out
-// of the accumulator, d = 2 m1 - s = m1 - m2), then m0 on top of s (-> y[2p], stored), then m3 on top of d (-> y[2p+1], stored): never more
-// than one finished tile next to acc + lo.  The bias enters through the cross-term accumulator of the m0 and m3 chains.
+// VALU instructions do not issue under the SIMD's own matrix instruction, so the combination is arranged to need as few as
+// possible: ONE accumulator chain runs through m1, m2, m0 (it ends as y[2p] = m0 + m1 + m2, bias included: the bias enters once, through
+// the cross-term accumulator of the first product); m1 is read out of it on the way (keep = m1 + bias), and behind m2 the chain's value
+// s = m1 + m2 + bias turns keep into d = 2 keep - s = m1 - m2 + bias, which is the C operand of the m3 chain (-> y[2p+1]).
+// 96 VALU instructions per item: bias 16, m1 16, d 32, and the two read-outs in front of the stores.
 template <int BUF, bool FULL>
 __device__ __forceinline__ void gw_item(char *lds, const GxItem &cur, bool more, const GxItem &nxt, const char *wx, float *kpack,
                                         const float4 (&wq)[2][16], float bias_lo, const int (&aoff)[2][4], int B, int T, int P,
@@ -808,16 +813,39 @@ __device__ __forceinline__ void gw_item(char *lds, const GxItem &cur, bool more,
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const char *hb = lds + BUF * GW_WINB;
     constexpr int ORDER[4] = {1, 2, 0, 3};
-    f32x16 keep;      // m1, then d = m1 - m2
-    f32x16 acc = zero, lo = zero;
-    float4 a1 = *reinterpret_cast<const float4 *>(hb + aoff[0][0] + ORDER[0] * 256), a2 = *reinterpret_cast<const float4 *>(hb + aoff[1][0] + ORDER[0] * 256);
+    f32x16 keep, acc, lo;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lo[r] = bias_lo;      // 2048 * bias: it travels through the chain into both outputs
+    float4 a1, a2;
+    auto store16 = [&](int odd) {
+#ifdef FD_GX_NO_STORE      // probe: the matrix + combination work alone
+        if (FULL) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float v_ = fmaf(lo[r], GX_INV_SCALE, acc[r]); asm volatile("" :: "v"(v_)); }
+            (void)rs; (void)loff;
+            return;
+        }
+#endif
+        if (FULL) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[r] = fmaf(lo[r], GX_INV_SCALE, acc[r]);      // (in place: no second tile of values next to the chain's registers)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), rs, loff * 4u, (2 * ((r & 3) + 8 * (r >> 2)) + odd) * fd::KREC * 4,
+                                                      FD_GX_STORE_AUX);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (t_begin + 2 * drow(r, hi) + odd < Tb) (krow + (2 * ((r & 3) + 8 * (r >> 2)) + odd) * fd::KREC)[loff] = fmaf(lo[r], GX_INV_SCALE, acc[r]);
+        }
+    };
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int j = ORDER[s];
-        if (s == 2 || s == 3) {      // (acc already holds s / d: see below); 2048 * bias in every register of the cross-term accumulator
-#pragma unroll
-            for (int r = 0; r < 16; ++r) lo[r] = bias_lo;
-        } else lo = zero;
+        // (operands are requested one k step ahead inside a product, not across products: the registers that would hold them over the
+        // read-outs between two products are the ones this kernel does not have; the CU's other workgroup covers the four exposed reads)
+        a1 = *reinterpret_cast<const float4 *>(hb + aoff[0][0] + j * 256);
+        a2 = *reinterpret_cast<const float4 *>(hb + aoff[1][0] + j * 256);
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4) {
             const int kg = j * 4 + k4;
@@ -825,43 +853,29 @@ __device__ __forceinline__ void gw_item(char *lds, const GxItem &cur, bool more,
             if (k4 + 1 < 4) {
                 n1 = *reinterpret_cast<const float4 *>(hb + aoff[0][k4 + 1] + j * 256);
                 n2 = *reinterpret_cast<const float4 *>(hb + aoff[1][k4 + 1] + j * 256);
-            } else if (s + 1 < 4) {
-                n1 = *reinterpret_cast<const float4 *>(hb + aoff[0][0] + ORDER[s + 1 < 4 ? s + 1 : 3] * 256);
-                n2 = *reinterpret_cast<const float4 *>(hb + aoff[1][0] + ORDER[s + 1 < 4 ? s + 1 : 3] * 256);
             }
-            acc = mfma_f16(a1, wq[0][kg], acc);
-            lo = mfma_f16(a2, wq[0][kg], lo);
+            // the chain starts from 0 (m1) and, for m3, from d; its cross-term accumulator from 2048 * bias (m1) and from 0 (m3)
+            acc = mfma_f16(a1, wq[0][kg], (k4 == 0 && s == 0) ? zero : ((k4 == 0 && s == 3) ? keep : acc));
+            lo = mfma_f16(a2, wq[0][kg], (k4 == 0 && s == 3) ? zero : lo);
             lo = mfma_f16(a1, wq[1][kg], lo);
             a1 = n1;
             a2 = n2;
         }
-        if (s == 0) {                // m1: kept, and the start of the m2 chain
+        if (s == 0) {                // keep = m1 + bias
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { keep[r] = fmaf(lo[r], GX_INV_SCALE, acc[r]); acc[r] = keep[r]; }
-        } else if (s == 1) {         // s = m1 + m2 (the start of the m0 chain), d = 2 m1 - s = m1 - m2
+            for (int r = 0; r < 16; ++r) keep[r] = fmaf(lo[r], GX_INV_SCALE, acc[r]);
+        } else if (s == 1) {         // the chain holds s = m1 + m2 + bias: keep = d = 2 (m1 + bias) - s = m1 - m2 + bias
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[r] = fmaf(lo[r], GX_INV_SCALE, acc[r]); keep[r] = fmaf(2.0f, keep[r], -acc[r]); }
-        } else {                     // y[2p] = s + m0 (+ bias), then y[2p+1] = d + m3 (+ bias)
-            const int odd = (s == 3) ? 1 : 0;
-            if (FULL) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaf(lo[r], GX_INV_SCALE, acc[r])), rs, loff * 4u,
-                                                          (2 * ((r & 3) + 8 * (r >> 2)) + odd) * fd::KREC * 4, FD_GX_STORE_AUX);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (t_begin + 2 * drow(r, hi) + odd < Tb) (krow + (2 * ((r & 3) + 8 * (r >> 2)) + odd) * fd::KREC)[loff] = fmaf(lo[r], GX_INV_SCALE, acc[r]);
-            }
-            if (s == 2) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = keep[r];      // the m3 chain starts from d
-            }
-        }
+            for (int r = 0; r < 16; ++r) keep[r] = fmaf(2.0f, keep[r], -fmaf(lo[r], GX_INV_SCALE, acc[r]));
+        } else store16(s == 3 ? 1 : 0);      // y[2p] = s + m0, then y[2p+1] = d + m3
     }
     if (more) {      // the DMA has landed; this item's 32 buffer stores may still fly
+#ifdef FD_GX_NO_STORE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         if (FULL) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     }
     __builtin_amdgcn_s_barrier();
 }
