@@ -167,6 +167,8 @@ FD_API int fd_set_noise_streams(fd_handle h, const uint64_t *stream_ids, int B);
  * variants are not options (LABBOOK.md keeps their numbers).
  *   "gemm" | "lvc" | "conv" = "f16x2" | "fp32"   the predictor GEMM / the LVC layers / DBlocks + ConvTranspose + predictor front on the
  *                          fp16 matrix pipe with 2-piece operands (22 significant bits, fp32 accumulation) or on the exact-fp32 one
+ *   "gemm_form" = "winograd" | "direct"   the fp16x2 predictor GEMM evaluates kernel_conv's three taps as Winograd F(2,3) over the frame
+ *                          axis (2/3 of the matrix work, same 2-piece arithmetic per product) or tap by tap
  *   "fallback" = "host" | "graph"  what fd_sample does about an operand outside the fp16 range: see fd_sample
  *   "defer_check" = "0" | "1"      fallback = host: settle inside fd_sample | the pipelined form (fd_sample_check / _settle)
  *   "t_bucket" = "32" | frames     fd_sample's buffers and graphs are sized for T rounded up to a multiple of this (0 = exact T)
