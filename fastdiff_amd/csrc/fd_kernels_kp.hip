@@ -273,16 +273,18 @@ __global__ void __launch_bounds__(256, 2) k_kp_front_h2(const float *__restrict_
                     mx = fmaxf(mx, fabsf(v[i]));
                     hout[(((int64_t)blk * B + b) * fd::HID + mt * 32 + drow(r, hi)) * T + t] = v[i];
                 }
-                uint2 ph, pl;
-                split2(v[0], v[1], ph.x, pl.x);
-                split2(v[2], v[3], ph.y, pl.y);
-                *reinterpret_cast<uint2 *>(irow + (((mt * 4 + j) ^ sw) << 4) + 8 * hi) = ph;
-                *reinterpret_cast<uint2 *>(irow + (((8 + mt * 4 + j) ^ sw) << 4) + 8 * hi) = pl;
+                if (himg) {      // (null: the GEMM builds its own operand image from hout -- the Winograd form, k_h_wino)
+                    uint2 ph, pl;
+                    split2(v[0], v[1], ph.x, pl.x);
+                    split2(v[2], v[3], ph.y, pl.y);
+                    *reinterpret_cast<uint2 *>(irow + (((mt * 4 + j) ^ sw) << 4) + 8 * hi) = ph;
+                    *reinterpret_cast<uint2 *>(irow + (((8 + mt * 4 + j) ^ sw) << 4) + 8 * hi) = pl;
+                }
             }
         }
     }
     // the image's padding rows (0 and T+1 .. R-1) must read as zeros: first and last tile of the utterance write them
-    {
+    if (himg) {
         char *ib = himg + ((int64_t)blk * B + b) * R * 256;
         if (blockIdx.x == 0 && tid < 16) *reinterpret_cast<float4 *>(ib + tid * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
         if (blockIdx.x == gridDim.x - 1)
@@ -995,9 +997,12 @@ hipError_t fast_kp_front(const Launch &L, const StepIO &io, int B, int T)
             k2.in_pack[n] = reinterpret_cast<const float4 *>(w.kp_in_h2[n]); k2.in_b[n] = w.blk[n].kp_in.b;
             for (int l = 0; l < 6; ++l) { k2.res_pack[n][l] = reinterpret_cast<const float4 *>(w.kp_res_h2[n][l]); k2.res_b[n][l] = w.blk[n].kp_res[l].b; }
         }
-        FD_LAUNCH(L, name, k_kp_front_h2, grid, dim3(256), 0, io.mel, c->ws.kp_hB, reinterpret_cast<char *>(c->ws.h_f16), k2,
+        // the direct fp16x2 GEMM reads the piece image this kernel can write on its way out; the Winograd form builds its own (k_h_wino)
+        // and the fp32 GEMM reads hout
+        const bool image = fd_pipe(c, c->gemm_f16 && w.gemm_f16_ok, 0) != PIPE_F32_ONLY && !(c->gemm_wino && w.gemm_w_ok);
+        FD_LAUNCH(L, name, k_kp_front_h2, grid, dim3(256), 0, io.mel, c->ws.kp_hB, image ? reinterpret_cast<char *>(c->ws.h_f16) : (char *)nullptr, k2,
                   (const float *)c->ws.noise, (const StepParams *)c->ws.params, io.sampler, B, T, gx_rows(T), c->ws.range_flag, c->step_lens);
-        c->h_image_ready = true;      // the GEMM's fp16 image of h is written (k_h_split not needed)
+        c->h_image_ready = image;      // the GEMM's fp16 image of h is written (k_h_split not needed)
         run_if = c->ws.range_flag + 19;
         name = "kp_front_fp32_fallback";
         if (pipe == PIPE_F16_ONLY) return hipSuccess;
