@@ -340,7 +340,12 @@ def test_roofline_numerators_are_the_surveys_algorithmic_figures():
     assert bench.unfused_bytes("lvc_final_h256", 8, 864) == bench.kernel_model("lvc_layer_h256", 8, 864)[1]
     assert bench.unfused_bytes("lvc_up_h256", 1, 864) == bench.kernel_model("lvc_layer_h256", 1, 864)[1] + 4.0 * 864 * (32 * 64 + 32 * 256)
     # the f16x2 GEMM: algorithmic flops in the model, the three passes it executes under their own name
+    # (x 3 for the 2-piece split; as Winograd F(2,3) over frames, the default, four K = 64 products per pair of frames instead of six: x 2/3)
+    bench.GEMM_FORM = "direct"
     assert bench.executed_flops("kp_gemm_f16x2", 8, 864) == 3 * bench.kernel_model("kp_gemm_f16x2", 8, 864)[2] == 3 * 3 * 2.0 * 24832 * 192 * 8 * 864
+    bench.GEMM_FORM = "winograd"
+    assert abs(bench.executed_flops("kp_gemm_f16x2", 8, 864) - 2 * bench.kernel_model("kp_gemm_f16x2", 8, 864)[2]) < 1.0
+    assert bench.rocprof_row("fdk_fast::k_kp_gemm_w(char const*, float*)") == "kp_gemm_f16x2" and bench.rocprof_row("fdk_fast::k_h_wino(float const*)") == "h_wino"
     assert bench.kernel_model("kp_gemm_f16x2", 8, 864)[2] == bench.kernel_model("kp_gemm", 8, 864)[2]
     assert [bench.template_group(k) for k in ("lvc_layer_h256", "lvc_final_h256", "lvc_up_h256", "lvc_up_h64", "kp_gemm_f16x2")] == ["lvc_h256"] * 3 + ["lvc_h64", "kp_gemm_f16x2"]
     # rocprofv3 kernel names -> rows: one per instantiation kind of the LVC layer template <HOP, DIL, FINAL, UP>
