@@ -51,7 +51,7 @@ SR, HOP = 22050, 256
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix = fp32 vector peak
 MFMA_F16_PEAK_TFLOPS = 2500.0 # dense fp16/bf16 matrix peak (MI355X_MICROARCH.md)
-DTYPE = "f32 results; contractions as 2-piece fp16 operands (22 bits) on fp16 MFMA, fp32 accumulate (predictor GEMM: Winograd F(2,3) over frames); exact-fp32 MFMA twin"
+DTYPE = "f32 results; 2-piece fp16 operands (22 bit) on fp16 MFMA, fp32 accumulate; GEMM as Winograd F(2,3); exact-fp32 twin"
 
 
 def kernel_model(name, B, T):
