@@ -1389,6 +1389,32 @@ def test_long_utterance_beyond_the_benchmark_length(model, gc):
     assert changed.size > 0 and changed.min() >= (4990 - 16) * 256
 
 
+def test_batch_past_two_to_the_31_record_elements(gc):
+    """Maximum sizes: 104 utterances x 864 frames put the predicted-kernel records of one block past 2^31 elements (104 * 864 * 24832),
+    the activations at 0.74e9 floats per buffer.  Utterances at both ends and in the middle of the batch equal themselves alone, bit for
+    bit (the lens contract), so no index on the way wrapped; one utterance more than the documented limit (B * T * 256 * 32 < 2^31) is
+    refused with the library's message instead of being computed wrongly."""
+    import synth
+    from fastdiff_amd import infer
+    m = gc.make_model()
+    rows = infer._step_rows(m, 4, None, None)
+    B, T = 104, 864
+    mel = torch.from_numpy(synth.synth_mel(5, 4, T)).cuda().repeat(B // 4, 1, 1).contiguous()
+    lens = [T - (b % 7) * 3 for b in range(B)]
+    with torch.no_grad():
+        y = m.sample(mel, rows, seed=9, lens=lens, stream_ids=list(range(B)))
+        for b in (0, 51, B - 1):
+            y1 = m.sample(mel[b:b + 1, :, : lens[b]].contiguous(), rows, seed=9, stream_ids=[b])
+            assert torch.equal(y[b, :, : lens[b] * 256], y1[0]), b
+        assert torch.isfinite(y1).all()
+        del y, mel
+        big = torch.zeros(304, 80, T, device="cuda")
+        with pytest.raises(AssertionError, match="too large"):
+            m.sample(big, rows, seed=9)
+    del m, big
+    torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------------------------------------ epilogue (8f row 1)
 def test_peak_normalize_int16_bit_exact(model, oracle64):
     rng = np.random.default_rng(3)
