@@ -143,5 +143,29 @@ __device__ __forceinline__ void lvc_st(float4 *p, const float4 &v)
     else *p = v;
 }
 
+// Tile order of the LVC layers.  The dispatcher hands workgroup n of a launch to XCD n % 8 (eight L2s of 4 MB), so with tile = blockIdx.x
+// the two neighbours of every tile run on OTHER XCDs and the halo columns a tile reads on either side -- one 128 B line per channel row
+// and side, of x and of skip -- miss its L2 although a neighbour fetches the same lines at the same moment.  Here XCD k takes runs of
+// LVC_XCD_RUN consecutive tiles: within a group of 8 * RUN workgroups, workgroup n works on tile (n % 8) * RUN + (n / 8) % RUN of the group.
+// Seven of eight tile borders then lie inside one L2.  Round 6, PMC (profiles/r06/s24): the plain hop-256 layer fetches 869 MB instead
+// of 965 per launch (1.02x algorithmic instead of 1.13x), every h2 launch ~95 MB (hop 64: 21 MB) less; time -1 ... -1.5 %.  Groups, not
+// whole XCD ranges (round 1: idled the XCDs that owned the tail of a ragged batch): the utterance's end cuts at most one run short.
+// gridDim.x must be a multiple of 8 (the launchers round up; a tile past the utterance exits at once); a last partial group keeps
+// tile = n.  Results do not depend on the order.  Run lengths timed against each other in one session (profiles/r06/s25): 8 and 16 equal
+// for the hop-64 / hop-256 kernels (8 ships); the hop-8 kernel (32-column tiles, halo up to 28 columns a side) 45.0 us with tile = n,
+// 44.9-46.8 with runs of 8, 44.6-44.7 with runs of 16 (ships: 224 -> 202 MB per launch).
+#ifndef FD_LVC_XCD_RUN
+#define FD_LVC_XCD_RUN 8
+#endif
+template <int R = FD_LVC_XCD_RUN>
+__device__ __forceinline__ int lvc_tile_of_workgroup()
+{
+    constexpr int G = 8 * R;
+    const int n = blockIdx.x;
+    if constexpr (R <= 1) return n;
+    const int g0 = (n / G) * G;
+    return (g0 + G <= (int)gridDim.x) ? g0 + (n % 8) * R + (n / 8) % R : n;
+}
+
 }  // namespace fdk_fast
 #endif /* FD_KERNELS_COMMON_H */

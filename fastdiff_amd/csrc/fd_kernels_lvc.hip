@@ -337,9 +337,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h2(const float *__restrict__ xin
     __shared__ __attribute__((aligned(16))) char ys[YC * 128];       // first the raw x + skip of the centre (fp32 [32][256]), then
     static_assert(YC * 128 >= fd::C * W * 4, "parking area");        // the conv output pieces, row = column + 1
     const int Ln = T * HOP;
-    // (an XCD-contiguous tile order was tried for L2 reuse of the halo columns: no measurable gain, and with ragged batches
-    // it leaves the XCDs that own the tail of every utterance idle)
-    const int ntile = (T * HOP + W - 1) / W, tile = blockIdx.x;
+    const int ntile = (T * HOP + W - 1) / W, tile = lvc_tile_of_workgroup();      // runs of tiles per XCD (fd_kernels_common.h)
     const int b = blockIdx.y, w0 = tile * W;
     const int Lnb = frames_of(lens, b, T) * HOP;      // this utterance's own length (ragged batch): every bound below; Ln = row stride
     if (tile >= ntile || w0 >= Lnb || skip_after_previous_overflow(range_flag)) return;
@@ -957,7 +955,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h8m(const float *__restrict__ xi
     __shared__ __attribute__((aligned(16))) char ys[(W + 2) * 128];     // conv output pieces, row = column + 1
     __shared__ __attribute__((aligned(16))) float xr[fd::C * W];        // raw x + skip of the centre: the residual
     const int Ln = T * HOP;
-    const int b = blockIdx.y, w0 = blockIdx.x * W;
+    const int b = blockIdx.y, w0 = lvc_tile_of_workgroup<2 * FD_LVC_XCD_RUN>() * W;      // runs of 16 tiles per XCD (fd_kernels_common.h)
     const int Tb = frames_of(lens, b, T), Lnb = Tb * HOP;
     if (w0 >= Lnb || skip_after_previous_overflow(range_flag)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, g4 = lane >> 4;
@@ -1203,7 +1201,7 @@ hipError_t fast_lvc_layer(const Launch &L, int n, int layer, const float *x_in, 
         const DevWeights &w = c->w;
         const int Ln = T * 8;
         const float *kp = c->ws.kpack + (int64_t)c->hoist_step * B * T * fd::KREC;      // (block 0; hoisted predictor: this step's entries)
-        const dim3 grid((Ln + 31) / 32, B);
+        const dim3 grid(((Ln + 31) / 32 + 7) / 8 * 8, B);      // a multiple of 8: blockIdx.x % 8 is the XCD (lvc_tile_of_workgroup)
         const Pipe pipe = fd_pipe(c, c->lvc_f16 && w.lvc_f16_ok && c->lvc_h8_mfma, 1 + layer);
         int *flag = c->ws.range_flag + 1 + layer;
 #define FD_H8(DIL_, NAME_)                                                                                          \

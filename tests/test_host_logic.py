@@ -430,7 +430,7 @@ def test_the_shipped_build_defines_no_probe_macro():
     assert probes, "no probe switch found: the pattern no longer matches"
     # a switch may only be #defined inside its own #ifndef default block (FD_LVC_NT, FD_*_OCC: tunables with a shipped default)
     # (FD_STAMP_X: the timeline stamps' no-op default, #defined empty unless a timeline build defines it)
-    defaults = {"FD_LVC_NT", "FD_DBLOCK_OCC", "FD_CONVT_OCC", "FD_GX_STORE_AUX", "FD_STAMP_X"}
+    defaults = {"FD_LVC_NT", "FD_LVC_XCD_RUN", "FD_DBLOCK_OCC", "FD_CONVT_OCC", "FD_GX_STORE_AUX", "FD_STAMP_X"}
     assert (probes & defined) <= defaults, sorted((probes & defined) - defaults)
     script = open(os.path.join(ROOT, "tools", "build_variant.sh")).read()
     assert "build.FLAGS" in script and "--offload-arch" not in script      # the variant build takes its flags from build.py
