@@ -955,7 +955,7 @@ __global__ void __launch_bounds__(256, 2) k_lvc_h8m(const float *__restrict__ xi
     __shared__ __attribute__((aligned(16))) char ys[(W + 2) * 128];     // conv output pieces, row = column + 1
     __shared__ __attribute__((aligned(16))) float xr[fd::C * W];        // raw x + skip of the centre: the residual
     const int Ln = T * HOP;
-    const int b = blockIdx.y, w0 = lvc_tile_of_workgroup<2 * FD_LVC_XCD_RUN>() * W;      // runs of 16 tiles per XCD (fd_kernels_common.h)
+    const int b = blockIdx.y, w0 = lvc_tile_of_workgroup<(FD_LVC_XCD_RUN > 1 ? 2 * FD_LVC_XCD_RUN : 1)>() * W;      // runs of 16 tiles per XCD (fd_kernels_common.h)
     const int Tb = frames_of(lens, b, T), Lnb = Tb * HOP;
     if (w0 >= Lnb || skip_after_previous_overflow(range_flag)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, g4 = lane >> 4;
